@@ -1,0 +1,159 @@
+/* signaltrain_hip.h -- C ABI of libsignaltrain_hip.so (MI355X / gfx950).
+ *
+ * The reference (drscotthawley/signaltrain) has no FFI / operator registry: its hot path is
+ * plain PyTorch modules.  This header is therefore the boundary a maintainer
+ * would bind (ctypes stub in INTEGRATION.md); every entry point names the reference code it
+ * replaces.  Conventions:
+ *   - all pointers are DEVICE pointers to contiguous fp32 unless stated; the caller (PyTorch)
+ *     owns every buffer, including workspaces and saved activations;
+ *   - every compute entry is asynchronous on `stream` (a hipStream_t passed as void*), does
+ *     no allocation and no host synchronisation;
+ *   - return value: 0 = ok, <0 = error; message via st_last_error();
+ *   - shapes use the reference's names: B windows, L samples/window, N=ft_size, H=hop,
+ *     T input frames, OT output frames, F=N/2+1 bins, K knobs, y output samples.
+ */
+#ifndef SIGNALTRAIN_HIP_H
+#define SIGNALTRAIN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ST_OK 0
+#define ST_ERR_ARG (-1)      /* bad dimension / null pointer / misalignment */
+#define ST_ERR_LAUNCH (-2)   /* HIP launch error */
+#define ST_ERR_UNSUPPORTED (-3)
+
+/* Geometry of one model instance (nn_proc.py:357-385). */
+typedef struct st_dims {
+    int B;   /* windows in this (per-GPU) minibatch                         */
+    int L;   /* samples per input window  (8192*scale)                      */
+    int N;   /* ft_size (1024)                                              */
+    int H;   /* hop (384)                                                   */
+    int T;   /* input STFT frames  = ceil(L/H)+ceil(N/H)                    */
+    int OT;  /* output STFT frames = ceil(out/H)+ceil(N/H)                  */
+    int F;   /* N/2+1                                                       */
+    int K;   /* knobs                                                       */
+    int y;   /* output samples = (OT-1)*H - N                               */
+} st_dims;
+
+/* Internal padded spectral pitch: re bins at [0,F), im bins at [KP/2, KP/2+F). */
+int st_kp(int F);
+
+const char* st_last_error(void);
+int st_version(void);
+
+/* nn_proc.py:357-385 (st_model.__init__ geometry); lean scheme when legacy==0. Host only. */
+int st_geometry(double scale_factor, double shrink_factor, int legacy, int K, int B, st_dims* out);
+
+/* Flat parameter buffer layout: the 40 state_dict tensors in registration order,
+ * each start aligned to 4 floats.  st_param_offsets fills offs[40] (in floats) and returns the
+ * total length in floats (or <0). */
+int64_t st_param_offsets(const st_dims* d, int64_t* offs /*[40]*/);
+
+/* Workspace sizes in bytes for st_model_fwd / st_train_step (pure functions of dims). */
+size_t st_workspace_bytes(const st_dims* d);
+
+/* ---------------------------------------------------------------- per-op entry points --- */
+/* cls_fe_dft.py:50-58 Analysis.forward fused with nn_proc.py:309-310 (mag, phs).
+ * x[B,L]; Wr,Wi[N,N] (rows >= F unused); in_scale multiplies x (0.5, nn_proc.py:307).
+ * Outputs [B,T,F] each; any of re/im/mag/phs may be NULL. */
+int st_analysis_fwd(const st_dims* d, const float* x, const float* Wr, const float* Wi, float in_scale,
+                    float* re, float* im, float* mag, float* phs, void* stream);
+
+/* nn_proc.py:77-126 AsymAutoEncoder.forward for both nets + nn_proc.py:322-326 polar->rect.
+ * ae_m / ae_p: the 18 tensors of one autoencoder, packed contiguously in state_dict order with
+ * the 4-float alignment of st_param_offsets (i.e. pointer into the flat parameter buffer).
+ * Outputs: mag_hat, phs_hat [B,OT,F]; AA [B*OT, KP] (an_real | an_imag, padded);
+ * reg_partial: per-wave partial sums of |mag_hat * exp(7 f/F)| (st_ae_fwd_partials() floats). */
+int st_ae_fwd(const st_dims* d, const float* mag, const float* phs, const float* knobs,
+              const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA,
+              float* reg_partial, void* stream);
+int st_ae_fwd_partials(const st_dims* d);
+
+/* Hermitian fold of the synthesis bases (cls_fe_dft.py:109-110 expressed on the weights):
+ * Sfold[KP,N]: rows [0,F) = Sr[k]+Sr[N-k], rows [KP/2,KP/2+F) = Si[k]-Si[N-k]; other rows 0. */
+int st_synth_fold(const st_dims* d, const float* Sr, const float* Si, float* Sfold, void* stream);
+
+/* cls_fe_dft.py:112 ConvTranspose1d as a GEMM: frs[B*OT,N] = AA[B*OT,KP] * Sfold[KP,N]. */
+int st_synthesis_frames(const st_dims* d, const float* AA, const float* Sfold, float* frs, void* stream);
+
+/* cls_fe_dft.py:112-113 overlap-add + crop, nn_proc.py:332,340 residual and x2,
+ * loss_functions.py:9-10 log-cosh partial sums and d loss/d syn.
+ * y_true may be NULL (inference): then only y_hat is produced. */
+int st_ola_loss(const st_dims* d, const float* frs, const float* x, const float* y_true,
+                float* y_hat, float* dsyn, float* loss_partial, void* stream);
+int st_ola_loss_partials(const st_dims* d);
+
+/* Backward of the synthesis GEMM wrt its input: dAA[B*OT,KP] = frames(dsyn) * Sfold^T. */
+int st_synthesis_dgrad(const st_dims* d, const float* dsyn, const float* Sfold, float* dAA, void* stream);
+
+/* Weight gradient of the synthesis bases (folded then unfolded to Sr/Si [N,N]); also emits
+ * partial sums of |g| for the L1 clip (nn_proc.py:299-302).  ws: split-K scratch. */
+int st_synthesis_wgrad(const st_dims* d, const float* AA, const float* dsyn, float* ws,
+                       float* gSr, float* gSi, float* norm_partial, void* stream);
+
+/* Backward of both autoencoders (recomputes activations) incl. nn_proc.py:322-326 and the
+ * L1 term of loss_functions.py:36.  Outputs dmag, dphs [B,T,F]; per-wave partial weight grads
+ * in ws (st_ae_bwd_ws_floats()), reduced into g_m / g_p (same packing as ae_m / ae_p). */
+int st_ae_bwd(const st_dims* d, const float* mag, const float* phs, const float* knobs,
+              const float* ae_m, const float* ae_p, const float* mag_hat, const float* phs_hat,
+              const float* dAA, const float* g_mag_hat /* optional extra d/d mag_hat */, float reg_coef,
+              float* dmag, float* dphs, float* ws, float* g_m, float* g_p, void* stream);
+size_t st_ae_bwd_ws_floats(const st_dims* d);
+
+/* Backward of nn_proc.py:309-310: dG[B*T,KP] (d re | d im) from (re,im,dmag,dphs). */
+int st_polar_bwd(const st_dims* d, const float* re, const float* im, const float* dmag, const float* dphs,
+                 const float* g_mag /* optional extra d/d mag */, float* dG, void* stream);
+
+/* Weight gradient of the analysis bases: gWr/gWi[N,N] rows [0,F) written, rows >= F untouched
+ * (they are structurally zero).  Emits |g| partial sums. */
+int st_analysis_wgrad(const st_dims* d, const float* dG, const float* x, float in_scale, float* ws,
+                      float* gWr, float* gWi, float* norm_partial, void* stream);
+size_t st_wgrad_ws_floats(const st_dims* d);
+int st_norm_partials(const st_dims* d);
+
+/* nn_proc.py:299-302 L1 clip (STFT tensors = first 4 tensors of the flat buffer) fused with
+ * torch.optim.Adam.step (train.py:147).  scalars: device float[8] written by st_finalize_scalars. */
+int st_finalize_scalars(const st_dims* d, const float* loss_partial, const float* reg_partial,
+                        const float* norm_partial_a, const float* norm_partial_s, float inv_world,
+                        float* scalars /* [0]=loss [1]=logcosh [2]=reg [3]=l1norm [4]=clip_coef */, void* stream);
+int st_clip_adam(float* params, float* grads, float* m, float* v, int64_t n_total, int64_t n_stft,
+                 const float* scalars, float grad_scale, float lr, float beta1, float beta2, float eps, int step,
+                 void* stream);
+
+/* ---------------------------------------------------------------- fused entry points ----- */
+/* st_model.forward (nn_proc.py:392 -> :305-340), inference/validation: y_hat[B,y], mag[B,T,F],
+ * mag_hat[B,OT,F].  params = flat parameter buffer; ws = st_workspace_bytes(). */
+int st_model_fwd(const st_dims* d, const float* params, const float* x, const float* knobs,
+                 float* y_hat, float* mag, float* mag_hat, void* ws, int save_for_backward, void* stream);
+
+/* Autograd backward of st_model_fwd(save_for_backward=1) for arbitrary upstream gradients
+ * g_y_hat[B,y] (required), g_mag_hat[B,OT,F], g_mag[B,T,F] (optional): fills the flat `grads`
+ * (rows >= F of the analysis tensors are never written: keep them zero). */
+int st_model_bwd(const st_dims* d, const float* params, float* grads, const float* x, const float* knobs,
+                 const float* g_y_hat, const float* g_mag_hat, const float* g_mag, void* ws, void* stream);
+
+/* One optimisation step of train.py:112-151 WITHOUT the optimiser: forward, loss, backward.
+ * grads (flat, same layout as params) are overwritten; scalars[0..3] receive loss terms and the
+ * STFT L1 norm (before any all-reduce).  y_hat/mag/mag_hat may be NULL. */
+int st_loss_backward(const st_dims* d, const float* params, float* grads, const float* x, const float* knobs,
+                     const float* y_true, float* y_hat, float* mag, float* mag_hat, void* ws,
+                     float* scalars, void* stream);
+
+/* Full single-GPU step: st_loss_backward + L1 clip + Adam (train.py:131-151). */
+int st_train_step(const st_dims* d, float* params, float* grads, float* m, float* v, const float* x,
+                  const float* knobs, const float* y_true, void* ws, float* scalars,
+                  float lr, float beta1, float beta2, float eps, int step, void* stream);
+
+/* After an external all-reduce of `grads` (data parallel): recompute the STFT L1 norm of the
+ * reduced, scaled gradient, clip and Adam.  grad_scale = 1/world. */
+int st_dp_clip_adam(const st_dims* d, float* params, float* grads, float* m, float* v, void* ws,
+                    float* scalars, float grad_scale, float lr, float beta1, float beta2, float eps,
+                    int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,108 @@
+"""ctypes binding of libsignaltrain_hip.so (C ABI declared in include/signaltrain_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised.  PyTorch is used only for device memory and streams.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsignaltrain_hip.so")
+
+
+class st_dims(C.Structure):
+    """Mirror of `struct st_dims` (include/signaltrain_hip.h)."""
+    _fields_ = [(n, C.c_int) for n in ("B", "L", "N", "H", "T", "OT", "F", "K", "y")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+    def with_batch(self, B):
+        d = st_dims(); C.memmove(C.byref(d), C.byref(self), C.sizeof(st_dims)); d.B = int(B); return d
+
+
+_p = C.c_void_p
+_f = C.c_float
+_i = C.c_int
+_D = C.POINTER(st_dims)
+
+# name -> (restype, argtypes)   -- must list every symbol declared in include/signaltrain_hip.h
+SIGNATURES = {
+    "st_kp": (_i, [_i]),
+    "st_last_error": (C.c_char_p, []),
+    "st_version": (_i, []),
+    "st_geometry": (_i, [C.c_double, C.c_double, _i, _i, _i, _D]),
+    "st_param_offsets": (C.c_int64, [_D, C.POINTER(C.c_int64)]),
+    "st_workspace_bytes": (C.c_size_t, [_D]),
+    "st_analysis_fwd": (_i, [_D, _p, _p, _p, _f, _p, _p, _p, _p, _p]),
+    "st_ae_fwd": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "st_ae_fwd_partials": (_i, [_D]),
+    "st_synth_fold": (_i, [_D, _p, _p, _p, _p]),
+    "st_synthesis_frames": (_i, [_D, _p, _p, _p, _p]),
+    "st_ola_loss": (_i, [_D, _p, _p, _p, _p, _p, _p, _p]),
+    "st_ola_loss_partials": (_i, [_D]),
+    "st_synthesis_dgrad": (_i, [_D, _p, _p, _p, _p]),
+    "st_synthesis_wgrad": (_i, [_D, _p, _p, _p, _p, _p, _p, _p]),
+    "st_ae_bwd": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p]),
+    "st_ae_bwd_ws_floats": (C.c_size_t, [_D]),
+    "st_polar_bwd": (_i, [_D, _p, _p, _p, _p, _p, _p, _p]),
+    "st_analysis_wgrad": (_i, [_D, _p, _p, _f, _p, _p, _p, _p, _p]),
+    "st_wgrad_ws_floats": (C.c_size_t, [_D]),
+    "st_norm_partials": (_i, [_D]),
+    "st_finalize_scalars": (_i, [_D, _p, _p, _p, _p, _f, _p, _p]),
+    "st_clip_adam": (_i, [_p, _p, _p, _p, C.c_int64, C.c_int64, _p, _f, _f, _f, _f, _f, _i, _p]),
+    "st_model_fwd": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
+    "st_model_bwd": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "st_loss_backward": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "st_train_step": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _p]),
+    "st_dp_clip_adam": (_i, [_D, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _i, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises RuntimeError (never falls back) if it is unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f"signaltrain_amd: {LIB_PATH} is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C signaltrain_amd/csrc`. There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().st_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"signaltrain_hip {what} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device (or host) pointer of a contiguous float32 torch tensor; None -> NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "signaltrain_amd: tensor must be contiguous"
+    return C.c_void_p(t.data_ptr())
+
+
+def geometry(scale_factor=1, shrink_factor=4, num_knobs=4, batch=1, scale_scheme="lean"):
+    d = st_dims()
+    check(load().st_geometry(float(scale_factor), float(shrink_factor), 0 if scale_scheme == "lean" else 1,
+                             int(num_knobs), int(batch), C.byref(d)), "st_geometry")
+    return d
+
+
+def param_offsets(d):
+    offs = (C.c_int64 * 40)()
+    total = load().st_param_offsets(C.byref(d), offs)
+    if total < 0:
+        check(-1, "st_param_offsets")
+    return list(offs), int(total)

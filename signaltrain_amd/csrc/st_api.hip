@@ -1,0 +1,419 @@
+// st_api.hip -- extern "C" entry points of libsignaltrain_hip.so (see include/signaltrain_hip.h).
+// All device work is launched on the caller's stream; no allocation, no synchronisation.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include "st_common.h"
+#include "st_gemm.h"
+#include "st_misc.h"
+#include "st_ae.h"
+
+// ------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+int st_fail(int code, const char* fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    return code;
+}
+int st_check_launch(const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return st_fail(ST_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return ST_OK;
+}
+#define ST_TRY(x) do { int rc_ = (x); if (rc_ != ST_OK) return rc_; } while (0)
+#define ST_REQ(cond, ...) do { if (!(cond)) return st_fail(ST_ERR_ARG, __VA_ARGS__); } while (0)
+
+extern "C" const char* st_last_error(void) { return g_err; }
+extern "C" int st_version(void) { return 100; }
+extern "C" int st_kp(int F) { return st_kp_of(F); }
+
+// ------------------------------------------------------------------------------ geometry / layout
+extern "C" int st_geometry(double scale_factor, double shrink_factor, int legacy, int K, int B, st_dims* o)
+{
+    ST_REQ(o && scale_factor > 0 && shrink_factor > 0, "st_geometry: bad arguments");
+    const int chunk = (int)(8192 * scale_factor);              // nn_proc.py:357
+    const int out_chunk = (int)(chunk / shrink_factor);        // nn_proc.py:358
+    int ft = 1024, hop = 384;                                  // nn_proc.py:370-371
+    if (legacy) { ft = (int)(ft * scale_factor); hop = (int)(hop * scale_factor); }   // nn_proc.py:374-376
+    o->B = B; o->L = chunk; o->N = ft; o->H = hop; o->K = K;
+    o->T = (int)(ceil(chunk / (double)hop) + ceil(ft / (double)hop));                 // nn_proc.py:378
+    o->OT = (int)(ceil(out_chunk / (double)hop) + ceil(ft / (double)hop));            // nn_proc.py:379
+    o->y = (o->OT - 1) * hop - ft;                                                    // nn_proc.py:380
+    o->F = ft / 2 + 1;
+    return ST_OK;
+}
+
+static int check_dims(const st_dims* d)
+{
+    ST_REQ(d, "null dims");
+    ST_REQ(d->B > 0 && d->L > 0 && d->N > 0 && d->H > 0 && d->T > 0 && d->OT > 0 && d->K >= 0, "non-positive dimension");
+    ST_REQ(d->F == d->N / 2 + 1, "F must be N/2+1");
+    ST_REQ(d->N % 32 == 0 && d->H % 4 == 0 && d->L % 4 == 0 && d->y % 4 == 0, "N%%32, H%%4, L%%4, y%%4 required");
+    ST_REQ(d->y == (d->OT - 1) * d->H - d->N && d->y > 0 && d->y <= d->L, "y must equal (OT-1)*H-N");
+    ST_REQ(d->OT <= d->T, "OT must be <= T");
+    ST_REQ(d->K <= 16, "at most 16 knobs");
+    return ST_OK;
+}
+
+static void ae_shapes(const st_dims* d, int* out, int* in)
+{
+    const int o[9] = {64, 32, 16, 16, 16, 16, 32, 64, d->OT};
+    const int i[9] = {d->T, 64, 32, 16, 16 + d->K, 16, 16, 32, 64};
+    memcpy(out, o, sizeof(o)); memcpy(in, i, sizeof(i));
+}
+
+extern "C" int64_t st_param_offsets(const st_dims* d, int64_t* offs)
+{
+    if (check_dims(d) != ST_OK) return -1;
+    int64_t off = 0; int n = 0;
+    auto put = [&](int64_t sz) { if (offs) offs[n] = off; ++n; off += (sz + 3) / 4 * 4; };
+    for (int s = 0; s < 4; ++s) put((int64_t)d->N * d->N);
+    int out[9], in[9]; ae_shapes(d, out, in);
+    for (int a = 0; a < 2; ++a)
+        for (int l = 0; l < 9; ++l) { put((int64_t)out[l] * in[l]); put(out[l]); }
+    return off;
+}
+
+struct Layout {            // everything derived from dims that the host side needs
+    int64_t offs[40]; int64_t total; int64_t n_stft; int PG; sta::AEOffsets go; int KP;
+};
+static int make_layout(const st_dims* d, Layout* L)
+{
+    ST_TRY(check_dims(d));
+    L->total = st_param_offsets(d, L->offs);
+    L->n_stft = L->offs[4];
+    L->PG = (int)(L->offs[22] - L->offs[4]);
+    for (int l = 0; l < 9; ++l) {
+        L->go.w[l] = (int)(L->offs[4 + 2 * l] - L->offs[4]);
+        L->go.b[l] = (int)(L->offs[5 + 2 * l] - L->offs[4]);
+    }
+    L->KP = st_kp_of(d->F);
+    return ST_OK;
+}
+
+// ------------------------------------------------------------------------------ launch parameters
+static int num_cus()
+{
+    static int n = 0;
+    if (!n) { int dev = 0; hipGetDevice(&dev); hipDeviceProp_t p; if (hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount; if (n <= 0) n = 256; }
+    return n;
+}
+static const int AE_FWD_NW = 8, AE_BWD_NW = 4;
+static int ae_fwd_grid(const st_dims* d) { int g = (d->B * (st_kp_of(d->F) / 32) + AE_FWD_NW - 1) / AE_FWD_NW; int c = num_cus(); return g < c ? g : c; }
+static int ae_bwd_grid(const st_dims* d) { int pairs = (d->B * (st_kp_of(d->F) / 32) + 1) / 2; int g = (pairs + AE_BWD_NW - 1) / AE_BWD_NW; int c = num_cus() / 2; if (c < 1) c = 1; return g < c ? g : c; }
+static int wgrad_split(int R) { int s = R / 512; if (s < 1) s = 1; if (s > 4) s = 4; return s; }
+
+extern "C" int st_ae_fwd_partials(const st_dims* d) { return ae_fwd_grid(d) * AE_FWD_NW; }
+extern "C" int st_ola_loss_partials(const st_dims* d) { return d->B * ((d->y + 255) / 256); }
+extern "C" int st_norm_partials(const st_dims* d) { return 2 * d->F; }
+extern "C" size_t st_wgrad_ws_floats(const st_dims* d)
+{
+    const int s = wgrad_split(d->B * d->T);
+    return (size_t)s * st_kp_of(d->F) * d->N;
+}
+extern "C" size_t st_ae_bwd_ws_floats(const st_dims* d)
+{
+    Layout L; if (make_layout(d, &L) != ST_OK) return 0;
+    return (size_t)ae_bwd_grid(d) * AE_BWD_NW * 2 * L.PG;
+}
+
+// ------------------------------------------------------------------------------ per-op entry points
+extern "C" int st_analysis_fwd(const st_dims* d, const float* x, const float* Wr, const float* Wi, float in_scale,
+                               float* re, float* im, float* mag, float* phs, void* stream)
+{
+    ST_TRY(check_dims(d)); ST_REQ(x && Wr && Wi, "st_analysis_fwd: null input");
+    const int R = d->B * d->T;
+    stg::FramedNT al{x, d->L, d->T, d->H, d->N, R, d->N, in_scale};
+    stg::AnalysisW bl{Wr, Wi, d->F, d->N};
+    stg::PolarStore ep{re, im, mag, phs, R, d->F};
+    stg::launch<4>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream));
+    return st_check_launch("analysis_fwd");
+}
+
+extern "C" int st_ae_fwd(const st_dims* d, const float* mag, const float* phs, const float* knobs,
+                         const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA,
+                         float* reg_partial, void* stream)
+{
+    Layout L; ST_TRY(make_layout(d, &L));
+    ST_REQ(mag && phs && knobs && ae_m && ae_p && mag_hat && phs_hat && AA, "st_ae_fwd: null pointer");
+    const sta::AELds ll = sta::ae_lds_layout(d->T, d->OT, d->K);
+    const size_t lds = (size_t)2 * ll.total * sizeof(float);
+    ST_REQ(lds <= 160 * 1024, "st_ae_fwd: geometry needs %zu B of LDS (>160 KiB)", lds);
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_fwd_kernel<AE_FWD_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    const float expfac = (float)(7.0 / d->F);
+    hipLaunchKernelGGL((sta::ae_fwd_kernel<AE_FWD_NW>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, st_stream(stream),
+                       mag, phs, knobs, ae_m, ae_p, L.go, mag_hat, phs_hat, AA, reg_partial,
+                       d->B, d->T, d->OT, d->F, d->K, L.KP, expfac);
+    return st_check_launch("ae_fwd");
+}
+
+extern "C" int st_synth_fold(const st_dims* d, const float* Sr, const float* Si, float* Sfold, void* stream)
+{
+    ST_TRY(check_dims(d)); ST_REQ(Sr && Si && Sfold, "st_synth_fold: null pointer");
+    const int KP = st_kp_of(d->F);
+    hipLaunchKernelGGL(stm::fold_kernel, dim3(KP), dim3(256), 0, st_stream(stream), Sr, Si, Sfold, d->N, d->F, KP);
+    return st_check_launch("synth_fold");
+}
+
+extern "C" int st_synthesis_frames(const st_dims* d, const float* AA, const float* Sfold, float* frs, void* stream)
+{
+    ST_TRY(check_dims(d)); ST_REQ(AA && Sfold && frs, "st_synthesis_frames: null pointer");
+    const int R = d->B * d->OT, KP = st_kp_of(d->F);
+    stg::PlainNT al{AA, R, KP, KP};
+    stg::PlainTN bl{Sfold, KP, d->N, d->N};
+    stg::StoreC ep{frs, R, d->N, d->N, 0};
+    if (R >= 4096) stg::launch<4>(al, bl, ep, R, d->N, KP, 1, st_stream(stream));
+    else stg::launch<2>(al, bl, ep, R, d->N, KP, 1, st_stream(stream));
+    return st_check_launch("synthesis_frames");
+}
+
+extern "C" int st_ola_loss(const st_dims* d, const float* frs, const float* x, const float* y_true,
+                           float* y_hat, float* dsyn, float* loss_partial, void* stream)
+{
+    ST_TRY(check_dims(d)); ST_REQ(frs && x, "st_ola_loss: null pointer");
+    const float inv = 1.0f / ((float)d->B * (float)d->y);
+    hipLaunchKernelGGL(stm::ola_loss_kernel, dim3((d->y + 255) / 256, d->B), dim3(256), 0, st_stream(stream),
+                       frs, x, y_true, y_hat, dsyn, loss_partial, d->L, d->N, d->H, d->OT, d->y, inv);
+    return st_check_launch("ola_loss");
+}
+
+extern "C" int st_synthesis_dgrad(const st_dims* d, const float* dsyn, const float* Sfold, float* dAA, void* stream)
+{
+    ST_TRY(check_dims(d)); ST_REQ(dsyn && Sfold && dAA, "st_synthesis_dgrad: null pointer");
+    const int R = d->B * d->OT, KP = st_kp_of(d->F);
+    // dfrs[b,t,n] = dfull[b, H t + n] with dfull = zero-pad(dsyn, N each side)  == frames of dsyn with pad N
+    stg::FramedNT al{dsyn, d->y, d->OT, d->H, d->N, R, d->N, 1.0f};
+    stg::PlainNT bl{Sfold, KP, d->N, d->N};
+    stg::StoreC ep{dAA, R, KP, KP, 0};
+    if (R >= 4096) stg::launch<4>(al, bl, ep, R, KP, d->N, 1, st_stream(stream));
+    else stg::launch<2>(al, bl, ep, R, KP, d->N, 1, st_stream(stream));
+    return st_check_launch("synthesis_dgrad");
+}
+
+extern "C" int st_synthesis_wgrad(const st_dims* d, const float* AA, const float* dsyn, float* ws,
+                                  float* gSr, float* gSi, float* norm_partial, void* stream)
+{
+    ST_TRY(check_dims(d)); ST_REQ(AA && dsyn && ws && gSr && gSi && norm_partial, "st_synthesis_wgrad: null pointer");
+    const int R = d->B * d->OT, KP = st_kp_of(d->F);
+    const int ns = wgrad_split(R);
+    stg::PlainTN al{AA, R, KP, KP};
+    stg::FramedTN bl{dsyn, d->y, d->OT, d->H, d->N, R, d->N, 1.0f};
+    stg::StoreC ep{ws, KP, d->N, d->N, (size_t)KP * d->N};
+    stg::launch<3>(al, bl, ep, KP, d->N, R, ns, st_stream(stream));
+    ST_TRY(st_check_launch("synthesis_wgrad"));
+    const int ksplit = st_round_up((R + ns - 1) / ns, stg::BK);
+    const int nz = (R + ksplit - 1) / ksplit;
+    hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(2 * d->F), dim3(256), 0, st_stream(stream),
+                       ws, nz, gSr, gSi, norm_partial, d->N, d->F, KP, 1);
+    return st_check_launch("synthesis_wgrad_reduce");
+}
+
+extern "C" int st_ae_bwd(const st_dims* d, const float* mag, const float* phs, const float* knobs,
+                         const float* ae_m, const float* ae_p, const float* mag_hat, const float* phs_hat,
+                         const float* dAA, const float* g_mag_hat, float reg_coef, float* dmag, float* dphs, float* ws,
+                         float* g_m, float* g_p, void* stream)
+{
+    Layout L; ST_TRY(make_layout(d, &L));
+    ST_REQ(mag && phs && knobs && ae_m && ae_p && mag_hat && phs_hat && dAA && dmag && dphs && ws && g_m && g_p, "st_ae_bwd: null pointer");
+    if (d->T > 32 || d->OT > 16)
+        return st_fail(ST_ERR_UNSUPPORTED, "st_ae_bwd: T=%d OT=%d not instantiated yet (T<=32, OT<=16)", d->T, d->OT);
+    const sta::AELds ll = sta::ae_lds_layout(d->T, d->OT, d->K);
+    const size_t lds = ((size_t)ll.total + (size_t)AE_BWD_NW * 2 * (32 + 64 + 64 + 16) * sta::SP) * sizeof(float);
+    ST_REQ(lds <= 160 * 1024, "st_ae_bwd: needs %zu B of LDS", lds);
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    const float expfac = (float)(7.0 / d->F);
+    const int grid = ae_bwd_grid(d);
+    hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, st_stream(stream),
+                       mag, phs, knobs, ae_m, ae_p, L.go, L.PG, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, expfac,
+                       dmag, dphs, ws, d->B, d->T, d->OT, d->F, d->K, L.KP);
+    ST_TRY(st_check_launch("ae_bwd"));
+    hipLaunchKernelGGL(stm::ae_grad_reduce_kernel, dim3((L.PG + 255) / 256, 2), dim3(256), 0, st_stream(stream),
+                       ws, grid * AE_BWD_NW, L.PG, g_m, g_p);
+    return st_check_launch("ae_grad_reduce");
+}
+
+extern "C" int st_polar_bwd(const st_dims* d, const float* re, const float* im, const float* dmag, const float* dphs,
+                            const float* g_mag, float* dG, void* stream)
+{
+    ST_TRY(check_dims(d)); ST_REQ(re && im && dmag && dphs && dG, "st_polar_bwd: null pointer");
+    const int R = d->B * d->T, KP = st_kp_of(d->F);
+    hipLaunchKernelGGL(stm::polar_bwd_kernel, dim3((KP / 2 + 255) / 256, R), dim3(256), 0, st_stream(stream),
+                       re, im, dmag, dphs, g_mag, dG, R, d->F, KP);
+    return st_check_launch("polar_bwd");
+}
+
+extern "C" int st_analysis_wgrad(const st_dims* d, const float* dG, const float* x, float in_scale, float* ws,
+                                 float* gWr, float* gWi, float* norm_partial, void* stream)
+{
+    ST_TRY(check_dims(d)); ST_REQ(dG && x && ws && gWr && gWi && norm_partial, "st_analysis_wgrad: null pointer");
+    const int R = d->B * d->T, KP = st_kp_of(d->F);
+    const int ns = wgrad_split(R);
+    stg::PlainTN al{dG, R, KP, KP};
+    stg::FramedTN bl{x, d->L, d->T, d->H, d->N, R, d->N, in_scale};
+    stg::StoreC ep{ws, KP, d->N, d->N, (size_t)KP * d->N};
+    stg::launch<3>(al, bl, ep, KP, d->N, R, ns, st_stream(stream));
+    ST_TRY(st_check_launch("analysis_wgrad"));
+    const int ksplit = st_round_up((R + ns - 1) / ns, stg::BK);
+    const int nz = (R + ksplit - 1) / ksplit;
+    hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(2 * d->F), dim3(256), 0, st_stream(stream),
+                       ws, nz, gWr, gWi, norm_partial, d->N, d->F, KP, 0);
+    return st_check_launch("analysis_wgrad_reduce");
+}
+
+extern "C" int st_finalize_scalars(const st_dims* d, const float* loss_partial, const float* reg_partial,
+                                   const float* norm_a, const float* norm_s, float inv_world, float* scalars, void* stream)
+{
+    ST_TRY(check_dims(d)); ST_REQ(scalars, "st_finalize_scalars: null pointer");
+    const float inv_y = 1.0f / ((float)d->B * (float)d->y);
+    const float reg_scale = (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);   // loss_functions.py:36
+    hipLaunchKernelGGL(stm::finalize_kernel, dim3(1), dim3(256), 0, st_stream(stream),
+                       loss_partial, st_ola_loss_partials(d), reg_partial, st_ae_fwd_partials(d),
+                       norm_a, st_norm_partials(d), norm_s, st_norm_partials(d), inv_y, reg_scale, inv_world, scalars);
+    return st_check_launch("finalize_scalars");
+}
+
+extern "C" int st_clip_adam(float* params, float* grads, float* m, float* v, int64_t n_total, int64_t n_stft,
+                            const float* scalars, float grad_scale, float lr, float beta1, float beta2, float eps, int step,
+                            void* stream)
+{
+    ST_REQ(params && grads && m && v && scalars, "st_clip_adam: null pointer");
+    ST_REQ(n_total % 4 == 0 && n_stft % 4 == 0 && n_stft <= n_total && step >= 1, "st_clip_adam: bad sizes/step");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const float neg_step = (float)(-(double)lr / bc1);
+    const float bc2s = (float)sqrt(bc2);
+    const float w1 = (float)(1.0 - (double)beta1), w2 = (float)(1.0 - (double)beta2);
+    int grid = (int)((n_total / 4 + 255) / 256); if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(stm::clip_adam_kernel, dim3(grid), dim3(256), 0, st_stream(stream),
+                       params, grads, m, v, n_total / 4, n_stft / 4, scalars, grad_scale, neg_step, w1, beta2, w2, bc2s, eps);
+    return st_check_launch("clip_adam");
+}
+
+// ------------------------------------------------------------------------------ workspace
+struct WS {
+    float *re, *im, *mag, *phs, *mag_hat, *phs_hat, *AA, *dAA, *Sfold, *frs, *y_hat, *dsyn, *dmag, *dphs, *dG;
+    float *wg, *aews, *loss_p, *reg_p, *norm_a, *norm_s;
+    size_t bytes;
+};
+static void carve(const st_dims* d, void* base, WS* w)
+{
+    const size_t RT = (size_t)d->B * d->T, RO = (size_t)d->B * d->OT, F = d->F, KP = st_kp_of(d->F), N = d->N;
+    size_t off = 0;
+    auto take = [&](size_t n) { float* p = base ? reinterpret_cast<float*>(base) + off : nullptr; off += (n + 63) / 64 * 64; return p; };
+    w->re = take(RT * F); w->im = take(RT * F); w->mag = take(RT * F); w->phs = take(RT * F);
+    w->mag_hat = take(RO * F); w->phs_hat = take(RO * F);
+    w->AA = take(RO * KP); w->dAA = take(RO * KP);
+    w->Sfold = take(KP * N); w->frs = take(RO * N);
+    w->y_hat = take((size_t)d->B * d->y); w->dsyn = take((size_t)d->B * d->y);
+    w->dmag = take(RT * F); w->dphs = take(RT * F); w->dG = take(RT * KP);
+    w->wg = take(st_wgrad_ws_floats(d)); w->aews = take(st_ae_bwd_ws_floats(d));
+    w->loss_p = take(st_ola_loss_partials(d)); w->reg_p = take(st_ae_fwd_partials(d));
+    w->norm_a = take(st_norm_partials(d)); w->norm_s = take(st_norm_partials(d));
+    w->bytes = off * sizeof(float);
+}
+extern "C" size_t st_workspace_bytes(const st_dims* d)
+{
+    if (check_dims(d) != ST_OK) return 0;
+    WS w; carve(d, nullptr, &w); return w.bytes;
+}
+
+// ------------------------------------------------------------------------------ fused entry points
+static int forward_impl(const st_dims* d, const Layout& L, const float* params, const float* x, const float* knobs,
+                        const float* y_true, float* y_hat, float* mag, float* mag_hat, WS& w, bool save, void* stream)
+{
+    const float* Wr = params + L.offs[0]; const float* Wi = params + L.offs[1];
+    const float* Sr = params + L.offs[2]; const float* Si = params + L.offs[3];
+    const float* ae_m = params + L.offs[4]; const float* ae_p = params + L.offs[22];
+    // saved-for-backward state always lives in the workspace; user-visible outputs are copies
+    ST_TRY(st_analysis_fwd(d, x, Wr, Wi, 0.5f, save ? w.re : nullptr, save ? w.im : nullptr, w.mag, w.phs, stream));
+    ST_TRY(st_ae_fwd(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.AA, w.reg_p, stream));
+    ST_TRY(st_synth_fold(d, Sr, Si, w.Sfold, stream));
+    ST_TRY(st_synthesis_frames(d, w.AA, w.Sfold, w.frs, stream));
+    ST_TRY(st_ola_loss(d, w.frs, x, y_true, y_hat ? y_hat : w.y_hat, (save && y_true) ? w.dsyn : nullptr,
+                       y_true ? w.loss_p : nullptr, stream));
+    const size_t nm = (size_t)d->B * d->T * d->F * sizeof(float), nh = (size_t)d->B * d->OT * d->F * sizeof(float);
+    if (mag && hipMemcpyAsync(mag, w.mag, nm, hipMemcpyDeviceToDevice, st_stream(stream)) != hipSuccess) return st_fail(ST_ERR_LAUNCH, "copy mag");
+    if (mag_hat && hipMemcpyAsync(mag_hat, w.mag_hat, nh, hipMemcpyDeviceToDevice, st_stream(stream)) != hipSuccess) return st_fail(ST_ERR_LAUNCH, "copy mag_hat");
+    return ST_OK;
+}
+
+// backward of everything behind d syn (workspace holds the forward state): autograd of train.py:138
+static int backward_impl(const st_dims* d, const Layout& L, const float* params, float* grads, const float* x,
+                         const float* knobs, const float* g_mag_hat, const float* g_mag, float reg_coef, WS& w, void* stream)
+{
+    const float* ae_m = params + L.offs[4]; const float* ae_p = params + L.offs[22];
+    ST_TRY(st_synthesis_dgrad(d, w.dsyn, w.Sfold, w.dAA, stream));
+    ST_TRY(st_synthesis_wgrad(d, w.AA, w.dsyn, w.wg, grads + L.offs[2], grads + L.offs[3], w.norm_s, stream));
+    ST_TRY(st_ae_bwd(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.dAA, g_mag_hat, reg_coef, w.dmag, w.dphs,
+                     w.aews, grads + L.offs[4], grads + L.offs[22], stream));
+    ST_TRY(st_polar_bwd(d, w.re, w.im, w.dmag, w.dphs, g_mag, w.dG, stream));
+    ST_TRY(st_analysis_wgrad(d, w.dG, x, 0.5f, w.wg, grads + L.offs[0], grads + L.offs[1], w.norm_a, stream));
+    return ST_OK;
+}
+
+extern "C" int st_model_fwd(const st_dims* d, const float* params, const float* x, const float* knobs,
+                            float* y_hat, float* mag, float* mag_hat, void* ws, int save_for_backward, void* stream)
+{
+    Layout L; ST_TRY(make_layout(d, &L));
+    ST_REQ(params && x && knobs && ws, "st_model_fwd: null pointer");
+    WS w; carve(d, ws, &w);
+    return forward_impl(d, L, params, x, knobs, nullptr, y_hat, mag, mag_hat, w, save_for_backward != 0, stream);
+}
+
+extern "C" int st_model_bwd(const st_dims* d, const float* params, float* grads, const float* x, const float* knobs,
+                            const float* g_y_hat, const float* g_mag_hat, const float* g_mag, void* ws, void* stream)
+{
+    Layout L; ST_TRY(make_layout(d, &L));
+    ST_REQ(params && grads && x && knobs && g_y_hat && ws, "st_model_bwd: null pointer");
+    WS w; carve(d, ws, &w);
+    const int64_t n = (int64_t)d->B * d->y;
+    hipLaunchKernelGGL(stm::scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st_stream(stream), g_y_hat, w.dsyn, n, 2.0f);
+    ST_TRY(st_check_launch("scale(dsyn)"));
+    return backward_impl(d, L, params, grads, x, knobs, g_mag_hat, g_mag, 0.0f, w, stream);
+}
+
+extern "C" int st_loss_backward(const st_dims* d, const float* params, float* grads, const float* x, const float* knobs,
+                                const float* y_true, float* y_hat, float* mag, float* mag_hat, void* ws,
+                                float* scalars, void* stream)
+{
+    Layout L; ST_TRY(make_layout(d, &L));
+    ST_REQ(params && grads && x && knobs && y_true && ws && scalars, "st_loss_backward: null pointer");
+    WS w; carve(d, ws, &w);
+    ST_TRY(forward_impl(d, L, params, x, knobs, y_true, y_hat, mag, mag_hat, w, true, stream));
+    const float reg_coef = (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);   // loss_functions.py:36
+    ST_TRY(backward_impl(d, L, params, grads, x, knobs, nullptr, nullptr, reg_coef, w, stream));
+    ST_TRY(st_finalize_scalars(d, w.loss_p, w.reg_p, w.norm_a, w.norm_s, 1.0f, scalars, stream));
+    return ST_OK;
+}
+
+extern "C" int st_train_step(const st_dims* d, float* params, float* grads, float* m, float* v, const float* x,
+                             const float* knobs, const float* y_true, void* ws, float* scalars,
+                             float lr, float beta1, float beta2, float eps, int step, void* stream)
+{
+    Layout L; ST_TRY(make_layout(d, &L));
+    ST_TRY(st_loss_backward(d, params, grads, x, knobs, y_true, nullptr, nullptr, nullptr, ws, scalars, stream));
+    return st_clip_adam(params, grads, m, v, L.total, L.n_stft, scalars, 1.0f, lr, beta1, beta2, eps, step, stream);
+}
+
+extern "C" int st_dp_clip_adam(const st_dims* d, float* params, float* grads, float* m, float* v, void* ws,
+                               float* scalars, float grad_scale, float lr, float beta1, float beta2, float eps,
+                               int step, void* stream)
+{
+    Layout L; ST_TRY(make_layout(d, &L));
+    ST_REQ(params && grads && m && v && ws && scalars, "st_dp_clip_adam: null pointer");
+    WS w; carve(d, ws, &w);
+    // L1 norm of the all-reduced, 1/world-scaled STFT gradient: identical on every rank, no second collective
+    const int np = st_norm_partials(d);
+    hipLaunchKernelGGL(stm::l1_partial_kernel, dim3(np), dim3(256), 0, st_stream(stream),
+                       grads, L.n_stft, grad_scale, w.norm_a);
+    ST_TRY(st_check_launch("l1_partial"));
+    hipLaunchKernelGGL(stm::finalize_kernel, dim3(1), dim3(256), 0, st_stream(stream),
+                       (const float*)nullptr, 0, (const float*)nullptr, 0, (const float*)w.norm_a, np, (const float*)nullptr, 0,
+                       0.f, 0.f, 1.0f, scalars);
+    ST_TRY(st_check_launch("finalize(dp)"));
+    return st_clip_adam(params, grads, m, v, L.total, L.n_stft, scalars, grad_scale, lr, beta1, beta2, eps, step, stream);
+}

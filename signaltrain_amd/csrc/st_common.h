@@ -1,0 +1,46 @@
+// st_common.h -- shared device/host helpers for libsignaltrain_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/signaltrain_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define ST_WAVE 64
+
+// error plumbing (st_api.hip)
+int st_fail(int code, const char* fmt, ...);
+int st_check_launch(const char* what);
+
+static inline hipStream_t st_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+__host__ __device__ static inline int st_kp_of(int F) { return 2 * ((F + 15) / 16 * 16); }
+__host__ __device__ static inline int st_round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// ---------------------------------------------------------------- wave / block reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Sum over the block; result valid in thread 0.  `red` = LDS float[NWAVES].
+template <int NWAVES>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NWAVES; ++i) t += red[i];
+    }
+    __syncthreads();
+    return t;
+}
+
+__device__ __forceinline__ float elu_f(float a) { return a > 0.f ? a : (__expf(a) - 1.0f); }
+// ELU'(a) through h = ELU(a):  1 if h > 0 else h + 1 (= exp(a)).
+__device__ __forceinline__ float elu_grad_from_out(float h) { return h > 0.f ? 1.0f : h + 1.0f; }

@@ -1,0 +1,226 @@
+// st_misc.h -- HBM-bound helper kernels of the SignalTrain step (gfx950).
+#pragma once
+#include "st_common.h"
+
+namespace stm {
+
+// ---------------------------------------------------------------- synthesis basis fold
+// Sfold[KP,N]: rows [0,F) = Sr[k] (+ Sr[N-k], 1<=k<=F-2); rows [KP/2, KP/2+F) = Si[k] (- Si[N-k]); rest 0.
+// Weight-side form of the Hermitian extension at cls_fe_dft.py:109-110.
+__global__ void __launch_bounds__(256)
+fold_kernel(const float* __restrict__ Sr, const float* __restrict__ Si, float* __restrict__ Sfold,
+            int N, int F, int KP)
+{
+    const int row = blockIdx.x;                      // 0..KP-1
+    const int half = KP / 2;
+    const bool is_im = row >= half;
+    const int k = is_im ? row - half : row;
+    const float* S = is_im ? Si : Sr;
+    const bool valid = k < F;
+    const bool paired = valid && k >= 1 && k <= F - 2;
+    const float sgn = is_im ? -1.f : 1.f;
+    for (int n4 = threadIdx.x; n4 < N / 4; n4 += blockDim.x) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+            v = reinterpret_cast<const float4*>(S + (size_t)k * N)[n4];
+            if (paired) {
+                const float4 u = reinterpret_cast<const float4*>(S + (size_t)(N - k) * N)[n4];
+                v.x += sgn * u.x; v.y += sgn * u.y; v.z += sgn * u.z; v.w += sgn * u.w;
+            }
+        }
+        reinterpret_cast<float4*>(Sfold + (size_t)row * N)[n4] = v;
+    }
+}
+
+// ---------------------------------------------------------------- overlap-add + residual + log-cosh
+// y_hat[b,j] = 2 * sum_t frs[b,t, N + j - H t] + x[b, L-y+j]     (cls_fe_dft.py:112-113, nn_proc.py:332,340)
+// loss partial = sum log cosh(y - y_hat) ; dsyn = 2 * (-tanh(y - y_hat)) * inv_count  (loss_functions.py:9-10)
+__global__ void __launch_bounds__(256)
+ola_loss_kernel(const float* __restrict__ frs, const float* __restrict__ x, const float* __restrict__ y_true,
+                float* __restrict__ y_hat, float* __restrict__ dsyn, float* __restrict__ loss_partial,
+                int L, int N, int H, int OT, int ysz, float inv_count)
+{
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    float lc = 0.f;
+    if (j < ysz) {
+        int t0 = j / H + 1;                           // first frame with N + j - H t < N
+        int t1 = (N + j) / H;                         // last frame with N + j - H t >= 0
+        if (t1 > OT - 1) t1 = OT - 1;
+        const float* fb = frs + (size_t)b * OT * N;
+        float s = 0.f;
+        for (int t = t0; t <= t1; ++t) s += fb[(size_t)t * N + (N + j - H * t)];
+        const float out = 2.0f * (s + 0.5f * x[(size_t)b * L + (L - ysz) + j]);
+        if (y_hat) y_hat[(size_t)b * ysz + j] = out;
+        if (y_true) {
+            const float dlt = y_true[(size_t)b * ysz + j] - out;
+            const float a = fabsf(dlt);
+            lc = a + log1pf(__expf(-2.0f * a)) - 0.69314718056f;      // log(cosh(d)), overflow-free
+            if (dsyn) dsyn[(size_t)b * ysz + j] = -2.0f * tanhf(dlt) * inv_count;
+        }
+    }
+    if (loss_partial) {
+        const float tot = block_sum<4>(lc, red);
+        if (threadIdx.x == 0) loss_partial[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+    }
+}
+
+// dsyn = 2 * g_y_hat  (y_hat = 2*(syn + x/2), nn_proc.py:332,340) -- generic autograd entry
+__global__ void __launch_bounds__(256)
+scale_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, float s)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = s * in[i];
+}
+
+// ---------------------------------------------------------------- polar backward (nn_proc.py:309-310)
+// dre = dmag*re/mag [0 at mag==0] - dphs*im/((re+eps)^2+im^2);  dim = dmag*im/mag + dphs*(re+eps)/(...)
+// Output dG[R,KP]: d re at [0,F), d im at [KP/2,KP/2+F), pads written as zeros.
+__global__ void __launch_bounds__(256)
+polar_bwd_kernel(const float* __restrict__ re, const float* __restrict__ im, const float* __restrict__ dmag,
+                 const float* __restrict__ dphs, const float* __restrict__ g_mag, float* __restrict__ dG, int R, int F, int KP)
+{
+    const int half = KP / 2;
+    const int r = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;     // column in [0, half)
+    if (c >= half) return;
+    float gre = 0.f, gim = 0.f;
+    if (c < F) {
+        const size_t i = (size_t)r * F + c;
+        const float a = re[i], bb = im[i], dm = dmag[i] + (g_mag ? g_mag[i] : 0.f), dp = dphs[i];
+        const float mg = sqrtf(a * a + bb * bb);
+        const float inv = mg > 0.f ? 1.0f / mg : 0.f;
+        const float rp = a + 1e-7f;
+        const float den = rp * rp + bb * bb;
+        gre = dm * a * inv - dp * bb / den;
+        gim = dm * bb * inv + dp * rp / den;
+    }
+    dG[(size_t)r * KP + c] = gre;
+    dG[(size_t)r * KP + half + c] = gim;
+}
+
+// ---------------------------------------------------------------- split-K slab reduce (+ unfold, + |g| sums)
+// ws[nz][KP][N] -> gradient tensors [N,N].  mode 0 (analysis): row k<F -> gRe[k], row half+k -> gIm[k].
+// mode 1 (synthesis): additionally mirror to row N-k with sign +1 (real) / -1 (imag)  (SURVEY.md 8a' "unfold").
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ ws, int nz, float* __restrict__ gRe, float* __restrict__ gIm,
+                    float* __restrict__ norm_partial, int N, int F, int KP, int mode)
+{
+    __shared__ float red[4];
+    const int row = blockIdx.x;                       // 0 .. 2F-1 : [0,F) real rows, [F,2F) imag rows
+    const bool is_im = row >= F;
+    const int k = is_im ? row - F : row;
+    const int src = is_im ? KP / 2 + k : k;
+    float* g = is_im ? gIm : gRe;
+    const bool mirror = mode == 1 && k >= 1 && k <= F - 2;
+    const float sgn = is_im ? -1.f : 1.f;
+    const size_t slab = (size_t)KP * N;
+    float na = 0.f;
+    for (int n4 = threadIdx.x; n4 < N / 4; n4 += blockDim.x) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = 0; z < nz; ++z) {
+            const float4 u = reinterpret_cast<const float4*>(ws + z * slab + (size_t)src * N)[n4];
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        reinterpret_cast<float4*>(g + (size_t)k * N)[n4] = v;
+        float a = fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
+        if (mirror) {
+            reinterpret_cast<float4*>(g + (size_t)(N - k) * N)[n4] = make_float4(sgn * v.x, sgn * v.y, sgn * v.z, sgn * v.w);
+            a *= 2.f;
+        }
+        na += a;
+    }
+    const float tot = block_sum<4>(na, red);
+    if (threadIdx.x == 0) norm_partial[row] = tot;
+}
+
+// L1 norm partials of an arbitrary flat range (data-parallel path: norm of the *reduced* gradient).
+__global__ void __launch_bounds__(256)
+l1_partial_kernel(const float* __restrict__ g, int64_t n, float scale, float* __restrict__ partial)
+{
+    __shared__ float red[4];
+    float a = 0.f;
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        a += fabsf(v.x * scale) + fabsf(v.y * scale) + fabsf(v.z * scale) + fabsf(v.w * scale);
+    }
+    const float tot = block_sum<4>(a, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------- per-wave AE gradient partial reduce
+// ws[nparts][2][PG] -> g_m[PG], g_p[PG]
+__global__ void __launch_bounds__(256)
+ae_grad_reduce_kernel(const float* __restrict__ ws, int nparts, int PG, float* __restrict__ g_m, float* __restrict__ g_p)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int ae = blockIdx.y;
+    if (i >= PG) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += ws[((size_t)p * 2 + ae) * PG + i];
+    (ae ? g_p : g_m)[i] = s;
+}
+
+// ---------------------------------------------------------------- scalars
+// scalars: [0]=loss [1]=mean logcosh [2]=reg term [3]=L1 norm of STFT grads [4]=clip coef
+// (torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm/(norm+1e-6)), nn_proc.py:299-302)
+__global__ void __launch_bounds__(256)
+finalize_kernel(const float* __restrict__ loss_partial, int n_loss, const float* __restrict__ reg_partial, int n_reg,
+                const float* __restrict__ norm_a, int n_na, const float* __restrict__ norm_s, int n_ns,
+                float inv_ycount, float reg_scale, float norm_scale, float* __restrict__ scalars)
+{
+    __shared__ float red[4];
+    float a = 0.f, b = 0.f, c = 0.f;
+    if (loss_partial) for (int i = threadIdx.x; i < n_loss; i += 256) a += loss_partial[i];
+    if (reg_partial) for (int i = threadIdx.x; i < n_reg; i += 256) b += reg_partial[i];
+    if (norm_a) for (int i = threadIdx.x; i < n_na; i += 256) c += norm_a[i];
+    if (norm_s) for (int i = threadIdx.x; i < n_ns; i += 256) c += norm_s[i];
+    a = block_sum<4>(a, red); b = block_sum<4>(b, red); c = block_sum<4>(c, red);
+    if (threadIdx.x == 0) {
+        const float lc = a * inv_ycount, rg = b * reg_scale;
+        if (loss_partial) { scalars[1] = lc; scalars[2] = rg; scalars[0] = lc + rg; }
+        if (norm_a || norm_s) {
+            const float nrm = c * norm_scale;
+            scalars[3] = nrm;
+            const float coef = 1.0f / (nrm + 1e-6f);
+            scalars[4] = coef < 1.0f ? coef : 1.0f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- L1 clip + Adam (train.py:145-147)
+// torch.optim.Adam (single-tensor path): m.lerp_(g, 1-b1); v = v*b2 + (1-b2)*g*g;
+// denom = sqrt(v)/sqrt(bc2) + eps ; p += (-lr/bc1) * m / denom.   STFT range [0,n_stft) is scaled by
+// the clip coefficient first; every gradient is pre-scaled by grad_scale (1/world in data parallel).
+__global__ void __launch_bounds__(256)
+clip_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                 int64_t n4_total, int64_t n4_stft, const float* __restrict__ scalars, float grad_scale,
+                 float neg_step_size, float w1, float b2, float w2, float bc2_sqrt, float eps)
+{
+    const float coef = scalars[4];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4_total; i += (int64_t)gridDim.x * 256) {
+        const float sc = (i < n4_stft) ? grad_scale * coef : grad_scale;
+        float4 G = reinterpret_cast<float4*>(g)[i];
+        float4 M = reinterpret_cast<float4*>(m)[i];
+        float4 V = reinterpret_cast<float4*>(v)[i];
+        float4 P = reinterpret_cast<float4*>(p)[i];
+#define ST_ADAM1(c)                                                        \
+        {                                                                  \
+            const float gg = (sc == 1.0f) ? G.c : G.c * sc;                \
+            M.c = M.c + w1 * (gg - M.c);                                   \
+            V.c = V.c * b2 + (w2 * gg) * gg;                               \
+            const float den = sqrtf(V.c) / bc2_sqrt + eps;                 \
+            P.c = P.c + (neg_step_size * M.c) / den;                       \
+            G.c = gg;                                                      \
+        }
+        ST_ADAM1(x) ST_ADAM1(y) ST_ADAM1(z) ST_ADAM1(w)
+#undef ST_ADAM1
+        reinterpret_cast<float4*>(g)[i] = G;       // clipped gradient is observable in the reference (p.grad)
+        reinterpret_cast<float4*>(m)[i] = M;
+        reinterpret_cast<float4*>(v)[i] = V;
+        reinterpret_cast<float4*>(p)[i] = P;
+    }
+}
+
+}  // namespace stm

@@ -1,0 +1,171 @@
+"""Fused train-step engine over libsignaltrain_hip.so.
+
+Owns (as torch tensors -- PyTorch is the allocator, nothing more) the flat fp32 parameter /
+gradient / Adam-moment buffers laid out by `st_param_offsets` and the workspace the C library
+carves.  One engine = one GPU = one process; data parallelism (dp.py) all-reduces `grads`.
+
+Reference mapping: one `train_step` call == the body of train_loop's minibatch iteration,
+signaltrain/train.py:112-151 (forward, calc_loss, backward, clip_grad_norm_, Adam.step).
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+
+AE_LAYERS = ("fnn_enc", "fnn_enc2", "fnn_enc3", "fnn_enc4", "fnn_addknobs",
+             "fnn_dec4", "fnn_dec3", "fnn_dec2", "fnn_dec")          # nn_proc.py:64-65
+STFT_KEYS = ("mpaec.dft_analysis.conv_analysis_real.weight",
+             "mpaec.dft_analysis.conv_analysis_imag.weight",
+             "mpaec.dft_synthesis.conv_synthesis_real.weight",
+             "mpaec.dft_synthesis.conv_synthesis_imag.weight")
+
+
+def param_names():
+    """state_dict() key order of the reference st_model."""
+    keys = list(STFT_KEYS)
+    for ae in ("aenc", "phs_aenc"):
+        for n in AE_LAYERS:
+            keys += [f"mpaec.{ae}.{n}.weight", f"mpaec.{ae}.{n}.bias"]
+    return keys
+
+
+def param_shapes(d):
+    R = 64
+    ae = [(R, d.T), (R // 2, R), (R // 4, R // 2), (R // 4, R // 4), (R // 4, R // 4 + d.K),
+          (R // 4, R // 4), (R // 2, R // 4), (R, R // 2), (d.OT, R)]           # nn_proc.py:46-61
+    shapes = [(d.N, 1, d.N)] * 4
+    for _ in range(2):
+        for (o, i) in ae:
+            shapes += [(o, i), (o,)]
+    return shapes
+
+
+class ParamLayout:
+    """Names, shapes and float offsets of the 40 tensors inside the flat buffers."""
+
+    def __init__(self, d):
+        self.names = param_names()
+        self.shapes = param_shapes(d)
+        self.offsets, self.total = _lib.param_offsets(d)
+        self.n_stft = self.offsets[4]
+
+    def views(self, flat):
+        out = OrderedDict()
+        for n, s, o in zip(self.names, self.shapes, self.offsets):
+            out[n] = flat[o:o + int(np.prod(s))].view(*s)
+        return out
+
+
+class StepEngine:
+    """Holds device state for one model replica and drives the HIP step."""
+
+    def __init__(self, dims, device="cuda:0", max_batch=None):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("signaltrain_amd.StepEngine needs a ROCm device (there is no CPU fallback)")
+        self.dims = dims
+        self.max_batch = int(max_batch or dims.B)
+        self.layout = ParamLayout(dims)
+        n = self.layout.total
+        z = lambda: torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.params, self.grads, self.m, self.v = z(), z(), z(), z()
+        dmax = dims.with_batch(self.max_batch)
+        self.ws = torch.zeros(self.lib.st_workspace_bytes(C.byref(dmax)), dtype=torch.uint8, device=self.device)
+        self.scalars = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self.named = self.layout.views(self.params)
+        self.named_grads = self.layout.views(self.grads)
+        self.step_count = 0
+
+    # ---------------------------------------------------------------- parameters
+    def load_state_dict(self, sd):
+        for k, v in self.named.items():
+            src = sd[k]
+            src = torch.as_tensor(np.asarray(src)) if not torch.is_tensor(src) else src
+            v.copy_(src.to(device=self.device, dtype=torch.float32).reshape(v.shape))
+
+    def state_dict(self):
+        return OrderedDict((k, v.detach().clone()) for k, v in self.named.items())
+
+    def _dims(self, B):
+        if B > self.max_batch:
+            raise RuntimeError(f"batch {B} exceeds the engine's workspace (max_batch={self.max_batch})")
+        return self.dims if B == self.dims.B else self.dims.with_batch(B)
+
+    @staticmethod
+    def _stream():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _prep(self, x, knobs, y=None):
+        f = lambda t: None if t is None else t.to(device=self.device, dtype=torch.float32).contiguous()
+        x, knobs, y = f(x), f(knobs), f(y)
+        d = self._dims(x.shape[0])
+        assert x.shape == (d.B, d.L) and knobs.shape == (d.B, d.K), (x.shape, knobs.shape, d.as_dict())
+        if y is not None:
+            assert y.shape == (d.B, d.y), (y.shape, d.y)
+        return d, x, knobs, y
+
+    # ---------------------------------------------------------------- forward / backward / step
+    def forward(self, x, knobs, save_for_backward=False):
+        """st_model.forward (nn_proc.py:392): returns (y_hat[B,y], mag[B,T,F], mag_hat[B,OT,F])."""
+        d, x, knobs, _ = self._prep(x, knobs)
+        y_hat = torch.empty(d.B, d.y, dtype=torch.float32, device=self.device)
+        mag = torch.empty(d.B, d.T, d.F, dtype=torch.float32, device=self.device)
+        mag_hat = torch.empty(d.B, d.OT, d.F, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.st_model_fwd(C.byref(d), _lib.ptr(self.params), _lib.ptr(x), _lib.ptr(knobs),
+                                         _lib.ptr(y_hat), _lib.ptr(mag), _lib.ptr(mag_hat), _lib.ptr(self.ws),
+                                         1 if save_for_backward else 0, self._stream()), "st_model_fwd")
+        return y_hat, mag, mag_hat
+
+    def backward(self, x, knobs, g_y_hat, g_mag_hat=None, g_mag=None):
+        """Autograd backward for arbitrary upstream gradients (after forward(save_for_backward=True))."""
+        d, x, knobs, _ = self._prep(x, knobs)
+        f = lambda t: None if t is None else t.to(device=self.device, dtype=torch.float32).contiguous()
+        g_y_hat, g_mag_hat, g_mag = f(g_y_hat), f(g_mag_hat), f(g_mag)
+        _lib.check(self.lib.st_model_bwd(C.byref(d), _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(x),
+                                         _lib.ptr(knobs), _lib.ptr(g_y_hat), _lib.ptr(g_mag_hat), _lib.ptr(g_mag),
+                                         _lib.ptr(self.ws), self._stream()), "st_model_bwd")
+        return self.grads
+
+    def loss_backward(self, x, knobs, y, want_outputs=False):
+        """forward + calc_loss (loss_functions.py:26-36 with scale_by_freq) + backward; fills self.grads.
+        self.scalars[0..4] = loss, mean log-cosh, L1 term, L1 norm of STFT grads, clip coefficient."""
+        d, x, knobs, y = self._prep(x, knobs, y)
+        outs = (None, None, None)
+        if want_outputs:
+            outs = (torch.empty(d.B, d.y, dtype=torch.float32, device=self.device),
+                    torch.empty(d.B, d.T, d.F, dtype=torch.float32, device=self.device),
+                    torch.empty(d.B, d.OT, d.F, dtype=torch.float32, device=self.device))
+        _lib.check(self.lib.st_loss_backward(C.byref(d), _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(x),
+                                             _lib.ptr(knobs), _lib.ptr(y), _lib.ptr(outs[0]), _lib.ptr(outs[1]),
+                                             _lib.ptr(outs[2]), _lib.ptr(self.ws), _lib.ptr(self.scalars),
+                                             self._stream()), "st_loss_backward")
+        return outs
+
+    def train_step(self, x, knobs, y, lr, betas=(0.9, 0.999), eps=1e-8):
+        """One optimisation step (train.py:112-151).  `lr` is the value sitting in param_groups at step
+        time, i.e. lr_sched[max(i-1,0)] in the reference loop (train.py:150).  No host sync."""
+        d, x, knobs, y = self._prep(x, knobs, y)
+        self.step_count += 1
+        _lib.check(self.lib.st_train_step(C.byref(d), _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.m),
+                                          _lib.ptr(self.v), _lib.ptr(x), _lib.ptr(knobs), _lib.ptr(y), _lib.ptr(self.ws),
+                                          _lib.ptr(self.scalars), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                          int(self.step_count), self._stream()), "st_train_step")
+        return self.scalars
+
+    def clip_adam(self, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
+        """L1 clip + Adam on the current self.grads (data parallel: call after the all-reduce with
+        grad_scale = 1/world; the norm is recomputed on the reduced gradient, identically on all ranks)."""
+        self.step_count += 1
+        _lib.check(self.lib.st_dp_clip_adam(C.byref(self.dims), _lib.ptr(self.params), _lib.ptr(self.grads),
+                                            _lib.ptr(self.m), _lib.ptr(self.v), _lib.ptr(self.ws), _lib.ptr(self.scalars),
+                                            float(grad_scale), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                            int(self.step_count), self._stream()), "st_dp_clip_adam")
+        return self.scalars
+
+    def loss(self):
+        """Host copy of the last loss (device->host sync; the reference does this every 10 iterations)."""
+        return float(self.scalars[0].item())

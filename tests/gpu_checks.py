@@ -1,0 +1,267 @@
+"""Stage-by-stage parity checks of the HIP path against the oracle (needs a GPU).
+
+Used by tests/test_gpu_parity.py (asserting) and tools/gpu_diag.py (verbose report).  Each check
+calls the C ABI through ctypes on seeded inputs, computes the same quantity with oracle/st_oracle.py
+in float64 *from the same fp32 inputs*, and returns (name, max_abs_err, scale, tolerance).
+Tolerances are relative to max|reference| of the tensor (north_star: 1e-4 rel fp32).
+"""
+import ctypes as C
+import numpy as np
+import torch
+
+from oracle import st_oracle as O
+from signaltrain_amd import _lib
+from signaltrain_amd.engine import StepEngine, ParamLayout, STFT_KEYS
+from tests.golden_util import perturb_stft
+
+DEV = "cuda:0"
+TOL = 1e-4           # BASELINE.json north_star: <= 1e-4 relative, fp32
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+
+
+def n(x):
+    return x.detach().cpu().numpy().astype(np.float64)
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_case(B=3, seed=0, scale=1, shrink=4, K=4, pert=7):
+    """Seeded comp_4c-shaped inputs + 'learned' (perturbed) parameters, as fp32 numpy."""
+    geo = O.geometry(scale, shrink)
+    rng = np.random.default_rng(seed)
+    X, Y, KN = O.synth_comp4c_batch(B, geo["L"], geo["y"], rng)
+    if K != 4:
+        KN = (rng.beta(0.8, 0.8, size=(B, K)) - 0.5).astype(np.float32)
+    P = O.init_params(geo, K, np.random.default_rng(seed + 100))
+    for k in P:                                   # non-zero biases so that bias paths are exercised
+        if k.endswith(".bias"):
+            P[k] = (0.05 * rng.standard_normal(P[k].shape)).astype(np.float32)
+    perturb_stft(P, seed=pert)
+    return geo, X, Y, KN, P
+
+
+def dims_of(geo, B, K):
+    d = _lib.st_dims()
+    d.B, d.L, d.N, d.H, d.T, d.OT, d.F, d.K, d.y = B, geo["L"], geo["N"], geo["H"], geo["T"], geo["OT"], geo["F"], K, geo["y"]
+    return d
+
+
+def to_kp(re, im, KP):
+    """[R,F] pair -> padded [R,KP] (re at 0.., im at KP/2..)."""
+    R, F = re.shape
+    out = np.zeros((R, KP), re.dtype)
+    out[:, :F] = re; out[:, KP // 2:KP // 2 + F] = im
+    return out
+
+
+def from_kp(a, F):
+    KP = a.shape[1]
+    return a[:, :F], a[:, KP // 2:KP // 2 + F]
+
+
+def err(name, got, ref, tol=TOL, scale=None):
+    got = np.asarray(got, np.float64); ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    sc = float(np.max(np.abs(ref))) if scale is None else float(scale)
+    d = np.abs(got - ref)
+    bad = ~np.isfinite(got)
+    e = float(np.max(np.where(bad, np.inf, d))) if got.size else 0.0
+    worst = np.unravel_index(int(np.argmax(np.where(bad, np.inf, d))), d.shape) if got.size else ()
+    return dict(name=name, err=e, scale=sc, rel=e / max(sc, 1e-30), tol=tol, ok=bool(e <= tol * max(sc, 1e-30)),
+                worst=tuple(int(i) for i in worst), got=float(got[worst]) if got.size else 0.0,
+                ref=float(ref[worst]) if got.size else 0.0)
+
+
+def phase_err(name, got, ref, mag, tol=TOL):
+    """Phase compared modulo 2*pi and weighted by mag/max(mag): atan2 is ill-conditioned where mag ~ 0
+    and discontinuous at +-pi (SURVEY.md section 7 'hard parts')."""
+    dphi = np.angle(np.exp(1j * (np.asarray(got, np.float64) - ref)))
+    w = mag / max(float(mag.max()), 1e-30)
+    e = np.abs(dphi) * w
+    worst = np.unravel_index(int(np.argmax(e)), e.shape)
+    return dict(name=name, err=float(e.max()), scale=1.0, rel=float(e.max()), tol=tol, ok=bool(e.max() <= tol),
+                worst=tuple(int(i) for i in worst), got=float(got[worst]), ref=float(ref[worst]))
+
+
+# --------------------------------------------------------------------------------------------- stages
+def run_all(B=3, seed=0, K=4, verbose=False):
+    """Run every per-op entry point on oracle-provided inputs; returns list of result dicts."""
+    lib = _lib.load()
+    geo, X, Y, KN, P = make_case(B, seed, K=K)
+    d = dims_of(geo, B, K)
+    KP = lib.st_kp(d.F); F, T, OT, N = d.F, d.T, d.OT, d.N
+    res = []
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    loss, G, c = O.model_loss_bwd(X.astype(np.float64), KN.astype(np.float64), Y.astype(np.float64), P64, geo)
+
+    lay = ParamLayout(d)
+    flat = torch.zeros(lay.total, device=DEV)
+    for k, v in lay.views(flat).items():
+        v.copy_(t(P[k]).reshape(v.shape))
+    V = lay.views(flat)
+    Wr, Wi, Sr, Si = (V[k] for k in STFT_KEYS)
+    ae_m = flat[lay.offsets[4]:lay.offsets[22]]; ae_p = flat[lay.offsets[22]:]
+    PG = lay.offsets[22] - lay.offsets[4]
+    x, kn, y = t(X), t(KN), t(Y)
+    z = lambda *s: torch.zeros(*s, device=DEV)
+
+    # 1. analysis + polar
+    re, im, mag, phs = z(B, T, F), z(B, T, F), z(B, T, F), z(B, T, F)
+    _lib.check(lib.st_analysis_fwd(C.byref(d), _lib.ptr(x), _lib.ptr(Wr), _lib.ptr(Wi), 0.5, _lib.ptr(re), _lib.ptr(im),
+                                   _lib.ptr(mag), _lib.ptr(phs), stream()), "analysis_fwd")
+    sc = float(np.abs(c["mag"]).max())
+    res += [err("analysis.re", n(re), c["re"], scale=sc), err("analysis.im", n(im), c["im"], scale=sc),
+            err("analysis.mag", n(mag), c["mag"]), phase_err("analysis.phs", n(phs), c["phs"], c["mag"])]
+    # frame indexing is bit-exact: zero-padded frames give exact zeros
+    res.append(err("analysis.zero_frames", n(re)[:, [0, T - 1]], np.zeros((B, 2, F)), scale=1.0, tol=0.0))
+
+    # 2. autoencoders forward (oracle inputs)
+    mag_o, phs_o = t(c["mag"]), t(c["phs"])
+    mag_hat, phs_hat, AA = z(B, OT, F), z(B, OT, F), z(B * OT, KP)
+    regp = z(lib.st_ae_fwd_partials(C.byref(d)))
+    _lib.check(lib.st_ae_fwd(C.byref(d), _lib.ptr(mag_o), _lib.ptr(phs_o), _lib.ptr(kn), _lib.ptr(ae_m), _lib.ptr(ae_p),
+                             _lib.ptr(mag_hat), _lib.ptr(phs_hat), _lib.ptr(AA), _lib.ptr(regp), stream()), "ae_fwd")
+    aa_re, aa_im = from_kp(n(AA), F)
+    sa = float(max(np.abs(c["Are"]).max(), np.abs(c["Aim"]).max()))
+    w = O.freq_weights(F, np.float64)
+    res += [err("ae_fwd.mag_hat", n(mag_hat), c["mag_hat"]), err("ae_fwd.phs_hat", n(phs_hat), c["phs_hat"]),
+            err("ae_fwd.an_real", aa_re.reshape(B, OT, F), c["Are"], scale=sa),
+            err("ae_fwd.an_imag", aa_im.reshape(B, OT, F), c["Aim"], scale=sa),
+            err("ae_fwd.pads", n(AA)[:, F:KP // 2], 0 * n(AA)[:, F:KP // 2], scale=1.0, tol=0.0),
+            err("ae_fwd.reg_sum", n(regp).sum(), np.abs(c["mag_hat"] * w).sum())]
+
+    # 3. fold + synthesis GEMM + OLA/loss
+    Sfold = z(KP, N)
+    _lib.check(lib.st_synth_fold(C.byref(d), _lib.ptr(Sr), _lib.ptr(Si), _lib.ptr(Sfold), stream()), "fold")
+    fr_, fi_ = O.fold_synthesis(P64[STFT_KEYS[2]], P64[STFT_KEYS[3]], F)
+    sf_re, sf_im = n(Sfold)[:F], n(Sfold)[KP // 2:KP // 2 + F]
+    res += [err("fold.re", sf_re, fr_), err("fold.im", sf_im, fi_, scale=np.abs(fr_).max())]
+    AAo = t(to_kp(c["Are"].reshape(-1, F), c["Aim"].reshape(-1, F), KP))
+    frs = z(B * OT, N)
+    _lib.check(lib.st_synthesis_frames(C.byref(d), _lib.ptr(AAo), _lib.ptr(Sfold), _lib.ptr(frs), stream()), "synth")
+    frs_ref = c["Are"].reshape(-1, F) @ fr_ + c["Aim"].reshape(-1, F) @ fi_
+    res.append(err("synthesis.frames", n(frs), frs_ref))
+    y_hat, dsyn = z(B, d.y), z(B, d.y)
+    lp = z(lib.st_ola_loss_partials(C.byref(d)))
+    frs_o = t(frs_ref)
+    _lib.check(lib.st_ola_loss(C.byref(d), _lib.ptr(frs_o), _lib.ptr(x), _lib.ptr(y), _lib.ptr(y_hat), _lib.ptr(dsyn),
+                               _lib.ptr(lp), stream()), "ola")
+    res += [err("ola.y_hat", n(y_hat), c["out"]), err("ola.dsyn", n(dsyn), 2 * c["dy"]),
+            err("ola.logcosh", n(lp).sum() / (B * d.y), np.mean(O.logcosh(Y.astype(np.float64) - c["out"])))]
+
+    # 4. synthesis dgrad / wgrad
+    dsyn_o = t(2 * c["dy"])
+    dAA = z(B * OT, KP)
+    _lib.check(lib.st_synthesis_dgrad(C.byref(d), _lib.ptr(dsyn_o), _lib.ptr(Sfold), _lib.ptr(dAA), stream()), "dgrad")
+    g_re, g_im = from_kp(n(dAA), F)
+    sd = float(max(np.abs(c["dAre"]).max(), np.abs(c["dAim"]).max()))
+    res += [err("syn_dgrad.dAre", g_re.reshape(B, OT, F), c["dAre"], scale=sd),
+            err("syn_dgrad.dAim", g_im.reshape(B, OT, F), c["dAim"], scale=sd)]
+    wsg = z(lib.st_wgrad_ws_floats(C.byref(d)))
+    gSr, gSi = z(N, N), z(N, N)
+    npart = lib.st_norm_partials(C.byref(d))
+    norm_s = z(npart)
+    _lib.check(lib.st_synthesis_wgrad(C.byref(d), _lib.ptr(AAo), _lib.ptr(dsyn_o), _lib.ptr(wsg), _lib.ptr(gSr), _lib.ptr(gSi),
+                                      _lib.ptr(norm_s), stream()), "syn_wgrad")
+    ss = float(max(np.abs(G[STFT_KEYS[2]]).max(), np.abs(G[STFT_KEYS[3]]).max()))
+    res += [err("syn_wgrad.gSr", n(gSr), G[STFT_KEYS[2]][:, 0], scale=ss), err("syn_wgrad.gSi", n(gSi), G[STFT_KEYS[3]][:, 0], scale=ss),
+            err("syn_wgrad.l1", n(norm_s).sum(), np.abs(G[STFT_KEYS[2]]).sum() + np.abs(G[STFT_KEYS[3]]).sum(), tol=1e-3)]
+
+    # 5. autoencoders backward (oracle inputs)
+    dAAo = t(to_kp(c["dAre"].reshape(-1, F), c["dAim"].reshape(-1, F), KP))
+    mh_o, ph_o = t(c["mag_hat"]), t(c["phs_hat"])
+    dmag, dphs = z(B, T, F), z(B, T, F)
+    aews = z(lib.st_ae_bwd_ws_floats(C.byref(d)))
+    g_m, g_p = z(PG), z(lay.total - lay.offsets[22])
+    reg_coef = (2e-5 / 10) / (B * OT * F)
+    _lib.check(lib.st_ae_bwd(C.byref(d), _lib.ptr(mag_o), _lib.ptr(phs_o), _lib.ptr(kn), _lib.ptr(ae_m), _lib.ptr(ae_p),
+                             _lib.ptr(mh_o), _lib.ptr(ph_o), _lib.ptr(dAAo), None, reg_coef, _lib.ptr(dmag), _lib.ptr(dphs),
+                             _lib.ptr(aews), _lib.ptr(g_m), _lib.ptr(g_p), stream()), "ae_bwd")
+    res += [err("ae_bwd.dmag", n(dmag), c["dmag"]), err("ae_bwd.dphs", n(dphs), c["dphs"])]
+    for ai, (pref, gbuf) in enumerate((("mpaec.aenc", g_m), ("mpaec.phs_aenc", g_p))):
+        gb = n(gbuf)
+        for li, nm in enumerate(O.AE_LAYERS):
+            for j, wb in enumerate(("weight", "bias")):
+                k = f"{pref}.{nm}.{wb}"
+                off = lay.offsets[4 + 2 * li + j] - lay.offsets[4]
+                ref = G[k]
+                res.append(err("ae_bwd.g." + k.replace("mpaec.", ""), gb[off:off + ref.size].reshape(ref.shape), ref))
+
+    # 6. polar backward + analysis wgrad
+    dG = z(B * T, KP)
+    _lib.check(lib.st_polar_bwd(C.byref(d), _lib.ptr(t(c["re"])), _lib.ptr(t(c["im"])), _lib.ptr(t(c["dmag"])),
+                                _lib.ptr(t(c["dphs"])), None, _lib.ptr(dG), stream()), "polar_bwd")
+    # zero-padded frames carry d atan2 = 1e7 * dphs: compare on the live frames, and the
+    # degenerate frames separately against the same formula
+    live = np.ones(T, bool); live[[0, T - 1]] = False
+    dre_g, dim_g = from_kp(n(dG), F)
+    dre_g, dim_g = dre_g.reshape(B, T, F), dim_g.reshape(B, T, F)
+    sl = float(max(np.abs(c["dre"][:, live]).max(), np.abs(c["dim"][:, live]).max()))
+    res += [err("polar_bwd.dre", dre_g[:, live], c["dre"][:, live], scale=sl), err("polar_bwd.dim", dim_g[:, live], c["dim"][:, live], scale=sl),
+            err("polar_bwd.dim(zero frames)", dim_g[:, ~live], c["dim"][:, ~live], tol=1e-3)]
+    dGo = t(to_kp(c["dre"].reshape(-1, F), c["dim"].reshape(-1, F), KP))
+    gWr, gWi = z(N, N), z(N, N)
+    norm_a = z(npart)
+    _lib.check(lib.st_analysis_wgrad(C.byref(d), _lib.ptr(dGo), _lib.ptr(x), 0.5, _lib.ptr(wsg), _lib.ptr(gWr), _lib.ptr(gWi),
+                                     _lib.ptr(norm_a), stream()), "an_wgrad")
+    sw = float(max(np.abs(G[STFT_KEYS[0]]).max(), np.abs(G[STFT_KEYS[1]]).max()))
+    res += [err("an_wgrad.gWr", n(gWr), G[STFT_KEYS[0]][:, 0], scale=sw), err("an_wgrad.gWi", n(gWi), G[STFT_KEYS[1]][:, 0], scale=sw),
+            err("an_wgrad.rows>=F", n(gWr)[F:], 0 * n(gWr)[F:], scale=1.0, tol=0.0)]
+    torch.cuda.synchronize()
+    return res
+
+
+def run_fused(B=3, seed=1, K=4, steps=3):
+    """Fused entry points: st_model_fwd, st_loss_backward, st_train_step x steps vs the oracle."""
+    geo, X, Y, KN, P = make_case(B, seed, K=K)
+    d = dims_of(geo, B, K)
+    eng = StepEngine(d, DEV)
+    eng.load_state_dict(P)
+    res = []
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    loss, G, c = O.model_loss_bwd(X.astype(np.float64), KN.astype(np.float64), Y.astype(np.float64), P64, geo)
+    y_hat, mag, mag_hat = eng.forward(t(X), t(KN))
+    res += [err("fwd.y_hat", n(y_hat), c["out"]), err("fwd.mag", n(mag), c["mag"]), err("fwd.mag_hat", n(mag_hat), c["mag_hat"])]
+    outs = eng.loss_backward(t(X), t(KN), t(Y), want_outputs=True)
+    sc = n(eng.scalars)
+    res += [err("step.y_hat", n(outs[0]), c["out"]), err("step.loss", sc[0], loss, tol=1e-4)]
+    g = eng.layout.views(eng.grads)
+    ss = {k: float(max(np.abs(G[a]).max(), np.abs(G[b]).max())) for k, (a, b) in
+          {"an": STFT_KEYS[:2], "sy": STFT_KEYS[2:]}.items()}
+    for k in eng.layout.names:
+        scale = ss["an"] if k in STFT_KEYS[:2] else ss["sy"] if k in STFT_KEYS[2:] else None
+        res.append(err("grad." + k.replace("mpaec.", ""), n(g[k]), G[k], tol=2e-4, scale=scale))
+    l1 = sum(np.abs(G[k]).sum() for k in STFT_KEYS)
+    res.append(err("step.l1norm", sc[3], l1, tol=1e-3))
+    # training steps (train.py:131-151 ordering) vs oracle in float32 arithmetic
+    eng2 = StepEngine(d, DEV); eng2.load_state_dict(P)
+    Pq = {k: P[k].copy() for k in O.param_order()}
+    Mq = {k: np.zeros_like(v) for k, v in Pq.items()}; Vq = {k: np.zeros_like(v) for k, v in Pq.items()}
+    lrs, _ = O.get_1cycle_schedule(lr_max=1e-3, n_data_points=200, epochs=1, batch_size=2)
+    lr = lrs[0]
+    for it in range(steps):
+        Xi = np.roll(X, 17 * it, axis=1).copy(); Yi = np.roll(Y, 17 * it, axis=1).copy()
+        eng2.train_step(t(Xi), t(KN), t(Yi), lr)
+        lo, no, co = O.train_step(Xi, KN, Yi, Pq, Mq, Vq, it + 1, lr, geo)
+        lr = lrs[it]
+        res.append(err(f"train{it}.loss", n(eng2.scalars)[0], lo, tol=1e-4))
+        worst = max((err(k, n(v), Pq[k], scale=1.0, tol=2e-5) for k, v in eng2.named.items()), key=lambda r: r["err"])
+        worst["name"] = f"train{it}.params(worst:{worst['name'].replace('mpaec.', '')})"
+        res.append(worst)
+    torch.cuda.synchronize()
+    return res
+
+
+def report(res, out=print):
+    bad = 0
+    for r in res:
+        flag = "ok " if r["ok"] else "BAD"
+        bad += not r["ok"]
+        out(f"{flag} {r['name']:44s} err={r['err']:.3e} scale={r['scale']:.3e} rel={r['rel']:.2e} tol={r['tol']:.0e}"
+            + ("" if r["ok"] else f"  worst@{r['worst']} got={r['got']:.6g} ref={r['ref']:.6g}"))
+    return bad
