@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- SignalTrain train-step throughput on MI355X (driver contract, see DESIGN.md 'Measurement').
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload = BASELINE.json configs[1]: comp_4c synthetic, 8192-sample windows, batch 256 per GPU, fp32
+(weak scaling: global batch 256*N).  One step = forward + calc_loss + backward + L1 clip + Adam
+[+ RCCL all-reduce of the 16.8 MB gradient], inputs resident in HBM.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_FP32_MFMA_TF = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense fp32
+METRIC = "audio-frames/sec (train step) comp_4c 8192-sample windows @ 1/2/4/8 GPUs"
+
+
+def algorithmic_flops(d):
+    """SURVEY.md 8(d) 'useful-dense' convention, per launch of each GEMM-shaped kernel (1 MAC = 2 FLOP)."""
+    B, T, OT, F, N, K = d.B, d.T, d.OT, d.F, d.N, d.K
+    ae_mac = 64 * T + 32 * 64 + 16 * 32 + 16 * 16 + 16 * (16 + K) + 16 * 16 + 32 * 16 + 64 * 32 + OT * 64
+    an = 2.0 * B * T * (2 * F) * N
+    sy = 2.0 * B * OT * (2 * F) * N              # Hermitian-folded: 9.46 M MAC/window at the default geometry
+    ae = 2.0 * B * F * 2 * ae_mac
+    return {"analysis_fwd": an, "analysis_wgrad": an, "synthesis_frames": sy, "synthesis_dgrad": sy,
+            "synthesis_wgrad": sy, "ae_fwd": ae, "ae_bwd": 2 * ae}, (2 * an + 3 * sy + 3 * ae)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="windows per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run for N>1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (there is no CPU fallback of the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from signaltrain_amd import _lib, nn_proc, audio, datasets, learningrate
+    from signaltrain_amd.engine import StepEngine
+    from signaltrain_amd.dp import DataParallel
+    nn_proc._QUIET = True
+
+    B = args.batch
+    d = _lib.geometry(1, 4, 4, B)
+    # identical init on every rank (run_train.py:20-21 seeds 218), distinct data per rank
+    torch.manual_seed(218); np.random.seed(218)
+    model = nn_proc.st_model(scale_factor=1, shrink_factor=4, num_knobs=4)
+    eng = StepEngine(d, dev)
+    eng.load_state_dict(model.state_dict())
+    dp = DataParallel(eng)
+    dp.broadcast_parameters()
+    np.random.seed(218 + 1000 * (rank + 1))
+    ds = datasets.SynthAudioDataSet(d.L, audio.Compressor_4c(), y_size=d.y, augment=True)
+    X, Y, KN = ds.batch(B)
+    x, y, kn = (torch.from_numpy(a).to(dev) for a in (X, Y, KN))
+    lrs, _ = learningrate.get_1cycle_schedule(lr_max=1e-4, n_data_points=200000, epochs=100, batch_size=B * world)
+
+    def step(i):
+        dp.train_step(x, kn, y, float(lrs[max(i - 1, 0)]))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss = dp.mean_loss()
+    ms = dt / args.steps * 1e3
+    windows_s = B * world / (ms * 1e-3)
+
+    out = None
+    if rank == 0:
+        flops_k, flops_step = algorithmic_flops(d)
+        out = {"metric": METRIC, "value": windows_s * d.T, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "comp_4c synthetic, 8192-sample windows, batch 256/GPU, fp32 (BASELINE configs[1])",
+                          "window": d.L, "frames_per_window": d.T, "global_batch": B * world, "parallelism": f"dp{world}"},
+               "windows_per_s": windows_s, "samples_per_s": windows_s * d.L, "loss": loss,
+               "step_tflops": flops_step / (ms * 1e-3) / 1e12 * world,
+               "step_frac_of_fp32_mfma_peak": flops_step / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TF}
+
+    # ------------------------------------------------------------------ roofline leg (outside the timed region)
+    if not args.no_roofline:
+        lib = eng.lib
+        _lib.check(lib.st_profile_enable(1), "profile_enable")
+        nprof = min(args.steps, 20)
+        for i in range(nprof):
+            eng.loss_backward(x, kn, y)          # same kernels as the step; events recorded on the launch stream
+        torch.cuda.synchronize()
+        buf = C.create_string_buffer(1 << 16)
+        _lib.check(lib.st_profile_report(buf, len(buf)), "profile_report")
+        lib.st_profile_enable(0)
+        if rank == 0:
+            rows = {}
+            for line in buf.value.decode().strip().splitlines():
+                name, tot, cnt = line.split()
+                rows[name] = (float(tot) / int(cnt), int(cnt))
+            kern = {k: {"avg_us": v[0] * 1e3, "launches": v[1],
+                        **({"tflops": flops_k[k] / (v[0] * 1e-3) / 1e12} if k in flops_k else {})} for k, v in rows.items()}
+            dom = max((k for k in rows if k in flops_k), key=lambda k: rows[k][0])
+            ach = flops_k[dom] / (rows[dom][0] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_FP32_MFMA_TF, "traffic": None,
+                               "algorithmic_flops_per_launch": flops_k[dom], "avg_launch_us": rows[dom][0] * 1e3}
+            out["kernels"] = kern
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only, bounded)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.torch_cpu_step import CpuPort          # checker-side code: timed beside, never the product path
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        Bc = 32
+        port = CpuPort({k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
+        xc, yc, kc = (torch.from_numpy(a[:Bc].copy()) for a in (X, Y, KN))
+        for _ in range(2):
+            port.step(xc, kc, yc, 1e-5)
+        n, t1 = 0, time.perf_counter()
+        while n < 40 and (time.perf_counter() - t1) < 15.0:
+            port.step(xc, kc, yc, 1e-5); n += 1
+        tc = (time.perf_counter() - t1) / max(n, 1)
+        out["cpu_baseline"] = {"value": Bc * d.T / tc, "unit": "frames/s", "cores": cores, "kind": "port",
+                               "sample": f"{n} train steps of batch {Bc} (BASELINE configs[0] shape), same comp_4c windows, fp32, "
+                                         f"PyTorch-CPU restatement of the reference op sequence, {torch.get_num_threads()} threads",
+                               "ms_per_step": tc * 1e3, "windows_per_s": Bc / tc}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

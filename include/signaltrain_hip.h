@@ -44,6 +44,12 @@ int st_kp(int F);
 const char* st_last_error(void);
 int st_version(void);
 
+/* Optional per-kernel HIP-event profiling of the fused entry points (off by default; used by
+ * bench.py's roofline leg outside the timed region).  st_profile_report fills buf with
+ * "kernel_name total_ms launches\n" lines; synchronise the stream first. */
+int st_profile_enable(int on);
+int st_profile_report(char* buf, int buflen);
+
 /* nn_proc.py:357-385 (st_model.__init__ geometry); lean scheme when legacy==0. Host only. */
 int st_geometry(double scale_factor, double shrink_factor, int legacy, int K, int B, st_dims* out);
 
@@ -141,6 +147,13 @@ int st_model_bwd(const st_dims* d, const float* params, float* grads, const floa
 int st_loss_backward(const st_dims* d, const float* params, float* grads, const float* x, const float* knobs,
                      const float* y_true, float* y_hat, float* mag, float* mag_hat, void* ws,
                      float* scalars, void* stream);
+
+/* Data-parallel split of st_loss_backward.  After p1 the gradients of the synthesis bases and both
+ * autoencoders (grads[offs[2]..end)) are final: all-reduce them while p2 computes the analysis
+ * weight gradient (rows [0,F) of tensors 0 and 1) and the loss scalars. */
+int st_loss_backward_p1(const st_dims* d, const float* params, float* grads, const float* x, const float* knobs,
+                        const float* y_true, void* ws, void* stream);
+int st_loss_backward_p2(const st_dims* d, float* grads, const float* x, void* ws, float* scalars, void* stream);
 
 /* Full single-GPU step: st_loss_backward + L1 clip + Adam (train.py:131-151). */
 int st_train_step(const st_dims* d, float* params, float* grads, float* m, float* v, const float* x,

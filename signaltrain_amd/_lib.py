@@ -31,6 +31,8 @@ SIGNATURES = {
     "st_kp": (_i, [_i]),
     "st_last_error": (C.c_char_p, []),
     "st_version": (_i, []),
+    "st_profile_enable": (_i, [_i]),
+    "st_profile_report": (_i, [C.c_char_p, _i]),
     "st_geometry": (_i, [C.c_double, C.c_double, _i, _i, _i, _D]),
     "st_param_offsets": (C.c_int64, [_D, C.POINTER(C.c_int64)]),
     "st_workspace_bytes": (C.c_size_t, [_D]),
@@ -54,6 +56,8 @@ SIGNATURES = {
     "st_model_fwd": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "st_model_bwd": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "st_loss_backward": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "st_loss_backward_p1": (_i, [_D, _p, _p, _p, _p, _p, _p, _p]),
+    "st_loss_backward_p2": (_i, [_D, _p, _p, _p, _p, _p]),
     "st_train_step": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _p]),
     "st_dp_clip_adam": (_i, [_D, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _i, _p]),
 }

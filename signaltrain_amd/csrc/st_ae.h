@@ -48,18 +48,29 @@ __host__ __device__ inline AELds ae_lds_layout(int T, int OT, int K)
     return L;
 }
 
-// Cooperative load of one autoencoder's parameters into LDS (zero padded).
+// Cooperative load of one autoencoder's parameters into LDS (zero padded): zero-fill, then a coalesced copy of
+// the packed global tensors with 8 independent loads in flight per thread (a dependent load->store loop costs
+// ~40 serialized L2 round trips per workgroup, i.e. tens of microseconds before the first MFMA).
 __device__ inline void ae_load_lds(float* lds, const AELds& L, const float* __restrict__ ae, const AEOffsets& go,
                                    int tid, int nthreads)
 {
+    for (int e = tid; e < L.total; e += nthreads) lds[e] = 0.f;
+    __syncthreads();
     for (int l = 0; l < NL; ++l) {
-        const int P = L.P[l], n = L.OUTp[l] * P;
-        for (int e = tid; e < n; e += nthreads) {
-            const int o = e / P, i = e - o * P;
-            lds[L.w[l] + e] = (o < L.OUT[l] && i < L.IN[l]) ? ae[go.w[l] + o * L.IN[l] + i] : 0.f;
+        const int P = L.P[l], IN = L.IN[l], n = L.OUT[l] * IN;
+        const float* src = ae + go.w[l];
+        float* dst = lds + L.w[l];
+        for (int e0 = tid; e0 < n; e0 += 8 * nthreads) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = e0 + u * nthreads; v[u] = src[e < n ? e : 0]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * nthreads;
+                if (e < n) { const int o = e / IN; dst[o * P + (e - o * IN)] = v[u]; }
+            }
         }
-        for (int e = tid; e < L.OUTp[l]; e += nthreads)
-            lds[L.b[l] + e] = (e < L.OUT[l]) ? ae[go.b[l] + e] : 0.f;
+        if (tid < L.OUT[l]) lds[L.b[l] + tid] = ae[go.b[l] + tid];
     }
 }
 
@@ -93,8 +104,35 @@ __device__ __forceinline__ void layer_fwd(const float* const (&W)[NC], const flo
 }
 
 // ------------------------------------------------------------------------------------------ forward
+// Per-group inputs of one lane: layer-1 B operands (t = 4*ks + g, ks < 8 -> T <= 32) and the skip/residual
+// tails (t = T-OT + 4g + r, OT <= 16).  Loaded in one burst and prefetched one group ahead.
+struct FwdIn { float v[2][8]; float tl[2][4]; };
+
+__device__ __forceinline__ void fwd_load(FwdIn& in, const float* __restrict__ mag, const float* __restrict__ phs,
+                                         const int b, const int f, const bool fv, const int T, const int OT, const int F, const int g)
+{
+    const size_t base = (size_t)b * T * F + (fv ? f : 0);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const int t = 4 * ks + g;
+        const bool ok = fv && t < T;
+        const size_t o = base + (size_t)(ok ? t : 0) * F;
+        const float a = mag[o], p = phs[o];
+        in.v[0][ks] = ok ? a : 0.f; in.v[1][ks] = ok ? p : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int to = 4 * g + r;
+        const bool ok = fv && to < OT;
+        const size_t o = base + (size_t)(ok ? T - OT + to : 0) * F;
+        const float a = mag[o], p = phs[o];
+        in.tl[0][r] = ok ? a : 0.f; in.tl[1][r] = ok ? p : 0.f;
+    }
+}
+
 // grid.x workgroups of NW waves; each wave walks 16-row groups: group id = b*(FP/16) + fg.
-template <int NW>
+// FAST = true requires T <= 32 and OT <= 16 (register-prefetched inputs); FAST = false is the generic path.
+template <int NW, bool FAST>
 __global__ void __launch_bounds__(NW * 64)
 ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, const float* __restrict__ knobs,
               const float* __restrict__ ae_m, const float* __restrict__ ae_p, const AEOffsets go,
@@ -116,15 +154,30 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     const int KS1 = (T + 3) / 4;
     const int KQ = (K + 3) / 4;
     const int OT9 = (OT + 15) / 16;
+    const int gstride = gridDim.x * NW;
     float reg = 0.f;
 
-    for (int grp = blockIdx.x * NW + wave; grp < ngroups; grp += gridDim.x * NW) {
+    FwdIn cur;
+    int grp = blockIdx.x * NW + wave;
+    if (FAST && grp < ngroups) {
+        const int b = grp / gpw, f = (grp - b * gpw) * 16 + c;
+        fwd_load(cur, mag, phs, b, f, f < F, T, OT, F, g);
+    }
+    for (; grp < ngroups; grp += gstride) {
         asm volatile("" ::: "memory");      // keep the (loop-invariant) LDS weight fetches inside the loop: hoisting them spills
         const int b = grp / gpw, f = (grp - b * gpw) * 16 + c;
         const bool fv = f < F;
         const float* src[2] = {mag + (size_t)b * T * F + f, phs + (size_t)b * T * F + f};
+        FwdIn nxt;
+        if (FAST) {
+            const int gn = grp + gstride;
+            if (gn < ngroups) {
+                const int bn = gn / gpw, fn = (gn - bn * gpw) * 16 + c;
+                fwd_load(nxt, mag, phs, bn, fn, fn < F, T, OT, F, g);
+            }
+        }
 
-        // ---- layer 1 (IN = T, runtime k-steps; B operand straight from global: t = 4*ks + g)
+        // ---- layer 1 (IN = T; B operand: t = 4*ks + g)
         f32x4 h1[2][4];
         {
             f32x4 acc[2][4];
@@ -133,19 +186,31 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
 #pragma unroll
                 for (int ot = 0; ot < 4; ++ot) acc[ch][ot] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int P1 = L.P[0];
-            for (int ks = 0; ks < KS1; ++ks) {
-                const int t = 4 * ks + g;
-                const bool ok = fv && t < T;
-                float v[2];
-                v[0] = ok ? src[0][(size_t)t * F] : 0.f;
-                v[1] = ok ? src[1][(size_t)t * F] : 0.f;
+            if (FAST) {
 #pragma unroll
-                for (int ot = 0; ot < 4; ++ot)
+                for (int ks = 0; ks < 8; ++ks) {
+                    if (ks < KS1) {
+                        const int t = 4 * ks + g;
 #pragma unroll
-                    for (int ch = 0; ch < 2; ++ch) {
-                        const float a = lw[ch][L.w[0] + (16 * ot + c) * P1 + t];
-                        acc[ch][ot] = ST_MFMA16(a, v[ch], acc[ch][ot]);
+                        for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+                            for (int ch = 0; ch < 2; ++ch)
+                                acc[ch][ot] = ST_MFMA16(lw[ch][L.w[0] + (16 * ot + c) * P1 + t], cur.v[ch][ks], acc[ch][ot]);
                     }
+                }
+            } else {
+                for (int ks = 0; ks < KS1; ++ks) {
+                    const int t = 4 * ks + g;
+                    const bool ok = fv && t < T;
+                    float v[2];
+                    v[0] = ok ? src[0][(size_t)t * F] : 0.f;
+                    v[1] = ok ? src[1][(size_t)t * F] : 0.f;
+#pragma unroll
+                    for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+                        for (int ch = 0; ch < 2; ++ch)
+                            acc[ch][ot] = ST_MFMA16(lw[ch][L.w[0] + (16 * ot + c) * P1 + t], v[ch], acc[ch][ot]);
+                }
             }
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch)
@@ -222,8 +287,10 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
                     float mh = 0.f, ph = 0.f, sn = 0.f, cs = 1.f;
                     if (fv) {
                         const size_t ti = (size_t)(T - OT + to) * F;
-                        mh = e9[0][0][r] * src[0][ti];                 // 'sf' skip-filter
-                        ph = e9[1][0][r] + src[1][ti];                 // phase residual
+                        const float mt = FAST ? cur.tl[0][r] : src[0][ti];
+                        const float pt = FAST ? cur.tl[1][r] : src[1][ti];
+                        mh = e9[0][0][r] * mt;                         // 'sf' skip-filter
+                        ph = e9[1][0][r] + pt;                         // phase residual
                         sincosf(ph, &sn, &cs);
                         mag_hat[ro * F + f] = mh;
                         phs_hat[ro * F + f] = ph;
@@ -234,13 +301,13 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
                 }
             }
         }
+        if (FAST) cur = nxt;
     }
     if (reg_partial) {
         reg = wave_sum(reg);
         if (lane == 0) reg_partial[blockIdx.x * NW + wave] = reg;
     }
 }
-
 
 // ========================================================================================== backward
 // One workgroup = NW waves, 1 wave per SIMD (the wave owns up to 512 registers).  blockIdx.y selects the
@@ -371,7 +438,8 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
               const float* __restrict__ mag_hat, const float* __restrict__ phs_hat, const float* __restrict__ dAA,
               const float* __restrict__ g_mag_hat, const float reg_coef, const float expfac,
               float* __restrict__ dmag, float* __restrict__ dphs, float* __restrict__ ws,
-              const int B, const int T, const int OT, const int F, const int K, const int KP)
+              const int B, const int T, const int OT, const int F, const int K, const int KP,
+              const int to_lo, const int to_hi)      // live synthesis frames: dAA rows outside are treated as zero
 {
     constexpr int NC = 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -395,7 +463,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     float* dvout = ae ? dphs : dmag;
     const int FP = KP / 2, gpw = FP / 16;
     const int ngroups = B * gpw, npairs = (ngroups + 1) / 2;
-    const int KS1 = (T + 3) / 4, KQ = (K + 3) / 4;
+    const int KS1 = (T + 3) / 4;
 
     // persistent weight-gradient accumulators (144 regs) + 9 bias-gradient registers
     f32x4 dW1[4][2], dW2[2][4], dW3[1][2], dW4[1][1], dW5[1][2], dW6[1][1], dW7[2][1], dW8[4][2], dW9[1][4];
@@ -431,20 +499,27 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
 #pragma unroll
                 for (int ot = 0; ot < 4; ++ot) acc[ch][ot] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int P1 = L.P[0];
-            for (int ks = 0; ks < 8; ++ks) {              // 8 k-steps cover the 32 padded input features
-                const int t = 4 * ks + g;
-                float v[NC];
+            float vr[NC][8];                              // burst-load all inputs first (8 k-steps = 32 padded features)
 #pragma unroll
-                for (int ch = 0; ch < NC; ++ch) {
-                    v[ch] = (fv[ch] && t < T) ? vin[((size_t)bb[ch] * T + t) * F + ff[ch]] : 0.f;
-                    Vs[ch][t * SP + c] = v[ch];           // [feat = t][row = c] for the layer-1 weight gradient
+            for (int ch = 0; ch < NC; ++ch)
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int t = 4 * ks + g;
+                    const bool ok = fv[ch] && t < T;
+                    const float x = vin[((size_t)bb[ch] * T + (ok ? t : 0)) * F + (fv[ch] ? ff[ch] : 0)];
+                    vr[ch][ks] = ok ? x : 0.f;
                 }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int t = 4 * ks + g;
+#pragma unroll
+                for (int ch = 0; ch < NC; ++ch) Vs[ch][t * SP + c] = vr[ch][ks];   // [feat = t][row = c] for the layer-1 weight gradient
                 if (ks < KS1) {
 #pragma unroll
                     for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
                         for (int ch = 0; ch < NC; ++ch)
-                            acc[ch][ot] = ST_MFMA16(Wl[0][(16 * ot + c) * P1 + t], v[ch], acc[ch][ot]);
+                            acc[ch][ot] = ST_MFMA16(Wl[0][(16 * ot + c) * P1 + t], vr[ch][ks], acc[ch][ot]);
                 }
             }
 #pragma unroll
@@ -466,6 +541,23 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             const float* const W[NC] = {Wl[3], Wl[3]}; const float* const bs[NC] = {Bl[3], Bl[3]};
             layer_fwd<NC, 1, 1>(W, bs, L.P[3], h3, h4, g, c);
         }
+        // d-out inputs (needed after the forward recompute): issue the loads now so they land under layers 5..9
+        float q_gre[NC][4], q_gim[NC][4], q_ph[NC][4], q_mh[NC][4], q_mt[NC][4];
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int to = 4 * g + r;
+                const bool ok = fv[ch] && to < OT;
+                const bool lv = ok && to >= to_lo && to <= to_hi;
+                const size_t ro = (size_t)bb[ch] * OT + (ok ? to : 0);
+                const int fq = fv[ch] ? ff[ch] : 0;
+                const float a0 = dAA[(lv ? ro : 0) * KP + fq], a1 = dAA[(lv ? ro : 0) * KP + FP + fq];
+                const float a2 = phs_hat[ro * F + fq], a3 = mag_hat[ro * F + fq];
+                const float a4 = vin[((size_t)bb[ch] * T + (ok ? T - OT + to : 0)) * F + fq];
+                q_gre[ch][r] = lv ? a0 : 0.f; q_gim[ch][r] = lv ? a1 : 0.f;
+                q_ph[ch][r] = a2; q_mh[ch][r] = a3; q_mt[ch][r] = a4;
+            }
         {
             f32x4 acc[NC];
             const int P5 = L.P[4];
@@ -520,14 +612,14 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
                 float d9 = 0.f, tail = 0.f;
                 if (fv[ch] && to < OT) {
                     const size_t ro = (size_t)bb[ch] * OT + to;
-                    const float gre = dAA[ro * KP + ff[ch]], gim = dAA[ro * KP + FP + ff[ch]];
-                    const float ph = phs_hat[ro * F + ff[ch]], mh = mag_hat[ro * F + ff[ch]];
+                    const float gre = q_gre[ch][r], gim = q_gim[ch][r];
+                    const float ph = q_ph[ch][r], mh = q_mh[ch][r];
                     float sn, cs; sincosf(ph, &sn, &cs);
                     if (ae == 0) {
                         const float sg = mh > 0.f ? 1.f : (mh < 0.f ? -1.f : 0.f);
                         float dmh = gre * cs + gim * sn + reg_coef * sg * wf;
                         if (g_mag_hat) dmh += g_mag_hat[ro * F + ff[ch]];   // generic upstream gradient (autograd path)
-                        const float mt = vin[((size_t)bb[ch] * T + (T - OT + to)) * F + ff[ch]];
+                        const float mt = q_mt[ch][r];
                         d9 = dmh * mt * elu_grad_from_out(e9[ch][0][r]);
                         tail = dmh * e9[ch][0][r];
                     } else {

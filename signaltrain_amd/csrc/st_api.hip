@@ -23,10 +23,57 @@ int st_check_launch(const char* what)
     if (e != hipSuccess) return st_fail(ST_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
     return ST_OK;
 }
+static void prof_mark(const char* name, void* stream);
+#define ST_LAUNCHED(what) do { int rc_ = st_check_launch(what); if (rc_ != ST_OK) return rc_; prof_mark(what, stream); } while (0)
 #define ST_TRY(x) do { int rc_ = (x); if (rc_ != ST_OK) return rc_; } while (0)
 #define ST_REQ(cond, ...) do { if (!(cond)) return st_fail(ST_ERR_ARG, __VA_ARGS__); } while (0)
 
 extern "C" const char* st_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------ optional event profiling
+// Off by default (zero overhead).  When enabled, every kernel launch of the library is followed by a
+// hipEventRecord on the launch stream; st_profile_report() turns consecutive events into per-kernel
+// durations.  Used by bench.py's roofline leg only -- never inside the timed region.
+#define ST_PROF_MAX 4096
+static bool g_prof = false;
+static int g_prof_n = 0;
+static hipEvent_t g_prof_ev[ST_PROF_MAX];
+static const char* g_prof_name[ST_PROF_MAX];
+static bool g_prof_init = false;
+static void prof_mark(const char* name, void* stream)
+{
+    if (!g_prof || g_prof_n >= ST_PROF_MAX) return;
+    (void)hipEventRecord(g_prof_ev[g_prof_n], st_stream(stream));
+    g_prof_name[g_prof_n++] = name;
+}
+extern "C" int st_profile_enable(int on)
+{
+    if (on && !g_prof_init) {
+        for (int i = 0; i < ST_PROF_MAX; ++i)
+            if (hipEventCreate(&g_prof_ev[i]) != hipSuccess) return st_fail(ST_ERR_LAUNCH, "hipEventCreate");
+        g_prof_init = true;
+    }
+    g_prof = on != 0; g_prof_n = 0;
+    return ST_OK;
+}
+// Writes "name total_ms count\n" lines (aggregated by kernel name) into buf; caller must have synchronised the stream.
+extern "C" int st_profile_report(char* buf, int buflen)
+{
+    if (!buf || buflen <= 0) return st_fail(ST_ERR_ARG, "st_profile_report: bad buffer");
+    const char* names[64]; double tot[64]; int cnt[64]; int nn = 0;
+    for (int i = 1; i < g_prof_n; ++i) {
+        if (!strcmp(g_prof_name[i], "begin")) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_prof_ev[i - 1], g_prof_ev[i]) != hipSuccess) continue;
+        int k = 0; for (; k < nn; ++k) if (!strcmp(names[k], g_prof_name[i])) break;
+        if (k == nn) { if (nn == 64) continue; names[nn] = g_prof_name[i]; tot[nn] = 0; cnt[nn] = 0; ++nn; }
+        tot[k] += ms; cnt[k]++;
+    }
+    int off = 0; buf[0] = 0;
+    for (int k = 0; k < nn; ++k) off += snprintf(buf + off, off < buflen ? buflen - off : 0, "%s %.6f %d\n", names[k], tot[k], cnt[k]);
+    g_prof_n = 0;
+    return ST_OK;
+}
 extern "C" int st_version(void) { return 100; }
 extern "C" int st_kp(int F) { return st_kp_of(F); }
 
@@ -98,7 +145,7 @@ static int make_layout(const st_dims* d, Layout* L)
 static int num_cus()
 {
     static int n = 0;
-    if (!n) { int dev = 0; hipGetDevice(&dev); hipDeviceProp_t p; if (hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount; if (n <= 0) n = 256; }
+    if (!n) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t p; if (hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount; if (n <= 0) n = 256; }
     return n;
 }
 static const int AE_FWD_NW = 8, AE_BWD_NW = 4;
@@ -125,12 +172,19 @@ extern "C" int st_analysis_fwd(const st_dims* d, const float* x, const float* Wr
                                float* re, float* im, float* mag, float* phs, void* stream)
 {
     ST_TRY(check_dims(d)); ST_REQ(x && Wr && Wi, "st_analysis_fwd: null input");
-    const int R = d->B * d->T;
-    stg::FramedNT al{x, d->L, d->T, d->H, d->N, R, d->N, in_scale};
+    const stg::RowMap map = stg::live_frames(d->T, d->H, d->N, d->N, d->L);   // frames entirely inside the Conv1d padding are skipped
+    const int R = map.rows(d->B);
+    stg::FramedNT al{x, d->L, d->H, d->N, R, d->N, in_scale, map};
     stg::AnalysisW bl{Wr, Wi, d->F, d->N};
-    stg::PolarStore ep{re, im, mag, phs, R, d->F};
+    stg::PolarStore ep{re, im, mag, phs, R, d->F, map};
     stg::launch<4>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream));
-    return st_check_launch("analysis_fwd");
+    ST_LAUNCHED("analysis_fwd");
+    if (map.Tv < d->T) {                   // ... and are exact zeros (re=im=mag=0, phs=atan2(0,1e-7)=0)
+        hipLaunchKernelGGL(stm::zero_dead_frames_kernel, dim3(d->B * (d->T - map.Tv)), dim3(256), 0, st_stream(stream),
+                           re, im, mag, phs, d->T, d->F, map.t_lo, map.Tv);
+        ST_LAUNCHED("zero_dead_frames");
+    }
+    return ST_OK;
 }
 
 extern "C" int st_ae_fwd(const st_dims* d, const float* mag, const float* phs, const float* knobs,
@@ -143,12 +197,21 @@ extern "C" int st_ae_fwd(const st_dims* d, const float* mag, const float* phs, c
     const size_t lds = (size_t)2 * ll.total * sizeof(float);
     ST_REQ(lds <= 160 * 1024, "st_ae_fwd: geometry needs %zu B of LDS (>160 KiB)", lds);
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_fwd_kernel<AE_FWD_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_fwd_kernel<AE_FWD_NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_fwd_kernel<AE_FWD_NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
     const float expfac = (float)(7.0 / d->F);
-    hipLaunchKernelGGL((sta::ae_fwd_kernel<AE_FWD_NW>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, st_stream(stream),
-                       mag, phs, knobs, ae_m, ae_p, L.go, mag_hat, phs_hat, AA, reg_partial,
-                       d->B, d->T, d->OT, d->F, d->K, L.KP, expfac);
-    return st_check_launch("ae_fwd");
+    if (d->T <= 32 && d->OT <= 16)
+        hipLaunchKernelGGL((sta::ae_fwd_kernel<AE_FWD_NW, true>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, st_stream(stream),
+                           mag, phs, knobs, ae_m, ae_p, L.go, mag_hat, phs_hat, AA, reg_partial,
+                           d->B, d->T, d->OT, d->F, d->K, L.KP, expfac);
+    else
+        hipLaunchKernelGGL((sta::ae_fwd_kernel<AE_FWD_NW, false>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, st_stream(stream),
+                           mag, phs, knobs, ae_m, ae_p, L.go, mag_hat, phs_hat, AA, reg_partial,
+                           d->B, d->T, d->OT, d->F, d->K, L.KP, expfac);
+    ST_LAUNCHED("ae_fwd"); return ST_OK;
 }
 
 extern "C" int st_synth_fold(const st_dims* d, const float* Sr, const float* Si, float* Sfold, void* stream)
@@ -156,60 +219,69 @@ extern "C" int st_synth_fold(const st_dims* d, const float* Sr, const float* Si,
     ST_TRY(check_dims(d)); ST_REQ(Sr && Si && Sfold, "st_synth_fold: null pointer");
     const int KP = st_kp_of(d->F);
     hipLaunchKernelGGL(stm::fold_kernel, dim3(KP), dim3(256), 0, st_stream(stream), Sr, Si, Sfold, d->N, d->F, KP);
-    return st_check_launch("synth_fold");
+    ST_LAUNCHED("synth_fold"); return ST_OK;
 }
+
+static stg::RowMap synth_live(const st_dims* d) { return stg::live_frames(d->OT, d->H, d->N, d->N, d->y); }
 
 extern "C" int st_synthesis_frames(const st_dims* d, const float* AA, const float* Sfold, float* frs, void* stream)
 {
     ST_TRY(check_dims(d)); ST_REQ(AA && Sfold && frs, "st_synthesis_frames: null pointer");
-    const int R = d->B * d->OT, KP = st_kp_of(d->F);
-    stg::PlainNT al{AA, R, KP, KP};
-    stg::PlainTN bl{Sfold, KP, d->N, d->N};
-    stg::StoreC ep{frs, R, d->N, d->N, 0};
+    const int KP = st_kp_of(d->F);
+    const stg::RowMap ms = synth_live(d);      // output frames that land wholly in the cropped margins are never needed
+    const int R = ms.rows(d->B);
+    stg::PlainNT al{AA, R, KP, KP, ms};
+    stg::PlainTN bl{Sfold, KP, d->N, d->N, stg::all_frames(1)};
+    stg::StoreC ep{frs, R, d->N, d->N, 0, ms};
     if (R >= 4096) stg::launch<4>(al, bl, ep, R, d->N, KP, 1, st_stream(stream));
     else stg::launch<2>(al, bl, ep, R, d->N, KP, 1, st_stream(stream));
-    return st_check_launch("synthesis_frames");
+    ST_LAUNCHED("synthesis_frames"); return ST_OK;
 }
 
 extern "C" int st_ola_loss(const st_dims* d, const float* frs, const float* x, const float* y_true,
                            float* y_hat, float* dsyn, float* loss_partial, void* stream)
 {
-    ST_TRY(check_dims(d)); ST_REQ(frs && x, "st_ola_loss: null pointer");
+    ST_TRY(check_dims(d)); ST_REQ(frs, "st_ola_loss: null pointer");
     const float inv = 1.0f / ((float)d->B * (float)d->y);
     hipLaunchKernelGGL(stm::ola_loss_kernel, dim3((d->y + 255) / 256, d->B), dim3(256), 0, st_stream(stream),
                        frs, x, y_true, y_hat, dsyn, loss_partial, d->L, d->N, d->H, d->OT, d->y, inv);
-    return st_check_launch("ola_loss");
+    ST_LAUNCHED("ola_loss"); return ST_OK;
 }
 
 extern "C" int st_synthesis_dgrad(const st_dims* d, const float* dsyn, const float* Sfold, float* dAA, void* stream)
 {
     ST_TRY(check_dims(d)); ST_REQ(dsyn && Sfold && dAA, "st_synthesis_dgrad: null pointer");
-    const int R = d->B * d->OT, KP = st_kp_of(d->F);
-    // dfrs[b,t,n] = dfull[b, H t + n] with dfull = zero-pad(dsyn, N each side)  == frames of dsyn with pad N
-    stg::FramedNT al{dsyn, d->y, d->OT, d->H, d->N, R, d->N, 1.0f};
-    stg::PlainNT bl{Sfold, KP, d->N, d->N};
-    stg::StoreC ep{dAA, R, KP, KP, 0};
+    const int KP = st_kp_of(d->F);
+    const stg::RowMap ms = synth_live(d);
+    const int R = ms.rows(d->B);
+    // dfrs[b,t,n] = dfull[b, H t + n] with dfull = zero-pad(dsyn, N each side)  == frames of dsyn with pad N.
+    // Rows of dAA for dead frames are NOT written (st_ae_bwd treats them as zero).
+    stg::FramedNT al{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms};
+    stg::PlainNT bl{Sfold, KP, d->N, d->N, stg::all_frames(1)};
+    stg::StoreC ep{dAA, R, KP, KP, 0, ms};
     if (R >= 4096) stg::launch<4>(al, bl, ep, R, KP, d->N, 1, st_stream(stream));
     else stg::launch<2>(al, bl, ep, R, KP, d->N, 1, st_stream(stream));
-    return st_check_launch("synthesis_dgrad");
+    ST_LAUNCHED("synthesis_dgrad"); return ST_OK;
 }
 
 extern "C" int st_synthesis_wgrad(const st_dims* d, const float* AA, const float* dsyn, float* ws,
                                   float* gSr, float* gSi, float* norm_partial, void* stream)
 {
     ST_TRY(check_dims(d)); ST_REQ(AA && dsyn && ws && gSr && gSi && norm_partial, "st_synthesis_wgrad: null pointer");
-    const int R = d->B * d->OT, KP = st_kp_of(d->F);
+    const int KP = st_kp_of(d->F);
+    const stg::RowMap ms = synth_live(d);
+    const int R = ms.rows(d->B);
     const int ns = wgrad_split(R);
-    stg::PlainTN al{AA, R, KP, KP};
-    stg::FramedTN bl{dsyn, d->y, d->OT, d->H, d->N, R, d->N, 1.0f};
-    stg::StoreC ep{ws, KP, d->N, d->N, (size_t)KP * d->N};
+    stg::PlainTN al{AA, R, KP, KP, ms};
+    stg::FramedTN bl{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms};
+    stg::StoreC ep{ws, KP, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
     stg::launch<3>(al, bl, ep, KP, d->N, R, ns, st_stream(stream));
-    ST_TRY(st_check_launch("synthesis_wgrad"));
+    ST_LAUNCHED("synthesis_wgrad");
     const int ksplit = st_round_up((R + ns - 1) / ns, stg::BK);
     const int nz = (R + ksplit - 1) / ksplit;
     hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(2 * d->F), dim3(256), 0, st_stream(stream),
                        ws, nz, gSr, gSi, norm_partial, d->N, d->F, KP, 1);
-    return st_check_launch("synthesis_wgrad_reduce");
+    ST_LAUNCHED("synthesis_wgrad_reduce"); return ST_OK;
 }
 
 extern "C" int st_ae_bwd(const st_dims* d, const float* mag, const float* phs, const float* knobs,
@@ -225,16 +297,16 @@ extern "C" int st_ae_bwd(const st_dims* d, const float* mag, const float* phs, c
     const size_t lds = ((size_t)ll.total + (size_t)AE_BWD_NW * 2 * (32 + 64 + 64 + 16) * sta::SP) * sizeof(float);
     ST_REQ(lds <= 160 * 1024, "st_ae_bwd: needs %zu B of LDS", lds);
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     const float expfac = (float)(7.0 / d->F);
     const int grid = ae_bwd_grid(d);
     hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, st_stream(stream),
                        mag, phs, knobs, ae_m, ae_p, L.go, L.PG, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, expfac,
-                       dmag, dphs, ws, d->B, d->T, d->OT, d->F, d->K, L.KP);
-    ST_TRY(st_check_launch("ae_bwd"));
+                       dmag, dphs, ws, d->B, d->T, d->OT, d->F, d->K, L.KP, synth_live(d).t_lo, synth_live(d).t_lo + synth_live(d).Tv - 1);
+    ST_LAUNCHED("ae_bwd");
     hipLaunchKernelGGL(stm::ae_grad_reduce_kernel, dim3((L.PG + 255) / 256, 2), dim3(256), 0, st_stream(stream),
                        ws, grid * AE_BWD_NW, L.PG, g_m, g_p);
-    return st_check_launch("ae_grad_reduce");
+    ST_LAUNCHED("ae_grad_reduce"); return ST_OK;
 }
 
 extern "C" int st_polar_bwd(const st_dims* d, const float* re, const float* im, const float* dmag, const float* dphs,
@@ -244,25 +316,27 @@ extern "C" int st_polar_bwd(const st_dims* d, const float* re, const float* im, 
     const int R = d->B * d->T, KP = st_kp_of(d->F);
     hipLaunchKernelGGL(stm::polar_bwd_kernel, dim3((KP / 2 + 255) / 256, R), dim3(256), 0, st_stream(stream),
                        re, im, dmag, dphs, g_mag, dG, R, d->F, KP);
-    return st_check_launch("polar_bwd");
+    ST_LAUNCHED("polar_bwd"); return ST_OK;
 }
 
 extern "C" int st_analysis_wgrad(const st_dims* d, const float* dG, const float* x, float in_scale, float* ws,
                                  float* gWr, float* gWi, float* norm_partial, void* stream)
 {
     ST_TRY(check_dims(d)); ST_REQ(dG && x && ws && gWr && gWi && norm_partial, "st_analysis_wgrad: null pointer");
-    const int R = d->B * d->T, KP = st_kp_of(d->F);
+    const int KP = st_kp_of(d->F);
+    const stg::RowMap ma = stg::live_frames(d->T, d->H, d->N, d->N, d->L);   // all-zero frames contribute nothing
+    const int R = ma.rows(d->B);
     const int ns = wgrad_split(R);
-    stg::PlainTN al{dG, R, KP, KP};
-    stg::FramedTN bl{x, d->L, d->T, d->H, d->N, R, d->N, in_scale};
-    stg::StoreC ep{ws, KP, d->N, d->N, (size_t)KP * d->N};
+    stg::PlainTN al{dG, R, KP, KP, ma};
+    stg::FramedTN bl{x, d->L, d->H, d->N, R, d->N, in_scale, ma};
+    stg::StoreC ep{ws, KP, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
     stg::launch<3>(al, bl, ep, KP, d->N, R, ns, st_stream(stream));
-    ST_TRY(st_check_launch("analysis_wgrad"));
+    ST_LAUNCHED("analysis_wgrad");
     const int ksplit = st_round_up((R + ns - 1) / ns, stg::BK);
     const int nz = (R + ksplit - 1) / ksplit;
     hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(2 * d->F), dim3(256), 0, st_stream(stream),
                        ws, nz, gWr, gWi, norm_partial, d->N, d->F, KP, 0);
-    return st_check_launch("analysis_wgrad_reduce");
+    ST_LAUNCHED("analysis_wgrad_reduce"); return ST_OK;
 }
 
 extern "C" int st_finalize_scalars(const st_dims* d, const float* loss_partial, const float* reg_partial,
@@ -274,7 +348,7 @@ extern "C" int st_finalize_scalars(const st_dims* d, const float* loss_partial, 
     hipLaunchKernelGGL(stm::finalize_kernel, dim3(1), dim3(256), 0, st_stream(stream),
                        loss_partial, st_ola_loss_partials(d), reg_partial, st_ae_fwd_partials(d),
                        norm_a, st_norm_partials(d), norm_s, st_norm_partials(d), inv_y, reg_scale, inv_world, scalars);
-    return st_check_launch("finalize_scalars");
+    ST_LAUNCHED("finalize_scalars"); return ST_OK;
 }
 
 extern "C" int st_clip_adam(float* params, float* grads, float* m, float* v, int64_t n_total, int64_t n_stft,
@@ -290,7 +364,7 @@ extern "C" int st_clip_adam(float* params, float* grads, float* m, float* v, int
     int grid = (int)((n_total / 4 + 255) / 256); if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(stm::clip_adam_kernel, dim3(grid), dim3(256), 0, st_stream(stream),
                        params, grads, m, v, n_total / 4, n_stft / 4, scalars, grad_scale, neg_step, w1, beta2, w2, bc2s, eps);
-    return st_check_launch("clip_adam");
+    ST_LAUNCHED("clip_adam"); return ST_OK;
 }
 
 // ------------------------------------------------------------------------------ workspace
@@ -341,9 +415,11 @@ static int forward_impl(const st_dims* d, const Layout& L, const float* params, 
     return ST_OK;
 }
 
-// backward of everything behind d syn (workspace holds the forward state): autograd of train.py:138
-static int backward_impl(const st_dims* d, const Layout& L, const float* params, float* grads, const float* x,
-                         const float* knobs, const float* g_mag_hat, const float* g_mag, float reg_coef, WS& w, void* stream)
+// backward of everything behind d syn (workspace holds the forward state): autograd of train.py:138.
+// phase 1 = synthesis dgrad/wgrad + autoencoders + polar backward (fills grads[n_stft/2 ..));
+// phase 2 = analysis weight gradient (fills rows [0,F) of the first two tensors).
+static int backward_p1(const st_dims* d, const Layout& L, const float* params, float* grads,
+                       const float* knobs, const float* g_mag_hat, const float* g_mag, float reg_coef, WS& w, void* stream)
 {
     const float* ae_m = params + L.offs[4]; const float* ae_p = params + L.offs[22];
     ST_TRY(st_synthesis_dgrad(d, w.dsyn, w.Sfold, w.dAA, stream));
@@ -351,8 +427,17 @@ static int backward_impl(const st_dims* d, const Layout& L, const float* params,
     ST_TRY(st_ae_bwd(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.dAA, g_mag_hat, reg_coef, w.dmag, w.dphs,
                      w.aews, grads + L.offs[4], grads + L.offs[22], stream));
     ST_TRY(st_polar_bwd(d, w.re, w.im, w.dmag, w.dphs, g_mag, w.dG, stream));
-    ST_TRY(st_analysis_wgrad(d, w.dG, x, 0.5f, w.wg, grads + L.offs[0], grads + L.offs[1], w.norm_a, stream));
     return ST_OK;
+}
+static int backward_p2(const st_dims* d, const Layout& L, float* grads, const float* x, WS& w, void* stream)
+{
+    return st_analysis_wgrad(d, w.dG, x, 0.5f, w.wg, grads + L.offs[0], grads + L.offs[1], w.norm_a, stream);
+}
+static int backward_impl(const st_dims* d, const Layout& L, const float* params, float* grads, const float* x,
+                         const float* knobs, const float* g_mag_hat, const float* g_mag, float reg_coef, WS& w, void* stream)
+{
+    ST_TRY(backward_p1(d, L, params, grads, knobs, g_mag_hat, g_mag, reg_coef, w, stream));
+    return backward_p2(d, L, grads, x, w, stream);
 }
 
 extern "C" int st_model_fwd(const st_dims* d, const float* params, const float* x, const float* knobs,
@@ -372,7 +457,7 @@ extern "C" int st_model_bwd(const st_dims* d, const float* params, float* grads,
     WS w; carve(d, ws, &w);
     const int64_t n = (int64_t)d->B * d->y;
     hipLaunchKernelGGL(stm::scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st_stream(stream), g_y_hat, w.dsyn, n, 2.0f);
-    ST_TRY(st_check_launch("scale(dsyn)"));
+    ST_LAUNCHED("scale(dsyn)");
     return backward_impl(d, L, params, grads, x, knobs, g_mag_hat, g_mag, 0.0f, w, stream);
 }
 
@@ -383,11 +468,34 @@ extern "C" int st_loss_backward(const st_dims* d, const float* params, float* gr
     Layout L; ST_TRY(make_layout(d, &L));
     ST_REQ(params && grads && x && knobs && y_true && ws && scalars, "st_loss_backward: null pointer");
     WS w; carve(d, ws, &w);
+    prof_mark("begin", stream);
     ST_TRY(forward_impl(d, L, params, x, knobs, y_true, y_hat, mag, mag_hat, w, true, stream));
     const float reg_coef = (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);   // loss_functions.py:36
     ST_TRY(backward_impl(d, L, params, grads, x, knobs, nullptr, nullptr, reg_coef, w, stream));
     ST_TRY(st_finalize_scalars(d, w.loss_p, w.reg_p, w.norm_a, w.norm_s, 1.0f, scalars, stream));
     return ST_OK;
+}
+
+// Data-parallel split of st_loss_backward: after phase 1 the synthesis + autoencoder gradients
+// (grads[offs[2] ..)) are final and can be all-reduced while phase 2 (analysis wgrad) runs.
+extern "C" int st_loss_backward_p1(const st_dims* d, const float* params, float* grads, const float* x, const float* knobs,
+                                   const float* y_true, void* ws, void* stream)
+{
+    Layout L; ST_TRY(make_layout(d, &L));
+    ST_REQ(params && grads && x && knobs && y_true && ws, "st_loss_backward_p1: null pointer");
+    WS w; carve(d, ws, &w);
+    prof_mark("begin", stream);
+    ST_TRY(forward_impl(d, L, params, x, knobs, y_true, nullptr, nullptr, nullptr, w, true, stream));
+    const float reg_coef = (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);
+    return backward_p1(d, L, params, grads, knobs, nullptr, nullptr, reg_coef, w, stream);
+}
+extern "C" int st_loss_backward_p2(const st_dims* d, float* grads, const float* x, void* ws, float* scalars, void* stream)
+{
+    Layout L; ST_TRY(make_layout(d, &L));
+    ST_REQ(grads && x && ws && scalars, "st_loss_backward_p2: null pointer");
+    WS w; carve(d, ws, &w);
+    ST_TRY(backward_p2(d, L, grads, x, w, stream));
+    return st_finalize_scalars(d, w.loss_p, w.reg_p, w.norm_a, w.norm_s, 1.0f, scalars, stream);
 }
 
 extern "C" int st_train_step(const st_dims* d, float* params, float* grads, float* m, float* v, const float* x,
@@ -410,10 +518,10 @@ extern "C" int st_dp_clip_adam(const st_dims* d, float* params, float* grads, fl
     const int np = st_norm_partials(d);
     hipLaunchKernelGGL(stm::l1_partial_kernel, dim3(np), dim3(256), 0, st_stream(stream),
                        grads, L.n_stft, grad_scale, w.norm_a);
-    ST_TRY(st_check_launch("l1_partial"));
+    ST_LAUNCHED("l1_partial");
     hipLaunchKernelGGL(stm::finalize_kernel, dim3(1), dim3(256), 0, st_stream(stream),
                        (const float*)nullptr, 0, (const float*)nullptr, 0, (const float*)w.norm_a, np, (const float*)nullptr, 0,
                        0.f, 0.f, 1.0f, scalars);
-    ST_TRY(st_check_launch("finalize(dp)"));
+    ST_LAUNCHED("finalize(dp)");
     return st_clip_adam(params, grads, m, v, L.total, L.n_stft, scalars, grad_scale, lr, beta1, beta2, eps, step, stream);
 }

@@ -8,11 +8,22 @@
 // 32 x 96 output strip = 3 accumulators of v_mfma_f32_32x32x2_f32 (exact fp32, 64 cyc/issue ==
 // dependent latency, so 3 independent accumulators keep the pipe full).  BN = 96 because the
 // spectral width is 2*513 = 1026 = 10.7 * 96 (11 tiles, 2.8 % pad) whereas 128-wide tiles
-// would waste 12.5 % on the Nyquist bin.  BK = 32.  Operand tiles are staged k-major in LDS
-// (As[k][m], Bs[k][n]) so that an MFMA operand fetch is one conflict-free ds_read_b32 per lane
-// (lanes 0-31 / 32-63 read two consecutive k rows).  fp32 MFMA is so slow relative to LDS/L2
-// (64 cycles per 32x32x2) that register-staged double buffering with one barrier per k-tile is
-// sufficient: 64 MFMA-issue cycles x 48 per wave per barrier.
+// would waste 12.5 % on the Nyquist bin.  BK = 32.
+//
+// LDS staging, two layouts chosen by how the operand lies in memory:
+//  * "NT" operand (memory contiguous along k): row-major tile Xs[row][36]; a global float4 becomes
+//    ONE ds_write_b128 and the wave's MFMA fragments for the whole k-tile are 4 ds_read_b128 per
+//    32-row block (lane (m, h) takes k = 16h..16h+15: the reduction order inside a tile is free,
+//    A and B only have to agree).  Pitch 36 floats keeps both conflict-free.
+//  * "TN" operand (memory contiguous along m/n): k-major tile Xs[k][rows+4], ds_write_b128 in,
+//    one ds_read_b32 per MFMA operand out.
+// Global loads are branch-free (clamped pointer + select) so all 7-10 loads of the next k-tile are
+// in flight while the current tile's 48 MFMAs per wave run; scaling (x/2, nn_proc.py:307) is applied
+// at the LDS store so no load result is touched early.
+//
+// Zero-padding frames (frames that lie completely in the Conv1d padding / in the cropped margins of
+// the transposed conv) are never computed: the framed loaders enumerate only the live frames of each
+// window (RowMap) -- 23 of 25 analysis frames, 7 of 9 synthesis frames at the default geometry.
 #pragma once
 #include "st_common.h"
 
@@ -21,28 +32,45 @@ namespace stg {
 constexpr int BK = 32;
 constexpr int BN = 96;
 constexpr int NJ = BN / 32;   // MFMA column tiles per wave
+constexpr int PK = BK + 4;    // row pitch (floats) of an NT tile in LDS
 
-// ------------------------------------------------------------------------------ loaders
-// "NT-type" operand: memory is contiguous along the reduction index k.
-//   RowState row_state(row)        -- per output row/col, computed once per thread
-//   float4   load(st, k)           -- 4 consecutive k (k % 4 == 0); zero outside [lo,hi)
-// "TN-type" operand: memory is contiguous along the non-reduction index.
-//   float4   load(k, col)          -- 4 consecutive cols at reduction index k
+// Compact row index r' (live frames only) -> (window b, frame t); full row = b*T + t.
+struct RowMap {
+    int Tv, t_lo, T;
+    __host__ __device__ int rows(int B) const { return B * Tv; }
+    __device__ void split(int r, int& b, int& t) const { b = r / Tv; t = t_lo + (r - b * Tv); }
+    __device__ int full(int r) const { int b, t; split(r, b, t); return b * T + t; }
+};
+// Frames t with a non-empty intersection [H t - pad, H t - pad + N) x [0, Ls)
+static inline RowMap live_frames(int T, int H, int N, int pad, int Ls)
+{
+    int lo = 0, hi = T - 1;
+    while (lo < T && H * lo - pad + N <= 0) ++lo;
+    while (hi >= lo && H * hi - pad >= Ls) --hi;
+    RowMap m; m.t_lo = lo; m.Tv = hi - lo + 1; m.T = T;
+    if (m.Tv <= 0) { m.Tv = T; m.t_lo = 0; }
+    return m;
+}
+static inline RowMap all_frames(int T) { RowMap m; m.Tv = T; m.t_lo = 0; m.T = T; return m; }
+
+struct Src { const float* p; bool ok; };
 
 struct RowState {
     const float* p;   // element k of this row lives at p[k] (only dereferenced for lo <= k < hi)
     int lo, hi;
 };
 
-// Rows = overlapped frames of a batch of signals: row r = (b, t), element k = sig[b, H*t - pad + k].
+// ------------------------------------------------------------------------------ loaders
+// Rows = overlapped frames of a batch of signals: compact row r -> (b, t), element k = sig[b, H*t - pad + k].
 // Replaces Conv1d's implicit im2col (cls_fe_dft.py:55-56) and the framed operand of every backward GEMM.
 struct FramedNT {
     static constexpr bool kTN = false;
-    const float* sig; int Ls, T, H, pad, R, Kw; float scale;
+    const float* sig; int Ls, H, pad, R, Kw; float scale; RowMap map;
+    __device__ const float* dummy() const { return sig; }
     __device__ RowState row_state(int r) const {
         RowState s; s.p = sig; s.lo = 0; s.hi = 0;
         if (r < R) {
-            const int b = r / T, t = r - b * T;
+            int b, t; map.split(r, b, t);
             const int start = H * t - pad;                 // frame start in the unpadded signal (bit-exact contract)
             s.p = sig + (size_t)b * Ls + start;
             s.lo = start < 0 ? -start : 0;
@@ -51,58 +79,52 @@ struct FramedNT {
         }
         return s;
     }
-    __device__ float4 load(const RowState& s, int k) const {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k >= s.lo && k < s.hi) {
-            v = *reinterpret_cast<const float4*>(s.p + k);
-            v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
-        }
-        return v;
-    }
+    __device__ Src src(const RowState& s, int k) const { return Src{s.p + k, k >= s.lo && k < s.hi}; }
+    __device__ float4 post(float4 v) const { v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; return v; }
 };
 
-// Same frames, TN-type (reduction index = frame row r, contiguous along the tap n).
+// Same frames, TN-type (reduction index = compact frame row r, contiguous along the tap n).
 struct FramedTN {
     static constexpr bool kTN = true;
-    const float* sig; int Ls, T, H, pad, R, Kw; float scale;
-    __device__ float4 load(int r, int n) const {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* sig; int Ls, H, pad, R, Kw; float scale; RowMap map;
+    __device__ const float* dummy() const { return sig; }
+    __device__ Src src(int r, int n) const {
+        Src s{sig, false};
         if (r < R && n < Kw) {
-            const int b = r / T, t = r - b * T;
+            int b, t; map.split(r, b, t);
             const int pos = H * t - pad + n;
-            if (pos >= 0 && pos < Ls) {
-                v = *reinterpret_cast<const float4*>(sig + (size_t)b * Ls + pos);
-                v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
-            }
+            s.ok = pos >= 0 && pos < Ls;
+            s.p = sig + (size_t)b * Ls + pos;
         }
-        return v;
-    }
-};
-
-// Dense row-major [rows][ld] matrix, reduction along the row (NT-type).
-struct PlainNT {
-    static constexpr bool kTN = false;
-    const float* base; int rows, ld, K;
-    __device__ RowState row_state(int r) const {
-        RowState s; s.p = base + (size_t)(r < rows ? r : 0) * ld; s.lo = 0; s.hi = (r < rows) ? K : 0;
         return s;
     }
-    __device__ float4 load(const RowState& s, int k) const {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < s.hi) v = *reinterpret_cast<const float4*>(s.p + k);
-        return v;
-    }
+    __device__ float4 post(float4 v) const { v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; return v; }
 };
 
-// Dense row-major [K][ld] matrix, reduction along the rows (TN-type).
+// Dense row-major [rows][ld] matrix, reduction along the row (NT-type); compact rows via RowMap.
+struct PlainNT {
+    static constexpr bool kTN = false;
+    const float* base; int R, ld, K; RowMap map;
+    __device__ const float* dummy() const { return base; }
+    __device__ RowState row_state(int r) const {
+        RowState s; s.lo = 0; s.hi = (r < R) ? K : 0;
+        s.p = base + (size_t)(r < R ? map.full(r) : 0) * ld;
+        return s;
+    }
+    __device__ Src src(const RowState& s, int k) const { return Src{s.p + k, k < s.hi}; }
+    __device__ float4 post(float4 v) const { return v; }
+};
+
+// Dense row-major [K][ld] matrix, reduction along the (compact) rows (TN-type).
 struct PlainTN {
     static constexpr bool kTN = true;
-    const float* base; int K, ld, cols;
-    __device__ float4 load(int k, int c) const {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < K && c < cols) v = *reinterpret_cast<const float4*>(base + (size_t)k * ld + c);
-        return v;
+    const float* base; int K, ld, cols; RowMap map;
+    __device__ const float* dummy() const { return base; }
+    __device__ Src src(int k, int c) const {
+        const bool ok = k < K && c < cols;
+        return Src{base + (size_t)(ok ? map.full(k) : 0) * ld + c, ok};
     }
+    __device__ float4 post(float4 v) const { return v; }
 };
 
 // Analysis bases as the B operand: GEMM column j -> (bin = j>>1, re/im = j&1); only the F used rows
@@ -110,6 +132,7 @@ struct PlainTN {
 struct AnalysisW {
     static constexpr bool kTN = false;
     const float* Wr; const float* Wi; int F, N;
+    __device__ const float* dummy() const { return Wr; }
     __device__ RowState row_state(int j) const {
         const int bin = j >> 1;
         RowState s; s.lo = 0;
@@ -118,11 +141,8 @@ struct AnalysisW {
         s.hi = ok ? N : 0;
         return s;
     }
-    __device__ float4 load(const RowState& s, int k) const {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < s.hi) v = *reinterpret_cast<const float4*>(s.p + k);
-        return v;
-    }
+    __device__ Src src(const RowState& s, int k) const { return Src{s.p + k, k < s.hi}; }
+    __device__ float4 post(float4 v) const { return v; }
 };
 
 // ------------------------------------------------------------------------------ epilogues
@@ -130,18 +150,21 @@ struct AnalysisW {
 //   row = (i&3) + 8*(i>>2) + 4*(l>>5),  col = l&31.
 __device__ __forceinline__ int d_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
 
-struct StoreC {       // out[(z*M + row)*ld + col]; z = blockIdx.z (split-K slab) when slabbed
-    float* out; int M, Nc, ld; size_t slab;
+struct StoreC {       // out[(z*slab) + full_row*ld + col]; z = blockIdx.z (split-K slab)
+    float* out; int M, Nc, ld; size_t slab; RowMap map;
     __device__ void operator()(int m0, int n0, const f32x16 (&acc)[NJ]) const {
         const int lane = threadIdx.x & 63;
         float* o = out + (size_t)blockIdx.z * slab;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int col = n0 + 32 * j + (lane & 31);
+        for (int i = 0; i < 16; ++i) {
+            const int row = m0 + d_row(i, lane);
+            if (row < M) {
+                float* orow = o + (size_t)map.full(row) * ld;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = m0 + d_row(i, lane);
-                if (row < M && col < Nc) o[(size_t)row * ld + col] = acc[j][i];
+                for (int j = 0; j < NJ; ++j) {
+                    const int col = n0 + 32 * j + (lane & 31);
+                    if (col < Nc) orow[col] = acc[j][i];
+                }
             }
         }
     }
@@ -150,21 +173,22 @@ struct StoreC {       // out[(z*M + row)*ld + col]; z = blockIdx.z (split-K slab
 // Analysis epilogue: nn_proc.py:309-310 fused.  Columns are interleaved (re,im) pairs of one bin in
 // adjacent lanes; a lane-pair exchange gives both, even lanes store (re, mag), odd lanes (im, phs).
 struct PolarStore {
-    float* re; float* im; float* mag; float* phs; int R, F;
+    float* re; float* im; float* mag; float* phs; int R, F; RowMap map;
     __device__ void operator()(int m0, int n0, const f32x16 (&acc)[NJ]) const {
         const int lane = threadIdx.x & 63;
         const bool odd = lane & 1;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int bin = (n0 + 32 * j + (lane & 31)) >> 1;
+        for (int i = 0; i < 16; ++i) {
+            const int row = m0 + d_row(i, lane);
+            const size_t rbase = (size_t)(row < R ? map.full(row) : 0) * F;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int j = 0; j < NJ; ++j) {
+                const int bin = (n0 + 32 * j + (lane & 31)) >> 1;
                 const float v = acc[j][i];
                 const float o = __shfl_xor(v, 1);
                 const float vr = odd ? o : v, vi = odd ? v : o;
-                const int row = m0 + d_row(i, lane);
                 if (row < R && bin < F) {
-                    const size_t idx = (size_t)row * F + bin;
+                    const size_t idx = rbase + bin;
                     if (!odd) {
                         if (re) re[idx] = vr;
                         if (mag) mag[idx] = sqrtf(vr * vr + vi * vi);
@@ -184,67 +208,63 @@ __global__ void __launch_bounds__(WAVES_M * 64)
 gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int ksplit)
 {
     constexpr int BM = 32 * WAVES_M, NT = 64 * WAVES_M;
-    constexpr int LDA = AL::kTN ? BM + 4 : BM + 2;     // TN: 16-B aligned rows for ds_write_b128; NT: 4*LD = 8 (mod 32) -> conflict-free transposing ds_write_b32
-    constexpr int LDB = BL::kTN ? BN + 4 : BN + 2;
-    constexpr int A_IT = BM * (BK / 4) / NT;           // float4 items per thread per k-tile (= 4)
-    constexpr int B_IT = BN * (BK / 4) / NT;           // 6 / 4 / 3 for WAVES_M = 2 / 3 / 4
+    constexpr int LDA = AL::kTN ? BM + 4 : PK;          // TN: k-major [BK][BM+4] ; NT: row-major [BM][36]
+    constexpr int LDB = BL::kTN ? BN + 4 : PK;
+    constexpr int A_SZ = AL::kTN ? BK * LDA : BM * LDA;
+    constexpr int B_SZ = BL::kTN ? BK * LDB : BN * LDB;
+    constexpr int A_IT = BM * (BK / 4) / NT;            // float4 items per thread per k-tile (= 4)
+    constexpr int B_IT = BN * (BK / 4) / NT;            // 6 / 4 / 3 for WAVES_M = 2 / 3 / 4
     static_assert(BM * (BK / 4) % NT == 0 && BN * (BK / 4) % NT == 0, "tile/threads mismatch");
-    __shared__ __attribute__((aligned(16))) float As[2 * BK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * BK * LDB];
+    __shared__ __attribute__((aligned(16))) float As[2 * A_SZ];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * B_SZ];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m_blk = blockIdx.y * BM, n_blk = blockIdx.x * BN;
     const int k_begin = blockIdx.z * ksplit;
     const int k_end = (k_begin + ksplit < K) ? k_begin + ksplit : K;
 
-    // per-thread item coordinates (fixed across k-tiles)
-    int a_i[A_IT], a_k[A_IT], b_i[B_IT], b_k[B_IT];
+    // per-thread item coordinates (fixed across k-tiles): (row-in-tile, k-in-tile) and LDS offset
+    int a_i[A_IT], a_k[A_IT], a_l[A_IT], b_i[B_IT], b_k[B_IT], b_l[B_IT];
     RowState a_st[AL::kTN ? 1 : A_IT], b_st[BL::kTN ? 1 : B_IT];
 #pragma unroll
     for (int p = 0; p < A_IT; ++p) {
         const int idx = tid + NT * p;
-        if constexpr (AL::kTN) { a_i[p] = (idx % (BM / 4)) * 4; a_k[p] = idx / (BM / 4); }
-        else { const int t2 = idx >> 2; a_i[p] = t2 % BM; a_k[p] = 16 * (t2 / BM) + 4 * (idx & 3); a_st[p] = al.row_state(m_blk + a_i[p]); }
+        if constexpr (AL::kTN) { a_i[p] = (idx % (BM / 4)) * 4; a_k[p] = idx / (BM / 4); a_l[p] = a_k[p] * LDA + a_i[p]; }
+        else { a_i[p] = idx >> 3; a_k[p] = (idx & 7) * 4; a_l[p] = a_i[p] * LDA + a_k[p]; a_st[p] = al.row_state(m_blk + a_i[p]); }
     }
 #pragma unroll
     for (int p = 0; p < B_IT; ++p) {
         const int idx = tid + NT * p;
-        if constexpr (BL::kTN) { b_i[p] = (idx % (BN / 4)) * 4; b_k[p] = idx / (BN / 4); }
-        else { const int t2 = idx >> 2; b_i[p] = t2 % BN; b_k[p] = 16 * (t2 / BN) + 4 * (idx & 3); b_st[p] = bl.row_state(n_blk + b_i[p]); }
+        if constexpr (BL::kTN) { b_i[p] = (idx % (BN / 4)) * 4; b_k[p] = idx / (BN / 4); b_l[p] = b_k[p] * LDB + b_i[p]; }
+        else { b_i[p] = idx >> 3; b_k[p] = (idx & 7) * 4; b_l[p] = b_i[p] * LDB + b_k[p]; b_st[p] = bl.row_state(n_blk + b_i[p]); }
     }
 
     float4 ra[A_IT], rb[B_IT];
+    bool oa[A_IT], ob[B_IT];
     auto gload = [&](int kt) {
 #pragma unroll
         for (int p = 0; p < A_IT; ++p) {
-            if constexpr (AL::kTN) ra[p] = al.load(kt + a_k[p], m_blk + a_i[p]);
-            else ra[p] = al.load(a_st[p], kt + a_k[p]);
+            Src s;
+            if constexpr (AL::kTN) s = al.src(kt + a_k[p], m_blk + a_i[p]); else s = al.src(a_st[p], kt + a_k[p]);
+            oa[p] = s.ok;
+            ra[p] = *reinterpret_cast<const float4*>(s.ok ? s.p : al.dummy());
         }
 #pragma unroll
         for (int p = 0; p < B_IT; ++p) {
-            if constexpr (BL::kTN) rb[p] = bl.load(kt + b_k[p], n_blk + b_i[p]);
-            else rb[p] = bl.load(b_st[p], kt + b_k[p]);
+            Src s;
+            if constexpr (BL::kTN) s = bl.src(kt + b_k[p], n_blk + b_i[p]); else s = bl.src(b_st[p], kt + b_k[p]);
+            ob[p] = s.ok;
+            rb[p] = *reinterpret_cast<const float4*>(s.ok ? s.p : bl.dummy());
         }
     };
     auto lstore = [&](int buf) {
-        float* as = As + buf * BK * LDA;
-        float* bs = Bs + buf * BK * LDB;
+        float* as = As + buf * A_SZ;
+        float* bs = Bs + buf * B_SZ;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int p = 0; p < A_IT; ++p) {
-            if constexpr (AL::kTN) *reinterpret_cast<float4*>(as + a_k[p] * LDA + a_i[p]) = ra[p];
-            else {
-                float* q = as + a_k[p] * LDA + a_i[p];
-                q[0] = ra[p].x; q[LDA] = ra[p].y; q[2 * LDA] = ra[p].z; q[3 * LDA] = ra[p].w;
-            }
-        }
+        for (int p = 0; p < A_IT; ++p) *reinterpret_cast<float4*>(as + a_l[p]) = oa[p] ? al.post(ra[p]) : zero;
 #pragma unroll
-        for (int p = 0; p < B_IT; ++p) {
-            if constexpr (BL::kTN) *reinterpret_cast<float4*>(bs + b_k[p] * LDB + b_i[p]) = rb[p];
-            else {
-                float* q = bs + b_k[p] * LDB + b_i[p];
-                q[0] = rb[p].x; q[LDB] = rb[p].y; q[2 * LDB] = rb[p].z; q[3 * LDB] = rb[p].w;
-            }
-        }
+        for (int p = 0; p < B_IT; ++p) *reinterpret_cast<float4*>(bs + b_l[p]) = ob[p] ? bl.post(rb[p]) : zero;
     };
 
     f32x16 acc[NJ];
@@ -258,19 +278,40 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
         lstore(0);
         __syncthreads();
         int cur = 0;
-        const int a_off = (lane >> 5) * LDA + wave * 32 + (lane & 31);
-        const int b_off = (lane >> 5) * LDB + (lane & 31);
+        const int h = lane >> 5, l31 = lane & 31;
+        // NT: lane reads 16 consecutive floats of its row; TN: lane reads column l31 of rows 16h..16h+15
+        const int a_off = AL::kTN ? (16 * h) * LDA + wave * 32 + l31 : (wave * 32 + l31) * LDA + 16 * h;
+        const int b_off = BL::kTN ? (16 * h) * LDB + l31 : l31 * LDB + 16 * h;
         for (int kt = k_begin; kt < k_end; kt += BK) {
             const bool more = kt + BK < k_end;
             if (more) gload(kt + BK);
-            const float* as = As + cur * BK * LDA + a_off;
-            const float* bs = Bs + cur * BK * LDB + b_off;
+            const float* as = As + cur * A_SZ + a_off;
+            const float* bs = Bs + cur * B_SZ + b_off;
+            float af[16], bf[NJ][16];
+            if constexpr (!AL::kTN) {
 #pragma unroll
-            for (int kk = 0; kk < BK / 2; ++kk) {
-                const float a = as[2 * kk * LDA];
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(as + 4 * q);
+                    af[4 * q] = v.x; af[4 * q + 1] = v.y; af[4 * q + 2] = v.z; af[4 * q + 3] = v.w;
+                }
+            }
+            if constexpr (!BL::kTN) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = *reinterpret_cast<const float4*>(bs + 32 * j * LDB + 4 * q);
+                        bf[j][4 * q] = v.x; bf[j][4 * q + 1] = v.y; bf[j][4 * q + 2] = v.z; bf[j][4 * q + 3] = v.w;
+                    }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                float a;
+                if constexpr (AL::kTN) a = as[kk * LDA]; else a = af[kk];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const float b = bs[2 * kk * LDB + 32 * j];
+                    float b;
+                    if constexpr (BL::kTN) b = bs[kk * LDB + 32 * j]; else b = bf[j][kk];
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
                 }
             }

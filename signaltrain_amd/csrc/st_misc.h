@@ -32,6 +32,23 @@ fold_kernel(const float* __restrict__ Sr, const float* __restrict__ Si, float* _
     }
 }
 
+// Frames that lie entirely in the Conv1d zero padding: re = im = mag = 0 and phs = atan2(0, 1e-7) = 0 exactly.
+__global__ void __launch_bounds__(256)
+zero_dead_frames_kernel(float* __restrict__ a0, float* __restrict__ a1, float* __restrict__ a2, float* __restrict__ a3,
+                        int T, int F, int t_lo, int Tv)
+{
+    const int nd = T - Tv;
+    const int b = blockIdx.x / nd, j = blockIdx.x - b * nd;
+    const int t = j < t_lo ? j : j + Tv;
+    const size_t base = ((size_t)b * T + t) * F;
+    for (int f = threadIdx.x; f < F; f += 256) {
+        if (a0) a0[base + f] = 0.f;
+        if (a1) a1[base + f] = 0.f;
+        if (a2) a2[base + f] = 0.f;
+        if (a3) a3[base + f] = 0.f;
+    }
+}
+
 // ---------------------------------------------------------------- overlap-add + residual + log-cosh
 // y_hat[b,j] = 2 * sum_t frs[b,t, N + j - H t] + x[b, L-y+j]     (cls_fe_dft.py:112-113, nn_proc.py:332,340)
 // loss partial = sum log cosh(y - y_hat) ; dsyn = 2 * (-tanh(y - y_hat)) * inv_count  (loss_functions.py:9-10)
@@ -51,7 +68,7 @@ ola_loss_kernel(const float* __restrict__ frs, const float* __restrict__ x, cons
         const float* fb = frs + (size_t)b * OT * N;
         float s = 0.f;
         for (int t = t0; t <= t1; ++t) s += fb[(size_t)t * N + (N + j - H * t)];
-        const float out = 2.0f * (s + 0.5f * x[(size_t)b * L + (L - ysz) + j]);
+        const float out = x ? 2.0f * (s + 0.5f * x[(size_t)b * L + (L - ysz) + j]) : s;   // x == NULL: plain Synthesis.forward (cls_fe_dft.py:112-113)
         if (y_hat) y_hat[(size_t)b * ysz + j] = out;
         if (y_true) {
             const float dlt = y_true[(size_t)b * ysz + j] - out;

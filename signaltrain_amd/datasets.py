@@ -1,0 +1,58 @@
+"""SynthAudioDataSet -- mirror of signaltrain/datasets.py:263-334 (on-the-fly synthetic windows) and
+do_augment (:21-29).  Items: (x f32[chunk], y[y_size], knobs f32[K])."""
+import numpy as np
+from torch.utils.data import Dataset
+
+from . import audio
+
+
+def do_augment(x, y, rand_invert=True):
+    if rand_invert and np.random.choice([True, False]):
+        x, y = -x, -y
+    return x, y
+
+
+def worker_init(worker_id):
+    """datasets.py:54-61: reseed numpy per DataLoader worker (not reproducible by design)."""
+    np.random.seed()
+
+
+class SynthAudioDataSet(Dataset):
+    def __init__(self, chunk_size, effect, sr=44100, datapoints=8000, dtype=np.float32, recycle=False, y_size=None, augment=True):
+        super().__init__()
+        self.chunk_size, self.effect, self.sr, self.datapoints, self.dtype = chunk_size, effect, sr, datapoints, dtype
+        self.recycle, self.num_knobs, self.augment = recycle, len(effect.knob_names), augment
+        self.y_size = chunk_size if y_size is None else y_size
+        self.t = np.arange(chunk_size, dtype=np.float32) / sr
+        if recycle:
+            self.x = np.zeros((datapoints, chunk_size), dtype=dtype); self.y = np.zeros((datapoints, self.y_size), dtype=dtype)
+            self.knobs = np.zeros((datapoints, self.num_knobs), dtype=dtype)
+            for i in range(datapoints):
+                self.x[i], self.y[i], self.knobs[i] = self.gen_single_chunk()
+
+    def __len__(self):
+        return self.datapoints
+
+    def __getitem__(self, idx):
+        if self.recycle:
+            return self.x[idx], self.y[idx], self.knobs[idx]
+        x, y, knobs = self.gen_single_chunk()
+        return x.astype(self.dtype, copy=False)[-self.chunk_size:], y[-self.y_size:].astype(self.dtype, copy=False), \
+            knobs.astype(self.dtype, copy=False)
+
+    def gen_single_chunk(self, chooser=None, knobs=None):
+        if chooser is None:
+            chooser = np.random.choice([0, 1, 2, 4, 6, 7])            # datasets.py:317
+        x = audio.synth_input_sample(self.t, chooser)
+        if knobs is None:
+            knobs = audio.random_ends(len(self.effect.knob_ranges)) - 0.5
+        y, x = self.effect.go(x, knobs)
+        y = y[-self.y_size:]
+        if self.augment:
+            x, y = do_augment(x, y)
+        return x, y, knobs
+
+    def batch(self, B):
+        """B stacked items as float32 arrays (used by bench.py / tests for device-resident synthetic data)."""
+        xs, ys, ks = zip(*(self.gen_single_chunk() for _ in range(B)))
+        return (np.stack(xs).astype(np.float32), np.stack(ys).astype(np.float32), np.stack(ks).astype(np.float32))

@@ -145,6 +145,25 @@ class StepEngine:
                                              self._stream()), "st_loss_backward")
         return outs
 
+    def loss_backward_p1(self, x, knobs, y):
+        """Forward + backward up to (excluding) the analysis weight gradient; see dp.DataParallel."""
+        d, x, knobs, y = self._prep(x, knobs, y)
+        self._pending = (d, x)
+        _lib.check(self.lib.st_loss_backward_p1(C.byref(d), _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(x),
+                                                _lib.ptr(knobs), _lib.ptr(y), _lib.ptr(self.ws), self._stream()), "st_loss_backward_p1")
+
+    def loss_backward_p2(self):
+        d, x = self._pending
+        _lib.check(self.lib.st_loss_backward_p2(C.byref(d), _lib.ptr(self.grads), _lib.ptr(x), _lib.ptr(self.ws),
+                                                _lib.ptr(self.scalars), self._stream()), "st_loss_backward_p2")
+
+    def grad_buckets(self):
+        """Gradient ranges in the order they become final: [synthesis + autoencoders], then the live rows
+        [0,F) of the two analysis tensors (rows >= F are structurally zero and never move)."""
+        o, d = self.layout.offsets, self.dims
+        live = d.F * d.N
+        return [self.grads[o[2]:], self.grads[o[0]:o[0] + live], self.grads[o[1]:o[1] + live]]
+
     def train_step(self, x, knobs, y, lr, betas=(0.9, 0.999), eps=1e-8):
         """One optimisation step (train.py:112-151).  `lr` is the value sitting in param_groups at step
         time, i.e. lr_sched[max(i-1,0)] in the reference loop (train.py:150).  No host sync."""

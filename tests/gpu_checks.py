@@ -145,7 +145,9 @@ def run_all(B=3, seed=0, K=4, verbose=False):
     frs = z(B * OT, N)
     _lib.check(lib.st_synthesis_frames(C.byref(d), _lib.ptr(AAo), _lib.ptr(Sfold), _lib.ptr(frs), stream()), "synth")
     frs_ref = c["Are"].reshape(-1, F) @ fr_ + c["Aim"].reshape(-1, F) @ fi_
-    res.append(err("synthesis.frames", n(frs), frs_ref))
+    # only frames that reach the cropped output are computed (t with 0 < H t and H t - N < y)
+    live = np.array([(geo["H"] * tt > 0) and (geo["H"] * tt - N < geo["y"]) for tt in range(OT)])
+    res.append(err("synthesis.frames", n(frs).reshape(B, OT, N)[:, live], frs_ref.reshape(B, OT, N)[:, live]))
     y_hat, dsyn = z(B, d.y), z(B, d.y)
     lp = z(lib.st_ola_loss_partials(C.byref(d)))
     frs_o = t(frs_ref)
@@ -194,11 +196,12 @@ def run_all(B=3, seed=0, K=4, verbose=False):
 
     # 6. polar backward + analysis wgrad
     dG = z(B * T, KP)
-    _lib.check(lib.st_polar_bwd(C.byref(d), _lib.ptr(t(c["re"])), _lib.ptr(t(c["im"])), _lib.ptr(t(c["dmag"])),
-                                _lib.ptr(t(c["dphs"])), None, _lib.ptr(dG), stream()), "polar_bwd")
+    keep = [t(c["re"]), t(c["im"]), t(c["dmag"]), t(c["dphs"])]        # hold references until the launch is queued
+    _lib.check(lib.st_polar_bwd(C.byref(d), _lib.ptr(keep[0]), _lib.ptr(keep[1]), _lib.ptr(keep[2]),
+                                _lib.ptr(keep[3]), None, _lib.ptr(dG), stream()), "polar_bwd")
     # zero-padded frames carry d atan2 = 1e7 * dphs: compare on the live frames, and the
     # degenerate frames separately against the same formula
-    live = np.ones(T, bool); live[[0, T - 1]] = False
+    live = np.ones(T, bool); live[[0, T - 1]] = False          # noqa: F841 (analysis frames 0 and T-1 are all padding)
     dre_g, dim_g = from_kp(n(dG), F)
     dre_g, dim_g = dre_g.reshape(B, T, F), dim_g.reshape(B, T, F)
     sl = float(max(np.abs(c["dre"][:, live]).max(), np.abs(c["dim"][:, live]).max()))

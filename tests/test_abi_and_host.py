@@ -1,0 +1,141 @@
+"""CPU: the C-ABI library loads and exports every symbol include/signaltrain_hip.h declares (no compute calls),
+host-side geometry / layout logic, the Python mirror of the reference surface, and the CPU baseline port."""
+import ctypes as C
+import os
+import re
+import numpy as np
+import pytest
+import torch
+
+from oracle import st_oracle as O
+from signaltrain_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "signaltrain_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(st_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    syms = header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in the header but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
+    assert lib.st_version() >= 100
+
+
+def test_geometry_matches_oracle_and_golden(golden_dir):
+    tab = np.load(os.path.join(golden_dir, "g1_geometry.npz"))["table"]
+    for s, sh, legacy, L, y, T, OT, N, H in tab:
+        d = _lib.geometry(int(s), int(sh), 4, 1, "legacy" if legacy else "lean")
+        assert (d.L, d.y, d.T, d.OT, d.N, d.H) == (L, y, T, OT, N, H)
+
+
+def test_param_layout_and_workspace():
+    d = _lib.geometry(1, 4, 4, 256)
+    offs, total = _lib.param_offsets(d)
+    assert offs[:5] == [0, 1 << 20, 2 << 20, 3 << 20, 4 << 20] and total == 4211096 and all(o % 4 == 0 for o in offs)
+    from signaltrain_amd.engine import param_names, param_shapes
+    names, shapes = param_names(), param_shapes(d)
+    assert names == O.param_order() and sum(int(np.prod(s)) for s in shapes) == 4211090
+    lib = _lib.load()
+    assert lib.st_kp(513) == 1056
+    assert 50e6 < lib.st_workspace_bytes(C.byref(d)) < 2e9
+    bad = _lib.st_dims(); bad.B = 1
+    assert lib.st_workspace_bytes(C.byref(bad)) == 0 and b"dimension" in lib.st_last_error()
+
+
+def test_error_reporting_without_gpu():
+    lib = _lib.load()
+    d = _lib.geometry(1, 4, 4, 2)
+    rc = lib.st_analysis_fwd(C.byref(d), None, None, None, 0.5, None, None, None, None, None)
+    assert rc == -1 and b"null" in lib.st_last_error()
+    with pytest.raises(RuntimeError):
+        _lib.check(rc, "st_analysis_fwd")
+
+
+def test_model_mirror_state_dict_and_init(golden_dir):
+    from signaltrain_amd import nn_proc
+    nn_proc._QUIET = True
+    m = nn_proc.st_model(scale_factor=1, shrink_factor=4, num_knobs=4)
+    sd = m.state_dict()
+    assert list(sd.keys()) == O.param_order()
+    assert (m.in_chunk_size, m.out_chunk_size, m.num_knobs, m.scale_factor, m.shrink_factor) == (8192, 2048, 4, 1, 4)
+    g = np.load(os.path.join(golden_dir, "g2_init_bases.npz"))
+    from tests.golden_util import SAMPLE_ROWS, STFT_KEYS
+    for k in STFT_KEYS:                       # init bases == the reference's, to <= 1 ulp on the sampled rows
+        np.testing.assert_allclose(sd[k].numpy()[SAMPLE_ROWS, 0], g["rows_" + k], rtol=0, atol=4e-9)
+    assert m.mpaec.dft_analysis.conv_analysis_real.weight.shape == (1024, 1, 1024)     # io_methods.py:484-493 attribute path
+    b = sd["mpaec.aenc.fnn_enc.bias"]; w = sd["mpaec.aenc.fnn_addknobs.weight"]
+    assert float(b.abs().max()) == 0.0 and w.shape == (16, 20) and 0.1 < float(w.std()) < 0.4   # xavier_normal: sqrt(2/36)
+    m8 = nn_proc.st_model(scale_factor=8, shrink_factor=4, num_knobs=4)
+    assert (m8.in_chunk_size, m8.out_chunk_size, m8.mpaec.aenc._T, m8.mpaec.aenc._OT) == (65536, 16256, 174, 46)
+    with pytest.raises(RuntimeError):         # the product path fails loudly without a GPU
+        m(torch.zeros(1, 8192), torch.zeros(1, 4))
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    from signaltrain_amd import nn_proc, misc, audio
+    nn_proc._QUIET = True
+    m = nn_proc.st_model(num_knobs=4)
+    eff = audio.Compressor_4c()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    f = str(tmp_path / "modelcheckpoint.tar")
+    misc.save_checkpoint(f, m, 4, False, opt, eff, 44100)
+    sd, rv = misc.load_checkpoint(f, device="cpu")
+    assert set(rv) == {"epoch", "optimizer", "effect_name", "knob_names", "knob_ranges", "scale_factor", "shrink_factor",
+                       "in_chunk_size", "out_chunk_size", "sr"}           # misc.py:28-34 keys
+    assert rv["epoch"] == 5 and rv["in_chunk_size"] == 8192 and rv["out_chunk_size"] == 2048
+    m2 = nn_proc.st_model(num_knobs=4); m2.load_state_dict(sd)
+    for k in sd:
+        assert torch.equal(m2.state_dict()[k], m.state_dict()[k])
+
+
+def test_learningrate_and_loss_mirrors(golden_dir):
+    from signaltrain_amd import learningrate, loss_functions
+    g = np.load(os.path.join(golden_dir, "g6_1cycle.npz"))
+    lr, mom = learningrate.get_1cycle_schedule(lr_max=1e-4, n_data_points=200000, epochs=100, batch_size=200)
+    np.testing.assert_allclose(lr[g["idx"]], g["lr"], rtol=1e-15); np.testing.assert_allclose(mom[g["idx"]], g["mom"], rtol=1e-15)
+    rng = np.random.default_rng(0)
+    yh, y, mh = rng.standard_normal((3, 64)), rng.standard_normal((3, 64)), rng.standard_normal((3, 9, 513))
+    w = O.freq_weights(513, np.float64)
+    ref = O.calc_loss(yh, y, mh, w)
+    got = loss_functions.calc_loss(torch.from_numpy(yh), torch.from_numpy(y), torch.from_numpy(mh), scale_by_freq=torch.from_numpy(w))
+    assert abs(float(got) - ref) < 1e-12
+
+
+def test_audio_and_dataset_contract(golden_dir):
+    from signaltrain_amd import audio, datasets
+    g = np.load(os.path.join(golden_dir, "g9_compressor.npz"))
+    y = audio.compressor_4controls(g["x"], *g["knobs"][:4], sr=g["knobs"][4])
+    assert np.abs(y - g["y"]).max() < 1e-6
+    np.testing.assert_array_equal(audio.sliding_window(np.arange(10), 5, overlap=2), [[0, 1, 2, 3, 4], [3, 4, 5, 6, 7], [6, 7, 8, 9, 0]])
+    np.random.seed(1)
+    ds = datasets.SynthAudioDataSet(8192, audio.Compressor_4c(), y_size=2048)
+    x, yy, k = ds[0]
+    assert x.shape == (8192,) and yy.shape == (2048,) and k.shape == (4,) and x.dtype == np.float32 and k.dtype == np.float32
+    assert np.all(np.abs(k) <= 0.5) and np.abs(x).max() < 1.5
+
+
+def test_cpu_port_matches_oracle():
+    """bench.py's cpu_baseline 'port' computes the same step as the oracle."""
+    from oracle.torch_cpu_step import CpuPort
+    from tests.golden_util import perturb_stft
+    geo = O.geometry(1, 4)
+    rng = np.random.default_rng(3)
+    P = O.init_params(geo, 4, rng); perturb_stft(P, seed=5)
+    X, Y, KN = O.synth_comp4c_batch(2, geo["L"], geo["y"], rng)
+    port = CpuPort(P, lr=1e-3)
+    Pq = {k: P[k].copy() for k in O.param_order()}
+    M = {k: np.zeros_like(v) for k, v in Pq.items()}; V = {k: np.zeros_like(v) for k, v in Pq.items()}
+    for it in range(2):
+        lp = port.step(torch.from_numpy(X), torch.from_numpy(KN), torch.from_numpy(Y), 1e-3)
+        lo, _, _ = O.train_step(X, KN, Y, Pq, M, V, it + 1, 1e-3, geo)
+        assert abs(lp - lo) <= 3e-5 * abs(lo)
+        for k in Pq:
+            assert np.abs(port.P[k].detach().numpy() - Pq[k]).max() < 2e-5, k   # Adam normalises noise-level gradient elements: lr-sized differences are expected there

