@@ -82,7 +82,11 @@ int st_ae_fwd_partials(const st_dims* d);
  * Sfold[KP,N]: rows [0,F) = Sr[k]+Sr[N-k], rows [KP/2,KP/2+F) = Si[k]-Si[N-k]; other rows 0. */
 int st_synth_fold(const st_dims* d, const float* Sr, const float* Si, float* Sfold, void* stream);
 
-/* cls_fe_dft.py:112 ConvTranspose1d as a GEMM: frs[B*OT,N] = AA[B*OT,KP] * Sfold[KP,N]. */
+/* Number of split-K slabs the two small-M synthesis GEMMs write (frs: slabs x [B*OT,N]; dAA: slabs x [B*OT,KP]);
+ * st_ola_loss / st_ae_bwd sum the slabs while reading. */
+int st_synth_slabs(const st_dims* d);
+
+/* cls_fe_dft.py:112 ConvTranspose1d as a GEMM: frs[B*OT,N] = AA[B*OT,KP] * Sfold[KP,N] (live frames only). */
 int st_synthesis_frames(const st_dims* d, const float* AA, const float* Sfold, float* frs, void* stream);
 
 /* cls_fe_dft.py:112-113 overlap-add + crop, nn_proc.py:332,340 residual and x2,

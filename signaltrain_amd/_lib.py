@@ -39,6 +39,7 @@ SIGNATURES = {
     "st_analysis_fwd": (_i, [_D, _p, _p, _p, _f, _p, _p, _p, _p, _p]),
     "st_ae_fwd": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "st_ae_fwd_partials": (_i, [_D]),
+    "st_synth_slabs": (_i, [_D]),
     "st_synth_fold": (_i, [_D, _p, _p, _p, _p]),
     "st_synthesis_frames": (_i, [_D, _p, _p, _p, _p]),
     "st_ola_loss": (_i, [_D, _p, _p, _p, _p, _p, _p, _p]),

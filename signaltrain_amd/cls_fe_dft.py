@@ -106,7 +106,7 @@ class _SynthesisFn(torch.autograd.Function):
         KP = lib.st_kp(F)
         AA = torch.zeros(B * OT, KP, device=real.device)
         AA[:, :F] = real.reshape(B * OT, F); AA[:, KP // 2:KP // 2 + F] = imag.reshape(B * OT, F)
-        Sfold = torch.empty(KP, N, device=real.device); frs = torch.zeros(B * OT, N, device=real.device)
+        Sfold = torch.empty(KP, N, device=real.device); frs = torch.zeros(lib.st_synth_slabs(C.byref(d)), B * OT, N, device=real.device)
         wave = torch.empty(B, d.y, device=real.device)
         Sr_, Si_ = Sr.contiguous(), Si.contiguous()
         _lib.check(lib.st_synth_fold(C.byref(d), _lib.ptr(Sr_), _lib.ptr(Si_), _lib.ptr(Sfold), _stream()), "fold")
@@ -123,13 +123,14 @@ class _SynthesisFn(torch.autograd.Function):
         d = _dims(B, 4 * ((OT - 1) * H - N), N, H, OT, OT)
         KP = lib.st_kp(F)
         dsyn = g_wave.contiguous().float()
-        dAA = torch.zeros(B * OT, KP, device=AA.device)
+        dAA = torch.zeros(lib.st_synth_slabs(C.byref(d)), B * OT, KP, device=AA.device)
         _lib.check(lib.st_synthesis_dgrad(C.byref(d), _lib.ptr(dsyn), _lib.ptr(Sfold), _lib.ptr(dAA), _stream()), "dgrad")
         ws = torch.empty(lib.st_wgrad_ws_floats(C.byref(d)), device=AA.device)
         gSr = torch.zeros(N, 1, N, device=AA.device); gSi = torch.zeros(N, 1, N, device=AA.device)
         npart = torch.empty(lib.st_norm_partials(C.byref(d)), device=AA.device)
         _lib.check(lib.st_synthesis_wgrad(C.byref(d), _lib.ptr(AA), _lib.ptr(dsyn), _lib.ptr(ws), _lib.ptr(gSr), _lib.ptr(gSi),
                                           _lib.ptr(npart), _stream()), "wgrad")
+        dAA = dAA.sum(0)
         g_re = dAA[:, :F].reshape(B, OT, F); g_im = dAA[:, KP // 2:KP // 2 + F].reshape(B, OT, F)
         return g_re, g_im, gSr, gSi, None, None
 

@@ -310,439 +310,583 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
 }
 
 // ========================================================================================== backward
-// One workgroup = NW waves, 1 wave per SIMD (the wave owns up to 512 registers).  blockIdx.y selects the
-// autoencoder (0 = magnitude 'sf', 1 = phase).  Each wave walks PAIRS of 16-row groups (two interleaved
-// chains).  Per pair it
-//   1. recomputes the forward chain keeping every post-ELU activation in registers (68 regs / chain);
+// blockIdx.y selects the autoencoder (0 = magnitude 'sf', 1 = phase); one workgroup = NW waves, two waves per SIMD.
+// Per 16-row group a wave
+//   1. recomputes the forward chain, keeping every post-ELU activation in registers in D layout (68 regs);
 //   2. forms d out (polar->rect backward of nn_proc.py:322-326 + the L1 term of loss_functions.py:36);
-//   3. walks the layers backwards: da_l (D layout) is the B operand of the next dgrad MFMA as is; for the
-//      weight gradient both operands need rows on the k index, i.e. the transposed layout, obtained by a
-//      wave-private LDS round trip (write [feat][row] pitch 20, read A/B fragments); the 16x16 tiles of
-//      dW_l = sum_rows da_l (x) h_{l-1} accumulate in 144 persistent registers for the whole kernel;
-//   4. writes d input rows (dmag / dphs).
-// At the end each wave stores its partial dW/db (packed like the parameters); ae_grad_reduce_kernel sums.
+//   3. walks the layers backwards.  The data gradient continues the D-layout chain (A = W^T fragments).  The
+//      weight gradient dW_l = sum_rows da_l (x) h_{l-1} needs both operands with ROWS on the MFMA k index, i.e.
+//      transposed.  Instead of LDS round trips the transposed copies come from the SECOND MFMA ORIENTATION
+//          D[row][o] = sum_i H[row][i] * W^T[i][o]      (A = activations in D layout, B = the SAME weight fragment)
+//      whose result layout (lane (g,c), reg r <-> row 4g+r, feature 16*tile+c) is exactly the wgrad operand layout;
+//      likewise da^T_{l-1} = (da_l W_l)^T.  ~1.6x the MFMAs, zero transposes, activations stay in registers.
+//   4. the 16x16 tiles of dW_l are added into an LDS copy of the gradient with ds_add_f32 (one per workgroup) --
+//      no persistent accumulator registers, so two waves per SIMD hide each other's latencies.  (The summation
+//      order of these LDS atomics is not deterministic: last-bit run-to-run differences in the AE gradients.)
+// At the end the workgroup stores its partial dW/db (packed like the parameters); ae_grad_reduce_kernel sums them.
 constexpr int SP = 20;                 // scratch pitch (floats): 16 rows + 4, keeps rows 16-B aligned
 
+// ---------------------------------------------------------------------------------------------------------
+// Weight fragments in registers.  Left to itself the compiler issues each MFMA's LDS weight fetch just before
+// the MFMA (one s_waitcnt per MFMA: the AE kernels were LDS-latency-bound).  These helpers burst-load every
+// fragment of a layer stage into a register array; the caller places a scheduling fence between the burst and
+// the MFMAs, so a stage pays one LDS round trip instead of one per MFMA.
+// forward-order fragment (ot, it, r):  W[o = 16 ot + c][i = 16 it + 4 g + r]
 template <int OTL, int ITL>
-struct Tiles { f32x4 t[OTL][ITL]; };
-
-template <int NC, int OTL, int ITL>
-__device__ __forceinline__ void wgrad_mfma(const float* const (&Ysc)[NC], const float* const (&Xsc)[NC],
-                                           f32x4 (&dW)[OTL][ITL], const int g, const int c)
-{
-#pragma unroll
-    for (int ch = 0; ch < NC; ++ch)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            float a[OTL], b[ITL];
-#pragma unroll
-            for (int ot = 0; ot < OTL; ++ot) a[ot] = Ysc[ch][(16 * ot + c) * SP + 4 * ks + g];
-#pragma unroll
-            for (int it = 0; it < ITL; ++it) b[it] = Xsc[ch][(16 * it + c) * SP + 4 * ks + g];
-#pragma unroll
-            for (int ot = 0; ot < OTL; ++ot)
-#pragma unroll
-                for (int it = 0; it < ITL; ++it) dW[ot][it] = ST_MFMA16(a[ot], b[it], dW[ot][it]);
-        }
-}
-
-template <int TL>
-__device__ __forceinline__ void scratch_put(float* sc, const f32x4 (&x)[TL], const int g, const int c)
-{
-#pragma unroll
-    for (int t = 0; t < TL; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sc[(16 * t + 4 * g + r) * SP + c] = x[t][r];
-}
-
-// sum over the 16 rows of scratch row `o` (bias gradient), lanes o < n
-template <int NC>
-__device__ __forceinline__ float scratch_rowsum(const float* const (&Ysc)[NC], const int o, const int n)
-{
-    float s = 0.f;
-    if (o < n) {
-#pragma unroll
-        for (int ch = 0; ch < NC; ++ch) {
-            const float4* q = reinterpret_cast<const float4*>(Ysc[ch] + o * SP);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const float4 v = q[j]; s += (v.x + v.y) + (v.z + v.w); }
-        }
-    }
-    return s;
-}
-
-// dh_in[it] = sum_o W[o][16 it + c] * da[o]  (A = W^T fragments read from the row-major padded matrix)
-template <int NC, int OTL, int ITL>
-__device__ __forceinline__ void layer_dgrad(const float* W, const int P, const f32x4 (&da)[NC][OTL],
-                                            f32x4 (&dh)[NC][ITL], const int g, const int c)
-{
-#pragma unroll
-    for (int it = 0; it < ITL; ++it) {
-        f32x4 acc[NC];
-#pragma unroll
-        for (int ch = 0; ch < NC; ++ch) acc[ch] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ot = 0; ot < OTL; ++ot)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float a = W[(16 * ot + 4 * g + r) * P + 16 * it + c];
-#pragma unroll
-                for (int ch = 0; ch < NC; ++ch) acc[ch] = ST_MFMA16(a, da[ch][ot][r], acc[ch]);
-            }
-#pragma unroll
-        for (int ch = 0; ch < NC; ++ch) dh[ch][it] = acc[ch];
-    }
-}
-
-template <int NC, int TL>
-__device__ __forceinline__ void apply_elu_grad(f32x4 (&d)[NC][TL], const f32x4 (&h)[NC][TL])
-{
-#pragma unroll
-    for (int ch = 0; ch < NC; ++ch)
-#pragma unroll
-        for (int t = 0; t < TL; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) d[ch][t][r] *= elu_grad_from_out(h[ch][t][r]);
-}
-
-// store a D-layout accumulator tile set of one layer's dW into the packed partial buffer
-template <int OTL, int ITL>
-__device__ __forceinline__ void store_dw(float* base, const int woff, const int OUT, const int IN,
-                                         const f32x4 (&dW)[OTL][ITL], const int g, const int c)
+__device__ __forceinline__ void frags_fwd(float (&fr)[OTL * ITL * 4], const float* W, const int P, const int g, const int c)
 {
 #pragma unroll
     for (int ot = 0; ot < OTL; ++ot)
 #pragma unroll
         for (int it = 0; it < ITL; ++it)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = 16 * ot + 4 * g + r, i = 16 * it + c;
-                if (o < OUT && i < IN) base[woff + o * IN + i] = dW[ot][it][r];
-            }
+            for (int r = 0; r < 4; ++r) fr[(ot * ITL + it) * 4 + r] = W[(16 * ot + c) * P + 16 * it + 4 * g + r];
 }
-
+// dgrad-order fragment (it, ot, r):  W[o = 16 ot + 4 g + r][i = 16 it + c]
 template <int OTL, int ITL>
-__device__ __forceinline__ void zero_tiles(f32x4 (&x)[OTL][ITL])
+__device__ __forceinline__ void frags_dgrad(float (&fr)[OTL * ITL * 4], const float* W, const int P, const int g, const int c)
 {
 #pragma unroll
-    for (int a = 0; a < OTL; ++a)
+    for (int it = 0; it < ITL; ++it)
 #pragma unroll
-        for (int b = 0; b < ITL; ++b) x[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ot = 0; ot < OTL; ++ot)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fr[(it * OTL + ot) * 4 + r] = W[(16 * ot + 4 * g + r) * P + 16 * it + c];
+}
+#define ST_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <int OTL, int ITL>
+__device__ __forceinline__ void fwdD_fr(const float (&fr)[OTL * ITL * 4], const float* bias, const f32x4 (&hin)[ITL],
+                                        f32x4 (&hout)[OTL], const int g)
+{
+#pragma unroll
+    for (int ot = 0; ot < OTL; ++ot) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < ITL; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = ST_MFMA16(fr[(ot * ITL + it) * 4 + r], hin[it][r], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hout[ot][r] = elu_f(acc[r] + bias[16 * ot + 4 * g + r]);
+    }
+}
+template <int OTL, int ITL>
+__device__ __forceinline__ void fwdT_fr(const float (&fr)[OTL * ITL * 4], const float* bias, const f32x4 (&hin)[ITL],
+                                        f32x4 (&houtT)[OTL], const int c)
+{
+#pragma unroll
+    for (int ot = 0; ot < OTL; ++ot) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < ITL; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = ST_MFMA16(hin[it][r], fr[(ot * ITL + it) * 4 + r], acc);
+        const float bv = bias[16 * ot + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) houtT[ot][r] = elu_f(acc[r] + bv);
+    }
+}
+// both data-gradient orientations from one fragment set
+template <int OTL, int ITL>
+__device__ __forceinline__ void dgrad_fr(const float (&fr)[OTL * ITL * 4], const f32x4 (&da)[OTL], f32x4 (&dh)[ITL], f32x4 (&dhT)[ITL])
+{
+#pragma unroll
+    for (int it = 0; it < ITL; ++it) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, accT = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ot = 0; ot < OTL; ++ot)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float w = fr[(it * OTL + ot) * 4 + r];
+                acc = ST_MFMA16(w, da[ot][r], acc);
+                accT = ST_MFMA16(da[ot][r], w, accT);
+            }
+        dh[it] = acc; dhT[it] = accT;
+    }
+}
+template <int OTL, int ITL>
+__device__ __forceinline__ void dgradD_fr(const float (&fr)[OTL * ITL * 4], const f32x4 (&da)[OTL], f32x4 (&dh)[ITL])
+{
+#pragma unroll
+    for (int it = 0; it < ITL; ++it) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ot = 0; ot < OTL; ++ot)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = ST_MFMA16(fr[(it * OTL + ot) * 4 + r], da[ot][r], acc);
+        dh[it] = acc;
+    }
 }
 
-// Supported geometry of this instantiation: T <= 32 (T16 = 2 input tiles), OT <= 16, K <= 16.
-template <int NW>
-__global__ void __launch_bounds__(NW * 64, 1)
+// T-layout forward of one layer from the D-layout activations of the previous one:
+// houtT[ot][r] = ELU(a)[row 4g+r][feature 16 ot + c]
+template <int OTL, int ITL>
+__device__ __forceinline__ void layer_fwdT(const float* W, const float* bias, const int P, const f32x4 (&hin)[ITL],
+                                           f32x4 (&houtT)[OTL], const int g, const int c)
+{
+#pragma unroll
+    for (int ot = 0; ot < OTL; ++ot) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < ITL; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc = ST_MFMA16(hin[it][r], W[(16 * ot + c) * P + 16 * it + 4 * g + r], acc);
+        const float bv = bias[16 * ot + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) houtT[ot][r] = elu_f(acc[r] + bv);
+    }
+}
+
+// D-layout forward, single chain
+template <int OTL, int ITL>
+__device__ __forceinline__ void layer_fwdD(const float* W, const float* bias, const int P, const f32x4 (&hin)[ITL],
+                                           f32x4 (&hout)[OTL], const int g, const int c)
+{
+#pragma unroll
+    for (int ot = 0; ot < OTL; ++ot) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < ITL; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc = ST_MFMA16(W[(16 * ot + c) * P + 16 * it + 4 * g + r], hin[it][r], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hout[ot][r] = elu_f(acc[r] + bias[16 * ot + 4 * g + r]);
+    }
+}
+
+// D-layout data gradient: dh[it] = sum_o W[o][16 it + c-th feature] * da[o]   (A = W^T fragments)
+template <int OTL, int ITL>
+__device__ __forceinline__ void layer_dgrad(const float* W, const int P, const f32x4 (&da)[OTL], f32x4 (&dh)[ITL],
+                                            const int g, const int c)
+{
+#pragma unroll
+    for (int it = 0; it < ITL; ++it) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ot = 0; ot < OTL; ++ot)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc = ST_MFMA16(W[(16 * ot + 4 * g + r) * P + 16 * it + c], da[ot][r], acc);
+        dh[it] = acc;
+    }
+}
+// T-layout data gradient: dhT[it][r] = (da W)[row 4g+r][feature 16 it + c]   (A = da in D layout, B = same fragments)
+template <int OTL, int ITL>
+__device__ __forceinline__ void layer_dgradT(const float* W, const int P, const f32x4 (&da)[OTL], f32x4 (&dhT)[ITL],
+                                             const int g, const int c)
+{
+#pragma unroll
+    for (int it = 0; it < ITL; ++it) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ot = 0; ot < OTL; ++ot)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc = ST_MFMA16(da[ot][r], W[(16 * ot + 4 * g + r) * P + 16 * it + c], acc);
+        dhT[it] = acc;
+    }
+}
+
+template <int TL>
+__device__ __forceinline__ void mul_elu_grad(f32x4 (&d)[TL], const f32x4 (&h)[TL])
+{
+#pragma unroll
+    for (int t = 0; t < TL; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[t][r] *= elu_grad_from_out(h[t][r]);
+}
+
+// dW_l tile(ot,it) += sum_rows daT[ot] (x) hT[it]; result (D layout: o = 16ot+4g+r, i = 16it+c) -> LDS atomics.
+// db_l (lane c <-> o = 16 ot + c) accumulates the row sums of daT in registers.
+template <int OTL, int ITL>
+__device__ __forceinline__ void wgrad_lds(float* dW, const int P, const f32x4 (&daT)[OTL], const f32x4 (&hT)[ITL],
+                                          float* db, const int g, const int c)
+{
+#pragma unroll
+    for (int ot = 0; ot < OTL; ++ot) {
+#pragma unroll
+        for (int it = 0; it < ITL; ++it) {
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = ST_MFMA16(daT[ot][r], hT[it][r], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(dW + (16 * ot + 4 * g + r) * P + 16 * it + c, acc[r]);
+        }
+        atomicAdd(db + 16 * ot + c, (daT[ot][0] + daT[ot][1]) + (daT[ot][2] + daT[ot][3]));   // bias gradient: row sums (4 lane groups hit the same word)
+    }
+}
+
+// Register-accumulator form: dW tiles and the bias row sums persist in registers for the whole kernel.
+template <int OTL, int ITL>
+__device__ __forceinline__ void wgrad_reg(f32x4 (&dW)[OTL][ITL], float (&db)[OTL], const f32x4 (&daT)[OTL], const f32x4 (&hT)[ITL])
+{
+#pragma unroll
+    for (int ot = 0; ot < OTL; ++ot) {
+#pragma unroll
+        for (int it = 0; it < ITL; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dW[ot][it] = ST_MFMA16(daT[ot][r], hT[it][r], dW[ot][it]);
+        db[ot] += (daT[ot][0] + daT[ot][1]) + (daT[ot][2] + daT[ot][3]);
+    }
+}
+template <int OTL, int ITL>
+__device__ __forceinline__ void dw_flush(float* dW, const int P, const f32x4 (&acc)[OTL][ITL], const int g, const int c)
+{
+#pragma unroll
+    for (int ot = 0; ot < OTL; ++ot)
+#pragma unroll
+        for (int it = 0; it < ITL; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(dW + (16 * ot + 4 * g + r) * P + 16 * it + c, acc[ot][it][r]);
+}
+
+template <int OTL>
+__device__ __forceinline__ void db_flush(float* dst, float (&db)[OTL], const int g, const int c)
+{
+#pragma unroll
+    for (int ot = 0; ot < OTL; ++ot) {
+        float v = db[ot];
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        if (g == 0) atomicAdd(dst + 16 * ot + c, v);
+    }
+}
+
+// Compile-time LDS layout of the (T <= 32, OT <= 16, K <= 16) instantiation: every padded dimension is fixed
+// (IN_1 -> 32, OUT_9 -> 16, IN_5 -> 32), so all offsets / pitches fold into instruction immediates.
+struct CL {
+    static constexpr int P0 = 33, P1 = 65, P2 = 33, P3 = 17, P4 = 33, P5 = 17, P6 = 17, P7 = 33, P8 = 65;
+    static constexpr int W0 = 0,            B0 = W0 + 64 * P0;
+    static constexpr int W1 = B0 + 64,      B1 = W1 + 32 * P1;
+    static constexpr int W2 = B1 + 32,      B2 = W2 + 16 * P2;
+    static constexpr int W3 = B2 + 16,      B3 = W3 + 16 * P3;
+    static constexpr int W4 = B3 + 16,      B4 = W4 + 16 * P4;
+    static constexpr int W5 = B4 + 16,      B5 = W5 + 16 * P5;
+    static constexpr int W6 = B5 + 16,      B6 = W6 + 32 * P6;
+    static constexpr int W7 = B6 + 32,      B7 = W7 + 64 * P7;
+    static constexpr int W8 = B7 + 64,      B8 = W8 + 16 * P8;
+    static constexpr int TOTAL = (B8 + 16 + 3) / 4 * 4;
+};
+#define ST_SCHED_FENCE() do { if constexpr (!REG) __builtin_amdgcn_sched_barrier(0); } while (0)
+
+// Supported geometry of this instantiation: T <= 32, OT <= 16, K <= 16.
+template <int NW, bool REG>      // REG: persistent register accumulators (1 wave/SIMD); else per-group LDS atomics (2 waves/SIMD)
+__global__ void __launch_bounds__(NW * 64, REG ? 1 : 2)
 ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, const float* __restrict__ knobs,
               const float* __restrict__ ae_m, const float* __restrict__ ae_p, const AEOffsets go, const int PG,
               const float* __restrict__ mag_hat, const float* __restrict__ phs_hat, const float* __restrict__ dAA,
               const float* __restrict__ g_mag_hat, const float reg_coef, const float expfac,
               float* __restrict__ dmag, float* __restrict__ dphs, float* __restrict__ ws,
               const int B, const int T, const int OT, const int F, const int K, const int KP,
-              const int to_lo, const int to_hi)      // live synthesis frames: dAA rows outside are treated as zero
+              const int to_lo, const int to_hi,      // live synthesis frames: dAA rows outside are treated as zero
+              const int nslab, const size_t slab)     // dAA arrives as split-K slabs of the synthesis dgrad GEMM
 {
-    constexpr int NC = 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int ae = blockIdx.y;
     const AELds L = ae_lds_layout(T, OT, K);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
-    float* lw = lds;
+    float* lw = lds;                                   // weights (+bias), padded
+    float* dwl = lds + CL::TOTAL;                      // gradient accumulator, same layout
+    // wave-private scratch: V[32*SP] (input rows, transposed), Y[16*SP] (d a9 transposed), TAIL[16*SP]
+    constexpr int SCR = (32 + 16 + 16) * SP;
+    float* Vs = lds + 2 * CL::TOTAL + wave * SCR;
+    float* Ys = Vs + 32 * SP;
+    float* Ts = Ys + 16 * SP;
+    for (int e = tid; e < CL::TOTAL; e += NW * 64) dwl[e] = 0.f;
     ae_load_lds(lw, L, ae ? ae_p : ae_m, go, tid, NW * 64);
-    // wave-private scratch: per chain  V[32*SP] | X[64*SP] | Y[64*SP] | TAIL[16*SP]
-    constexpr int SCR = (32 + 64 + 64 + 16) * SP;
-    float* scr = lds + L.total + wave * (NC * SCR);
-    float* Vs[NC]; float* Xs[NC]; float* Ys[NC]; float* Ts[NC];
-#pragma unroll
-    for (int ch = 0; ch < NC; ++ch) {
-        Vs[ch] = scr + ch * SCR; Xs[ch] = Vs[ch] + 32 * SP; Ys[ch] = Xs[ch] + 64 * SP; Ts[ch] = Ys[ch] + 64 * SP;
-    }
     __syncthreads();
 
     const float* vin = ae ? phs : mag;
     float* dvout = ae ? dphs : dmag;
     const int FP = KP / 2, gpw = FP / 16;
-    const int ngroups = B * gpw, npairs = (ngroups + 1) / 2;
+    const int ngroups = B * gpw;
     const int KS1 = (T + 3) / 4;
+    const int gstride = gridDim.x * NW;
 
-    // persistent weight-gradient accumulators (144 regs) + 9 bias-gradient registers
-    f32x4 dW1[4][2], dW2[2][4], dW3[1][2], dW4[1][1], dW5[1][2], dW6[1][1], dW7[2][1], dW8[4][2], dW9[1][4];
-    zero_tiles(dW1); zero_tiles(dW2); zero_tiles(dW3); zero_tiles(dW4); zero_tiles(dW5);
-    zero_tiles(dW6); zero_tiles(dW7); zero_tiles(dW8); zero_tiles(dW9);
-    float db[NL];
+    const float* const Wl[NL] = {lw + CL::W0, lw + CL::W1, lw + CL::W2, lw + CL::W3, lw + CL::W4, lw + CL::W5, lw + CL::W6, lw + CL::W7, lw + CL::W8};
+    const float* const Bl[NL] = {lw + CL::B0, lw + CL::B1, lw + CL::B2, lw + CL::B3, lw + CL::B4, lw + CL::B5, lw + CL::B6, lw + CL::B7, lw + CL::B8};
+    float* const Dl[NL] = {dwl + CL::W0, dwl + CL::W1, dwl + CL::W2, dwl + CL::W3, dwl + CL::W4, dwl + CL::W5, dwl + CL::W6, dwl + CL::W7, dwl + CL::W8};
+    float* const db1 = dwl + CL::B0; float* const db2 = dwl + CL::B1; float* const db3 = dwl + CL::B2;
+    float* const db4 = dwl + CL::B3; float* const db5 = dwl + CL::B4; float* const db6 = dwl + CL::B5;
+    float* const db7 = dwl + CL::B6; float* const db8 = dwl + CL::B7; float* const db9 = dwl + CL::B8;
+    // REG mode: 36 persistent 16x16 dW tiles (144 registers) + 17 bias-gradient registers
+    f32x4 rW1[4][2], rW2[2][4], rW3[1][2], rW4[1][1], rW5[1][2], rW6[1][1], rW7[2][1], rW8[4][2], rW9[1][4];
+    float rb1[4], rb2[2], rb3[1], rb4[1], rb5[1], rb6[1], rb7[2], rb8[4], rb9[1];
+#define ST_ZT(x, A, Bq) { _Pragma("unroll") for (int a_ = 0; a_ < A; ++a_) _Pragma("unroll") for (int b_ = 0; b_ < Bq; ++b_) x[a_][b_] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#define ST_ZB(x, A) { _Pragma("unroll") for (int a_ = 0; a_ < A; ++a_) x[a_] = 0.f; }
+    ST_ZT(rW1, 4, 2) ST_ZT(rW2, 2, 4) ST_ZT(rW3, 1, 2) ST_ZT(rW4, 1, 1) ST_ZT(rW5, 1, 2) ST_ZT(rW6, 1, 1) ST_ZT(rW7, 2, 1) ST_ZT(rW8, 4, 2) ST_ZT(rW9, 1, 4)
+    ST_ZB(rb1, 4) ST_ZB(rb2, 2) ST_ZB(rb3, 1) ST_ZB(rb4, 1) ST_ZB(rb5, 1) ST_ZB(rb6, 1) ST_ZB(rb7, 2) ST_ZB(rb8, 4) ST_ZB(rb9, 1)
+#undef ST_ZT
+#undef ST_ZB
+
+    // input rows of the first group (prefetched one group ahead afterwards): t = 4 ks + g, row c
+    float vr[8];
+    int grp = blockIdx.x * NW + wave;
+    auto load_v = [&](int gq, float (&dst)[8]) {
+        const int bq = gq / gpw, fq = (gq - bq * gpw) * 16 + c;
+        const bool ok0 = fq < F;
 #pragma unroll
-    for (int l = 0; l < NL; ++l) db[l] = 0.f;
-
-    const float* const Wl[NL] = {lw + L.w[0], lw + L.w[1], lw + L.w[2], lw + L.w[3], lw + L.w[4],
-                                 lw + L.w[5], lw + L.w[6], lw + L.w[7], lw + L.w[8]};
-    const float* const Bl[NL] = {lw + L.b[0], lw + L.b[1], lw + L.b[2], lw + L.b[3], lw + L.b[4],
-                                 lw + L.b[5], lw + L.b[6], lw + L.b[7], lw + L.b[8]};
-
-    for (int pr = blockIdx.x * NW + wave; pr < npairs; pr += gridDim.x * NW) {
-        asm volatile("" ::: "memory");      // see ae_fwd_kernel
-        int bb[NC], ff[NC]; bool fv[NC];
-#pragma unroll
-        for (int ch = 0; ch < NC; ++ch) {
-            const int grp = 2 * pr + ch;
-            const bool gv = grp < ngroups;
-            const int gg = gv ? grp : ngroups - 1;
-            bb[ch] = gg / gpw; ff[ch] = (gg - bb[ch] * gpw) * 16 + c;
-            fv[ch] = gv && ff[ch] < F;
+        for (int ks = 0; ks < 8; ++ks) {
+            const int t = 4 * ks + g;
+            const bool ok = ok0 && t < T;
+            const float x = vin[((size_t)bq * T + (ok ? t : 0)) * F + (ok0 ? fq : 0)];
+            dst[ks] = ok ? x : 0.f;
         }
-        // ------------------------------------------------------------------ forward recompute
-        f32x4 h1[NC][4], h2[NC][2], h3[NC][1], h4[NC][1], h5[NC][1], h6[NC][1], h7[NC][2], h8[NC][4], e9[NC][1];
-        f32x4 kn[NC][1];                                  // knob "tile": feature 16 + 4g + r of layer 5's input
+    };
+    if (grp < ngroups) load_v(grp, vr);
+
+    for (; grp < ngroups; grp += gstride) {
+        asm volatile("" ::: "memory");      // keep the (loop-invariant) LDS weight fetches inside the loop
+        const int b = grp / gpw, f = (grp - b * gpw) * 16 + c;
+        const bool fv = f < F;
+        const int fq = fv ? f : 0;
+        // ---- d-out inputs for this group (D layout: t' = 4g + r), issued early
+        float q_gre[4], q_gim[4], q_ph[4], q_mh[4], q_mt[4], q_gm[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int to = 4 * g + r;
+            const bool ok = fv && to < OT;
+            const bool lv = ok && to >= to_lo && to <= to_hi;
+            const size_t ro = (size_t)b * OT + (ok ? to : 0);
+            float a0 = 0.f, a1 = 0.f;
+            for (int z = 0; z < nslab; ++z) { a0 += dAA[z * slab + (lv ? ro : 0) * KP + fq]; a1 += dAA[z * slab + (lv ? ro : 0) * KP + FP + fq]; }
+            q_gre[r] = lv ? a0 : 0.f; q_gim[r] = lv ? a1 : 0.f;
+            q_ph[r] = phs_hat[ro * F + fq]; q_mh[r] = mag_hat[ro * F + fq];
+            q_mt[r] = vin[((size_t)b * T + (ok ? T - OT + to : 0)) * F + fq];
+            q_gm[r] = (g_mag_hat && ok) ? g_mag_hat[ro * F + fq] : 0.f;
+        }
+        float vn[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) vn[ks] = 0.f;
+        if (grp + gstride < ngroups) load_v(grp + gstride, vn);
+
+        // ------------------------------------------------------------------ forward recompute (D layout)
+        f32x4 h1[4], h2[2], h3[1], h4[1], h5[1], h6[1], h7[2], h8[4], e9[1], kn[1];
         {
-            f32x4 acc[NC][4];
+            f32x4 acc[4];
 #pragma unroll
-            for (int ch = 0; ch < NC; ++ch)
+            for (int ot = 0; ot < 4; ++ot) acc[ot] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int P1 = CL::P0;
+            float ff[4 * 8];
 #pragma unroll
-                for (int ot = 0; ot < 4; ++ot) acc[ch][ot] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int P1 = L.P[0];
-            float vr[NC][8];                              // burst-load all inputs first (8 k-steps = 32 padded features)
+            for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
-            for (int ch = 0; ch < NC; ++ch)
+                for (int ks = 0; ks < 8; ++ks) ff[ot * 8 + ks] = Wl[0][(16 * ot + c) * P1 + 4 * ks + g];
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    const int t = 4 * ks + g;
-                    const bool ok = fv[ch] && t < T;
-                    const float x = vin[((size_t)bb[ch] * T + (ok ? t : 0)) * F + (fv[ch] ? ff[ch] : 0)];
-                    vr[ch][ks] = ok ? x : 0.f;
-                }
+            for (int ks = 0; ks < 8; ++ks) Vs[(4 * ks + g) * SP + c] = vr[ks];   // [feature t][row c]: read back transposed for the layer-1 wgrad
+            ST_FENCE();
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const int t = 4 * ks + g;
-#pragma unroll
-                for (int ch = 0; ch < NC; ++ch) Vs[ch][t * SP + c] = vr[ch][ks];   // [feat = t][row = c] for the layer-1 weight gradient
+            for (int ks = 0; ks < 8; ++ks)
                 if (ks < KS1) {
 #pragma unroll
-                    for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-                        for (int ch = 0; ch < NC; ++ch)
-                            acc[ch][ot] = ST_MFMA16(Wl[0][(16 * ot + c) * P1 + t], vr[ch][ks], acc[ch][ot]);
+                    for (int ot = 0; ot < 4; ++ot) acc[ot] = ST_MFMA16(ff[ot * 8 + ks], vr[ks], acc[ot]);
                 }
-            }
 #pragma unroll
-            for (int ch = 0; ch < NC; ++ch)
+            for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
-                for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) h1[ch][ot][r] = elu_f(acc[ch][ot][r] + Bl[0][16 * ot + 4 * g + r]);
+                for (int r = 0; r < 4; ++r) h1[ot][r] = elu_f(acc[ot][r] + Bl[0][16 * ot + 4 * g + r]);
         }
+        { float fr[2 * 4 * 4]; frags_fwd<2, 4>(fr, Wl[1], CL::P1, g, c); ST_FENCE(); fwdD_fr<2, 4>(fr, Bl[1], h1, h2, g); }
+        { float fr[1 * 2 * 4]; frags_fwd<1, 2>(fr, Wl[2], CL::P2, g, c); ST_FENCE(); fwdD_fr<1, 2>(fr, Bl[2], h2, h3, g); }
+        { float fr[1 * 1 * 4]; frags_fwd<1, 1>(fr, Wl[3], CL::P3, g, c); ST_FENCE(); fwdD_fr<1, 1>(fr, Bl[3], h3, h4, g); }
         {
-            const float* const W[NC] = {Wl[1], Wl[1]}; const float* const bs[NC] = {Bl[1], Bl[1]};
-            layer_fwd<NC, 2, 4>(W, bs, L.P[1], h1, h2, g, c);
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int P5 = CL::P4;
+            float fa[4], fb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int kidx = 4 * g + r; kn[0][r] = kidx < K ? knobs[(size_t)b * K + kidx] : 0.f;
+                                         fa[r] = Wl[4][c * P5 + 4 * g + r]; fb[r] = Wl[4][c * P5 + 16 + 4 * g + r]; }
+            ST_FENCE();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = ST_MFMA16(fa[r], h4[0][r], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = ST_MFMA16(fb[r], kn[0][r], acc);   // knob features 16 + 4g + r
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h5[0][r] = elu_f(acc[r] + Bl[4][4 * g + r]);
         }
-        {
-            const float* const W[NC] = {Wl[2], Wl[2]}; const float* const bs[NC] = {Bl[2], Bl[2]};
-            layer_fwd<NC, 1, 2>(W, bs, L.P[2], h2, h3, g, c);
-        }
-        {
-            const float* const W[NC] = {Wl[3], Wl[3]}; const float* const bs[NC] = {Bl[3], Bl[3]};
-            layer_fwd<NC, 1, 1>(W, bs, L.P[3], h3, h4, g, c);
-        }
-        // d-out inputs (needed after the forward recompute): issue the loads now so they land under layers 5..9
-        float q_gre[NC][4], q_gim[NC][4], q_ph[NC][4], q_mh[NC][4], q_mt[NC][4];
-#pragma unroll
-        for (int ch = 0; ch < NC; ++ch)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int to = 4 * g + r;
-                const bool ok = fv[ch] && to < OT;
-                const bool lv = ok && to >= to_lo && to <= to_hi;
-                const size_t ro = (size_t)bb[ch] * OT + (ok ? to : 0);
-                const int fq = fv[ch] ? ff[ch] : 0;
-                const float a0 = dAA[(lv ? ro : 0) * KP + fq], a1 = dAA[(lv ? ro : 0) * KP + FP + fq];
-                const float a2 = phs_hat[ro * F + fq], a3 = mag_hat[ro * F + fq];
-                const float a4 = vin[((size_t)bb[ch] * T + (ok ? T - OT + to : 0)) * F + fq];
-                q_gre[ch][r] = lv ? a0 : 0.f; q_gim[ch][r] = lv ? a1 : 0.f;
-                q_ph[ch][r] = a2; q_mh[ch][r] = a3; q_mt[ch][r] = a4;
-            }
-        {
-            f32x4 acc[NC];
-            const int P5 = L.P[4];
-#pragma unroll
-            for (int ch = 0; ch < NC; ++ch) {
-                acc[ch] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int kidx = 4 * g + r;
-                    kn[ch][0][r] = kidx < K ? knobs[(size_t)bb[ch] * K + kidx] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int ch = 0; ch < NC; ++ch)
-                    acc[ch] = ST_MFMA16(Wl[4][c * P5 + 4 * g + r], h4[ch][0][r], acc[ch]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)                    // knob features 16 + 4g + r (K <= 16)
-#pragma unroll
-                for (int ch = 0; ch < NC; ++ch)
-                    acc[ch] = ST_MFMA16(Wl[4][c * P5 + 16 + 4 * g + r], kn[ch][0][r], acc[ch]);
-#pragma unroll
-            for (int ch = 0; ch < NC; ++ch)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) h5[ch][0][r] = elu_f(acc[ch][r] + Bl[4][4 * g + r]);
-        }
-        {
-            const float* const W[NC] = {Wl[5], Wl[5]}; const float* const bs[NC] = {Bl[5], Bl[5]};
-            layer_fwd<NC, 1, 1>(W, bs, L.P[5], h5, h6, g, c);
-        }
-        {
-            const float* const W[NC] = {Wl[6], Wl[6]}; const float* const bs[NC] = {Bl[6], Bl[6]};
-            layer_fwd<NC, 2, 1>(W, bs, L.P[6], h6, h7, g, c);
-        }
-        {
-            const float* const W[NC] = {Wl[7], Wl[7]}; const float* const bs[NC] = {Bl[7], Bl[7]};
-            layer_fwd<NC, 4, 2>(W, bs, L.P[7], h7, h8, g, c);
-        }
-        {
-            const float* const W[NC] = {Wl[8], Wl[8]}; const float* const bs[NC] = {Bl[8], Bl[8]};
-            layer_fwd<NC, 1, 4>(W, bs, L.P[8], h8, e9, g, c);
-        }
+        { float fr[1 * 1 * 4]; frags_fwd<1, 1>(fr, Wl[5], CL::P5, g, c); ST_FENCE(); fwdD_fr<1, 1>(fr, Bl[5], h5, h6, g); }
+        { float fr[2 * 1 * 4]; frags_fwd<2, 1>(fr, Wl[6], CL::P6, g, c); ST_FENCE(); fwdD_fr<2, 1>(fr, Bl[6], h6, h7, g); }
+        { float fr[4 * 2 * 4]; frags_fwd<4, 2>(fr, Wl[7], CL::P7, g, c); ST_FENCE(); fwdD_fr<4, 2>(fr, Bl[7], h7, h8, g); }
+        { float fr[1 * 4 * 4]; frags_fwd<1, 4>(fr, Wl[8], CL::P8, g, c); ST_FENCE(); fwdD_fr<1, 4>(fr, Bl[8], h8, e9, g); }
+        ST_SCHED_FENCE();
         // ------------------------------------------------------------------ d out  (D layout: t' = 4g + r)
-        f32x4 da9[NC][1];
-#pragma unroll
-        for (int ch = 0; ch < NC; ++ch) {
-            const float wf = fv[ch] ? expf(expfac * (float)ff[ch]) : 0.f;
+        f32x4 da9[1];
+        {
+            const float wf = fv ? expf(expfac * (float)f) : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int to = 4 * g + r;
                 float d9 = 0.f, tail = 0.f;
-                if (fv[ch] && to < OT) {
-                    const size_t ro = (size_t)bb[ch] * OT + to;
-                    const float gre = q_gre[ch][r], gim = q_gim[ch][r];
-                    const float ph = q_ph[ch][r], mh = q_mh[ch][r];
+                if (fv && to < OT) {
+                    const float gre = q_gre[r], gim = q_gim[r], ph = q_ph[r], mh = q_mh[r];
                     float sn, cs; sincosf(ph, &sn, &cs);
                     if (ae == 0) {
                         const float sg = mh > 0.f ? 1.f : (mh < 0.f ? -1.f : 0.f);
-                        float dmh = gre * cs + gim * sn + reg_coef * sg * wf;
-                        if (g_mag_hat) dmh += g_mag_hat[ro * F + ff[ch]];   // generic upstream gradient (autograd path)
-                        const float mt = q_mt[ch][r];
-                        d9 = dmh * mt * elu_grad_from_out(e9[ch][0][r]);
-                        tail = dmh * e9[ch][0][r];
+                        const float dmh = gre * cs + gim * sn + reg_coef * sg * wf + q_gm[r];
+                        d9 = dmh * q_mt[r] * elu_grad_from_out(e9[0][r]);
+                        tail = dmh * e9[0][r];
                     } else {
                         const float dph = mh * (gim * cs - gre * sn);
-                        d9 = dph * elu_grad_from_out(e9[ch][0][r]);
+                        d9 = dph * elu_grad_from_out(e9[0][r]);
                         tail = dph;
                     }
                 }
-                da9[ch][0][r] = d9;
-                Ts[ch][to * SP + c] = tail;
+                da9[0][r] = d9;
+                Ts[to * SP + c] = tail;
+                Ys[to * SP + c] = d9;                      // [feature t'][row c] -> read back transposed below
             }
         }
         // ------------------------------------------------------------------ backward through the layers
-        const float* const Yc[NC] = {Ys[0], Ys[1]};
-        const float* const Xc[NC] = {Xs[0], Xs[1]};
-        const float* const Vc[NC] = {Vs[0], Vs[1]};
-        // layer 9 (64 -> OT)
-        f32x4 da8[NC][4];
-#pragma unroll
-        for (int ch = 0; ch < NC; ++ch) { scratch_put<1>(Ys[ch], da9[ch], g, c); scratch_put<4>(Xs[ch], h8[ch], g, c); }
-        wgrad_mfma<NC, 1, 4>(Yc, Xc, dW9, g, c);
-        db[8] += scratch_rowsum<NC>(Yc, lane, 16);
-        layer_dgrad<NC, 1, 4>(Wl[8], L.P[8], da9, da8, g, c);
-        apply_elu_grad<NC, 4>(da8, h8);
-        // layer 8 (32 -> 64)
-        f32x4 da7[NC][2];
-#pragma unroll
-        for (int ch = 0; ch < NC; ++ch) { scratch_put<4>(Ys[ch], da8[ch], g, c); scratch_put<2>(Xs[ch], h7[ch], g, c); }
-        wgrad_mfma<NC, 4, 2>(Yc, Xc, dW8, g, c);
-        db[7] += scratch_rowsum<NC>(Yc, lane, 64);
-        layer_dgrad<NC, 4, 2>(Wl[7], L.P[7], da8, da7, g, c);
-        apply_elu_grad<NC, 2>(da7, h7);
-        // layer 7 (16 -> 32)
-        f32x4 da6[NC][1];
-#pragma unroll
-        for (int ch = 0; ch < NC; ++ch) { scratch_put<2>(Ys[ch], da7[ch], g, c); scratch_put<1>(Xs[ch], h6[ch], g, c); }
-        wgrad_mfma<NC, 2, 1>(Yc, Xc, dW7, g, c);
-        db[6] += scratch_rowsum<NC>(Yc, lane, 32);
-        layer_dgrad<NC, 2, 1>(Wl[6], L.P[6], da7, da6, g, c);
-        apply_elu_grad<NC, 1>(da6, h6);
-        // layer 6 (16 -> 16)
-        f32x4 da5[NC][1];
-#pragma unroll
-        for (int ch = 0; ch < NC; ++ch) { scratch_put<1>(Ys[ch], da6[ch], g, c); scratch_put<1>(Xs[ch], h5[ch], g, c); }
-        wgrad_mfma<NC, 1, 1>(Yc, Xc, dW6, g, c);
-        db[5] += scratch_rowsum<NC>(Yc, lane, 16);
-        layer_dgrad<NC, 1, 1>(Wl[5], L.P[5], da6, da5, g, c);
-        apply_elu_grad<NC, 1>(da5, h5);
-        // layer 5 ([h4 ; knobs] -> 16): weight gradient over both input tiles, data gradient to h4 only
-        f32x4 da4[NC][1];
-#pragma unroll
-        for (int ch = 0; ch < NC; ++ch) {
-            scratch_put<1>(Ys[ch], da5[ch], g, c);
-            scratch_put<1>(Xs[ch], h4[ch], g, c);
-            scratch_put<1>(Xs[ch] + 16 * SP, kn[ch], g, c);
+        // T layout: lane (g,c), reg r  <->  row 4g + r, feature 16*tile + c
+        f32x4 daT9[1];
+        { const float4 v = *reinterpret_cast<const float4*>(Ys + c * SP + 4 * g); daT9[0] = (f32x4){v.x, v.y, v.z, v.w}; }
+#define ST_WG(O_, I_, D_, P_, RW_, RB_, DB_, DAT_, HT_) \
+        if constexpr (REG) wgrad_reg<O_, I_>(RW_, RB_, DAT_, HT_); else wgrad_lds<O_, I_>(D_, P_, DAT_, HT_, DB_, g, c);
+        // layer 9 (64 -> OT): needs h8^T (layer-8 forward fragments) and W9 in dgrad order
+        f32x4 hT8[4], da8[4], daT8[4];
+        {
+            float ff[4 * 2 * 4], fd[1 * 4 * 4];
+            frags_fwd<4, 2>(ff, Wl[7], CL::P7, g, c); frags_dgrad<1, 4>(fd, Wl[8], CL::P8, g, c); ST_FENCE();
+            fwdT_fr<4, 2>(ff, Bl[7], h7, hT8, c);
+            ST_WG(1, 4, Dl[8], CL::P8, rW9, rb9, db9, daT9, hT8)
+            dgrad_fr<1, 4>(fd, da9, da8, daT8); mul_elu_grad<4>(da8, h8); mul_elu_grad<4>(daT8, hT8);
         }
-        wgrad_mfma<NC, 1, 2>(Yc, Xc, dW5, g, c);
-        db[4] += scratch_rowsum<NC>(Yc, lane, 16);
-        layer_dgrad<NC, 1, 1>(Wl[4], L.P[4], da5, da4, g, c);
-        apply_elu_grad<NC, 1>(da4, h4);
+        // layer 8 (32 -> 64)
+        f32x4 hT7[2], da7[2], daT7[2];
+        {
+            float ff[2 * 1 * 4], fd[4 * 2 * 4];
+            frags_fwd<2, 1>(ff, Wl[6], CL::P6, g, c); frags_dgrad<4, 2>(fd, Wl[7], CL::P7, g, c); ST_FENCE();
+            fwdT_fr<2, 1>(ff, Bl[6], h6, hT7, c);
+            ST_WG(4, 2, Dl[7], CL::P7, rW8, rb8, db8, daT8, hT7)
+            dgrad_fr<4, 2>(fd, da8, da7, daT7); mul_elu_grad<2>(da7, h7); mul_elu_grad<2>(daT7, hT7);
+        }
+        // layer 7 (16 -> 32)
+        f32x4 hT6[1], da6[1], daT6[1];
+        {
+            float ff[1 * 1 * 4], fd[2 * 1 * 4];
+            frags_fwd<1, 1>(ff, Wl[5], CL::P5, g, c); frags_dgrad<2, 1>(fd, Wl[6], CL::P6, g, c); ST_FENCE();
+            fwdT_fr<1, 1>(ff, Bl[5], h5, hT6, c);
+            ST_WG(2, 1, Dl[6], CL::P6, rW7, rb7, db7, daT7, hT6)
+            dgrad_fr<2, 1>(fd, da7, da6, daT6); mul_elu_grad<1>(da6, h6); mul_elu_grad<1>(daT6, hT6);
+        }
+        // layer 6 (16 -> 16); h5^T needs the knob k-steps of layer 5
+        f32x4 hT5[1], da5[1], daT5[1];
+        {
+            float fa[4], fb[4], fd[1 * 1 * 4];
+            const int P5 = CL::P4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { fa[r] = Wl[4][c * P5 + 4 * g + r]; fb[r] = Wl[4][c * P5 + 16 + 4 * g + r]; }
+            frags_dgrad<1, 1>(fd, Wl[5], CL::P5, g, c); ST_FENCE();
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = ST_MFMA16(h4[0][r], fa[r], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = ST_MFMA16(kn[0][r], fb[r], acc);
+            const float bv = Bl[4][c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hT5[0][r] = elu_f(acc[r] + bv);
+            ST_WG(1, 1, Dl[5], CL::P5, rW6, rb6, db6, daT6, hT5)
+            dgrad_fr<1, 1>(fd, da6, da5, daT5); mul_elu_grad<1>(da5, h5); mul_elu_grad<1>(daT5, hT5);
+        }
+        // layer 5 ([h4 ; knobs] -> 16): weight gradient over both input tiles, data gradient to h4 only
+        f32x4 hT4[1], hT4k[2], da4[1], daT4[1];
+        {
+            float ff[1 * 1 * 4], fd[1 * 1 * 4];
+            frags_fwd<1, 1>(ff, Wl[3], CL::P3, g, c); frags_dgrad<1, 1>(fd, Wl[4], CL::P4, g, c); ST_FENCE();
+            fwdT_fr<1, 1>(ff, Bl[3], h3, hT4, c);
+            hT4k[0] = hT4[0];
+            { const float kv = c < K ? knobs[(size_t)b * K + c] : 0.f; hT4k[1] = (f32x4){kv, kv, kv, kv}; }   // features 16 + c = knob c, every row
+            ST_WG(1, 2, Dl[4], CL::P4, rW5, rb5, db5, daT5, hT4k)
+            dgrad_fr<1, 1>(fd, da5, da4, daT4); mul_elu_grad<1>(da4, h4); mul_elu_grad<1>(daT4, hT4);
+        }
         // layer 4 (16 -> 16)
-        f32x4 da3[NC][1];
-#pragma unroll
-        for (int ch = 0; ch < NC; ++ch) { scratch_put<1>(Ys[ch], da4[ch], g, c); scratch_put<1>(Xs[ch], h3[ch], g, c); }
-        wgrad_mfma<NC, 1, 1>(Yc, Xc, dW4, g, c);
-        db[3] += scratch_rowsum<NC>(Yc, lane, 16);
-        layer_dgrad<NC, 1, 1>(Wl[3], L.P[3], da4, da3, g, c);
-        apply_elu_grad<NC, 1>(da3, h3);
+        f32x4 hT3[1], da3[1], daT3[1];
+        {
+            float ff[1 * 2 * 4], fd[1 * 1 * 4];
+            frags_fwd<1, 2>(ff, Wl[2], CL::P2, g, c); frags_dgrad<1, 1>(fd, Wl[3], CL::P3, g, c); ST_FENCE();
+            fwdT_fr<1, 2>(ff, Bl[2], h2, hT3, c);
+            ST_WG(1, 1, Dl[3], CL::P3, rW4, rb4, db4, daT4, hT3)
+            dgrad_fr<1, 1>(fd, da4, da3, daT3); mul_elu_grad<1>(da3, h3); mul_elu_grad<1>(daT3, hT3);
+        }
         // layer 3 (32 -> 16)
-        f32x4 da2[NC][2];
+        f32x4 hT2[2], da2[2], daT2[2];
+        {
+            float ff[2 * 4 * 4], fd[1 * 2 * 4];
+            frags_fwd<2, 4>(ff, Wl[1], CL::P1, g, c); frags_dgrad<1, 2>(fd, Wl[2], CL::P2, g, c); ST_FENCE();
+            fwdT_fr<2, 4>(ff, Bl[1], h1, hT2, c);
+            ST_WG(1, 2, Dl[2], CL::P2, rW3, rb3, db3, daT3, hT2)
+            dgrad_fr<1, 2>(fd, da3, da2, daT2); mul_elu_grad<2>(da2, h2); mul_elu_grad<2>(daT2, hT2);
+        }
+        // layer 2 (64 -> 32); h1^T from the input rows
+        f32x4 hT1[4], da1[4], daT1[4];
+        {
+            float ff[4 * 8], fd[2 * 4 * 4];
+            const int P1 = CL::P0;
 #pragma unroll
-        for (int ch = 0; ch < NC; ++ch) { scratch_put<1>(Ys[ch], da3[ch], g, c); scratch_put<2>(Xs[ch], h2[ch], g, c); }
-        wgrad_mfma<NC, 1, 2>(Yc, Xc, dW3, g, c);
-        db[2] += scratch_rowsum<NC>(Yc, lane, 16);
-        layer_dgrad<NC, 1, 2>(Wl[2], L.P[2], da3, da2, g, c);
-        apply_elu_grad<NC, 2>(da2, h2);
-        // layer 2 (64 -> 32)
-        f32x4 da1[NC][4];
+            for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
-        for (int ch = 0; ch < NC; ++ch) { scratch_put<2>(Ys[ch], da2[ch], g, c); scratch_put<4>(Xs[ch], h1[ch], g, c); }
-        wgrad_mfma<NC, 2, 4>(Yc, Xc, dW2, g, c);
-        db[1] += scratch_rowsum<NC>(Yc, lane, 32);
-        layer_dgrad<NC, 2, 4>(Wl[1], L.P[1], da2, da1, g, c);
-        apply_elu_grad<NC, 4>(da1, h1);
-        // layer 1 (T -> 64): input rows were staged in Vs during the forward pass
-        f32x4 dv[NC][2];
+                for (int ks = 0; ks < 8; ++ks) ff[ot * 8 + ks] = Wl[0][(16 * ot + c) * P1 + 4 * ks + g];
+            frags_dgrad<2, 4>(fd, Wl[1], CL::P1, g, c); ST_FENCE();
 #pragma unroll
-        for (int ch = 0; ch < NC; ++ch) scratch_put<4>(Ys[ch], da1[ch], g, c);
-        wgrad_mfma<NC, 4, 2>(Yc, Vc, dW1, g, c);
-        db[0] += scratch_rowsum<NC>(Yc, lane, 64);
-        layer_dgrad<NC, 4, 2>(Wl[0], L.P[0], da1, dv, g, c);
+            for (int ot = 0; ot < 4; ++ot) {
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    if (ks < KS1) acc = ST_MFMA16(vr[ks], ff[ot * 8 + ks], acc);
+                const float bv = Bl[0][16 * ot + c];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hT1[ot][r] = elu_f(acc[r] + bv);
+            }
+            ST_WG(2, 4, Dl[1], CL::P1, rW2, rb2, db2, daT2, hT1)
+            dgrad_fr<2, 4>(fd, da2, da1, daT1); mul_elu_grad<4>(da1, h1); mul_elu_grad<4>(daT1, hT1);
+        }
+        // layer 1 (T -> 64): input rows transposed through the wave's scratch
+        f32x4 vT[2], dv[2];
+        {
+            float fd[4 * 2 * 4];
+            frags_dgrad<4, 2>(fd, Wl[0], CL::P0, g, c);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) { const float4 v = *reinterpret_cast<const float4*>(Vs + (16 * it + c) * SP + 4 * g); vT[it] = (f32x4){v.x, v.y, v.z, v.w}; }
+            ST_FENCE();
+            ST_WG(4, 2, Dl[0], CL::P0, rW1, rb1, db1, daT1, vT)
+            dgradD_fr<4, 2>(fd, da1, dv);
+        }
+#undef ST_WG
         // ------------------------------------------------------------------ d input rows (+ skip / residual tails)
 #pragma unroll
-        for (int ch = 0; ch < NC; ++ch)
+        for (int it = 0; it < 2; ++it)
 #pragma unroll
-            for (int it = 0; it < 2; ++it)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int t = 16 * it + 4 * g + r;
-                    if (fv[ch] && t < T) {
-                        float v = dv[ch][it][r];
-                        if (t >= T - OT) v += Ts[ch][(t - (T - OT)) * SP + c];
-                        dvout[((size_t)bb[ch] * T + t) * F + ff[ch]] = v;
-                    }
+            for (int r = 0; r < 4; ++r) {
+                const int t = 16 * it + 4 * g + r;
+                if (fv && t < T) {
+                    float v = dv[it][r];
+                    if (t >= T - OT) v += Ts[(t - (T - OT)) * SP + c];
+                    dvout[((size_t)b * T + t) * F + f] = v;
                 }
-    }
-    // ---------------------------------------------------------------------- per-wave partial gradients
-    float* base = ws + ((size_t)(blockIdx.x * NW + wave) * 2 + ae) * PG;
-    for (int i = lane; i < PG; i += 64) base[i] = 0.f;        // alignment pads and never-touched entries
-    __builtin_amdgcn_s_waitcnt(0);                             // (stores below overwrite; same lane order not guaranteed across lanes)
-    __builtin_amdgcn_wave_barrier();
-    store_dw(base, go.w[0], L.OUT[0], L.IN[0], dW1, g, c);
-    store_dw(base, go.w[1], L.OUT[1], L.IN[1], dW2, g, c);
-    store_dw(base, go.w[2], L.OUT[2], L.IN[2], dW3, g, c);
-    store_dw(base, go.w[3], L.OUT[3], L.IN[3], dW4, g, c);
-    store_dw(base, go.w[4], L.OUT[4], L.IN[4], dW5, g, c);
-    store_dw(base, go.w[5], L.OUT[5], L.IN[5], dW6, g, c);
-    store_dw(base, go.w[6], L.OUT[6], L.IN[6], dW7, g, c);
-    store_dw(base, go.w[7], L.OUT[7], L.IN[7], dW8, g, c);
-    store_dw(base, go.w[8], L.OUT[8], L.IN[8], dW9, g, c);
+            }
 #pragma unroll
-    for (int l = 0; l < NL; ++l)
-        if (lane < L.OUT[l]) base[go.b[l] + lane] = db[l];
+        for (int ks = 0; ks < 8; ++ks) vr[ks] = vn[ks];
+    }
+    // ---------------------------------------------------------------------- workgroup partial gradients
+    if constexpr (REG) {
+        dw_flush<4, 2>(Dl[0], CL::P0, rW1, g, c); dw_flush<2, 4>(Dl[1], CL::P1, rW2, g, c); dw_flush<1, 2>(Dl[2], CL::P2, rW3, g, c);
+        dw_flush<1, 1>(Dl[3], CL::P3, rW4, g, c); dw_flush<1, 2>(Dl[4], CL::P4, rW5, g, c); dw_flush<1, 1>(Dl[5], CL::P5, rW6, g, c);
+        dw_flush<2, 1>(Dl[6], CL::P6, rW7, g, c); dw_flush<4, 2>(Dl[7], CL::P7, rW8, g, c); dw_flush<1, 4>(Dl[8], CL::P8, rW9, g, c);
+        db_flush<4>(db1, rb1, g, c); db_flush<2>(db2, rb2, g, c); db_flush<1>(db3, rb3, g, c); db_flush<1>(db4, rb4, g, c);
+        db_flush<1>(db5, rb5, g, c); db_flush<1>(db6, rb6, g, c); db_flush<2>(db7, rb7, g, c); db_flush<4>(db8, rb8, g, c);
+        db_flush<1>(db9, rb9, g, c);
+    }
+    __syncthreads();
+    float* base = ws + ((size_t)blockIdx.x * 2 + ae) * PG;
+    for (int i = tid; i < PG; i += NW * 64) base[i] = 0.f;                 // alignment pads
+    __syncthreads();
+    for (int l = 0; l < NL; ++l) {
+        const int P = L.P[l], IN = L.IN[l], n = L.OUT[l] * IN;
+        for (int e = tid; e < n; e += NW * 64) { const int o = e / IN; base[go.w[l] + e] = dwl[L.w[l] + o * P + (e - o * IN)]; }
+        if (tid < L.OUT[l]) base[go.b[l] + tid] = dwl[L.b[l] + tid];
+    }
 }
 
 }  // namespace sta

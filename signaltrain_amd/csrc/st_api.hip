@@ -149,9 +149,15 @@ static int num_cus()
     return n;
 }
 static const int AE_FWD_NW = 8, AE_BWD_NW = 4;
+static const bool AE_BWD_REG = true;     // persistent register accumulators, 1 wave/SIMD (LDS float atomics per group measured 3x slower)
+static int synth_live_rows(const st_dims* d);
 static int ae_fwd_grid(const st_dims* d) { int g = (d->B * (st_kp_of(d->F) / 32) + AE_FWD_NW - 1) / AE_FWD_NW; int c = num_cus(); return g < c ? g : c; }
-static int ae_bwd_grid(const st_dims* d) { int pairs = (d->B * (st_kp_of(d->F) / 32) + 1) / 2; int g = (pairs + AE_BWD_NW - 1) / AE_BWD_NW; int c = num_cus() / 2; if (c < 1) c = 1; return g < c ? g : c; }
-static int wgrad_split(int R) { int s = R / 512; if (s < 1) s = 1; if (s > 4) s = 4; return s; }
+static int ae_bwd_grid(const st_dims* d) { int groups = d->B * (st_kp_of(d->F) / 32); int g = (groups + AE_BWD_NW - 1) / AE_BWD_NW; int c = num_cus() / 2; if (c < 1) c = 1; return g < c ? g : c; }
+// split-K factors.  fp32 MFMA tiles are long serial chains (48 MFMAs x 64 cycles per k-tile per wave), so a GEMM
+// needs >= ~2 waves per SIMD (2048 waves) to overlap its load/LDS phases; the small-M synthesis GEMMs and the
+// 121-tile weight-gradient GEMMs get there by splitting K and summing the slabs in the consumer kernel.
+static int wgrad_split(int R) { int s = R / 200; if (s < 1) s = 1; if (s > 8) s = 8; return s; }
+static int synth_split(int R) { return R >= 4096 ? 1 : 3; }
 
 extern "C" int st_ae_fwd_partials(const st_dims* d) { return ae_fwd_grid(d) * AE_FWD_NW; }
 extern "C" int st_ola_loss_partials(const st_dims* d) { return d->B * ((d->y + 255) / 256); }
@@ -161,10 +167,11 @@ extern "C" size_t st_wgrad_ws_floats(const st_dims* d)
     const int s = wgrad_split(d->B * d->T);
     return (size_t)s * st_kp_of(d->F) * d->N;
 }
+extern "C" int st_synth_slabs(const st_dims* d) { return synth_split(synth_live_rows(d)); }
 extern "C" size_t st_ae_bwd_ws_floats(const st_dims* d)
 {
     Layout L; if (make_layout(d, &L) != ST_OK) return 0;
-    return (size_t)ae_bwd_grid(d) * AE_BWD_NW * 2 * L.PG;
+    return (size_t)ae_bwd_grid(d) * 2 * L.PG;
 }
 
 // ------------------------------------------------------------------------------ per-op entry points
@@ -223,6 +230,7 @@ extern "C" int st_synth_fold(const st_dims* d, const float* Sr, const float* Si,
 }
 
 static stg::RowMap synth_live(const st_dims* d) { return stg::live_frames(d->OT, d->H, d->N, d->N, d->y); }
+static int synth_live_rows(const st_dims* d) { return synth_live(d).rows(d->B); }
 
 extern "C" int st_synthesis_frames(const st_dims* d, const float* AA, const float* Sfold, float* frs, void* stream)
 {
@@ -232,9 +240,10 @@ extern "C" int st_synthesis_frames(const st_dims* d, const float* AA, const floa
     const int R = ms.rows(d->B);
     stg::PlainNT al{AA, R, KP, KP, ms};
     stg::PlainTN bl{Sfold, KP, d->N, d->N, stg::all_frames(1)};
-    stg::StoreC ep{frs, R, d->N, d->N, 0, ms};
+    // frs holds st_synth_slabs() split-K slabs [B*OT, N]; st_ola_loss sums them
+    stg::StoreC ep{frs, R, d->N, d->N, (size_t)d->B * d->OT * d->N, ms};
     if (R >= 4096) stg::launch<4>(al, bl, ep, R, d->N, KP, 1, st_stream(stream));
-    else stg::launch<2>(al, bl, ep, R, d->N, KP, 1, st_stream(stream));
+    else stg::launch<2>(al, bl, ep, R, d->N, KP, synth_split(R), st_stream(stream));
     ST_LAUNCHED("synthesis_frames"); return ST_OK;
 }
 
@@ -244,7 +253,8 @@ extern "C" int st_ola_loss(const st_dims* d, const float* frs, const float* x, c
     ST_TRY(check_dims(d)); ST_REQ(frs, "st_ola_loss: null pointer");
     const float inv = 1.0f / ((float)d->B * (float)d->y);
     hipLaunchKernelGGL(stm::ola_loss_kernel, dim3((d->y + 255) / 256, d->B), dim3(256), 0, st_stream(stream),
-                       frs, x, y_true, y_hat, dsyn, loss_partial, d->L, d->N, d->H, d->OT, d->y, inv);
+                       frs, x, y_true, y_hat, dsyn, loss_partial, d->L, d->N, d->H, d->OT, d->y, inv,
+                       st_synth_slabs(d), (size_t)d->B * d->OT * d->N);
     ST_LAUNCHED("ola_loss"); return ST_OK;
 }
 
@@ -258,9 +268,10 @@ extern "C" int st_synthesis_dgrad(const st_dims* d, const float* dsyn, const flo
     // Rows of dAA for dead frames are NOT written (st_ae_bwd treats them as zero).
     stg::FramedNT al{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms};
     stg::PlainNT bl{Sfold, KP, d->N, d->N, stg::all_frames(1)};
-    stg::StoreC ep{dAA, R, KP, KP, 0, ms};
+    // dAA holds st_synth_slabs() split-K slabs [B*OT, KP]; st_ae_bwd sums them
+    stg::StoreC ep{dAA, R, KP, KP, (size_t)d->B * d->OT * KP, ms};
     if (R >= 4096) stg::launch<4>(al, bl, ep, R, KP, d->N, 1, st_stream(stream));
-    else stg::launch<2>(al, bl, ep, R, KP, d->N, 1, st_stream(stream));
+    else stg::launch<2>(al, bl, ep, R, KP, d->N, synth_split(R), st_stream(stream));
     ST_LAUNCHED("synthesis_dgrad"); return ST_OK;
 }
 
@@ -277,10 +288,8 @@ extern "C" int st_synthesis_wgrad(const st_dims* d, const float* AA, const float
     stg::StoreC ep{ws, KP, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
     stg::launch<3>(al, bl, ep, KP, d->N, R, ns, st_stream(stream));
     ST_LAUNCHED("synthesis_wgrad");
-    const int ksplit = st_round_up((R + ns - 1) / ns, stg::BK);
-    const int nz = (R + ksplit - 1) / ksplit;
     hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(2 * d->F), dim3(256), 0, st_stream(stream),
-                       ws, nz, gSr, gSi, norm_partial, d->N, d->F, KP, 1);
+                       ws, ns, gSr, gSi, norm_partial, d->N, d->F, KP, 1);
     ST_LAUNCHED("synthesis_wgrad_reduce"); return ST_OK;
 }
 
@@ -294,18 +303,18 @@ extern "C" int st_ae_bwd(const st_dims* d, const float* mag, const float* phs, c
     if (d->T > 32 || d->OT > 16)
         return st_fail(ST_ERR_UNSUPPORTED, "st_ae_bwd: T=%d OT=%d not instantiated yet (T<=32, OT<=16)", d->T, d->OT);
     const sta::AELds ll = sta::ae_lds_layout(d->T, d->OT, d->K);
-    const size_t lds = ((size_t)ll.total + (size_t)AE_BWD_NW * 2 * (32 + 64 + 64 + 16) * sta::SP) * sizeof(float);
+    const size_t lds = ((size_t)2 * ll.total + (size_t)AE_BWD_NW * (32 + 16 + 16) * sta::SP) * sizeof(float);
     ST_REQ(lds <= 160 * 1024, "st_ae_bwd: needs %zu B of LDS", lds);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, AE_BWD_REG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     const float expfac = (float)(7.0 / d->F);
     const int grid = ae_bwd_grid(d);
-    hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, st_stream(stream),
+    hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, AE_BWD_REG>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, st_stream(stream),
                        mag, phs, knobs, ae_m, ae_p, L.go, L.PG, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, expfac,
-                       dmag, dphs, ws, d->B, d->T, d->OT, d->F, d->K, L.KP, synth_live(d).t_lo, synth_live(d).t_lo + synth_live(d).Tv - 1);
+                       dmag, dphs, ws, d->B, d->T, d->OT, d->F, d->K, L.KP, synth_live(d).t_lo, synth_live(d).t_lo + synth_live(d).Tv - 1, st_synth_slabs(d), (size_t)d->B * d->OT * L.KP);
     ST_LAUNCHED("ae_bwd");
-    hipLaunchKernelGGL(stm::ae_grad_reduce_kernel, dim3((L.PG + 255) / 256, 2), dim3(256), 0, st_stream(stream),
-                       ws, grid * AE_BWD_NW, L.PG, g_m, g_p);
+    hipLaunchKernelGGL(stm::ae_grad_reduce_kernel, dim3((L.PG + 63) / 64, 2), dim3(256), 0, st_stream(stream),
+                       ws, grid, L.PG, g_m, g_p);
     ST_LAUNCHED("ae_grad_reduce"); return ST_OK;
 }
 
@@ -332,10 +341,8 @@ extern "C" int st_analysis_wgrad(const st_dims* d, const float* dG, const float*
     stg::StoreC ep{ws, KP, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
     stg::launch<3>(al, bl, ep, KP, d->N, R, ns, st_stream(stream));
     ST_LAUNCHED("analysis_wgrad");
-    const int ksplit = st_round_up((R + ns - 1) / ns, stg::BK);
-    const int nz = (R + ksplit - 1) / ksplit;
     hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(2 * d->F), dim3(256), 0, st_stream(stream),
-                       ws, nz, gWr, gWi, norm_partial, d->N, d->F, KP, 0);
+                       ws, ns, gWr, gWi, norm_partial, d->N, d->F, KP, 0);
     ST_LAUNCHED("analysis_wgrad_reduce"); return ST_OK;
 }
 
@@ -380,8 +387,9 @@ static void carve(const st_dims* d, void* base, WS* w)
     auto take = [&](size_t n) { float* p = base ? reinterpret_cast<float*>(base) + off : nullptr; off += (n + 63) / 64 * 64; return p; };
     w->re = take(RT * F); w->im = take(RT * F); w->mag = take(RT * F); w->phs = take(RT * F);
     w->mag_hat = take(RO * F); w->phs_hat = take(RO * F);
-    w->AA = take(RO * KP); w->dAA = take(RO * KP);
-    w->Sfold = take(KP * N); w->frs = take(RO * N);
+    const size_t nsl = st_synth_slabs(d);
+    w->AA = take(RO * KP); w->dAA = take(nsl * RO * KP);
+    w->Sfold = take(KP * N); w->frs = take(nsl * RO * N);
     w->y_hat = take((size_t)d->B * d->y); w->dsyn = take((size_t)d->B * d->y);
     w->dmag = take(RT * F); w->dphs = take(RT * F); w->dG = take(RT * KP);
     w->wg = take(st_wgrad_ws_floats(d)); w->aews = take(st_ae_bwd_ws_floats(d));

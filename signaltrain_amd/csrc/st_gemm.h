@@ -330,8 +330,8 @@ static inline void launch(const AL& al, const BL& bl, const EPI& epi, int M, int
     constexpr int BM = 32 * WAVES_M;
     int ksplit = K;
     if (nsplit > 1) ksplit = st_round_up((K + nsplit - 1) / nsplit, BK);
-    const int nz = (K + ksplit - 1) / ksplit;
-    dim3 grid((Nc + BN - 1) / BN, (M + BM - 1) / BM, nz);
+    // exactly nsplit z-slices: a slice that starts past K stores zeros, so consumers sum a fixed slab count
+    dim3 grid((Nc + BN - 1) / BN, (M + BM - 1) / BM, nsplit > 1 ? nsplit : 1);
     hipLaunchKernelGGL((gemm_kernel<WAVES_M, AL, BL, EPI>), grid, dim3(WAVES_M * 64), 0, s, al, bl, epi, K, ksplit);
 }
 

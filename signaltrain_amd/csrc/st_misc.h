@@ -55,7 +55,7 @@ zero_dead_frames_kernel(float* __restrict__ a0, float* __restrict__ a1, float* _
 __global__ void __launch_bounds__(256)
 ola_loss_kernel(const float* __restrict__ frs, const float* __restrict__ x, const float* __restrict__ y_true,
                 float* __restrict__ y_hat, float* __restrict__ dsyn, float* __restrict__ loss_partial,
-                int L, int N, int H, int OT, int ysz, float inv_count)
+                int L, int N, int H, int OT, int ysz, float inv_count, int nslab, size_t slab)
 {
     __shared__ float red[4];
     const int b = blockIdx.y;
@@ -67,7 +67,8 @@ ola_loss_kernel(const float* __restrict__ frs, const float* __restrict__ x, cons
         if (t1 > OT - 1) t1 = OT - 1;
         const float* fb = frs + (size_t)b * OT * N;
         float s = 0.f;
-        for (int t = t0; t <= t1; ++t) s += fb[(size_t)t * N + (N + j - H * t)];
+        for (int t = t0; t <= t1; ++t)
+            for (int z = 0; z < nslab; ++z) s += fb[z * slab + (size_t)t * N + (N + j - H * t)];   // split-K slabs of the synthesis GEMM
         const float out = x ? 2.0f * (s + 0.5f * x[(size_t)b * L + (L - ysz) + j]) : s;   // x == NULL: plain Synthesis.forward (cls_fe_dft.py:112-113)
         if (y_hat) y_hat[(size_t)b * ysz + j] = out;
         if (y_true) {
@@ -167,16 +168,29 @@ l1_partial_kernel(const float* __restrict__ g, int64_t n, float scale, float* __
 }
 
 // ---------------------------------------------------------------- per-wave AE gradient partial reduce
-// ws[nparts][2][PG] -> g_m[PG], g_p[PG]
+// ws[nparts][2][PG] -> g_m[PG], g_p[PG].  Block = 64 columns x 4 partial-lanes; 8 loads in flight per thread.
 __global__ void __launch_bounds__(256)
 ae_grad_reduce_kernel(const float* __restrict__ ws, int nparts, int PG, float* __restrict__ g_m, float* __restrict__ g_p)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + col;
     const int ae = blockIdx.y;
-    if (i >= PG) return;
     float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += ws[((size_t)p * 2 + ae) * PG + i];
-    (ae ? g_p : g_m)[i] = s;
+    if (i < PG) {
+        const float* base = ws + (size_t)ae * PG + i;
+        const size_t stride = (size_t)2 * PG;
+        for (int p0 = pl; p0 < nparts; p0 += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int p = p0 + 4 * u; v[u] = p < nparts ? base[(size_t)p * stride] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+    }
+    red[pl][col] = s;
+    __syncthreads();
+    if (pl == 0 && i < PG) (ae ? g_p : g_m)[i] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
 }
 
 // ---------------------------------------------------------------- scalars

@@ -142,15 +142,16 @@ def run_all(B=3, seed=0, K=4, verbose=False):
     sf_re, sf_im = n(Sfold)[:F], n(Sfold)[KP // 2:KP // 2 + F]
     res += [err("fold.re", sf_re, fr_), err("fold.im", sf_im, fi_, scale=np.abs(fr_).max())]
     AAo = t(to_kp(c["Are"].reshape(-1, F), c["Aim"].reshape(-1, F), KP))
-    frs = z(B * OT, N)
+    nsl = lib.st_synth_slabs(C.byref(d))
+    frs = z(nsl, B * OT, N)
     _lib.check(lib.st_synthesis_frames(C.byref(d), _lib.ptr(AAo), _lib.ptr(Sfold), _lib.ptr(frs), stream()), "synth")
     frs_ref = c["Are"].reshape(-1, F) @ fr_ + c["Aim"].reshape(-1, F) @ fi_
     # only frames that reach the cropped output are computed (t with 0 < H t and H t - N < y)
     live = np.array([(geo["H"] * tt > 0) and (geo["H"] * tt - N < geo["y"]) for tt in range(OT)])
-    res.append(err("synthesis.frames", n(frs).reshape(B, OT, N)[:, live], frs_ref.reshape(B, OT, N)[:, live]))
+    res.append(err("synthesis.frames", n(frs).sum(0).reshape(B, OT, N)[:, live], frs_ref.reshape(B, OT, N)[:, live]))
     y_hat, dsyn = z(B, d.y), z(B, d.y)
     lp = z(lib.st_ola_loss_partials(C.byref(d)))
-    frs_o = t(frs_ref)
+    frs_o = z(nsl, B * OT, N); frs_o[0] = t(frs_ref)
     _lib.check(lib.st_ola_loss(C.byref(d), _lib.ptr(frs_o), _lib.ptr(x), _lib.ptr(y), _lib.ptr(y_hat), _lib.ptr(dsyn),
                                _lib.ptr(lp), stream()), "ola")
     res += [err("ola.y_hat", n(y_hat), c["out"]), err("ola.dsyn", n(dsyn), 2 * c["dy"]),
@@ -158,9 +159,9 @@ def run_all(B=3, seed=0, K=4, verbose=False):
 
     # 4. synthesis dgrad / wgrad
     dsyn_o = t(2 * c["dy"])
-    dAA = z(B * OT, KP)
+    dAA = z(nsl, B * OT, KP)
     _lib.check(lib.st_synthesis_dgrad(C.byref(d), _lib.ptr(dsyn_o), _lib.ptr(Sfold), _lib.ptr(dAA), stream()), "dgrad")
-    g_re, g_im = from_kp(n(dAA), F)
+    g_re, g_im = from_kp(n(dAA).sum(0), F)
     sd = float(max(np.abs(c["dAre"]).max(), np.abs(c["dAim"]).max()))
     res += [err("syn_dgrad.dAre", g_re.reshape(B, OT, F), c["dAre"], scale=sd),
             err("syn_dgrad.dAim", g_im.reshape(B, OT, F), c["dAim"], scale=sd)]
@@ -175,7 +176,7 @@ def run_all(B=3, seed=0, K=4, verbose=False):
             err("syn_wgrad.l1", n(norm_s).sum(), np.abs(G[STFT_KEYS[2]]).sum() + np.abs(G[STFT_KEYS[3]]).sum(), tol=1e-3)]
 
     # 5. autoencoders backward (oracle inputs)
-    dAAo = t(to_kp(c["dAre"].reshape(-1, F), c["dAim"].reshape(-1, F), KP))
+    dAAo = z(nsl, B * OT, KP); dAAo[0] = t(to_kp(c["dAre"].reshape(-1, F), c["dAim"].reshape(-1, F), KP))
     mh_o, ph_o = t(c["mag_hat"]), t(c["phs_hat"])
     dmag, dphs = z(B, T, F), z(B, T, F)
     aews = z(lib.st_ae_bwd_ws_floats(C.byref(d)))

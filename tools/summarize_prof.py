@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 CSV output (kernel stats + PMC counters per kernel) into a small text table."""
+import csv, glob, os, sys, collections
+root = sys.argv[1]
+
+
+def short(n):
+    n = n.replace("stg::", "").replace("sta::", "").replace("stm::", "")
+    for a, b in (("gemm_kernel<4, FramedNT, AnalysisW, PolarStore>", "gemm:analysis_fwd"),
+                 ("gemm_kernel<3, PlainTN, FramedTN, StoreC>", "gemm:wgrad(TN)"),
+                 ("gemm_kernel<2, PlainNT, PlainTN, StoreC>", "gemm:synthesis_frames"),
+                 ("gemm_kernel<2, FramedNT, PlainNT, StoreC>", "gemm:synthesis_dgrad")):
+        if a in n:
+            return b
+    return n.split("(")[0][:60]
+
+
+for f in sorted(glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True)):
+    print("== kernel stats:", os.path.relpath(f, root))
+    rows = list(csv.DictReader(open(f)))
+    for r in rows[:24]:
+        print(f"  {short(r['Name']):44s} calls={r['Calls']:>5s} avg_ns={float(r['AverageNs']):>10.0f} total%={r['Percentage']}")
+for sub in ("pmc1", "pmc2", "pmc3", "pmc4", "pmc5"):
+    for f in sorted(glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True)):
+        print("== counters:", os.path.relpath(f, root))
+        acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"]); acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+        for k in acc:
+            print("  " + k[:44].ljust(44) + "  " + "  ".join(f"{c}={v / max(cnt[(k, c)], 1):.4g}" for c, v in sorted(acc[k].items())))
