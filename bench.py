@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="windows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--bk", type=int, default=0, help="GEMM k-tile depth override (16/32)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -66,6 +67,8 @@ def main():
     nn_proc._QUIET = True
 
     B = args.batch
+    if args.bk:
+        _lib.check(_lib.load().st_set_tuning(args.bk), 'st_set_tuning')
     d = _lib.geometry(1, 4, 4, B)
     # identical init on every rank (run_train.py:20-21 seeds 218), distinct data per rank
     torch.manual_seed(218); np.random.seed(218)

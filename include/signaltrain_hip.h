@@ -44,6 +44,12 @@ int st_kp(int F);
 const char* st_last_error(void);
 int st_version(void);
 
+/* Tuning knob (process-wide): k-tile depth of the GEMM family, 16 (default) or 32. */
+int st_set_tuning(int bk);
+/* Timing-only ablation switches for diagnostics (bit0: skip k-loop loads/stores, bit1: skip barriers, bit2: skip MFMAs);
+ * results are INVALID when non-zero.  Never set by the product path. */
+int st_set_debug(int v);
+
 /* Optional per-kernel HIP-event profiling of the fused entry points (off by default; used by
  * bench.py's roofline leg outside the timed region).  st_profile_report fills buf with
  * "kernel_name total_ms launches\n" lines; synchronise the stream first. */

@@ -31,6 +31,8 @@ SIGNATURES = {
     "st_kp": (_i, [_i]),
     "st_last_error": (C.c_char_p, []),
     "st_version": (_i, []),
+    "st_set_tuning": (_i, [_i]),
+    "st_set_debug": (_i, [_i]),
     "st_profile_enable": (_i, [_i]),
     "st_profile_report": (_i, [C.c_char_p, _i]),
     "st_geometry": (_i, [C.c_double, C.c_double, _i, _i, _i, _D]),

@@ -148,6 +148,11 @@ static int num_cus()
     if (!n) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t p; if (hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount; if (n <= 0) n = 256; }
     return n;
 }
+static int g_dbg = 0;   // timing-only ablation switches (bench/diagnostics); results are invalid when non-zero
+extern "C" int st_set_debug(int v) { g_dbg = v; return ST_OK; }
+static int g_bk = 16;   // k-tile depth of the GEMM family (16: 36 KB LDS/WG -> 4 WGs/CU; 32: 64 KB -> 2 WGs/CU)
+extern "C" int st_set_tuning(int bk) { if (bk != 16 && bk != 32) return st_fail(ST_ERR_ARG, "bk must be 16 or 32"); g_bk = bk; return ST_OK; }
+#define ST_GEMM(W_, ...) do { if (g_bk == 16) stg::launch<W_, 16>(__VA_ARGS__, g_dbg); else stg::launch<W_, 32>(__VA_ARGS__, g_dbg); } while (0)
 static const int AE_FWD_NW = 8, AE_BWD_NW = 4;
 static const bool AE_BWD_REG = true;     // persistent register accumulators, 1 wave/SIMD (LDS float atomics per group measured 3x slower)
 static int synth_live_rows(const st_dims* d);
@@ -184,7 +189,7 @@ extern "C" int st_analysis_fwd(const st_dims* d, const float* x, const float* Wr
     stg::FramedNT al{x, d->L, d->H, d->N, R, d->N, in_scale, map};
     stg::AnalysisW bl{Wr, Wi, d->F, d->N};
     stg::PolarStore ep{re, im, mag, phs, R, d->F, map};
-    stg::launch<4>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream));
+    ST_GEMM(4, al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream));
     ST_LAUNCHED("analysis_fwd");
     if (map.Tv < d->T) {                   // ... and are exact zeros (re=im=mag=0, phs=atan2(0,1e-7)=0)
         hipLaunchKernelGGL(stm::zero_dead_frames_kernel, dim3(d->B * (d->T - map.Tv)), dim3(256), 0, st_stream(stream),
@@ -242,8 +247,8 @@ extern "C" int st_synthesis_frames(const st_dims* d, const float* AA, const floa
     stg::PlainTN bl{Sfold, KP, d->N, d->N, stg::all_frames(1)};
     // frs holds st_synth_slabs() split-K slabs [B*OT, N]; st_ola_loss sums them
     stg::StoreC ep{frs, R, d->N, d->N, (size_t)d->B * d->OT * d->N, ms};
-    if (R >= 4096) stg::launch<4>(al, bl, ep, R, d->N, KP, 1, st_stream(stream));
-    else stg::launch<2>(al, bl, ep, R, d->N, KP, synth_split(R), st_stream(stream));
+    if (R >= 4096) ST_GEMM(4, al, bl, ep, R, d->N, KP, 1, st_stream(stream));
+    else ST_GEMM(2, al, bl, ep, R, d->N, KP, synth_split(R), st_stream(stream));
     ST_LAUNCHED("synthesis_frames"); return ST_OK;
 }
 
@@ -270,8 +275,8 @@ extern "C" int st_synthesis_dgrad(const st_dims* d, const float* dsyn, const flo
     stg::PlainNT bl{Sfold, KP, d->N, d->N, stg::all_frames(1)};
     // dAA holds st_synth_slabs() split-K slabs [B*OT, KP]; st_ae_bwd sums them
     stg::StoreC ep{dAA, R, KP, KP, (size_t)d->B * d->OT * KP, ms};
-    if (R >= 4096) stg::launch<4>(al, bl, ep, R, KP, d->N, 1, st_stream(stream));
-    else stg::launch<2>(al, bl, ep, R, KP, d->N, synth_split(R), st_stream(stream));
+    if (R >= 4096) ST_GEMM(4, al, bl, ep, R, KP, d->N, 1, st_stream(stream));
+    else ST_GEMM(2, al, bl, ep, R, KP, d->N, synth_split(R), st_stream(stream));
     ST_LAUNCHED("synthesis_dgrad"); return ST_OK;
 }
 
@@ -286,7 +291,7 @@ extern "C" int st_synthesis_wgrad(const st_dims* d, const float* AA, const float
     stg::PlainTN al{AA, R, KP, KP, ms};
     stg::FramedTN bl{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms};
     stg::StoreC ep{ws, KP, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
-    stg::launch<3>(al, bl, ep, KP, d->N, R, ns, st_stream(stream));
+    ST_GEMM(3, al, bl, ep, KP, d->N, R, ns, st_stream(stream));
     ST_LAUNCHED("synthesis_wgrad");
     hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(2 * d->F), dim3(256), 0, st_stream(stream),
                        ws, ns, gSr, gSi, norm_partial, d->N, d->F, KP, 1);
@@ -339,7 +344,7 @@ extern "C" int st_analysis_wgrad(const st_dims* d, const float* dG, const float*
     stg::PlainTN al{dG, R, KP, KP, ma};
     stg::FramedTN bl{x, d->L, d->H, d->N, R, d->N, in_scale, ma};
     stg::StoreC ep{ws, KP, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
-    stg::launch<3>(al, bl, ep, KP, d->N, R, ns, st_stream(stream));
+    ST_GEMM(3, al, bl, ep, KP, d->N, R, ns, st_stream(stream));
     ST_LAUNCHED("analysis_wgrad");
     hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(2 * d->F), dim3(256), 0, st_stream(stream),
                        ws, ns, gWr, gWi, norm_partial, d->N, d->F, KP, 0);

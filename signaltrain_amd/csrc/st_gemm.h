@@ -203,18 +203,22 @@ struct PolarStore {
 };
 
 // ------------------------------------------------------------------------------ kernel
-template <int WAVES_M, class AL, class BL, class EPI>
+// BKT = k-tile depth (32: 64 KB LDS/WG, 2 WGs/CU; 16: 36 KB, 4 WGs/CU -- better for the small-M split-K GEMMs).
+// dbg: timing-only ablation switches (bit0 skip loads/stores in the k-loop, bit1 skip barriers, bit2 skip MFMAs).
+template <int WAVES_M, int BKT, class AL, class BL, class EPI>
 __global__ void __launch_bounds__(WAVES_M * 64)
-gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int ksplit)
+gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int ksplit, const int dbg)
 {
     constexpr int BM = 32 * WAVES_M, NT = 64 * WAVES_M;
-    constexpr int LDA = AL::kTN ? BM + 4 : PK;          // TN: k-major [BK][BM+4] ; NT: row-major [BM][36]
-    constexpr int LDB = BL::kTN ? BN + 4 : PK;
-    constexpr int A_SZ = AL::kTN ? BK * LDA : BM * LDA;
-    constexpr int B_SZ = BL::kTN ? BK * LDB : BN * LDB;
-    constexpr int A_IT = BM * (BK / 4) / NT;            // float4 items per thread per k-tile (= 4)
-    constexpr int B_IT = BN * (BK / 4) / NT;            // 6 / 4 / 3 for WAVES_M = 2 / 3 / 4
-    static_assert(BM * (BK / 4) % NT == 0 && BN * (BK / 4) % NT == 0, "tile/threads mismatch");
+    constexpr int PKT = BKT + 4;                         // NT row pitch: 36 (BK 32) / 20 (BK 16) floats, both conflict-free for b128
+    constexpr int LDA = AL::kTN ? BM + 4 : PKT;         // TN: k-major [BK][BM+4] ; NT: row-major [BM][PKT]
+    constexpr int LDB = BL::kTN ? BN + 4 : PKT;
+    constexpr int A_SZ = AL::kTN ? BKT * LDA : BM * LDA;
+    constexpr int B_SZ = BL::kTN ? BKT * LDB : BN * LDB;
+    constexpr int KQ = BKT / 4;                          // float4 per row per k-tile
+    constexpr int A_N = BM * KQ, B_N = BN * KQ;          // float4 items per k-tile
+    constexpr int A_IT = (A_N + NT - 1) / NT, B_IT = (B_N + NT - 1) / NT;
+    constexpr int HK = BKT / 2;                          // k per lane-half: lane (m, h) covers k = HK*h .. HK*h + HK-1
     __shared__ __attribute__((aligned(16))) float As[2 * A_SZ];
     __shared__ __attribute__((aligned(16))) float Bs[2 * B_SZ];
 
@@ -225,18 +229,23 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
 
     // per-thread item coordinates (fixed across k-tiles): (row-in-tile, k-in-tile) and LDS offset
     int a_i[A_IT], a_k[A_IT], a_l[A_IT], b_i[B_IT], b_k[B_IT], b_l[B_IT];
+    bool a_v[A_IT], b_v[B_IT];
     RowState a_st[AL::kTN ? 1 : A_IT], b_st[BL::kTN ? 1 : B_IT];
 #pragma unroll
     for (int p = 0; p < A_IT; ++p) {
         const int idx = tid + NT * p;
-        if constexpr (AL::kTN) { a_i[p] = (idx % (BM / 4)) * 4; a_k[p] = idx / (BM / 4); a_l[p] = a_k[p] * LDA + a_i[p]; }
-        else { a_i[p] = idx >> 3; a_k[p] = (idx & 7) * 4; a_l[p] = a_i[p] * LDA + a_k[p]; a_st[p] = al.row_state(m_blk + a_i[p]); }
+        a_v[p] = idx < A_N;
+        const int id = a_v[p] ? idx : 0;
+        if constexpr (AL::kTN) { a_i[p] = (id % (BM / 4)) * 4; a_k[p] = id / (BM / 4); a_l[p] = a_k[p] * LDA + a_i[p]; }
+        else { a_i[p] = id / KQ; a_k[p] = (id % KQ) * 4; a_l[p] = a_i[p] * LDA + a_k[p]; a_st[p] = al.row_state(m_blk + a_i[p]); }
     }
 #pragma unroll
     for (int p = 0; p < B_IT; ++p) {
         const int idx = tid + NT * p;
-        if constexpr (BL::kTN) { b_i[p] = (idx % (BN / 4)) * 4; b_k[p] = idx / (BN / 4); b_l[p] = b_k[p] * LDB + b_i[p]; }
-        else { b_i[p] = idx >> 3; b_k[p] = (idx & 7) * 4; b_l[p] = b_i[p] * LDB + b_k[p]; b_st[p] = bl.row_state(n_blk + b_i[p]); }
+        b_v[p] = idx < B_N;
+        const int id = b_v[p] ? idx : 0;
+        if constexpr (BL::kTN) { b_i[p] = (id % (BN / 4)) * 4; b_k[p] = id / (BN / 4); b_l[p] = b_k[p] * LDB + b_i[p]; }
+        else { b_i[p] = id / KQ; b_k[p] = (id % KQ) * 4; b_l[p] = b_i[p] * LDB + b_k[p]; b_st[p] = bl.row_state(n_blk + b_i[p]); }
     }
 
     float4 ra[A_IT], rb[B_IT];
@@ -262,9 +271,11 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
         float* bs = Bs + buf * B_SZ;
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int p = 0; p < A_IT; ++p) *reinterpret_cast<float4*>(as + a_l[p]) = oa[p] ? al.post(ra[p]) : zero;
+        for (int p = 0; p < A_IT; ++p)
+            if (A_N % NT == 0 || a_v[p]) *reinterpret_cast<float4*>(as + a_l[p]) = oa[p] ? al.post(ra[p]) : zero;
 #pragma unroll
-        for (int p = 0; p < B_IT; ++p) *reinterpret_cast<float4*>(bs + b_l[p]) = ob[p] ? bl.post(rb[p]) : zero;
+        for (int p = 0; p < B_IT; ++p)
+            if (B_N % NT == 0 || b_v[p]) *reinterpret_cast<float4*>(bs + b_l[p]) = ob[p] ? bl.post(rb[p]) : zero;
     };
 
     f32x16 acc[NJ];
@@ -279,60 +290,62 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
         __syncthreads();
         int cur = 0;
         const int h = lane >> 5, l31 = lane & 31;
-        // NT: lane reads 16 consecutive floats of its row; TN: lane reads column l31 of rows 16h..16h+15
-        const int a_off = AL::kTN ? (16 * h) * LDA + wave * 32 + l31 : (wave * 32 + l31) * LDA + 16 * h;
-        const int b_off = BL::kTN ? (16 * h) * LDB + l31 : l31 * LDB + 16 * h;
-        for (int kt = k_begin; kt < k_end; kt += BK) {
-            const bool more = kt + BK < k_end;
-            if (more) gload(kt + BK);
+        // NT: lane reads HK consecutive floats of its row; TN: lane reads column l31 of rows HK*h .. HK*h+HK-1
+        const int a_off = AL::kTN ? (HK * h) * LDA + wave * 32 + l31 : (wave * 32 + l31) * LDA + HK * h;
+        const int b_off = BL::kTN ? (HK * h) * LDB + l31 : l31 * LDB + HK * h;
+        for (int kt = k_begin; kt < k_end; kt += BKT) {
+            const bool more = kt + BKT < k_end;
+            if (more && !(dbg & 1)) gload(kt + BKT);
             const float* as = As + cur * A_SZ + a_off;
             const float* bs = Bs + cur * B_SZ + b_off;
-            float af[16], bf[NJ][16];
-            if constexpr (!AL::kTN) {
+            if (!(dbg & 4)) {
+                float af[HK], bf[NJ][HK];
+                if constexpr (!AL::kTN) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 v = *reinterpret_cast<const float4*>(as + 4 * q);
-                    af[4 * q] = v.x; af[4 * q + 1] = v.y; af[4 * q + 2] = v.z; af[4 * q + 3] = v.w;
-                }
-            }
-            if constexpr (!BL::kTN) {
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 v = *reinterpret_cast<const float4*>(bs + 32 * j * LDB + 4 * q);
-                        bf[j][4 * q] = v.x; bf[j][4 * q + 1] = v.y; bf[j][4 * q + 2] = v.z; bf[j][4 * q + 3] = v.w;
+                    for (int q = 0; q < HK / 4; ++q) {
+                        const float4 v = *reinterpret_cast<const float4*>(as + 4 * q);
+                        af[4 * q] = v.x; af[4 * q + 1] = v.y; af[4 * q + 2] = v.z; af[4 * q + 3] = v.w;
                     }
-            }
+                }
+                if constexpr (!BL::kTN) {
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-                float a;
-                if constexpr (AL::kTN) a = as[kk * LDA]; else a = af[kk];
+                    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    float b;
-                    if constexpr (BL::kTN) b = bs[kk * LDB + 32 * j]; else b = bf[j][kk];
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+                        for (int q = 0; q < HK / 4; ++q) {
+                            const float4 v = *reinterpret_cast<const float4*>(bs + 32 * j * LDB + 4 * q);
+                            bf[j][4 * q] = v.x; bf[j][4 * q + 1] = v.y; bf[j][4 * q + 2] = v.z; bf[j][4 * q + 3] = v.w;
+                        }
+                }
+#pragma unroll
+                for (int kk = 0; kk < HK; ++kk) {
+                    float a;
+                    if constexpr (AL::kTN) a = as[kk * LDA]; else a = af[kk];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        float b;
+                        if constexpr (BL::kTN) b = bs[kk * LDB + 32 * j]; else b = bf[j][kk];
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+                    }
                 }
             }
-            if (more) lstore(cur ^ 1);
-            __syncthreads();
+            if (more && !(dbg & 1)) lstore(cur ^ 1);
+            if (!(dbg & 2)) __syncthreads();
             cur ^= 1;
         }
     }
     epi(m_blk + wave * 32, n_blk, acc);
 }
 
-template <int WAVES_M, class AL, class BL, class EPI>
+template <int WAVES_M, int BKT, class AL, class BL, class EPI>
 static inline void launch(const AL& al, const BL& bl, const EPI& epi, int M, int Nc, int K, int nsplit,
-                          hipStream_t s)
+                          hipStream_t s, int dbg = 0)
 {
     constexpr int BM = 32 * WAVES_M;
     int ksplit = K;
     if (nsplit > 1) ksplit = st_round_up((K + nsplit - 1) / nsplit, BK);
     // exactly nsplit z-slices: a slice that starts past K stores zeros, so consumers sum a fixed slab count
     dim3 grid((Nc + BN - 1) / BN, (M + BM - 1) / BM, nsplit > 1 ? nsplit : 1);
-    hipLaunchKernelGGL((gemm_kernel<WAVES_M, AL, BL, EPI>), grid, dim3(WAVES_M * 64), 0, s, al, bl, epi, K, ksplit);
+    hipLaunchKernelGGL((gemm_kernel<WAVES_M, BKT, AL, BL, EPI>), grid, dim3(WAVES_M * 64), 0, s, al, bl, epi, K, ksplit, dbg);
 }
 
 }  // namespace stg
