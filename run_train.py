@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""CLI mirror of the reference's run_train.py (flags of run_train.py:32-47) on the MI355X-native engine.
+Multi-GPU: `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 run_train.py ...`."""
+import argparse
+import os
+import numpy as np
+import torch
+
+if __name__ == "__main__":
+    np.random.seed(218); torch.manual_seed(218)                      # run_train.py:20-21
+    p = argparse.ArgumentParser(description="trains SignalTrain network", formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument('--apex', help="accepted for compatibility (no Apex on ROCm; fp32 engine)", default="O0")
+    p.add_argument('-b', '--batch', type=int, help="batch size (per GPU)", default=200)
+    p.add_argument('--checkpoint', help='name of checkpoint .tar file to start from', default='modelcheckpoint.tar')
+    p.add_argument('-c', '--compand', help='accepted for compatibility', action='store_true')
+    p.add_argument('--effect', help='effect to learn', default='comp_4c', choices=['comp_4c', 'comp_4c_large'])
+    p.add_argument('--epochs', type=int, default=1000)
+    p.add_argument('--lrmax', type=float, help="maximum learning rate", default=1e-4)
+    p.add_argument('-n', '--num', type=int, help='number of data points per epoch', default=200000)
+    p.add_argument('--path', help='dataset directory (file datasets are not built yet)', default=None)
+    p.add_argument('--sr', type=int, default=44100)
+    p.add_argument('--scale', type=float, help='scale factor (of input size & whole model)', default=1.0)
+    p.add_argument('--shrink', type=int, help='shrink output chunk relative to input by this divisor', default=4)
+    p.add_argument('-t', '--target', help='accepted for compatibility', default="stream")
+    args = p.parse_args()
+
+    import torch.distributed as dist
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from signaltrain_amd import audio, train
+    effect = audio.Compressor_4c() if args.effect == 'comp_4c' else audio.Compressor_4c_Large()
+    train.train(epochs=args.epochs, n_data_points=args.num, batch_size=args.batch, device=torch.device("cuda", local),
+                effect=effect, datapath=args.path, scale_factor=args.scale, shrink_factor=args.shrink, apex_opt=args.apex,
+                target_type=args.target, lr_max=args.lrmax, in_checkpointname=args.checkpoint, compand=args.compand)
+    if dist.is_initialized():
+        dist.destroy_process_group()

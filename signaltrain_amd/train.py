@@ -1,0 +1,147 @@
+"""Training driver -- mirror of signaltrain/train.py (train :167-278, train_loop :84-164, eval_status_save :28-80).
+
+Same call signature, same step ordering (forward -> calc_loss -> backward -> L1 clip of the STFT gradients ->
+Adam -> learning-rate write taking effect on the NEXT step, train.py:104-151), same log files
+(vl_avg_out.dat, val_err_mae.dat) and checkpoint format.  The step itself is one fused call into
+libsignaltrain_hip.so (engine.StepEngine.train_step); with torch.distributed initialised (one process per GPU)
+each rank trains on its shard and dp.DataParallel all-reduces the flat gradient over RCCL.
+Plots (io_methods.plot_valdata / plot_spectrograms) are out of scope and skipped.
+"""
+import time
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader
+
+from . import audio, datasets, learningrate, loss_functions, misc, nn_proc
+from .dp import DataParallel
+
+
+class _AdamState:
+    """Minimal optimizer stand-in for misc.save_checkpoint (the reference saves but never restores it, train.py:229)."""
+
+    def __init__(self, engine, lr):
+        self.engine, self.lr = engine, lr
+
+    def state_dict(self):
+        e = self.engine
+        return {"state": {"step": e.step_count, "exp_avg": e.m.detach().cpu(), "exp_avg_sq": e.v.detach().cpu()},
+                "param_groups": [{"lr": self.lr, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0}]}
+
+
+def eval_status_save(model, engine, effect, epoch, epochs, lr, mom, device, dataloader_val, logfilename, first_time,
+                     beta, vl_avg, out_checkpointname, parallel, optimizer, data_point, smoothed_loss, y_size, sr,
+                     status_every, plot_every=10, cp_every=25, scale_by_freq=None, is_main=True):
+    """train.py:28-80: validation pass, log files, checkpoint cadence."""
+    val_batch_num, val_mae = 0, float("nan")
+    for x_val, y_val, knobs_val in dataloader_val:
+        val_batch_num += 1
+        x_c, y_c, k_c = x_val.to(device), y_val.to(device).float(), knobs_val.to(device)
+        y_hat, mag_val, mag_val_hat = engine.forward(x_c, k_c)
+        if scale_by_freq is None or scale_by_freq.shape != mag_val_hat.shape:
+            F = mag_val_hat.shape[-1]
+            scale_by_freq = torch.exp((7. / F) * torch.arange(0., F, device=device)).expand_as(mag_val_hat).float()
+        loss_val = loss_functions.calc_loss(y_hat, y_c, mag_val_hat, scale_by_freq=scale_by_freq)
+        vl_avg = beta * vl_avg + (1 - beta) * loss_val.item()
+        val_mae = loss_functions.mae(y_hat, y_c).item()
+        if 0 == val_batch_num % status_every and is_main:
+            print(f"\repoch {epoch+1}/{epochs}, time: {time.time()-first_time:.2f}: lr={lr:.2e},mom={mom:.3f} data_point {data_point}: "
+                  f"loss: {smoothed_loss:.3e} val_loss: {vl_avg:.3e}   ", end="")
+    if is_main:
+        with open(logfilename, "a") as f:
+            f.write(f"{epoch+1} {vl_avg:.3e}\n")
+        with open("val_err_mae.dat", "a") as f:
+            f.write(f"{epoch+1} {val_mae:.3e}\n")
+        if ((epoch + 1) % cp_every == 0) or (epoch == epochs - 1):
+            misc.save_checkpoint(out_checkpointname, model, epoch, parallel, optimizer, effect, sr)
+        if (epoch + 1) == 1:
+            hours = (time.time() - first_time) * (epochs - 1) / 3600.0
+            print(f"\nExpect run to finish in roughly {hours:.1f} hours")
+    return vl_avg
+
+
+def train_loop(model, engine, effect, device, epochs, batch_size, lr_sched, mom_sched, dataloader, dataloader_val,
+               y_size, logfilename, out_checkpointname, plot_every=10, cp_every=25, sr=44100, lr_max=1e-4):
+    """train.py:84-164."""
+    dp = DataParallel(engine)
+    dp.broadcast_parameters()
+    is_main = (not dist.is_initialized()) or dist.get_rank() == 0
+    iter_count, batch_num, status_every = 0, 0, 10
+    avg_loss, vl_avg, beta = 0.0, 0.0, 0.98
+    smoothed_loss = float("nan")          # the reference leaves this unbound for epochs shorter than 10 batches
+    first_time = time.time()
+    lr_in_optimizer = lr_sched[0]         # torch.optim.Adam(lr=lr_sched[0]), train.py:228
+    opt = _AdamState(engine, lr_in_optimizer)
+    windows, t_train = 0, 0.0
+    for epoch in range(epochs):
+        if is_main:
+            print("")
+        data_point = 0
+        t_ep = time.time()
+        for x, y, knobs in dataloader:
+            if x.shape[0] != batch_size:  # keep batches uniform (the reference's expand_as quirk)
+                continue
+            x_c, y_c, k_c = x.to(device), y.to(device).float(), knobs.to(device)
+            lr = lr_sched[min(iter_count, len(lr_sched) - 1)]
+            mom = mom_sched[min(iter_count, len(mom_sched) - 1)]
+            data_point += batch_size
+            dp.train_step(x_c, k_c, y_c, lr_in_optimizer)          # forward, loss, backward, clip, Adam (train.py:112-147)
+            batch_num += 1
+            if 0 == batch_num % status_every:                        # train.py:124-129 (the only device->host sync)
+                avg_loss = beta * avg_loss + (1 - beta) * dp.mean_loss()
+                smoothed_loss = avg_loss / (1 - beta ** batch_num)
+                if is_main:
+                    print(f"\repoch {epoch+1}/{epochs}, time: {time.time()-first_time:.2f}: lr={lr:.2e},mom={mom:.3f}, "
+                          f"data_point {data_point}: loss: {smoothed_loss:.3e}   ", end="")
+            lr_in_optimizer = lr                                     # train.py:150: takes effect on the next step
+            opt.lr = lr
+            iter_count += 1
+            windows += batch_size
+        torch.cuda.synchronize()
+        t_train += time.time() - t_ep
+        vl_avg = eval_status_save(model, engine, effect, epoch, epochs, lr_in_optimizer, 0.0, device, dataloader_val, logfilename,
+                                  first_time, beta, vl_avg, out_checkpointname, False, opt, data_point, smoothed_loss, y_size, sr,
+                                  status_every, is_main=is_main)
+    if is_main:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        print(f"\nTotal elapsed time for training loop = {time.time() - first_time:.2f}  "
+              f"({windows * world / max(t_train, 1e-9):.0f} train windows/s incl. the CPU data feed)")
+    return None
+
+
+def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=None, plot_every=10, cp_every=25, sr=44100,
+          datapath=None, scale_factor=1, shrink_factor=4, apex_opt="O0", target_type="stream", lr_max=1e-4,
+          in_checkpointname='modelcheckpoint.tar', compand=False, num_workers=10):
+    """train.py:167-278.  apex_opt / target_type / compand are accepted for signature compatibility;
+    datapath (AudioFileDataSet) is not built yet -- the synthetic feed is."""
+    effect = audio.Compressor_4c() if effect is None else effect
+    device = torch.device("cuda:0") if device is None else torch.device(device)
+    if datapath is not None:
+        raise NotImplementedError("signaltrain_amd.train: file datasets (datapath=...) are not built; use the synthetic feed")
+    print(f'SignalTrain (MI355X) training execution began at {time.ctime()}. Options:')
+    print(f'    epochs = {epochs}, n_data_points = {n_data_points}, batch_size = {batch_size}')
+    print(f'    scale_factor = {scale_factor}, shrink_factor = {shrink_factor}')
+    num_knobs = len(effect.knob_names)
+    effect.info()
+    state_dict, rv = misc.load_checkpoint(in_checkpointname, fatal=False, device="cpu")
+    if state_dict != {}:
+        scale_factor, shrink_factor, sr = rv['scale_factor'], rv['shrink_factor'], rv['sr']
+    model = nn_proc.st_model(scale_factor=scale_factor, shrink_factor=shrink_factor, num_knobs=num_knobs, sr=sr)
+    if state_dict != {}:
+        model.load_state_dict(state_dict)
+    chunk_size, out_chunk_size = model.in_chunk_size, model.out_chunk_size
+    print("Model defined.  Number of trainable parameters:", sum(p.numel() for p in model.parameters() if p.requires_grad))
+    model.to(device)
+    engine = model.engine(torch.zeros(batch_size, chunk_size, device=device))     # parameters become views of the engine's flat buffer
+    lr_sched, mom_sched = learningrate.get_1cycle_schedule(lr_max=lr_max, n_data_points=n_data_points, epochs=epochs, batch_size=batch_size)
+    dataset = datasets.SynthAudioDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points, y_size=out_chunk_size, augment=True)
+    dataset_val = datasets.SynthAudioDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points // 4, recycle=True,
+                                             y_size=out_chunk_size, augment=False)
+    dataloader = DataLoader(dataset, batch_size=batch_size, num_workers=num_workers, shuffle=True, worker_init_fn=datasets.worker_init,
+                            drop_last=True)
+    dataloader_val = DataLoader(dataset_val, batch_size=batch_size, num_workers=num_workers, shuffle=False, drop_last=True)
+    logfilename = "vl_avg_out.dat"
+    open(logfilename, "a").close()
+    train_loop(model, engine, effect, device, epochs, batch_size, lr_sched, mom_sched, dataloader, dataloader_val,
+               out_chunk_size, logfilename, "modelcheckpoint.tar", sr=sr, lr_max=lr_max)
+    return model

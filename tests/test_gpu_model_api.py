@@ -1,0 +1,112 @@
+"""GPU: the drop-in Python surface -- st_model through torch.autograd against the fused engine and the golden
+forward fixture captured from the reference; Analysis/Synthesis modules; a short train.train() run."""
+import os
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _golden_model(golden_dir):
+    from oracle import st_oracle as O
+    from tests.golden_util import perturb_stft, ae_keys
+    from signaltrain_amd import nn_proc
+    nn_proc._QUIET = True
+    g = np.load(os.path.join(golden_dir, "g3_forward.npz"))
+    geo = O.geometry(1, 4)
+    P = O.init_params(geo, 4)
+    for k in ae_keys():
+        P[k] = g["ae_" + k]
+    perturb_stft(P, seed=7)
+    m = nn_proc.st_model(scale_factor=1, shrink_factor=4, num_knobs=4)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    return m.to("cuda:0"), g, P, geo
+
+
+def test_golden_forward_through_st_model(golden_dir):
+    """The reference's own forward outputs (golden G3) reproduced by the drop-in st_model on the GPU."""
+    m, g, P, geo = _golden_model(golden_dir)
+    x, kn = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["knobs"]).cuda()
+    y, mag, mag_hat = m.forward(x, kn)
+    for got, ref, name in ((y, g["y_hat"], "y_hat"), (mag, g["mag"], "mag"), (mag_hat, g["mag_hat"], "mag_hat")):
+        e = np.abs(got.detach().cpu().numpy() - ref).max()
+        assert e <= 1e-4 * np.abs(ref).max(), (name, e)          # north_star tolerance: 1e-4 relative, fp32
+    y2, _, _, acts = m.forward(x, kn, return_acts=True)
+    assert len(acts) == 30 and acts[0].shape == (2, 25, 513) and acts[-1].shape == (2, 2048)
+
+
+def test_autograd_matches_golden_backward(golden_dir):
+    """loss.backward() through the custom autograd Function vs the reference's autograd (golden G4)."""
+    from signaltrain_amd import loss_functions
+    from tests.golden_util import ae_keys, projections, SAMPLE_ROWS, STFT_KEYS
+    m, g, P, geo = _golden_model(golden_dir)
+    g4 = np.load(os.path.join(golden_dir, "g4_backward.npz"))
+    x, kn, yt = (torch.from_numpy(g[k]).cuda() for k in ("x", "knobs", "y"))
+    y, mag, mag_hat = m.forward(x, kn)
+    sbf = torch.exp((7. / 513) * torch.arange(0., 513, device="cuda")).expand_as(mag_hat).float()
+    loss = loss_functions.calc_loss(y, yt, mag_hat, scale_by_freq=sbf)
+    loss.backward()
+    assert abs(loss.item() - float(g4["loss"])) <= 1e-4 * abs(float(g4["loss"]))
+    grads = {k: p.grad.detach().cpu().numpy().astype(np.float64) for k, p in m.named_parameters()}
+    for k in ae_keys():
+        ref = g4["g_" + k]
+        assert np.abs(grads[k] - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-12, k
+    PROJ = projections(seed=11)
+    for k in STFT_KEYS:
+        gk = grads[k][:, 0, :]
+        sc = np.abs(g4["rows_" + k]).max()
+        assert np.abs(gk[SAMPLE_ROWS] - g4["rows_" + k]).max() <= 2e-4 * sc
+        assert np.abs(PROJ @ gk - g4["proj_" + k]).max() <= 2e-4 * np.abs(g4["proj_" + k]).max()
+    m.clip_grad_norm_()                                              # nn_proc.py:299-302 on the torch side
+    n = sum(float(m.state_dict()[k].new_tensor(0)) for k in [])      # no-op; the call above must simply work
+
+
+def test_reference_style_loop_equals_fused_step(golden_dir):
+    """zero_grad / backward / clip_grad_norm_ / torch.optim.Adam.step on the drop-in model == StepEngine.train_step."""
+    from signaltrain_amd import loss_functions
+    from signaltrain_amd.engine import StepEngine
+    m, g, P, geo = _golden_model(golden_dir)
+    x, kn, yt = (torch.from_numpy(g[k]).cuda() for k in ("x", "knobs", "y"))
+    eng2 = StepEngine(m.engine(x).dims, "cuda:0"); eng2.load_state_dict(P)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0)
+    for it in range(2):
+        y, mag, mag_hat = m.forward(x, kn)
+        sbf = torch.exp((7. / 513) * torch.arange(0., 513, device="cuda")).expand_as(mag_hat).float()
+        loss = loss_functions.calc_loss(y, yt, mag_hat, scale_by_freq=sbf)
+        opt.zero_grad(); loss.backward(); m.clip_grad_norm_(); opt.step()
+        eng2.train_step(x, kn, yt, 1e-3)
+    for k, v in m.state_dict().items():
+        # Adam's m/(sqrt(v)+eps) turns ~1e-12 differences on noise-level gradient elements (|g| ~ eps) into a fraction of
+        # lr; everything else agrees to fp32 rounding.  Bound: 10 % of one lr-sized update.
+        assert (v - eng2.named[k]).abs().max().item() < 1e-4, k
+
+
+def test_analysis_synthesis_modules_perfect_reconstruction():
+    """cls_fe_dft.Analysis -> Synthesis at init is the identity (implicit invariant of the reference's init)."""
+    from signaltrain_amd.cls_fe_dft import Analysis, Synthesis
+    an, sy = Analysis().cuda(), Synthesis().cuda()
+    x = (torch.randn(3, 8192, device="cuda") * 0.3)
+    re, im = an(x)
+    assert re.shape == (3, 25, 513)
+    wave = sy(re, im)                      # all 25 frames -> (25-1)*384-1024 = 8192 samples
+    assert wave.shape == (3, 8192)
+    assert (wave - x).abs().max().item() < 1e-5
+    (wave.square().mean()).backward()
+    assert an.conv_analysis_real.weight.grad is not None and sy.conv_synthesis_imag.weight.grad.abs().max() > 0
+
+
+def test_train_driver_short_run(tmp_path):
+    from signaltrain_amd import train, audio, nn_proc
+    nn_proc._QUIET = True
+    cwd = os.getcwd(); os.chdir(tmp_path)
+    try:
+        model = train.train(effect=audio.Compressor_4c(), epochs=1, n_data_points=256, batch_size=32,
+                            device=torch.device("cuda:0"), num_workers=2)
+        assert os.path.isfile("modelcheckpoint.tar") and os.path.isfile("vl_avg_out.dat") and os.path.isfile("val_err_mae.dat")
+        from signaltrain_amd import misc
+        sd, rv = misc.load_checkpoint("modelcheckpoint.tar", device="cpu")
+        assert len(sd) == 40 and rv["in_chunk_size"] == 8192 and rv["out_chunk_size"] == 2048
+        assert all(torch.isfinite(v).all() for v in sd.values())
+    finally:
+        os.chdir(cwd)
