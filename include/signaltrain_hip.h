@@ -49,6 +49,7 @@ int st_set_tuning(int bk);
 /* Timing-only ablation switches for diagnostics (bit0: skip k-loop loads/stores, bit1: skip barriers, bit2: skip MFMAs);
  * results are INVALID when non-zero.  Never set by the product path. */
 int st_set_debug(int v);
+int st_debug_read_stage_cycles(unsigned long long* out32);   /* diagnostics: s_memtime per stage of ae_bwd (st_set_debug(256)) */
 
 /* Optional per-kernel HIP-event profiling of the fused entry points (off by default; used by
  * bench.py's roofline leg outside the timed region).  st_profile_report fills buf with

@@ -33,6 +33,7 @@ SIGNATURES = {
     "st_version": (_i, []),
     "st_set_tuning": (_i, [_i]),
     "st_set_debug": (_i, [_i]),
+    "st_debug_read_stage_cycles": (_i, [C.POINTER(C.c_uint64)]),
     "st_profile_enable": (_i, [_i]),
     "st_profile_report": (_i, [C.c_char_p, _i]),
     "st_geometry": (_i, [C.c_double, C.c_double, _i, _i, _i, _D]),

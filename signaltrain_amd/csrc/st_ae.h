@@ -86,7 +86,9 @@ __device__ __forceinline__ void layer_fwd(const float* const (&W)[NC], const flo
     for (int ot = 0; ot < OTL; ++ot) {
         f32x4 acc[NC];
 #pragma unroll
-        for (int ch = 0; ch < NC; ++ch) acc[ch] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ch = 0; ch < NC; ++ch)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[ch][r] = bias[ch][16 * ot + 4 * g + r];     // accumulator starts at the bias
 #pragma unroll
         for (int it = 0; it < ITL; ++it)
 #pragma unroll
@@ -99,18 +101,21 @@ __device__ __forceinline__ void layer_fwd(const float* const (&W)[NC], const flo
 #pragma unroll
         for (int ch = 0; ch < NC; ++ch)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) hout[ch][ot][r] = elu_f(acc[ch][r] + bias[ch][16 * ot + 4 * g + r]);
+            for (int r = 0; r < 4; ++r) hout[ch][ot][r] = elu_f(acc[ch][r]);
     }
 }
 
 // ------------------------------------------------------------------------------------------ forward
 // Per-group inputs of one lane: layer-1 B operands (t = 4*ks + g, ks < 8 -> T <= 32) and the skip/residual
 // tails (t = T-OT + 4g + r, OT <= 16).  Loaded in one burst and prefetched one group ahead.
-struct FwdIn { float v[2][8]; float tl[2][4]; };
+struct FwdIn { float v[2][8]; float tl[2][4]; float kn[4]; };   // kn: knob 4q + g for the (up to 4) knob k-steps of layer 5
 
 __device__ __forceinline__ void fwd_load(FwdIn& in, const float* __restrict__ mag, const float* __restrict__ phs,
+                                         const float* __restrict__ knobs, const int K,
                                          const int b, const int f, const bool fv, const int T, const int OT, const int F, const int g)
 {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int kn = 4 * q + g; const float x = knobs[(size_t)b * K + (kn < K ? kn : 0)]; in.kn[q] = kn < K ? x : 0.f; }
     const size_t base = (size_t)b * T * F + (fv ? f : 0);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
@@ -161,7 +166,7 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     int grp = blockIdx.x * NW + wave;
     if (FAST && grp < ngroups) {
         const int b = grp / gpw, f = (grp - b * gpw) * 16 + c;
-        fwd_load(cur, mag, phs, b, f, f < F, T, OT, F, g);
+        fwd_load(cur, mag, phs, knobs, K, b, f, f < F, T, OT, F, g);
     }
     for (; grp < ngroups; grp += gstride) {
         asm volatile("" ::: "memory");      // keep the (loop-invariant) LDS weight fetches inside the loop: hoisting them spills
@@ -173,7 +178,7 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             const int gn = grp + gstride;
             if (gn < ngroups) {
                 const int bn = gn / gpw, fn = (gn - bn * gpw) * 16 + c;
-                fwd_load(nxt, mag, phs, bn, fn, fn < F, T, OT, F, g);
+                fwd_load(nxt, mag, phs, knobs, K, bn, fn, fn < F, T, OT, F, g);
             }
         }
 
@@ -248,7 +253,7 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
                     acc[ch] = ST_MFMA16(lw[ch][L.w[4] + c * P5 + 4 * g + r], h4[ch][0][r], acc[ch]);
             for (int q = 0; q < KQ; ++q) {
                 const int kn = 4 * q + g;
-                const float kv = kn < K ? knobs[(size_t)b * K + kn] : 0.f;
+                const float kv = (FAST && q < 4) ? cur.kn[q] : (kn < K ? knobs[(size_t)b * K + kn] : 0.f);   // prefetched with the inputs
 #pragma unroll
                 for (int ch = 0; ch < 2; ++ch)
                     acc[ch] = ST_MFMA16(lw[ch][L.w[4] + c * P5 + 16 + kn], kv, acc[ch]);
@@ -326,6 +331,10 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
 // At the end the workgroup stores its partial dW/db (packed like the parameters); ae_grad_reduce_kernel sums them.
 constexpr int SP = 20;                 // scratch pitch (floats): 16 rows + 4, keeps rows 16-B aligned
 
+// Diagnostics only (st_set_debug bit 8): wave 0 of workgroup (0,0) accumulates s_memtime deltas per kernel stage.
+__device__ unsigned long long g_ae_stage_cycles[32];
+#define ST_T(i_) do { if (timing) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_ae_stage_cycles[i_] += t1_ - t0_; t0_ = __builtin_amdgcn_s_memtime(); } } while (0)
+
 // ---------------------------------------------------------------------------------------------------------
 // Weight fragments in registers.  Left to itself the compiler issues each MFMA's LDS weight fetch just before
 // the MFMA (one s_waitcnt per MFMA: the AE kernels were LDS-latency-bound).  These helpers burst-load every
@@ -361,13 +370,14 @@ __device__ __forceinline__ void fwdD_fr(const float (&fr)[OTL * ITL * 4], const 
 {
 #pragma unroll
     for (int ot = 0; ot < OTL; ++ot) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float4 bq = *reinterpret_cast<const float4*>(bias + 16 * ot + 4 * g);   // accumulator starts at the bias (D layout: o = 16 ot + 4 g + r)
+        f32x4 acc = (f32x4){bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
         for (int it = 0; it < ITL; ++it)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc = ST_MFMA16(fr[(ot * ITL + it) * 4 + r], hin[it][r], acc);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hout[ot][r] = elu_f(acc[r] + bias[16 * ot + 4 * g + r]);
+        for (int r = 0; r < 4; ++r) hout[ot][r] = elu_f(acc[r]);
     }
 }
 template <int OTL, int ITL>
@@ -376,14 +386,14 @@ __device__ __forceinline__ void fwdT_fr(const float (&fr)[OTL * ITL * 4], const 
 {
 #pragma unroll
     for (int ot = 0; ot < OTL; ++ot) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float bv = bias[16 * ot + c];                    // T layout: feature 16 ot + c in every register
+        f32x4 acc = (f32x4){bv, bv, bv, bv};
 #pragma unroll
         for (int it = 0; it < ITL; ++it)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc = ST_MFMA16(hin[it][r], fr[(ot * ITL + it) * 4 + r], acc);
-        const float bv = bias[16 * ot + c];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) houtT[ot][r] = elu_f(acc[r] + bv);
+        for (int r = 0; r < 4; ++r) houtT[ot][r] = elu_f(acc[r]);
     }
 }
 // both data-gradient orientations from one fragment set
@@ -580,10 +590,13 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
               float* __restrict__ dmag, float* __restrict__ dphs, float* __restrict__ ws,
               const int B, const int T, const int OT, const int F, const int K, const int KP,
               const int to_lo, const int to_hi,      // live synthesis frames: dAA rows outside are treated as zero
-              const int nslab, const size_t slab)     // dAA arrives as split-K slabs of the synthesis dgrad GEMM
+              const int nslab, const size_t slab,     // dAA arrives as split-K slabs of the synthesis dgrad GEMM
+              const int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int ae = blockIdx.y;
+    const bool timing = (dbg & 256) && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x >> 6) == 0;
+    unsigned long long t0_ = timing ? __builtin_amdgcn_s_memtime() : 0ull;
     const AELds L = ae_lds_layout(T, OT, K);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
@@ -650,20 +663,32 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             const bool ok = fv && to < OT;
             const bool lv = ok && to >= to_lo && to <= to_hi;
             const size_t ro = (size_t)b * OT + (ok ? to : 0);
-            float a0 = 0.f, a1 = 0.f;
-            for (int z = 0; z < nslab; ++z) { a0 += dAA[z * slab + (lv ? ro : 0) * KP + fq]; a1 += dAA[z * slab + (lv ? ro : 0) * KP + FP + fq]; }
+            // up to 3 split-K slabs: all six loads are issued together, then summed (a runtime-trip-count loop here
+            // serialised ~12 memory round trips per group)
+            const float* p0 = dAA + ((lv ? ro : (size_t)0) * (size_t)KP + (size_t)fq);
+            const size_t o1 = nslab > 1 ? slab : (size_t)0, o2 = nslab > 2 ? 2 * slab : (size_t)0;
+            const float x0 = p0[0], x1 = p0[o1], x2 = p0[o2];
+            const float y0 = p0[FP], y1 = p0[o1 + FP], y2 = p0[o2 + FP];
+            const float a0 = x0 + (nslab > 1 ? x1 : 0.f) + (nslab > 2 ? x2 : 0.f);
+            const float a1 = y0 + (nslab > 1 ? y1 : 0.f) + (nslab > 2 ? y2 : 0.f);
             q_gre[r] = lv ? a0 : 0.f; q_gim[r] = lv ? a1 : 0.f;
             q_ph[r] = phs_hat[ro * F + fq]; q_mh[r] = mag_hat[ro * F + fq];
             q_mt[r] = vin[((size_t)b * T + (ok ? T - OT + to : 0)) * F + fq];
             q_gm[r] = (g_mag_hat && ok) ? g_mag_hat[ro * F + fq] : 0.f;
         }
+        // knob values: D-layout feature tile (16 + 4g + r) and T-layout feature lane (16 + c), loaded up front
+        f32x4 kn[1]; float knT;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int kidx = 4 * g + r; const float x = knobs[(size_t)b * K + (kidx < K ? kidx : 0)]; kn[0][r] = kidx < K ? x : 0.f; }
+        { const float x = knobs[(size_t)b * K + (c < K ? c : 0)]; knT = c < K ? x : 0.f; }
         float vn[8];
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) vn[ks] = 0.f;
         if (grp + gstride < ngroups) load_v(grp + gstride, vn);
+        ST_T(0);
 
         // ------------------------------------------------------------------ forward recompute (D layout)
-        f32x4 h1[4], h2[2], h3[1], h4[1], h5[1], h6[1], h7[2], h8[4], e9[1], kn[1];
+        f32x4 h1[4], h2[2], h3[1], h4[1], h5[1], h6[1], h7[2], h8[4], e9[1];
         {
             f32x4 acc[4];
 #pragma unroll
@@ -688,7 +713,9 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h1[ot][r] = elu_f(acc[ot][r] + Bl[0][16 * ot + 4 * g + r]);
         }
+        ST_T(1);
         { float fr[2 * 4 * 4]; frags_fwd<2, 4>(fr, Wl[1], CL::P1, g, c); ST_FENCE(); fwdD_fr<2, 4>(fr, Bl[1], h1, h2, g); }
+        ST_T(2);
         { float fr[1 * 2 * 4]; frags_fwd<1, 2>(fr, Wl[2], CL::P2, g, c); ST_FENCE(); fwdD_fr<1, 2>(fr, Bl[2], h2, h3, g); }
         { float fr[1 * 1 * 4]; frags_fwd<1, 1>(fr, Wl[3], CL::P3, g, c); ST_FENCE(); fwdD_fr<1, 1>(fr, Bl[3], h3, h4, g); }
         {
@@ -696,8 +723,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             const int P5 = CL::P4;
             float fa[4], fb[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const int kidx = 4 * g + r; kn[0][r] = kidx < K ? knobs[(size_t)b * K + kidx] : 0.f;
-                                         fa[r] = Wl[4][c * P5 + 4 * g + r]; fb[r] = Wl[4][c * P5 + 16 + 4 * g + r]; }
+            for (int r = 0; r < 4; ++r) { fa[r] = Wl[4][c * P5 + 4 * g + r]; fb[r] = Wl[4][c * P5 + 16 + 4 * g + r]; }
             ST_FENCE();
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc = ST_MFMA16(fa[r], h4[0][r], acc);
@@ -706,10 +732,14 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
 #pragma unroll
             for (int r = 0; r < 4; ++r) h5[0][r] = elu_f(acc[r] + Bl[4][4 * g + r]);
         }
+        ST_T(3);
         { float fr[1 * 1 * 4]; frags_fwd<1, 1>(fr, Wl[5], CL::P5, g, c); ST_FENCE(); fwdD_fr<1, 1>(fr, Bl[5], h5, h6, g); }
         { float fr[2 * 1 * 4]; frags_fwd<2, 1>(fr, Wl[6], CL::P6, g, c); ST_FENCE(); fwdD_fr<2, 1>(fr, Bl[6], h6, h7, g); }
+        ST_T(4);
         { float fr[4 * 2 * 4]; frags_fwd<4, 2>(fr, Wl[7], CL::P7, g, c); ST_FENCE(); fwdD_fr<4, 2>(fr, Bl[7], h7, h8, g); }
+        ST_T(5);
         { float fr[1 * 4 * 4]; frags_fwd<1, 4>(fr, Wl[8], CL::P8, g, c); ST_FENCE(); fwdD_fr<1, 4>(fr, Bl[8], h8, e9, g); }
+        ST_T(6);
         ST_SCHED_FENCE();
         // ------------------------------------------------------------------ d out  (D layout: t' = 4g + r)
         f32x4 da9[1];
@@ -744,6 +774,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         { const float4 v = *reinterpret_cast<const float4*>(Ys + c * SP + 4 * g); daT9[0] = (f32x4){v.x, v.y, v.z, v.w}; }
 #define ST_WG(O_, I_, D_, P_, RW_, RB_, DB_, DAT_, HT_) \
         if constexpr (REG) wgrad_reg<O_, I_>(RW_, RB_, DAT_, HT_); else wgrad_lds<O_, I_>(D_, P_, DAT_, HT_, DB_, g, c);
+        ST_T(7);
         // layer 9 (64 -> OT): needs h8^T (layer-8 forward fragments) and W9 in dgrad order
         f32x4 hT8[4], da8[4], daT8[4];
         {
@@ -753,6 +784,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             ST_WG(1, 4, Dl[8], CL::P8, rW9, rb9, db9, daT9, hT8)
             dgrad_fr<1, 4>(fd, da9, da8, daT8); mul_elu_grad<4>(da8, h8); mul_elu_grad<4>(daT8, hT8);
         }
+        ST_T(8);
         // layer 8 (32 -> 64)
         f32x4 hT7[2], da7[2], daT7[2];
         {
@@ -762,6 +794,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             ST_WG(4, 2, Dl[7], CL::P7, rW8, rb8, db8, daT8, hT7)
             dgrad_fr<4, 2>(fd, da8, da7, daT7); mul_elu_grad<2>(da7, h7); mul_elu_grad<2>(daT7, hT7);
         }
+        ST_T(9);
         // layer 7 (16 -> 32)
         f32x4 hT6[1], da6[1], daT6[1];
         {
@@ -771,6 +804,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             ST_WG(2, 1, Dl[6], CL::P6, rW7, rb7, db7, daT7, hT6)
             dgrad_fr<2, 1>(fd, da7, da6, daT6); mul_elu_grad<1>(da6, h6); mul_elu_grad<1>(daT6, hT6);
         }
+        ST_T(10);
         // layer 6 (16 -> 16); h5^T needs the knob k-steps of layer 5
         f32x4 hT5[1], da5[1], daT5[1];
         {
@@ -797,7 +831,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             frags_fwd<1, 1>(ff, Wl[3], CL::P3, g, c); frags_dgrad<1, 1>(fd, Wl[4], CL::P4, g, c); ST_FENCE();
             fwdT_fr<1, 1>(ff, Bl[3], h3, hT4, c);
             hT4k[0] = hT4[0];
-            { const float kv = c < K ? knobs[(size_t)b * K + c] : 0.f; hT4k[1] = (f32x4){kv, kv, kv, kv}; }   // features 16 + c = knob c, every row
+            hT4k[1] = (f32x4){knT, knT, knT, knT};                   // features 16 + c = knob c, every row
             ST_WG(1, 2, Dl[4], CL::P4, rW5, rb5, db5, daT5, hT4k)
             dgrad_fr<1, 1>(fd, da5, da4, daT4); mul_elu_grad<1>(da4, h4); mul_elu_grad<1>(daT4, hT4);
         }
@@ -810,6 +844,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             ST_WG(1, 1, Dl[3], CL::P3, rW4, rb4, db4, daT4, hT3)
             dgrad_fr<1, 1>(fd, da4, da3, daT3); mul_elu_grad<1>(da3, h3); mul_elu_grad<1>(daT3, hT3);
         }
+        ST_T(11);
         // layer 3 (32 -> 16)
         f32x4 hT2[2], da2[2], daT2[2];
         {
@@ -819,6 +854,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             ST_WG(1, 2, Dl[2], CL::P2, rW3, rb3, db3, daT3, hT2)
             dgrad_fr<1, 2>(fd, da3, da2, daT2); mul_elu_grad<2>(da2, h2); mul_elu_grad<2>(daT2, hT2);
         }
+        ST_T(12);
         // layer 2 (64 -> 32); h1^T from the input rows
         f32x4 hT1[4], da1[4], daT1[4];
         {
@@ -842,6 +878,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             ST_WG(2, 4, Dl[1], CL::P1, rW2, rb2, db2, daT2, hT1)
             dgrad_fr<2, 4>(fd, da2, da1, daT1); mul_elu_grad<4>(da1, h1); mul_elu_grad<4>(daT1, hT1);
         }
+        ST_T(13);
         // layer 1 (T -> 64): input rows transposed through the wave's scratch
         f32x4 vT[2], dv[2];
         {
@@ -854,6 +891,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             dgradD_fr<4, 2>(fd, da1, dv);
         }
 #undef ST_WG
+        ST_T(14);
         // ------------------------------------------------------------------ d input rows (+ skip / residual tails)
 #pragma unroll
         for (int it = 0; it < 2; ++it)
@@ -866,6 +904,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
                     dvout[((size_t)b * T + t) * F + f] = v;
                 }
             }
+        ST_T(15);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) vr[ks] = vn[ks];
     }

@@ -150,6 +150,9 @@ static int num_cus()
 }
 static int g_dbg = 0;   // timing-only ablation switches (bench/diagnostics); results are invalid when non-zero
 extern "C" int st_set_debug(int v) { g_dbg = v; return ST_OK; }
+namespace sta { extern __device__ unsigned long long g_ae_stage_cycles[32]; }
+// Diagnostics: read (and clear) the per-stage s_memtime accumulators of ae_bwd_kernel (st_set_debug(256)).
+extern "C" int st_debug_read_stage_cycles(unsigned long long* out32);
 static int g_bk = 16;   // k-tile depth of the GEMM family (16: 36 KB LDS/WG -> 4 WGs/CU; 32: 64 KB -> 2 WGs/CU)
 extern "C" int st_set_tuning(int bk) { if (bk != 16 && bk != 32) return st_fail(ST_ERR_ARG, "bk must be 16 or 32"); g_bk = bk; return ST_OK; }
 #define ST_GEMM(W_, ...) do { if (g_bk == 16) stg::launch<W_, 16>(__VA_ARGS__, g_dbg); else stg::launch<W_, 32>(__VA_ARGS__, g_dbg); } while (0)
@@ -162,7 +165,7 @@ static int ae_bwd_grid(const st_dims* d) { int groups = d->B * (st_kp_of(d->F) /
 // needs >= ~2 waves per SIMD (2048 waves) to overlap its load/LDS phases; the small-M synthesis GEMMs and the
 // 121-tile weight-gradient GEMMs get there by splitting K and summing the slabs in the consumer kernel.
 static int wgrad_split(int R) { int s = R / 200; if (s < 1) s = 1; if (s > 8) s = 8; return s; }
-static int synth_split(int R) { return R >= 4096 ? 1 : 3; }
+static int synth_split(int R) { return R >= 4096 ? 1 : 3; }   // consumers (ola_loss_kernel, ae_bwd_kernel) sum at most 3 slabs
 
 extern "C" int st_ae_fwd_partials(const st_dims* d) { return ae_fwd_grid(d) * AE_FWD_NW; }
 extern "C" int st_ola_loss_partials(const st_dims* d) { return d->B * ((d->y + 255) / 256); }
@@ -180,22 +183,34 @@ extern "C" size_t st_ae_bwd_ws_floats(const st_dims* d)
 }
 
 // ------------------------------------------------------------------------------ per-op entry points
-extern "C" int st_analysis_fwd(const st_dims* d, const float* x, const float* Wr, const float* Wi, float in_scale,
-                               float* re, float* im, float* mag, float* phs, void* stream)
+// `padded`: sig is the workspace copy [B][N + L + N] (zero margins, input scale applied) written by pad_scale_kernel.
+static int analysis_fwd_impl(const st_dims* d, const float* sig, bool padded, const float* Wr, const float* Wi, float in_scale,
+                             float* re, float* im, float* mag, float* phs, void* stream)
 {
-    ST_TRY(check_dims(d)); ST_REQ(x && Wr && Wi, "st_analysis_fwd: null input");
     const stg::RowMap map = stg::live_frames(d->T, d->H, d->N, d->N, d->L);   // frames entirely inside the Conv1d padding are skipped
     const int R = map.rows(d->B);
-    stg::FramedNT al{x, d->L, d->H, d->N, R, d->N, in_scale, map};
     stg::AnalysisW bl{Wr, Wi, d->F, d->N};
     stg::PolarStore ep{re, im, mag, phs, R, d->F, map};
-    ST_GEMM(4, al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream));
+    if (padded) { stg::FramedNT<true> al{sig, d->L, d->H, d->N, R, d->N, 1.0f, map}; ST_GEMM(4, al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream)); }
+    else { stg::FramedNT<false> al{sig, d->L, d->H, d->N, R, d->N, in_scale, map}; ST_GEMM(4, al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream)); }
     ST_LAUNCHED("analysis_fwd");
     if (map.Tv < d->T) {                   // ... and are exact zeros (re=im=mag=0, phs=atan2(0,1e-7)=0)
         hipLaunchKernelGGL(stm::zero_dead_frames_kernel, dim3(d->B * (d->T - map.Tv)), dim3(256), 0, st_stream(stream),
                            re, im, mag, phs, d->T, d->F, map.t_lo, map.Tv);
         ST_LAUNCHED("zero_dead_frames");
     }
+    return ST_OK;
+}
+extern "C" int st_analysis_fwd(const st_dims* d, const float* x, const float* Wr, const float* Wi, float in_scale,
+                               float* re, float* im, float* mag, float* phs, void* stream)
+{
+    ST_TRY(check_dims(d)); ST_REQ(x && Wr && Wi, "st_analysis_fwd: null input");
+    return analysis_fwd_impl(d, x, false, Wr, Wi, in_scale, re, im, mag, phs, stream);
+}
+static int pad_scale(const float* in, float* out, int B, int Ls, int pad, float s, void* stream)
+{
+    hipLaunchKernelGGL(stm::pad_scale_kernel, dim3(((Ls + 2 * pad) / 4 + 255) / 256, B), dim3(256), 0, st_stream(stream), in, out, Ls, pad, s);
+    ST_LAUNCHED("pad_scale");
     return ST_OK;
 }
 
@@ -252,50 +267,72 @@ extern "C" int st_synthesis_frames(const st_dims* d, const float* AA, const floa
     ST_LAUNCHED("synthesis_frames"); return ST_OK;
 }
 
+static int ola_loss_impl(const st_dims* d, const float* frs, const float* x, const float* y_true,
+                         float* y_hat, float* dsyn, int dsyn_pad, float* loss_partial, void* stream)
+{
+    const float inv = 1.0f / ((float)d->B * (float)d->y);
+    hipLaunchKernelGGL(stm::ola_loss_kernel, dim3((d->y + 255) / 256, d->B), dim3(256), 0, st_stream(stream),
+                       frs, x, y_true, y_hat, dsyn, loss_partial, d->L, d->N, d->H, d->OT, d->y, inv,
+                       st_synth_slabs(d), (size_t)d->B * d->OT * d->N, dsyn_pad);
+    ST_LAUNCHED("ola_loss");
+    return ST_OK;
+}
 extern "C" int st_ola_loss(const st_dims* d, const float* frs, const float* x, const float* y_true,
                            float* y_hat, float* dsyn, float* loss_partial, void* stream)
 {
     ST_TRY(check_dims(d)); ST_REQ(frs, "st_ola_loss: null pointer");
-    const float inv = 1.0f / ((float)d->B * (float)d->y);
-    hipLaunchKernelGGL(stm::ola_loss_kernel, dim3((d->y + 255) / 256, d->B), dim3(256), 0, st_stream(stream),
-                       frs, x, y_true, y_hat, dsyn, loss_partial, d->L, d->N, d->H, d->OT, d->y, inv,
-                       st_synth_slabs(d), (size_t)d->B * d->OT * d->N);
-    ST_LAUNCHED("ola_loss"); return ST_OK;
+    return ola_loss_impl(d, frs, x, y_true, y_hat, dsyn, 0, loss_partial, stream);
 }
 
-extern "C" int st_synthesis_dgrad(const st_dims* d, const float* dsyn, const float* Sfold, float* dAA, void* stream)
+static int synthesis_dgrad_impl(const st_dims* d, const float* dsyn, bool padded, const float* Sfold, float* dAA, void* stream)
 {
-    ST_TRY(check_dims(d)); ST_REQ(dsyn && Sfold && dAA, "st_synthesis_dgrad: null pointer");
     const int KP = st_kp_of(d->F);
     const stg::RowMap ms = synth_live(d);
     const int R = ms.rows(d->B);
     // dfrs[b,t,n] = dfull[b, H t + n] with dfull = zero-pad(dsyn, N each side)  == frames of dsyn with pad N.
     // Rows of dAA for dead frames are NOT written (st_ae_bwd treats them as zero).
-    stg::FramedNT al{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms};
-    stg::PlainNT bl{Sfold, KP, d->N, d->N, stg::all_frames(1)};
     // dAA holds st_synth_slabs() split-K slabs [B*OT, KP]; st_ae_bwd sums them
+    stg::PlainNT bl{Sfold, KP, d->N, d->N, stg::all_frames(1)};
     stg::StoreC ep{dAA, R, KP, KP, (size_t)d->B * d->OT * KP, ms};
-    if (R >= 4096) ST_GEMM(4, al, bl, ep, R, KP, d->N, 1, st_stream(stream));
-    else ST_GEMM(2, al, bl, ep, R, KP, d->N, synth_split(R), st_stream(stream));
-    ST_LAUNCHED("synthesis_dgrad"); return ST_OK;
+    const int ns = R >= 4096 ? 1 : synth_split(R);
+    if (padded) {
+        stg::FramedNT<true> al{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms};
+        if (R >= 4096) ST_GEMM(4, al, bl, ep, R, KP, d->N, ns, st_stream(stream)); else ST_GEMM(2, al, bl, ep, R, KP, d->N, ns, st_stream(stream));
+    } else {
+        stg::FramedNT<false> al{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms};
+        if (R >= 4096) ST_GEMM(4, al, bl, ep, R, KP, d->N, ns, st_stream(stream)); else ST_GEMM(2, al, bl, ep, R, KP, d->N, ns, st_stream(stream));
+    }
+    ST_LAUNCHED("synthesis_dgrad");
+    return ST_OK;
+}
+extern "C" int st_synthesis_dgrad(const st_dims* d, const float* dsyn, const float* Sfold, float* dAA, void* stream)
+{
+    ST_TRY(check_dims(d)); ST_REQ(dsyn && Sfold && dAA, "st_synthesis_dgrad: null pointer");
+    return synthesis_dgrad_impl(d, dsyn, false, Sfold, dAA, stream);
 }
 
-extern "C" int st_synthesis_wgrad(const st_dims* d, const float* AA, const float* dsyn, float* ws,
-                                  float* gSr, float* gSi, float* norm_partial, void* stream)
+static int synthesis_wgrad_impl(const st_dims* d, const float* AA, const float* dsyn, bool padded, float* ws,
+                                float* gSr, float* gSi, float* norm_partial, void* stream)
 {
-    ST_TRY(check_dims(d)); ST_REQ(AA && dsyn && ws && gSr && gSi && norm_partial, "st_synthesis_wgrad: null pointer");
     const int KP = st_kp_of(d->F);
     const stg::RowMap ms = synth_live(d);
     const int R = ms.rows(d->B);
     const int ns = wgrad_split(R);
     stg::PlainTN al{AA, R, KP, KP, ms};
-    stg::FramedTN bl{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms};
     stg::StoreC ep{ws, KP, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
-    ST_GEMM(3, al, bl, ep, KP, d->N, R, ns, st_stream(stream));
+    if (padded) { stg::FramedTN<true> bl{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms}; ST_GEMM(3, al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
+    else { stg::FramedTN<false> bl{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms}; ST_GEMM(3, al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
     ST_LAUNCHED("synthesis_wgrad");
     hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(2 * d->F), dim3(256), 0, st_stream(stream),
                        ws, ns, gSr, gSi, norm_partial, d->N, d->F, KP, 1);
-    ST_LAUNCHED("synthesis_wgrad_reduce"); return ST_OK;
+    ST_LAUNCHED("synthesis_wgrad_reduce");
+    return ST_OK;
+}
+extern "C" int st_synthesis_wgrad(const st_dims* d, const float* AA, const float* dsyn, float* ws,
+                                  float* gSr, float* gSi, float* norm_partial, void* stream)
+{
+    ST_TRY(check_dims(d)); ST_REQ(AA && dsyn && ws && gSr && gSi && norm_partial, "st_synthesis_wgrad: null pointer");
+    return synthesis_wgrad_impl(d, AA, dsyn, false, ws, gSr, gSi, norm_partial, stream);
 }
 
 extern "C" int st_ae_bwd(const st_dims* d, const float* mag, const float* phs, const float* knobs,
@@ -316,7 +353,7 @@ extern "C" int st_ae_bwd(const st_dims* d, const float* mag, const float* phs, c
     const int grid = ae_bwd_grid(d);
     hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, AE_BWD_REG>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, st_stream(stream),
                        mag, phs, knobs, ae_m, ae_p, L.go, L.PG, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, expfac,
-                       dmag, dphs, ws, d->B, d->T, d->OT, d->F, d->K, L.KP, synth_live(d).t_lo, synth_live(d).t_lo + synth_live(d).Tv - 1, st_synth_slabs(d), (size_t)d->B * d->OT * L.KP);
+                       dmag, dphs, ws, d->B, d->T, d->OT, d->F, d->K, L.KP, synth_live(d).t_lo, synth_live(d).t_lo + synth_live(d).Tv - 1, st_synth_slabs(d), (size_t)d->B * d->OT * L.KP, g_dbg);
     ST_LAUNCHED("ae_bwd");
     hipLaunchKernelGGL(stm::ae_grad_reduce_kernel, dim3((L.PG + 63) / 64, 2), dim3(256), 0, st_stream(stream),
                        ws, grid, L.PG, g_m, g_p);
@@ -333,22 +370,28 @@ extern "C" int st_polar_bwd(const st_dims* d, const float* re, const float* im, 
     ST_LAUNCHED("polar_bwd"); return ST_OK;
 }
 
-extern "C" int st_analysis_wgrad(const st_dims* d, const float* dG, const float* x, float in_scale, float* ws,
-                                 float* gWr, float* gWi, float* norm_partial, void* stream)
+static int analysis_wgrad_impl(const st_dims* d, const float* dG, const float* sig, bool padded, float in_scale, float* ws,
+                               float* gWr, float* gWi, float* norm_partial, void* stream)
 {
-    ST_TRY(check_dims(d)); ST_REQ(dG && x && ws && gWr && gWi && norm_partial, "st_analysis_wgrad: null pointer");
     const int KP = st_kp_of(d->F);
     const stg::RowMap ma = stg::live_frames(d->T, d->H, d->N, d->N, d->L);   // all-zero frames contribute nothing
     const int R = ma.rows(d->B);
     const int ns = wgrad_split(R);
     stg::PlainTN al{dG, R, KP, KP, ma};
-    stg::FramedTN bl{x, d->L, d->H, d->N, R, d->N, in_scale, ma};
     stg::StoreC ep{ws, KP, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
-    ST_GEMM(3, al, bl, ep, KP, d->N, R, ns, st_stream(stream));
+    if (padded) { stg::FramedTN<true> bl{sig, d->L, d->H, d->N, R, d->N, 1.0f, ma}; ST_GEMM(3, al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
+    else { stg::FramedTN<false> bl{sig, d->L, d->H, d->N, R, d->N, in_scale, ma}; ST_GEMM(3, al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
     ST_LAUNCHED("analysis_wgrad");
     hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(2 * d->F), dim3(256), 0, st_stream(stream),
                        ws, ns, gWr, gWi, norm_partial, d->N, d->F, KP, 0);
-    ST_LAUNCHED("analysis_wgrad_reduce"); return ST_OK;
+    ST_LAUNCHED("analysis_wgrad_reduce");
+    return ST_OK;
+}
+extern "C" int st_analysis_wgrad(const st_dims* d, const float* dG, const float* x, float in_scale, float* ws,
+                                 float* gWr, float* gWi, float* norm_partial, void* stream)
+{
+    ST_TRY(check_dims(d)); ST_REQ(dG && x && ws && gWr && gWi && norm_partial, "st_analysis_wgrad: null pointer");
+    return analysis_wgrad_impl(d, dG, x, false, in_scale, ws, gWr, gWi, norm_partial, stream);
 }
 
 extern "C" int st_finalize_scalars(const st_dims* d, const float* loss_partial, const float* reg_partial,
@@ -379,9 +422,17 @@ extern "C" int st_clip_adam(float* params, float* grads, float* m, float* v, int
     ST_LAUNCHED("clip_adam"); return ST_OK;
 }
 
+extern "C" int st_debug_read_stage_cycles(unsigned long long* out32)
+{
+    unsigned long long z[32] = {0};
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(sta::g_ae_stage_cycles), sizeof(z)) != hipSuccess) return st_fail(ST_ERR_LAUNCH, "memcpyFromSymbol");
+    if (hipMemcpyToSymbol(HIP_SYMBOL(sta::g_ae_stage_cycles), z, sizeof(z)) != hipSuccess) return st_fail(ST_ERR_LAUNCH, "memcpyToSymbol");
+    return ST_OK;
+}
+
 // ------------------------------------------------------------------------------ workspace
 struct WS {
-    float *re, *im, *mag, *phs, *mag_hat, *phs_hat, *AA, *dAA, *Sfold, *frs, *y_hat, *dsyn, *dmag, *dphs, *dG;
+    float *re, *im, *mag, *phs, *mag_hat, *phs_hat, *AA, *dAA, *Sfold, *frs, *y_hat, *dsyn, *dmag, *dphs, *dG, *xp;
     float *wg, *aews, *loss_p, *reg_p, *norm_a, *norm_s;
     size_t bytes;
 };
@@ -395,7 +446,8 @@ static void carve(const st_dims* d, void* base, WS* w)
     const size_t nsl = st_synth_slabs(d);
     w->AA = take(RO * KP); w->dAA = take(nsl * RO * KP);
     w->Sfold = take(KP * N); w->frs = take(nsl * RO * N);
-    w->y_hat = take((size_t)d->B * d->y); w->dsyn = take((size_t)d->B * d->y);
+    w->y_hat = take((size_t)d->B * d->y); w->dsyn = take((size_t)d->B * (d->y + 2 * d->N));   // dsyn padded [B][N + y + N]
+    w->xp = take((size_t)d->B * (d->L + 2 * d->N));                                               // x/2 padded  [B][N + L + N]
     w->dmag = take(RT * F); w->dphs = take(RT * F); w->dG = take(RT * KP);
     w->wg = take(st_wgrad_ws_floats(d)); w->aews = take(st_ae_bwd_ws_floats(d));
     w->loss_p = take(st_ola_loss_partials(d)); w->reg_p = take(st_ae_fwd_partials(d));
@@ -416,12 +468,13 @@ static int forward_impl(const st_dims* d, const Layout& L, const float* params, 
     const float* Sr = params + L.offs[2]; const float* Si = params + L.offs[3];
     const float* ae_m = params + L.offs[4]; const float* ae_p = params + L.offs[22];
     // saved-for-backward state always lives in the workspace; user-visible outputs are copies
-    ST_TRY(st_analysis_fwd(d, x, Wr, Wi, 0.5f, save ? w.re : nullptr, save ? w.im : nullptr, w.mag, w.phs, stream));
+    ST_TRY(pad_scale(x, w.xp, d->B, d->L, d->N, 0.5f, stream));                 // x/2 (nn_proc.py:307) + Conv1d padding, once
+    ST_TRY(analysis_fwd_impl(d, w.xp, true, Wr, Wi, 1.0f, save ? w.re : nullptr, save ? w.im : nullptr, w.mag, w.phs, stream));
     ST_TRY(st_ae_fwd(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.AA, w.reg_p, stream));
     ST_TRY(st_synth_fold(d, Sr, Si, w.Sfold, stream));
     ST_TRY(st_synthesis_frames(d, w.AA, w.Sfold, w.frs, stream));
-    ST_TRY(st_ola_loss(d, w.frs, x, y_true, y_hat ? y_hat : w.y_hat, (save && y_true) ? w.dsyn : nullptr,
-                       y_true ? w.loss_p : nullptr, stream));
+    ST_TRY(ola_loss_impl(d, w.frs, x, y_true, y_hat ? y_hat : w.y_hat, (save && y_true) ? w.dsyn : nullptr, d->N,
+                         y_true ? w.loss_p : nullptr, stream));
     const size_t nm = (size_t)d->B * d->T * d->F * sizeof(float), nh = (size_t)d->B * d->OT * d->F * sizeof(float);
     if (mag && hipMemcpyAsync(mag, w.mag, nm, hipMemcpyDeviceToDevice, st_stream(stream)) != hipSuccess) return st_fail(ST_ERR_LAUNCH, "copy mag");
     if (mag_hat && hipMemcpyAsync(mag_hat, w.mag_hat, nh, hipMemcpyDeviceToDevice, st_stream(stream)) != hipSuccess) return st_fail(ST_ERR_LAUNCH, "copy mag_hat");
@@ -435,8 +488,8 @@ static int backward_p1(const st_dims* d, const Layout& L, const float* params, f
                        const float* knobs, const float* g_mag_hat, const float* g_mag, float reg_coef, WS& w, void* stream)
 {
     const float* ae_m = params + L.offs[4]; const float* ae_p = params + L.offs[22];
-    ST_TRY(st_synthesis_dgrad(d, w.dsyn, w.Sfold, w.dAA, stream));
-    ST_TRY(st_synthesis_wgrad(d, w.AA, w.dsyn, w.wg, grads + L.offs[2], grads + L.offs[3], w.norm_s, stream));
+    ST_TRY(synthesis_dgrad_impl(d, w.dsyn, true, w.Sfold, w.dAA, stream));
+    ST_TRY(synthesis_wgrad_impl(d, w.AA, w.dsyn, true, w.wg, grads + L.offs[2], grads + L.offs[3], w.norm_s, stream));
     ST_TRY(st_ae_bwd(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.dAA, g_mag_hat, reg_coef, w.dmag, w.dphs,
                      w.aews, grads + L.offs[4], grads + L.offs[22], stream));
     ST_TRY(st_polar_bwd(d, w.re, w.im, w.dmag, w.dphs, g_mag, w.dG, stream));
@@ -444,7 +497,8 @@ static int backward_p1(const st_dims* d, const Layout& L, const float* params, f
 }
 static int backward_p2(const st_dims* d, const Layout& L, float* grads, const float* x, WS& w, void* stream)
 {
-    return st_analysis_wgrad(d, w.dG, x, 0.5f, w.wg, grads + L.offs[0], grads + L.offs[1], w.norm_a, stream);
+    (void)x;
+    return analysis_wgrad_impl(d, w.dG, w.xp, true, 1.0f, w.wg, grads + L.offs[0], grads + L.offs[1], w.norm_a, stream);
 }
 static int backward_impl(const st_dims* d, const Layout& L, const float* params, float* grads, const float* x,
                          const float* knobs, const float* g_mag_hat, const float* g_mag, float reg_coef, WS& w, void* stream)
@@ -468,9 +522,7 @@ extern "C" int st_model_bwd(const st_dims* d, const float* params, float* grads,
     Layout L; ST_TRY(make_layout(d, &L));
     ST_REQ(params && grads && x && knobs && g_y_hat && ws, "st_model_bwd: null pointer");
     WS w; carve(d, ws, &w);
-    const int64_t n = (int64_t)d->B * d->y;
-    hipLaunchKernelGGL(stm::scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st_stream(stream), g_y_hat, w.dsyn, n, 2.0f);
-    ST_LAUNCHED("scale(dsyn)");
+    ST_TRY(pad_scale(g_y_hat, w.dsyn, d->B, d->y, d->N, 2.0f, stream));     // dsyn = 2 * g_y_hat, padded for the framed loaders
     return backward_impl(d, L, params, grads, x, knobs, g_mag_hat, g_mag, 0.0f, w, stream);
 }
 

@@ -61,17 +61,29 @@ struct RowState {
 };
 
 // ------------------------------------------------------------------------------ loaders
+// A loader either needs per-load validity (kCheck: the load is clamped to a valid address and the value replaced by
+// zero) or not: operands whose out-of-range rows/columns only feed output elements that the epilogue masks are simply
+// clamped (garbage in, masked out), which removes the compare/select VALU work from the k-loop.
+//
 // Rows = overlapped frames of a batch of signals: compact row r -> (b, t), element k = sig[b, H*t - pad + k].
 // Replaces Conv1d's implicit im2col (cls_fe_dft.py:55-56) and the framed operand of every backward GEMM.
+// PADDED = true: `sig` is the workspace copy [B][pad + Ls + pad] with zero margins and the input scale already
+// applied (st_pad_scale / ola_loss_kernel write it once per step): every frame element exists, no validity logic.
+template <bool PADDED>
 struct FramedNT {
     static constexpr bool kTN = false;
+    static constexpr bool kCheck = !PADDED;
     const float* sig; int Ls, H, pad, R, Kw; float scale; RowMap map;
     __device__ const float* dummy() const { return sig; }
     __device__ RowState row_state(int r) const {
         RowState s; s.p = sig; s.lo = 0; s.hi = 0;
-        if (r < R) {
+        if (PADDED) {
+            int b, t; map.split(r < R ? r : 0, b, t);         // rows >= R: clamped, their outputs are masked
+            s.p = sig + (size_t)b * (Ls + 2 * pad) + H * t;   // padded coordinate of frame start (bit-exact contract: H*t - pad + pad)
+            s.hi = Kw;
+        } else if (r < R) {
             int b, t; map.split(r, b, t);
-            const int start = H * t - pad;                 // frame start in the unpadded signal (bit-exact contract)
+            const int start = H * t - pad;                    // frame start in the unpadded signal
             s.p = sig + (size_t)b * Ls + start;
             s.lo = start < 0 ? -start : 0;
             s.hi = (Ls - start) < Kw ? (Ls - start) : Kw;
@@ -79,16 +91,26 @@ struct FramedNT {
         }
         return s;
     }
-    __device__ Src src(const RowState& s, int k) const { return Src{s.p + k, k >= s.lo && k < s.hi}; }
-    __device__ float4 post(float4 v) const { v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; return v; }
+    __device__ Src src(const RowState& s, int k) const { return Src{s.p + k, PADDED || (k >= s.lo && k < s.hi)}; }
+    __device__ float4 post(float4 v) const {
+        if (!PADDED) { v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; }
+        return v;
+    }
 };
 
-// Same frames, TN-type (reduction index = compact frame row r, contiguous along the tap n).
+// Same frames, TN-type (reduction index = compact frame row r, contiguous along the tap n).  With PADDED the rows past
+// R are clamped: the other operand of a weight-gradient GEMM zeroes them.
+template <bool PADDED>
 struct FramedTN {
     static constexpr bool kTN = true;
+    static constexpr bool kCheck = !PADDED;
     const float* sig; int Ls, H, pad, R, Kw; float scale; RowMap map;
     __device__ const float* dummy() const { return sig; }
     __device__ Src src(int r, int n) const {
+        if (PADDED) {
+            int b, t; map.split(r < R ? r : 0, b, t);
+            return Src{sig + (size_t)b * (Ls + 2 * pad) + H * t + n, true};
+        }
         Src s{sig, false};
         if (r < R && n < Kw) {
             int b, t; map.split(r, b, t);
@@ -98,26 +120,32 @@ struct FramedTN {
         }
         return s;
     }
-    __device__ float4 post(float4 v) const { v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; return v; }
+    __device__ float4 post(float4 v) const {
+        if (!PADDED) { v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; }
+        return v;
+    }
 };
 
-// Dense row-major [rows][ld] matrix, reduction along the row (NT-type); compact rows via RowMap.
+// Dense row-major [rows][ld] matrix, reduction along the row (NT-type); compact rows via RowMap.  Requires K % BK == 0;
+// rows past R are clamped (masked outputs).
 struct PlainNT {
     static constexpr bool kTN = false;
+    static constexpr bool kCheck = false;
     const float* base; int R, ld, K; RowMap map;
     __device__ const float* dummy() const { return base; }
     __device__ RowState row_state(int r) const {
-        RowState s; s.lo = 0; s.hi = (r < R) ? K : 0;
-        s.p = base + (size_t)(r < R ? map.full(r) : 0) * ld;
+        RowState s; s.lo = 0; s.hi = K;
+        s.p = base + (size_t)map.full(r < R ? r : 0) * ld;
         return s;
     }
-    __device__ Src src(const RowState& s, int k) const { return Src{s.p + k, k < s.hi}; }
+    __device__ Src src(const RowState& s, int k) const { return Src{s.p + k, true}; }
     __device__ float4 post(float4 v) const { return v; }
 };
 
-// Dense row-major [K][ld] matrix, reduction along the (compact) rows (TN-type).
+// Dense row-major [K][ld] matrix, reduction along the (compact) rows (TN-type): rows past K must read as zero.
 struct PlainTN {
     static constexpr bool kTN = true;
+    static constexpr bool kCheck = true;
     const float* base; int K, ld, cols; RowMap map;
     __device__ const float* dummy() const { return base; }
     __device__ Src src(int k, int c) const {
@@ -128,20 +156,20 @@ struct PlainTN {
 };
 
 // Analysis bases as the B operand: GEMM column j -> (bin = j>>1, re/im = j&1); only the F used rows
-// of the [N,N] parameters are ever touched (cls_fe_dft.py:55-56 computes all N then slices).
+// of the [N,N] parameters are ever touched (cls_fe_dft.py:55-56 computes all N then slices).  Columns past 2F are
+// clamped (the polar epilogue masks bin >= F).
 struct AnalysisW {
     static constexpr bool kTN = false;
+    static constexpr bool kCheck = false;
     const float* Wr; const float* Wi; int F, N;
     __device__ const float* dummy() const { return Wr; }
     __device__ RowState row_state(int j) const {
         const int bin = j >> 1;
-        RowState s; s.lo = 0;
-        const bool ok = bin < F;
-        s.p = ((j & 1) ? Wi : Wr) + (size_t)(ok ? bin : 0) * N;
-        s.hi = ok ? N : 0;
+        RowState s; s.lo = 0; s.hi = N;
+        s.p = ((j & 1) ? Wi : Wr) + (size_t)(bin < F ? bin : 0) * N;
         return s;
     }
-    __device__ Src src(const RowState& s, int k) const { return Src{s.p + k, k < s.hi}; }
+    __device__ Src src(const RowState& s, int k) const { return Src{s.p + k, true}; }
     __device__ float4 post(float4 v) const { return v; }
 };
 
@@ -170,32 +198,30 @@ struct StoreC {       // out[(z*slab) + full_row*ld + col]; z = blockIdx.z (spli
     }
 };
 
-// Analysis epilogue: nn_proc.py:309-310 fused.  Columns are interleaved (re,im) pairs of one bin in
-// adjacent lanes; a lane-pair exchange gives both, even lanes store (re, mag), odd lanes (im, phs).
+// Analysis epilogue: nn_proc.py:309-310 fused.  Columns are interleaved (re,im) pairs of one bin in adjacent lanes.
+// Registers are processed in pairs (rows r, r+1): one lane-pair exchange hands the even lane the full complex value
+// of row r and the odd lane that of row r+1, so every lane does ONE sqrt and ONE atan2 per register pair.
 struct PolarStore {
     float* re; float* im; float* mag; float* phs; int R, F; RowMap map;
     __device__ void operator()(int m0, int n0, const f32x16 (&acc)[NJ]) const {
         const int lane = threadIdx.x & 63;
         const bool odd = lane & 1;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = m0 + d_row(i, lane);
+        for (int i = 0; i < 16; i += 2) {
+            const int row = m0 + d_row(i + (odd ? 1 : 0), lane);
             const size_t rbase = (size_t)(row < R ? map.full(row) : 0) * F;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int bin = (n0 + 32 * j + (lane & 31)) >> 1;
-                const float v = acc[j][i];
-                const float o = __shfl_xor(v, 1);
-                const float vr = odd ? o : v, vi = odd ? v : o;
+                const float v0 = acc[j][i], v1 = acc[j][i + 1];
+                const float got = __shfl_xor(odd ? v0 : v1, 1);      // even lane receives im(row r), odd lane re(row r+1)
+                const float vr = odd ? got : v0, vi = odd ? v1 : got;
                 if (row < R && bin < F) {
                     const size_t idx = rbase + bin;
-                    if (!odd) {
-                        if (re) re[idx] = vr;
-                        if (mag) mag[idx] = sqrtf(vr * vr + vi * vi);
-                    } else {
-                        if (im) im[idx] = vi;
-                        if (phs) phs[idx] = atan2f(vi, vr + 1e-7f);
-                    }
+                    if (re) re[idx] = vr;
+                    if (im) im[idx] = vi;
+                    if (mag) mag[idx] = sqrtf(vr * vr + vi * vi);
+                    if (phs) phs[idx] = atan2f(vi, vr + 1e-7f);
                 }
             }
         }
@@ -255,15 +281,15 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
         for (int p = 0; p < A_IT; ++p) {
             Src s;
             if constexpr (AL::kTN) s = al.src(kt + a_k[p], m_blk + a_i[p]); else s = al.src(a_st[p], kt + a_k[p]);
-            oa[p] = s.ok;
-            ra[p] = *reinterpret_cast<const float4*>(s.ok ? s.p : al.dummy());
+            if constexpr (AL::kCheck) { oa[p] = s.ok; ra[p] = *reinterpret_cast<const float4*>(s.ok ? s.p : al.dummy()); }
+            else ra[p] = *reinterpret_cast<const float4*>(s.p);
         }
 #pragma unroll
         for (int p = 0; p < B_IT; ++p) {
             Src s;
             if constexpr (BL::kTN) s = bl.src(kt + b_k[p], n_blk + b_i[p]); else s = bl.src(b_st[p], kt + b_k[p]);
-            ob[p] = s.ok;
-            rb[p] = *reinterpret_cast<const float4*>(s.ok ? s.p : bl.dummy());
+            if constexpr (BL::kCheck) { ob[p] = s.ok; rb[p] = *reinterpret_cast<const float4*>(s.ok ? s.p : bl.dummy()); }
+            else rb[p] = *reinterpret_cast<const float4*>(s.p);
         }
     };
     auto lstore = [&](int buf) {
@@ -272,10 +298,10 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int p = 0; p < A_IT; ++p)
-            if (A_N % NT == 0 || a_v[p]) *reinterpret_cast<float4*>(as + a_l[p]) = oa[p] ? al.post(ra[p]) : zero;
+            if (A_N % NT == 0 || a_v[p]) *reinterpret_cast<float4*>(as + a_l[p]) = (!AL::kCheck || oa[p]) ? al.post(ra[p]) : zero;
 #pragma unroll
         for (int p = 0; p < B_IT; ++p)
-            if (B_N % NT == 0 || b_v[p]) *reinterpret_cast<float4*>(bs + b_l[p]) = ob[p] ? bl.post(rb[p]) : zero;
+            if (B_N % NT == 0 || b_v[p]) *reinterpret_cast<float4*>(bs + b_l[p]) = (!BL::kCheck || ob[p]) ? bl.post(rb[p]) : zero;
     };
 
     f32x16 acc[NJ];

@@ -55,7 +55,7 @@ zero_dead_frames_kernel(float* __restrict__ a0, float* __restrict__ a1, float* _
 __global__ void __launch_bounds__(256)
 ola_loss_kernel(const float* __restrict__ frs, const float* __restrict__ x, const float* __restrict__ y_true,
                 float* __restrict__ y_hat, float* __restrict__ dsyn, float* __restrict__ loss_partial,
-                int L, int N, int H, int OT, int ysz, float inv_count, int nslab, size_t slab)
+                int L, int N, int H, int OT, int ysz, float inv_count, int nslab, size_t slab, int dsyn_pad)
 {
     __shared__ float red[4];
     const int b = blockIdx.y;
@@ -67,20 +67,44 @@ ola_loss_kernel(const float* __restrict__ frs, const float* __restrict__ x, cons
         if (t1 > OT - 1) t1 = OT - 1;
         const float* fb = frs + (size_t)b * OT * N;
         float s = 0.f;
-        for (int t = t0; t <= t1; ++t)
-            for (int z = 0; z < nslab; ++z) s += fb[z * slab + (size_t)t * N + (N + j - H * t)];   // split-K slabs of the synthesis GEMM
+        for (int t = t0; t <= t1; ++t) {            // up to 3 split-K slabs of the synthesis GEMM, loads issued together
+            const size_t o = (size_t)t * N + (N + j - H * t);
+            const float v0 = fb[o], v1 = fb[(nslab > 1 ? slab : 0) + o], v2 = fb[(nslab > 2 ? 2 * slab : 0) + o];
+            s += v0 + (nslab > 1 ? v1 : 0.f) + (nslab > 2 ? v2 : 0.f);
+        }
         const float out = x ? 2.0f * (s + 0.5f * x[(size_t)b * L + (L - ysz) + j]) : s;   // x == NULL: plain Synthesis.forward (cls_fe_dft.py:112-113)
         if (y_hat) y_hat[(size_t)b * ysz + j] = out;
         if (y_true) {
             const float dlt = y_true[(size_t)b * ysz + j] - out;
             const float a = fabsf(dlt);
             lc = a + log1pf(__expf(-2.0f * a)) - 0.69314718056f;      // log(cosh(d)), overflow-free
-            if (dsyn) dsyn[(size_t)b * ysz + j] = -2.0f * tanhf(dlt) * inv_count;
+            if (dsyn) dsyn[(size_t)b * (ysz + 2 * dsyn_pad) + dsyn_pad + j] = -2.0f * tanhf(dlt) * inv_count;   // dsyn_pad > 0: padded layout for the framed loaders
         }
+    }
+    if (dsyn && dsyn_pad > 0) {                  // zero margins of the padded gradient signal (2*pad floats per window)
+        float* row = dsyn + (size_t)b * (ysz + 2 * dsyn_pad);
+        for (int m = blockIdx.x * 256 + threadIdx.x; m < 2 * dsyn_pad; m += gridDim.x * 256)
+            row[m < dsyn_pad ? m : ysz + m] = 0.f;
     }
     if (loss_partial) {
         const float tot = block_sum<4>(lc, red);
         if (threadIdx.x == 0) loss_partial[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+    }
+}
+
+// out[b][pad + Ls + pad] = zero margins | s * in[b][Ls]: the padded, pre-scaled signal the framed GEMM loaders read
+// (x/2 of nn_proc.py:307 with the Conv1d padding of cls_fe_dft.py:28-31 materialised once per step, 10 MB at B=256).
+__global__ void __launch_bounds__(256)
+pad_scale_kernel(const float* __restrict__ in, float* __restrict__ out, int Ls, int pad, float s)
+{
+    const int b = blockIdx.y, Lp4 = (Ls + 2 * pad) / 4;
+    const float4* src = reinterpret_cast<const float4*>(in + (size_t)b * Ls);
+    float4* dst = reinterpret_cast<float4*>(out + (size_t)b * (Ls + 2 * pad));
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < Lp4; i += gridDim.x * 256) {
+        const int j = i - pad / 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j >= 0 && j < Ls / 4) { v = src[j]; v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
+        dst[i] = v;
     }
 }
 
