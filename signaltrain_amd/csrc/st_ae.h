@@ -333,7 +333,11 @@ constexpr int SP = 20;                 // scratch pitch (floats): 16 rows + 4, k
 
 // Diagnostics only (st_set_debug bit 8): wave 0 of workgroup (0,0) accumulates s_memtime deltas per kernel stage.
 __device__ unsigned long long g_ae_stage_cycles[32];
-#define ST_T(i_) do { if (timing) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_ae_stage_cycles[i_] += t1_ - t0_; t0_ = __builtin_amdgcn_s_memtime(); } } while (0)
+// Stage timers exist only in the TIMED instantiation.  They must not be a run-time branch of the production kernel:
+// a basic-block boundary between an MFMA chain and the first v_accvgpr_read of its result escapes the compiler's
+// MFMA->VALU hazard padding (measured: the last k-step of layer 5 missing from accumulator element 3), hence the
+// explicit wait states ahead of the branch in the TIMED build.
+#define ST_T(i_) do { if constexpr (TIMED) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 15\n\ts_nop 15"); __builtin_amdgcn_sched_barrier(0); if (timing) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_ae_stage_cycles[i_] += t1_ - t0_; t0_ = __builtin_amdgcn_s_memtime(); } } } while (0)
 
 // ---------------------------------------------------------------------------------------------------------
 // Weight fragments in registers.  Left to itself the compiler issues each MFMA's LDS weight fetch just before
@@ -581,7 +585,7 @@ struct CL {
 #define ST_SCHED_FENCE() do { if constexpr (!REG) __builtin_amdgcn_sched_barrier(0); } while (0)
 
 // Supported geometry of this instantiation: T <= 32, OT <= 16, K <= 16.
-template <int NW, bool REG>      // REG: persistent register accumulators (1 wave/SIMD); else per-group LDS atomics (2 waves/SIMD)
+template <int NW, bool REG, bool TIMED>   // REG: persistent register accumulators (1 wave/SIMD); else per-group LDS atomics (2 waves/SIMD)
 __global__ void __launch_bounds__(NW * 64, REG ? 1 : 2)
 ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, const float* __restrict__ knobs,
               const float* __restrict__ ae_m, const float* __restrict__ ae_p, const AEOffsets go, const int PG,
@@ -595,7 +599,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int ae = blockIdx.y;
-    const bool timing = (dbg & 256) && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x >> 6) == 0;
+    const bool timing = TIMED && (dbg & 256) && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x >> 6) == 0;
     unsigned long long t0_ = timing ? __builtin_amdgcn_s_memtime() : 0ull;
     const AELds L = ae_lds_layout(T, OT, K);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -676,7 +680,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             q_mt[r] = vin[((size_t)b * T + (ok ? T - OT + to : 0)) * F + fq];
             q_gm[r] = (g_mag_hat && ok) ? g_mag_hat[ro * F + fq] : 0.f;
         }
-        // knob values: D-layout feature tile (16 + 4g + r) and T-layout feature lane (16 + c), loaded up front
+        // knob values: D-layout feature tile (16 + 4g + r) and T-layout feature lane (16 + c)
         f32x4 kn[1]; float knT;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const int kidx = 4 * g + r; const float x = knobs[(size_t)b * K + (kidx < K ? kidx : 0)]; kn[0][r] = kidx < K ? x : 0.f; }

@@ -348,12 +348,20 @@ extern "C" int st_ae_bwd(const st_dims* d, const float* mag, const float* phs, c
     const size_t lds = ((size_t)2 * ll.total + (size_t)AE_BWD_NW * (32 + 16 + 16) * sta::SP) * sizeof(float);
     ST_REQ(lds <= 160 * 1024, "st_ae_bwd: needs %zu B of LDS", lds);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, AE_BWD_REG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, AE_BWD_REG, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, AE_BWD_REG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
     const float expfac = (float)(7.0 / d->F);
     const int grid = ae_bwd_grid(d);
-    hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, AE_BWD_REG>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, st_stream(stream),
-                       mag, phs, knobs, ae_m, ae_p, L.go, L.PG, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, expfac,
-                       dmag, dphs, ws, d->B, d->T, d->OT, d->F, d->K, L.KP, synth_live(d).t_lo, synth_live(d).t_lo + synth_live(d).Tv - 1, st_synth_slabs(d), (size_t)d->B * d->OT * L.KP, g_dbg);
+#define ST_AE_BWD_LAUNCH(TIMED_) \
+    hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, AE_BWD_REG, TIMED_>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, st_stream(stream), \
+                       mag, phs, knobs, ae_m, ae_p, L.go, L.PG, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, expfac, \
+                       dmag, dphs, ws, d->B, d->T, d->OT, d->F, d->K, L.KP, synth_live(d).t_lo, synth_live(d).t_lo + synth_live(d).Tv - 1, st_synth_slabs(d), (size_t)d->B * d->OT * L.KP, g_dbg)
+    if (g_dbg & 256) ST_AE_BWD_LAUNCH(true);      // stage-timer build (tools/ae_stage_times.py)
+    else ST_AE_BWD_LAUNCH(false);
+#undef ST_AE_BWD_LAUNCH
     ST_LAUNCHED("ae_bwd");
     hipLaunchKernelGGL(stm::ae_grad_reduce_kernel, dim3((L.PG + 63) / 64, 2), dim3(256), 0, st_stream(stream),
                        ws, grid, L.PG, g_m, g_p);

@@ -139,3 +139,12 @@ def test_cpu_port_matches_oracle():
         assert abs(lp - lo) <= 3e-5 * abs(lo)
         for k in Pq:
             assert np.abs(port.P[k].detach().numpy() - Pq[k]).max() < 2e-5, k   # Adam normalises noise-level gradient elements: lr-sized differences are expected there
+
+
+def test_no_cross_block_mfma_result_hazards():
+    """ISA regression check (tools/check_mfma_hazards.py): no MFMA result is first read behind a basic-block
+    boundary with fewer wait states than the compiler pads inside a block.  Round 1 found exactly that in
+    ae_bwd_kernel (a run-time stage-timer branch after an MFMA chain): timing-dependent wrong results."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_mfma_hazards.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
