@@ -641,54 +641,63 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     // input rows of the first group (prefetched one group ahead afterwards): t = 4 ks + g, row c
     float vr[8];
     int grp = blockIdx.x * NW + wave;
+    // Input rows of group gq as RAW loads from clamped (always valid) addresses; mask_v() zeroes the padding
+    // rows/bins afterwards.  Keeping the select out of the load sequence (and the whole prefetch out of a
+    // conditional block) matters: the `if (next < ngroups) { x = load; dst = ok ? x : 0; }` form compiled to
+    // eight load / s_waitcnt vmcnt(0) pairs, i.e. eight serialized memory round trips per group.
     auto load_v = [&](int gq, float (&dst)[8]) {
         const int bq = gq / gpw, fq = (gq - bq * gpw) * 16 + c;
-        const bool ok0 = fq < F;
+        const int fc = fq < F ? fq : 0;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const int t = 4 * ks + g;
-            const bool ok = ok0 && t < T;
-            const float x = vin[((size_t)bq * T + (ok ? t : 0)) * F + (ok0 ? fq : 0)];
-            dst[ks] = ok ? x : 0.f;
+            dst[ks] = vin[((unsigned)bq * T + (t < T ? t : 0)) * F + fc];
         }
     };
-    if (grp < ngroups) load_v(grp, vr);
+    auto mask_v = [&](int gq, float (&dst)[8]) {
+        const int bq = gq / gpw, fq = (gq - bq * gpw) * 16 + c;
+        const bool ok0 = fq < F;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) dst[ks] = (ok0 && 4 * ks + g < T) ? dst[ks] : 0.f;
+    };
+    if (grp < ngroups) { load_v(grp, vr); mask_v(grp, vr); }
 
     for (; grp < ngroups; grp += gstride) {
         asm volatile("" ::: "memory");      // keep the (loop-invariant) LDS weight fetches inside the loop
         const int b = grp / gpw, f = (grp - b * gpw) * 16 + c;
         const bool fv = f < F;
         const int fq = fv ? f : 0;
-        // ---- d-out inputs for this group (D layout: t' = 4g + r), issued early
+        // ---- d-out inputs for this group (D layout: t' = 4g + r), issued early.  (Slicing these 53 loads between the
+        // forward stages to overlap their issue with MFMA execution was measured: no gain.)
         float q_gre[4], q_gim[4], q_ph[4], q_mh[4], q_mt[4], q_gm[4];
+        const float* gmp = g_mag_hat ? g_mag_hat : mag_hat;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int to = 4 * g + r;
             const bool ok = fv && to < OT;
             const bool lv = ok && to >= to_lo && to <= to_hi;
-            const size_t ro = (size_t)b * OT + (ok ? to : 0);
+            const unsigned ro = (unsigned)b * OT + (ok ? to : 0);      // 32-bit offsets throughout (host checks the sizes): saddr + voffset loads
             // up to 3 split-K slabs: all six loads are issued together, then summed (a runtime-trip-count loop here
             // serialised ~12 memory round trips per group)
-            const float* p0 = dAA + ((lv ? ro : (size_t)0) * (size_t)KP + (size_t)fq);
-            const size_t o1 = nslab > 1 ? slab : (size_t)0, o2 = nslab > 2 ? 2 * slab : (size_t)0;
-            const float x0 = p0[0], x1 = p0[o1], x2 = p0[o2];
-            const float y0 = p0[FP], y1 = p0[o1 + FP], y2 = p0[o2 + FP];
+            const unsigned p0 = (lv ? ro : 0u) * KP + fq;
+            const unsigned o1 = nslab > 1 ? (unsigned)slab : 0u, o2 = nslab > 2 ? 2u * (unsigned)slab : 0u;
+            const float x0 = dAA[p0], x1 = dAA[p0 + o1], x2 = dAA[p0 + o2];
+            const float y0 = dAA[p0 + FP], y1 = dAA[p0 + o1 + FP], y2 = dAA[p0 + o2 + FP];
             const float a0 = x0 + (nslab > 1 ? x1 : 0.f) + (nslab > 2 ? x2 : 0.f);
             const float a1 = y0 + (nslab > 1 ? y1 : 0.f) + (nslab > 2 ? y2 : 0.f);
             q_gre[r] = lv ? a0 : 0.f; q_gim[r] = lv ? a1 : 0.f;
             q_ph[r] = phs_hat[ro * F + fq]; q_mh[r] = mag_hat[ro * F + fq];
-            q_mt[r] = vin[((size_t)b * T + (ok ? T - OT + to : 0)) * F + fq];
-            q_gm[r] = (g_mag_hat && ok) ? g_mag_hat[ro * F + fq] : 0.f;
+            q_mt[r] = vin[((unsigned)b * T + (ok ? T - OT + to : 0)) * F + fq];
+            { const float x = gmp[ro * F + fq]; q_gm[r] = (g_mag_hat && ok) ? x : 0.f; }      // branch-free (see load_v)
         }
         // knob values: D-layout feature tile (16 + 4g + r) and T-layout feature lane (16 + c)
         f32x4 kn[1]; float knT;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int kidx = 4 * g + r; const float x = knobs[(size_t)b * K + (kidx < K ? kidx : 0)]; kn[0][r] = kidx < K ? x : 0.f; }
-        { const float x = knobs[(size_t)b * K + (c < K ? c : 0)]; knT = c < K ? x : 0.f; }
+        for (int r = 0; r < 4; ++r) { const int kidx = 4 * g + r; const float x = knobs[(unsigned)b * K + (kidx < K ? kidx : 0)]; kn[0][r] = kidx < K ? x : 0.f; }
+        { const float x = knobs[(unsigned)b * K + (c < K ? c : 0)]; knT = c < K ? x : 0.f; }
         float vn[8];
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) vn[ks] = 0.f;
-        if (grp + gstride < ngroups) load_v(grp + gstride, vn);
+        const int gnext = grp + gstride < ngroups ? grp + gstride : grp;      // last iteration: harmless reload of this group
+        load_v(gnext, vn);
         ST_T(0);
 
         // ------------------------------------------------------------------ forward recompute (D layout)
@@ -905,10 +914,11 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
                 if (fv && t < T) {
                     float v = dv[it][r];
                     if (t >= T - OT) v += Ts[(t - (T - OT)) * SP + c];
-                    dvout[((size_t)b * T + t) * F + f] = v;
+                    dvout[((unsigned)b * T + t) * F + f] = v;
                 }
             }
         ST_T(15);
+        mask_v(gnext, vn);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) vr[ks] = vn[ks];
     }

@@ -347,6 +347,8 @@ extern "C" int st_ae_bwd(const st_dims* d, const float* mag, const float* phs, c
     const sta::AELds ll = sta::ae_lds_layout(d->T, d->OT, d->K);
     const size_t lds = ((size_t)2 * ll.total + (size_t)AE_BWD_NW * (32 + 16 + 16) * sta::SP) * sizeof(float);
     ST_REQ(lds <= 160 * 1024, "st_ae_bwd: needs %zu B of LDS", lds);
+    ST_REQ((size_t)st_synth_slabs(d) * d->B * d->OT * L.KP < ((size_t)1 << 31) && (size_t)d->B * d->T * L.KP < ((size_t)1 << 31),
+           "st_ae_bwd: batch too large for the kernel's 32-bit element offsets (B=%d)", d->B);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, AE_BWD_REG, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

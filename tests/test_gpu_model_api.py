@@ -110,3 +110,23 @@ def test_train_driver_short_run(tmp_path):
         assert all(torch.isfinite(v).all() for v in sd.values())
     finally:
         os.chdir(cwd)
+
+
+def test_scale8_golden_forward(golden_dir):
+    """BASELINE configs[4] geometry (65536-sample window: T=174, OT=46, y=16256): the reference's forward
+    outputs (golden G8, mag_hat sampled every 4th bin) reproduced by the HIP path through st_model."""
+    from oracle import st_oracle as O
+    from tests.test_oracle_golden import golden_params
+    from signaltrain_amd import nn_proc
+    nn_proc._QUIET = True
+    g = np.load(os.path.join(golden_dir, "g8_scale8.npz"))
+    geo = O.geometry(8, 4)
+    P = golden_params(golden_dir, geo, "g8_scale8.npz", "ae_", seed=9)
+    m = nn_proc.st_model(scale_factor=8, shrink_factor=4, num_knobs=g["knobs"].shape[1])
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in P.items()})
+    m = m.to("cuda:0")
+    y, mag, mag_hat = m.forward(torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["knobs"]).cuda())
+    assert y.shape == (1, 16256) and mag.shape == (1, 174, 513) and mag_hat.shape == (1, 46, 513)
+    for got, ref, name in ((y, g["y_hat"], "y_hat"), (mag_hat[:, :, ::4], g["mag_hat"], "mag_hat")):
+        e = np.abs(got.detach().cpu().numpy() - ref).max()
+        assert e <= 1e-4 * np.abs(ref).max(), (name, e)
