@@ -82,8 +82,12 @@ int st_analysis_fwd(const st_dims* d, const float* x, const float* Wr, const flo
  * reg_partial: per-wave partial sums of |mag_hat * exp(7 f/F)| (st_ae_fwd_partials() floats). */
 int st_ae_fwd(const st_dims* d, const float* mag, const float* phs, const float* knobs,
               const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA,
-              float* reg_partial, void* stream);
+              float* reg_partial, float* ws, void* stream);
 int st_ae_fwd_partials(const st_dims* d);
+/* Floats of workspace st_ae_fwd needs in `ws`: 0 (ws may be NULL) for the fused kernels (T <= 32 and OT <= 16); wide
+ * geometries (e.g. the 65536-sample window: T = 174, OT = 46) run the layers as feature-major GEMMs and keep their
+ * activations there.  st_ae_bwd_ws_floats() covers the backward of either path. */
+size_t st_ae_fwd_ws_floats(const st_dims* d);
 
 /* Hermitian fold of the synthesis bases (cls_fe_dft.py:109-110 expressed on the weights):
  * Sfold[KP,N]: rows [0,F) = Sr[k]+Sr[N-k], rows [KP/2,KP/2+F) = Si[k]-Si[N-k]; other rows 0. */

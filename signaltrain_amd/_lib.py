@@ -40,7 +40,8 @@ SIGNATURES = {
     "st_param_offsets": (C.c_int64, [_D, C.POINTER(C.c_int64)]),
     "st_workspace_bytes": (C.c_size_t, [_D]),
     "st_analysis_fwd": (_i, [_D, _p, _p, _p, _f, _p, _p, _p, _p, _p]),
-    "st_ae_fwd": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "st_ae_fwd": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "st_ae_fwd_ws_floats": (C.c_size_t, [_D]),
     "st_ae_fwd_partials": (_i, [_D]),
     "st_synth_slabs": (_i, [_D]),
     "st_synth_fold": (_i, [_D, _p, _p, _p, _p]),

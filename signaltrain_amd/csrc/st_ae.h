@@ -545,6 +545,8 @@ __device__ __forceinline__ void wgrad_reg(f32x4 (&dW)[OTL][ITL], float (&db)[OTL
         db[ot] += (daT[ot][0] + daT[ot][1]) + (daT[ot][2] + daT[ot][3]);
     }
 }
+// Flush of one wave's persistent accumulators into the workgroup's LDS gradient copy: plain read-modify-write -- the
+// caller serialises the waves (wave 0, barrier, wave 1, ...) so the summation order, hence every bit, is fixed.
 template <int OTL, int ITL>
 __device__ __forceinline__ void dw_flush(float* dW, const int P, const f32x4 (&acc)[OTL][ITL], const int g, const int c)
 {
@@ -553,7 +555,7 @@ __device__ __forceinline__ void dw_flush(float* dW, const int P, const f32x4 (&a
 #pragma unroll
         for (int it = 0; it < ITL; ++it)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(dW + (16 * ot + 4 * g + r) * P + 16 * it + c, acc[ot][it][r]);
+            for (int r = 0; r < 4; ++r) dW[(16 * ot + 4 * g + r) * P + 16 * it + c] += acc[ot][it][r];
 }
 
 template <int OTL>
@@ -563,7 +565,7 @@ __device__ __forceinline__ void db_flush(float* dst, float (&db)[OTL], const int
     for (int ot = 0; ot < OTL; ++ot) {
         float v = db[ot];
         v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-        if (g == 0) atomicAdd(dst + 16 * ot + c, v);
+        if (g == 0) dst[16 * ot + c] += v;
     }
 }
 
@@ -924,12 +926,17 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     }
     // ---------------------------------------------------------------------- workgroup partial gradients
     if constexpr (REG) {
-        dw_flush<4, 2>(Dl[0], CL::P0, rW1, g, c); dw_flush<2, 4>(Dl[1], CL::P1, rW2, g, c); dw_flush<1, 2>(Dl[2], CL::P2, rW3, g, c);
-        dw_flush<1, 1>(Dl[3], CL::P3, rW4, g, c); dw_flush<1, 2>(Dl[4], CL::P4, rW5, g, c); dw_flush<1, 1>(Dl[5], CL::P5, rW6, g, c);
-        dw_flush<2, 1>(Dl[6], CL::P6, rW7, g, c); dw_flush<4, 2>(Dl[7], CL::P7, rW8, g, c); dw_flush<1, 4>(Dl[8], CL::P8, rW9, g, c);
-        db_flush<4>(db1, rb1, g, c); db_flush<2>(db2, rb2, g, c); db_flush<1>(db3, rb3, g, c); db_flush<1>(db4, rb4, g, c);
-        db_flush<1>(db5, rb5, g, c); db_flush<1>(db6, rb6, g, c); db_flush<2>(db7, rb7, g, c); db_flush<4>(db8, rb8, g, c);
-        db_flush<1>(db9, rb9, g, c);
+        for (int wv = 0; wv < NW; ++wv) {          // ordered, non-atomic: run-to-run identical bits
+            if (wave == wv) {
+                dw_flush<4, 2>(Dl[0], CL::P0, rW1, g, c); dw_flush<2, 4>(Dl[1], CL::P1, rW2, g, c); dw_flush<1, 2>(Dl[2], CL::P2, rW3, g, c);
+                dw_flush<1, 1>(Dl[3], CL::P3, rW4, g, c); dw_flush<1, 2>(Dl[4], CL::P4, rW5, g, c); dw_flush<1, 1>(Dl[5], CL::P5, rW6, g, c);
+                dw_flush<2, 1>(Dl[6], CL::P6, rW7, g, c); dw_flush<4, 2>(Dl[7], CL::P7, rW8, g, c); dw_flush<1, 4>(Dl[8], CL::P8, rW9, g, c);
+                db_flush<4>(db1, rb1, g, c); db_flush<2>(db2, rb2, g, c); db_flush<1>(db3, rb3, g, c); db_flush<1>(db4, rb4, g, c);
+                db_flush<1>(db5, rb5, g, c); db_flush<1>(db6, rb6, g, c); db_flush<2>(db7, rb7, g, c); db_flush<4>(db8, rb8, g, c);
+                db_flush<1>(db9, rb9, g, c);
+            }
+            __syncthreads();
+        }
     }
     __syncthreads();
     float* base = ws + ((size_t)blockIdx.x * 2 + ae) * PG;

@@ -1,0 +1,225 @@
+// st_ae_wide.h -- the knob-conditioned autoencoders (nn_proc.py:28-126) for WIDE geometries (T > 32 or OT > 16, e.g. the
+// 65536-sample window of BASELINE configs[4]: T = 174, OT = 46), where the first/last layers no longer fit the fused
+// register/LDS kernels of st_ae.h (64 x 174 weights + 44 persistent dW tiles per wave).
+//
+// Layout decision: activations are kept FEATURE-MAJOR over the whole batch, X[feature][R] with R = B * FP columns
+// (column = b * FP + f, FP = roundup(F, 16) "virtual bins", pad columns hold zeros).  Then every layer of the MLP is a
+// plain 2-D GEMM on the one MFMA GEMM family (st_gemm.h), with the fusions moved into epilogues:
+//     forward   H_l  [OUT][R] = ELU( W_l [OUT][IN] . H_{l-1} [IN][R] + b_l )            (ActStore / OutStore for layer 9)
+//     dgrad     dA_{l-1}[IN][R] = ( W_l^T . dA_l ) * ELU'(H_{l-1})                        (DgradStore / DvStore for layer 1)
+//     wgrad     dW_l [OUT][IN] = dA_l [OUT][R] . H_{l-1}[IN][R]^T   (K = R, split-K slabs, summed in slab order)
+// The knobs (nn_proc.py:92-93, concatenated after the 16-wide code) are K extra ROWS of the layer-5 input, so layer 5
+// and its weight gradient need no special case.  Weight matrices whose row length is not a multiple of the k-tile
+// (W_1: T, W_5: 16 + K) are re-packed zero-padded once per call (pad_rows_kernel).
+#pragma once
+#include "st_common.h"
+#include "st_gemm.h"
+
+namespace stw {
+using stg::NJ;
+using stg::d_row;
+
+// ------------------------------------------------------------------------------------------------ epilogues
+struct ActStore {          // layers 1..8 forward: out[row][col] = ELU(acc + bias[row]) on real bins, 0 on pad columns
+    float* out; const float* bias; int M, R, FP, F;
+    __device__ void operator()(int m0, int n0, const f32x16 (&acc)[NJ]) const {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = m0 + d_row(i, lane);
+            if (row < M) {
+                const float bv = bias[row];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int col = n0 + 32 * j + (lane & 31);
+                    if (col < R) out[(size_t)row * R + col] = (col % FP) < F ? elu_f(acc[j][i] + bv) : 0.f;
+                }
+            }
+        }
+    }
+};
+
+struct OutStore {          // layer 9 forward (nn_proc.py:113-117, :322): e = ELU(a9); 'sf': e * input tail; phase: e + input tail
+    float* e9; float* outp; const float* tail; const float* bias; int M, R, FP, F, mode;      // M = OT; outp [B][OT][F] or null
+    __device__ void operator()(int m0, int n0, const f32x16 (&acc)[NJ]) const {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = m0 + d_row(i, lane);
+            if (row < M) {
+                const float bv = bias[row];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int col = n0 + 32 * j + (lane & 31);
+                    if (col < R) {
+                        const int b = col / FP, f = col - b * FP;
+                        const float e = elu_f(acc[j][i] + bv);
+                        const size_t ix = (size_t)row * R + col;
+                        e9[ix] = f < F ? e : 0.f;
+                        if (outp && f < F) { const float tl = tail[ix]; outp[((size_t)b * M + row) * F + f] = mode ? e + tl : e * tl; }
+                    }
+                }
+            }
+        }
+    }
+};
+
+struct DgradStore {        // dA_{l-1} = (W_l^T dA_l) * ELU'(h_{l-1}), ELU' from the stored output: h > 0 ? 1 : h + 1
+    float* out; const float* H; int M, R;
+    __device__ void operator()(int m0, int n0, const f32x16 (&acc)[NJ]) const {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = m0 + d_row(i, lane);
+            if (row < M) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int col = n0 + 32 * j + (lane & 31);
+                    if (col < R) { const size_t ix = (size_t)row * R + col; out[ix] = acc[j][i] * elu_grad_from_out(H[ix]); }
+                }
+            }
+        }
+    }
+};
+
+struct DvStore {           // gradient w.r.t. the AE input rows, written in the [B][T][F] layout of mag / phs (+ skip / residual tails)
+    float* dv; const float* tail; int T, OT, R, FP, F;
+    __device__ void operator()(int m0, int n0, const f32x16 (&acc)[NJ]) const {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = m0 + d_row(i, lane);
+            if (row < T) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int col = n0 + 32 * j + (lane & 31);
+                    if (col < R) {
+                        const int b = col / FP, f = col - b * FP;
+                        if (f < F) {
+                            float v = acc[j][i];
+                            if (row >= T - OT) v += tail[(size_t)(row - (T - OT)) * R + col];
+                            dv[((size_t)b * T + row) * F + f] = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ small kernels
+__global__ void pad_rows_kernel(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst, int pitch)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * pitch) return;
+    const int r = i / pitch, c = i - r * pitch;
+    dst[i] = c < cols ? src[r * cols + c] : 0.f;
+}
+
+// Inputs in the feature-major layout: V[a][t][b*FP + f] = (mag | phs)[b][t][f]; knob rows 16.. of the layer-5 input.
+// grid (T + K, B)
+__global__ void __launch_bounds__(256)
+wide_in_kernel(const float* __restrict__ mag, const float* __restrict__ phs, const float* __restrict__ knobs,
+               float* __restrict__ Vm, float* __restrict__ Vp, float* __restrict__ H4Km, float* __restrict__ H4Kp,
+               int B, int T, int F, int FP, int K)
+{
+    const int row = blockIdx.x, b = blockIdx.y;
+    const size_t R = (size_t)B * FP;
+    if (row < T) {
+        const float* sm = mag + ((size_t)b * T + row) * F;
+        const float* sp = phs + ((size_t)b * T + row) * F;
+        float* dm = Vm + (size_t)row * R + (size_t)b * FP;
+        float* dp = Vp + (size_t)row * R + (size_t)b * FP;
+        for (int f = threadIdx.x; f < FP; f += 256) { const bool ok = f < F; dm[f] = ok ? sm[f] : 0.f; dp[f] = ok ? sp[f] : 0.f; }
+    } else {
+        const int k = row - T;
+        const float v = knobs[b * K + k];
+        float* dm = H4Km + (size_t)(16 + k) * R + (size_t)b * FP;
+        float* dp = H4Kp + (size_t)(16 + k) * R + (size_t)b * FP;
+        for (int f = threadIdx.x; f < FP; f += 256) { const float x = f < F ? v : 0.f; dm[f] = x; dp[f] = x; }
+    }
+}
+
+// nn_proc.py:325-326 (polar -> rectangular) into the KP-pitched synthesis operand + partial sums of the L1 term
+// (loss_functions.py:33-36).  One partial per workgroup (st_ae_fwd_partials() of them), fixed summation order.
+__global__ void __launch_bounds__(256)
+wide_polar_out_kernel(const float* __restrict__ mag_hat, const float* __restrict__ phs_hat, float* __restrict__ AA,
+                      float* __restrict__ reg_partial, int B, int OT, int F, int FP, int KP, float expfac)
+{
+    __shared__ float red[256];
+    const size_t n = (size_t)B * OT * FP;
+    float reg = 0.f;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
+        const size_t ro = idx / FP; const int f = (int)(idx - ro * FP);
+        float re = 0.f, im = 0.f;
+        if (f < F) {
+            const float mh = mag_hat[ro * F + f], ph = phs_hat[ro * F + f];
+            float sn, cs; sincosf(ph, &sn, &cs);
+            re = mh * cs; im = mh * sn;
+            reg += fabsf(mh * expf(expfac * (float)f));
+        }
+        AA[ro * KP + f] = re; AA[ro * KP + FP + f] = im;
+    }
+    red[threadIdx.x] = reg; __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (reg_partial && threadIdx.x == 0) reg_partial[blockIdx.x] = red[0];
+}
+
+// Gradient entering the two output layers (same algebra as the d-out stage of sta::ae_bwd_kernel): from d(AA) (split-K
+// slabs of the synthesis dgrad, dead frames = 0), the L1 term and an optional upstream d(mag_hat).
+__global__ void __launch_bounds__(256)
+wide_dout_kernel(const float* __restrict__ dAA, int nslab, size_t slab, const float* __restrict__ mag_hat, const float* __restrict__ phs_hat,
+                 const float* __restrict__ E9m, const float* __restrict__ E9p, const float* __restrict__ mag_tail,
+                 const float* __restrict__ g_mag_hat, float reg_coef, float expfac,
+                 float* __restrict__ DA9m, float* __restrict__ DA9p, float* __restrict__ TLm, float* __restrict__ TLp,
+                 int B, int OT, int F, int FP, int KP, int to_lo, int to_hi)
+{
+    const size_t n = (size_t)B * OT * FP, R = (size_t)B * FP;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
+        const size_t ro = idx / FP; const int f = (int)(idx - ro * FP);
+        const int b = (int)(ro / OT), to = (int)(ro - (size_t)b * OT);
+        const size_t ix = (size_t)to * R + (size_t)b * FP + f;
+        float d9m = 0.f, d9p = 0.f, tm = 0.f, tp = 0.f;
+        if (f < F) {
+            float gre = 0.f, gim = 0.f;
+            if (to >= to_lo && to <= to_hi)
+                for (int z = 0; z < nslab; ++z) { gre += dAA[z * slab + ro * KP + f]; gim += dAA[z * slab + ro * KP + FP + f]; }
+            const float mh = mag_hat[ro * F + f], ph = phs_hat[ro * F + f];
+            float sn, cs; sincosf(ph, &sn, &cs);
+            const float wf = expf(expfac * (float)f);
+            const float sg = mh > 0.f ? 1.f : (mh < 0.f ? -1.f : 0.f);
+            const float dmh = gre * cs + gim * sn + reg_coef * sg * wf + (g_mag_hat ? g_mag_hat[ro * F + f] : 0.f);
+            const float em = E9m[ix], ep = E9p[ix];
+            d9m = dmh * mag_tail[ix] * elu_grad_from_out(em);
+            tm = dmh * em;
+            const float dph = mh * (gim * cs - gre * sn);
+            d9p = dph * elu_grad_from_out(ep);
+            tp = dph;
+        }
+        DA9m[ix] = d9m; DA9p[ix] = d9p; TLm[ix] = tm; TLp[ix] = tp;
+    }
+}
+
+// bias gradient: out[row] = sum over the R columns of X[row][.]   (one workgroup per row, fixed order)
+__global__ void __launch_bounds__(256)
+row_sum_kernel(const float* __restrict__ X, size_t R, float* __restrict__ out)
+{
+    __shared__ float red[256];
+    const float* x = X + (size_t)blockIdx.x * R;
+    float s = 0.f;
+    for (size_t c = threadIdx.x; c < R; c += 256) s += x[c];
+    red[threadIdx.x] = s; __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+__global__ void sum_slabs_kernel(const float* __restrict__ ws, int nslab, int n, float* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int z = 0; z < nslab; ++z) s += ws[(size_t)z * n + i];
+    out[i] = s;
+}
+
+}  // namespace stw

@@ -9,6 +9,7 @@
 #include "st_gemm.h"
 #include "st_misc.h"
 #include "st_ae.h"
+#include "st_ae_wide.h"
 
 // ------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -176,11 +177,52 @@ extern "C" size_t st_wgrad_ws_floats(const st_dims* d)
     return (size_t)s * st_kp_of(d->F) * d->N;
 }
 extern "C" int st_synth_slabs(const st_dims* d) { return synth_split(synth_live_rows(d)); }
+// Wide geometries (T > 32 or OT > 16) run the autoencoders as feature-major GEMMs (st_ae_wide.h) and need workspace
+// for the activations [features][B*FP]; the fused kernels of st_ae.h need none in forward.
+static bool ae_is_wide(const st_dims* d) { return d->T > 32 || d->OT > 16; }
+struct WideWS {
+    float *W1p[2], *W5p[2], *V[2], *H[2][8], *E9[2];         // forward: H[a][j] = output of layer j+1 (H[a][3] has 16 + K rows: [h4 ; knobs])
+    float *DA[2][9], *TL[2], *slabs;                          // backward: dA_l, skip/residual tails, split-K slabs of the weight gradients
+    size_t fwd_floats, floats; int Tp, nsplit; size_t R;
+};
+static void wide_carve(const st_dims* d, float* base, WideWS* w)
+{
+    const int FP = st_kp_of(d->F) / 2;
+    const size_t R = (size_t)d->B * FP;
+    const int hrows[8] = {64, 32, 16, 16 + d->K, 16, 16, 32, 64};
+    const int drows[9] = {64, 32, 16, 16, 16, 16, 32, 64, d->OT};
+    w->R = R; w->Tp = st_round_up(d->T, 16);
+    w->nsplit = d->B < 64 ? d->B : 64;
+    size_t off = 0;
+    auto take = [&](size_t n) { float* p = base ? base + off : nullptr; off += (n + 63) / 64 * 64; return p; };
+    for (int a = 0; a < 2; ++a) {
+        w->W1p[a] = take((size_t)64 * w->Tp); w->W5p[a] = take(16 * 32);
+        w->V[a] = take((size_t)d->T * R);
+        for (int j = 0; j < 8; ++j) w->H[a][j] = take((size_t)hrows[j] * R);
+        w->E9[a] = take((size_t)d->OT * R);
+    }
+    w->fwd_floats = off;
+    for (int a = 0; a < 2; ++a) {
+        for (int l = 0; l < 9; ++l) w->DA[a][l] = take((size_t)drows[l] * R);
+        w->TL[a] = take((size_t)d->OT * R);
+    }
+    w->slabs = take((size_t)w->nsplit * 64 * w->Tp);
+    w->floats = off;
+}
+extern "C" size_t st_ae_fwd_ws_floats(const st_dims* d)
+{
+    if (check_dims(d) != ST_OK || !ae_is_wide(d)) return 0;
+    WideWS w; wide_carve(d, nullptr, &w); return w.fwd_floats;
+}
 extern "C" size_t st_ae_bwd_ws_floats(const st_dims* d)
 {
     Layout L; if (make_layout(d, &L) != ST_OK) return 0;
+    if (ae_is_wide(d)) { WideWS w; wide_carve(d, nullptr, &w); return w.floats; }
     return (size_t)ae_bwd_grid(d) * 2 * L.PG;
 }
+static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, const float* phs, const float* knobs,
+                       const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA, float* reg_partial,
+                       WideWS& w, void* stream);
 
 // ------------------------------------------------------------------------------ per-op entry points
 // `padded`: sig is the workspace copy [B][N + L + N] (zero margins, input scale applied) written by pad_scale_kernel.
@@ -216,10 +258,15 @@ static int pad_scale(const float* in, float* out, int B, int Ls, int pad, float 
 
 extern "C" int st_ae_fwd(const st_dims* d, const float* mag, const float* phs, const float* knobs,
                          const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA,
-                         float* reg_partial, void* stream)
+                         float* reg_partial, float* ws, void* stream)
 {
     Layout L; ST_TRY(make_layout(d, &L));
     ST_REQ(mag && phs && knobs && ae_m && ae_p && mag_hat && phs_hat && AA, "st_ae_fwd: null pointer");
+    if (ae_is_wide(d)) {
+        ST_REQ(ws, "st_ae_fwd: this geometry (T=%d, OT=%d) needs st_ae_fwd_ws_floats() floats of workspace", d->T, d->OT);
+        WideWS w; wide_carve(d, ws, &w);
+        return ae_wide_fwd(d, L, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, AA, reg_partial, w, stream);
+    }
     const sta::AELds ll = sta::ae_lds_layout(d->T, d->OT, d->K);
     const size_t lds = (size_t)2 * ll.total * sizeof(float);
     ST_REQ(lds <= 160 * 1024, "st_ae_fwd: geometry needs %zu B of LDS (>160 KiB)", lds);
@@ -335,6 +382,107 @@ extern "C" int st_synthesis_wgrad(const st_dims* d, const float* AA, const float
     return synthesis_wgrad_impl(d, AA, dsyn, false, ws, gSr, gSi, norm_partial, stream);
 }
 
+
+// ------------------------------------------------------------------------------ wide-geometry autoencoders (st_ae_wide.h)
+#define ST_WGEMM(...) stg::launch<2, 16>(__VA_ARGS__, g_dbg)          // BM = 64, k-tile 16 (every K below is a multiple of 16 or checked)
+static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, const float* phs, const float* knobs,
+                       const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA, float* reg_partial,
+                       WideWS& w, void* stream)
+{
+    hipStream_t s = st_stream(stream);
+    const int FP = L.KP / 2, F = d->F, T = d->T, OT = d->OT, R = (int)w.R, Tp = w.Tp;
+    ST_REQ(w.R * (size_t)(T > 64 ? T : 64) < ((size_t)1 << 31), "wide autoencoder path: batch too large (B=%d)", d->B);
+    const stg::RowMap id = stg::all_frames(1);
+    int out[9], in[9]; ae_shapes(d, out, in);
+    for (int a = 0; a < 2; ++a) {
+        const float* ae = a ? ae_p : ae_m;
+        hipLaunchKernelGGL(stw::pad_rows_kernel, dim3((64 * Tp + 255) / 256), dim3(256), 0, s, ae + L.go.w[0], 64, T, w.W1p[a], Tp);
+        hipLaunchKernelGGL(stw::pad_rows_kernel, dim3(2), dim3(256), 0, s, ae + L.go.w[4], 16, 16 + d->K, w.W5p[a], 32);
+    }
+    hipLaunchKernelGGL(stw::wide_in_kernel, dim3(T + d->K, d->B), dim3(256), 0, s, mag, phs, knobs, w.V[0], w.V[1], w.H[0][3], w.H[1][3],
+                       d->B, T, F, FP, d->K);
+    ST_LAUNCHED("ae_wide_in");
+    for (int a = 0; a < 2; ++a) {
+        const float* ae = a ? ae_p : ae_m;
+        for (int l = 0; l < 8; ++l) {
+            const float* Wl = l == 0 ? w.W1p[a] : (l == 4 ? w.W5p[a] : ae + L.go.w[l]);
+            const int kp = l == 0 ? Tp : (l == 4 ? 32 : in[l]);                       // padded reduction length = row pitch of Wl
+            const float* Hin = l == 0 ? w.V[a] : w.H[a][l - 1];
+            stg::PlainNT al{Wl, out[l], kp, kp, id};
+            stg::PlainTN bl{Hin, in[l], R, R, id};
+            stw::ActStore ep{w.H[a][l], ae + L.go.b[l], out[l], R, FP, F};
+            ST_WGEMM(al, bl, ep, out[l], R, kp, 1, s);
+        }
+        stg::PlainNT al{ae + L.go.w[8], OT, 64, 64, id};
+        stg::PlainTN bl{w.H[a][7], 64, R, R, id};
+        stw::OutStore ep{w.E9[a], a ? phs_hat : mag_hat, w.V[a] + (size_t)(T - OT) * R, ae + L.go.b[8], OT, R, FP, F, a};
+        ST_WGEMM(al, bl, ep, OT, R, 64, 1, s);
+    }
+    ST_LAUNCHED("ae_wide_fwd");
+    if (AA) {
+        const float expfac = (float)(7.0 / d->F);
+        hipLaunchKernelGGL(stw::wide_polar_out_kernel, dim3(st_ae_fwd_partials(d)), dim3(256), 0, s, mag_hat, phs_hat, AA, reg_partial,
+                           d->B, OT, F, FP, L.KP, expfac);
+        ST_LAUNCHED("ae_wide_polar_out");
+    }
+    return ST_OK;
+}
+
+static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, const float* phs, const float* knobs,
+                       const float* ae_m, const float* ae_p, const float* mag_hat, const float* phs_hat, const float* dAA,
+                       const float* g_mag_hat, float reg_coef, float* dmag, float* dphs, WideWS& w, float* g_m, float* g_p, void* stream)
+{
+    hipStream_t s = st_stream(stream);
+    const int FP = L.KP / 2, F = d->F, T = d->T, OT = d->OT, R = (int)w.R, Tp = w.Tp;
+    const stg::RowMap id = stg::all_frames(1);
+    int out[9], in[9]; ae_shapes(d, out, in);
+    // forward recompute into the workspace (activations + ELU outputs of layer 9); no user-visible outputs
+    ST_TRY(ae_wide_fwd(d, L, mag, phs, knobs, ae_m, ae_p, nullptr, nullptr, nullptr, nullptr, w, stream));
+    const float expfac = (float)(7.0 / d->F);
+    const stg::RowMap ms = synth_live(d);
+    {
+        const size_t n = (size_t)d->B * OT * FP;
+        int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(stw::wide_dout_kernel, dim3(grid), dim3(256), 0, s, dAA, st_synth_slabs(d), (size_t)d->B * OT * L.KP,
+                           mag_hat, phs_hat, w.E9[0], w.E9[1], w.V[0] + (size_t)(T - OT) * R, g_mag_hat, reg_coef, expfac,
+                           w.DA[0][8], w.DA[1][8], w.TL[0], w.TL[1], d->B, OT, F, FP, L.KP, ms.t_lo, ms.t_lo + ms.Tv - 1);
+        ST_LAUNCHED("ae_wide_dout");
+    }
+    for (int a = 0; a < 2; ++a) {
+        const float* ae = a ? ae_p : ae_m;
+        float* g = a ? g_p : g_m;
+        for (int l = 8; l >= 0; --l) {
+            const float* Hin = l == 0 ? w.V[a] : w.H[a][l - 1];
+            // weight gradient: K = R columns, split-K slabs [nsplit][OUT][IN] summed in slab order; bias gradient = row sums
+            {
+                stg::PlainNT al{w.DA[a][l], out[l], R, R, id};
+                stg::PlainNT bl{Hin, in[l], R, R, id};
+                stg::StoreC ep{w.slabs, out[l], in[l], in[l], (size_t)out[l] * in[l], id};
+                ST_WGEMM(al, bl, ep, out[l], in[l], R, w.nsplit, s);
+                const int n = out[l] * in[l];
+                hipLaunchKernelGGL(stw::sum_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w.slabs, w.nsplit, n, g + L.go.w[l]);
+                hipLaunchKernelGGL(stw::row_sum_kernel, dim3(out[l]), dim3(256), 0, s, w.DA[a][l], (size_t)R, g + L.go.b[l]);
+            }
+            // data gradient through W_l (layer 5: only the 16 code columns; the knobs take no gradient)
+            const float* Wl = l == 0 ? w.W1p[a] : (l == 4 ? w.W5p[a] : ae + L.go.w[l]);
+            const int pitch = l == 0 ? Tp : (l == 4 ? 32 : in[l]);
+            const int m = l == 0 ? T : (l == 4 ? 16 : in[l]);
+            stg::PlainTN al{Wl, out[l], pitch, m, id};
+            stg::PlainTN bl{w.DA[a][l], out[l], R, R, id};
+            if (l > 0) {
+                stw::DgradStore ep{w.DA[a][l - 1], w.H[a][l - 1], m, R};
+                ST_WGEMM(al, bl, ep, m, R, out[l], 1, s);
+            } else {
+                stw::DvStore ep{a ? dphs : dmag, w.TL[a], T, OT, R, FP, F};
+                ST_WGEMM(al, bl, ep, T, R, out[l], 1, s);
+            }
+        }
+    }
+    ST_LAUNCHED("ae_wide_bwd");
+    return ST_OK;
+}
+#undef ST_WGEMM
+
 extern "C" int st_ae_bwd(const st_dims* d, const float* mag, const float* phs, const float* knobs,
                          const float* ae_m, const float* ae_p, const float* mag_hat, const float* phs_hat,
                          const float* dAA, const float* g_mag_hat, float reg_coef, float* dmag, float* dphs, float* ws,
@@ -342,8 +490,10 @@ extern "C" int st_ae_bwd(const st_dims* d, const float* mag, const float* phs, c
 {
     Layout L; ST_TRY(make_layout(d, &L));
     ST_REQ(mag && phs && knobs && ae_m && ae_p && mag_hat && phs_hat && dAA && dmag && dphs && ws && g_m && g_p, "st_ae_bwd: null pointer");
-    if (d->T > 32 || d->OT > 16)
-        return st_fail(ST_ERR_UNSUPPORTED, "st_ae_bwd: T=%d OT=%d not instantiated yet (T<=32, OT<=16)", d->T, d->OT);
+    if (ae_is_wide(d)) {
+        WideWS w; wide_carve(d, ws, &w);
+        return ae_wide_bwd(d, L, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, dmag, dphs, w, g_m, g_p, stream);
+    }
     const sta::AELds ll = sta::ae_lds_layout(d->T, d->OT, d->K);
     const size_t lds = ((size_t)2 * ll.total + (size_t)AE_BWD_NW * (32 + 16 + 16) * sta::SP) * sizeof(float);
     ST_REQ(lds <= 160 * 1024, "st_ae_bwd: needs %zu B of LDS", lds);
@@ -480,7 +630,7 @@ static int forward_impl(const st_dims* d, const Layout& L, const float* params, 
     // saved-for-backward state always lives in the workspace; user-visible outputs are copies
     ST_TRY(pad_scale(x, w.xp, d->B, d->L, d->N, 0.5f, stream));                 // x/2 (nn_proc.py:307) + Conv1d padding, once
     ST_TRY(analysis_fwd_impl(d, w.xp, true, Wr, Wi, 1.0f, save ? w.re : nullptr, save ? w.im : nullptr, w.mag, w.phs, stream));
-    ST_TRY(st_ae_fwd(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.AA, w.reg_p, stream));
+    ST_TRY(st_ae_fwd(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.AA, w.reg_p, w.aews, stream));
     ST_TRY(st_synth_fold(d, Sr, Si, w.Sfold, stream));
     ST_TRY(st_synthesis_frames(d, w.AA, w.Sfold, w.frs, stream));
     ST_TRY(ola_loss_impl(d, w.frs, x, y_true, y_hat ? y_hat : w.y_hat, (save && y_true) ? w.dsyn : nullptr, d->N,

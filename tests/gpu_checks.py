@@ -89,10 +89,10 @@ def phase_err(name, got, ref, mag, tol=TOL):
 
 
 # --------------------------------------------------------------------------------------------- stages
-def run_all(B=3, seed=0, K=4, verbose=False):
+def run_all(B=3, seed=0, K=4, verbose=False, scale=1):
     """Run every per-op entry point on oracle-provided inputs; returns list of result dicts."""
     lib = _lib.load()
-    geo, X, Y, KN, P = make_case(B, seed, K=K)
+    geo, X, Y, KN, P = make_case(B, seed, K=K, scale=scale)
     d = dims_of(geo, B, K)
     KP = lib.st_kp(d.F); F, T, OT, N = d.F, d.T, d.OT, d.N
     res = []
@@ -118,14 +118,17 @@ def run_all(B=3, seed=0, K=4, verbose=False):
     res += [err("analysis.re", n(re), c["re"], scale=sc), err("analysis.im", n(im), c["im"], scale=sc),
             err("analysis.mag", n(mag), c["mag"]), phase_err("analysis.phs", n(phs), c["phs"], c["mag"])]
     # frame indexing is bit-exact: zero-padded frames give exact zeros
-    res.append(err("analysis.zero_frames", n(re)[:, [0, T - 1]], np.zeros((B, 2, F)), scale=1.0, tol=0.0))
+    dead = [tt for tt in range(T) if d.H * tt - d.N + d.N <= 0 or d.H * tt - d.N >= d.L]      # frames wholly inside the Conv1d padding
+    assert 0 in dead
+    res.append(err("analysis.zero_frames", n(re)[:, dead], np.zeros((B, len(dead), F)), scale=1.0, tol=0.0))
 
     # 2. autoencoders forward (oracle inputs)
     mag_o, phs_o = t(c["mag"]), t(c["phs"])
     mag_hat, phs_hat, AA = z(B, OT, F), z(B, OT, F), z(B * OT, KP)
     regp = z(lib.st_ae_fwd_partials(C.byref(d)))
+    aefws = z(max(1, lib.st_ae_fwd_ws_floats(C.byref(d))))       # 0 floats needed unless the geometry is wide (T > 32 or OT > 16)
     _lib.check(lib.st_ae_fwd(C.byref(d), _lib.ptr(mag_o), _lib.ptr(phs_o), _lib.ptr(kn), _lib.ptr(ae_m), _lib.ptr(ae_p),
-                             _lib.ptr(mag_hat), _lib.ptr(phs_hat), _lib.ptr(AA), _lib.ptr(regp), stream()), "ae_fwd")
+                             _lib.ptr(mag_hat), _lib.ptr(phs_hat), _lib.ptr(AA), _lib.ptr(regp), _lib.ptr(aefws), stream()), "ae_fwd")
     aa_re, aa_im = from_kp(n(AA), F)
     sa = float(max(np.abs(c["Are"]).max(), np.abs(c["Aim"]).max()))
     w = O.freq_weights(F, np.float64)
@@ -220,9 +223,9 @@ def run_all(B=3, seed=0, K=4, verbose=False):
     return res
 
 
-def run_fused(B=3, seed=1, K=4, steps=3):
+def run_fused(B=3, seed=1, K=4, steps=3, scale=1):
     """Fused entry points: st_model_fwd, st_loss_backward, st_train_step x steps vs the oracle."""
-    geo, X, Y, KN, P = make_case(B, seed, K=K)
+    geo, X, Y, KN, P = make_case(B, seed, K=K, scale=scale)
     d = dims_of(geo, B, K)
     eng = StepEngine(d, DEV)
     eng.load_state_dict(P)

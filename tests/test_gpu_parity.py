@@ -9,13 +9,50 @@ def _assert_ok(res):
     assert not bad, "\n".join(f"{r['name']}: err={r['err']:.3e} scale={r['scale']:.3e} tol={r['tol']}" for r in bad)
 
 
-@pytest.mark.parametrize("B,seed,K", [(3, 0, 4), (5, 2, 3), (1, 9, 4)])
+@pytest.mark.parametrize("B,seed,K", [(3, 0, 4), (5, 2, 3), (1, 9, 4), (2, 4, 4), (6, 6, 1), (7, 7, 4)])
 def test_per_op_parity(B, seed, K):
     from tests import gpu_checks as G
     _assert_ok(G.run_all(B=B, seed=seed, K=K))
+
+
+@pytest.mark.parametrize("B,seed,K", [(1, 3, 4), (2, 4, 3)])
+def test_per_op_parity_scale8(B, seed, K):
+    """BASELINE configs[4] geometry (65536-sample window, T=174, OT=46): the autoencoders take the wide
+    feature-major GEMM path (st_ae_wide.h); everything else is the same kernels at larger sizes."""
+    from tests import gpu_checks as G
+    _assert_ok(G.run_all(B=B, seed=seed, K=K, scale=8))
 
 
 @pytest.mark.parametrize("B,seed,K,steps", [(3, 1, 4, 3), (7, 4, 2, 2)])
 def test_fused_step_parity(B, seed, K, steps):
     from tests import gpu_checks as G
     _assert_ok(G.run_fused(B=B, seed=seed, K=K, steps=steps))
+
+
+def test_fused_step_parity_scale8():
+    from tests import gpu_checks as G
+    _assert_ok(G.run_fused(B=2, seed=5, K=4, steps=2, scale=8))
+
+
+def test_ae_bwd_repeatable():
+    """Run-to-run determinism of the dominant kernel (and a regression check for the timing-dependent MFMA
+    result hazard found in round 1): three back-to-back launches with other work in between give identical bits."""
+    import ctypes as C
+    import numpy as np, torch
+    from tests import gpu_checks as G
+    from signaltrain_amd import _lib
+    from signaltrain_amd.engine import StepEngine
+    B, K = 5, 4
+    geo, X, Y, KN, P = G.make_case(B, 11, K=K)
+    d = G.dims_of(geo, B, K)
+    eng = StepEngine(d, G.DEV); eng.load_state_dict(P)
+    x, kn, y = G.t(X), G.t(KN), G.t(Y)
+    outs = []
+    for rep in range(3):
+        eng.loss_backward(x, kn, y)
+        torch.cuda.synchronize()
+        outs.append(eng.grads.clone())
+        junk = torch.randn(2048, 2048, device=G.DEV); (junk @ junk).sum().item()
+    names = [k for k, v in eng.layout.views(outs[0]).items()
+             if not (torch.equal(v, eng.layout.views(outs[1])[k]) and torch.equal(v, eng.layout.views(outs[2])[k]))]
+    assert not names, names

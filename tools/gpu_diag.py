@@ -87,7 +87,7 @@ MAC = 2.0
 print(f"---- per-kernel timings at B={B}")
 timeit("analysis_fwd(+polar)", lambda: lib.st_analysis_fwd(D, p(x), p(V[STFT_KEYS[0]]), p(V[STFT_KEYS[1]]), 0.5, p(re), p(im), p(mag), p(phs), S()),
        flops=MAC * B * T * 2 * F * N)
-timeit("ae_fwd", lambda: lib.st_ae_fwd(D, p(mag), p(phs), p(kn), p(ae_m), p(ae_p), p(mag_hat), p(phs_hat), p(AA), p(regp), S()),
+timeit("ae_fwd", lambda: lib.st_ae_fwd(D, p(mag), p(phs), p(kn), p(ae_m), p(ae_p), p(mag_hat), p(phs_hat), p(AA), p(regp), None, S()),
        flops=MAC * B * F * 2 * 8128)
 timeit("synth_fold", lambda: lib.st_synth_fold(D, p(V[STFT_KEYS[2]]), p(V[STFT_KEYS[3]]), p(Sfold), S()))
 timeit("synthesis_frames", lambda: lib.st_synthesis_frames(D, p(AA), p(Sfold), p(frs), S()), flops=MAC * B * OT * 2 * F * N)
