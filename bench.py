@@ -34,7 +34,8 @@ def algorithmic_flops(d):
     sy = 2.0 * B * OT * (2 * F) * N              # Hermitian-folded: 9.46 M MAC/window at the default geometry
     ae = 2.0 * B * F * 2 * ae_mac
     return {"analysis_fwd": an, "analysis_wgrad": an, "synthesis_frames": sy, "synthesis_dgrad": sy,
-            "synthesis_wgrad": sy, "ae_fwd": ae, "ae_bwd": 2 * ae}, (2 * an + 3 * sy + 3 * ae)
+            "synthesis_wgrad": sy, "ae_fwd": ae, "ae_bwd": 2 * ae,
+            "ae_wide_fwd": ae, "ae_wide_bwd": 2 * ae}, (2 * an + 3 * sy + 3 * ae)      # wide geometries: st_ae_wide.h
 
 
 def main():
@@ -46,6 +47,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--bk", type=int, default=0, help="GEMM k-tile depth override (16/32)")
+    ap.add_argument("--scale", type=int, default=1, help="window scale factor (8 = the 65536-sample window of BASELINE configs[4], "
+                                                          "fp32 here; informational -- the headline workload is scale 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -69,10 +72,10 @@ def main():
     B = args.batch
     if args.bk:
         _lib.check(_lib.load().st_set_tuning(args.bk), 'st_set_tuning')
-    d = _lib.geometry(1, 4, 4, B)
+    d = _lib.geometry(args.scale, 4, 4, B)
     # identical init on every rank (run_train.py:20-21 seeds 218), distinct data per rank
     torch.manual_seed(218); np.random.seed(218)
-    model = nn_proc.st_model(scale_factor=1, shrink_factor=4, num_knobs=4)
+    model = nn_proc.st_model(scale_factor=args.scale, shrink_factor=4, num_knobs=4)
     eng = StepEngine(d, dev)
     eng.load_state_dict(model.state_dict())
     dp = DataParallel(eng)
@@ -114,7 +117,8 @@ def main():
         out = {"metric": METRIC, "value": windows_s * d.T, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "comp_4c synthetic, 8192-sample windows, batch 256/GPU, fp32 (BASELINE configs[1])",
+               "config": {"workload": (f"comp_4c synthetic, 8192-sample windows, batch {B}/GPU, fp32 (BASELINE configs[1])" if args.scale == 1 else
+                                       f"comp_4c synthetic, {d.L}-sample windows, batch {B}/GPU, fp32 (geometry of BASELINE configs[4])"),
                           "window": d.L, "frames_per_window": d.T, "global_batch": B * world, "parallelism": f"dp{world}"},
                "windows_per_s": windows_s, "samples_per_s": windows_s * d.L, "loss": loss,
                "step_tflops": flops_step / (ms * 1e-3) / 1e12 * world,
@@ -146,7 +150,7 @@ def main():
             out["kernels"] = kern
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only, bounded)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.scale == 1:
         from oracle.torch_cpu_step import CpuPort          # checker-side code: timed beside, never the product path
         # a B=32 step is a handful of small ops: past a few dozen threads torch's CPU backend only adds
         # synchronisation cost (256 threads measured 75 s/step here), so probe a few counts and time the best one

@@ -200,26 +200,39 @@ wide_dout_kernel(const float* __restrict__ dAA, int nslab, size_t slab, const fl
     }
 }
 
-// bias gradient: out[row] = sum over the R columns of X[row][.]   (one workgroup per row, fixed order)
+// The bias gradient rides in the weight-gradient GEMM: every layer input buffer carries one extra row of ones (on real
+// bins), so column IN of the [OUT][IN + 1] product is the row sum of dA.  grid (18, B): the 9 input buffers of both nets.
+struct OnesRows { float* p[18]; };
 __global__ void __launch_bounds__(256)
-row_sum_kernel(const float* __restrict__ X, size_t R, float* __restrict__ out)
+wide_ones_kernel(const OnesRows rows, int FP, int F)
 {
-    __shared__ float red[256];
-    const float* x = X + (size_t)blockIdx.x * R;
-    float s = 0.f;
-    for (size_t c = threadIdx.x; c < R; c += 256) s += x[c];
-    red[threadIdx.x] = s; __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) { if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
-    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+    float* d = rows.p[blockIdx.x] + (size_t)blockIdx.y * FP;
+    for (int f = threadIdx.x; f < FP; f += 256) d[f] = f < F ? 1.f : 0.f;
 }
 
-__global__ void sum_slabs_kernel(const float* __restrict__ ws, int nslab, int n, float* __restrict__ out)
+// Sum of the split-K slabs of all nine weight-gradient GEMMs of one autoencoder (fixed slab order) scattered into the
+// packed gradient block: slab layout per layer [OUT][IN + 1] at so[l]; column IN is the bias gradient.
+struct GradTab { int so[10]; int out[9]; int in[9]; int gw[9]; int gb[9]; };
+__global__ void __launch_bounds__(256)
+wide_grad_finish_kernel(const float* __restrict__ slabs, int nslab, size_t SL, const GradTab tab, float* __restrict__ g)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int z = 0; z < nslab; ++z) s += ws[(size_t)z * n + i];
-    out[i] = s;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= tab.so[9]) return;
+    int l = 0;
+#pragma unroll
+    for (int q = 1; q < 9; ++q) l += idx >= tab.so[q];
+    const int e = idx - tab.so[l], n1 = tab.in[l] + 1;
+    if (e >= tab.out[l] * n1) return;                      // alignment pad between layers
+    const int o = e / n1, i = e - o * n1;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // 4 independent chains: slabs are L2-resident, latency-bound otherwise
+    int z = 0;
+    for (; z + 4 <= nslab; z += 4) {
+        s0 += slabs[(size_t)z * SL + idx]; s1 += slabs[(size_t)(z + 1) * SL + idx];
+        s2 += slabs[(size_t)(z + 2) * SL + idx]; s3 += slabs[(size_t)(z + 3) * SL + idx];
+    }
+    for (; z < nslab; ++z) s0 += slabs[(size_t)z * SL + idx];
+    const float s = (s0 + s1) + (s2 + s3);
+    if (i < tab.in[l]) g[tab.gw[l] + o * tab.in[l] + i] = s; else g[tab.gb[l] + o] = s;
 }
 
 }  // namespace stw

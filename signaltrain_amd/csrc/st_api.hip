@@ -183,7 +183,8 @@ static bool ae_is_wide(const st_dims* d) { return d->T > 32 || d->OT > 16; }
 struct WideWS {
     float *W1p[2], *W5p[2], *V[2], *H[2][8], *E9[2];         // forward: H[a][j] = output of layer j+1 (H[a][3] has 16 + K rows: [h4 ; knobs])
     float *DA[2][9], *TL[2], *slabs;                          // backward: dA_l, skip/residual tails, split-K slabs of the weight gradients
-    size_t fwd_floats, floats; int Tp, nsplit; size_t R;
+    // every layer-input buffer (V, H[.][j]) has ONE extra row (index = that layer's IN) of ones: bias gradient via the wgrad GEMM
+    size_t fwd_floats, floats; int Tp, nsplit; size_t R, SL; int so[10];
 };
 static void wide_carve(const st_dims* d, float* base, WideWS* w)
 {
@@ -191,14 +192,18 @@ static void wide_carve(const st_dims* d, float* base, WideWS* w)
     const size_t R = (size_t)d->B * FP;
     const int hrows[8] = {64, 32, 16, 16 + d->K, 16, 16, 32, 64};
     const int drows[9] = {64, 32, 16, 16, 16, 16, 32, 64, d->OT};
+    int out[9], in[9]; ae_shapes(d, out, in);
     w->R = R; w->Tp = st_round_up(d->T, 16);
-    w->nsplit = d->B < 64 ? d->B : 64;
+    { long ns = (long)(R / 128); w->nsplit = (int)(ns < 1 ? 1 : (ns > 256 ? 256 : ns)); }   // wgrad K = R: short k-chains on many workgroups
+    w->so[0] = 0;
+    for (int l = 0; l < 9; ++l) w->so[l + 1] = w->so[l] + st_round_up(out[l] * (in[l] + 1), 64);
+    w->SL = (size_t)w->so[9];
     size_t off = 0;
     auto take = [&](size_t n) { float* p = base ? base + off : nullptr; off += (n + 63) / 64 * 64; return p; };
     for (int a = 0; a < 2; ++a) {
         w->W1p[a] = take((size_t)64 * w->Tp); w->W5p[a] = take(16 * 32);
-        w->V[a] = take((size_t)d->T * R);
-        for (int j = 0; j < 8; ++j) w->H[a][j] = take((size_t)hrows[j] * R);
+        w->V[a] = take((size_t)(d->T + 1) * R);
+        for (int j = 0; j < 8; ++j) w->H[a][j] = take((size_t)(hrows[j] + 1) * R);
         w->E9[a] = take((size_t)d->OT * R);
     }
     w->fwd_floats = off;
@@ -206,7 +211,7 @@ static void wide_carve(const st_dims* d, float* base, WideWS* w)
         for (int l = 0; l < 9; ++l) w->DA[a][l] = take((size_t)drows[l] * R);
         w->TL[a] = take((size_t)d->OT * R);
     }
-    w->slabs = take((size_t)w->nsplit * 64 * w->Tp);
+    w->slabs = take((size_t)w->nsplit * w->SL);
     w->floats = off;
 }
 extern "C" size_t st_ae_fwd_ws_floats(const st_dims* d)
@@ -430,14 +435,24 @@ static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, cons
 
 static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, const float* phs, const float* knobs,
                        const float* ae_m, const float* ae_p, const float* mag_hat, const float* phs_hat, const float* dAA,
-                       const float* g_mag_hat, float reg_coef, float* dmag, float* dphs, WideWS& w, float* g_m, float* g_p, void* stream)
+                       const float* g_mag_hat, float reg_coef, float* dmag, float* dphs, WideWS& w, float* g_m, float* g_p,
+                       bool have_fwd, void* stream)
 {
     hipStream_t s = st_stream(stream);
     const int FP = L.KP / 2, F = d->F, T = d->T, OT = d->OT, R = (int)w.R, Tp = w.Tp;
     const stg::RowMap id = stg::all_frames(1);
     int out[9], in[9]; ae_shapes(d, out, in);
-    // forward recompute into the workspace (activations + ELU outputs of layer 9); no user-visible outputs
-    ST_TRY(ae_wide_fwd(d, L, mag, phs, knobs, ae_m, ae_p, nullptr, nullptr, nullptr, nullptr, w, stream));
+    // forward state (activations + ELU outputs of layer 9): recomputed into the workspace unless the fused step's own
+    // forward just left it there (same workspace, same layout); no user-visible outputs
+    if (!have_fwd) ST_TRY(ae_wide_fwd(d, L, mag, phs, knobs, ae_m, ae_p, nullptr, nullptr, nullptr, nullptr, w, stream));
+    {
+        stw::OnesRows rows;
+        for (int a = 0; a < 2; ++a) {
+            rows.p[9 * a] = w.V[a] + (size_t)in[0] * R;
+            for (int j = 0; j < 8; ++j) rows.p[9 * a + 1 + j] = w.H[a][j] + (size_t)in[j + 1] * R;
+        }
+        hipLaunchKernelGGL(stw::wide_ones_kernel, dim3(18, d->B), dim3(256), 0, s, rows, FP, F);
+    }
     const float expfac = (float)(7.0 / d->F);
     const stg::RowMap ms = synth_live(d);
     {
@@ -453,15 +468,12 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
         float* g = a ? g_p : g_m;
         for (int l = 8; l >= 0; --l) {
             const float* Hin = l == 0 ? w.V[a] : w.H[a][l - 1];
-            // weight gradient: K = R columns, split-K slabs [nsplit][OUT][IN] summed in slab order; bias gradient = row sums
+            // weight (+ bias: the ones row) gradient: K = R columns, split-K slabs [nsplit][OUT][IN + 1], summed after the loop
             {
                 stg::PlainNT al{w.DA[a][l], out[l], R, R, id};
-                stg::PlainNT bl{Hin, in[l], R, R, id};
-                stg::StoreC ep{w.slabs, out[l], in[l], in[l], (size_t)out[l] * in[l], id};
-                ST_WGEMM(al, bl, ep, out[l], in[l], R, w.nsplit, s);
-                const int n = out[l] * in[l];
-                hipLaunchKernelGGL(stw::sum_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w.slabs, w.nsplit, n, g + L.go.w[l]);
-                hipLaunchKernelGGL(stw::row_sum_kernel, dim3(out[l]), dim3(256), 0, s, w.DA[a][l], (size_t)R, g + L.go.b[l]);
+                stg::PlainNT bl{Hin, in[l] + 1, R, R, id};
+                stg::StoreC ep{w.slabs + w.so[l], out[l], in[l] + 1, in[l] + 1, w.SL, id};
+                ST_WGEMM(al, bl, ep, out[l], in[l] + 1, R, w.nsplit, s);
             }
             // data gradient through W_l (layer 5: only the 16 code columns; the knobs take no gradient)
             const float* Wl = l == 0 ? w.W1p[a] : (l == 4 ? w.W5p[a] : ae + L.go.w[l]);
@@ -477,22 +489,27 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
                 ST_WGEMM(al, bl, ep, T, R, out[l], 1, s);
             }
         }
+        stw::GradTab tab;
+        for (int l = 0; l < 9; ++l) { tab.so[l] = w.so[l]; tab.out[l] = out[l]; tab.in[l] = in[l]; tab.gw[l] = L.go.w[l]; tab.gb[l] = L.go.b[l]; }
+        tab.so[9] = w.so[9];
+        // NB: slabs of net a are consumed before net a+1 overwrites them (same stream)
+        hipLaunchKernelGGL(stw::wide_grad_finish_kernel, dim3((w.so[9] + 255) / 256), dim3(256), 0, s, w.slabs, w.nsplit, w.SL, tab, g);
     }
     ST_LAUNCHED("ae_wide_bwd");
     return ST_OK;
 }
 #undef ST_WGEMM
 
-extern "C" int st_ae_bwd(const st_dims* d, const float* mag, const float* phs, const float* knobs,
-                         const float* ae_m, const float* ae_p, const float* mag_hat, const float* phs_hat,
-                         const float* dAA, const float* g_mag_hat, float reg_coef, float* dmag, float* dphs, float* ws,
-                         float* g_m, float* g_p, void* stream)
+static int ae_bwd_impl(const st_dims* d, const float* mag, const float* phs, const float* knobs,
+                       const float* ae_m, const float* ae_p, const float* mag_hat, const float* phs_hat,
+                       const float* dAA, const float* g_mag_hat, float reg_coef, float* dmag, float* dphs, float* ws,
+                       float* g_m, float* g_p, bool have_fwd, void* stream)
 {
     Layout L; ST_TRY(make_layout(d, &L));
     ST_REQ(mag && phs && knobs && ae_m && ae_p && mag_hat && phs_hat && dAA && dmag && dphs && ws && g_m && g_p, "st_ae_bwd: null pointer");
     if (ae_is_wide(d)) {
         WideWS w; wide_carve(d, ws, &w);
-        return ae_wide_bwd(d, L, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, dmag, dphs, w, g_m, g_p, stream);
+        return ae_wide_bwd(d, L, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, dmag, dphs, w, g_m, g_p, have_fwd, stream);
     }
     const sta::AELds ll = sta::ae_lds_layout(d->T, d->OT, d->K);
     const size_t lds = ((size_t)2 * ll.total + (size_t)AE_BWD_NW * (32 + 16 + 16) * sta::SP) * sizeof(float);
@@ -518,6 +535,13 @@ extern "C" int st_ae_bwd(const st_dims* d, const float* mag, const float* phs, c
     hipLaunchKernelGGL(stm::ae_grad_reduce_kernel, dim3((L.PG + 63) / 64, 2), dim3(256), 0, st_stream(stream),
                        ws, grid, L.PG, g_m, g_p);
     ST_LAUNCHED("ae_grad_reduce"); return ST_OK;
+}
+extern "C" int st_ae_bwd(const st_dims* d, const float* mag, const float* phs, const float* knobs,
+                         const float* ae_m, const float* ae_p, const float* mag_hat, const float* phs_hat,
+                         const float* dAA, const float* g_mag_hat, float reg_coef, float* dmag, float* dphs, float* ws,
+                         float* g_m, float* g_p, void* stream)
+{
+    return ae_bwd_impl(d, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, dmag, dphs, ws, g_m, g_p, false, stream);
 }
 
 extern "C" int st_polar_bwd(const st_dims* d, const float* re, const float* im, const float* dmag, const float* dphs,
@@ -650,8 +674,8 @@ static int backward_p1(const st_dims* d, const Layout& L, const float* params, f
     const float* ae_m = params + L.offs[4]; const float* ae_p = params + L.offs[22];
     ST_TRY(synthesis_dgrad_impl(d, w.dsyn, true, w.Sfold, w.dAA, stream));
     ST_TRY(synthesis_wgrad_impl(d, w.AA, w.dsyn, true, w.wg, grads + L.offs[2], grads + L.offs[3], w.norm_s, stream));
-    ST_TRY(st_ae_bwd(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.dAA, g_mag_hat, reg_coef, w.dmag, w.dphs,
-                     w.aews, grads + L.offs[4], grads + L.offs[22], stream));
+    ST_TRY(ae_bwd_impl(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.dAA, g_mag_hat, reg_coef, w.dmag, w.dphs,
+                       w.aews, grads + L.offs[4], grads + L.offs[22], true, stream));      // the forward left its AE state in w.aews
     ST_TRY(st_polar_bwd(d, w.re, w.im, w.dmag, w.dphs, g_mag, w.dG, stream));
     return ST_OK;
 }
