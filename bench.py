@@ -39,6 +39,11 @@ def algorithmic_flops(d):
 
 
 def main():
+    # Native libraries write to stdout behind our back (RCCL prints a version banner at exit); the contract is ONE JSON
+    # line on stdout, so fd 1 is pointed at stderr for the whole run and the result goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -47,6 +52,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--bk", type=int, default=0, help="GEMM k-tile depth override (16/32)")
+    ap.add_argument("--force-dp", action="store_true", help="run the N > 1 code path (bucketed RCCL all-reduce, st_dp_clip_adam) "
+                                                            "even with one rank, to measure its overhead on one GPU")
     ap.add_argument("--scale", type=int, default=1, help="window scale factor (8 = the 65536-sample window of BASELINE configs[4], "
                                                           "fp32 here; informational -- the headline workload is scale 1)")
     args = ap.parse_args()
@@ -60,8 +67,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1 or args.force_dp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from signaltrain_amd import _lib, nn_proc, audio, datasets, learningrate
@@ -78,7 +85,7 @@ def main():
     model = nn_proc.st_model(scale_factor=args.scale, shrink_factor=4, num_knobs=4)
     eng = StepEngine(d, dev)
     eng.load_state_dict(model.state_dict())
-    dp = DataParallel(eng)
+    dp = DataParallel(eng, force_collectives=args.force_dp)
     dp.broadcast_parameters()
     np.random.seed(218 + 1000 * (rank + 1))
     ds = datasets.SynthAudioDataSet(d.L, audio.Compressor_4c(), y_size=d.y, augment=True)
@@ -175,8 +182,8 @@ def main():
                                          f"PyTorch-CPU restatement of the reference op sequence, {torch.get_num_threads()} threads",
                                "ms_per_step": tc * 1e3, "windows_per_s": Bc / tc}
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if world > 1 or args.force_dp:
         dist.destroy_process_group()
 
 

@@ -130,3 +130,34 @@ def test_scale8_golden_forward(golden_dir):
     for got, ref, name in ((y, g["y_hat"], "y_hat"), (mag_hat[:, :, ::4], g["mag_hat"], "mag_hat")):
         e = np.abs(got.detach().cpu().numpy() - ref).max()
         assert e <= 1e-4 * np.abs(ref).max(), (name, e)
+
+
+def test_dp_collective_path_single_rank():
+    """The N > 1 step (phase-1 backward -> bucketed RCCL all-reduce overlapping the analysis weight gradient ->
+    st_dp_clip_adam) executed on ONE GPU with a single-rank RCCL group must reproduce the fused single-GPU step."""
+    import socket
+    import torch.distributed as dist
+    from tests import gpu_checks as G
+    from signaltrain_amd.engine import StepEngine
+    from signaltrain_amd.dp import DataParallel
+    B, K = 4, 4
+    geo, X, Y, KN, P = G.make_case(B, 21, K=K)
+    d = G.dims_of(geo, B, K)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        e1 = StepEngine(d, G.DEV); e1.load_state_dict(P)
+        e2 = StepEngine(d, G.DEV); e2.load_state_dict(P)
+        dp = DataParallel(e2, force_collectives=True)
+        dp.broadcast_parameters()
+        x, kn, y = G.t(X), G.t(KN), G.t(Y)
+        for it in range(3):
+            e1.train_step(x, kn, y, 1e-3)
+            dp.train_step(x, kn, y, 1e-3)
+            torch.cuda.synchronize()
+            l1, l2 = float(e1.scalars[0]), dp.mean_loss()
+            assert abs(l1 - l2) <= 1e-5 * abs(l1), (it, l1, l2)
+            err = (e1.params - e2.params).abs().max().item()
+            assert err <= 2e-5, (it, err)          # same tolerance as the fused-vs-oracle parameter check (Adam amplifies ulp noise)
+    finally:
+        dist.destroy_process_group()

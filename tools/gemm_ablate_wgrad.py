@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Timing-only ablation of the analysis weight-gradient GEMM (TN x FramedTN, split-K) -- results invalid under the switches."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import torch
+from signaltrain_amd import _lib
+lib = _lib.load()
+B = 256
+d = _lib.geometry(1, 4, 4, B)
+dev = "cuda:0"
+KP = lib.st_kp(d.F)
+x = torch.randn(B, d.L, device=dev); dG = torch.randn(B * d.T, KP, device=dev)
+ws = torch.empty(lib.st_wgrad_ws_floats(C.byref(d)), device=dev)
+gWr = torch.empty(d.N, d.N, device=dev); gWi = torch.empty_like(gWr); na = torch.empty(lib.st_norm_partials(C.byref(d)), device=dev)
+S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def run():
+    lib.st_analysis_wgrad(C.byref(d), _lib.ptr(dG), _lib.ptr(x), 0.5, _lib.ptr(ws), _lib.ptr(gWr), _lib.ptr(gWi), _lib.ptr(na), S())
+def t(n=20):
+    for _ in range(3): run()
+    torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): run()
+    e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / n * 1e3
+for bk in (16, 32):
+    lib.st_set_tuning(bk)
+    for dbg, name in ((0, "full"), (1, "no loads/stores in loop"), (2, "no barriers"), (3, "no loads, no barriers (MFMA + LDS reads)"), (4, "no MFMA (data movement only)"), (7, "empty loop")):
+        lib.st_set_debug(dbg)
+        print(f"bk={bk} dbg={dbg} {name:44s} {t():8.1f} us (incl. ~11us slab reduce)")
+lib.st_set_debug(0); lib.st_set_tuning(16)
