@@ -151,8 +151,24 @@ def main():
                         **({"tflops": flops_k[k] / (v[0] * 1e-3) / 1e12} if k in flops_k else {})} for k, v in rows.items()}
             dom = max((k for k in rows if k in flops_k), key=lambda k: rows[k][0])
             ach = flops_k[dom] / (rows[dom][0] * 1e-3) / 1e12
+            # HBM-side bytes per launch of that kernel: PMC counters cannot be collected from inside this process, so
+            # the value is quoted from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+            # command (tools/profile_gpu.sh -> profiles/*_pmc_traffic.json); null when there is no such file.
+            traffic, tsrc = None, None
+            try:
+                import glob
+                cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+                if cand and args.scale == 1 and B == 256:
+                    tj = json.load(open(cand[-1]))
+                    key = {"ae_bwd": "ae_bwd_kernel", "ae_fwd": "ae_fwd_kernel"}.get(dom)
+                    hit = [v for k, v in tj.items() if key and key in k]
+                    if hit and "FETCH_SIZE_KB" in hit[0] and "WRITE_SIZE_KB" in hit[0]:
+                        traffic = (hit[0]["FETCH_SIZE_KB"] + hit[0]["WRITE_SIZE_KB"]) * 1024.0
+                        tsrc = os.path.basename(cand[-1]) + " (FETCH_SIZE + WRITE_SIZE, KB per dispatch, uncorrected: dword accesses)"
+            except Exception:
+                traffic, tsrc = None, None
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_FP32_MFMA_TF, "traffic": None,
+                               "frac": ach / PEAK_FP32_MFMA_TF, "traffic": traffic, "traffic_source": tsrc,
                                "algorithmic_flops_per_launch": flops_k[dom], "avg_launch_us": rows[dom][0] * 1e3}
             out["kernels"] = kern
 

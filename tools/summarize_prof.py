@@ -28,3 +28,18 @@ for sub in ("pmc1", "pmc2", "pmc3", "pmc4", "pmc5"):
             k = short(r["Kernel_Name"]); acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
         for k in acc:
             print("  " + k[:44].ljust(44) + "  " + "  ".join(f"{c}={v / max(cnt[(k, c)], 1):.4g}" for c, v in sorted(acc[k].items())))
+
+# per-launch memory-side traffic of every kernel (FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch):
+# profiles/<tag>_pmc_traffic.json is what bench.py's roofline.traffic quotes.
+import json
+traffic = collections.defaultdict(dict)
+for sub, cname in (("pmc3", "FETCH_SIZE"), ("pmc4", "WRITE_SIZE")):
+    for f in sorted(glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True)):
+        acc = collections.defaultdict(float); cnt = collections.Counter()
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == cname:
+                k = r["Kernel_Name"].split("(")[0]; acc[k] += float(r["Counter_Value"]); cnt[k] += 1
+        for k in acc:
+            traffic[k][cname + "_KB"] = acc[k] / cnt[k]
+if traffic:
+    json.dump(traffic, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
