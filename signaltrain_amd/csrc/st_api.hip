@@ -155,8 +155,20 @@ namespace sta { extern __device__ unsigned long long g_ae_stage_cycles[32]; }
 // Diagnostics: read (and clear) the per-stage s_memtime accumulators of ae_bwd_kernel (st_set_debug(256)).
 extern "C" int st_debug_read_stage_cycles(unsigned long long* out32);
 static int g_bk = 16;   // k-tile depth of the GEMM family (16: 36 KB LDS/WG -> 4 WGs/CU; 32: 64 KB -> 2 WGs/CU)
-extern "C" int st_set_tuning(int bk) { if (bk != 16 && bk != 32) return st_fail(ST_ERR_ARG, "bk must be 16 or 32"); g_bk = bk; return ST_OK; }
+static int g_wg_mode_set(int v);
+static int g_wsplit_max = 16, g_wsplit_div = 200;
+extern "C" int st_set_tuning(int bk)
+{
+    if (bk >= 1000) { g_wsplit_div = bk - 1000; return ST_OK; }  // 1000 + n: rows per weight-gradient k-slice (diagnostics)
+    if (bk >= 200) { g_wsplit_max = bk - 200; return ST_OK; }      // 200 + n: cap of the weight-gradient split-K (diagnostics)
+    if (bk >= 100) return g_wg_mode_set(bk - 100);           // 100 / 101: weight-gradient tile mode (diagnostics)
+    if (bk != 16 && bk != 32) return st_fail(ST_ERR_ARG, "bk must be 16 or 32"); g_bk = bk; return ST_OK;
+}
 #define ST_GEMM(W_, ...) do { if (g_bk == 16) stg::launch<W_, 16>(__VA_ARGS__, g_dbg); else stg::launch<W_, 32>(__VA_ARGS__, g_dbg); } while (0)
+// weight-gradient GEMMs: g_wg_mode 0 = three waves share a 96x96 tile (32x96 strips), 1 = one wave per 96x96 tile
+static int g_wg_mode = 0;
+static int g_wg_mode_set(int v) { g_wg_mode = v ? 1 : 0; return ST_OK; }
+#define ST_GEMM_WG(...) do { if (g_wg_mode == 1) stg::launch<1, 16, 3>(__VA_ARGS__, g_dbg); else ST_GEMM(3, __VA_ARGS__); } while (0)
 static const int AE_FWD_NW = 8, AE_BWD_NW = 4;
 static const bool AE_BWD_REG = true;     // persistent register accumulators, 1 wave/SIMD (LDS float atomics per group measured 3x slower)
 static int synth_live_rows(const st_dims* d);
@@ -165,7 +177,7 @@ static int ae_bwd_grid(const st_dims* d) { int groups = d->B * (st_kp_of(d->F) /
 // split-K factors.  fp32 MFMA tiles are long serial chains (48 MFMAs x 64 cycles per k-tile per wave), so a GEMM
 // needs >= ~2 waves per SIMD (2048 waves) to overlap its load/LDS phases; the small-M synthesis GEMMs and the
 // 121-tile weight-gradient GEMMs get there by splitting K and summing the slabs in the consumer kernel.
-static int wgrad_split(int R) { int s = R / 200; if (s < 1) s = 1; if (s > 8) s = 8; return s; }
+static int wgrad_split(int R) { int s = R / g_wsplit_div; if (s < 1) s = 1; if (s > g_wsplit_max) s = g_wsplit_max; return s; }
 static int synth_split(int R) { return R >= 4096 ? 1 : 3; }   // consumers (ola_loss_kernel, ae_bwd_kernel) sum at most 3 slabs
 
 extern "C" int st_ae_fwd_partials(const st_dims* d) { return ae_fwd_grid(d) * AE_FWD_NW; }
@@ -372,8 +384,8 @@ static int synthesis_wgrad_impl(const st_dims* d, const float* AA, const float* 
     const int ns = wgrad_split(R);
     stg::PlainTN al{AA, R, KP, KP, ms};
     stg::StoreC ep{ws, KP, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
-    if (padded) { stg::FramedTN<true> bl{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms}; ST_GEMM(3, al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
-    else { stg::FramedTN<false> bl{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms}; ST_GEMM(3, al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
+    if (padded) { stg::FramedTN<true> bl{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms}; ST_GEMM_WG(al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
+    else { stg::FramedTN<false> bl{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms}; ST_GEMM_WG(al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
     ST_LAUNCHED("synthesis_wgrad");
     hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(2 * d->F), dim3(256), 0, st_stream(stream),
                        ws, ns, gSr, gSi, norm_partial, d->N, d->F, KP, 1);
@@ -563,8 +575,8 @@ static int analysis_wgrad_impl(const st_dims* d, const float* dG, const float* s
     const int ns = wgrad_split(R);
     stg::PlainTN al{dG, R, KP, KP, ma};
     stg::StoreC ep{ws, KP, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
-    if (padded) { stg::FramedTN<true> bl{sig, d->L, d->H, d->N, R, d->N, 1.0f, ma}; ST_GEMM(3, al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
-    else { stg::FramedTN<false> bl{sig, d->L, d->H, d->N, R, d->N, in_scale, ma}; ST_GEMM(3, al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
+    if (padded) { stg::FramedTN<true> bl{sig, d->L, d->H, d->N, R, d->N, 1.0f, ma}; ST_GEMM_WG(al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
+    else { stg::FramedTN<false> bl{sig, d->L, d->H, d->N, R, d->N, in_scale, ma}; ST_GEMM_WG(al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
     ST_LAUNCHED("analysis_wgrad");
     hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(2 * d->F), dim3(256), 0, st_stream(stream),
                        ws, ns, gWr, gWi, norm_partial, d->N, d->F, KP, 0);

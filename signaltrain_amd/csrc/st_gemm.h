@@ -231,11 +231,14 @@ struct PolarStore {
 // ------------------------------------------------------------------------------ kernel
 // BKT = k-tile depth (32: 64 KB LDS/WG, 2 WGs/CU; 16: 36 KB, 4 WGs/CU -- better for the small-M split-K GEMMs).
 // dbg: timing-only ablation switches (bit0 skip loads/stores in the k-loop, bit1 skip barriers, bit2 skip MFMAs).
-template <int WAVES_M, int BKT, class AL, class BL, class EPI>
+// MI = 32-row blocks per wave: MI = 1 is the 32 x 96 wave strip; WAVES_M = 1, MI = 3 lets ONE wave own a 96 x 96 tile
+// (9 accumulators): same global traffic per MFMA as three waves sharing the tile, half the LDS fragment reads (B is read
+// once instead of three times) and no cross-wave barrier stalls -- for the split-K weight-gradient GEMMs.
+template <int WAVES_M, int BKT, int MI, class AL, class BL, class EPI>
 __global__ void __launch_bounds__(WAVES_M * 64)
 gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int ksplit, const int dbg)
 {
-    constexpr int BM = 32 * WAVES_M, NT = 64 * WAVES_M;
+    constexpr int BM = 32 * WAVES_M * MI, NT = 64 * WAVES_M;
     constexpr int PKT = BKT + 4;                         // NT row pitch: 36 (BK 32) / 20 (BK 16) floats, both conflict-free for b128
     constexpr int LDA = AL::kTN ? BM + 4 : PKT;         // TN: k-major [BK][BM+4] ; NT: row-major [BM][PKT]
     constexpr int LDB = BL::kTN ? BN + 4 : PKT;
@@ -304,11 +307,13 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
             if (B_N % NT == 0 || b_v[p]) *reinterpret_cast<float4*>(bs + b_l[p]) = (!BL::kCheck || ob[p]) ? bl.post(rb[p]) : zero;
     };
 
-    f32x16 acc[NJ];
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mi][j][i] = 0.f;
 
     if (k_begin < k_end) {
         gload(k_begin);
@@ -317,7 +322,8 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
         int cur = 0;
         const int h = lane >> 5, l31 = lane & 31;
         // NT: lane reads HK consecutive floats of its row; TN: lane reads column l31 of rows HK*h .. HK*h+HK-1
-        const int a_off = AL::kTN ? (HK * h) * LDA + wave * 32 + l31 : (wave * 32 + l31) * LDA + HK * h;
+        const int a_off = AL::kTN ? (HK * h) * LDA + wave * (32 * MI) + l31 : (wave * (32 * MI) + l31) * LDA + HK * h;
+        constexpr int A_MI = AL::kTN ? 32 : 32 * LDA;          // LDS offset between the wave's 32-row blocks
         const int b_off = BL::kTN ? (HK * h) * LDB + l31 : l31 * LDB + HK * h;
         for (int kt = k_begin; kt < k_end; kt += BKT) {
             const bool more = kt + BKT < k_end;
@@ -325,13 +331,15 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
             const float* as = As + cur * A_SZ + a_off;
             const float* bs = Bs + cur * B_SZ + b_off;
             if (!(dbg & 4)) {
-                float af[HK], bf[NJ][HK];
+                float af[MI][HK], bf[NJ][HK];
                 if constexpr (!AL::kTN) {
 #pragma unroll
-                    for (int q = 0; q < HK / 4; ++q) {
-                        const float4 v = *reinterpret_cast<const float4*>(as + 4 * q);
-                        af[4 * q] = v.x; af[4 * q + 1] = v.y; af[4 * q + 2] = v.z; af[4 * q + 3] = v.w;
-                    }
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int q = 0; q < HK / 4; ++q) {
+                            const float4 v = *reinterpret_cast<const float4*>(as + mi * A_MI + 4 * q);
+                            af[mi][4 * q] = v.x; af[mi][4 * q + 1] = v.y; af[mi][4 * q + 2] = v.z; af[mi][4 * q + 3] = v.w;
+                        }
                 }
                 if constexpr (!BL::kTN) {
 #pragma unroll
@@ -344,14 +352,16 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
                 }
 #pragma unroll
                 for (int kk = 0; kk < HK; ++kk) {
-                    float a;
-                    if constexpr (AL::kTN) a = as[kk * LDA]; else a = af[kk];
+                    float a[MI], b[NJ];
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        float b;
-                        if constexpr (BL::kTN) b = bs[kk * LDB + 32 * j]; else b = bf[j][kk];
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
-                    }
+                    for (int mi = 0; mi < MI; ++mi) { if constexpr (AL::kTN) a[mi] = as[kk * LDA + mi * A_MI]; else a[mi] = af[mi][kk]; }
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) { if constexpr (BL::kTN) b[j] = bs[kk * LDB + 32 * j]; else b[j] = bf[j][kk]; }
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[j], acc[mi][j], 0, 0, 0);
                 }
             }
             if (more && !(dbg & 1)) lstore(cur ^ 1);
@@ -359,19 +369,20 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
             cur ^= 1;
         }
     }
-    epi(m_blk + wave * 32, n_blk, acc);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) epi(m_blk + (wave * MI + mi) * 32, n_blk, acc[mi]);
 }
 
-template <int WAVES_M, int BKT, class AL, class BL, class EPI>
+template <int WAVES_M, int BKT, int MI = 1, class AL, class BL, class EPI>
 static inline void launch(const AL& al, const BL& bl, const EPI& epi, int M, int Nc, int K, int nsplit,
                           hipStream_t s, int dbg = 0)
 {
-    constexpr int BM = 32 * WAVES_M;
+    constexpr int BM = 32 * WAVES_M * MI;
     int ksplit = K;
     if (nsplit > 1) ksplit = st_round_up((K + nsplit - 1) / nsplit, BK);
     // exactly nsplit z-slices: a slice that starts past K stores zeros, so consumers sum a fixed slab count
     dim3 grid((Nc + BN - 1) / BN, (M + BM - 1) / BM, nsplit > 1 ? nsplit : 1);
-    hipLaunchKernelGGL((gemm_kernel<WAVES_M, BKT, AL, BL, EPI>), grid, dim3(WAVES_M * 64), 0, s, al, bl, epi, K, ksplit, dbg);
+    hipLaunchKernelGGL((gemm_kernel<WAVES_M, BKT, MI, AL, BL, EPI>), grid, dim3(WAVES_M * 64), 0, s, al, bl, epi, K, ksplit, dbg);
 }
 
 }  // namespace stg

@@ -21,9 +21,9 @@ def t(n=20):
     e0.record()
     for _ in range(n): run()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / n * 1e3
-for bk in (16, 32):
-    lib.st_set_tuning(bk)
+for mode in (101, 100):
+    lib.st_set_tuning(mode); bk = mode
     for dbg, name in ((0, "full"), (1, "no loads/stores in loop"), (2, "no barriers"), (3, "no loads, no barriers (MFMA + LDS reads)"), (4, "no MFMA (data movement only)"), (7, "empty loop")):
         lib.st_set_debug(dbg)
         print(f"bk={bk} dbg={dbg} {name:44s} {t():8.1f} us (incl. ~11us slab reduce)")
-lib.st_set_debug(0); lib.st_set_tuning(16)
+lib.st_set_debug(0); lib.st_set_tuning(101)
