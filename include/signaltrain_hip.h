@@ -181,6 +181,13 @@ int st_dp_clip_adam(const st_dims* d, float* params, float* grads, float* m, flo
                     float* scalars, float grad_scale, float lr, float beta1, float beta2, float eps,
                     int step, void* stream);
 
+/* ---- device-side data feed -------------------------------------------------------------------
+ * audio.compressor_4controls (signaltrain/audio.py:380-426), the effect of the synthetic comp_4c task
+ * (SynthAudioDataSet, datasets.py:312-334), for a batch of device-resident windows:
+ *   x [B][L] fp32, knobs_wc [B][4] = (threshold dB, ratio, attack s, release s) in WORLD coordinates
+ *   (Effect.knobs_wc, audio.py:455), y [B][ysz] = the last ysz samples of the processed window (datasets.py:327-330). */
+int st_compressor_4c(const float* x, const float* knobs_wc, float sr, int B, int L, int ysz, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

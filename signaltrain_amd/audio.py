@@ -177,6 +177,24 @@ class Compressor_4c(Effect):
         return compressor_4controls(x, thresh=knobs_w[0], ratio=knobs_w[1], attackTime=knobs_w[2],
                                     releaseTime=knobs_w[3], sr=self.sr), x
 
+    def go_device(self, x, knobs_nn, y_size=None):
+        """Batched effect on the GPU (st_compressor_4c): x [B,L] and knobs_nn [B,4] in [-.5,.5] as device tensors ->
+        y [B,y_size] (the last y_size samples, datasets.py:327-330).  No CPU fallback."""
+        import ctypes as C
+        import torch
+        from . import _lib
+        if x.device.type != "cuda":
+            raise RuntimeError("Compressor_4c.go_device needs ROCm device tensors")
+        x = x.to(torch.float32).contiguous(); B, L = x.shape
+        y_size = L if y_size is None else int(y_size)
+        lo = torch.as_tensor(self.knob_ranges[:, 0], dtype=torch.float32, device=x.device)
+        hi = torch.as_tensor(self.knob_ranges[:, 1], dtype=torch.float32, device=x.device)
+        kw = (lo + (knobs_nn.to(torch.float32) + 0.5) * (hi - lo)).contiguous()          # Effect.knobs_wc, audio.py:455
+        y = torch.empty(B, y_size, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().st_compressor_4c(_lib.ptr(x), _lib.ptr(kw), float(self.sr), B, L, y_size, _lib.ptr(y),
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "st_compressor_4c")
+        return y
+
 
 class Compressor_4c_Large(Compressor_4c):
     """audio.py:503-510."""

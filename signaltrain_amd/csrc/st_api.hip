@@ -786,3 +786,12 @@ extern "C" int st_dp_clip_adam(const st_dims* d, float* params, float* grads, fl
     ST_LAUNCHED("finalize(dp)");
     return st_clip_adam(params, grads, m, v, L.total, L.n_stft, scalars, grad_scale, lr, beta1, beta2, eps, step, stream);
 }
+
+// ------------------------------------------------------------------------------ device-side data feed
+extern "C" int st_compressor_4c(const float* x, const float* knobs_wc, float sr, int B, int L, int ysz, float* y, void* stream)
+{
+    ST_REQ(x && knobs_wc && y, "st_compressor_4c: null pointer");
+    ST_REQ(B > 0 && L > 0 && ysz > 0 && ysz <= L && sr > 0.f, "st_compressor_4c: bad sizes (B=%d L=%d ysz=%d)", B, L, ysz);
+    hipLaunchKernelGGL(stm::compressor_4c_kernel, dim3(B), dim3(256), 0, st_stream(stream), x, knobs_wc, sr, L, ysz, y);
+    ST_LAUNCHED("compressor_4c"); return ST_OK;
+}

@@ -281,4 +281,71 @@ clip_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict
     }
 }
 
+
+// ------------------------------------------------------------------------------ device-side data feed
+// audio.compressor_4controls (audio.py:380-426) for a batch of windows: static gain curve (parallel), switched one-pole
+// attack/release smoother of the gain in dB (inherently sequential per window: the coefficient depends on the previous
+// OUTPUT), dB -> linear and apply (parallel).  One workgroup per window; the recurrence runs in one lane over an LDS
+// copy of the gain curve, in chunks of CH samples so any window length fits.  State is rounded to float32 every step
+// exactly like the reference's float32 lin_A array; the step arithmetic is float64 (numpy float64 scalars alphaA/R).
+// y receives the LAST ysz samples of each processed window (the training target, datasets.py:327-330).
+constexpr int COMP_CH = 8192;
+__global__ void __launch_bounds__(256)
+compressor_4c_kernel(const float* __restrict__ x, const float* __restrict__ knobs_wc, float sr, int L, int ysz, float* __restrict__ y)
+{
+    __shared__ __attribute__((aligned(16))) float g[COMP_CH];
+    __shared__ float carry;
+    const int b = blockIdx.x;
+    const float* xb = x + (size_t)b * L;
+    float* yb = y + (size_t)b * ysz;
+    const double thresh = knobs_wc[4 * b + 0], ratio = knobs_wc[4 * b + 1];
+    const double alphaA = exp(-log(9.0) / ((double)sr * (double)knobs_wc[4 * b + 2]));
+    const double alphaR = exp(-log(9.0) / ((double)sr * (double)knobs_wc[4 * b + 3]));
+    if (threadIdx.x == 0) carry = 0.f;
+    for (int c0 = 0; c0 < L; c0 += COMP_CH) {
+        const int n = L - c0 < COMP_CH ? L - c0 : COMP_CH;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            float xdb = (float)(20.0 * log10((double)fabsf(xb[c0 + i]) + 1e-8));
+            if (xdb < -96.0f) xdb = -96.0f;
+            float gc = 0.0f;
+            if ((double)xdb > thresh) gc = (float)(thresh + ((double)xdb - thresh) / ratio - (double)xdb);
+            g[i] = gc;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float prev = carry;
+            if (c0 == 0) g[0] = 0.f;                      // lin_A[0] = 0: the loop of the reference starts at n = 1
+            // one step: lin_A[n] = float32( (1-a) g + a prev ), a = attack coefficient while the gain is falling.
+            // Evaluated as g + a (prev - g) in float64 (differs from the reference's expression by < 1e-16 relative
+            // before the float32 rounding); the compare runs on the float32 values beside the convert.
+            auto step = [&](float gi_f) {
+                const double a = gi_f < prev ? alphaA : alphaR;
+                const double gi = gi_f;
+                prev = (float)__builtin_fma(a, (double)prev - gi, gi);
+                return prev;
+            };
+            // 8 samples per trip through registers: the LDS round trip leaves the dependent chain (the chain is the
+            // float32->float64 convert, compare, select, multiply-add, round of each step)
+            int i = 0;
+            if (c0 == 0) {                                // first block: sample 0 stays 0 and does not update the state
+                for (i = 1; i < 8 && i < n; ++i) g[i] = step(g[i]);
+            }
+            for (; i + 8 <= n; i += 8) {
+                float4 u = *reinterpret_cast<const float4*>(g + i), v = *reinterpret_cast<const float4*>(g + i + 4);
+                u.x = step(u.x); u.y = step(u.y); u.z = step(u.z); u.w = step(u.w);
+                v.x = step(v.x); v.y = step(v.y); v.z = step(v.z); v.w = step(v.w);
+                *reinterpret_cast<float4*>(g + i) = u; *reinterpret_cast<float4*>(g + i + 4) = v;
+            }
+            for (; i < n; ++i) g[i] = step(g[i]);
+            carry = prev;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int j = c0 + i - (L - ysz);
+            if (j >= 0) yb[j] = (float)pow(10.0, (double)g[i] / 20.0) * xb[c0 + i];
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace stm

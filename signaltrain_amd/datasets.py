@@ -56,3 +56,17 @@ class SynthAudioDataSet(Dataset):
         """B stacked items as float32 arrays (used by bench.py / tests for device-resident synthetic data)."""
         xs, ys, ks = zip(*(self.gen_single_chunk() for _ in range(B)))
         return (np.stack(xs).astype(np.float32), np.stack(ys).astype(np.float32), np.stack(ks).astype(np.float32))
+
+    def batch_device(self, B, device="cuda:0"):
+        """Device-resident minibatch with the effect computed ON the GPU: the input signals and
+        knob settings come from the same numpy generators as batch(); the sequential compressor -- the expensive
+        part of the CPU feed -- runs as one HIP launch for the whole batch.  Returns (x, y, knobs) torch tensors."""
+        import torch
+        xs = np.stack([audio.synth_input_sample(self.t, np.random.choice([0, 1, 2, 4, 6, 7])) for _ in range(B)]).astype(np.float32)
+        ks = np.stack([audio.random_ends(len(self.effect.knob_ranges)) - 0.5 for _ in range(B)]).astype(np.float32)
+        x = torch.from_numpy(xs).to(device); kn = torch.from_numpy(ks).to(device)
+        y = self.effect.go_device(x, kn, self.y_size)
+        if self.augment:                                   # do_augment: random polarity flip of the pair (datasets.py:27-29)
+            sgn = torch.where(torch.rand(B, 1, device=x.device) < 0.5, -1.0, 1.0)
+            x, y = x * sgn, y * sgn
+        return x, y, kn

@@ -161,3 +161,34 @@ def test_dp_collective_path_single_rank():
             assert err <= 2e-5, (it, err)          # same tolerance as the fused-vs-oracle parameter check (Adam amplifies ulp noise)
     finally:
         dist.destroy_process_group()
+
+
+def test_device_compressor_matches_reference_golden(golden_dir):
+    """st_compressor_4c (HIP) against the reference's own compressor_4controls output (golden G9),
+    against the oracle on a batch of windows with different knob settings, and through SynthAudioDataSet.batch_device."""
+    from oracle import st_oracle as O
+    from signaltrain_amd import audio, datasets
+    g = np.load(os.path.join(golden_dir, "g9_compressor.npz"))
+    fx = audio.Compressor_4c(sr=float(g["knobs"][4]))
+    x = torch.from_numpy(g["x"].astype(np.float32))[None].cuda()
+    rng_ = fx.knob_ranges
+    kn = torch.tensor([[(g["knobs"][i] - rng_[i, 0]) / (rng_[i, 1] - rng_[i, 0]) - 0.5 for i in range(4)]], dtype=torch.float32).cuda()
+    y = fx.go_device(x, kn).cpu().numpy()[0]
+    assert np.abs(y - g["y"]).max() <= 2e-6 * max(1.0, np.abs(g["y"]).max())
+    # batch: several windows / knob settings / lengths incl. a ragged chunk boundary (L > 8192, not a multiple of the chunk)
+    rng = np.random.default_rng(5)
+    for L, ysz in ((8192, 2048), (20000, 20000), (65536, 16256)):
+        B = 5
+        X = (rng.standard_normal((B, L)) * np.linspace(0.02, 0.9, B)[:, None]).astype(np.float32)
+        X[1, 100:900] = 0.0                                # silence: the -96 dB floor path
+        KN = (rng.beta(0.8, 0.8, size=(B, 4)) - 0.5).astype(np.float32)
+        fx = audio.Compressor_4c()
+        yd = fx.go_device(torch.from_numpy(X).cuda(), torch.from_numpy(KN).cuda(), ysz).cpu().numpy()
+        for b in range(B):
+            kv = O.COMP4C_RANGES[:, 0] + (KN[b].astype(np.float64) + 0.5) * (O.COMP4C_RANGES[:, 1] - O.COMP4C_RANGES[:, 0])
+            ref = audio.compressor_4controls(X[b], *kv, sr=44100.0)[-ysz:]          # gcc-built host helper (same float32 state rounding)
+            assert np.abs(yd[b] - ref).max() <= 1e-5 * max(1e-3, np.abs(ref).max()), (L, b)
+    ds = datasets.SynthAudioDataSet(8192, audio.Compressor_4c(), y_size=2048)
+    xb, yb, kb = ds.batch_device(6)
+    assert xb.shape == (6, 8192) and yb.shape == (6, 2048) and kb.shape == (6, 4) and torch.isfinite(yb).all()
+    assert float(yb.abs().max()) <= float(xb.abs().max()) + 1e-6             # a downward compressor never amplifies
