@@ -96,8 +96,10 @@ class AsymAutoEncoder(nn.Module):
         mh = torch.empty(B, self._OT, F, device=x.device); ph = torch.empty_like(mh)
         AA = torch.empty(B * self._OT, KP, device=x.device)
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        nws = int(lib.st_ae_fwd_ws_floats(C.byref(d)))                 # 0 unless the geometry is wide (T > 32 or OT > 16)
+        ws = torch.empty(nws, device=x.device) if nws else None
         _lib.check(lib.st_ae_fwd(C.byref(d), _lib.ptr(x), _lib.ptr(x), _lib.ptr(kn), _lib.ptr(packed), _lib.ptr(packed),
-                                 _lib.ptr(mh), _lib.ptr(ph), _lib.ptr(AA), None, st), "st_ae_fwd")
+                                 _lib.ptr(mh), _lib.ptr(ph), _lib.ptr(AA), None, _lib.ptr(ws), st), "st_ae_fwd")
         out = mh if skip_connections == 'sf' else ph - x[:, T - self._OT:, :]
         return out, (self.acts_reference(x_input, knobs, skip_connections) if return_acts else [])
 

@@ -192,3 +192,35 @@ def test_device_compressor_matches_reference_golden(golden_dir):
     xb, yb, kb = ds.batch_device(6)
     assert xb.shape == (6, 8192) and yb.shape == (6, 2048) and kb.shape == (6, 4) and torch.isfinite(yb).all()
     assert float(yb.abs().max()) <= float(xb.abs().max()) + 1e-6             # a downward compressor never amplifies
+
+
+def test_predict_long_matches_windowed_oracle(golden_dir):
+    """long-file inference (utils/predict_long.py) -- device-side framing + HIP forward against the
+    oracle run window by window on the host (audio.sliding_window), including the zero-padded last window."""
+    from oracle import st_oracle as O
+    from signaltrain_amd import audio
+    from signaltrain_amd.predict import predict_long
+    m, g, P, geo = _golden_model(golden_dir)
+    rng = np.random.default_rng(3)
+    n = 8192 + 2048 * 6 + 777                                   # not a whole number of hops: exercises the tail padding
+    sig = (0.4 * np.sin(np.arange(n) * 0.013) + 0.05 * rng.standard_normal(n)).astype(np.float32)
+    kn = np.array([0.1, -0.3, 0.25, -0.45], np.float32)
+    y = predict_long(sig, kn, m, geo["L"], geo["y"], batch_size=3)
+    # like the reference, the prediction starts after the first window's lookback: n - (chunk - out_chunk) samples
+    assert y.shape == (n - (geo["L"] - geo["y"]),) and y.dtype == np.float32
+    xw = audio.sliding_window(sig, geo["L"], overlap=geo["L"] - geo["y"])
+    ref = O.model_fwd(np.ascontiguousarray(xw), np.tile(kn, (xw.shape[0], 1)), P, geo)[0].reshape(-1)[:y.size]
+    assert np.abs(y - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+def test_standalone_autoencoder_module(golden_dir):
+    """AsymAutoEncoder.forward used on its own (nn_proc.py:77-126, modes 'sf' and '') against the oracle."""
+    from oracle import st_oracle as O
+    m, g, P, geo = _golden_model(golden_dir)
+    rng = np.random.default_rng(8)
+    v = np.abs(rng.standard_normal((2, geo["T"], geo["F"]))).astype(np.float32)
+    kn = (rng.random((2, 4)) - 0.5).astype(np.float32)
+    for mod, prefix, mode in ((m.mpaec.aenc, "mpaec.aenc", "sf"), (m.mpaec.phs_aenc, "mpaec.phs_aenc", "")):
+        out, _ = mod.forward(torch.from_numpy(v).cuda(), torch.from_numpy(kn).cuda(), skip_connections=mode)
+        ref = O.ae_fwd(v, kn, P, prefix, mode)[0]
+        assert np.abs(out.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max(), mode
