@@ -188,6 +188,23 @@ int st_dp_clip_adam(const st_dims* d, float* params, float* grads, float* m, flo
  *   (Effect.knobs_wc, audio.py:455), y [B][ysz] = the last ysz samples of the processed window (datasets.py:327-330). */
 int st_compressor_4c(const float* x, const float* knobs_wc, float sr, int B, int L, int ysz, float* y, void* stream);
 
+/* ---- generic learned-basis front end: SURVEY.md row a15, signaltrain/cls_fe_dct_bases.py ------------------------------
+ * Analysis.forward (:129-136)  = Conv1d(1 -> C, kernel KW, stride hop, padding pad, bias) transposed to [B][T][C];
+ * Synthesis.forward (:174-179) = ConvTranspose1d(C -> 1, kernel KW, stride hop) with `crop` samples cut from both ends.
+ * W is the [C][1][KW] Conv weight seen as [C][KW].  T = st_fe_frames(L, KW, hop, pad).  The *_bwd entries are the
+ * autograd of the forward ones (weight, bias and input gradients).  ws: st_fe_ws_floats() floats (for synthesis pass
+ * L = the output length + 2*crop - 2*pad equivalent, i.e. call it with the analysis geometry of the same model). */
+int st_fe_frames(int L, int KW, int hop, int pad);
+size_t st_fe_ws_floats(int B, int L, int C, int KW, int hop, int pad);
+int st_fe_analysis_fwd(const float* x, int B, int L, const float* W, const float* bias, int C, int KW, int hop, int pad,
+                       float* out, void* stream);
+int st_fe_synthesis_fwd(const float* xft, int B, int T, const float* W, int C, int KW, int hop, int crop,
+                        float* ws, float* out, void* stream);
+int st_fe_analysis_bwd(const float* x, int B, int L, const float* W, int C, int KW, int hop, int pad, const float* g_out,
+                       float* ws, float* gW, float* gbias, float* gx, void* stream);
+int st_fe_synthesis_bwd(const float* xft, int B, int T, const float* W, int C, int KW, int hop, int crop, const float* g_wave,
+                        float* ws, float* gW, float* g_xft, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

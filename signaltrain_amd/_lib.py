@@ -43,6 +43,12 @@ SIGNATURES = {
     "st_ae_fwd": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "st_ae_fwd_ws_floats": (C.c_size_t, [_D]),
     "st_compressor_4c": (_i, [_p, _p, C.c_float, C.c_int, C.c_int, C.c_int, _p, _p]),
+    "st_fe_frames": (_i, [C.c_int] * 4),
+    "st_fe_ws_floats": (C.c_size_t, [C.c_int] * 6),
+    "st_fe_analysis_fwd": (_i, [_p, C.c_int, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
+    "st_fe_synthesis_fwd": (_i, [_p, C.c_int, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
+    "st_fe_analysis_bwd": (_i, [_p, C.c_int, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p, _p]),
+    "st_fe_synthesis_bwd": (_i, [_p, C.c_int, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p]),
     "st_ae_fwd_partials": (_i, [_D]),
     "st_synth_slabs": (_i, [_D]),
     "st_synth_fold": (_i, [_D, _p, _p, _p, _p]),

@@ -795,3 +795,103 @@ extern "C" int st_compressor_4c(const float* x, const float* knobs_wc, float sr,
     hipLaunchKernelGGL(stm::compressor_4c_kernel, dim3(B), dim3(256), 0, st_stream(stream), x, knobs_wc, sr, L, ysz, y);
     ST_LAUNCHED("compressor_4c"); return ST_OK;
 }
+
+// ------------------------------------------------------------------------------ generic learned-basis front end (a15)
+// cls_fe_dct_bases.Analysis / Synthesis: Conv1d(1 -> C, k = KW, stride = hop, padding = pad, bias) and
+// ConvTranspose1d(C -> 1, k = KW, stride = hop) + crop, forward and backward, on the same framed GEMM family.
+static int fe_check(int B, int L, int C, int KW, int hop, int pad)
+{
+    ST_REQ(B > 0 && L > 0 && C > 0 && KW > 0 && hop > 0 && pad >= 0, "front end: non-positive dimension");
+    ST_REQ(KW % 16 == 0 && C % 16 == 0 && hop % 4 == 0 && pad % 4 == 0 && L % 4 == 0, "front end: KW%%16, C%%16, hop%%4, pad%%4, L%%4 required");
+    return ST_OK;
+}
+extern "C" int st_fe_frames(int L, int KW, int hop, int pad) { return (L + 2 * pad - KW) / hop + 1; }
+extern "C" size_t st_fe_ws_floats(int B, int L, int C, int KW, int hop, int pad)
+{
+    const int T = st_fe_frames(L, KW, hop, pad);
+    const size_t R = (size_t)B * T;
+    // frames [R][KW] + padded gradient signal [B][L + 2 KW] + split-K slabs of the weight gradient
+    return R * KW + (size_t)B * ((size_t)L + 2 * (size_t)KW + 2 * (size_t)pad) + (size_t)wgrad_split((int)R) * C * KW + 1024;
+}
+extern "C" int st_fe_analysis_fwd(const float* x, int B, int L, const float* W, const float* bias, int C, int KW, int hop, int pad,
+                                  float* out, void* stream)
+{
+    ST_TRY(fe_check(B, L, C, KW, hop, pad)); ST_REQ(x && W && out, "st_fe_analysis_fwd: null pointer");
+    const int T = st_fe_frames(L, KW, hop, pad), R = B * T;
+    ST_REQ(T > 0, "st_fe_analysis_fwd: window longer than the padded signal");
+    stg::FramedNT<false> al{x, L, hop, pad, R, KW, 1.0f, stg::all_frames(T)};
+    stg::PlainNT bl{W, C, KW, KW, stg::all_frames(1)};
+    stg::BiasStore ep{out, bias, R, C, C};
+    stg::launch<2, 16>(al, bl, ep, R, C, KW, 1, st_stream(stream), g_dbg);
+    ST_LAUNCHED("fe_analysis_fwd"); return ST_OK;
+}
+static int fe_frames_ola(const float* xft, int B, int T, const float* W, int C, int KW, int hop, int crop, int len,
+                         float* frs, float* out, void* stream)
+{
+    const int R = B * T;
+    stg::PlainNT al{xft, R, C, C, stg::all_frames(1)};
+    stg::PlainTN bl{W, C, KW, KW, stg::all_frames(1)};
+    stg::StoreC ep{frs, R, KW, KW, 0, stg::all_frames(1)};
+    stg::launch<2, 16>(al, bl, ep, R, KW, C, 1, st_stream(stream), g_dbg);
+    hipLaunchKernelGGL(stm::ola_crop_kernel, dim3((len + 255) / 256, B), dim3(256), 0, st_stream(stream), frs, out, T, KW, hop, crop, len);
+    return ST_OK;
+}
+extern "C" int st_fe_synthesis_fwd(const float* xft, int B, int T, const float* W, int C, int KW, int hop, int crop,
+                                   float* ws, float* out, void* stream)
+{
+    ST_REQ(xft && W && ws && out && B > 0 && T > 0, "st_fe_synthesis_fwd: bad arguments");
+    ST_REQ(KW % 16 == 0 && C % 16 == 0 && hop % 4 == 0 && crop % 4 == 0, "st_fe_synthesis_fwd: KW%%16, C%%16, hop%%4, crop%%4 required");
+    const int len = (T - 1) * hop + KW - 2 * crop;
+    ST_REQ(len > 0, "st_fe_synthesis_fwd: nothing left after the crop");
+    ST_TRY(fe_frames_ola(xft, B, T, W, C, KW, hop, crop, len, ws, out, stream));
+    ST_LAUNCHED("fe_synthesis_fwd"); return ST_OK;
+}
+// autograd of st_fe_analysis_fwd: gW [C][KW], gbias [C] (may be null), gx [B][L] (may be null)
+extern "C" int st_fe_analysis_bwd(const float* x, int B, int L, const float* W, int C, int KW, int hop, int pad, const float* g_out,
+                                  float* ws, float* gW, float* gbias, float* gx, void* stream)
+{
+    ST_TRY(fe_check(B, L, C, KW, hop, pad)); ST_REQ(x && W && g_out && ws && gW, "st_fe_analysis_bwd: null pointer");
+    const int T = st_fe_frames(L, KW, hop, pad), R = B * T;
+    const int ns = wgrad_split(R);
+    float* slabs = ws;                                       // [ns][C][KW]
+    float* frs = ws + (size_t)ns * C * KW;                   // [R][KW]
+    {
+        stg::PlainTN al{g_out, R, C, C, stg::all_frames(1)};
+        stg::FramedTN<false> bl{x, L, hop, pad, R, KW, 1.0f, stg::all_frames(T)};
+        stg::StoreC ep{slabs, C, KW, KW, (size_t)C * KW, stg::all_frames(1)};
+        stg::launch<3, 16>(al, bl, ep, C, KW, R, ns, st_stream(stream), g_dbg);
+        const size_t n = (size_t)C * KW;
+        hipLaunchKernelGGL(stm::sum_slabs_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st_stream(stream), slabs, ns, n, gW);
+    }
+    if (gbias) hipLaunchKernelGGL(stm::col_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st_stream(stream), g_out, R, C, gbias);
+    if (gx) ST_TRY(fe_frames_ola(g_out, B, T, W, C, KW, hop, pad, L, frs, gx, stream));   // conv-transpose of the output gradient, cropped by the padding
+    ST_LAUNCHED("fe_analysis_bwd"); return ST_OK;
+}
+// autograd of st_fe_synthesis_fwd: gW [C][KW], g_xft [B][T][C] (may be null)
+extern "C" int st_fe_synthesis_bwd(const float* xft, int B, int T, const float* W, int C, int KW, int hop, int crop, const float* g_wave,
+                                   float* ws, float* gW, float* g_xft, void* stream)
+{
+    ST_REQ(xft && W && g_wave && ws && gW && B > 0 && T > 0, "st_fe_synthesis_bwd: bad arguments");
+    ST_REQ(KW % 16 == 0 && C % 16 == 0 && hop % 4 == 0 && crop % 4 == 0, "st_fe_synthesis_bwd: KW%%16, C%%16, hop%%4, crop%%4 required");
+    const int len = (T - 1) * hop + KW - 2 * crop, R = B * T;
+    ST_REQ(len > 0 && len % 4 == 0, "st_fe_synthesis_bwd: bad output length %d", len);
+    const int ns = wgrad_split(R);
+    float* slabs = ws;                                       // [ns][C][KW]
+    float* gp = ws + (size_t)ns * C * KW;                    // padded gradient signal [B][crop + len + crop]: its frames are d(frames)
+    ST_TRY(pad_scale(g_wave, gp, B, len, crop, 1.0f, stream));
+    if (g_xft) {
+        stg::FramedNT<true> al{gp, len, hop, crop, R, KW, 1.0f, stg::all_frames(T)};
+        stg::PlainNT bl{W, C, KW, KW, stg::all_frames(1)};
+        stg::StoreC ep{g_xft, R, C, C, 0, stg::all_frames(1)};
+        stg::launch<2, 16>(al, bl, ep, R, C, KW, 1, st_stream(stream), g_dbg);
+    }
+    {
+        stg::PlainTN al{xft, R, C, C, stg::all_frames(1)};
+        stg::FramedTN<true> bl{gp, len, hop, crop, R, KW, 1.0f, stg::all_frames(T)};
+        stg::StoreC ep{slabs, C, KW, KW, (size_t)C * KW, stg::all_frames(1)};
+        stg::launch<3, 16>(al, bl, ep, C, KW, R, ns, st_stream(stream), g_dbg);
+        const size_t n = (size_t)C * KW;
+        hipLaunchKernelGGL(stm::sum_slabs_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st_stream(stream), slabs, ns, n, gW);
+    }
+    ST_LAUNCHED("fe_synthesis_bwd"); return ST_OK;
+}

@@ -198,6 +198,27 @@ struct StoreC {       // out[(z*slab) + full_row*ld + col]; z = blockIdx.z (spli
     }
 };
 
+struct BiasStore {    // out[row*ld + col] = acc + bias[col]   (Conv1d bias; bias may be null)
+    float* out; const float* bias; int M, Nc, ld;
+    __device__ void operator()(int m0, int n0, const f32x16 (&acc)[NJ]) const {
+        const int lane = threadIdx.x & 63;
+        float bv[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { const int col = n0 + 32 * j + (lane & 31); bv[j] = (bias && col < Nc) ? bias[col] : 0.f; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = m0 + d_row(i, lane);
+            if (row < M) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int col = n0 + 32 * j + (lane & 31);
+                    if (col < Nc) out[(size_t)row * ld + col] = acc[j][i] + bv[j];
+                }
+            }
+        }
+    }
+};
+
 // Analysis epilogue: nn_proc.py:309-310 fused.  Columns are interleaved (re,im) pairs of one bin in adjacent lanes.
 // Registers are processed in pairs (rows r, r+1): one lane-pair exchange hands the even lane the full complex value
 // of row r and the odd lane that of row r+1, so every lane does ONE sqrt and ONE atan2 per register pair.

@@ -348,4 +348,41 @@ compressor_4c_kernel(const float* __restrict__ x, const float* __restrict__ knob
     }
 }
 
+
+// ------------------------------------------------------------------------------ generic learned-basis front end (cls_fe_dct_bases.py)
+// ConvTranspose1d(C -> 1, k = KW, stride = hop) after its GEMM: overlap-add of the frames [B*T][KW] and crop
+// (cls_fe_dct_bases.py:174-179); also the input gradient of Conv1d(1 -> C) (crop = its padding).
+// out[b][j] = sum_t frs[b, t, j + crop - hop t]
+__global__ void __launch_bounds__(256)
+ola_crop_kernel(const float* __restrict__ frs, float* __restrict__ out, int T, int KW, int hop, int crop, int len)
+{
+    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= len) return;
+    const int p = j + crop;
+    int t1 = p / hop; if (t1 > T - 1) t1 = T - 1;
+    int t0 = p - KW + 1 <= 0 ? 0 : (p - KW + hop) / hop;       // ceil((p - KW + 1) / hop)
+    float s = 0.f;
+    for (int t = t0; t <= t1; ++t) s += frs[((size_t)b * T + t) * KW + (p - hop * t)];
+    out[(size_t)b * len + j] = s;
+}
+
+__global__ void sum_slabs_flat_kernel(const float* __restrict__ ws, int nslab, size_t n, float* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int z = 0; z < nslab; ++z) s += ws[(size_t)z * n + i];
+    out[i] = s;
+}
+
+// column sums of a row-major [R][C] matrix (Conv1d bias gradient); one thread per column, fixed order
+__global__ void col_sum_kernel(const float* __restrict__ X, int R, int C, float* __restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += X[(size_t)r * C + c];
+    out[c] = s;
+}
+
 }  // namespace stm

@@ -224,3 +224,53 @@ def test_standalone_autoencoder_module(golden_dir):
         out, _ = mod.forward(torch.from_numpy(v).cuda(), torch.from_numpy(kn).cuda(), skip_connections=mode)
         ref = O.ae_fwd(v, kn, P, prefix, mode)[0]
         assert np.abs(out.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max(), mode
+
+
+def test_dct_front_end_golden_and_autograd(golden_dir):
+    """SURVEY.md row a15 (cls_fe_dct_bases.py): forward against the reference's golden G7; autograd (weight, bias and
+    input gradients of both modules) against torch-CPU autograd of the same Conv1d / ConvTranspose1d with learned
+    (perturbed) bases, odd batch."""
+    import torch.nn.functional as Fn
+    from signaltrain_amd import cls_fe_dct_bases as D
+    g = np.load(os.path.join(golden_dir, "g7_dct.npz"))
+    an, sy = D.Analysis().cuda(), D.Synthesis().cuda()
+    with torch.no_grad():
+        an.conv_analysis.bias.copy_(torch.from_numpy(g["bias"]))
+    from tests.golden_util import SAMPLE_ROWS
+    assert np.array_equal(an.conv_analysis.weight.detach().cpu().numpy()[SAMPLE_ROWS, 0], g["basis_rows"])
+    xft = an.forward(g["x"])                                     # numpy input like the reference
+    assert xft.shape == (1, 9, 1024)
+    e = np.abs(xft.detach().cpu().numpy()[:, :, ::8] - g["xft"]).max()
+    assert e <= 1e-4 * np.abs(g["xft"]).max(), e
+    wav = sy.forward(xft)
+    assert wav.shape == (1, 1, 8192)
+    e = np.abs(wav.detach().cpu().numpy() - g["wav"]).max()
+    assert e <= 1e-4 * np.abs(g["wav"]).max(), e
+    # autograd vs torch CPU on perturbed bases
+    rng = np.random.default_rng(4)
+    B, L = 3, 8192
+    Wa = (D.core_modulation(1024, 2048) + 0.01 * rng.standard_normal((1024, 2048))).astype(np.float32)
+    Ws = (D.core_modulation(1024, 2048) + 0.01 * rng.standard_normal((1024, 2048))).astype(np.float32)
+    bias = (0.1 * rng.standard_normal(1024)).astype(np.float32)
+    x = (0.3 * rng.standard_normal((B, L))).astype(np.float32)
+    proj = rng.standard_normal((B, 1, 8192)).astype(np.float32)
+    # reference ops on CPU (float64)
+    xc = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    Wac = torch.tensor(Wa[:, None, :], dtype=torch.float64, requires_grad=True); bc = torch.tensor(bias, dtype=torch.float64, requires_grad=True)
+    Wsc = torch.tensor(Ws[:, None, :], dtype=torch.float64, requires_grad=True)
+    ft = Fn.conv1d(xc[:, None, :], Wac, bc, stride=1024, padding=1024).transpose(2, 1)
+    wv = Fn.conv_transpose1d(ft.transpose(2, 1), Wsc, stride=1024)[:, :, 1024:-1024]
+    (wv * torch.tensor(proj, dtype=torch.float64)).sum().backward()
+    # HIP path
+    with torch.no_grad():
+        an.conv_analysis.weight.copy_(torch.from_numpy(Wa[:, None, :])); an.conv_analysis.bias.copy_(torch.from_numpy(bias))
+        sy.conv_synthesis.weight.copy_(torch.from_numpy(Ws[:, None, :]))
+    xg = torch.from_numpy(x).cuda().requires_grad_(True)
+    ftg = an.forward(xg); wvg = sy.forward(ftg)
+    (wvg * torch.from_numpy(proj).cuda()).sum().backward()
+    def chk(name, got, ref):
+        ref = ref.detach().numpy(); e = np.abs(got.detach().cpu().numpy() - ref).max()
+        assert e <= 1e-4 * np.abs(ref).max(), (name, e, np.abs(ref).max())
+    chk("ft", ftg, ft); chk("wave", wvg, wv)
+    chk("g_x", xg.grad, xc.grad); chk("g_Wa", an.conv_analysis.weight.grad, Wac.grad); chk("g_bias", an.conv_analysis.bias.grad, bc.grad)
+    chk("g_Ws", sy.conv_synthesis.weight.grad, Wsc.grad)
