@@ -110,29 +110,37 @@ __device__ __forceinline__ void layer_fwd(const float* const (&W)[NC], const flo
 // tails (t = T-OT + 4g + r, OT <= 16).  Loaded in one burst and prefetched one group ahead.
 struct FwdIn { float v[2][8]; float tl[2][4]; float kn[4]; };   // kn: knob 4q + g for the (up to 4) knob k-steps of layer 5
 
+// RAW loads from clamped (always valid) addresses; fwd_mask() zeroes the padding rows / bins / knobs afterwards.  The
+// selects must not sit right behind the loads, and the prefetch must not sit in a conditional block: either makes the
+// compiler wait for the loads on the spot, turning the one-group-ahead prefetch into a synchronous load.
 __device__ __forceinline__ void fwd_load(FwdIn& in, const float* __restrict__ mag, const float* __restrict__ phs,
                                          const float* __restrict__ knobs, const int K,
                                          const int b, const int f, const bool fv, const int T, const int OT, const int F, const int g)
 {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { const int kn = 4 * q + g; const float x = knobs[(size_t)b * K + (kn < K ? kn : 0)]; in.kn[q] = kn < K ? x : 0.f; }
-    const size_t base = (size_t)b * T * F + (fv ? f : 0);
+    for (int q = 0; q < 4; ++q) { const int kn = 4 * q + g; in.kn[q] = knobs[(unsigned)b * K + (kn < K ? kn : 0)]; }
+    const unsigned base = (unsigned)b * T * F + (fv ? f : 0);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
         const int t = 4 * ks + g;
-        const bool ok = fv && t < T;
-        const size_t o = base + (size_t)(ok ? t : 0) * F;
-        const float a = mag[o], p = phs[o];
-        in.v[0][ks] = ok ? a : 0.f; in.v[1][ks] = ok ? p : 0.f;
+        const unsigned o = base + (unsigned)(t < T ? t : 0) * F;
+        in.v[0][ks] = mag[o]; in.v[1][ks] = phs[o];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int to = 4 * g + r;
-        const bool ok = fv && to < OT;
-        const size_t o = base + (size_t)(ok ? T - OT + to : 0) * F;
-        const float a = mag[o], p = phs[o];
-        in.tl[0][r] = ok ? a : 0.f; in.tl[1][r] = ok ? p : 0.f;
+        const unsigned o = base + (unsigned)(to < OT ? T - OT + to : 0) * F;
+        in.tl[0][r] = mag[o]; in.tl[1][r] = phs[o];
     }
+}
+__device__ __forceinline__ void fwd_mask(FwdIn& in, const int K, const bool fv, const int T, const int OT, const int g)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) in.kn[q] = (4 * q + g) < K ? in.kn[q] : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) { const bool ok = fv && 4 * ks + g < T; in.v[0][ks] = ok ? in.v[0][ks] : 0.f; in.v[1][ks] = ok ? in.v[1][ks] : 0.f; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const bool ok = fv && 4 * g + r < OT; in.tl[0][r] = ok ? in.tl[0][r] : 0.f; in.tl[1][r] = ok ? in.tl[1][r] : 0.f; }
 }
 
 // grid.x workgroups of NW waves; each wave walks 16-row groups: group id = b*(FP/16) + fg.
@@ -167,6 +175,7 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     if (FAST && grp < ngroups) {
         const int b = grp / gpw, f = (grp - b * gpw) * 16 + c;
         fwd_load(cur, mag, phs, knobs, K, b, f, f < F, T, OT, F, g);
+        fwd_mask(cur, K, f < F, T, OT, g);
     }
     for (; grp < ngroups; grp += gstride) {
         asm volatile("" ::: "memory");      // keep the (loop-invariant) LDS weight fetches inside the loop: hoisting them spills
@@ -174,13 +183,9 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         const bool fv = f < F;
         const float* src[2] = {mag + (size_t)b * T * F + f, phs + (size_t)b * T * F + f};
         FwdIn nxt;
-        if (FAST) {
-            const int gn = grp + gstride;
-            if (gn < ngroups) {
-                const int bn = gn / gpw, fn = (gn - bn * gpw) * 16 + c;
-                fwd_load(nxt, mag, phs, knobs, K, bn, fn, fn < F, T, OT, F, g);
-            }
-        }
+        const int gn = grp + gstride < ngroups ? grp + gstride : grp;      // last iteration: harmless reload of this group
+        const int bn = gn / gpw, fn = (gn - bn * gpw) * 16 + c;
+        if (FAST) fwd_load(nxt, mag, phs, knobs, K, bn, fn, fn < F, T, OT, F, g);
 
         // ---- layer 1 (IN = T; B operand: t = 4*ks + g)
         f32x4 h1[2][4];
@@ -306,7 +311,7 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
                 }
             }
         }
-        if (FAST) cur = nxt;
+        if (FAST) { fwd_mask(nxt, K, fn < F, T, OT, g); cur = nxt; }
     }
     if (reg_partial) {
         reg = wave_sum(reg);

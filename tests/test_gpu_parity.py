@@ -56,3 +56,40 @@ def test_ae_bwd_repeatable():
     names = [k for k, v in eng.layout.views(outs[0]).items()
              if not (torch.equal(v, eng.layout.views(outs[1])[k]) and torch.equal(v, eng.layout.views(outs[2])[k]))]
     assert not names, names
+
+
+def test_full_size_batch_properties():
+    """BASELINE configs[1] size (B = 256 windows of 8192 samples): properties that do not need the (slow) oracle.
+    Windows are independent, the loss is a mean over the batch and the L1 term a mean over B*OT*F, so
+      forward(B) == concat(forward(halves)),   grads(B) == (grads(half 1) + grads(half 2)) / 2,
+    and two runs give identical bits.  Exercises the full-size tiling / split-K / reduction paths."""
+    import numpy as np, torch
+    from tests import gpu_checks as G
+    from signaltrain_amd.engine import StepEngine
+    B, K = 256, 4
+    geo, X, Y, KN, P = G.make_case(8, 31, K=K)
+    rng = np.random.default_rng(1)
+    reps = B // 8
+    X = (np.tile(X, (reps, 1)) * rng.uniform(0.4, 1.0, (B, 1))).astype(np.float32)
+    Y = (np.tile(Y, (reps, 1)) * rng.uniform(0.4, 1.0, (B, 1))).astype(np.float32)
+    KN = (rng.random((B, K)) - 0.5).astype(np.float32)
+    x, y, kn = G.t(X), G.t(Y), G.t(KN)
+    full = StepEngine(G.dims_of(geo, B, K), G.DEV); full.load_state_dict(P)
+    half = StepEngine(G.dims_of(geo, B // 2, K), G.DEV); half.load_state_dict(P)
+    yf, mf, hf = full.forward(x, kn)
+    parts = [half.forward(x[i:i + B // 2], kn[i:i + B // 2]) for i in (0, B // 2)]
+    for a, name, j in ((yf, "y_hat", 0), (mf, "mag", 1), (hf, "mag_hat", 2)):
+        ref = torch.cat([p[j] for p in parts])
+        assert (a - ref).abs().max().item() <= 1e-6 * ref.abs().max().item(), name
+    full.loss_backward(x, kn, y); torch.cuda.synchronize(); g_full = full.grads.clone(); l_full = float(full.scalars[0])
+    full.loss_backward(x, kn, y); torch.cuda.synchronize()
+    assert torch.equal(g_full, full.grads)                          # bit-repeatable at full size
+    gs, ls = [], []
+    for i in (0, B // 2):
+        half.loss_backward(x[i:i + B // 2], kn[i:i + B // 2], y[i:i + B // 2]); torch.cuda.synchronize()
+        gs.append(half.grads.clone()); ls.append(float(half.scalars[0]))
+    g_ref = 0.5 * (gs[0] + gs[1])
+    assert abs(l_full - 0.5 * (ls[0] + ls[1])) <= 1e-5 * abs(l_full)
+    for name, v in full.layout.views(g_full).items():
+        r = full.layout.views(g_ref)[name]
+        assert (v - r).abs().max().item() <= 2e-5 * max(r.abs().max().item(), 1e-12), name
