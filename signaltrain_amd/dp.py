@@ -2,9 +2,9 @@
 
 The reference's only multi-GPU mechanism is a disabled nn.DataParallel stub (train.py:259-263).  Here each
 rank runs the fused step on its shard of the minibatch with identical parameters; the flat fp32 gradient
-buffer (16.8 MB) is sum-all-reduced in two buckets -- [synthesis bases + both autoencoders] as soon as
-they are final, overlapping the analysis weight-gradient GEMM, then the 513 live rows of the two analysis
-tensors -- scaled by 1/world, and only then L1-clipped (the norm is a function of the reduced gradient, so it
+buffer (16.8 MB) is sum-all-reduced in two buckets -- [synthesis bases + both autoencoders] (8.45 MB) as soon as
+they are final, overlapping the analysis weight-gradient GEMM, then one contiguous range holding the 513 live rows
+of the two analysis tensors (6.3 MB incl. 2 MB of structural zeros) -- scaled by 1/world, and only then L1-clipped (the norm is a function of the reduced gradient, so it
 is identical on every rank and needs no second collective) and fed to the replicated Adam.
 """
 import torch
@@ -35,9 +35,7 @@ class DataParallel:
         h0 = dist.all_reduce(b[0], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         eng.loss_backward_p2()
         h1 = dist.all_reduce(b[1], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        h2 = dist.all_reduce(b[2], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        for h in (h0, h1, h2):
-            h.wait()
+        h0.wait(); h1.wait()
         return eng.clip_adam(lr, grad_scale=1.0 / self.world, **kw)
 
     def mean_loss(self):

@@ -158,11 +158,13 @@ class StepEngine:
                                                 _lib.ptr(self.scalars), self._stream()), "st_loss_backward_p2")
 
     def grad_buckets(self):
-        """Gradient ranges in the order they become final: [synthesis + autoencoders], then the live rows
-        [0,F) of the two analysis tensors (rows >= F are structurally zero and never move)."""
+        """Gradient ranges in the order they become final: [synthesis + autoencoders] after phase 1, then ONE contiguous
+        range covering the live rows [0,F) of both analysis tensors (it spans the structurally-zero rows [F,N) of the
+        first tensor: 2 MB of zeros is cheaper than the ~25 us fixed cost of a third collective; rows >= F of the second
+        tensor never move)."""
         o, d = self.layout.offsets, self.dims
         live = d.F * d.N
-        return [self.grads[o[2]:], self.grads[o[0]:o[0] + live], self.grads[o[1]:o[1] + live]]
+        return [self.grads[o[2]:], self.grads[o[0]:o[1] + live]]
 
     def train_step(self, x, knobs, y, lr, betas=(0.9, 0.999), eps=1e-8):
         """One optimisation step (train.py:112-151).  `lr` is the value sitting in param_groups at step

@@ -44,7 +44,7 @@ class OracleEngine:
 
     def grad_buckets(self):
         n = 1 << 20
-        return [self.grads[2 * n:], self.grads[0:513 * 1024], self.grads[n:n + 513 * 1024]]
+        return [self.grads[2 * n:], self.grads[0:n + 513 * 1024]]            # same two ranges as StepEngine.grad_buckets()
 
     def clip_adam(self, lr, grad_scale=1.0, **kw):
         self.step_count += 1
