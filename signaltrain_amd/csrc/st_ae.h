@@ -514,7 +514,7 @@ __device__ __forceinline__ void mul_elu_grad(f32x4 (&d)[TL], const f32x4 (&h)[TL
 #pragma unroll
     for (int t = 0; t < TL; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) d[t][r] *= elu_grad_from_out(h[t][r]);
+        for (int r = 0; r < 4; ++r) d[t][r] = __builtin_fmaf(d[t][r], fminf(h[t][r], 0.f), d[t][r]);   // d * ELU'(a) = d * (1 + min(h, 0)): v_min + v_fma
 }
 
 // dW_l tile(ot,it) += sum_rows daT[ot] (x) hT[it]; result (D layout: o = 16ot+4g+r, i = 16it+c) -> LDS atomics.
