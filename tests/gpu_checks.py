@@ -30,9 +30,9 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def make_case(B=3, seed=0, scale=1, shrink=4, K=4, pert=7):
+def make_case(B=3, seed=0, scale=1, shrink=4, K=4, pert=7, scheme="lean"):
     """Seeded comp_4c-shaped inputs + 'learned' (perturbed) parameters, as fp32 numpy."""
-    geo = O.geometry(scale, shrink)
+    geo = O.geometry(scale, shrink, scheme)
     rng = np.random.default_rng(seed)
     X, Y, KN = O.synth_comp4c_batch(B, geo["L"], geo["y"], rng)
     if K != 4:
@@ -89,10 +89,10 @@ def phase_err(name, got, ref, mag, tol=TOL):
 
 
 # --------------------------------------------------------------------------------------------- stages
-def run_all(B=3, seed=0, K=4, verbose=False, scale=1):
+def run_all(B=3, seed=0, K=4, verbose=False, scale=1, scheme="lean"):
     """Run every per-op entry point on oracle-provided inputs; returns list of result dicts."""
     lib = _lib.load()
-    geo, X, Y, KN, P = make_case(B, seed, K=K, scale=scale)
+    geo, X, Y, KN, P = make_case(B, seed, K=K, scale=scale, scheme=scheme)
     d = dims_of(geo, B, K)
     KP = lib.st_kp(d.F); F, T, OT, N = d.F, d.T, d.OT, d.N
     res = []
@@ -223,9 +223,9 @@ def run_all(B=3, seed=0, K=4, verbose=False, scale=1):
     return res
 
 
-def run_fused(B=3, seed=1, K=4, steps=3, scale=1):
+def run_fused(B=3, seed=1, K=4, steps=3, scale=1, scheme="lean"):
     """Fused entry points: st_model_fwd, st_loss_backward, st_train_step x steps vs the oracle."""
-    geo, X, Y, KN, P = make_case(B, seed, K=K, scale=scale)
+    geo, X, Y, KN, P = make_case(B, seed, K=K, scale=scale, scheme=scheme)
     d = dims_of(geo, B, K)
     eng = StepEngine(d, DEV)
     eng.load_state_dict(P)

@@ -29,6 +29,14 @@ def test_fused_step_parity(B, seed, K, steps):
     _assert_ok(G.run_fused(B=B, seed=seed, K=K, steps=steps))
 
 
+def test_legacy_large_fft_scheme():
+    """nn_proc.py:374-376 (scale_scheme != 'lean'): ft and hop scale with the window -- scale 2: N=2048, H=768, F=1025,
+    T=25, OT=9.  Same kernels, different GEMM sizes / spectral pitch."""
+    from tests import gpu_checks as G
+    _assert_ok(G.run_all(B=2, seed=3, K=4, scale=2, scheme="legacy"))
+    _assert_ok(G.run_fused(B=3, seed=5, K=3, steps=2, scale=2, scheme="legacy"))
+
+
 def test_fused_step_parity_scale8():
     from tests import gpu_checks as G
     _assert_ok(G.run_fused(B=2, seed=5, K=4, steps=2, scale=8))
