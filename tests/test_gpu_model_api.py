@@ -274,3 +274,35 @@ def test_dct_front_end_golden_and_autograd(golden_dir):
     chk("ft", ftg, ft); chk("wave", wvg, wv)
     chk("g_x", xg.grad, xc.grad); chk("g_Wa", an.conv_analysis.weight.grad, Wac.grad); chk("g_bias", an.conv_analysis.bias.grad, bc.grad)
     chk("g_Ws", sy.conv_synthesis.weight.grad, Wsc.grad)
+
+
+def test_training_trajectory_matches_cpu_port():
+    """25 consecutive optimisation steps (1-cycle learning rates, four alternating minibatches) on the GPU vs the
+    PyTorch-CPU restatement of the reference's op sequence on identical data: the loss trajectory and the parameters
+    after training.  (The 3-step oracle comparison pins the arithmetic; this pins the absence of drift.)"""
+    from tests import gpu_checks as G
+    from oracle.torch_cpu_step import CpuPort
+    from signaltrain_amd.engine import StepEngine
+    from signaltrain_amd import learningrate
+    B, K, steps = 4, 4, 25
+    geo, X, Y, KN, P = G.make_case(4 * B, 41, K=K)
+    d = G.dims_of(geo, B, K)
+    eng = StepEngine(d, G.DEV); eng.load_state_dict(P)
+    port = CpuPort(P)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    lrs, _ = learningrate.get_1cycle_schedule(lr_max=2e-4, n_data_points=steps * B, epochs=1, batch_size=B)
+    lg, lc = [], []
+    for it in range(steps):
+        sl = slice((it % 4) * B, (it % 4 + 1) * B)
+        lr = float(lrs[max(it - 1, 0)])                                   # train.py:150: lr written for the NEXT step
+        eng.train_step(G.t(X[sl]), G.t(KN[sl]), G.t(Y[sl]), lr)
+        lg.append(float(eng.scalars[0]))
+        lc.append(port.step(torch.from_numpy(X[sl]), torch.from_numpy(KN[sl]), torch.from_numpy(Y[sl]), lr))
+    lg, lc = np.array(lg), np.array(lc)
+    assert np.all(np.isfinite(lg))
+    assert np.abs(lg - lc).max() <= 2e-3 * np.abs(lc).max(), (lg, lc)      # float32 log-cosh noise of the CPU port is ~1e-3
+    worst = 0.0
+    for k, v in eng.named.items():
+        ref = port.P[k].detach().numpy().reshape(v.shape)
+        worst = max(worst, float(np.abs(v.cpu().numpy() - ref).max()))
+    assert worst <= 2e-4, worst                                            # 25 Adam steps of <= 2e-4 each: no drift beyond noise-level sign flips
