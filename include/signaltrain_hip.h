@@ -93,9 +93,11 @@ size_t st_ae_fwd_ws_floats(const st_dims* d);
  * Sfold[KP,N]: rows [0,F) = Sr[k]+Sr[N-k], rows [KP/2,KP/2+F) = Si[k]-Si[N-k]; other rows 0. */
 int st_synth_fold(const st_dims* d, const float* Sr, const float* Si, float* Sfold, void* stream);
 
-/* Number of split-K slabs the two small-M synthesis GEMMs write (frs: slabs x [B*OT,N]; dAA: slabs x [B*OT,KP]);
- * st_ola_loss / st_ae_bwd sum the slabs while reading. */
+/* Number of split-K slabs the two small-M synthesis GEMMs write: st_synth_frame_slabs() for st_synthesis_frames'
+ * output frs (slabs x [B*OT,N], summed by st_ola_loss) and st_synth_slabs() for st_synthesis_dgrad's output dAA
+ * (slabs x [B*OT,KP], summed by st_ae_bwd). */
 int st_synth_slabs(const st_dims* d);
+int st_synth_frame_slabs(const st_dims* d);
 
 /* cls_fe_dft.py:112 ConvTranspose1d as a GEMM: frs[B*OT,N] = AA[B*OT,KP] * Sfold[KP,N] (live frames only). */
 int st_synthesis_frames(const st_dims* d, const float* AA, const float* Sfold, float* frs, void* stream);

@@ -51,6 +51,7 @@ SIGNATURES = {
     "st_fe_synthesis_bwd": (_i, [_p, C.c_int, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p]),
     "st_ae_fwd_partials": (_i, [_D]),
     "st_synth_slabs": (_i, [_D]),
+    "st_synth_frame_slabs": (_i, [_D]),
     "st_synth_fold": (_i, [_D, _p, _p, _p, _p]),
     "st_synthesis_frames": (_i, [_D, _p, _p, _p, _p]),
     "st_ola_loss": (_i, [_D, _p, _p, _p, _p, _p, _p, _p]),

@@ -106,7 +106,7 @@ class _SynthesisFn(torch.autograd.Function):
         KP = lib.st_kp(F)
         AA = torch.zeros(B * OT, KP, device=real.device)
         AA[:, :F] = real.reshape(B * OT, F); AA[:, KP // 2:KP // 2 + F] = imag.reshape(B * OT, F)
-        Sfold = torch.empty(KP, N, device=real.device); frs = torch.zeros(lib.st_synth_slabs(C.byref(d)), B * OT, N, device=real.device)
+        Sfold = torch.empty(KP, N, device=real.device); frs = torch.zeros(lib.st_synth_frame_slabs(C.byref(d)), B * OT, N, device=real.device)
         wave = torch.empty(B, d.y, device=real.device)
         Sr_, Si_ = Sr.contiguous(), Si.contiguous()
         _lib.check(lib.st_synth_fold(C.byref(d), _lib.ptr(Sr_), _lib.ptr(Si_), _lib.ptr(Sfold), _stream()), "fold")

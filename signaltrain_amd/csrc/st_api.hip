@@ -156,9 +156,12 @@ namespace sta { extern __device__ unsigned long long g_ae_stage_cycles[32]; }
 extern "C" int st_debug_read_stage_cycles(unsigned long long* out32);
 static int g_bk = 16;   // k-tile depth of the GEMM family (16: 36 KB LDS/WG -> 4 WGs/CU; 32: 64 KB -> 2 WGs/CU)
 static int g_wg_mode_set(int v);
-static int g_wsplit_max = 16, g_wsplit_div = 200;
+static int g_wsplit_max = 16, g_wsplit_div = 200, g_an_waves = 4, g_syn_split = 3, g_frs_split = 3;      // frames: 3, 4 measured equal, 6 slower (only 66 k-tiles to split)
 extern "C" int st_set_tuning(int bk)
 {
+    if (bk >= 4000) { g_frs_split = bk - 4000; return (g_frs_split >= 1 && g_frs_split <= 6) ? ST_OK : st_fail(ST_ERR_ARG, "frames split must be 1..6"); }
+    if (bk >= 3000) { g_syn_split = bk - 3000; return ST_OK; }    // 3000 + n: synthesis split-K (<= 3: consumers sum at most 3 slabs)
+    if (bk >= 2000) { g_an_waves = bk - 2000; return ST_OK; }     // 2000 + n: waves per workgroup of the analysis forward GEMM
     if (bk >= 1000) { g_wsplit_div = bk - 1000; return ST_OK; }  // 1000 + n: rows per weight-gradient k-slice (diagnostics)
     if (bk >= 200) { g_wsplit_max = bk - 200; return ST_OK; }      // 200 + n: cap of the weight-gradient split-K (diagnostics)
     if (bk >= 100) return g_wg_mode_set(bk - 100);           // 100 / 101: weight-gradient tile mode (diagnostics)
@@ -178,7 +181,7 @@ static int ae_bwd_grid(const st_dims* d) { int groups = d->B * (st_kp_of(d->F) /
 // needs >= ~2 waves per SIMD (2048 waves) to overlap its load/LDS phases; the small-M synthesis GEMMs and the
 // 121-tile weight-gradient GEMMs get there by splitting K and summing the slabs in the consumer kernel.
 static int wgrad_split(int R) { int s = R / g_wsplit_div; if (s < 1) s = 1; if (s > g_wsplit_max) s = g_wsplit_max; return s; }
-static int synth_split(int R) { return R >= 4096 ? 1 : 3; }   // consumers (ola_loss_kernel, ae_bwd_kernel) sum at most 3 slabs
+static int synth_split(int R) { return R >= 4096 ? 1 : g_syn_split; }   // consumers (ola_loss_kernel, ae_bwd_kernel) sum at most 3 slabs
 
 extern "C" int st_ae_fwd_partials(const st_dims* d) { return ae_fwd_grid(d) * AE_FWD_NW; }
 extern "C" int st_ola_loss_partials(const st_dims* d) { return d->B * ((d->y + 255) / 256); }
@@ -189,6 +192,10 @@ extern "C" size_t st_wgrad_ws_floats(const st_dims* d)
     return (size_t)s * st_kp_of(d->F) * d->N;
 }
 extern "C" int st_synth_slabs(const st_dims* d) { return synth_split(synth_live_rows(d)); }
+// split-K slabs of the synthesis FRAMES GEMM (summed by ola_loss_kernel, which takes up to 6; the dgrad slabs are summed
+// inside ae_bwd_kernel where every extra slab costs 8 loads per row group, hence the separate, smaller count above)
+static int frames_split(int R) { return R >= 4096 ? 1 : g_frs_split; }
+extern "C" int st_synth_frame_slabs(const st_dims* d) { return frames_split(synth_live_rows(d)); }
 // Wide geometries (T > 32 or OT > 16) run the autoencoders as feature-major GEMMs (st_ae_wide.h) and need workspace
 // for the activations [features][B*FP]; the fused kernels of st_ae.h need none in forward.
 static bool ae_is_wide(const st_dims* d) { return d->T > 32 || d->OT > 16; }
@@ -250,7 +257,12 @@ static int analysis_fwd_impl(const st_dims* d, const float* sig, bool padded, co
     const int R = map.rows(d->B);
     stg::AnalysisW bl{Wr, Wi, d->F, d->N};
     stg::PolarStore ep{re, im, mag, phs, R, d->F, map};
-    if (padded) { stg::FramedNT<true> al{sig, d->L, d->H, d->N, R, d->N, 1.0f, map}; ST_GEMM(4, al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream)); }
+    if (padded) {
+        stg::FramedNT<true> al{sig, d->L, d->H, d->N, R, d->N, 1.0f, map};
+        if (g_an_waves == 2) ST_GEMM(2, al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream));
+        else if (g_an_waves == 3) ST_GEMM(3, al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream));
+        else ST_GEMM(4, al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream));
+    }
     else { stg::FramedNT<false> al{sig, d->L, d->H, d->N, R, d->N, in_scale, map}; ST_GEMM(4, al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream)); }
     ST_LAUNCHED("analysis_fwd");
     if (map.Tv < d->T) {                   // ... and are exact zeros (re=im=mag=0, phs=atan2(0,1e-7)=0)
@@ -324,10 +336,10 @@ extern "C" int st_synthesis_frames(const st_dims* d, const float* AA, const floa
     const int R = ms.rows(d->B);
     stg::PlainNT al{AA, R, KP, KP, ms};
     stg::PlainTN bl{Sfold, KP, d->N, d->N, stg::all_frames(1)};
-    // frs holds st_synth_slabs() split-K slabs [B*OT, N]; st_ola_loss sums them
+    // frs holds st_synth_frame_slabs() split-K slabs [B*OT, N]; st_ola_loss sums them
     stg::StoreC ep{frs, R, d->N, d->N, (size_t)d->B * d->OT * d->N, ms};
     if (R >= 4096) ST_GEMM(4, al, bl, ep, R, d->N, KP, 1, st_stream(stream));
-    else ST_GEMM(2, al, bl, ep, R, d->N, KP, synth_split(R), st_stream(stream));
+    else ST_GEMM(2, al, bl, ep, R, d->N, KP, frames_split(R), st_stream(stream));
     ST_LAUNCHED("synthesis_frames"); return ST_OK;
 }
 
@@ -337,7 +349,7 @@ static int ola_loss_impl(const st_dims* d, const float* frs, const float* x, con
     const float inv = 1.0f / ((float)d->B * (float)d->y);
     hipLaunchKernelGGL(stm::ola_loss_kernel, dim3((d->y + 255) / 256, d->B), dim3(256), 0, st_stream(stream),
                        frs, x, y_true, y_hat, dsyn, loss_partial, d->L, d->N, d->H, d->OT, d->y, inv,
-                       st_synth_slabs(d), (size_t)d->B * d->OT * d->N, dsyn_pad);
+                       st_synth_frame_slabs(d), (size_t)d->B * d->OT * d->N, dsyn_pad);
     ST_LAUNCHED("ola_loss");
     return ST_OK;
 }
@@ -639,9 +651,9 @@ static void carve(const st_dims* d, void* base, WS* w)
     auto take = [&](size_t n) { float* p = base ? reinterpret_cast<float*>(base) + off : nullptr; off += (n + 63) / 64 * 64; return p; };
     w->re = take(RT * F); w->im = take(RT * F); w->mag = take(RT * F); w->phs = take(RT * F);
     w->mag_hat = take(RO * F); w->phs_hat = take(RO * F);
-    const size_t nsl = st_synth_slabs(d);
+    const size_t nsl = st_synth_slabs(d), nfs = st_synth_frame_slabs(d);
     w->AA = take(RO * KP); w->dAA = take(nsl * RO * KP);
-    w->Sfold = take(KP * N); w->frs = take(nsl * RO * N);
+    w->Sfold = take(KP * N); w->frs = take(nfs * RO * N);
     w->y_hat = take((size_t)d->B * d->y); w->dsyn = take((size_t)d->B * (d->y + 2 * d->N));   // dsyn padded [B][N + y + N]
     w->xp = take((size_t)d->B * (d->L + 2 * d->N));                                               // x/2 padded  [B][N + L + N]
     w->dmag = take(RT * F); w->dphs = take(RT * F); w->dG = take(RT * KP);

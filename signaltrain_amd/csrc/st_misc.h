@@ -67,10 +67,13 @@ ola_loss_kernel(const float* __restrict__ frs, const float* __restrict__ x, cons
         if (t1 > OT - 1) t1 = OT - 1;
         const float* fb = frs + (size_t)b * OT * N;
         float s = 0.f;
-        for (int t = t0; t <= t1; ++t) {            // up to 3 split-K slabs of the synthesis GEMM, loads issued together
+        for (int t = t0; t <= t1; ++t) {            // up to 6 split-K slabs of the synthesis GEMM, loads issued together, fixed order
             const size_t o = (size_t)t * N + (N + j - H * t);
-            const float v0 = fb[o], v1 = fb[(nslab > 1 ? slab : 0) + o], v2 = fb[(nslab > 2 ? 2 * slab : 0) + o];
-            s += v0 + (nslab > 1 ? v1 : 0.f) + (nslab > 2 ? v2 : 0.f);
+            float v[6];
+#pragma unroll
+            for (int z = 0; z < 6; ++z) v[z] = fb[(z < nslab ? z * slab : 0) + o];
+#pragma unroll
+            for (int z = 0; z < 6; ++z) s += z < nslab ? v[z] : 0.f;
         }
         const float out = x ? 2.0f * (s + 0.5f * x[(size_t)b * L + (L - ysz) + j]) : s;   // x == NULL: plain Synthesis.forward (cls_fe_dft.py:112-113)
         if (y_hat) y_hat[(size_t)b * ysz + j] = out;

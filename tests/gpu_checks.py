@@ -146,7 +146,7 @@ def run_all(B=3, seed=0, K=4, verbose=False, scale=1, scheme="lean"):
     res += [err("fold.re", sf_re, fr_), err("fold.im", sf_im, fi_, scale=np.abs(fr_).max())]
     AAo = t(to_kp(c["Are"].reshape(-1, F), c["Aim"].reshape(-1, F), KP))
     nsl = lib.st_synth_slabs(C.byref(d))
-    frs = z(nsl, B * OT, N)
+    frs = z(lib.st_synth_frame_slabs(C.byref(d)), B * OT, N)
     _lib.check(lib.st_synthesis_frames(C.byref(d), _lib.ptr(AAo), _lib.ptr(Sfold), _lib.ptr(frs), stream()), "synth")
     frs_ref = c["Are"].reshape(-1, F) @ fr_ + c["Aim"].reshape(-1, F) @ fi_
     # only frames that reach the cropped output are computed (t with 0 < H t and H t - N < y)
@@ -154,7 +154,7 @@ def run_all(B=3, seed=0, K=4, verbose=False, scale=1, scheme="lean"):
     res.append(err("synthesis.frames", n(frs).sum(0).reshape(B, OT, N)[:, live], frs_ref.reshape(B, OT, N)[:, live]))
     y_hat, dsyn = z(B, d.y), z(B, d.y)
     lp = z(lib.st_ola_loss_partials(C.byref(d)))
-    frs_o = z(nsl, B * OT, N); frs_o[0] = t(frs_ref)
+    frs_o = z(lib.st_synth_frame_slabs(C.byref(d)), B * OT, N); frs_o[0] = t(frs_ref)
     _lib.check(lib.st_ola_loss(C.byref(d), _lib.ptr(frs_o), _lib.ptr(x), _lib.ptr(y), _lib.ptr(y_hat), _lib.ptr(dsyn),
                                _lib.ptr(lp), stream()), "ola")
     res += [err("ola.y_hat", n(y_hat), c["out"]), err("ola.dsyn", n(dsyn), 2 * c["dy"]),

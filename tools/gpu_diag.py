@@ -73,7 +73,7 @@ T, OT, F, N, KP = d.T, d.OT, d.F, d.N, lib.st_kp(d.F)
 re, im, mag, phs = z(B, T, F), z(B, T, F), z(B, T, F), z(B, T, F)
 nsl = lib.st_synth_slabs(C.byref(d))
 mag_hat, phs_hat, AA, dAA = z(B, OT, F), z(B, OT, F), z(B * OT, KP), z(nsl, B * OT, KP)
-Sfold, frs = z(KP, N), z(nsl, B * OT, N)
+Sfold, frs = z(KP, N), z(lib.st_synth_frame_slabs(C.byref(d)), B * OT, N)
 y_hat, dsyn = z(B, d.y), z(B, d.y)
 regp, lp = z(lib.st_ae_fwd_partials(C.byref(d))), z(lib.st_ola_loss_partials(C.byref(d)))
 wsg = z(lib.st_wgrad_ws_floats(C.byref(d))); aews = z(lib.st_ae_bwd_ws_floats(C.byref(d)))
