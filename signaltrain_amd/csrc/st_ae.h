@@ -52,11 +52,11 @@ __host__ __device__ inline AELds ae_lds_layout(int T, int OT, int K)
 // the packed global tensors with 8 independent loads in flight per thread (a dependent load->store loop costs
 // ~40 serialized L2 round trips per workgroup, i.e. tens of microseconds before the first MFMA).
 __device__ inline void ae_load_lds(float* lds, const AELds& L, const float* __restrict__ ae, const AEOffsets& go,
-                                   int tid, int nthreads)
+                                   int tid, int nthreads, int l0 = 0, int l1 = NL)     // layers [l0, l1): the wide path keeps 1..7 only
 {
     for (int e = tid; e < L.total; e += nthreads) lds[e] = 0.f;
     __syncthreads();
-    for (int l = 0; l < NL; ++l) {
+    for (int l = l0; l < l1; ++l) {
         const int P = L.P[l], IN = L.IN[l], n = L.OUT[l] * IN;
         const float* src = ae + go.w[l];
         float* dst = lds + L.w[l];
@@ -316,6 +316,100 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     if (reg_partial) {
         reg = wave_sum(reg);
         if (lane == 0) reg_partial[blockIdx.x * NW + wave] = reg;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ forward, inner layers only
+// Wide geometries (st_ae_wide.h): layers 1 and 9 are GEMMs over feature-major activations X[feature][R] (R = B*FP columns,
+// column = b*FP + f); this kernel fuses layers 2..8 (64 -> 32 -> 16 -> 16 -> [+knobs] 16 -> 16 -> 32 -> 64) for both
+// autoencoders: H1 [64][R] -> H8 [64][R], activations in registers exactly as in ae_fwd_kernel.  A 16-column group never
+// straddles windows (FP % 16 == 0), so the knobs stay wave-uniform.  Pad columns (f >= F) are written as zeros.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64)
+ae_inner_fwd_kernel(const float* __restrict__ H1m, const float* __restrict__ H1p, const float* __restrict__ knobs,
+                    const float* __restrict__ ae_m, const float* __restrict__ ae_p, const AEOffsets go,
+                    float* __restrict__ H8m, float* __restrict__ H8p, const int B, const int F, const int K, const int KP)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const AELds L = ae_lds_layout(16, 16, K);          // layers 0 and 8 get (unused) minimal regions
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    float* lw[2] = {lds, lds + L.total};
+    ae_load_lds(lw[0], L, ae_m, go, tid, NW * 64, 1, 8);
+    ae_load_lds(lw[1], L, ae_p, go, tid, NW * 64, 1, 8);
+    __syncthreads();
+    const int FP = KP / 2, gpw = FP / 16, ngroups = B * gpw;
+    const size_t R = (size_t)B * FP;
+    const int KQ = (K + 3) / 4;
+    const float* const Hin[2] = {H1m, H1p};
+    float* const Hout[2] = {H8m, H8p};
+    for (int grp = blockIdx.x * NW + wave; grp < ngroups; grp += gridDim.x * NW) {
+        asm volatile("" ::: "memory");
+        const int b = grp / gpw, f = (grp - b * gpw) * 16 + c;
+        const size_t col = (size_t)b * FP + f;
+        f32x4 h1[2][4];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h1[ch][ot][r] = Hin[ch][(size_t)(16 * ot + 4 * g + r) * R + col];
+        f32x4 h2[2][2], h3[2][1], h4[2][1];
+        {
+            const float* const W[2] = {lw[0] + L.w[1], lw[1] + L.w[1]}; const float* const bb[2] = {lw[0] + L.b[1], lw[1] + L.b[1]};
+            layer_fwd<2, 2, 4>(W, bb, L.P[1], h1, h2, g, c);
+        }
+        {
+            const float* const W[2] = {lw[0] + L.w[2], lw[1] + L.w[2]}; const float* const bb[2] = {lw[0] + L.b[2], lw[1] + L.b[2]};
+            layer_fwd<2, 1, 2>(W, bb, L.P[2], h2, h3, g, c);
+        }
+        {
+            const float* const W[2] = {lw[0] + L.w[3], lw[1] + L.w[3]}; const float* const bb[2] = {lw[0] + L.b[3], lw[1] + L.b[3]};
+            layer_fwd<2, 1, 1>(W, bb, L.P[3], h3, h4, g, c);
+        }
+        f32x4 h5[2][1];
+        {
+            f32x4 acc[2];
+            const int P5 = L.P[4];
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) acc[ch] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch)
+                    acc[ch] = ST_MFMA16(lw[ch][L.w[4] + c * P5 + 4 * g + r], h4[ch][0][r], acc[ch]);
+            for (int q = 0; q < KQ; ++q) {
+                const int kn = 4 * q + g;
+                const float kv = kn < K ? knobs[(size_t)b * K + kn] : 0.f;
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch)
+                    acc[ch] = ST_MFMA16(lw[ch][L.w[4] + c * P5 + 16 + kn], kv, acc[ch]);
+            }
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h5[ch][0][r] = elu_f(acc[ch][r] + lw[ch][L.b[4] + 4 * g + r]);
+        }
+        f32x4 h6[2][1], h7[2][2], h8[2][4];
+        {
+            const float* const W[2] = {lw[0] + L.w[5], lw[1] + L.w[5]}; const float* const bb[2] = {lw[0] + L.b[5], lw[1] + L.b[5]};
+            layer_fwd<2, 1, 1>(W, bb, L.P[5], h5, h6, g, c);
+        }
+        {
+            const float* const W[2] = {lw[0] + L.w[6], lw[1] + L.w[6]}; const float* const bb[2] = {lw[0] + L.b[6], lw[1] + L.b[6]};
+            layer_fwd<2, 2, 1>(W, bb, L.P[6], h6, h7, g, c);
+        }
+        {
+            const float* const W[2] = {lw[0] + L.w[7], lw[1] + L.w[7]}; const float* const bb[2] = {lw[0] + L.b[7], lw[1] + L.b[7]};
+            layer_fwd<2, 4, 2>(W, bb, L.P[7], h7, h8, g, c);
+        }
+        const bool fv = f < F;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Hout[ch][(size_t)(16 * ot + 4 * g + r) * R + col] = fv ? h8[ch][ot][r] : 0.f;
     }
 }
 
@@ -592,7 +686,12 @@ struct CL {
 #define ST_SCHED_FENCE() do { if constexpr (!REG) __builtin_amdgcn_sched_barrier(0); } while (0)
 
 // Supported geometry of this instantiation: T <= 32, OT <= 16, K <= 16.
-template <int NW, bool REG, bool TIMED>   // REG: persistent register accumulators (1 wave/SIMD); else per-group LDS atomics (2 waves/SIMD)
+// INNER (wide geometries, st_ae_wide.h): only layers 2..8 -- layers 1 and 9 are feature-major GEMMs.  Pointer roles then:
+//   mag / phs         -> H1 [64][R] of the two nets (layer-1 outputs, R = B*FP columns)
+//   mag_hat / phs_hat -> dH8 [64][R] = W9^T dA9 (the kernel applies ELU'(h8) itself: h8 is recomputed)
+//   dmag / dphs       -> dA1 [64][R] = (W2^T dA2) * ELU'(h1), consumed by the layer-1 weight/data-gradient GEMMs
+// and the partial gradients of layers 1 and 9 stay zero.
+template <int NW, bool REG, bool TIMED, bool INNER = false>   // REG: persistent register accumulators (1 wave/SIMD); else per-group LDS atomics (2 waves/SIMD)
 __global__ void __launch_bounds__(NW * 64, REG ? 1 : 2)
 ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, const float* __restrict__ knobs,
               const float* __restrict__ ae_m, const float* __restrict__ ae_p, const AEOffsets go, const int PG,
@@ -608,7 +707,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     const int ae = blockIdx.y;
     const bool timing = TIMED && (dbg & 256) && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x >> 6) == 0;
     unsigned long long t0_ = timing ? __builtin_amdgcn_s_memtime() : 0ull;
-    const AELds L = ae_lds_layout(T, OT, K);
+    const AELds L = INNER ? ae_lds_layout(32, 16, K) : ae_lds_layout(T, OT, K);       // INNER: the CL layout with layers 1 / 9 left empty
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
     float* lw = lds;                                   // weights (+bias), padded
@@ -619,10 +718,11 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     float* Ys = Vs + 32 * SP;
     float* Ts = Ys + 16 * SP;
     for (int e = tid; e < CL::TOTAL; e += NW * 64) dwl[e] = 0.f;
-    ae_load_lds(lw, L, ae ? ae_p : ae_m, go, tid, NW * 64);
+    ae_load_lds(lw, L, ae ? ae_p : ae_m, go, tid, NW * 64, INNER ? 1 : 0, INNER ? 8 : NL);
     __syncthreads();
 
     const float* vin = ae ? phs : mag;
+    const float* dh8in = ae ? phs_hat : mag_hat;       // INNER only
     float* dvout = ae ? dphs : dmag;
     const int FP = KP / 2, gpw = FP / 16;
     const int ngroups = B * gpw;
@@ -667,7 +767,8 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) dst[ks] = (ok0 && 4 * ks + g < T) ? dst[ks] : 0.f;
     };
-    if (grp < ngroups) { load_v(grp, vr); mask_v(grp, vr); }
+    if constexpr (!INNER) { if (grp < ngroups) { load_v(grp, vr); mask_v(grp, vr); } }
+    const unsigned Rw = (unsigned)B * FP;              // INNER: columns of the feature-major buffers
 
     for (; grp < ngroups; grp += gstride) {
         asm volatile("" ::: "memory");      // keep the (loop-invariant) LDS weight fetches inside the loop
@@ -678,6 +779,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         // forward stages to overlap their issue with MFMA execution was measured: no gain.)
         float q_gre[4], q_gim[4], q_ph[4], q_mh[4], q_mt[4], q_gm[4];
         const float* gmp = g_mag_hat ? g_mag_hat : mag_hat;
+        if constexpr (!INNER) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int to = 4 * g + r;
@@ -697,6 +799,25 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             q_mt[r] = vin[((unsigned)b * T + (ok ? T - OT + to : 0)) * F + fq];
             { const float x = gmp[ro * F + fq]; q_gm[r] = (g_mag_hat && ok) ? x : 0.f; }      // branch-free (see load_v)
         }
+        }
+        // INNER: layer-1 outputs in both layouts and the gradient entering layer 8's output, straight from the
+        // feature-major buffers (D layout: feature 16 tile + 4g + r at column col0 + c; T layout: feature 16 tile + c at
+        // columns col0 + 4g .. + 3 = one aligned float4)
+        f32x4 h1in[4], hT1in[4], dh8[4], dhT8[4];
+        if constexpr (INNER) {
+            const unsigned col0 = (unsigned)b * FP + (unsigned)(grp - b * gpw) * 16;
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    h1in[ot][r] = vin[(unsigned)(16 * ot + 4 * g + r) * Rw + col0 + c];
+                    dh8[ot][r] = dh8in[(unsigned)(16 * ot + 4 * g + r) * Rw + col0 + c];
+                }
+                const float4 a = *reinterpret_cast<const float4*>(vin + (size_t)(16 * ot + c) * Rw + col0 + 4 * g);
+                const float4 d = *reinterpret_cast<const float4*>(dh8in + (size_t)(16 * ot + c) * Rw + col0 + 4 * g);
+                hT1in[ot] = (f32x4){a.x, a.y, a.z, a.w}; dhT8[ot] = (f32x4){d.x, d.y, d.z, d.w};
+            }
+        }
         // knob values: D-layout feature tile (16 + 4g + r) and T-layout feature lane (16 + c)
         f32x4 kn[1]; float knT;
 #pragma unroll
@@ -704,12 +825,15 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         { const float x = knobs[(unsigned)b * K + (c < K ? c : 0)]; knT = c < K ? x : 0.f; }
         float vn[8];
         const int gnext = grp + gstride < ngroups ? grp + gstride : grp;      // last iteration: harmless reload of this group
-        load_v(gnext, vn);
+        if constexpr (!INNER) load_v(gnext, vn);
         ST_T(0);
 
         // ------------------------------------------------------------------ forward recompute (D layout)
         f32x4 h1[4], h2[2], h3[1], h4[1], h5[1], h6[1], h7[2], h8[4], e9[1];
-        {
+        if constexpr (INNER) {
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot) h1[ot] = h1in[ot];
+        } else {
             f32x4 acc[4];
 #pragma unroll
             for (int ot = 0; ot < 4; ++ot) acc[ot] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -758,12 +882,12 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         ST_T(4);
         { float fr[4 * 2 * 4]; frags_fwd<4, 2>(fr, Wl[7], CL::P7, g, c); ST_FENCE(); fwdD_fr<4, 2>(fr, Bl[7], h7, h8, g); }
         ST_T(5);
-        { float fr[1 * 4 * 4]; frags_fwd<1, 4>(fr, Wl[8], CL::P8, g, c); ST_FENCE(); fwdD_fr<1, 4>(fr, Bl[8], h8, e9, g); }
+        if constexpr (!INNER) { float fr[1 * 4 * 4]; frags_fwd<1, 4>(fr, Wl[8], CL::P8, g, c); ST_FENCE(); fwdD_fr<1, 4>(fr, Bl[8], h8, e9, g); }
         ST_T(6);
         ST_SCHED_FENCE();
         // ------------------------------------------------------------------ d out  (D layout: t' = 4g + r)
         f32x4 da9[1];
-        {
+        if constexpr (!INNER) {
             const float wf = fv ? expf(expfac * (float)f) : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -791,13 +915,20 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         // ------------------------------------------------------------------ backward through the layers
         // T layout: lane (g,c), reg r  <->  row 4g + r, feature 16*tile + c
         f32x4 daT9[1];
-        { const float4 v = *reinterpret_cast<const float4*>(Ys + c * SP + 4 * g); daT9[0] = (f32x4){v.x, v.y, v.z, v.w}; }
+        if constexpr (!INNER) { const float4 v = *reinterpret_cast<const float4*>(Ys + c * SP + 4 * g); daT9[0] = (f32x4){v.x, v.y, v.z, v.w}; }
 #define ST_WG(O_, I_, D_, P_, RW_, RB_, DB_, DAT_, HT_) \
         if constexpr (REG) wgrad_reg<O_, I_>(RW_, RB_, DAT_, HT_); else wgrad_lds<O_, I_>(D_, P_, DAT_, HT_, DB_, g, c);
         ST_T(7);
         // layer 9 (64 -> OT): needs h8^T (layer-8 forward fragments) and W9 in dgrad order
         f32x4 hT8[4], da8[4], daT8[4];
-        {
+        if constexpr (INNER) {                     // dH8 arrives from the layer-9 data-gradient GEMM; h8^T is still needed for ELU' and dW8
+            float ff[4 * 2 * 4];
+            frags_fwd<4, 2>(ff, Wl[7], CL::P7, g, c); ST_FENCE();
+            fwdT_fr<4, 2>(ff, Bl[7], h7, hT8, c);
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot) { da8[ot] = dh8[ot]; daT8[ot] = dhT8[ot]; }
+            mul_elu_grad<4>(da8, h8); mul_elu_grad<4>(daT8, hT8);
+        } else {
             float ff[4 * 2 * 4], fd[1 * 4 * 4];
             frags_fwd<4, 2>(ff, Wl[7], CL::P7, g, c); frags_dgrad<1, 4>(fd, Wl[8], CL::P8, g, c); ST_FENCE();
             fwdT_fr<4, 2>(ff, Bl[7], h7, hT8, c);
@@ -877,7 +1008,19 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         ST_T(12);
         // layer 2 (64 -> 32); h1^T from the input rows
         f32x4 hT1[4], da1[4], daT1[4];
-        {
+        if constexpr (INNER) {                     // h1^T comes from memory; dA1 goes back to memory for the layer-1 GEMMs
+            float fd[2 * 4 * 4];
+            frags_dgrad<2, 4>(fd, Wl[1], CL::P1, g, c); ST_FENCE();
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot) hT1[ot] = hT1in[ot];
+            ST_WG(2, 4, Dl[1], CL::P1, rW2, rb2, db2, daT2, hT1)
+            dgrad_fr<2, 4>(fd, da2, da1, daT1); mul_elu_grad<4>(da1, h1);
+            const unsigned col0 = (unsigned)b * FP + (unsigned)(grp - b * gpw) * 16;
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dvout[(unsigned)(16 * ot + 4 * g + r) * Rw + col0 + c] = da1[ot][r];
+        } else {
             float ff[4 * 8], fd[2 * 4 * 4];
             const int P1 = CL::P0;
 #pragma unroll
@@ -901,7 +1044,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         ST_T(13);
         // layer 1 (T -> 64): input rows transposed through the wave's scratch
         f32x4 vT[2], dv[2];
-        {
+        if constexpr (!INNER) {
             float fd[4 * 2 * 4];
             frags_dgrad<4, 2>(fd, Wl[0], CL::P0, g, c);
 #pragma unroll
@@ -913,6 +1056,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
 #undef ST_WG
         ST_T(14);
         // ------------------------------------------------------------------ d input rows (+ skip / residual tails)
+        if constexpr (!INNER) {
 #pragma unroll
         for (int it = 0; it < 2; ++it)
 #pragma unroll
@@ -924,21 +1068,24 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
                     dvout[((unsigned)b * T + t) * F + f] = v;
                 }
             }
+        }
         ST_T(15);
-        mask_v(gnext, vn);
+        if constexpr (!INNER) {
+            mask_v(gnext, vn);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) vr[ks] = vn[ks];
+            for (int ks = 0; ks < 8; ++ks) vr[ks] = vn[ks];
+        }
     }
     // ---------------------------------------------------------------------- workgroup partial gradients
     if constexpr (REG) {
         for (int wv = 0; wv < NW; ++wv) {          // ordered, non-atomic: run-to-run identical bits
             if (wave == wv) {
-                dw_flush<4, 2>(Dl[0], CL::P0, rW1, g, c); dw_flush<2, 4>(Dl[1], CL::P1, rW2, g, c); dw_flush<1, 2>(Dl[2], CL::P2, rW3, g, c);
+                if constexpr (!INNER) { dw_flush<4, 2>(Dl[0], CL::P0, rW1, g, c); dw_flush<1, 4>(Dl[8], CL::P8, rW9, g, c); db_flush<4>(db1, rb1, g, c); db_flush<1>(db9, rb9, g, c); }
+                dw_flush<2, 4>(Dl[1], CL::P1, rW2, g, c); dw_flush<1, 2>(Dl[2], CL::P2, rW3, g, c);
                 dw_flush<1, 1>(Dl[3], CL::P3, rW4, g, c); dw_flush<1, 2>(Dl[4], CL::P4, rW5, g, c); dw_flush<1, 1>(Dl[5], CL::P5, rW6, g, c);
-                dw_flush<2, 1>(Dl[6], CL::P6, rW7, g, c); dw_flush<4, 2>(Dl[7], CL::P7, rW8, g, c); dw_flush<1, 4>(Dl[8], CL::P8, rW9, g, c);
-                db_flush<4>(db1, rb1, g, c); db_flush<2>(db2, rb2, g, c); db_flush<1>(db3, rb3, g, c); db_flush<1>(db4, rb4, g, c);
+                dw_flush<2, 1>(Dl[6], CL::P6, rW7, g, c); dw_flush<4, 2>(Dl[7], CL::P7, rW8, g, c);
+                db_flush<2>(db2, rb2, g, c); db_flush<1>(db3, rb3, g, c); db_flush<1>(db4, rb4, g, c);
                 db_flush<1>(db5, rb5, g, c); db_flush<1>(db6, rb6, g, c); db_flush<2>(db7, rb7, g, c); db_flush<4>(db8, rb8, g, c);
-                db_flush<1>(db9, rb9, g, c);
             }
             __syncthreads();
         }
@@ -947,7 +1094,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     float* base = ws + ((size_t)blockIdx.x * 2 + ae) * PG;
     for (int i = tid; i < PG; i += NW * 64) base[i] = 0.f;                 // alignment pads
     __syncthreads();
-    for (int l = 0; l < NL; ++l) {
+    for (int l = INNER ? 1 : 0; l < (INNER ? 8 : NL); ++l) {       // INNER: layers 1 and 9 come from the GEMM path
         const int P = L.P[l], IN = L.IN[l], n = L.OUT[l] * IN;
         for (int e = tid; e < n; e += NW * 64) { const int o = e / IN; base[go.w[l] + e] = dwl[L.w[l] + o * P + (e - o * IN)]; }
         if (tid < L.OUT[l]) base[go.b[l] + tid] = dwl[L.b[l] + tid];

@@ -20,20 +20,34 @@ using stg::NJ;
 using stg::d_row;
 
 // ------------------------------------------------------------------------------------------------ epilogues
+// All epilogues: a lane owns 3 columns (col = n0 + 32 j + lane%32) and 16 rows of the 32 x 96 wave tile; everything that
+// depends on the column only (validity, batch index b = col / FP, bin f) is computed once per column, not per element
+// (the integer division is ~20 instructions).
+struct ColInfo { int col, b, f; bool ok, real; };
+__device__ __forceinline__ void col_info(ColInfo (&ci)[NJ], int n0, int lane, int R, int FP, int F)
+{
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + 32 * j + (lane & 31);
+        ci[j].col = col; ci[j].ok = col < R;
+        ci[j].b = col / FP; ci[j].f = col - ci[j].b * FP;
+        ci[j].real = ci[j].ok && ci[j].f < F;
+    }
+}
+
 struct ActStore {          // layers 1..8 forward: out[row][col] = ELU(acc + bias[row]) on real bins, 0 on pad columns
     float* out; const float* bias; int M, R, FP, F;
     __device__ void operator()(int m0, int n0, const f32x16 (&acc)[NJ]) const {
         const int lane = threadIdx.x & 63;
+        ColInfo ci[NJ]; col_info(ci, n0, lane, R, FP, F);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = m0 + d_row(i, lane);
             if (row < M) {
                 const float bv = bias[row];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int col = n0 + 32 * j + (lane & 31);
-                    if (col < R) out[(size_t)row * R + col] = (col % FP) < F ? elu_f(acc[j][i] + bv) : 0.f;
-                }
+                for (int j = 0; j < NJ; ++j)
+                    if (ci[j].ok) out[(size_t)row * R + ci[j].col] = ci[j].real ? elu_f(acc[j][i] + bv) : 0.f;
             }
         }
     }
@@ -43,6 +57,7 @@ struct OutStore {          // layer 9 forward (nn_proc.py:113-117, :322): e = EL
     float* e9; float* outp; const float* tail; const float* bias; int M, R, FP, F, mode;      // M = OT; outp [B][OT][F] or null
     __device__ void operator()(int m0, int n0, const f32x16 (&acc)[NJ]) const {
         const int lane = threadIdx.x & 63;
+        ColInfo ci[NJ]; col_info(ci, n0, lane, R, FP, F);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = m0 + d_row(i, lane);
@@ -50,13 +65,11 @@ struct OutStore {          // layer 9 forward (nn_proc.py:113-117, :322): e = EL
                 const float bv = bias[row];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const int col = n0 + 32 * j + (lane & 31);
-                    if (col < R) {
-                        const int b = col / FP, f = col - b * FP;
+                    if (ci[j].ok) {
                         const float e = elu_f(acc[j][i] + bv);
-                        const size_t ix = (size_t)row * R + col;
-                        e9[ix] = f < F ? e : 0.f;
-                        if (outp && f < F) { const float tl = tail[ix]; outp[((size_t)b * M + row) * F + f] = mode ? e + tl : e * tl; }
+                        const size_t ix = (size_t)row * R + ci[j].col;
+                        e9[ix] = ci[j].real ? e : 0.f;
+                        if (outp && ci[j].real) { const float tl = tail[ix]; outp[((size_t)ci[j].b * M + row) * F + ci[j].f] = mode ? e + tl : e * tl; }
                     }
                 }
             }
@@ -86,20 +99,17 @@ struct DvStore {           // gradient w.r.t. the AE input rows, written in the 
     float* dv; const float* tail; int T, OT, R, FP, F;
     __device__ void operator()(int m0, int n0, const f32x16 (&acc)[NJ]) const {
         const int lane = threadIdx.x & 63;
+        ColInfo ci[NJ]; col_info(ci, n0, lane, R, FP, F);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = m0 + d_row(i, lane);
             if (row < T) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const int col = n0 + 32 * j + (lane & 31);
-                    if (col < R) {
-                        const int b = col / FP, f = col - b * FP;
-                        if (f < F) {
-                            float v = acc[j][i];
-                            if (row >= T - OT) v += tail[(size_t)(row - (T - OT)) * R + col];
-                            dv[((size_t)b * T + row) * F + f] = v;
-                        }
+                    if (ci[j].real) {
+                        float v = acc[j][i];
+                        if (row >= T - OT) v += tail[(size_t)(row - (T - OT)) * R + ci[j].col];
+                        dv[((size_t)ci[j].b * T + row) * F + ci[j].f] = v;
                     }
                 }
             }

@@ -156,9 +156,10 @@ namespace sta { extern __device__ unsigned long long g_ae_stage_cycles[32]; }
 extern "C" int st_debug_read_stage_cycles(unsigned long long* out32);
 static int g_bk = 16;   // k-tile depth of the GEMM family (16: 36 KB LDS/WG -> 4 WGs/CU; 32: 64 KB -> 2 WGs/CU)
 static int g_wg_mode_set(int v);
-static int g_wsplit_max = 16, g_wsplit_div = 200, g_an_waves = 4, g_syn_split = 3, g_frs_split = 3;      // frames: 3, 4 measured equal, 6 slower (only 66 k-tiles to split)
+static int g_wsplit_max = 16, g_wsplit_div = 200, g_an_waves = 4, g_syn_split = 3, g_frs_split = 3, g_wide_fused = 1;      // frames: 3, 4 measured equal, 6 slower (only 66 k-tiles to split)
 extern "C" int st_set_tuning(int bk)
 {
+    if (bk >= 5000) { g_wide_fused = bk - 5000; return ST_OK; }   // 5000 / 5001: wide AE path all-GEMM / fused inner layers
     if (bk >= 4000) { g_frs_split = bk - 4000; return (g_frs_split >= 1 && g_frs_split <= 6) ? ST_OK : st_fail(ST_ERR_ARG, "frames split must be 1..6"); }
     if (bk >= 3000) { g_syn_split = bk - 3000; return ST_OK; }    // 3000 + n: synthesis split-K (<= 3: consumers sum at most 3 slabs)
     if (bk >= 2000) { g_an_waves = bk - 2000; return ST_OK; }     // 2000 + n: waves per workgroup of the analysis forward GEMM
@@ -201,7 +202,7 @@ extern "C" int st_synth_frame_slabs(const st_dims* d) { return frames_split(synt
 static bool ae_is_wide(const st_dims* d) { return d->T > 32 || d->OT > 16; }
 struct WideWS {
     float *W1p[2], *W5p[2], *V[2], *H[2][8], *E9[2];         // forward: H[a][j] = output of layer j+1 (H[a][3] has 16 + K rows: [h4 ; knobs])
-    float *DA[2][9], *TL[2], *slabs;                          // backward: dA_l, skip/residual tails, split-K slabs of the weight gradients
+    float *DA[2][9], *TL[2], *slabs, *inner_ws;               // backward: dA_l, skip/residual tails, split-K slabs (one set per net), workgroup partials of the fused inner kernel
     // every layer-input buffer (V, H[.][j]) has ONE extra row (index = that layer's IN) of ones: bias gradient via the wgrad GEMM
     size_t fwd_floats, floats; int Tp, nsplit; size_t R, SL; int so[10];
 };
@@ -230,7 +231,8 @@ static void wide_carve(const st_dims* d, float* base, WideWS* w)
         for (int l = 0; l < 9; ++l) w->DA[a][l] = take((size_t)drows[l] * R);
         w->TL[a] = take((size_t)d->OT * R);
     }
-    w->slabs = take((size_t)w->nsplit * w->SL);
+    w->slabs = take((size_t)2 * w->nsplit * w->SL);
+    { Layout L; if (make_layout(d, &L) == ST_OK) w->inner_ws = take((size_t)ae_bwd_grid(d) * 2 * L.PG); else w->inner_ws = nullptr; }
     w->floats = off;
 }
 extern "C" size_t st_ae_fwd_ws_floats(const st_dims* d)
@@ -431,9 +433,10 @@ static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, cons
     hipLaunchKernelGGL(stw::wide_in_kernel, dim3(T + d->K, d->B), dim3(256), 0, s, mag, phs, knobs, w.V[0], w.V[1], w.H[0][3], w.H[1][3],
                        d->B, T, F, FP, d->K);
     ST_LAUNCHED("ae_wide_in");
+    // layers 1..8: GEMM for layer 1 (K = T); layers 2..8 either one fused kernel for both nets (default) or seven more GEMMs
     for (int a = 0; a < 2; ++a) {
         const float* ae = a ? ae_p : ae_m;
-        for (int l = 0; l < 8; ++l) {
+        for (int l = 0; l < (g_wide_fused ? 1 : 8); ++l) {
             const float* Wl = l == 0 ? w.W1p[a] : (l == 4 ? w.W5p[a] : ae + L.go.w[l]);
             const int kp = l == 0 ? Tp : (l == 4 ? 32 : in[l]);                       // padded reduction length = row pitch of Wl
             const float* Hin = l == 0 ? w.V[a] : w.H[a][l - 1];
@@ -442,6 +445,17 @@ static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, cons
             stw::ActStore ep{w.H[a][l], ae + L.go.b[l], out[l], R, FP, F};
             ST_WGEMM(al, bl, ep, out[l], R, kp, 1, s);
         }
+    }
+    if (g_wide_fused) {
+        const sta::AELds ll = sta::ae_lds_layout(16, 16, d->K);
+        const size_t lds = (size_t)2 * ll.total * sizeof(float);
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_inner_fwd_kernel<AE_FWD_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        hipLaunchKernelGGL((sta::ae_inner_fwd_kernel<AE_FWD_NW>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, s,
+                           w.H[0][0], w.H[1][0], knobs, ae_m, ae_p, L.go, w.H[0][7], w.H[1][7], d->B, F, d->K, L.KP);
+    }
+    for (int a = 0; a < 2; ++a) {
+        const float* ae = a ? ae_p : ae_m;
         stg::PlainNT al{ae + L.go.w[8], OT, 64, 64, id};
         stg::PlainTN bl{w.H[a][7], 64, R, R, id};
         stw::OutStore ep{w.E9[a], a ? phs_hat : mag_hat, w.V[a] + (size_t)(T - OT) * R, ae + L.go.b[8], OT, R, FP, F, a};
@@ -455,6 +469,18 @@ static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, cons
         ST_LAUNCHED("ae_wide_polar_out");
     }
     return ST_OK;
+}
+
+// one weight-gradient GEMM of the wide path: dW_l (+ bias via the ones row) as split-K slabs of net a
+static void wide_wgrad(const st_dims* d, WideWS& w, int a, int l, const int* out, const int* in, hipStream_t s)
+{
+    const int R = (int)w.R;
+    const stg::RowMap id = stg::all_frames(1);
+    const float* Hin = l == 0 ? w.V[a] : w.H[a][l - 1];
+    stg::PlainNT al{w.DA[a][l], out[l], R, R, id};
+    stg::PlainNT bl{Hin, in[l] + 1, R, R, id};
+    stg::StoreC ep{w.slabs + (size_t)a * w.nsplit * w.SL + w.so[l], out[l], in[l] + 1, in[l] + 1, w.SL, id};
+    ST_WGEMM(al, bl, ep, out[l], in[l] + 1, R, w.nsplit, s);
 }
 
 static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, const float* phs, const float* knobs,
@@ -487,37 +513,48 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
                            w.DA[0][8], w.DA[1][8], w.TL[0], w.TL[1], d->B, OT, F, FP, L.KP, ms.t_lo, ms.t_lo + ms.Tv - 1);
         ST_LAUNCHED("ae_wide_dout");
     }
-    for (int a = 0; a < 2; ++a) {
+    // data gradient through W_l into dA_{l-1} (layer 5: only the 16 code columns; the knobs take no gradient)
+    auto dgrad = [&](int a, int l, bool plain) {
         const float* ae = a ? ae_p : ae_m;
-        float* g = a ? g_p : g_m;
-        for (int l = 8; l >= 0; --l) {
-            const float* Hin = l == 0 ? w.V[a] : w.H[a][l - 1];
-            // weight (+ bias: the ones row) gradient: K = R columns, split-K slabs [nsplit][OUT][IN + 1], summed after the loop
-            {
-                stg::PlainNT al{w.DA[a][l], out[l], R, R, id};
-                stg::PlainNT bl{Hin, in[l] + 1, R, R, id};
-                stg::StoreC ep{w.slabs + w.so[l], out[l], in[l] + 1, in[l] + 1, w.SL, id};
-                ST_WGEMM(al, bl, ep, out[l], in[l] + 1, R, w.nsplit, s);
-            }
-            // data gradient through W_l (layer 5: only the 16 code columns; the knobs take no gradient)
-            const float* Wl = l == 0 ? w.W1p[a] : (l == 4 ? w.W5p[a] : ae + L.go.w[l]);
-            const int pitch = l == 0 ? Tp : (l == 4 ? 32 : in[l]);
-            const int m = l == 0 ? T : (l == 4 ? 16 : in[l]);
-            stg::PlainTN al{Wl, out[l], pitch, m, id};
-            stg::PlainTN bl{w.DA[a][l], out[l], R, R, id};
-            if (l > 0) {
-                stw::DgradStore ep{w.DA[a][l - 1], w.H[a][l - 1], m, R};
-                ST_WGEMM(al, bl, ep, m, R, out[l], 1, s);
-            } else {
-                stw::DvStore ep{a ? dphs : dmag, w.TL[a], T, OT, R, FP, F};
-                ST_WGEMM(al, bl, ep, T, R, out[l], 1, s);
-            }
+        const float* Wl = l == 0 ? w.W1p[a] : (l == 4 ? w.W5p[a] : ae + L.go.w[l]);
+        const int pitch = l == 0 ? Tp : (l == 4 ? 32 : in[l]);
+        const int m = l == 0 ? T : (l == 4 ? 16 : in[l]);
+        stg::PlainTN al{Wl, out[l], pitch, m, id};
+        stg::PlainTN bl{w.DA[a][l], out[l], R, R, id};
+        if (l == 0) { stw::DvStore ep{a ? dphs : dmag, w.TL[a], T, OT, R, FP, F}; ST_WGEMM(al, bl, ep, T, R, out[l], 1, s); }
+        else if (plain) { stg::StoreC ep{w.DA[a][l - 1], m, R, R, 0, id}; ST_WGEMM(al, bl, ep, m, R, out[l], 1, s); }     // dH only: the fused kernel applies ELU'
+        else { stw::DgradStore ep{w.DA[a][l - 1], w.H[a][l - 1], m, R}; ST_WGEMM(al, bl, ep, m, R, out[l], 1, s); }
+    };
+    stw::GradTab tab;
+    for (int l = 0; l < 9; ++l) { tab.so[l] = w.so[l]; tab.out[l] = out[l]; tab.in[l] = in[l]; tab.gw[l] = L.go.w[l]; tab.gb[l] = L.go.b[l]; }
+    tab.so[9] = w.so[9];
+    if (g_wide_fused) {
+        // layer 9 as GEMMs, layers 8..2 in one fused kernel (both nets), layer 1 as GEMMs
+        for (int a = 0; a < 2; ++a) { wide_wgrad(d, w, a, 8, out, in, s); dgrad(a, 8, true); }
+        {
+            const sta::AELds ll = sta::ae_lds_layout(32, 16, d->K);
+            const size_t lds = ((size_t)2 * ll.total + (size_t)AE_BWD_NW * (32 + 16 + 16) * sta::SP) * sizeof(float);
+            static bool attr = false;
+            if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            const int grid = ae_bwd_grid(d);
+            hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, true, false, true>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, s,
+                               (const float*)w.H[0][0], (const float*)w.H[1][0], knobs, ae_m, ae_p, L.go, L.PG,
+                               (const float*)w.DA[0][7], (const float*)w.DA[1][7], (const float*)nullptr, (const float*)nullptr, 0.f, 0.f,
+                               w.DA[0][0], w.DA[1][0], w.inner_ws, d->B, T, OT, F, d->K, L.KP, 0, 0, 1, (size_t)0, 0);
+            hipLaunchKernelGGL(stm::ae_grad_reduce_kernel, dim3((L.PG + 63) / 64, 2), dim3(256), 0, s, w.inner_ws, grid, L.PG, g_m, g_p);
         }
-        stw::GradTab tab;
-        for (int l = 0; l < 9; ++l) { tab.so[l] = w.so[l]; tab.out[l] = out[l]; tab.in[l] = in[l]; tab.gw[l] = L.go.w[l]; tab.gb[l] = L.go.b[l]; }
-        tab.so[9] = w.so[9];
-        // NB: slabs of net a are consumed before net a+1 overwrites them (same stream)
-        hipLaunchKernelGGL(stw::wide_grad_finish_kernel, dim3((w.so[9] + 255) / 256), dim3(256), 0, s, w.slabs, w.nsplit, w.SL, tab, g);
+        for (int l = 1; l < 8; ++l) tab.out[l] = 0;                 // the finish kernel only scatters layers 1 and 9
+        for (int a = 0; a < 2; ++a) {
+            wide_wgrad(d, w, a, 0, out, in, s); dgrad(a, 0, false);
+            hipLaunchKernelGGL(stw::wide_grad_finish_kernel, dim3((w.so[9] + 255) / 256), dim3(256), 0, s,
+                               w.slabs + (size_t)a * w.nsplit * w.SL, w.nsplit, w.SL, tab, a ? g_p : g_m);
+        }
+    } else {
+        for (int a = 0; a < 2; ++a) {
+            for (int l = 8; l >= 0; --l) { wide_wgrad(d, w, a, l, out, in, s); dgrad(a, l, false); }
+            hipLaunchKernelGGL(stw::wide_grad_finish_kernel, dim3((w.so[9] + 255) / 256), dim3(256), 0, s,
+                               w.slabs + (size_t)a * w.nsplit * w.SL, w.nsplit, w.SL, tab, a ? g_p : g_m);
+        }
     }
     ST_LAUNCHED("ae_wide_bwd");
     return ST_OK;
