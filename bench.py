@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--bk", type=int, default=0, help="GEMM k-tile depth override (16/32)")
     ap.add_argument("--force-dp", action="store_true", help="run the N > 1 code path (bucketed RCCL all-reduce, st_dp_clip_adam) "
                                                             "even with one rank, to measure its overhead on one GPU")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="f32 = the headline / parity configuration; bf16 = bf16 operands with fp32 accumulation in the STFT GEMMs "
+                         "(arithmetic of BASELINE configs[2], [3]; informational, never the headline number)")
     ap.add_argument("--scale", type=int, default=1, help="window scale factor (8 = the 65536-sample window of BASELINE configs[4], "
                                                           "fp32 here; informational -- the headline workload is scale 1)")
     args = ap.parse_args()
@@ -83,7 +86,7 @@ def main():
     # identical init on every rank (run_train.py:20-21 seeds 218), distinct data per rank
     torch.manual_seed(218); np.random.seed(218)
     model = nn_proc.st_model(scale_factor=args.scale, shrink_factor=4, num_knobs=4)
-    eng = StepEngine(d, dev)
+    eng = StepEngine(d, dev, compute_dtype=args.dtype)
     eng.load_state_dict(model.state_dict())
     dp = DataParallel(eng, force_collectives=args.force_dp)
     dp.broadcast_parameters()
@@ -123,8 +126,8 @@ def main():
         flops_k, flops_step = algorithmic_flops(d)
         out = {"metric": METRIC, "value": windows_s * d.T, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
-               "config": {"workload": (f"comp_4c synthetic, 8192-sample windows, batch {B}/GPU, fp32 (BASELINE configs[1])" if args.scale == 1 else
+               "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": (f"comp_4c synthetic, 8192-sample windows, batch {B}/GPU, {'fp32 (BASELINE configs[1])' if args.dtype == 'f32' else 'bf16 GEMM operands / fp32 accumulate (arithmetic of BASELINE configs[2])'}" if args.scale == 1 else
                                        f"comp_4c synthetic, {d.L}-sample windows, batch {B}/GPU, fp32 (geometry of BASELINE configs[4])"),
                           "window": d.L, "frames_per_window": d.T, "global_batch": B * world, "parallelism": f"dp{world}"},
                "windows_per_s": windows_s, "samples_per_s": windows_s * d.L, "loss": loss,

@@ -183,6 +183,15 @@ int st_dp_clip_adam(const st_dims* d, float* params, float* grads, float* m, flo
                     float* scalars, float grad_scale, float lr, float beta1, float beta2, float eps,
                     int step, void* stream);
 
+/* ---- arithmetic of the STFT GEMMs (process-wide switch) -------------------------------------------------------------
+ * 0 (default): fp32 MFMA -- the parity path (<= 1e-4 of the fp32 reference).
+ * 1: bf16 operands, fp32 accumulation (BASELINE.json configs[2], [3]): both operands of the analysis / synthesis GEMMs
+ *    and of their data / weight gradients are rounded to bf16 (RNE) as they are staged; parameters, activations,
+ *    gradients, the autoencoders, the loss and Adam stay fp32.  Equals the reference run with those conv operands
+ *    rounded to bf16 (the oracle has the same switch), not the fp32 reference. */
+int st_set_precision(int bf16);
+int st_get_precision(void);
+
 /* ---- device-side data feed -------------------------------------------------------------------
  * audio.compressor_4controls (signaltrain/audio.py:380-426), the effect of the synthetic comp_4c task
  * (SynthAudioDataSet, datasets.py:312-334), for a batch of device-resident windows:

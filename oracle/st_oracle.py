@@ -25,6 +25,26 @@ AE_LAYERS = ("fnn_enc", "fnn_enc2", "fnn_enc3", "fnn_enc4", "fnn_addknobs",
 
 
 # ----------------------------------------------------------------------------- geometry
+# ----------------------------------------------------------------------------- mixed-precision emulation
+# GEMM_ROUND = None: exact arithmetic in the working dtype (the reference).  GEMM_ROUND = bf16_round: both operands of
+# every analysis / synthesis GEMM (forward, data gradient, weight gradient) are rounded to bfloat16 first -- the
+# arithmetic of the HIP library under st_set_precision(1) (bf16 operands, fp32 accumulation).
+GEMM_ROUND = None
+
+
+def bf16_round(a):
+    """Round-to-nearest-even to bfloat16 (via float32, like the device), returned in the input dtype."""
+    a = np.asarray(a)
+    f = np.ascontiguousarray(a, dtype=np.float32)
+    u = f.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return r.view(np.float32).astype(a.dtype).reshape(a.shape)
+
+
+def _r(a):
+    return a if GEMM_ROUND is None else GEMM_ROUND(a)
+
+
 def geometry(scale_factor=1, shrink_factor=4, scale_scheme="lean"):
     """st_model.__init__ geometry, nn_proc.py:357-385.  All integer, exact."""
     chunk = int(8192 * scale_factor)
@@ -159,8 +179,8 @@ def analysis_fwd(x_half, Wr, Wi, geo):
     Wr/Wi: [N,1,N]; only rows < F are used.  Returns re, im [B,T,F]."""
     N, H, T, F = geo["N"], geo["H"], geo["T"], geo["F"]
     fr = frames(x_half, N, H, T)
-    re = fr @ Wr[:F, 0, :].T.astype(x_half.dtype)
-    im = fr @ Wi[:F, 0, :].T.astype(x_half.dtype)
+    re = _r(fr) @ _r(Wr[:F, 0, :].T.astype(x_half.dtype))
+    im = _r(fr) @ _r(Wi[:F, 0, :].T.astype(x_half.dtype))
     return re, im
 
 
@@ -226,7 +246,7 @@ def synthesis_fwd(Are, Aim, Sr, Si, geo, folded=True):
     dt = Are.dtype
     if folded:
         fr, fi = fold_synthesis(Sr.astype(dt), Si.astype(dt), F)
-        frs = Are @ fr + Aim @ fi
+        frs = _r(Are) @ _r(fr) + _r(Aim) @ _r(fi)
     else:                                                    # literal flip/cat formulation
         re_full = np.concatenate([Are, Are[:, :, 1:-1][:, :, ::-1]], axis=2)
         im_full = np.concatenate([Aim, -Aim[:, :, 1:-1][:, :, ::-1]], axis=2)
@@ -328,10 +348,10 @@ def model_loss_bwd(x, knobs, y_true, P, geo, scale_by_freq=True):
     dfrs = dfull[:, idx]                                     # [B,OT,N]
     Sr, Si = P[STFT_KEYS[2]].astype(dt), P[STFT_KEYS[3]].astype(dt)
     fr_, fi_ = fold_synthesis(Sr, Si, F)
-    dAre = dfrs @ fr_.T
-    dAim = dfrs @ fi_.T
-    dfr = c["Are"].reshape(-1, F).T @ dfrs.reshape(-1, N)    # [F,N]
-    dfi = c["Aim"].reshape(-1, F).T @ dfrs.reshape(-1, N)
+    dAre = _r(dfrs) @ _r(fr_.T)
+    dAim = _r(dfrs) @ _r(fi_.T)
+    dfr = _r(c["Are"].reshape(-1, F).T) @ _r(dfrs.reshape(-1, N))    # [F,N]
+    dfi = _r(c["Aim"].reshape(-1, F).T) @ _r(dfrs.reshape(-1, N))
     gSr = np.zeros((N, N), dt); gSi = np.zeros((N, N), dt)
     gSr[:F] = dfr; gSi[:F] = dfi
     k = np.arange(1, F - 1)
@@ -353,8 +373,8 @@ def model_loss_bwd(x, knobs, y_true, P, geo, scale_by_freq=True):
     dim = dmag * im * inv + dphs * rp / den
     fr = frames(x / 2, N, H, T).reshape(-1, N)
     gWr = np.zeros((N, N), dt); gWi = np.zeros((N, N), dt)
-    gWr[:F] = dre.reshape(-1, F).T @ fr
-    gWi[:F] = dim.reshape(-1, F).T @ fr
+    gWr[:F] = _r(dre.reshape(-1, F).T) @ _r(fr)
+    gWi[:F] = _r(dim.reshape(-1, F).T) @ _r(fr)
     grads = {STFT_KEYS[0]: gWr[:, None, :], STFT_KEYS[1]: gWi[:, None, :],
              STFT_KEYS[2]: gSr[:, None, :], STFT_KEYS[3]: gSi[:, None, :]}
     grads.update(g_m); grads.update(g_p)

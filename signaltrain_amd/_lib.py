@@ -42,6 +42,8 @@ SIGNATURES = {
     "st_analysis_fwd": (_i, [_D, _p, _p, _p, _f, _p, _p, _p, _p, _p]),
     "st_ae_fwd": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "st_ae_fwd_ws_floats": (C.c_size_t, [_D]),
+    "st_set_precision": (_i, [C.c_int]),
+    "st_get_precision": (_i, []),
     "st_compressor_4c": (_i, [_p, _p, C.c_float, C.c_int, C.c_int, C.c_int, _p, _p]),
     "st_fe_frames": (_i, [C.c_int] * 4),
     "st_fe_ws_floats": (C.c_size_t, [C.c_int] * 6),

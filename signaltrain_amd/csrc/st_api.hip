@@ -168,11 +168,16 @@ extern "C" int st_set_tuning(int bk)
     if (bk >= 100) return g_wg_mode_set(bk - 100);           // 100 / 101: weight-gradient tile mode (diagnostics)
     if (bk != 16 && bk != 32) return st_fail(ST_ERR_ARG, "bk must be 16 or 32"); g_bk = bk; return ST_OK;
 }
-#define ST_GEMM(W_, ...) do { if (g_bk == 16) stg::launch<W_, 16>(__VA_ARGS__, g_dbg); else stg::launch<W_, 32>(__VA_ARGS__, g_dbg); } while (0)
+// g_prec: arithmetic of the STFT GEMMs -- 0 = fp32 MFMA (default, the parity path), 1 = bf16 operands / fp32 accumulation
+static int g_prec = 0;
+extern "C" int st_set_precision(int bf16) { g_prec = bf16 ? 1 : 0; return ST_OK; }
+extern "C" int st_get_precision(void) { return g_prec; }
+#define ST_GEMM(W_, ...) do { if (g_prec == 1) stg::launch_bf16<W_>(__VA_ARGS__); \
+                              else if (g_bk == 16) stg::launch<W_, 16>(__VA_ARGS__, g_dbg); else stg::launch<W_, 32>(__VA_ARGS__, g_dbg); } while (0)
 // weight-gradient GEMMs: g_wg_mode 0 = three waves share a 96x96 tile (32x96 strips), 1 = one wave per 96x96 tile
 static int g_wg_mode = 0;
 static int g_wg_mode_set(int v) { g_wg_mode = v ? 1 : 0; return ST_OK; }
-#define ST_GEMM_WG(...) do { if (g_wg_mode == 1) stg::launch<1, 16, 3>(__VA_ARGS__, g_dbg); else ST_GEMM(3, __VA_ARGS__); } while (0)
+#define ST_GEMM_WG(...) do { if (g_wg_mode == 1 && g_prec == 0) stg::launch<1, 16, 3>(__VA_ARGS__, g_dbg); else ST_GEMM(3, __VA_ARGS__); } while (0)
 static const int AE_FWD_NW = 8, AE_BWD_NW = 4;
 static const bool AE_BWD_REG = true;     // persistent register accumulators, 1 wave/SIMD (LDS float atomics per group measured 3x slower)
 static int synth_live_rows(const st_dims* d);

@@ -394,6 +394,168 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
     for (int mi = 0; mi < MI; ++mi) epi(m_blk + (wave * MI + mi) * 32, n_blk, acc[mi]);
 }
 
+// ------------------------------------------------------------------------------ mixed-precision variant
+// bf16 operands, fp32 accumulation (v_mfma_f32_32x32x16_bf16: 16x the fp32 MFMA rate) for the bf16 configurations of
+// BASELINE.json.  Global data stays fp32 (master weights, activations, gradients): the operands are rounded to bf16
+// (round-to-nearest-even, v_cvt_pk_bf16_f32) while they are staged into LDS, so loaders and epilogues are shared with
+// the fp32 kernel and the result equals "round both operands to bf16, multiply, accumulate in fp32".
+// LDS: both operands K-contiguous, [row][32 + 8] bf16 (80 B pitch: conflict-free 128-bit fragment reads).  M/N-contiguous
+// (TN-type) operands are transposed on the way in: a thread loads a 4(k) x 4(m) micro-tile as four float4 and writes
+// four 8-byte k-quads.  One k-tile = 32 = two MFMA k-steps; a lane's fragment is 8 consecutive k (k = 16 s + 8 (lane/32) + i)
+// for both operands, so the reduction order inside a step is whatever the hardware uses -- identically for A and B.
+typedef __bf16 st_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned st_pack_bf16(float a, float b)
+{
+    union { __bf16 h[2]; unsigned u; } p; p.h[0] = (__bf16)a; p.h[1] = (__bf16)b; return p.u;
+}
+
+template <int WAVES_M, class AL, class BL, class EPI>
+__global__ void __launch_bounds__(WAVES_M * 64)
+gemm_bf16_kernel(const AL al, const BL bl, const EPI epi, const int K, const int ksplit)
+{
+    constexpr int BKH = 32;
+    constexpr int BM = 32 * WAVES_M, NT = 64 * WAVES_M;
+    constexpr int LD = BKH + 8;                                   // bf16 elements per LDS row
+    constexpr int A_SZ = BM * LD, B_SZ = BN * LD;
+    constexpr int KQ = BKH / 4;
+    constexpr int A_N = AL::kTN ? (BM / 4) * KQ : BM * KQ;       // items: float4 along k (NT) or 4x4 micro-tiles (TN)
+    constexpr int B_N = BL::kTN ? (BN / 4) * KQ : BN * KQ;
+    constexpr int A_IT = (A_N + NT - 1) / NT, B_IT = (B_N + NT - 1) / NT;
+    constexpr int A_LDS = AL::kTN ? 4 : 1, B_LDS = BL::kTN ? 4 : 1;    // global float4 loads per item
+    __shared__ __attribute__((aligned(16))) unsigned short As[2 * A_SZ];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * B_SZ];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m_blk = blockIdx.y * BM, n_blk = blockIdx.x * BN;
+    const int k_begin = blockIdx.z * ksplit;
+    const int k_end = (k_begin + ksplit < K) ? k_begin + ksplit : K;
+
+    int a_i[A_IT], a_k[A_IT], b_i[B_IT], b_k[B_IT];
+    bool a_v[A_IT], b_v[B_IT];
+    RowState a_st[AL::kTN ? 1 : A_IT], b_st[BL::kTN ? 1 : B_IT];
+#pragma unroll
+    for (int p = 0; p < A_IT; ++p) {
+        const int idx = tid + NT * p; a_v[p] = idx < A_N; const int id = a_v[p] ? idx : 0;
+        if constexpr (AL::kTN) { a_i[p] = (id % (BM / 4)) * 4; a_k[p] = (id / (BM / 4)) * 4; }
+        else { a_i[p] = id / KQ; a_k[p] = (id % KQ) * 4; a_st[p] = al.row_state(m_blk + a_i[p]); }
+    }
+#pragma unroll
+    for (int p = 0; p < B_IT; ++p) {
+        const int idx = tid + NT * p; b_v[p] = idx < B_N; const int id = b_v[p] ? idx : 0;
+        if constexpr (BL::kTN) { b_i[p] = (id % (BN / 4)) * 4; b_k[p] = (id / (BN / 4)) * 4; }
+        else { b_i[p] = id / KQ; b_k[p] = (id % KQ) * 4; b_st[p] = bl.row_state(n_blk + b_i[p]); }
+    }
+
+    float4 ra[A_IT][A_LDS], rb[B_IT][B_LDS];
+    bool oa[A_IT][A_LDS], ob[B_IT][B_LDS];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int p = 0; p < A_IT; ++p)
+#pragma unroll
+            for (int q = 0; q < A_LDS; ++q) {
+                Src s;
+                if constexpr (AL::kTN) s = al.src(kt + a_k[p] + q, m_blk + a_i[p]); else s = al.src(a_st[p], kt + a_k[p]);
+                if constexpr (AL::kCheck) { oa[p][q] = s.ok; ra[p][q] = *reinterpret_cast<const float4*>(s.ok ? s.p : al.dummy()); }
+                else { oa[p][q] = true; ra[p][q] = *reinterpret_cast<const float4*>(s.p); }
+            }
+#pragma unroll
+        for (int p = 0; p < B_IT; ++p)
+#pragma unroll
+            for (int q = 0; q < B_LDS; ++q) {
+                Src s;
+                if constexpr (BL::kTN) s = bl.src(kt + b_k[p] + q, n_blk + b_i[p]); else s = bl.src(b_st[p], kt + b_k[p]);
+                if constexpr (BL::kCheck) { ob[p][q] = s.ok; rb[p][q] = *reinterpret_cast<const float4*>(s.ok ? s.p : bl.dummy()); }
+                else { ob[p][q] = true; rb[p][q] = *reinterpret_cast<const float4*>(s.p); }
+            }
+    };
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto lstore = [&](int buf) {
+        unsigned short* as = As + buf * A_SZ;
+        unsigned short* bs = Bs + buf * B_SZ;
+#pragma unroll
+        for (int p = 0; p < A_IT; ++p) {
+            if (A_N % NT != 0 && !a_v[p]) continue;
+            if constexpr (AL::kTN) {
+                float4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = oa[p][q] ? al.post(ra[p][q]) : zero4;
+                const float m0[4] = {v[0].x, v[1].x, v[2].x, v[3].x}, m1[4] = {v[0].y, v[1].y, v[2].y, v[3].y};
+                const float m2[4] = {v[0].z, v[1].z, v[2].z, v[3].z}, m3[4] = {v[0].w, v[1].w, v[2].w, v[3].w};
+                *reinterpret_cast<uint2*>(as + (a_i[p] + 0) * LD + a_k[p]) = make_uint2(st_pack_bf16(m0[0], m0[1]), st_pack_bf16(m0[2], m0[3]));
+                *reinterpret_cast<uint2*>(as + (a_i[p] + 1) * LD + a_k[p]) = make_uint2(st_pack_bf16(m1[0], m1[1]), st_pack_bf16(m1[2], m1[3]));
+                *reinterpret_cast<uint2*>(as + (a_i[p] + 2) * LD + a_k[p]) = make_uint2(st_pack_bf16(m2[0], m2[1]), st_pack_bf16(m2[2], m2[3]));
+                *reinterpret_cast<uint2*>(as + (a_i[p] + 3) * LD + a_k[p]) = make_uint2(st_pack_bf16(m3[0], m3[1]), st_pack_bf16(m3[2], m3[3]));
+            } else {
+                const float4 v = oa[p][0] ? al.post(ra[p][0]) : zero4;
+                *reinterpret_cast<uint2*>(as + a_i[p] * LD + a_k[p]) = make_uint2(st_pack_bf16(v.x, v.y), st_pack_bf16(v.z, v.w));
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < B_IT; ++p) {
+            if (B_N % NT != 0 && !b_v[p]) continue;
+            if constexpr (BL::kTN) {
+                float4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = ob[p][q] ? bl.post(rb[p][q]) : zero4;
+                const float m0[4] = {v[0].x, v[1].x, v[2].x, v[3].x}, m1[4] = {v[0].y, v[1].y, v[2].y, v[3].y};
+                const float m2[4] = {v[0].z, v[1].z, v[2].z, v[3].z}, m3[4] = {v[0].w, v[1].w, v[2].w, v[3].w};
+                *reinterpret_cast<uint2*>(bs + (b_i[p] + 0) * LD + b_k[p]) = make_uint2(st_pack_bf16(m0[0], m0[1]), st_pack_bf16(m0[2], m0[3]));
+                *reinterpret_cast<uint2*>(bs + (b_i[p] + 1) * LD + b_k[p]) = make_uint2(st_pack_bf16(m1[0], m1[1]), st_pack_bf16(m1[2], m1[3]));
+                *reinterpret_cast<uint2*>(bs + (b_i[p] + 2) * LD + b_k[p]) = make_uint2(st_pack_bf16(m2[0], m2[1]), st_pack_bf16(m2[2], m2[3]));
+                *reinterpret_cast<uint2*>(bs + (b_i[p] + 3) * LD + b_k[p]) = make_uint2(st_pack_bf16(m3[0], m3[1]), st_pack_bf16(m3[2], m3[3]));
+            } else {
+                const float4 v = ob[p][0] ? bl.post(rb[p][0]) : zero4;
+                *reinterpret_cast<uint2*>(bs + b_i[p] * LD + b_k[p]) = make_uint2(st_pack_bf16(v.x, v.y), st_pack_bf16(v.z, v.w));
+            }
+        }
+    };
+
+    f32x16 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+    if (k_begin < k_end) {
+        gload(k_begin);
+        lstore(0);
+        __syncthreads();
+        int cur = 0;
+        const int h = lane >> 5, l31 = lane & 31;
+        const int a_off = (wave * 32 + l31) * LD + 8 * h;
+        const int b_off = l31 * LD + 8 * h;
+        for (int kt = k_begin; kt < k_end; kt += BKH) {
+            const bool more = kt + BKH < k_end;
+            if (more) gload(kt + BKH);
+            const unsigned short* as = As + cur * A_SZ + a_off;
+            const unsigned short* bs = Bs + cur * B_SZ + b_off;
+#pragma unroll
+            for (int ks = 0; ks < BKH / 16; ++ks) {
+                const st_bf16x8 a = *reinterpret_cast<const st_bf16x8*>(as + 16 * ks);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const st_bf16x8 b = *reinterpret_cast<const st_bf16x8*>(bs + 32 * j * LD + 16 * ks);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+                }
+            }
+            if (more) lstore(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    epi(m_blk + wave * 32, n_blk, acc);
+}
+
+template <int WAVES_M, class AL, class BL, class EPI>
+static inline void launch_bf16(const AL& al, const BL& bl, const EPI& epi, int M, int Nc, int K, int nsplit, hipStream_t s)
+{
+    constexpr int BM = 32 * WAVES_M;
+    int ksplit = K;
+    if (nsplit > 1) ksplit = st_round_up((K + nsplit - 1) / nsplit, 32);
+    dim3 grid((Nc + BN - 1) / BN, (M + BM - 1) / BM, nsplit > 1 ? nsplit : 1);
+    hipLaunchKernelGGL((gemm_bf16_kernel<WAVES_M, AL, BL, EPI>), grid, dim3(WAVES_M * 64), 0, s, al, bl, epi, K, ksplit);
+}
+
 template <int WAVES_M, int BKT, int MI = 1, class AL, class BL, class EPI>
 static inline void launch(const AL& al, const BL& bl, const EPI& epi, int M, int Nc, int K, int nsplit,
                           hipStream_t s, int dbg = 0)

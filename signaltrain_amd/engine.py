@@ -62,7 +62,12 @@ class ParamLayout:
 class StepEngine:
     """Holds device state for one model replica and drives the HIP step."""
 
-    def __init__(self, dims, device="cuda:0", max_batch=None):
+    def __init__(self, dims, device="cuda:0", max_batch=None, compute_dtype="f32"):
+        """compute_dtype: "f32" (default, the parity path) or "bf16" = bf16 operands / fp32 accumulation in the STFT GEMMs
+        (BASELINE configs[2], [3]); parameters, gradients, autoencoders, loss and Adam are fp32 either way."""
+        if compute_dtype not in ("f32", "bf16"):
+            raise ValueError("compute_dtype must be 'f32' or 'bf16'")
+        self.compute_dtype = compute_dtype
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -95,8 +100,9 @@ class StepEngine:
             raise RuntimeError(f"batch {B} exceeds the engine's workspace (max_batch={self.max_batch})")
         return self.dims if B == self.dims.B else self.dims.with_batch(B)
 
-    @staticmethod
-    def _stream():
+    def _stream(self):
+        # every entry point fetches the stream right before its C call: the (process-wide) precision switch rides along
+        self.lib.st_set_precision(1 if self.compute_dtype == "bf16" else 0)
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def _prep(self, x, knobs, y=None):

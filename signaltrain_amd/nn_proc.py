@@ -155,6 +155,14 @@ class AsymMPAEC(nn.Module):
         sd = dict(self.named_parameters(prefix="mpaec"))
         return [sd[k] for k in param_names()]
 
+    def set_compute_dtype(self, dtype):
+        """'f32' (default) or 'bf16' (bf16 operands / fp32 accumulation in the STFT GEMMs, StepEngine.compute_dtype)."""
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("compute dtype must be 'f32' or 'bf16'")
+        self.compute_dtype = dtype
+        if self._engine is not None:
+            self._engine.compute_dtype = dtype
+
     def _ensure_engine(self, x):
         """Flatten the 40 parameters into the engine's buffer (parameters become views of it)."""
         B = x.shape[0]
@@ -167,7 +175,8 @@ class AsymMPAEC(nn.Module):
         d.B, d.L, d.N, d.H, d.T, d.OT, d.F, d.K = B, x.shape[1], self.ft_size, self.hop_size, self.expected_time_frames, \
             self.output_tf, self.ft_size // 2 + 1, self.n_knobs
         d.y = (d.OT - 1) * d.H - d.N
-        new = StepEngine(d, x.device, max_batch=max(B, eng.max_batch if eng is not None else 0))
+        new = StepEngine(d, x.device, max_batch=max(B, eng.max_batch if eng is not None else 0),
+                         compute_dtype=getattr(self, "compute_dtype", "f32"))
         with torch.no_grad():
             for p, v in zip(ps, new.named.values()):
                 v.copy_(p.detach().to(x.device).reshape(v.shape))
@@ -227,6 +236,10 @@ class st_model(nn.Module):
 
     def clip_grad_norm_(self):
         self.mpaec.clip_grad_norm_()
+
+    def set_compute_dtype(self, dtype):
+        """Mixed precision of the accelerated path: 'f32' (default) | 'bf16' (see AsymMPAEC.set_compute_dtype)."""
+        self.mpaec.set_compute_dtype(dtype)
 
     def forward(self, x_cuda, knobs_cuda, return_acts=False):
         return self.mpaec.forward(x_cuda, knobs_cuda, return_acts=return_acts)

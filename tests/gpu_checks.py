@@ -64,7 +64,26 @@ def from_kp(a, F):
     return a[:, :F], a[:, KP // 2:KP // 2 + F]
 
 
+TOL_SCALE = 1.0          # multiplies every tolerance (mixed-precision runs: see bf16_mode)
+ENGINE_DTYPE = "f32"     # compute_dtype of the StepEngines the checks create
+
+
+class bf16_mode:
+    """Context: HIP library in bf16-operand mode + the oracle's matching bf16 rounding of the GEMM operands.  Tolerances are
+    widened 10x: both sides round the SAME quantities, but an operand that differs by 1e-6 between the two can land on
+    the other side of a bf16 rounding boundary (1 in ~4000 elements does, each then differs by 0.4 %)."""
+
+    def __enter__(self):
+        global TOL_SCALE, ENGINE_DTYPE
+        _lib.check(_lib.load().st_set_precision(1), "st_set_precision"); O.GEMM_ROUND = O.bf16_round; TOL_SCALE = 10.0; ENGINE_DTYPE = "bf16"
+
+    def __exit__(self, *a):
+        global TOL_SCALE, ENGINE_DTYPE
+        _lib.load().st_set_precision(0); O.GEMM_ROUND = None; TOL_SCALE = 1.0; ENGINE_DTYPE = "f32"
+
+
 def err(name, got, ref, tol=TOL, scale=None):
+    tol = tol * TOL_SCALE
     got = np.asarray(got, np.float64); ref = np.asarray(ref, np.float64)
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     sc = float(np.max(np.abs(ref))) if scale is None else float(scale)
@@ -78,6 +97,7 @@ def err(name, got, ref, tol=TOL, scale=None):
 
 
 def phase_err(name, got, ref, mag, tol=TOL):
+    tol = tol * TOL_SCALE
     """Phase compared modulo 2*pi and weighted by mag/max(mag): atan2 is ill-conditioned where mag ~ 0
     and discontinuous at +-pi (SURVEY.md section 7 'hard parts')."""
     dphi = np.angle(np.exp(1j * (np.asarray(got, np.float64) - ref)))
@@ -148,7 +168,7 @@ def run_all(B=3, seed=0, K=4, verbose=False, scale=1, scheme="lean"):
     nsl = lib.st_synth_slabs(C.byref(d))
     frs = z(lib.st_synth_frame_slabs(C.byref(d)), B * OT, N)
     _lib.check(lib.st_synthesis_frames(C.byref(d), _lib.ptr(AAo), _lib.ptr(Sfold), _lib.ptr(frs), stream()), "synth")
-    frs_ref = c["Are"].reshape(-1, F) @ fr_ + c["Aim"].reshape(-1, F) @ fi_
+    frs_ref = O._r(c["Are"].reshape(-1, F)) @ O._r(fr_) + O._r(c["Aim"].reshape(-1, F)) @ O._r(fi_)     # O._r: identity unless bf16_mode
     # only frames that reach the cropped output are computed (t with 0 < H t and H t - N < y)
     live = np.array([(geo["H"] * tt > 0) and (geo["H"] * tt - N < geo["y"]) for tt in range(OT)])
     res.append(err("synthesis.frames", n(frs).sum(0).reshape(B, OT, N)[:, live], frs_ref.reshape(B, OT, N)[:, live]))
@@ -227,7 +247,7 @@ def run_fused(B=3, seed=1, K=4, steps=3, scale=1, scheme="lean"):
     """Fused entry points: st_model_fwd, st_loss_backward, st_train_step x steps vs the oracle."""
     geo, X, Y, KN, P = make_case(B, seed, K=K, scale=scale, scheme=scheme)
     d = dims_of(geo, B, K)
-    eng = StepEngine(d, DEV)
+    eng = StepEngine(d, DEV, compute_dtype=ENGINE_DTYPE)
     eng.load_state_dict(P)
     res = []
     P64 = {k: v.astype(np.float64) for k, v in P.items()}
@@ -246,7 +266,7 @@ def run_fused(B=3, seed=1, K=4, steps=3, scale=1, scheme="lean"):
     l1 = sum(np.abs(G[k]).sum() for k in STFT_KEYS)
     res.append(err("step.l1norm", sc[3], l1, tol=1e-3))
     # training steps (train.py:131-151 ordering) vs oracle in float32 arithmetic
-    eng2 = StepEngine(d, DEV); eng2.load_state_dict(P)
+    eng2 = StepEngine(d, DEV, compute_dtype=ENGINE_DTYPE); eng2.load_state_dict(P)
     Pq = {k: P[k].copy() for k in O.param_order()}
     Mq = {k: np.zeros_like(v) for k, v in Pq.items()}; Vq = {k: np.zeros_like(v) for k, v in Pq.items()}
     lrs, _ = O.get_1cycle_schedule(lr_max=1e-3, n_data_points=200, epochs=1, batch_size=2)

@@ -101,3 +101,30 @@ def test_full_size_batch_properties():
     for name, v in full.layout.views(g_full).items():
         r = full.layout.views(g_ref)[name]
         assert (v - r).abs().max().item() <= 2e-5 * max(r.abs().max().item(), 1e-12), name
+
+
+@pytest.mark.parametrize("B,seed,K", [(3, 0, 4), (5, 2, 3)])
+def test_bf16_mode_per_op(B, seed, K):
+    """st_set_precision(1): bf16 operands / fp32 accumulation in the STFT GEMMs (BASELINE configs[2], [3]) against the
+    oracle with the SAME operands rounded to bfloat16 (oracle.GEMM_ROUND): per-op agreement stays at the 1e-6 level
+    because both sides round identical inputs."""
+    from tests import gpu_checks as G
+    with G.bf16_mode():
+        _assert_ok(G.run_all(B=B, seed=seed, K=K))
+
+
+def test_bf16_mode_fused_step_and_differs_from_fp32():
+    import torch
+    from tests import gpu_checks as G
+    from signaltrain_amd.engine import StepEngine
+    with G.bf16_mode():
+        _assert_ok(G.run_fused(B=3, seed=1, K=4, steps=3))
+    geo, X, Y, KN, P = G.make_case(3, 0, K=4)
+    d = G.dims_of(geo, 3, 4)
+    e32 = StepEngine(d, G.DEV); e32.load_state_dict(P)
+    e16 = StepEngine(d, G.DEV, compute_dtype="bf16"); e16.load_state_dict(P)
+    y32 = e32.forward(G.t(X), G.t(KN))[0]; y16 = e16.forward(G.t(X), G.t(KN))[0]
+    y32b = e32.forward(G.t(X), G.t(KN))[0]
+    rel = float((y32 - y16).abs().max() / y32.abs().max())
+    assert 1e-5 < rel < 2e-2, rel                                  # really bf16 arithmetic, and sane
+    assert torch.equal(y32, y32b)                                  # the fp32 engine is unaffected by the other engine's mode
