@@ -148,3 +148,32 @@ def test_no_cross_block_mfma_result_hazards():
     import subprocess, sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_mfma_hazards.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
+
+
+def test_hazard_scanner_flags_the_known_bad_pattern():
+    """Self-test of tools/check_mfma_hazards.py on hand-written ISA: an accumulator read behind a conditional branch 3
+    instructions after the MFMA (the round-1 bug) must be flagged; the same read behind an s_nop 9 in one block, or a
+    dependent MFMA, must not."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("chk", os.path.join(ROOT, "tools", "check_mfma_hazards.py"))
+    chk = importlib.util.module_from_spec(spec); spec.loader.exec_module(chk)
+    bad = """
+	v_mfma_f32_16x16x4_f32 a[0:3], v9, v159, a[0:3]
+	s_and_saveexec_b64 s[2:3], s[68:69]
+	s_cbranch_execz .LBB0_2
+	s_memtime s[34:35]
+.LBB0_2:
+	s_or_b64 exec, exec, s[2:3]
+	v_accvgpr_read_b32 v9, a3
+""".splitlines()
+    good = """
+	v_mfma_f32_16x16x4_f32 a[0:3], v8, v131, a[0:3]
+	v_mfma_f32_16x16x4_f32 a[0:3], v9, v159, a[0:3]
+	s_nop 9
+	v_accvgpr_read_b32 v9, a3
+	s_cbranch_execz .LBB0_2
+.LBB0_2:
+	v_add_f32_e32 v1, v9, v9
+""".splitlines()
+    assert len(chk.scan_kernel("bad", bad)) == 1
+    assert chk.scan_kernel("good", good) == []
