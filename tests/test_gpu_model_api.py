@@ -306,3 +306,37 @@ def test_training_trajectory_matches_cpu_port():
         ref = port.P[k].detach().numpy().reshape(v.shape)
         worst = max(worst, float(np.abs(v.cpu().numpy() - ref).max()))
     assert worst <= 2e-4, worst                                            # 25 Adam steps of <= 2e-4 each: no drift beyond noise-level sign flips
+
+
+def test_autograd_all_three_outputs(golden_dir):
+    """loss = <y_hat, p1> + <mag, p2> + <mag_hat, p3> through st_model's autograd Function (exercises the upstream
+    gradients of ALL outputs: g_y_hat, g_mag -> st_polar_bwd, g_mag_hat -> st_ae_bwd) vs float64 torch-CPU autograd of
+    the reference op sequence (oracle/torch_cpu_step.forward)."""
+    from oracle import torch_cpu_step as TC
+    m, g, P, geo = _golden_model(golden_dir)
+    rng = np.random.default_rng(12)
+    B = 3
+    x = (0.3 * rng.standard_normal((B, geo["L"]))).astype(np.float32)
+    kn = (rng.random((B, 4)) - 0.5).astype(np.float32)
+    p1 = rng.standard_normal((B, geo["y"])).astype(np.float32)
+    p2 = (0.1 * rng.standard_normal((B, geo["T"], geo["F"]))).astype(np.float32)
+    p3 = (0.1 * rng.standard_normal((B, geo["OT"], geo["F"]))).astype(np.float32)
+    P64 = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in P.items()}
+    y, mg, mh = TC.forward(P64, torch.tensor(x, dtype=torch.float64), torch.tensor(kn, dtype=torch.float64))
+    ((y * torch.tensor(p1, dtype=torch.float64)).sum() + (mg * torch.tensor(p2, dtype=torch.float64)).sum()
+     + (mh * torch.tensor(p3, dtype=torch.float64)).sum()).backward()
+    m.zero_grad()
+    yg, mgg, mhg = m.forward(torch.from_numpy(x).cuda(), torch.from_numpy(kn).cuda())
+    ((yg * torch.from_numpy(p1).cuda()).sum() + (mgg * torch.from_numpy(p2).cuda()).sum() + (mhg * torch.from_numpy(p3).cuda()).sum()).backward()
+    sd = dict(m.named_parameters())
+    worst = ("", 0.0)
+    for k, ref in P64.items():
+        got = sd[k].grad.detach().cpu().numpy().reshape(ref.shape)
+        r = ref.grad.numpy()
+        scale = np.abs(r).max()
+        if "dft_" in k:                                            # rows >= F of the analysis tensors: exact zeros on both sides
+            scale = max(scale, 1e-30)
+        e = np.abs(got - r).max() / max(scale, 1e-30)
+        if e > worst[1]:
+            worst = (k, e)
+        assert e <= 2e-4, (k, e)
