@@ -517,6 +517,22 @@ __device__ __forceinline__ void dgrad_fr(const float (&fr)[OTL * ITL * 4], const
         dh[it] = acc; dhT[it] = accT;
     }
 }
+// D layout -> T layout of TL 16x16 tiles through a wave-private LDS scratch ([tile][row 16][feature 16, pitch 20]): one
+// ds_write_b128 + four ds_read_b32 per tile, no barrier (LDS operations of one wave execute in order).  The transposed
+// operands of the weight gradients used to be RE-COMPUTED with the second MFMA orientation (280 MFMAs + their ELU /
+// ELU' per group): in a kernel that is issue-bound, not MFMA-bound, the transpose is far cheaper.
+template <int TL>
+__device__ __forceinline__ void to_T(float* scr, const f32x4 (&d)[TL], f32x4 (&t)[TL], const int g, const int c)
+{
+#pragma unroll
+    for (int k = 0; k < TL; ++k)
+        *reinterpret_cast<float4*>(scr + k * 320 + c * 20 + 4 * g) = make_float4(d[k][0], d[k][1], d[k][2], d[k][3]);
+#pragma unroll
+    for (int k = 0; k < TL; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[k][r] = scr[k * 320 + (4 * g + r) * 20 + c];
+}
+
 template <int OTL, int ITL>
 __device__ __forceinline__ void dgradD_fr(const float (&fr)[OTL * ITL * 4], const f32x4 (&da)[OTL], f32x4 (&dh)[ITL])
 {
@@ -713,10 +729,12 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     float* lw = lds;                                   // weights (+bias), padded
     float* dwl = lds + CL::TOTAL;                      // gradient accumulator, same layout
     // wave-private scratch: V[32*SP] (input rows, transposed), Y[16*SP] (d a9 transposed), TAIL[16*SP]
-    constexpr int SCR = (32 + 16 + 16) * SP;
+    constexpr int SCR = (32 + 16 + 16) * SP + 2 * 4 * 320;      // + two 4-tile transpose scratches (to_T)
     float* Vs = lds + 2 * CL::TOTAL + wave * SCR;
     float* Ys = Vs + 32 * SP;
     float* Ts = Ys + 16 * SP;
+    float* XH = Ts + 16 * SP;                          // transposes of activations
+    float* XD = XH + 4 * 320;                          // transposes of activation gradients
     for (int e = tid; e < CL::TOTAL; e += NW * 64) dwl[e] = 0.f;
     ae_load_lds(lw, L, ae ? ae_p : ae_m, go, tid, NW * 64, INNER ? 1 : 0, INNER ? 8 : NL);
     __syncthreads();
@@ -803,7 +821,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         // INNER: layer-1 outputs in both layouts and the gradient entering layer 8's output, straight from the
         // feature-major buffers (D layout: feature 16 tile + 4g + r at column col0 + c; T layout: feature 16 tile + c at
         // columns col0 + 4g .. + 3 = one aligned float4)
-        f32x4 h1in[4], hT1in[4], dh8[4], dhT8[4];
+        f32x4 h1in[4], dh8[4];
         if constexpr (INNER) {
             const unsigned col0 = (unsigned)b * FP + (unsigned)(grp - b * gpw) * 16;
 #pragma unroll
@@ -813,9 +831,6 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
                     h1in[ot][r] = vin[(unsigned)(16 * ot + 4 * g + r) * Rw + col0 + c];
                     dh8[ot][r] = dh8in[(unsigned)(16 * ot + 4 * g + r) * Rw + col0 + c];
                 }
-                const float4 a = *reinterpret_cast<const float4*>(vin + (size_t)(16 * ot + c) * Rw + col0 + 4 * g);
-                const float4 d = *reinterpret_cast<const float4*>(dh8in + (size_t)(16 * ot + c) * Rw + col0 + 4 * g);
-                hT1in[ot] = (f32x4){a.x, a.y, a.z, a.w}; dhT8[ot] = (f32x4){d.x, d.y, d.z, d.w};
             }
         }
         // knob values: D-layout feature tile (16 + 4g + r) and T-layout feature lane (16 + c)
@@ -922,124 +937,97 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         // layer 9 (64 -> OT): needs h8^T (layer-8 forward fragments) and W9 in dgrad order
         f32x4 hT8[4], da8[4], daT8[4];
         if constexpr (INNER) {                     // dH8 arrives from the layer-9 data-gradient GEMM; h8^T is still needed for ELU' and dW8
-            float ff[4 * 2 * 4];
-            frags_fwd<4, 2>(ff, Wl[7], CL::P7, g, c); ST_FENCE();
-            fwdT_fr<4, 2>(ff, Bl[7], h7, hT8, c);
+            to_T<4>(XH, h8, hT8, g, c);
 #pragma unroll
-            for (int ot = 0; ot < 4; ++ot) { da8[ot] = dh8[ot]; daT8[ot] = dhT8[ot]; }
-            mul_elu_grad<4>(da8, h8); mul_elu_grad<4>(daT8, hT8);
+            for (int ot = 0; ot < 4; ++ot) da8[ot] = dh8[ot];
+            mul_elu_grad<4>(da8, h8); to_T<4>(XD, da8, daT8, g, c);
         } else {
-            float ff[4 * 2 * 4], fd[1 * 4 * 4];
-            frags_fwd<4, 2>(ff, Wl[7], CL::P7, g, c); frags_dgrad<1, 4>(fd, Wl[8], CL::P8, g, c); ST_FENCE();
-            fwdT_fr<4, 2>(ff, Bl[7], h7, hT8, c);
+            float fd[1 * 4 * 4];
+            frags_dgrad<1, 4>(fd, Wl[8], CL::P8, g, c); ST_FENCE();
+            to_T<4>(XH, h8, hT8, g, c);
             ST_WG(1, 4, Dl[8], CL::P8, rW9, rb9, db9, daT9, hT8)
-            dgrad_fr<1, 4>(fd, da9, da8, daT8); mul_elu_grad<4>(da8, h8); mul_elu_grad<4>(daT8, hT8);
+            dgradD_fr<1, 4>(fd, da9, da8); mul_elu_grad<4>(da8, h8); to_T<4>(XD, da8, daT8, g, c);
         }
         ST_T(8);
         // layer 8 (32 -> 64)
         f32x4 hT7[2], da7[2], daT7[2];
         {
-            float ff[2 * 1 * 4], fd[4 * 2 * 4];
-            frags_fwd<2, 1>(ff, Wl[6], CL::P6, g, c); frags_dgrad<4, 2>(fd, Wl[7], CL::P7, g, c); ST_FENCE();
-            fwdT_fr<2, 1>(ff, Bl[6], h6, hT7, c);
+            float fd[4 * 2 * 4];
+            frags_dgrad<4, 2>(fd, Wl[7], CL::P7, g, c); ST_FENCE();
+            to_T<2>(XH, h7, hT7, g, c);
             ST_WG(4, 2, Dl[7], CL::P7, rW8, rb8, db8, daT8, hT7)
-            dgrad_fr<4, 2>(fd, da8, da7, daT7); mul_elu_grad<2>(da7, h7); mul_elu_grad<2>(daT7, hT7);
+            dgradD_fr<4, 2>(fd, da8, da7); mul_elu_grad<2>(da7, h7); to_T<2>(XD, da7, daT7, g, c);
         }
         ST_T(9);
         // layer 7 (16 -> 32)
         f32x4 hT6[1], da6[1], daT6[1];
         {
-            float ff[1 * 1 * 4], fd[2 * 1 * 4];
-            frags_fwd<1, 1>(ff, Wl[5], CL::P5, g, c); frags_dgrad<2, 1>(fd, Wl[6], CL::P6, g, c); ST_FENCE();
-            fwdT_fr<1, 1>(ff, Bl[5], h5, hT6, c);
+            float fd[2 * 1 * 4];
+            frags_dgrad<2, 1>(fd, Wl[6], CL::P6, g, c); ST_FENCE();
+            to_T<1>(XH, h6, hT6, g, c);
             ST_WG(2, 1, Dl[6], CL::P6, rW7, rb7, db7, daT7, hT6)
-            dgrad_fr<2, 1>(fd, da7, da6, daT6); mul_elu_grad<1>(da6, h6); mul_elu_grad<1>(daT6, hT6);
+            dgradD_fr<2, 1>(fd, da7, da6); mul_elu_grad<1>(da6, h6); to_T<1>(XD, da6, daT6, g, c);
         }
         ST_T(10);
-        // layer 6 (16 -> 16); h5^T needs the knob k-steps of layer 5
+        // layer 6 (16 -> 16)
         f32x4 hT5[1], da5[1], daT5[1];
         {
-            float fa[4], fb[4], fd[1 * 1 * 4];
-            const int P5 = CL::P4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { fa[r] = Wl[4][c * P5 + 4 * g + r]; fb[r] = Wl[4][c * P5 + 16 + 4 * g + r]; }
+            float fd[1 * 1 * 4];
             frags_dgrad<1, 1>(fd, Wl[5], CL::P5, g, c); ST_FENCE();
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc = ST_MFMA16(h4[0][r], fa[r], acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc = ST_MFMA16(kn[0][r], fb[r], acc);
-            const float bv = Bl[4][c];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hT5[0][r] = elu_f(acc[r] + bv);
+            to_T<1>(XH, h5, hT5, g, c);
             ST_WG(1, 1, Dl[5], CL::P5, rW6, rb6, db6, daT6, hT5)
-            dgrad_fr<1, 1>(fd, da6, da5, daT5); mul_elu_grad<1>(da5, h5); mul_elu_grad<1>(daT5, hT5);
+            dgradD_fr<1, 1>(fd, da6, da5); mul_elu_grad<1>(da5, h5); to_T<1>(XD, da5, daT5, g, c);
         }
         // layer 5 ([h4 ; knobs] -> 16): weight gradient over both input tiles, data gradient to h4 only
         f32x4 hT4[1], hT4k[2], da4[1], daT4[1];
         {
-            float ff[1 * 1 * 4], fd[1 * 1 * 4];
-            frags_fwd<1, 1>(ff, Wl[3], CL::P3, g, c); frags_dgrad<1, 1>(fd, Wl[4], CL::P4, g, c); ST_FENCE();
-            fwdT_fr<1, 1>(ff, Bl[3], h3, hT4, c);
+            float fd[1 * 1 * 4];
+            frags_dgrad<1, 1>(fd, Wl[4], CL::P4, g, c); ST_FENCE();
+            to_T<1>(XH, h4, hT4, g, c);
             hT4k[0] = hT4[0];
             hT4k[1] = (f32x4){knT, knT, knT, knT};                   // features 16 + c = knob c, every row
             ST_WG(1, 2, Dl[4], CL::P4, rW5, rb5, db5, daT5, hT4k)
-            dgrad_fr<1, 1>(fd, da5, da4, daT4); mul_elu_grad<1>(da4, h4); mul_elu_grad<1>(daT4, hT4);
+            dgradD_fr<1, 1>(fd, da5, da4); mul_elu_grad<1>(da4, h4); to_T<1>(XD, da4, daT4, g, c);
         }
         // layer 4 (16 -> 16)
         f32x4 hT3[1], da3[1], daT3[1];
         {
-            float ff[1 * 2 * 4], fd[1 * 1 * 4];
-            frags_fwd<1, 2>(ff, Wl[2], CL::P2, g, c); frags_dgrad<1, 1>(fd, Wl[3], CL::P3, g, c); ST_FENCE();
-            fwdT_fr<1, 2>(ff, Bl[2], h2, hT3, c);
+            float fd[1 * 1 * 4];
+            frags_dgrad<1, 1>(fd, Wl[3], CL::P3, g, c); ST_FENCE();
+            to_T<1>(XH, h3, hT3, g, c);
             ST_WG(1, 1, Dl[3], CL::P3, rW4, rb4, db4, daT4, hT3)
-            dgrad_fr<1, 1>(fd, da4, da3, daT3); mul_elu_grad<1>(da3, h3); mul_elu_grad<1>(daT3, hT3);
+            dgradD_fr<1, 1>(fd, da4, da3); mul_elu_grad<1>(da3, h3); to_T<1>(XD, da3, daT3, g, c);
         }
         ST_T(11);
         // layer 3 (32 -> 16)
         f32x4 hT2[2], da2[2], daT2[2];
         {
-            float ff[2 * 4 * 4], fd[1 * 2 * 4];
-            frags_fwd<2, 4>(ff, Wl[1], CL::P1, g, c); frags_dgrad<1, 2>(fd, Wl[2], CL::P2, g, c); ST_FENCE();
-            fwdT_fr<2, 4>(ff, Bl[1], h1, hT2, c);
+            float fd[1 * 2 * 4];
+            frags_dgrad<1, 2>(fd, Wl[2], CL::P2, g, c); ST_FENCE();
+            to_T<2>(XH, h2, hT2, g, c);
             ST_WG(1, 2, Dl[2], CL::P2, rW3, rb3, db3, daT3, hT2)
-            dgrad_fr<1, 2>(fd, da3, da2, daT2); mul_elu_grad<2>(da2, h2); mul_elu_grad<2>(daT2, hT2);
+            dgradD_fr<1, 2>(fd, da3, da2); mul_elu_grad<2>(da2, h2); to_T<2>(XD, da2, daT2, g, c);
         }
         ST_T(12);
         // layer 2 (64 -> 32); h1^T from the input rows
         f32x4 hT1[4], da1[4], daT1[4];
-        if constexpr (INNER) {                     // h1^T comes from memory; dA1 goes back to memory for the layer-1 GEMMs
+        if constexpr (INNER) {                     // dA1 goes back to memory for the layer-1 GEMMs
             float fd[2 * 4 * 4];
             frags_dgrad<2, 4>(fd, Wl[1], CL::P1, g, c); ST_FENCE();
-#pragma unroll
-            for (int ot = 0; ot < 4; ++ot) hT1[ot] = hT1in[ot];
+            to_T<4>(XH, h1, hT1, g, c);
             ST_WG(2, 4, Dl[1], CL::P1, rW2, rb2, db2, daT2, hT1)
-            dgrad_fr<2, 4>(fd, da2, da1, daT1); mul_elu_grad<4>(da1, h1);
+            dgradD_fr<2, 4>(fd, da2, da1); mul_elu_grad<4>(da1, h1);
             const unsigned col0 = (unsigned)b * FP + (unsigned)(grp - b * gpw) * 16;
 #pragma unroll
             for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dvout[(unsigned)(16 * ot + 4 * g + r) * Rw + col0 + c] = da1[ot][r];
         } else {
-            float ff[4 * 8], fd[2 * 4 * 4];
-            const int P1 = CL::P0;
-#pragma unroll
-            for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) ff[ot * 8 + ks] = Wl[0][(16 * ot + c) * P1 + 4 * ks + g];
+            float fd[2 * 4 * 4];
             frags_dgrad<2, 4>(fd, Wl[1], CL::P1, g, c); ST_FENCE();
-#pragma unroll
-            for (int ot = 0; ot < 4; ++ot) {
-                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks)
-                    if (ks < KS1) acc = ST_MFMA16(vr[ks], ff[ot * 8 + ks], acc);
-                const float bv = Bl[0][16 * ot + c];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) hT1[ot][r] = elu_f(acc[r] + bv);
-            }
+            to_T<4>(XH, h1, hT1, g, c);
             ST_WG(2, 4, Dl[1], CL::P1, rW2, rb2, db2, daT2, hT1)
-            dgrad_fr<2, 4>(fd, da2, da1, daT1); mul_elu_grad<4>(da1, h1); mul_elu_grad<4>(daT1, hT1);
+            dgradD_fr<2, 4>(fd, da2, da1); mul_elu_grad<4>(da1, h1); to_T<4>(XD, da1, daT1, g, c);
         }
         ST_T(13);
         // layer 1 (T -> 64): input rows transposed through the wave's scratch
@@ -1057,13 +1045,21 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         ST_T(14);
         // ------------------------------------------------------------------ d input rows (+ skip / residual tails)
         if constexpr (!INNER) {
+        // Materialise the accumulators in VGPRs HERE, in the block of the MFMAs that produce them: the stores below sit in
+        // conditional blocks, and an accumulator first read behind a skipped block would be read before the MFMA has
+        // finished (the hazard class tools/check_mfma_hazards.py scans for).
+        float dvs[2][4];
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { dvs[it][r] = dv[it][r]; asm volatile("" : "+v"(dvs[it][r])); }
 #pragma unroll
         for (int it = 0; it < 2; ++it)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int t = 16 * it + 4 * g + r;
                 if (fv && t < T) {
-                    float v = dv[it][r];
+                    float v = dvs[it][r];
                     if (t >= T - OT) v += Ts[(t - (T - OT)) * SP + c];
                     dvout[((unsigned)b * T + t) * F + f] = v;
                 }

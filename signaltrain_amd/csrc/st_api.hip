@@ -538,7 +538,7 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
         for (int a = 0; a < 2; ++a) { wide_wgrad(d, w, a, 8, out, in, s); dgrad(a, 8, true); }
         {
             const sta::AELds ll = sta::ae_lds_layout(32, 16, d->K);
-            const size_t lds = ((size_t)2 * ll.total + (size_t)AE_BWD_NW * (32 + 16 + 16) * sta::SP) * sizeof(float);
+            const size_t lds = ((size_t)2 * ll.total + (size_t)AE_BWD_NW * ((32 + 16 + 16) * sta::SP + 2 * 4 * 320)) * sizeof(float);
             static bool attr = false;
             if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
             const int grid = ae_bwd_grid(d);
@@ -578,7 +578,7 @@ static int ae_bwd_impl(const st_dims* d, const float* mag, const float* phs, con
         return ae_wide_bwd(d, L, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, dmag, dphs, w, g_m, g_p, have_fwd, stream);
     }
     const sta::AELds ll = sta::ae_lds_layout(d->T, d->OT, d->K);
-    const size_t lds = ((size_t)2 * ll.total + (size_t)AE_BWD_NW * (32 + 16 + 16) * sta::SP) * sizeof(float);
+    const size_t lds = ((size_t)2 * ll.total + (size_t)AE_BWD_NW * ((32 + 16 + 16) * sta::SP + 2 * 4 * 320)) * sizeof(float);
     ST_REQ(lds <= 160 * 1024, "st_ae_bwd: needs %zu B of LDS", lds);
     ST_REQ((size_t)st_synth_slabs(d) * d->B * d->OT * L.KP < ((size_t)1 << 31) && (size_t)d->B * d->T * L.KP < ((size_t)1 << 31),
            "st_ae_bwd: batch too large for the kernel's 32-bit element offsets (B=%d)", d->B);
