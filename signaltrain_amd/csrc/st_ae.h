@@ -301,7 +301,7 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
                         const float pt = FAST ? cur.tl[1][r] : src[1][ti];
                         mh = e9[0][0][r] * mt;                         // 'sf' skip-filter
                         ph = e9[1][0][r] + pt;                         // phase residual
-                        sincosf(ph, &sn, &cs);
+                        st_sincos(ph, sn, cs);
                         mag_hat[ro * F + f] = mh;
                         phs_hat[ro * F + f] = ph;
                         reg += fabsf(mh * wf);
@@ -910,7 +910,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
                 float d9 = 0.f, tail = 0.f;
                 if (fv && to < OT) {
                     const float gre = q_gre[r], gim = q_gim[r], ph = q_ph[r], mh = q_mh[r];
-                    float sn, cs; sincosf(ph, &sn, &cs);
+                    float sn, cs; st_sincos(ph, sn, cs);
                     if (ae == 0) {
                         const float sg = mh > 0.f ? 1.f : (mh < 0.f ? -1.f : 0.f);
                         const float dmh = gre * cs + gim * sn + reg_coef * sg * wf + q_gm[r];

@@ -41,6 +41,11 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return t;
 }
 
+// sin / cos of a phase on the hardware path (v_sin_f32 / v_cos_f32 after a multiply by 1/2pi): absolute error ~1e-6 for
+// the |phase| < ~100 rad the model produces, against a 1e-4 parity tolerance; the full-precision sincosf costs ~10x the
+// instructions and sits on the critical path of the issue-bound autoencoder kernels.
+__device__ __forceinline__ void st_sincos(float x, float& sn, float& cs) { sn = __sinf(x); cs = __cosf(x); }
+
 __device__ __forceinline__ float elu_f(float a) { return a > 0.f ? a : (__expf(a) - 1.0f); }
 // ELU'(a) through h = ELU(a):  1 if h > 0 else h + 1 (= exp(a)).
 __device__ __forceinline__ float elu_grad_from_out(float h) { return h > 0.f ? 1.0f : h + 1.0f; }
