@@ -255,18 +255,27 @@ struct PolarStore {
 // MI = 32-row blocks per wave: MI = 1 is the 32 x 96 wave strip; WAVES_M = 1, MI = 3 lets ONE wave own a 96 x 96 tile
 // (9 accumulators): same global traffic per MFMA as three waves sharing the tile, half the LDS fragment reads (B is read
 // once instead of three times) and no cross-wave barrier stalls -- for the split-K weight-gradient GEMMs.
-template <int WAVES_M, int BKT, int MI, class AL, class BL, class EPI>
+// XT: M/N-contiguous (TN-type) operands are transposed on the way into LDS -- a thread loads a 4(k) x 4(m)
+// micro-tile as four float4 and writes four k-quads -- so BOTH operands sit row-major [row][BK+4] and every MFMA fragment
+// is fetched with ds_read_b128 (4 k per instruction).  MEASURED SLOWER in fp32 (analysis wgrad 179 -> 281 us): the four
+// row writes of a micro-tile are 80 floats apart and pile onto two LDS bank groups; the k-major staging (XT = false,
+// the default) stays.  The bf16 kernel needs K-contiguous operands and uses the transposed staging (half the data).
+template <int WAVES_M, int BKT, int MI, bool XT, class AL, class BL, class EPI>
 __global__ void __launch_bounds__(WAVES_M * 64)
 gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int ksplit, const int dbg)
 {
     constexpr int BM = 32 * WAVES_M * MI, NT = 64 * WAVES_M;
-    constexpr int PKT = BKT + 4;                         // NT row pitch: 36 (BK 32) / 20 (BK 16) floats, both conflict-free for b128
-    constexpr int LDA = AL::kTN ? BM + 4 : PKT;         // TN: k-major [BK][BM+4] ; NT: row-major [BM][PKT]
-    constexpr int LDB = BL::kTN ? BN + 4 : PKT;
-    constexpr int A_SZ = AL::kTN ? BKT * LDA : BM * LDA;
-    constexpr int B_SZ = BL::kTN ? BKT * LDB : BN * LDB;
+    constexpr int PKT = BKT + 4;                         // row pitch: 36 (BK 32) / 20 (BK 16) floats, both conflict-free for b128
+    constexpr bool A_T = AL::kTN && XT, A_K = AL::kTN && !XT;       // transposed staging / k-major staging
+    constexpr bool B_T = BL::kTN && XT, B_K = BL::kTN && !XT;
+    constexpr int LDA = A_K ? BM + 4 : PKT;             // k-major [BK][BM+4] ; row-major [BM][PKT]
+    constexpr int LDB = B_K ? BN + 4 : PKT;
+    constexpr int A_SZ = A_K ? BKT * LDA : BM * LDA;
+    constexpr int B_SZ = B_K ? BKT * LDB : BN * LDB;
     constexpr int KQ = BKT / 4;                          // float4 per row per k-tile
-    constexpr int A_N = BM * KQ, B_N = BN * KQ;          // float4 items per k-tile
+    constexpr int A_N = A_T ? (BM / 4) * KQ : BM * KQ;   // items per k-tile: float4s, or 4x4 micro-tiles (4 float4 loads each)
+    constexpr int B_N = B_T ? (BN / 4) * KQ : BN * KQ;
+    constexpr int A_LD = A_T ? 4 : 1, B_LD = B_T ? 4 : 1;
     constexpr int A_IT = (A_N + NT - 1) / NT, B_IT = (B_N + NT - 1) / NT;
     constexpr int HK = BKT / 2;                          // k per lane-half: lane (m, h) covers k = HK*h .. HK*h + HK-1
     __shared__ __attribute__((aligned(16))) float As[2 * A_SZ];
@@ -286,7 +295,8 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
         const int idx = tid + NT * p;
         a_v[p] = idx < A_N;
         const int id = a_v[p] ? idx : 0;
-        if constexpr (AL::kTN) { a_i[p] = (id % (BM / 4)) * 4; a_k[p] = id / (BM / 4); a_l[p] = a_k[p] * LDA + a_i[p]; }
+        if constexpr (A_T) { a_i[p] = (id % (BM / 4)) * 4; a_k[p] = (id / (BM / 4)) * 4; a_l[p] = a_i[p] * LDA + a_k[p]; }
+        else if constexpr (A_K) { a_i[p] = (id % (BM / 4)) * 4; a_k[p] = id / (BM / 4); a_l[p] = a_k[p] * LDA + a_i[p]; }
         else { a_i[p] = id / KQ; a_k[p] = (id % KQ) * 4; a_l[p] = a_i[p] * LDA + a_k[p]; a_st[p] = al.row_state(m_blk + a_i[p]); }
     }
 #pragma unroll
@@ -294,38 +304,67 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
         const int idx = tid + NT * p;
         b_v[p] = idx < B_N;
         const int id = b_v[p] ? idx : 0;
-        if constexpr (BL::kTN) { b_i[p] = (id % (BN / 4)) * 4; b_k[p] = id / (BN / 4); b_l[p] = b_k[p] * LDB + b_i[p]; }
+        if constexpr (B_T) { b_i[p] = (id % (BN / 4)) * 4; b_k[p] = (id / (BN / 4)) * 4; b_l[p] = b_i[p] * LDB + b_k[p]; }
+        else if constexpr (B_K) { b_i[p] = (id % (BN / 4)) * 4; b_k[p] = id / (BN / 4); b_l[p] = b_k[p] * LDB + b_i[p]; }
         else { b_i[p] = id / KQ; b_k[p] = (id % KQ) * 4; b_l[p] = b_i[p] * LDB + b_k[p]; b_st[p] = bl.row_state(n_blk + b_i[p]); }
     }
 
-    float4 ra[A_IT], rb[B_IT];
-    bool oa[A_IT], ob[B_IT];
+    float4 ra[A_IT][A_LD], rb[B_IT][B_LD];
+    bool oa[A_IT][A_LD], ob[B_IT][B_LD];
     auto gload = [&](int kt) {
 #pragma unroll
-        for (int p = 0; p < A_IT; ++p) {
-            Src s;
-            if constexpr (AL::kTN) s = al.src(kt + a_k[p], m_blk + a_i[p]); else s = al.src(a_st[p], kt + a_k[p]);
-            if constexpr (AL::kCheck) { oa[p] = s.ok; ra[p] = *reinterpret_cast<const float4*>(s.ok ? s.p : al.dummy()); }
-            else ra[p] = *reinterpret_cast<const float4*>(s.p);
-        }
+        for (int p = 0; p < A_IT; ++p)
 #pragma unroll
-        for (int p = 0; p < B_IT; ++p) {
-            Src s;
-            if constexpr (BL::kTN) s = bl.src(kt + b_k[p], n_blk + b_i[p]); else s = bl.src(b_st[p], kt + b_k[p]);
-            if constexpr (BL::kCheck) { ob[p] = s.ok; rb[p] = *reinterpret_cast<const float4*>(s.ok ? s.p : bl.dummy()); }
-            else rb[p] = *reinterpret_cast<const float4*>(s.p);
-        }
+            for (int q = 0; q < A_LD; ++q) {
+                Src s;
+                if constexpr (AL::kTN) s = al.src(kt + a_k[p] + q, m_blk + a_i[p]); else s = al.src(a_st[p], kt + a_k[p]);
+                if constexpr (AL::kCheck) { oa[p][q] = s.ok; ra[p][q] = *reinterpret_cast<const float4*>(s.ok ? s.p : al.dummy()); }
+                else { oa[p][q] = true; ra[p][q] = *reinterpret_cast<const float4*>(s.p); }
+            }
+#pragma unroll
+        for (int p = 0; p < B_IT; ++p)
+#pragma unroll
+            for (int q = 0; q < B_LD; ++q) {
+                Src s;
+                if constexpr (BL::kTN) s = bl.src(kt + b_k[p] + q, n_blk + b_i[p]); else s = bl.src(b_st[p], kt + b_k[p]);
+                if constexpr (BL::kCheck) { ob[p][q] = s.ok; rb[p][q] = *reinterpret_cast<const float4*>(s.ok ? s.p : bl.dummy()); }
+                else { ob[p][q] = true; rb[p][q] = *reinterpret_cast<const float4*>(s.p); }
+            }
     };
     auto lstore = [&](int buf) {
         float* as = As + buf * A_SZ;
         float* bs = Bs + buf * B_SZ;
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int p = 0; p < A_IT; ++p)
-            if (A_N % NT == 0 || a_v[p]) *reinterpret_cast<float4*>(as + a_l[p]) = (!AL::kCheck || oa[p]) ? al.post(ra[p]) : zero;
+        for (int p = 0; p < A_IT; ++p) {
+            if (A_N % NT != 0 && !a_v[p]) continue;
+            if constexpr (A_T) {                       // 4(k) x 4(m) micro-tile -> four k-quads
+                float4 v[4];
 #pragma unroll
-        for (int p = 0; p < B_IT; ++p)
-            if (B_N % NT == 0 || b_v[p]) *reinterpret_cast<float4*>(bs + b_l[p]) = (!BL::kCheck || ob[p]) ? bl.post(rb[p]) : zero;
+                for (int q = 0; q < 4; ++q) v[q] = oa[p][q] ? al.post(ra[p][q]) : zero;
+                *reinterpret_cast<float4*>(as + a_l[p] + 0 * LDA) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
+                *reinterpret_cast<float4*>(as + a_l[p] + 1 * LDA) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+                *reinterpret_cast<float4*>(as + a_l[p] + 2 * LDA) = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
+                *reinterpret_cast<float4*>(as + a_l[p] + 3 * LDA) = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
+            } else {
+                *reinterpret_cast<float4*>(as + a_l[p]) = oa[p][0] ? al.post(ra[p][0]) : zero;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < B_IT; ++p) {
+            if (B_N % NT != 0 && !b_v[p]) continue;
+            if constexpr (B_T) {
+                float4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = ob[p][q] ? bl.post(rb[p][q]) : zero;
+                *reinterpret_cast<float4*>(bs + b_l[p] + 0 * LDB) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
+                *reinterpret_cast<float4*>(bs + b_l[p] + 1 * LDB) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+                *reinterpret_cast<float4*>(bs + b_l[p] + 2 * LDB) = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
+                *reinterpret_cast<float4*>(bs + b_l[p] + 3 * LDB) = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
+            } else {
+                *reinterpret_cast<float4*>(bs + b_l[p]) = ob[p][0] ? bl.post(rb[p][0]) : zero;
+            }
+        }
     };
 
     f32x16 acc[MI][NJ];
@@ -343,9 +382,9 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
         int cur = 0;
         const int h = lane >> 5, l31 = lane & 31;
         // NT: lane reads HK consecutive floats of its row; TN: lane reads column l31 of rows HK*h .. HK*h+HK-1
-        const int a_off = AL::kTN ? (HK * h) * LDA + wave * (32 * MI) + l31 : (wave * (32 * MI) + l31) * LDA + HK * h;
-        constexpr int A_MI = AL::kTN ? 32 : 32 * LDA;          // LDS offset between the wave's 32-row blocks
-        const int b_off = BL::kTN ? (HK * h) * LDB + l31 : l31 * LDB + HK * h;
+        const int a_off = A_K ? (HK * h) * LDA + wave * (32 * MI) + l31 : (wave * (32 * MI) + l31) * LDA + HK * h;
+        constexpr int A_MI = A_K ? 32 : 32 * LDA;              // LDS offset between the wave's 32-row blocks
+        const int b_off = B_K ? (HK * h) * LDB + l31 : l31 * LDB + HK * h;
         for (int kt = k_begin; kt < k_end; kt += BKT) {
             const bool more = kt + BKT < k_end;
             if (more && !(dbg & 1)) gload(kt + BKT);
@@ -353,7 +392,7 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
             const float* bs = Bs + cur * B_SZ + b_off;
             if (!(dbg & 4)) {
                 float af[MI][HK], bf[NJ][HK];
-                if constexpr (!AL::kTN) {
+                if constexpr (!A_K) {
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -362,7 +401,7 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
                             af[mi][4 * q] = v.x; af[mi][4 * q + 1] = v.y; af[mi][4 * q + 2] = v.z; af[mi][4 * q + 3] = v.w;
                         }
                 }
-                if constexpr (!BL::kTN) {
+                if constexpr (!B_K) {
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -375,9 +414,9 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
                 for (int kk = 0; kk < HK; ++kk) {
                     float a[MI], b[NJ];
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) { if constexpr (AL::kTN) a[mi] = as[kk * LDA + mi * A_MI]; else a[mi] = af[mi][kk]; }
+                    for (int mi = 0; mi < MI; ++mi) { if constexpr (A_K) a[mi] = as[kk * LDA + mi * A_MI]; else a[mi] = af[mi][kk]; }
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) { if constexpr (BL::kTN) b[j] = bs[kk * LDB + 32 * j]; else b[j] = bf[j][kk]; }
+                    for (int j = 0; j < NJ; ++j) { if constexpr (B_K) b[j] = bs[kk * LDB + 32 * j]; else b[j] = bf[j][kk]; }
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -436,7 +475,7 @@ gemm_bf16_kernel(const AL al, const BL bl, const EPI epi, const int K, const int
 #pragma unroll
     for (int p = 0; p < A_IT; ++p) {
         const int idx = tid + NT * p; a_v[p] = idx < A_N; const int id = a_v[p] ? idx : 0;
-        if constexpr (AL::kTN) { a_i[p] = (id % (BM / 4)) * 4; a_k[p] = (id / (BM / 4)) * 4; }
+        if constexpr (AL::kTN) { a_i[p] = (id % (BM / 4)) * 4; a_k[p] = (id / (BM / 4)) * 4; }   // m fastest across lanes: coalesced global loads (a k-fastest order has conflict-free LDS writes but measured 10 % slower)
         else { a_i[p] = id / KQ; a_k[p] = (id % KQ) * 4; a_st[p] = al.row_state(m_blk + a_i[p]); }
     }
 #pragma unroll
@@ -556,7 +595,7 @@ static inline void launch_bf16(const AL& al, const BL& bl, const EPI& epi, int M
     hipLaunchKernelGGL((gemm_bf16_kernel<WAVES_M, AL, BL, EPI>), grid, dim3(WAVES_M * 64), 0, s, al, bl, epi, K, ksplit);
 }
 
-template <int WAVES_M, int BKT, int MI = 1, class AL, class BL, class EPI>
+template <int WAVES_M, int BKT, int MI = 1, bool XT = false, class AL, class BL, class EPI>
 static inline void launch(const AL& al, const BL& bl, const EPI& epi, int M, int Nc, int K, int nsplit,
                           hipStream_t s, int dbg = 0)
 {
@@ -565,7 +604,7 @@ static inline void launch(const AL& al, const BL& bl, const EPI& epi, int M, int
     if (nsplit > 1) ksplit = st_round_up((K + nsplit - 1) / nsplit, BK);
     // exactly nsplit z-slices: a slice that starts past K stores zeros, so consumers sum a fixed slab count
     dim3 grid((Nc + BN - 1) / BN, (M + BM - 1) / BM, nsplit > 1 ? nsplit : 1);
-    hipLaunchKernelGGL((gemm_kernel<WAVES_M, BKT, MI, AL, BL, EPI>), grid, dim3(WAVES_M * 64), 0, s, al, bl, epi, K, ksplit, dbg);
+    hipLaunchKernelGGL((gemm_kernel<WAVES_M, BKT, MI, XT, AL, BL, EPI>), grid, dim3(WAVES_M * 64), 0, s, al, bl, epi, K, ksplit, dbg);
 }
 
 }  // namespace stg
