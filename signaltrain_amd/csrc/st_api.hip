@@ -176,8 +176,9 @@ extern "C" int st_get_precision(void) { return g_prec; }
                               else if (g_bk == 16) stg::launch<W_, 16>(__VA_ARGS__, g_dbg); else stg::launch<W_, 32>(__VA_ARGS__, g_dbg); } while (0)
 // weight-gradient GEMMs: g_wg_mode 0 = three waves share a 96x96 tile (32x96 strips), 1 = one wave per 96x96 tile
 static int g_wg_mode = 0;
-static int g_wg_mode_set(int v) { g_wg_mode = v ? 1 : 0; return ST_OK; }
-#define ST_GEMM_WG(...) do { if (g_wg_mode == 1 && g_prec == 0) stg::launch<1, 16, 3>(__VA_ARGS__, g_dbg); else ST_GEMM(3, __VA_ARGS__); } while (0)
+static int g_wg_mode_set(int v) { g_wg_mode = v; return ST_OK; }
+#define ST_GEMM_WG(...) do { if (g_wg_mode == 1 && g_prec == 0) stg::launch<1, 16, 3>(__VA_ARGS__, g_dbg); \
+                             else if (g_wg_mode == 2 && g_prec == 0) stg::launch<3, 16, 1, true>(__VA_ARGS__, g_dbg); else ST_GEMM(3, __VA_ARGS__); } while (0)
 static const int AE_FWD_NW = 8, AE_BWD_NW = 4;
 static const bool AE_BWD_REG = true;     // persistent register accumulators, 1 wave/SIMD (LDS float atomics per group measured 3x slower)
 static int synth_live_rows(const st_dims* d);

@@ -295,7 +295,7 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
         const int idx = tid + NT * p;
         a_v[p] = idx < A_N;
         const int id = a_v[p] ? idx : 0;
-        if constexpr (A_T) { a_i[p] = (id % (BM / 4)) * 4; a_k[p] = (id / (BM / 4)) * 4; a_l[p] = a_i[p] * LDA + a_k[p]; }
+        if constexpr (A_T) { a_i[p] = ((id / (4 * KQ)) * 4 + (id % 4)) * 4; a_k[p] = ((id / 4) % KQ) * 4; a_l[p] = a_i[p] * LDA + a_k[p]; }   // quad = 64 B of one global row, then k-groups
         else if constexpr (A_K) { a_i[p] = (id % (BM / 4)) * 4; a_k[p] = id / (BM / 4); a_l[p] = a_k[p] * LDA + a_i[p]; }
         else { a_i[p] = id / KQ; a_k[p] = (id % KQ) * 4; a_l[p] = a_i[p] * LDA + a_k[p]; a_st[p] = al.row_state(m_blk + a_i[p]); }
     }
@@ -304,7 +304,7 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
         const int idx = tid + NT * p;
         b_v[p] = idx < B_N;
         const int id = b_v[p] ? idx : 0;
-        if constexpr (B_T) { b_i[p] = (id % (BN / 4)) * 4; b_k[p] = (id / (BN / 4)) * 4; b_l[p] = b_i[p] * LDB + b_k[p]; }
+        if constexpr (B_T) { b_i[p] = ((id / (4 * KQ)) * 4 + (id % 4)) * 4; b_k[p] = ((id / 4) % KQ) * 4; b_l[p] = b_i[p] * LDB + b_k[p]; }
         else if constexpr (B_K) { b_i[p] = (id % (BN / 4)) * 4; b_k[p] = id / (BN / 4); b_l[p] = b_k[p] * LDB + b_i[p]; }
         else { b_i[p] = id / KQ; b_k[p] = (id % KQ) * 4; b_l[p] = b_i[p] * LDB + b_k[p]; b_st[p] = bl.row_state(n_blk + b_i[p]); }
     }
