@@ -250,6 +250,14 @@ struct PolarStore {
 };
 
 // ------------------------------------------------------------------------------ kernel
+// The timing-only ablation switches are COMPILE-TIME (build with -DST_GEMM_ABLATE for tools/gemm_ablate*.py): as run-time
+// tests they split the k-loop body into several basic blocks, and the compiler then shuttled all 48 accumulator registers
+// between AGPRs and VGPRs on every iteration (96 extra instructions per 24 MFMAs).
+#ifdef ST_GEMM_ABLATE
+#define ST_DBG(bit_) (dbg & (bit_))
+#else
+#define ST_DBG(bit_) false
+#endif
 // BKT = k-tile depth (32: 64 KB LDS/WG, 2 WGs/CU; 16: 36 KB, 4 WGs/CU -- better for the small-M split-K GEMMs).
 // dbg: timing-only ablation switches (bit0 skip loads/stores in the k-loop, bit1 skip barriers, bit2 skip MFMAs).
 // MI = 32-row blocks per wave: MI = 1 is the 32 x 96 wave strip; WAVES_M = 1, MI = 3 lets ONE wave own a 96 x 96 tile
@@ -386,11 +394,15 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
         constexpr int A_MI = A_K ? 32 : 32 * LDA;              // LDS offset between the wave's 32-row blocks
         const int b_off = B_K ? (HK * h) * LDB + l31 : l31 * LDB + HK * h;
         for (int kt = k_begin; kt < k_end; kt += BKT) {
+            // branch-free body: the last iteration re-loads its own tile (harmless) instead of skipping the prefetch,
+            // so the whole loop is ONE basic block and the accumulators stay put
             const bool more = kt + BKT < k_end;
-            if (more && !(dbg & 1)) gload(kt + BKT);
+            if (!ST_DBG(1)) gload(more ? kt + BKT : kt);
+            __builtin_amdgcn_sched_barrier(0);           // phases stay in order: prefetch issue | fragments + MFMAs | LDS stores (else the
+                                                         // stores and their vmcnt waits get hoisted above the MFMAs)
             const float* as = As + cur * A_SZ + a_off;
             const float* bs = Bs + cur * B_SZ + b_off;
-            if (!(dbg & 4)) {
+            if (!ST_DBG(4)) {
                 float af[MI][HK], bf[NJ][HK];
                 if constexpr (!A_K) {
 #pragma unroll
@@ -424,8 +436,9 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
                             acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[j], acc[mi][j], 0, 0, 0);
                 }
             }
-            if (more && !(dbg & 1)) lstore(cur ^ 1);
-            if (!(dbg & 2)) __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            if (!ST_DBG(1)) lstore(cur ^ 1);
+            if (!ST_DBG(2)) __syncthreads();
             cur ^= 1;
         }
     }
@@ -565,7 +578,8 @@ gemm_bf16_kernel(const AL al, const BL bl, const EPI epi, const int K, const int
         const int b_off = l31 * LD + 8 * h;
         for (int kt = k_begin; kt < k_end; kt += BKH) {
             const bool more = kt + BKH < k_end;
-            if (more) gload(kt + BKH);
+            gload(more ? kt + BKH : kt);                     // branch-free body (see gemm_kernel)
+            __builtin_amdgcn_sched_barrier(0);
             const unsigned short* as = As + cur * A_SZ + a_off;
             const unsigned short* bs = Bs + cur * B_SZ + b_off;
 #pragma unroll
@@ -577,7 +591,8 @@ gemm_bf16_kernel(const AL al, const BL bl, const EPI epi, const int K, const int
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
                 }
             }
-            if (more) lstore(cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            lstore(cur ^ 1);
             __syncthreads();
             cur ^= 1;
         }
