@@ -171,7 +171,9 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     float reg = 0.f;
 
     FwdIn cur;
-    int grp = blockIdx.x * NW + wave;
+    // block-fastest group numbering: the partial last round (ngroups is rarely a multiple of the wave count) then puts ONE
+    // extra group on every workgroup instead of a full extra round on the first few workgroups while the rest idle
+    int grp = wave * gridDim.x + blockIdx.x;
     if (FAST && grp < ngroups) {
         const int b = grp / gpw, f = (grp - b * gpw) * 16 + c;
         fwd_load(cur, mag, phs, knobs, K, b, f, f < F, T, OT, F, g);
