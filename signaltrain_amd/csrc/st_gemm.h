@@ -173,6 +173,31 @@ struct AnalysisW {
     __device__ float4 post(float4 v) const { return v; }
 };
 
+// XCD-aware workgroup -> tile mapping.  The hardware hands consecutive workgroups (x fastest, then y, then z) to the 8
+// XCDs round-robin, and every XCD has its own L2: with the natural mapping the tiles that share an A row-block, a B
+// column-block or a split-K slice are spread over all eight L2s and every operand is fetched up to 8 times.  Here
+// workgroup L is given logical index  start(L % 8) + L / 8, so XCD j owns a CONTIGUOUS range of (k-slice, tile row,
+// tile column) and its L2 sees one band of A / one slice of K.  Bijective for any grid size.
+#ifndef ST_XCD_SWIZZLE
+#define ST_XCD_SWIZZLE 1
+#endif
+__device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz)
+{
+    bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+#if ST_XCD_SWIZZLE
+    const int nx = gridDim.x, ny = gridDim.y, nz = gridDim.z;
+    const int T = nx * ny * nz;
+    if (T < 16) return;
+    const int L = bx + nx * (by + ny * bz);
+    const int j = L & 7, q = T >> 3, r = T & 7;
+    const int Lp = j * q + (j < r ? j : r) + (L >> 3);
+    bz = Lp / (nx * ny);
+    const int rem = Lp - bz * (nx * ny);
+    if (ny > nx) { bx = rem / ny; by = rem - bx * ny; }      // many tile rows: an XCD owns a band of tile COLUMNS (a slice of B stays in its L2)
+    else { by = rem / nx; bx = rem - by * nx; }               // else a band of tile rows
+#endif
+}
+
 // ------------------------------------------------------------------------------ epilogues
 // D layout of v_mfma_f32_32x32x2_f32: reg i of lane l holds
 //   row = (i&3) + 8*(i>>2) + 4*(l>>5),  col = l&31.
@@ -182,7 +207,8 @@ struct StoreC {       // out[(z*slab) + full_row*ld + col]; z = blockIdx.z (spli
     float* out; int M, Nc, ld; size_t slab; RowMap map;
     __device__ void operator()(int m0, int n0, const f32x16 (&acc)[NJ]) const {
         const int lane = threadIdx.x & 63;
-        float* o = out + (size_t)blockIdx.z * slab;
+        int tbx, tby, tbz; xcd_tile(tbx, tby, tbz);               // the split-K slice this workgroup computed (see xcd_tile)
+        float* o = out + (size_t)tbz * slab;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = m0 + d_row(i, lane);
@@ -290,8 +316,9 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
     __shared__ __attribute__((aligned(16))) float Bs[2 * B_SZ];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m_blk = blockIdx.y * BM, n_blk = blockIdx.x * BN;
-    const int k_begin = blockIdx.z * ksplit;
+    int tbx, tby, tbz; xcd_tile(tbx, tby, tbz);
+    const int m_blk = tby * BM, n_blk = tbx * BN;
+    const int k_begin = tbz * ksplit;
     const int k_end = (k_begin + ksplit < K) ? k_begin + ksplit : K;
 
     // per-thread item coordinates (fixed across k-tiles): (row-in-tile, k-in-tile) and LDS offset
@@ -478,8 +505,9 @@ gemm_bf16_kernel(const AL al, const BL bl, const EPI epi, const int K, const int
     __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * B_SZ];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m_blk = blockIdx.y * BM, n_blk = blockIdx.x * BN;
-    const int k_begin = blockIdx.z * ksplit;
+    int tbx, tby, tbz; xcd_tile(tbx, tby, tbz);
+    const int m_blk = tby * BM, n_blk = tbx * BN;
+    const int k_begin = tbz * ksplit;
     const int k_end = (k_begin + ksplit < K) ? k_begin + ksplit : K;
 
     int a_i[A_IT], a_k[A_IT], b_i[B_IT], b_k[B_IT];
