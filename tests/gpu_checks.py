@@ -109,10 +109,10 @@ def phase_err(name, got, ref, mag, tol=TOL):
 
 
 # --------------------------------------------------------------------------------------------- stages
-def run_all(B=3, seed=0, K=4, verbose=False, scale=1, scheme="lean"):
+def run_all(B=3, seed=0, K=4, verbose=False, scale=1, scheme="lean", shrink=4):
     """Run every per-op entry point on oracle-provided inputs; returns list of result dicts."""
     lib = _lib.load()
-    geo, X, Y, KN, P = make_case(B, seed, K=K, scale=scale, scheme=scheme)
+    geo, X, Y, KN, P = make_case(B, seed, K=K, scale=scale, scheme=scheme, shrink=shrink)
     d = dims_of(geo, B, K)
     KP = lib.st_kp(d.F); F, T, OT, N = d.F, d.T, d.OT, d.N
     res = []
@@ -243,9 +243,9 @@ def run_all(B=3, seed=0, K=4, verbose=False, scale=1, scheme="lean"):
     return res
 
 
-def run_fused(B=3, seed=1, K=4, steps=3, scale=1, scheme="lean"):
+def run_fused(B=3, seed=1, K=4, steps=3, scale=1, scheme="lean", shrink=4):
     """Fused entry points: st_model_fwd, st_loss_backward, st_train_step x steps vs the oracle."""
-    geo, X, Y, KN, P = make_case(B, seed, K=K, scale=scale, scheme=scheme)
+    geo, X, Y, KN, P = make_case(B, seed, K=K, scale=scale, scheme=scheme, shrink=shrink)
     d = dims_of(geo, B, K)
     eng = StepEngine(d, DEV, compute_dtype=ENGINE_DTYPE)
     eng.load_state_dict(P)

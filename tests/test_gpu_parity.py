@@ -37,6 +37,15 @@ def test_legacy_large_fft_scheme():
     _assert_ok(G.run_fused(B=3, seed=5, K=3, steps=2, scale=2, scheme="legacy"))
 
 
+@pytest.mark.parametrize("shrink,seed", [(2, 5), (1, 6), (8, 5)])
+def test_other_shrink_factors(shrink, seed):
+    """st_model(shrink_factor=...) (nn_proc.py:358-380): shrink 2 -> OT = 14 (fused autoencoder kernels), shrink 1 -> OT = 25
+    = T (output as long as the input; wide autoencoder path with a narrow T), shrink 8 -> OT = 6."""
+    from tests import gpu_checks as G
+    _assert_ok(G.run_all(B=2, seed=3, K=4, shrink=shrink))
+    _assert_ok(G.run_fused(B=3, seed=seed, K=3, steps=2, shrink=shrink))
+
+
 def test_fused_step_parity_scale8():
     from tests import gpu_checks as G
     _assert_ok(G.run_fused(B=2, seed=5, K=4, steps=2, scale=8))
