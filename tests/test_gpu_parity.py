@@ -9,13 +9,13 @@ def _assert_ok(res):
     assert not bad, "\n".join(f"{r['name']}: err={r['err']:.3e} scale={r['scale']:.3e} tol={r['tol']}" for r in bad)
 
 
-@pytest.mark.parametrize("B,seed,K", [(3, 0, 4), (5, 2, 3), (1, 9, 4), (2, 4, 4), (6, 6, 1), (7, 7, 4)])
+@pytest.mark.parametrize("B,seed,K", [(3, 0, 4), (5, 2, 3), (1, 9, 4), (2, 4, 4), (6, 6, 1), (7, 7, 4), (2, 3, 16), (2, 3, 7)])
 def test_per_op_parity(B, seed, K):
     from tests import gpu_checks as G
     _assert_ok(G.run_all(B=B, seed=seed, K=K))
 
 
-@pytest.mark.parametrize("B,seed,K", [(1, 3, 4), (2, 4, 3)])
+@pytest.mark.parametrize("B,seed,K", [(1, 3, 4), (2, 4, 3), (2, 6, 16)])
 def test_per_op_parity_scale8(B, seed, K):
     """BASELINE configs[4] geometry (65536-sample window, T=174, OT=46): the autoencoders take the wide
     feature-major GEMM path (st_ae_wide.h); everything else is the same kernels at larger sizes."""
