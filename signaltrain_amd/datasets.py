@@ -70,3 +70,39 @@ class SynthAudioDataSet(Dataset):
             sgn = torch.where(torch.rand(B, 1, device=x.device) < 0.5, -1.0, 1.0)
             x, y = x * sgn, y * sgn
         return x, y, kn
+
+
+class DeviceRecycledDataSet:
+    """Device-resident counterpart of SynthAudioDataSet(recycle=True) (datasets.py:286-296): `datapoints` windows are
+    generated ONCE -- input signals and knob settings by the numpy generators, the effect on the GPU (st_compressor_4c) --
+    and kept in HBM (x: datapoints x chunk floats, 6.5 GB for the reference's 200 000 x 8192); minibatches are then random
+    index gathers on the device, so the training loop never waits for CPU workers.  iterate with batches(batch_size)."""
+
+    def __init__(self, chunk_size, effect, sr=44100, datapoints=8000, y_size=None, augment=True, device="cuda:0", gen_batch=2048):
+        import torch
+        self.device = torch.device(device)
+        self.datapoints, self.augment = int(datapoints), augment
+        self.y_size = chunk_size if y_size is None else y_size
+        gen = SynthAudioDataSet(chunk_size, effect, sr=sr, datapoints=datapoints, y_size=self.y_size, augment=False)
+        self.x = torch.empty(self.datapoints, chunk_size, dtype=torch.float32, device=self.device)
+        self.y = torch.empty(self.datapoints, self.y_size, dtype=torch.float32, device=self.device)
+        self.knobs = torch.empty(self.datapoints, gen.num_knobs, dtype=torch.float32, device=self.device)
+        for i in range(0, self.datapoints, gen_batch):
+            n = min(gen_batch, self.datapoints - i)
+            xb, yb, kb = gen.batch_device(n, self.device)
+            self.x[i:i + n], self.y[i:i + n], self.knobs[i:i + n] = xb, yb, kb
+
+    def __len__(self):
+        return self.datapoints
+
+    def batches(self, batch_size, shuffle=True):
+        """One epoch of (x, y, knobs) device batches (drop_last); do_augment's random polarity flip per item."""
+        import torch
+        order = torch.randperm(self.datapoints, device=self.device) if shuffle else torch.arange(self.datapoints, device=self.device)
+        for i in range(0, self.datapoints - batch_size + 1, batch_size):
+            idx = order[i:i + batch_size]
+            x, y, k = self.x[idx], self.y[idx], self.knobs[idx]
+            if self.augment:
+                sgn = torch.where(torch.rand(batch_size, 1, device=self.device) < 0.5, -1.0, 1.0)
+                x, y = x * sgn, y * sgn
+            yield x, y, k

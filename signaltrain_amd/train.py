@@ -105,15 +105,18 @@ def train_loop(model, engine, effect, device, epochs, batch_size, lr_sched, mom_
     if is_main:
         world = dist.get_world_size() if dist.is_initialized() else 1
         print(f"\nTotal elapsed time for training loop = {time.time() - first_time:.2f}  "
-              f"({windows * world / max(t_train, 1e-9):.0f} train windows/s incl. the CPU data feed)")
+              f"({windows * world / max(t_train, 1e-9):.0f} train windows/s incl. the data feed)")
     return None
 
 
 def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=None, plot_every=10, cp_every=25, sr=44100,
           datapath=None, scale_factor=1, shrink_factor=4, apex_opt="O0", target_type="stream", lr_max=1e-4,
-          in_checkpointname='modelcheckpoint.tar', compand=False, num_workers=10):
+          in_checkpointname='modelcheckpoint.tar', compand=False, num_workers=10, device_feed=False, compute_dtype="f32"):
     """train.py:167-278.  apex_opt / target_type / compand are accepted for signature compatibility;
-    datapath (AudioFileDataSet) is not built yet -- the synthetic feed is."""
+    datapath (AudioFileDataSet) is not built yet -- the synthetic feed is.
+    Two extra keywords (not in the reference): device_feed=True keeps a recycled synthetic dataset in HBM
+    (datasets.DeviceRecycledDataSet: generated once, effect computed on the GPU) instead of the 10-worker CPU DataLoader,
+    which otherwise caps training far below the GPU step rate; compute_dtype="bf16" selects the mixed-precision GEMMs."""
     effect = audio.Compressor_4c() if effect is None else effect
     device = torch.device("cuda:0") if device is None else torch.device(device)
     if datapath is not None:
@@ -132,13 +135,24 @@ def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=N
     chunk_size, out_chunk_size = model.in_chunk_size, model.out_chunk_size
     print("Model defined.  Number of trainable parameters:", sum(p.numel() for p in model.parameters() if p.requires_grad))
     model.to(device)
+    model.set_compute_dtype(compute_dtype)
     engine = model.engine(torch.zeros(batch_size, chunk_size, device=device))     # parameters become views of the engine's flat buffer
     lr_sched, mom_sched = learningrate.get_1cycle_schedule(lr_max=lr_max, n_data_points=n_data_points, epochs=epochs, batch_size=batch_size)
     dataset = datasets.SynthAudioDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points, y_size=out_chunk_size, augment=True)
     dataset_val = datasets.SynthAudioDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points // 4, recycle=True,
                                              y_size=out_chunk_size, augment=False)
-    dataloader = DataLoader(dataset, batch_size=batch_size, num_workers=num_workers, shuffle=True, worker_init_fn=datasets.worker_init,
-                            drop_last=True)
+    if device_feed:
+        t0 = time.time()
+        dev_ds = datasets.DeviceRecycledDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points, y_size=out_chunk_size, augment=True, device=device)
+        print(f"device-resident dataset: {n_data_points} windows generated in {time.time() - t0:.1f} s")
+
+        class _DevLoader:                      # iterable with the DataLoader's per-epoch semantics
+            def __iter__(self_inner):
+                return dev_ds.batches(batch_size, shuffle=True)
+        dataloader = _DevLoader()
+    else:
+        dataloader = DataLoader(dataset, batch_size=batch_size, num_workers=num_workers, shuffle=True, worker_init_fn=datasets.worker_init,
+                                drop_last=True)
     dataloader_val = DataLoader(dataset_val, batch_size=batch_size, num_workers=num_workers, shuffle=False, drop_last=True)
     logfilename = "vl_avg_out.dat"
     open(logfilename, "a").close()

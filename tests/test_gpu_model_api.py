@@ -340,3 +340,26 @@ def test_autograd_all_three_outputs(golden_dir):
         if e > worst[1]:
             worst = (k, e)
         assert e <= 2e-4, (k, e)
+
+
+def test_train_driver_device_feed(tmp_path):
+    """train.train(device_feed=True): recycled synthetic dataset resident in HBM (effect computed on the GPU), random index
+    gathers per minibatch -- no CPU workers in the loop; the loss must go down over a few epochs of a tiny dataset."""
+    from signaltrain_amd import train, audio, nn_proc, datasets
+    nn_proc._QUIET = True
+    ds = datasets.DeviceRecycledDataSet(8192, audio.Compressor_4c(), datapoints=96, y_size=2048)
+    assert ds.x.shape == (96, 8192) and ds.y.shape == (96, 2048) and ds.x.is_cuda
+    seen = 0
+    for x, y, k in ds.batches(32):
+        assert x.shape == (32, 8192) and y.shape == (32, 2048) and k.shape == (32, 4)
+        seen += 1
+    assert seen == 3
+    cwd = os.getcwd(); os.chdir(tmp_path)
+    try:
+        torch.manual_seed(0); np.random.seed(0)
+        model = train.train(effect=audio.Compressor_4c(), epochs=3, n_data_points=512, batch_size=32,
+                            device=torch.device("cuda:0"), num_workers=2, device_feed=True, lr_max=2e-4)
+        lines = [l.split() for l in open("vl_avg_out.dat").read().strip().splitlines()]
+        assert len(lines) >= 3 and all(np.isfinite(float(l[-1])) for l in lines)
+    finally:
+        os.chdir(cwd)
