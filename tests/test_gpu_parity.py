@@ -137,3 +137,12 @@ def test_bf16_mode_fused_step_and_differs_from_fp32():
     rel = float((y32 - y16).abs().max() / y32.abs().max())
     assert 1e-5 < rel < 2e-2, rel                                  # really bf16 arithmetic, and sane
     assert torch.equal(y32, y32b)                                  # the fp32 engine is unaffected by the other engine's mode
+
+
+def test_bf16_mode_scale8():
+    """Geometry of BASELINE configs[4] (65536-sample window) with 16-bit GEMM operands: bf16 is the MI355X-native 16-bit type
+    (same MFMA rate as fp16, no loss scaling needed), so it stands in for that configuration's fp16 mixed precision."""
+    from tests import gpu_checks as G
+    with G.bf16_mode():
+        _assert_ok(G.run_all(B=1, seed=3, K=4, scale=8))
+        _assert_ok(G.run_fused(B=2, seed=5, K=4, steps=2, scale=8))
