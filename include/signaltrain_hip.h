@@ -172,6 +172,17 @@ int st_loss_backward_p1(const st_dims* d, const float* params, float* grads, con
                         const float* y_true, void* ws, void* stream);
 int st_loss_backward_p2(const st_dims* d, float* grads, const float* x, void* ws, float* scalars, void* stream);
 
+/* Finer split of the same step for data parallel (no reference counterpart: train.py:259-263 is a disabled
+ * nn.DataParallel stub).  Call stage = 0, 1, 2, 3 in order on one stream; after stage s one gradient range is final
+ * and can be all-reduced while the next stage runs:
+ *   0  forward (nn_proc.py:304-340) + loss (loss_functions.py:26-36) + synthesis backward -> grads[offs[2], offs[4])
+ *   1  autoencoder + polar backward                                                       -> grads[offs[4], total)
+ *   2  analysis weight gradient, real basis      (cls_fe_dft.py:50-58 autograd)           -> grads[offs[0], offs[0] + F*N)
+ *   3  analysis weight gradient, imaginary basis + loss scalars                           -> grads[offs[1], offs[1] + F*N)
+ * Rows >= F of the analysis tensors are structurally zero and never need to move. */
+int st_loss_backward_stage(const st_dims* d, const float* params, float* grads, const float* x, const float* knobs,
+                           const float* y_true, void* ws, float* scalars, int stage, void* stream);
+
 /* Full single-GPU step: st_loss_backward + L1 clip + Adam (train.py:131-151). */
 int st_train_step(const st_dims* d, float* params, float* grads, float* m, float* v, const float* x,
                   const float* knobs, const float* y_true, void* ws, float* scalars,

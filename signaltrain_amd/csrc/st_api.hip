@@ -156,9 +156,10 @@ namespace sta { extern __device__ unsigned long long g_ae_stage_cycles[32]; }
 extern "C" int st_debug_read_stage_cycles(unsigned long long* out32);
 static int g_bk = 16;   // k-tile depth of the GEMM family (16: 36 KB LDS/WG -> 4 WGs/CU; 32: 64 KB -> 2 WGs/CU)
 static int g_wg_mode_set(int v);
-static int g_wsplit_max = 16, g_wsplit_div = 200, g_an_waves = 4, g_syn_split = 3, g_frs_split = 3, g_wide_fused = 1;      // frames: 3, 4 measured equal, 6 slower (only 66 k-tiles to split)
+static int g_wsplit_max = 16, g_wsplit_div = 200, g_an_waves = 4, g_syn_split = 3, g_frs_split = 3, g_wide_fused = 1, g_wsplit_half = 0;      // frames: 3, 4 measured equal, 6 slower (only 66 k-tiles to split)
 extern "C" int st_set_tuning(int bk)
 {
+    if (bk >= 6000) { g_wsplit_half = bk - 6000; return ST_OK; }  // 6000 + n: split-K of the half (one-basis) analysis weight-gradient GEMMs of st_loss_backward_stage (0: as the full GEMM)
     if (bk >= 5000) { g_wide_fused = bk - 5000; return ST_OK; }   // 5000 / 5001: wide AE path all-GEMM / fused inner layers
     if (bk >= 4000) { g_frs_split = bk - 4000; return (g_frs_split >= 1 && g_frs_split <= 6) ? ST_OK : st_fail(ST_ERR_ARG, "frames split must be 1..6"); }
     if (bk >= 3000) { g_syn_split = bk - 3000; return ST_OK; }    // 3000 + n: synthesis split-K (<= 3: consumers sum at most 3 slabs)
@@ -408,7 +409,7 @@ static int synthesis_wgrad_impl(const st_dims* d, const float* AA, const float* 
     else { stg::FramedTN<false> bl{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms}; ST_GEMM_WG(al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
     ST_LAUNCHED("synthesis_wgrad");
     hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(2 * d->F), dim3(256), 0, st_stream(stream),
-                       ws, ns, gSr, gSi, norm_partial, d->N, d->F, KP, 1);
+                       ws, ns, gSr, gSi, norm_partial, d->N, d->F, KP, 1, 0);
     ST_LAUNCHED("synthesis_wgrad_reduce");
     return ST_OK;
 }
@@ -621,20 +622,36 @@ extern "C" int st_polar_bwd(const st_dims* d, const float* re, const float* im, 
     ST_LAUNCHED("polar_bwd"); return ST_OK;
 }
 
+// half = -1: both bases in one GEMM (M = KP rows of dG^T); half = 0 / 1: only the real / imaginary basis (M = KP/2), so
+// that in data parallel the first half's all-reduce runs under the second half's GEMM (st_loss_backward_stage).
 static int analysis_wgrad_impl(const st_dims* d, const float* dG, const float* sig, bool padded, float in_scale, float* ws,
-                               float* gWr, float* gWi, float* norm_partial, void* stream)
+                               float* gWr, float* gWi, float* norm_partial, void* stream, int half = -1)
 {
     const int KP = st_kp_of(d->F);
     const stg::RowMap ma = stg::live_frames(d->T, d->H, d->N, d->N, d->L);   // all-zero frames contribute nothing
     const int R = ma.rows(d->B);
-    const int ns = wgrad_split(R);
-    stg::PlainTN al{dG, R, KP, KP, ma};
-    stg::StoreC ep{ws, KP, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
-    if (padded) { stg::FramedTN<true> bl{sig, d->L, d->H, d->N, R, d->N, 1.0f, ma}; ST_GEMM_WG(al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
-    else { stg::FramedTN<false> bl{sig, d->L, d->H, d->N, R, d->N, in_scale, ma}; ST_GEMM_WG(al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
+    int ns = wgrad_split(R);
+    if (half >= 0) {
+        // One-basis GEMM: 6 x 11 tiles of 96 x 96, one 3-wave workgroup per CU at a time, so the run time goes with
+        // ceil(tiles * ns / CUs) / ns (measured sawtooth, B=256: ns = 7, 11, 15 are the minima, 8 / 12 / 16 cost +40..60 us).
+        // Pick the split in [ns/2, ns] that fills its last round best; never above the slab count the workspace holds.
+        const int tiles = ((KP / 2 + 95) / 96) * ((d->N + 95) / 96), cus = num_cus();
+        int best = ns; double bf = -1.0;
+        for (int c = ns; c >= (ns + 1) / 2 && c >= 1; --c) {
+            const int w = tiles * c, rounds = (w + cus - 1) / cus;
+            const double f = (double)w / ((double)rounds * cus);
+            if (f > bf + 1e-9) { bf = f; best = c; }
+        }
+        ns = (g_wsplit_half > 0 && g_wsplit_half < ns) ? g_wsplit_half : best;
+    }
+    const int M = half < 0 ? KP : KP / 2, m0 = half > 0 ? KP / 2 : 0;
+    stg::PlainTN al{dG + m0, R, KP, M, ma};
+    stg::StoreC ep{ws + (size_t)m0 * d->N, M, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
+    if (padded) { stg::FramedTN<true> bl{sig, d->L, d->H, d->N, R, d->N, 1.0f, ma}; ST_GEMM_WG(al, bl, ep, M, d->N, R, ns, st_stream(stream)); }
+    else { stg::FramedTN<false> bl{sig, d->L, d->H, d->N, R, d->N, in_scale, ma}; ST_GEMM_WG(al, bl, ep, M, d->N, R, ns, st_stream(stream)); }
     ST_LAUNCHED("analysis_wgrad");
-    hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(2 * d->F), dim3(256), 0, st_stream(stream),
-                       ws, ns, gWr, gWi, norm_partial, d->N, d->F, KP, 0);
+    hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(half < 0 ? 2 * d->F : d->F), dim3(256), 0, st_stream(stream),
+                       ws, ns, gWr, gWi, norm_partial, d->N, d->F, KP, 0, half > 0 ? d->F : 0);
     ST_LAUNCHED("analysis_wgrad_reduce");
     return ST_OK;
 }
@@ -735,16 +752,24 @@ static int forward_impl(const st_dims* d, const Layout& L, const float* params, 
 // backward of everything behind d syn (workspace holds the forward state): autograd of train.py:138.
 // phase 1 = synthesis dgrad/wgrad + autoencoders + polar backward (fills grads[n_stft/2 ..));
 // phase 2 = analysis weight gradient (fills rows [0,F) of the first two tensors).
-static int backward_p1(const st_dims* d, const Layout& L, const float* params, float* grads,
+static int backward_syn(const st_dims* d, const Layout& L, float* grads, WS& w, void* stream)
+{
+    ST_TRY(synthesis_dgrad_impl(d, w.dsyn, true, w.Sfold, w.dAA, stream));
+    return synthesis_wgrad_impl(d, w.AA, w.dsyn, true, w.wg, grads + L.offs[2], grads + L.offs[3], w.norm_s, stream);
+}
+static int backward_ae(const st_dims* d, const Layout& L, const float* params, float* grads,
                        const float* knobs, const float* g_mag_hat, const float* g_mag, float reg_coef, WS& w, void* stream)
 {
     const float* ae_m = params + L.offs[4]; const float* ae_p = params + L.offs[22];
-    ST_TRY(synthesis_dgrad_impl(d, w.dsyn, true, w.Sfold, w.dAA, stream));
-    ST_TRY(synthesis_wgrad_impl(d, w.AA, w.dsyn, true, w.wg, grads + L.offs[2], grads + L.offs[3], w.norm_s, stream));
     ST_TRY(ae_bwd_impl(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.dAA, g_mag_hat, reg_coef, w.dmag, w.dphs,
                        w.aews, grads + L.offs[4], grads + L.offs[22], true, stream));      // the forward left its AE state in w.aews
-    ST_TRY(st_polar_bwd(d, w.re, w.im, w.dmag, w.dphs, g_mag, w.dG, stream));
-    return ST_OK;
+    return st_polar_bwd(d, w.re, w.im, w.dmag, w.dphs, g_mag, w.dG, stream);
+}
+static int backward_p1(const st_dims* d, const Layout& L, const float* params, float* grads,
+                       const float* knobs, const float* g_mag_hat, const float* g_mag, float reg_coef, WS& w, void* stream)
+{
+    ST_TRY(backward_syn(d, L, grads, w, stream));
+    return backward_ae(d, L, params, grads, knobs, g_mag_hat, g_mag, reg_coef, w, stream);
 }
 static int backward_p2(const st_dims* d, const Layout& L, float* grads, const float* x, WS& w, void* stream)
 {
@@ -812,6 +837,35 @@ extern "C" int st_loss_backward_p2(const st_dims* d, float* grads, const float* 
     WS w; carve(d, ws, &w);
     ST_TRY(backward_p2(d, L, grads, x, w, stream));
     return st_finalize_scalars(d, w.loss_p, w.reg_p, w.norm_a, w.norm_s, 1.0f, scalars, stream);
+}
+
+// Finer data-parallel split (dp.DataParallel): stage s leaves one gradient range final, in the order
+//   0: forward + loss + synthesis dgrad/wgrad   -> the two synthesis bases           grads[offs[2], offs[4])
+//   1: autoencoders + polar backward             -> both autoencoders                 grads[offs[4], total)
+//   2: analysis weight gradient, real basis      -> rows [0,F) of the first tensor    grads[offs[0], +F*N)
+//   3: analysis weight gradient, imaginary basis -> rows [0,F) of the second tensor   grads[offs[1], +F*N)  + scalars
+// so each all-reduce runs under the next stage and only the last, smallest range (2.1 MB) is exposed.
+extern "C" int st_loss_backward_stage(const st_dims* d, const float* params, float* grads, const float* x, const float* knobs,
+                                      const float* y_true, void* ws, float* scalars, int stage, void* stream)
+{
+    Layout L; ST_TRY(make_layout(d, &L));
+    ST_REQ(params && grads && x && knobs && y_true && ws && scalars, "st_loss_backward_stage: null pointer");
+    ST_REQ(stage >= 0 && stage < 4, "st_loss_backward_stage: stage %d not in 0..3", stage);
+    WS w; carve(d, ws, &w);
+    const float reg_coef = (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);
+    switch (stage) {
+    case 0:
+        prof_mark("begin", stream);
+        ST_TRY(forward_impl(d, L, params, x, knobs, y_true, nullptr, nullptr, nullptr, w, true, stream));
+        return backward_syn(d, L, grads, w, stream);
+    case 1:
+        return backward_ae(d, L, params, grads, knobs, nullptr, nullptr, reg_coef, w, stream);
+    case 2:
+        return analysis_wgrad_impl(d, w.dG, w.xp, true, 1.0f, w.wg, grads + L.offs[0], grads + L.offs[1], w.norm_a, stream, 0);
+    default:
+        ST_TRY(analysis_wgrad_impl(d, w.dG, w.xp, true, 1.0f, w.wg, grads + L.offs[0], grads + L.offs[1], w.norm_a, stream, 1));
+        return st_finalize_scalars(d, w.loss_p, w.reg_p, w.norm_a, w.norm_s, 1.0f, scalars, stream);
+    }
 }
 
 extern "C" int st_train_step(const st_dims* d, float* params, float* grads, float* m, float* v, const float* x,

@@ -152,10 +152,10 @@ polar_bwd_kernel(const float* __restrict__ re, const float* __restrict__ im, con
 // mode 1 (synthesis): additionally mirror to row N-k with sign +1 (real) / -1 (imag)  (SURVEY.md 8a' "unfold").
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ ws, int nz, float* __restrict__ gRe, float* __restrict__ gIm,
-                    float* __restrict__ norm_partial, int N, int F, int KP, int mode)
+                    float* __restrict__ norm_partial, int N, int F, int KP, int mode, int row0)
 {
     __shared__ float red[4];
-    const int row = blockIdx.x;                       // 0 .. 2F-1 : [0,F) real rows, [F,2F) imag rows
+    const int row = blockIdx.x + row0;                // 0 .. 2F-1 : [0,F) real rows, [F,2F) imag rows (row0: imag half only)
     const bool is_im = row >= F;
     const int k = is_im ? row - F : row;
     const int src = is_im ? KP / 2 + k : k;

@@ -1,18 +1,25 @@
 """Data-parallel training: one process per GPU, torch.distributed (backend "nccl" == RCCL over xGMI).
 
 The reference's only multi-GPU mechanism is a disabled nn.DataParallel stub (train.py:259-263).  Here each
-rank runs the fused step on its shard of the minibatch with identical parameters; the flat fp32 gradient
-buffer (16.8 MB) is sum-all-reduced in two buckets -- [synthesis bases + both autoencoders] (8.45 MB) as soon as
-they are final, overlapping the analysis weight-gradient GEMM, then one contiguous range holding the 513 live rows
-of the two analysis tensors (6.3 MB incl. 2 MB of structural zeros) -- scaled by 1/world, and only then L1-clipped (the norm is a function of the reduced gradient, so it
-is identical on every rank and needs no second collective) and fed to the replicated Adam.
+rank runs the fused step on its shard of the minibatch with identical parameters; the flat fp32 gradient buffer is
+sum-all-reduced range by range, in the order the backward makes the ranges final, each collective running under the
+next stage's kernels (engine.loss_backward_stage / stage_bucket):
+
+    stage 0  forward + loss + synthesis backward   -> all-reduce the two synthesis bases (4.2 MB)   || stage 1 (autoencoders)
+    stage 1  autoencoder + polar backward          -> all-reduce both autoencoders (67 KB)          || stage 2
+    stage 2  analysis wgrad, real basis            -> all-reduce its 513 live rows (2.1 MB)         || stage 3
+    stage 3  analysis wgrad, imaginary basis       -> all-reduce its 513 live rows (2.1 MB)  -- the only exposed one
+
+10.6 MB move per step instead of the 16.8 MB buffer (rows >= 513 of the analysis tensors are structurally zero).  The
+reduced gradient is scaled by 1/world and only then L1-clipped (the norm is a function of the reduced gradient, so it is
+identical on every rank and needs no second collective) and fed to the replicated Adam.
 """
 import torch
 import torch.distributed as dist
 
 
 class DataParallel:
-    """Wraps an engine exposing loss_backward_p1/p2, grad_buckets(), clip_adam(), scalars."""
+    """Wraps an engine exposing N_STAGES, loss_backward_stage(), stage_bucket(), clip_adam(), scalars."""
 
     def __init__(self, engine, process_group=None, force_collectives=False):
         self.engine = engine
@@ -29,13 +36,13 @@ class DataParallel:
         eng = self.engine
         if self.world == 1 and not self.force:
             return eng.train_step(x, knobs, y, lr, **kw)
-        eng.loss_backward_p1(x, knobs, y)
-        b = eng.grad_buckets()
-        # async collective on the communicator's stream: it waits for phase 1 only, phase 2 overlaps it
-        h0 = dist.all_reduce(b[0], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        eng.loss_backward_p2()
-        h1 = dist.all_reduce(b[1], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        h0.wait(); h1.wait()
+        handles = []
+        for s in range(eng.N_STAGES):
+            eng.loss_backward_stage(s, x, knobs, y)
+            # async collective on the communicator's stream: it waits for the stages issued so far, the next stage overlaps it
+            handles.append(dist.all_reduce(eng.stage_bucket(s), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for h in handles:
+            h.wait()
         return eng.clip_adam(lr, grad_scale=1.0 / self.world, **kw)
 
     def mean_loss(self):

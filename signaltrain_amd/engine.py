@@ -154,17 +154,37 @@ class StepEngine:
     def loss_backward_p1(self, x, knobs, y):
         """Forward + backward up to (excluding) the analysis weight gradient; see dp.DataParallel."""
         d, x, knobs, y = self._prep(x, knobs, y)
-        self._pending = (d, x)
+        self._pending = (d, x, knobs, y)
         _lib.check(self.lib.st_loss_backward_p1(C.byref(d), _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(x),
                                                 _lib.ptr(knobs), _lib.ptr(y), _lib.ptr(self.ws), self._stream()), "st_loss_backward_p1")
 
     def loss_backward_p2(self):
-        d, x = self._pending
+        d, x = self._pending[:2]
         _lib.check(self.lib.st_loss_backward_p2(C.byref(d), _lib.ptr(self.grads), _lib.ptr(x), _lib.ptr(self.ws),
                                                 _lib.ptr(self.scalars), self._stream()), "st_loss_backward_p2")
 
+    N_STAGES = 4
+
+    def loss_backward_stage(self, stage, x=None, knobs=None, y=None):
+        """Stage `stage` (0..3, in order) of forward + loss + backward; stage 0 takes the minibatch.  After stage s the
+        range stage_bucket(s) of self.grads is final (st_loss_backward_stage in include/signaltrain_hip.h)."""
+        if stage == 0:
+            self._pending = self._prep(x, knobs, y)
+        d, x, knobs, y = self._pending
+        _lib.check(self.lib.st_loss_backward_stage(C.byref(d), _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(x),
+                                                   _lib.ptr(knobs), _lib.ptr(y), _lib.ptr(self.ws), _lib.ptr(self.scalars),
+                                                   int(stage), self._stream()), "st_loss_backward_stage")
+
+    def stage_bucket(self, stage):
+        """Gradient range that is final after loss_backward_stage(stage): synthesis bases (4.2 MB at N=1024), both
+        autoencoders (67 KB), live rows [0,F) of the real analysis basis, live rows of the imaginary one (2.1 MB each)."""
+        o, d = self.layout.offsets, self.dims
+        live = d.F * d.N
+        return (self.grads[o[2]:o[4]], self.grads[o[4]:], self.grads[o[0]:o[0] + live], self.grads[o[1]:o[1] + live])[stage]
+
     def grad_buckets(self):
-        """Gradient ranges in the order they become final: [synthesis + autoencoders] after phase 1, then ONE contiguous
+        """Two-phase form (loss_backward_p1 / _p2; dp.DataParallel uses the finer loss_backward_stage / stage_bucket).
+        Gradient ranges in the order they become final: [synthesis + autoencoders] after phase 1, then ONE contiguous
         range covering the live rows [0,F) of both analysis tensors (it spans the structurally-zero rows [F,N) of the
         first tensor: 2 MB of zeros is cheaper than the ~25 us fixed cost of a third collective; rows >= F of the second
         tensor never move)."""

@@ -42,6 +42,16 @@ class OracleEngine:
     def loss_backward_p2(self):
         pass
 
+    N_STAGES = 4
+
+    def loss_backward_stage(self, stage, x=None, knobs=None, y=None):
+        if stage == 0:                                  # the oracle has no stages: everything is final after the first
+            self.loss_backward_p1(x, knobs, y)
+
+    def stage_bucket(self, stage):
+        n, live, e = 1 << 20, 513 * 1024, self.grads.numel()
+        return (self.grads[2 * n:4 * n], self.grads[4 * n:e], self.grads[0:live], self.grads[n:n + live])[stage]   # as StepEngine.stage_bucket
+
     def grad_buckets(self):
         n = 1 << 20
         return [self.grads[2 * n:], self.grads[0:n + 513 * 1024]]            # same two ranges as StepEngine.grad_buckets()

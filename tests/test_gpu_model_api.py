@@ -133,8 +133,8 @@ def test_scale8_golden_forward(golden_dir):
 
 
 def test_dp_collective_path_single_rank():
-    """The N > 1 step (phase-1 backward -> bucketed RCCL all-reduce overlapping the analysis weight gradient ->
-    st_dp_clip_adam) executed on ONE GPU with a single-rank RCCL group must reproduce the fused single-GPU step."""
+    """The N > 1 step (four backward stages, each followed by the RCCL all-reduce of the range it finalised, running under
+    the next stage -> st_dp_clip_adam) executed on ONE GPU with a single-rank RCCL group must reproduce the fused single-GPU step."""
     import socket
     import torch.distributed as dist
     from tests import gpu_checks as G
@@ -161,6 +161,37 @@ def test_dp_collective_path_single_rank():
             assert err <= 2e-5, (it, err)          # same tolerance as the fused-vs-oracle parameter check (Adam amplifies ulp noise)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scale,B", [(1, 5), (8, 2)])
+def test_staged_backward_is_bitwise_the_fused_backward(scale, B):
+    """the four data-parallel stages (st_loss_backward_stage) leave exactly the gradients and loss scalars
+    of st_loss_backward -- the per-basis analysis GEMMs use another split-K count, but every slab sum is formed in the
+    same order by the reduce kernel, so those are compared to fp32 reassociation tolerance and the rest bitwise; the four
+    stage buckets are disjoint and cover every non-zero gradient."""
+    from tests import gpu_checks as G
+    from signaltrain_amd.engine import StepEngine
+    geo, X, Y, KN, P = G.make_case(B, 3, K=4, scale=scale)
+    d = G.dims_of(geo, B, 4)
+    e1 = StepEngine(d, G.DEV); e1.load_state_dict(P)
+    e2 = StepEngine(d, G.DEV); e2.load_state_dict(P)
+    x, kn, y = G.t(X), G.t(KN), G.t(Y)
+    e1.loss_backward(x, kn, y)
+    for s in range(e2.N_STAGES):
+        e2.loss_backward_stage(s, x, kn, y)
+    torch.cuda.synchronize()
+    o = e2.layout.offsets
+    assert torch.equal(e1.grads[o[2]:], e2.grads[o[2]:])                        # synthesis bases + autoencoders: same kernels
+    assert torch.equal(e1.scalars[:3], e2.scalars[:3])
+    ga, gb = e1.grads[:o[2]], e2.grads[:o[2]]
+    assert (ga - gb).abs().max().item() <= 1e-5 * ga.abs().max().item()         # analysis bases: split-K regrouping only
+    cover = torch.zeros_like(e2.grads)
+    for s in range(e2.N_STAGES):
+        b = e2.stage_bucket(s)
+        start = (b.data_ptr() - e2.grads.data_ptr()) // 4
+        cover[start:start + b.numel()] += 1
+    assert int(cover.max()) == 1
+    assert int(((cover == 0) & (e2.grads != 0)).sum()) == 0
 
 
 def test_device_compressor_matches_reference_golden(golden_dir):
