@@ -3,63 +3,75 @@
 // Rows of the problem are (window b, frequency bin f); the features of a row are its T STFT frames.
 // A wave processes groups of 16 rows with v_mfma_f32_16x16x4_f32 in the orientation
 //     D[o][row] = sum_i W[o][i] * H[i][row]          (A = weights, B = activations)
-// whose result layout (lane (g,c) = (l>>4, l&15), reg r  <->  o = 16*tile + 4g + r, row = c) is exactly
+// whose result layout (lane (g,c) = (l>>4, l&15), reg r  <->  o = 16*tile + 4g + r, row = c; "D layout") is exactly
 // the B-operand layout of the next layer when its k-steps enumerate features in the order
 // i = 16*tile + 4g + r: activations never leave registers, no transposes, no LDS traffic for them.
-// All nine weight matrices of an autoencoder sit in LDS (zero padded to 16-multiples, odd row pitch),
-// the A operand of each MFMA is one ds_read_b32.  The two autoencoders (magnitude / phase) of the same
-// rows run as two interleaved chains in one wave (independent accumulators hide the 40-cycle dependent
-// MFMA latency) and meet in the epilogue (nn_proc.py:322-326: phase residual, polar -> rect).
+//
+// Weights sit in LDS as *fragment images*: the four A operands a lane needs for the k-steps r = 0..3 of one 16x16 tile
+// are 16 contiguous bytes, so a tile costs ONE ds_read_b128 per lane instead of four ds_read_b32, and the image is
+// k-block-major so the 16-lane service groups of ds_read_b128 (which mix g = 0/1 lanes) hit 16 distinct 16-B slots:
+//     forward image  A_l[(i >> 2)][o][i & 3]   lane (g,c), tile (ot,it) reads slot (4 it + g) * OUTp + 16 ot + c
+//     dgrad image    G_l[(o >> 2)][i][o & 3]   lane (g,c), tile (it,ot) reads slot (4 ot + g) * INp  + 16 it + c
+// (the first version kept one row-major copy with an odd pitch: every fragment read was a 2-way bank conflict in both
+// orientations -- a third of the LDS cycles of the backward kernel were conflict cycles).
+//
+// Forward: the two autoencoders (magnitude / phase) of the same rows run as two interleaved chains in one wave
+// (independent accumulators hide the dependent-MFMA latency) and meet in the epilogue (nn_proc.py:322-326: phase
+// residual, polar -> rect).  Backward: see ae_bwd_kernel.
 //
 // Row space is padded per window to FP = KP/2 = roundup(F,16) "virtual bins": groups never straddle
 // windows (knobs are wave-uniform) and the pad columns of the AA matrix get written as zeros.
+// These kernels cover T <= 32, OT <= 16, K <= 16 (every padded dimension fixed at compile time); wider geometries run
+// layers 1 and 9 as GEMMs (st_ae_wide.h) around the INNER forms below.
 #pragma once
 #include "st_common.h"
 
 namespace sta {
 
 constexpr int NL = 9;
-constexpr int R64 = 64, R32 = 32, R16 = 16;
 
 // Global-memory description of one autoencoder inside the flat parameter buffer (float offsets from
 // the autoencoder base: weight l at w[l], bias at b[l]); same for the gradient buffer.
 struct AEOffsets { int w[NL]; int b[NL]; };
 
-// LDS layout of one autoencoder (floats).  Layer l: Wpad[OUTp][P] (P odd), then bias[OUTp].
-struct AELds {
-    int w[NL], b[NL], P[NL], OUT[NL], IN[NL], OUTp[NL];
-    int total;
+// Compile-time LDS layout (floats).  Padded shapes OUTp x INp per layer:
+//   l = 0: 64 x 32 (IN = T)   1: 32 x 64   2: 16 x 32   3: 16 x 16   4: 16 x 32 (IN = 16 + K)   5: 16 x 16   6: 32 x 16
+//   7: 64 x 32   8: 16 x 64 (OUT = OT)
+struct CL {
+    static constexpr int O0 = 64, O1 = 32, O2 = 16, O3 = 16, O4 = 16, O5 = 16, O6 = 32, O7 = 64, O8 = 16;
+    static constexpr int I0 = 32, I1 = 64, I2 = 32, I3 = 16, I4 = 32, I5 = 16, I6 = 16, I7 = 32, I8 = 64;
+    // forward images
+    static constexpr int A0 = 0, A1 = A0 + O0 * I0, A2 = A1 + O1 * I1, A3 = A2 + O2 * I2, A4 = A3 + O3 * I3, A5 = A4 + O4 * I4,
+                         A6 = A5 + O5 * I5, A7 = A6 + O6 * I6, A8 = A7 + O7 * I7, AEND = A8 + O8 * I8;
+    // biases
+    static constexpr int B0 = AEND, B1 = B0 + O0, B2 = B1 + O1, B3 = B2 + O2, B4 = B3 + O3, B5 = B4 + O4, B6 = B5 + O5,
+                         B7 = B6 + O6, B8 = B7 + O7, FWD_TOTAL = B8 + O8;          // what the forward kernels keep per autoencoder
+    // dgrad images (backward kernel only)
+    static constexpr int G0 = FWD_TOTAL, G1 = G0 + O0 * I0, G2 = G1 + O1 * I1, G3 = G2 + O2 * I2, G4 = G3 + O3 * I3, G5 = G4 + O4 * I4,
+                         G6 = G5 + O5 * I5, G7 = G6 + O6 * I6, G8 = G7 + O7 * I7, BWD_TOTAL = G8 + O8 * I8;
+    static_assert(FWD_TOTAL % 4 == 0 && BWD_TOTAL % 4 == 0, "16-byte aligned regions");
 };
 
-__host__ __device__ inline AELds ae_lds_layout(int T, int OT, int K)
+// Cooperative load of one autoencoder's parameters into its LDS images (zero padded): zero-fill, then a coalesced read
+// of the packed global tensors with 8 independent loads in flight per thread (a dependent load->store loop costs
+// ~40 serialized L2 round trips per workgroup, i.e. tens of microseconds before the first MFMA) scattered to the image
+// positions.  Layers [l0, l1) only (the wide path keeps 1..7).  The caller synchronises afterwards.
+__device__ inline void ae_load_lds(float* lds, const float* __restrict__ ae, const AEOffsets& go, const int T, const int OT, const int K,
+                                   const int tid, const int nthreads, const int l0, const int l1, const bool dgrad_images)
 {
-    AELds L;
-    const int out[NL] = {R64, R32, R16, R16, R16, R16, R32, R64, OT};
-    const int in[NL]  = {T, R64, R32, R16, R16 + K, R16, R16, R32, R64};
-    int off = 0;
-    for (int l = 0; l < NL; ++l) {
-        L.OUT[l] = out[l]; L.IN[l] = in[l];
-        L.OUTp[l] = (out[l] + 15) / 16 * 16;
-        L.P[l] = (in[l] + 15) / 16 * 16 + 1;
-        L.w[l] = off; off += L.OUTp[l] * L.P[l];
-        L.b[l] = off; off += L.OUTp[l];
-    }
-    L.total = (off + 3) / 4 * 4;
-    return L;
-}
-
-// Cooperative load of one autoencoder's parameters into LDS (zero padded): zero-fill, then a coalesced copy of
-// the packed global tensors with 8 independent loads in flight per thread (a dependent load->store loop costs
-// ~40 serialized L2 round trips per workgroup, i.e. tens of microseconds before the first MFMA).
-__device__ inline void ae_load_lds(float* lds, const AELds& L, const float* __restrict__ ae, const AEOffsets& go,
-                                   int tid, int nthreads, int l0 = 0, int l1 = NL)     // layers [l0, l1): the wide path keeps 1..7 only
-{
-    for (int e = tid; e < L.total; e += nthreads) lds[e] = 0.f;
+    const int total = dgrad_images ? CL::BWD_TOTAL : CL::FWD_TOTAL;
+    for (int e = tid; e < total; e += nthreads) lds[e] = 0.f;
     __syncthreads();
+    const int out[NL] = {64, 32, 16, 16, 16, 16, 32, 64, OT};
+    const int in[NL] = {T, 64, 32, 16, 16 + K, 16, 16, 32, 64};
+    const int outp[NL] = {CL::O0, CL::O1, CL::O2, CL::O3, CL::O4, CL::O5, CL::O6, CL::O7, CL::O8};
+    const int inp[NL] = {CL::I0, CL::I1, CL::I2, CL::I3, CL::I4, CL::I5, CL::I6, CL::I7, CL::I8};
+    const int ao[NL] = {CL::A0, CL::A1, CL::A2, CL::A3, CL::A4, CL::A5, CL::A6, CL::A7, CL::A8};
+    const int bo[NL] = {CL::B0, CL::B1, CL::B2, CL::B3, CL::B4, CL::B5, CL::B6, CL::B7, CL::B8};
+    const int gi[NL] = {CL::G0, CL::G1, CL::G2, CL::G3, CL::G4, CL::G5, CL::G6, CL::G7, CL::G8};
     for (int l = l0; l < l1; ++l) {
-        const int P = L.P[l], IN = L.IN[l], n = L.OUT[l] * IN;
+        const int IN = in[l], n = out[l] * IN, OP = outp[l], IP = inp[l];
         const float* src = ae + go.w[l];
-        float* dst = lds + L.w[l];
         for (int e0 = tid; e0 < n; e0 += 8 * nthreads) {
             float v[8];
 #pragma unroll
@@ -67,37 +79,53 @@ __device__ inline void ae_load_lds(float* lds, const AELds& L, const float* __re
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int e = e0 + u * nthreads;
-                if (e < n) { const int o = e / IN; dst[o * P + (e - o * IN)] = v[u]; }
+                if (e < n) {
+                    const int o = e / IN, i = e - o * IN;
+                    lds[ao[l] + (((i >> 2) * OP + o) << 2) + (i & 3)] = v[u];
+                    if (dgrad_images) lds[gi[l] + (((o >> 2) * IP + i) << 2) + (o & 3)] = v[u];
+                }
             }
         }
-        if (tid < L.OUT[l]) lds[L.b[l] + tid] = ae[go.b[l] + tid];
+        if (tid < out[l]) lds[bo[l] + tid] = ae[go.b[l] + tid];
     }
 }
 
 #define ST_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-// Hidden layer for NC interleaved chains: hout[ch][ot] = ELU(W[ch] * hin[ch] + bias[ch]).
-// W[ch]: LDS pointer to the padded matrix of this layer, pitch P; lane (g,c).
-template <int NC, int OTL, int ITL>
-__device__ __forceinline__ void layer_fwd(const float* const (&W)[NC], const float* const (&bias)[NC], const int P,
+// One 16x16 tile of A operands (k-steps r = 0..3) from a forward image: W[o = 16 ot + c][i = 16 it + 4 g + r].
+template <int OUTP>
+__device__ __forceinline__ f32x4 frag_fwd(const float* img, const int ot, const int it, const int g, const int c)
+{
+    return *reinterpret_cast<const f32x4*>(img + (((4 * it + g) * OUTP + 16 * ot + c) << 2));
+}
+// ... from a dgrad image: W[o = 16 ot + 4 g + r][i = 16 it + c].
+template <int INP>
+__device__ __forceinline__ f32x4 frag_dgrad(const float* img, const int ot, const int it, const int g, const int c)
+{
+    return *reinterpret_cast<const f32x4*>(img + (((4 * ot + g) * INP + 16 * it + c) << 2));
+}
+
+// Hidden layer for NC interleaved chains: hout[ch][ot] = ELU(W[ch] * hin[ch] + bias[ch]), weights fetched just in time
+// (the forward kernels run two waves per SIMD, which hides the LDS latency).
+template <int NC, int OTL, int ITL, int OUTP>
+__device__ __forceinline__ void layer_fwd(const float* const (&W)[NC], const float* const (&bias)[NC],
                                           const f32x4 (&hin)[NC][ITL], f32x4 (&hout)[NC][OTL], const int g, const int c)
 {
 #pragma unroll
     for (int ot = 0; ot < OTL; ++ot) {
         f32x4 acc[NC];
 #pragma unroll
-        for (int ch = 0; ch < NC; ++ch)
+        for (int ch = 0; ch < NC; ++ch) acc[ch] = *reinterpret_cast<const f32x4*>(bias[ch] + 16 * ot + 4 * g);   // accumulator starts at the bias
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[ch][r] = bias[ch][16 * ot + 4 * g + r];     // accumulator starts at the bias
+        for (int it = 0; it < ITL; ++it) {
+            f32x4 w[NC];
 #pragma unroll
-        for (int it = 0; it < ITL; ++it)
+            for (int ch = 0; ch < NC; ++ch) w[ch] = frag_fwd<OUTP>(W[ch], ot, it, g, c);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int ch = 0; ch < NC; ++ch) {
-                    const float a = W[ch][(16 * ot + c) * P + 16 * it + 4 * g + r];
-                    acc[ch] = ST_MFMA16(a, hin[ch][it][r], acc[ch]);
-                }
+                for (int ch = 0; ch < NC; ++ch) acc[ch] = ST_MFMA16(w[ch][r], hin[ch][it][r], acc[ch]);
+        }
 #pragma unroll
         for (int ch = 0; ch < NC; ++ch)
 #pragma unroll
@@ -105,10 +133,38 @@ __device__ __forceinline__ void layer_fwd(const float* const (&W)[NC], const flo
     }
 }
 
+// Layer 5 of NC chains: [h4 ; knobs] -> 16 (nn_proc.py:92-96).  The knob block uses its own k-step order (step q: lane
+// group g carries knob 4q + g), so K <= 4 knobs cost one MFMA per chain instead of four.
+template <int NC>
+__device__ __forceinline__ void layer5_fwd(const float* const (&lw)[NC], const f32x4 (&h4)[NC][1], const float (&kn)[4], const int KQ,
+                                           f32x4 (&h5)[NC][1], const int g, const int c)
+{
+    f32x4 acc[NC], w[NC];
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) { acc[ch] = *reinterpret_cast<const f32x4*>(lw[ch] + CL::B4 + 4 * g); w[ch] = frag_fwd<CL::O4>(lw[ch] + CL::A4, 0, 0, g, c); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) acc[ch] = ST_MFMA16(w[ch][r], h4[ch][0][r], acc[ch]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (q < KQ) {
+#pragma unroll
+            for (int ch = 0; ch < NC; ++ch)
+                acc[ch] = ST_MFMA16(lw[ch][CL::A4 + (((4 + q) * CL::O4 + c) << 2) + g], kn[q], acc[ch]);      // W5[o = c][i = 16 + 4q + g]
+        }
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h5[ch][0][r] = elu_f(acc[ch][r]);
+}
+
+#define ST_W2(off_) {lw[0] + (off_), lw[1] + (off_)}
+
 // ------------------------------------------------------------------------------------------ forward
-// Per-group inputs of one lane: layer-1 B operands (t = 4*ks + g, ks < 8 -> T <= 32) and the skip/residual
+// Per-group inputs of one lane: layer-1 B operands (D layout: t = 16 it + 4g + r, T <= 32) and the skip/residual
 // tails (t = T-OT + 4g + r, OT <= 16).  Loaded in one burst and prefetched one group ahead.
-struct FwdIn { float v[2][8]; float tl[2][4]; float kn[4]; };   // kn: knob 4q + g for the (up to 4) knob k-steps of layer 5
+struct FwdIn { f32x4 v[2][2]; float tl[2][4]; float kn[4]; };   // kn: knob 4q + g for the (up to 4) knob k-steps of layer 5
 
 // RAW loads from clamped (always valid) addresses; fwd_mask() zeroes the padding rows / bins / knobs afterwards.  The
 // selects must not sit right behind the loads, and the prefetch must not sit in a conditional block: either makes the
@@ -121,11 +177,13 @@ __device__ __forceinline__ void fwd_load(FwdIn& in, const float* __restrict__ ma
     for (int q = 0; q < 4; ++q) { const int kn = 4 * q + g; in.kn[q] = knobs[(unsigned)b * K + (kn < K ? kn : 0)]; }
     const unsigned base = (unsigned)b * T * F + (fv ? f : 0);
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        const int t = 4 * ks + g;
-        const unsigned o = base + (unsigned)(t < T ? t : 0) * F;
-        in.v[0][ks] = mag[o]; in.v[1][ks] = phs[o];
-    }
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = 16 * it + 4 * g + r;
+            const unsigned o = base + (unsigned)(t < T ? t : 0) * F;
+            in.v[0][it][r] = mag[o]; in.v[1][it][r] = phs[o];
+        }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int to = 4 * g + r;
@@ -138,14 +196,18 @@ __device__ __forceinline__ void fwd_mask(FwdIn& in, const int K, const bool fv, 
 #pragma unroll
     for (int q = 0; q < 4; ++q) in.kn[q] = (4 * q + g) < K ? in.kn[q] : 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) { const bool ok = fv && 4 * ks + g < T; in.v[0][ks] = ok ? in.v[0][ks] : 0.f; in.v[1][ks] = ok ? in.v[1][ks] : 0.f; }
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = fv && 16 * it + 4 * g + r < T;
+            in.v[0][it][r] = ok ? in.v[0][it][r] : 0.f; in.v[1][it][r] = ok ? in.v[1][it][r] : 0.f;
+        }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { const bool ok = fv && 4 * g + r < OT; in.tl[0][r] = ok ? in.tl[0][r] : 0.f; in.tl[1][r] = ok ? in.tl[1][r] : 0.f; }
 }
 
-// grid.x workgroups of NW waves; each wave walks 16-row groups: group id = b*(FP/16) + fg.
-// FAST = true requires T <= 32 and OT <= 16 (register-prefetched inputs); FAST = false is the generic path.
-template <int NW, bool FAST>
+// grid.x workgroups of NW waves; each wave walks 16-row groups: group id = b*(FP/16) + fg.  Requires T <= 32, OT <= 16, K <= 16.
+template <int NW>
 __global__ void __launch_bounds__(NW * 64)
 ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, const float* __restrict__ knobs,
               const float* __restrict__ ae_m, const float* __restrict__ ae_p, const AEOffsets go,
@@ -154,19 +216,16 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
               const int B, const int T, const int OT, const int F, const int K, const int KP, const float expfac)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const AELds L = ae_lds_layout(T, OT, K);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
-    float* lw[2] = {lds, lds + L.total};
-    ae_load_lds(lw[0], L, ae_m, go, tid, NW * 64);
-    ae_load_lds(lw[1], L, ae_p, go, tid, NW * 64);
+    const float* const lw[2] = {lds, lds + CL::FWD_TOTAL};
+    ae_load_lds(lds, ae_m, go, T, OT, K, tid, NW * 64, 0, NL, false);
+    ae_load_lds(lds + CL::FWD_TOTAL, ae_p, go, T, OT, K, tid, NW * 64, 0, NL, false);
     __syncthreads();
 
     const int FP = KP / 2, gpw = FP / 16;              // groups per window
     const int ngroups = B * gpw;
-    const int KS1 = (T + 3) / 4;
     const int KQ = (K + 3) / 4;
-    const int OT9 = (OT + 15) / 16;
     const int gstride = gridDim.x * NW;
     float reg = 0.f;
 
@@ -174,7 +233,7 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     // block-fastest group numbering: the partial last round (ngroups is rarely a multiple of the wave count) then puts ONE
     // extra group on every workgroup instead of a full extra round on the first few workgroups while the rest idle
     int grp = wave * gridDim.x + blockIdx.x;
-    if (FAST && grp < ngroups) {
+    if (grp < ngroups) {
         const int b = grp / gpw, f = (grp - b * gpw) * 16 + c;
         fwd_load(cur, mag, phs, knobs, K, b, f, f < F, T, OT, F, g);
         fwd_mask(cur, K, f < F, T, OT, g);
@@ -183,137 +242,42 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         asm volatile("" ::: "memory");      // keep the (loop-invariant) LDS weight fetches inside the loop: hoisting them spills
         const int b = grp / gpw, f = (grp - b * gpw) * 16 + c;
         const bool fv = f < F;
-        const float* src[2] = {mag + (size_t)b * T * F + f, phs + (size_t)b * T * F + f};
         FwdIn nxt;
         const int gn = grp + gstride < ngroups ? grp + gstride : grp;      // last iteration: harmless reload of this group
         const int bn = gn / gpw, fn = (gn - bn * gpw) * 16 + c;
-        if (FAST) fwd_load(nxt, mag, phs, knobs, K, bn, fn, fn < F, T, OT, F, g);
+        fwd_load(nxt, mag, phs, knobs, K, bn, fn, fn < F, T, OT, F, g);
 
-        // ---- layer 1 (IN = T; B operand: t = 4*ks + g)
-        f32x4 h1[2][4];
-        {
-            f32x4 acc[2][4];
-#pragma unroll
-            for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-                for (int ot = 0; ot < 4; ++ot) acc[ch][ot] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int P1 = L.P[0];
-            if (FAST) {
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    if (ks < KS1) {
-                        const int t = 4 * ks + g;
-#pragma unroll
-                        for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-                            for (int ch = 0; ch < 2; ++ch)
-                                acc[ch][ot] = ST_MFMA16(lw[ch][L.w[0] + (16 * ot + c) * P1 + t], cur.v[ch][ks], acc[ch][ot]);
-                    }
-                }
-            } else {
-                for (int ks = 0; ks < KS1; ++ks) {
-                    const int t = 4 * ks + g;
-                    const bool ok = fv && t < T;
-                    float v[2];
-                    v[0] = ok ? src[0][(size_t)t * F] : 0.f;
-                    v[1] = ok ? src[1][(size_t)t * F] : 0.f;
-#pragma unroll
-                    for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-                        for (int ch = 0; ch < 2; ++ch)
-                            acc[ch][ot] = ST_MFMA16(lw[ch][L.w[0] + (16 * ot + c) * P1 + t], v[ch], acc[ch][ot]);
-                }
-            }
-#pragma unroll
-            for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-                for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        h1[ch][ot][r] = elu_f(acc[ch][ot][r] + lw[ch][L.b[0] + 16 * ot + 4 * g + r]);
-        }
-        // ---- layers 2..4
-        f32x4 h2[2][2], h3[2][1], h4[2][1];
-        {
-            const float* const W[2] = {lw[0] + L.w[1], lw[1] + L.w[1]}; const float* const bb[2] = {lw[0] + L.b[1], lw[1] + L.b[1]};
-            layer_fwd<2, 2, 4>(W, bb, L.P[1], h1, h2, g, c);
-        }
-        {
-            const float* const W[2] = {lw[0] + L.w[2], lw[1] + L.w[2]}; const float* const bb[2] = {lw[0] + L.b[2], lw[1] + L.b[2]};
-            layer_fwd<2, 1, 2>(W, bb, L.P[2], h2, h3, g, c);
-        }
-        {
-            const float* const W[2] = {lw[0] + L.w[3], lw[1] + L.w[3]}; const float* const bb[2] = {lw[0] + L.b[3], lw[1] + L.b[3]};
-            layer_fwd<2, 1, 1>(W, bb, L.P[3], h3, h4, g, c);
-        }
-        // ---- layer 5: [h4 ; knobs] (nn_proc.py:92-96); knob features 16 + 4q + g
-        f32x4 h5[2][1];
-        {
-            f32x4 acc[2];
-            const int P5 = L.P[4];
-#pragma unroll
-            for (int ch = 0; ch < 2; ++ch) acc[ch] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int ch = 0; ch < 2; ++ch)
-                    acc[ch] = ST_MFMA16(lw[ch][L.w[4] + c * P5 + 4 * g + r], h4[ch][0][r], acc[ch]);
-            for (int q = 0; q < KQ; ++q) {
-                const int kn = 4 * q + g;
-                const float kv = (FAST && q < 4) ? cur.kn[q] : (kn < K ? knobs[(size_t)b * K + kn] : 0.f);   // prefetched with the inputs
-#pragma unroll
-                for (int ch = 0; ch < 2; ++ch)
-                    acc[ch] = ST_MFMA16(lw[ch][L.w[4] + c * P5 + 16 + kn], kv, acc[ch]);
-            }
-#pragma unroll
-            for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) h5[ch][0][r] = elu_f(acc[ch][r] + lw[ch][L.b[4] + 4 * g + r]);
-        }
-        // ---- layers 6..8
-        f32x4 h6[2][1], h7[2][2], h8[2][4];
-        {
-            const float* const W[2] = {lw[0] + L.w[5], lw[1] + L.w[5]}; const float* const bb[2] = {lw[0] + L.b[5], lw[1] + L.b[5]};
-            layer_fwd<2, 1, 1>(W, bb, L.P[5], h5, h6, g, c);
-        }
-        {
-            const float* const W[2] = {lw[0] + L.w[6], lw[1] + L.w[6]}; const float* const bb[2] = {lw[0] + L.b[6], lw[1] + L.b[6]};
-            layer_fwd<2, 2, 1>(W, bb, L.P[6], h6, h7, g, c);
-        }
-        {
-            const float* const W[2] = {lw[0] + L.w[7], lw[1] + L.w[7]}; const float* const bb[2] = {lw[0] + L.b[7], lw[1] + L.b[7]};
-            layer_fwd<2, 4, 2>(W, bb, L.P[7], h7, h8, g, c);
-        }
-        // ---- layer 9 (OUT = OT, runtime output tiles) + epilogue (nn_proc.py:115,117,322-326)
+        f32x4 h1[2][4], h2[2][2], h3[2][1], h4[2][1], h5[2][1], h6[2][1], h7[2][2], h8[2][4], e9[2][1];
+        { const float* const W[2] = ST_W2(CL::A0); const float* const bb[2] = ST_W2(CL::B0); layer_fwd<2, 4, 2, CL::O0>(W, bb, cur.v, h1, g, c); }
+        { const float* const W[2] = ST_W2(CL::A1); const float* const bb[2] = ST_W2(CL::B1); layer_fwd<2, 2, 4, CL::O1>(W, bb, h1, h2, g, c); }
+        { const float* const W[2] = ST_W2(CL::A2); const float* const bb[2] = ST_W2(CL::B2); layer_fwd<2, 1, 2, CL::O2>(W, bb, h2, h3, g, c); }
+        { const float* const W[2] = ST_W2(CL::A3); const float* const bb[2] = ST_W2(CL::B3); layer_fwd<2, 1, 1, CL::O3>(W, bb, h3, h4, g, c); }
+        layer5_fwd<2>(lw, h4, cur.kn, KQ, h5, g, c);
+        { const float* const W[2] = ST_W2(CL::A5); const float* const bb[2] = ST_W2(CL::B5); layer_fwd<2, 1, 1, CL::O5>(W, bb, h5, h6, g, c); }
+        { const float* const W[2] = ST_W2(CL::A6); const float* const bb[2] = ST_W2(CL::B6); layer_fwd<2, 2, 1, CL::O6>(W, bb, h6, h7, g, c); }
+        { const float* const W[2] = ST_W2(CL::A7); const float* const bb[2] = ST_W2(CL::B7); layer_fwd<2, 4, 2, CL::O7>(W, bb, h7, h8, g, c); }
+        { const float* const W[2] = ST_W2(CL::A8); const float* const bb[2] = ST_W2(CL::B8); layer_fwd<2, 1, 4, CL::O8>(W, bb, h8, e9, g, c); }
+        // ---- epilogue (nn_proc.py:115,117,322-326)
         const float wf = fv ? expf(expfac * (float)f) : 0.f;     // train.py:115-117 frequency weight
-        for (int o9 = 0; o9 < OT9; ++o9) {
-            f32x4 e9[2][1];
-            const float* const W[2] = {lw[0] + L.w[8] + 16 * o9 * L.P[8], lw[1] + L.w[8] + 16 * o9 * L.P[8]};
-            const float* const bb[2] = {lw[0] + L.b[8] + 16 * o9, lw[1] + L.b[8] + 16 * o9};
-            layer_fwd<2, 1, 4>(W, bb, L.P[8], h8, e9, g, c);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int to = 16 * o9 + 4 * g + r;
-                if (to < OT) {
-                    const size_t ro = (size_t)b * OT + to;
-                    float mh = 0.f, ph = 0.f, sn = 0.f, cs = 1.f;
-                    if (fv) {
-                        const size_t ti = (size_t)(T - OT + to) * F;
-                        const float mt = FAST ? cur.tl[0][r] : src[0][ti];
-                        const float pt = FAST ? cur.tl[1][r] : src[1][ti];
-                        mh = e9[0][0][r] * mt;                         // 'sf' skip-filter
-                        ph = e9[1][0][r] + pt;                         // phase residual
-                        st_sincos(ph, sn, cs);
-                        mag_hat[ro * F + f] = mh;
-                        phs_hat[ro * F + f] = ph;
-                        reg += fabsf(mh * wf);
-                    }
-                    AA[ro * KP + f] = mh * cs;                          // f < FP always: pads get zeros
-                    AA[ro * KP + FP + f] = mh * sn;
+        for (int r = 0; r < 4; ++r) {
+            const int to = 4 * g + r;
+            if (to < OT) {
+                const size_t ro = (size_t)b * OT + to;
+                float mh = 0.f, ph = 0.f, sn = 0.f, cs = 1.f;
+                if (fv) {
+                    mh = e9[0][0][r] * cur.tl[0][r];               // 'sf' skip-filter
+                    ph = e9[1][0][r] + cur.tl[1][r];               // phase residual
+                    st_sincos(ph, sn, cs);
+                    mag_hat[ro * F + f] = mh;
+                    phs_hat[ro * F + f] = ph;
+                    reg += fabsf(mh * wf);
                 }
+                AA[ro * KP + f] = mh * cs;                          // f < FP always: pads get zeros
+                AA[ro * KP + FP + f] = mh * sn;
             }
         }
-        if (FAST) { fwd_mask(nxt, K, fn < F, T, OT, g); cur = nxt; }
+        fwd_mask(nxt, K, fn < F, T, OT, g); cur = nxt;
     }
     if (reg_partial) {
         reg = wave_sum(reg);
@@ -333,12 +297,11 @@ ae_inner_fwd_kernel(const float* __restrict__ H1m, const float* __restrict__ H1p
                     float* __restrict__ H8m, float* __restrict__ H8p, const int B, const int F, const int K, const int KP)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const AELds L = ae_lds_layout(16, 16, K);          // layers 0 and 8 get (unused) minimal regions
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
-    float* lw[2] = {lds, lds + L.total};
-    ae_load_lds(lw[0], L, ae_m, go, tid, NW * 64, 1, 8);
-    ae_load_lds(lw[1], L, ae_p, go, tid, NW * 64, 1, 8);
+    const float* const lw[2] = {lds, lds + CL::FWD_TOTAL};
+    ae_load_lds(lds, ae_m, go, 16, 16, K, tid, NW * 64, 1, 8, false);
+    ae_load_lds(lds + CL::FWD_TOTAL, ae_p, go, 16, 16, K, tid, NW * 64, 1, 8, false);
     __syncthreads();
     const int FP = KP / 2, gpw = FP / 16, ngroups = B * gpw;
     const size_t R = (size_t)B * FP;
@@ -356,55 +319,17 @@ ae_inner_fwd_kernel(const float* __restrict__ H1m, const float* __restrict__ H1p
             for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h1[ch][ot][r] = Hin[ch][(size_t)(16 * ot + 4 * g + r) * R + col];
-        f32x4 h2[2][2], h3[2][1], h4[2][1];
-        {
-            const float* const W[2] = {lw[0] + L.w[1], lw[1] + L.w[1]}; const float* const bb[2] = {lw[0] + L.b[1], lw[1] + L.b[1]};
-            layer_fwd<2, 2, 4>(W, bb, L.P[1], h1, h2, g, c);
-        }
-        {
-            const float* const W[2] = {lw[0] + L.w[2], lw[1] + L.w[2]}; const float* const bb[2] = {lw[0] + L.b[2], lw[1] + L.b[2]};
-            layer_fwd<2, 1, 2>(W, bb, L.P[2], h2, h3, g, c);
-        }
-        {
-            const float* const W[2] = {lw[0] + L.w[3], lw[1] + L.w[3]}; const float* const bb[2] = {lw[0] + L.b[3], lw[1] + L.b[3]};
-            layer_fwd<2, 1, 1>(W, bb, L.P[3], h3, h4, g, c);
-        }
-        f32x4 h5[2][1];
-        {
-            f32x4 acc[2];
-            const int P5 = L.P[4];
+        float kn[4];
 #pragma unroll
-            for (int ch = 0; ch < 2; ++ch) acc[ch] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int ch = 0; ch < 2; ++ch)
-                    acc[ch] = ST_MFMA16(lw[ch][L.w[4] + c * P5 + 4 * g + r], h4[ch][0][r], acc[ch]);
-            for (int q = 0; q < KQ; ++q) {
-                const int kn = 4 * q + g;
-                const float kv = kn < K ? knobs[(size_t)b * K + kn] : 0.f;
-#pragma unroll
-                for (int ch = 0; ch < 2; ++ch)
-                    acc[ch] = ST_MFMA16(lw[ch][L.w[4] + c * P5 + 16 + kn], kv, acc[ch]);
-            }
-#pragma unroll
-            for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) h5[ch][0][r] = elu_f(acc[ch][r] + lw[ch][L.b[4] + 4 * g + r]);
-        }
-        f32x4 h6[2][1], h7[2][2], h8[2][4];
-        {
-            const float* const W[2] = {lw[0] + L.w[5], lw[1] + L.w[5]}; const float* const bb[2] = {lw[0] + L.b[5], lw[1] + L.b[5]};
-            layer_fwd<2, 1, 1>(W, bb, L.P[5], h5, h6, g, c);
-        }
-        {
-            const float* const W[2] = {lw[0] + L.w[6], lw[1] + L.w[6]}; const float* const bb[2] = {lw[0] + L.b[6], lw[1] + L.b[6]};
-            layer_fwd<2, 2, 1>(W, bb, L.P[6], h6, h7, g, c);
-        }
-        {
-            const float* const W[2] = {lw[0] + L.w[7], lw[1] + L.w[7]}; const float* const bb[2] = {lw[0] + L.b[7], lw[1] + L.b[7]};
-            layer_fwd<2, 4, 2>(W, bb, L.P[7], h7, h8, g, c);
-        }
+        for (int q = 0; q < 4; ++q) { const int k = 4 * q + g; const float x = knobs[(size_t)b * K + (k < K ? k : 0)]; kn[q] = k < K ? x : 0.f; }
+        f32x4 h2[2][2], h3[2][1], h4[2][1], h5[2][1], h6[2][1], h7[2][2], h8[2][4];
+        { const float* const W[2] = ST_W2(CL::A1); const float* const bb[2] = ST_W2(CL::B1); layer_fwd<2, 2, 4, CL::O1>(W, bb, h1, h2, g, c); }
+        { const float* const W[2] = ST_W2(CL::A2); const float* const bb[2] = ST_W2(CL::B2); layer_fwd<2, 1, 2, CL::O2>(W, bb, h2, h3, g, c); }
+        { const float* const W[2] = ST_W2(CL::A3); const float* const bb[2] = ST_W2(CL::B3); layer_fwd<2, 1, 1, CL::O3>(W, bb, h3, h4, g, c); }
+        layer5_fwd<2>(lw, h4, kn, KQ, h5, g, c);
+        { const float* const W[2] = ST_W2(CL::A5); const float* const bb[2] = ST_W2(CL::B5); layer_fwd<2, 1, 1, CL::O5>(W, bb, h5, h6, g, c); }
+        { const float* const W[2] = ST_W2(CL::A6); const float* const bb[2] = ST_W2(CL::B6); layer_fwd<2, 2, 1, CL::O6>(W, bb, h6, h7, g, c); }
+        { const float* const W[2] = ST_W2(CL::A7); const float* const bb[2] = ST_W2(CL::B7); layer_fwd<2, 4, 2, CL::O7>(W, bb, h7, h8, g, c); }
         const bool fv = f < F;
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch)
@@ -414,22 +339,21 @@ ae_inner_fwd_kernel(const float* __restrict__ H1m, const float* __restrict__ H1p
                 for (int r = 0; r < 4; ++r) Hout[ch][(size_t)(16 * ot + 4 * g + r) * R + col] = fv ? h8[ch][ot][r] : 0.f;
     }
 }
+#undef ST_W2
 
 // ========================================================================================== backward
-// blockIdx.y selects the autoencoder (0 = magnitude 'sf', 1 = phase); one workgroup = NW waves, two waves per SIMD.
-// Per 16-row group a wave
+// blockIdx.y selects the autoencoder (0 = magnitude 'sf', 1 = phase); one workgroup = NW waves, ONE wave per SIMD (the 144
+// persistent weight-gradient accumulators + the activations fill the 512-register budget).  Per 16-row group a wave
 //   1. recomputes the forward chain, keeping every post-ELU activation in registers in D layout (68 regs);
 //   2. forms d out (polar->rect backward of nn_proc.py:322-326 + the L1 term of loss_functions.py:36);
-//   3. walks the layers backwards.  The data gradient continues the D-layout chain (A = W^T fragments).  The
-//      weight gradient dW_l = sum_rows da_l (x) h_{l-1} needs both operands with ROWS on the MFMA k index, i.e.
-//      transposed.  Instead of LDS round trips the transposed copies come from the SECOND MFMA ORIENTATION
-//          D[row][o] = sum_i H[row][i] * W^T[i][o]      (A = activations in D layout, B = the SAME weight fragment)
-//      whose result layout (lane (g,c), reg r <-> row 4g+r, feature 16*tile+c) is exactly the wgrad operand layout;
-//      likewise da^T_{l-1} = (da_l W_l)^T.  ~1.6x the MFMAs, zero transposes, activations stay in registers.
-//   4. the 16x16 tiles of dW_l are added into an LDS copy of the gradient with ds_add_f32 (one per workgroup) --
-//      no persistent accumulator registers, so two waves per SIMD hide each other's latencies.  (The summation
-//      order of these LDS atomics is not deterministic: last-bit run-to-run differences in the AE gradients.)
-// At the end the workgroup stores its partial dW/db (packed like the parameters); ae_grad_reduce_kernel sums them.
+//   3. walks the layers backwards.  The data gradient continues the D-layout chain (A = W^T fragments from the dgrad
+//      images).  The weight gradient dW_l = sum_rows da_l (x) h_{l-1} needs both operands with ROWS on the MFMA k index
+//      ("T layout": lane (g,c), reg r <-> row 4g + r, feature 16*tile + c): they come from wave-private LDS transposes
+//      (to_T: one ds_write_b128 + four ds_read_b32 per tile, no barrier);
+//   4. accumulates the 36 dW tiles and the bias row sums in registers for the whole kernel.
+// At the end the four waves add their accumulators into an LDS gradient image IN WAVE ORDER with plain adds (fixed
+// summation order: run-to-run identical bits), over the no-longer-needed forward image, and the workgroup stores its
+// partial dW/db (packed like the parameters); ae_grad_reduce_kernel sums the workgroups.
 constexpr int SP = 20;                 // scratch pitch (floats): 16 rows + 4, keeps rows 16-B aligned
 
 // Diagnostics only (st_set_debug bit 8): wave 0 of workgroup (0,0) accumulates s_memtime deltas per kernel stage.
@@ -442,81 +366,40 @@ __device__ unsigned long long g_ae_stage_cycles[32];
 
 // ---------------------------------------------------------------------------------------------------------
 // Weight fragments in registers.  Left to itself the compiler issues each MFMA's LDS weight fetch just before
-// the MFMA (one s_waitcnt per MFMA: the AE kernels were LDS-latency-bound).  These helpers burst-load every
-// fragment of a layer stage into a register array; the caller places a scheduling fence between the burst and
+// the MFMA (one s_waitcnt per MFMA: with one wave per SIMD the kernel was LDS-latency-bound).  These helpers burst-load
+// every fragment of a layer stage into a register array; the caller places a scheduling fence between the burst and
 // the MFMAs, so a stage pays one LDS round trip instead of one per MFMA.
-// forward-order fragment (ot, it, r):  W[o = 16 ot + c][i = 16 it + 4 g + r]
-template <int OTL, int ITL>
-__device__ __forceinline__ void frags_fwd(float (&fr)[OTL * ITL * 4], const float* W, const int P, const int g, const int c)
+template <int OTL, int ITL, int OUTP>
+__device__ __forceinline__ void frags_fwd(f32x4 (&fr)[OTL * ITL], const float* img, const int g, const int c)
 {
 #pragma unroll
     for (int ot = 0; ot < OTL; ++ot)
 #pragma unroll
-        for (int it = 0; it < ITL; ++it)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) fr[(ot * ITL + it) * 4 + r] = W[(16 * ot + c) * P + 16 * it + 4 * g + r];
+        for (int it = 0; it < ITL; ++it) fr[ot * ITL + it] = frag_fwd<OUTP>(img, ot, it, g, c);
 }
-// dgrad-order fragment (it, ot, r):  W[o = 16 ot + 4 g + r][i = 16 it + c]
-template <int OTL, int ITL>
-__device__ __forceinline__ void frags_dgrad(float (&fr)[OTL * ITL * 4], const float* W, const int P, const int g, const int c)
+template <int OTL, int ITL, int INP>
+__device__ __forceinline__ void frags_dgrad(f32x4 (&fr)[ITL * OTL], const float* img, const int g, const int c)
 {
 #pragma unroll
     for (int it = 0; it < ITL; ++it)
 #pragma unroll
-        for (int ot = 0; ot < OTL; ++ot)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) fr[(it * OTL + ot) * 4 + r] = W[(16 * ot + 4 * g + r) * P + 16 * it + c];
+        for (int ot = 0; ot < OTL; ++ot) fr[it * OTL + ot] = frag_dgrad<INP>(img, ot, it, g, c);
 }
 #define ST_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 template <int OTL, int ITL>
-__device__ __forceinline__ void fwdD_fr(const float (&fr)[OTL * ITL * 4], const float* bias, const f32x4 (&hin)[ITL],
+__device__ __forceinline__ void fwdD_fr(const f32x4 (&fr)[OTL * ITL], const float* bias, const f32x4 (&hin)[ITL],
                                         f32x4 (&hout)[OTL], const int g)
 {
 #pragma unroll
     for (int ot = 0; ot < OTL; ++ot) {
-        const float4 bq = *reinterpret_cast<const float4*>(bias + 16 * ot + 4 * g);   // accumulator starts at the bias (D layout: o = 16 ot + 4 g + r)
-        f32x4 acc = (f32x4){bq.x, bq.y, bq.z, bq.w};
+        f32x4 acc = *reinterpret_cast<const f32x4*>(bias + 16 * ot + 4 * g);   // accumulator starts at the bias (D layout: o = 16 ot + 4 g + r)
 #pragma unroll
         for (int it = 0; it < ITL; ++it)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc = ST_MFMA16(fr[(ot * ITL + it) * 4 + r], hin[it][r], acc);
+            for (int r = 0; r < 4; ++r) acc = ST_MFMA16(fr[ot * ITL + it][r], hin[it][r], acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) hout[ot][r] = elu_f(acc[r]);
-    }
-}
-template <int OTL, int ITL>
-__device__ __forceinline__ void fwdT_fr(const float (&fr)[OTL * ITL * 4], const float* bias, const f32x4 (&hin)[ITL],
-                                        f32x4 (&houtT)[OTL], const int c)
-{
-#pragma unroll
-    for (int ot = 0; ot < OTL; ++ot) {
-        const float bv = bias[16 * ot + c];                    // T layout: feature 16 ot + c in every register
-        f32x4 acc = (f32x4){bv, bv, bv, bv};
-#pragma unroll
-        for (int it = 0; it < ITL; ++it)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc = ST_MFMA16(hin[it][r], fr[(ot * ITL + it) * 4 + r], acc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) houtT[ot][r] = elu_f(acc[r]);
-    }
-}
-// both data-gradient orientations from one fragment set
-template <int OTL, int ITL>
-__device__ __forceinline__ void dgrad_fr(const float (&fr)[OTL * ITL * 4], const f32x4 (&da)[OTL], f32x4 (&dh)[ITL], f32x4 (&dhT)[ITL])
-{
-#pragma unroll
-    for (int it = 0; it < ITL; ++it) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, accT = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ot = 0; ot < OTL; ++ot)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float w = fr[(it * OTL + ot) * 4 + r];
-                acc = ST_MFMA16(w, da[ot][r], acc);
-                accT = ST_MFMA16(da[ot][r], w, accT);
-            }
-        dh[it] = acc; dhT[it] = accT;
     }
 }
 // D layout -> T layout of TL 16x16 tiles through a wave-private LDS scratch ([tile][row 16][feature 16, pitch 20]): one
@@ -527,8 +410,7 @@ template <int TL>
 __device__ __forceinline__ void to_T(float* scr, const f32x4 (&d)[TL], f32x4 (&t)[TL], const int g, const int c)
 {
 #pragma unroll
-    for (int k = 0; k < TL; ++k)
-        *reinterpret_cast<float4*>(scr + k * 320 + c * 20 + 4 * g) = make_float4(d[k][0], d[k][1], d[k][2], d[k][3]);
+    for (int k = 0; k < TL; ++k) *reinterpret_cast<f32x4*>(scr + k * 320 + c * 20 + 4 * g) = d[k];
 #pragma unroll
     for (int k = 0; k < TL; ++k)
 #pragma unroll
@@ -536,7 +418,7 @@ __device__ __forceinline__ void to_T(float* scr, const f32x4 (&d)[TL], f32x4 (&t
 }
 
 template <int OTL, int ITL>
-__device__ __forceinline__ void dgradD_fr(const float (&fr)[OTL * ITL * 4], const f32x4 (&da)[OTL], f32x4 (&dh)[ITL])
+__device__ __forceinline__ void dgradD_fr(const f32x4 (&fr)[ITL * OTL], const f32x4 (&da)[OTL], f32x4 (&dh)[ITL])
 {
 #pragma unroll
     for (int it = 0; it < ITL; ++it) {
@@ -544,79 +426,8 @@ __device__ __forceinline__ void dgradD_fr(const float (&fr)[OTL * ITL * 4], cons
 #pragma unroll
         for (int ot = 0; ot < OTL; ++ot)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc = ST_MFMA16(fr[(it * OTL + ot) * 4 + r], da[ot][r], acc);
+            for (int r = 0; r < 4; ++r) acc = ST_MFMA16(fr[it * OTL + ot][r], da[ot][r], acc);
         dh[it] = acc;
-    }
-}
-
-// T-layout forward of one layer from the D-layout activations of the previous one:
-// houtT[ot][r] = ELU(a)[row 4g+r][feature 16 ot + c]
-template <int OTL, int ITL>
-__device__ __forceinline__ void layer_fwdT(const float* W, const float* bias, const int P, const f32x4 (&hin)[ITL],
-                                           f32x4 (&houtT)[OTL], const int g, const int c)
-{
-#pragma unroll
-    for (int ot = 0; ot < OTL; ++ot) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int it = 0; it < ITL; ++it)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc = ST_MFMA16(hin[it][r], W[(16 * ot + c) * P + 16 * it + 4 * g + r], acc);
-        const float bv = bias[16 * ot + c];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) houtT[ot][r] = elu_f(acc[r] + bv);
-    }
-}
-
-// D-layout forward, single chain
-template <int OTL, int ITL>
-__device__ __forceinline__ void layer_fwdD(const float* W, const float* bias, const int P, const f32x4 (&hin)[ITL],
-                                           f32x4 (&hout)[OTL], const int g, const int c)
-{
-#pragma unroll
-    for (int ot = 0; ot < OTL; ++ot) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int it = 0; it < ITL; ++it)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc = ST_MFMA16(W[(16 * ot + c) * P + 16 * it + 4 * g + r], hin[it][r], acc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hout[ot][r] = elu_f(acc[r] + bias[16 * ot + 4 * g + r]);
-    }
-}
-
-// D-layout data gradient: dh[it] = sum_o W[o][16 it + c-th feature] * da[o]   (A = W^T fragments)
-template <int OTL, int ITL>
-__device__ __forceinline__ void layer_dgrad(const float* W, const int P, const f32x4 (&da)[OTL], f32x4 (&dh)[ITL],
-                                            const int g, const int c)
-{
-#pragma unroll
-    for (int it = 0; it < ITL; ++it) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ot = 0; ot < OTL; ++ot)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc = ST_MFMA16(W[(16 * ot + 4 * g + r) * P + 16 * it + c], da[ot][r], acc);
-        dh[it] = acc;
-    }
-}
-// T-layout data gradient: dhT[it][r] = (da W)[row 4g+r][feature 16 it + c]   (A = da in D layout, B = same fragments)
-template <int OTL, int ITL>
-__device__ __forceinline__ void layer_dgradT(const float* W, const int P, const f32x4 (&da)[OTL], f32x4 (&dhT)[ITL],
-                                             const int g, const int c)
-{
-#pragma unroll
-    for (int it = 0; it < ITL; ++it) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ot = 0; ot < OTL; ++ot)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc = ST_MFMA16(da[ot][r], W[(16 * ot + 4 * g + r) * P + 16 * it + c], acc);
-        dhT[it] = acc;
     }
 }
 
@@ -629,27 +440,8 @@ __device__ __forceinline__ void mul_elu_grad(f32x4 (&d)[TL], const f32x4 (&h)[TL
         for (int r = 0; r < 4; ++r) d[t][r] = __builtin_fmaf(d[t][r], fminf(h[t][r], 0.f), d[t][r]);   // d * ELU'(a) = d * (1 + min(h, 0)): v_min + v_fma
 }
 
-// dW_l tile(ot,it) += sum_rows daT[ot] (x) hT[it]; result (D layout: o = 16ot+4g+r, i = 16it+c) -> LDS atomics.
-// db_l (lane c <-> o = 16 ot + c) accumulates the row sums of daT in registers.
-template <int OTL, int ITL>
-__device__ __forceinline__ void wgrad_lds(float* dW, const int P, const f32x4 (&daT)[OTL], const f32x4 (&hT)[ITL],
-                                          float* db, const int g, const int c)
-{
-#pragma unroll
-    for (int ot = 0; ot < OTL; ++ot) {
-#pragma unroll
-        for (int it = 0; it < ITL; ++it) {
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc = ST_MFMA16(daT[ot][r], hT[it][r], acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(dW + (16 * ot + 4 * g + r) * P + 16 * it + c, acc[r]);
-        }
-        atomicAdd(db + 16 * ot + c, (daT[ot][0] + daT[ot][1]) + (daT[ot][2] + daT[ot][3]));   // bias gradient: row sums (4 lane groups hit the same word)
-    }
-}
-
-// Register-accumulator form: dW tiles and the bias row sums persist in registers for the whole kernel.
+// dW_l tile(ot,it) += sum_rows daT[ot] (x) hT[it] (result in D layout: o = 16ot+4g+r, i = 16it+c); db_l (lane c <-> o = 16 ot + c)
+// accumulates the row sums of daT.  Tiles and sums persist in registers for the whole kernel.
 template <int OTL, int ITL>
 __device__ __forceinline__ void wgrad_reg(f32x4 (&dW)[OTL][ITL], float (&db)[OTL], const f32x4 (&daT)[OTL], const f32x4 (&hT)[ITL])
 {
@@ -662,55 +454,40 @@ __device__ __forceinline__ void wgrad_reg(f32x4 (&dW)[OTL][ITL], float (&db)[OTL
         db[ot] += (daT[ot][0] + daT[ot][1]) + (daT[ot][2] + daT[ot][3]);
     }
 }
-// Flush of one wave's persistent accumulators into the workgroup's LDS gradient copy: plain read-modify-write -- the
-// caller serialises the waves (wave 0, barrier, wave 1, ...) so the summation order, hence every bit, is fixed.
-template <int OTL, int ITL>
-__device__ __forceinline__ void dw_flush(float* dW, const int P, const f32x4 (&acc)[OTL][ITL], const int g, const int c)
+// Flush of one wave's persistent accumulators into the workgroup's LDS gradient image ([o][INP] row-major): the caller
+// serialises the waves (wave 0 stores, barrier, wave 1 adds, ...) so the summation order, hence every bit, is fixed.
+template <int OTL, int ITL, int INP, bool FIRST>
+__device__ __forceinline__ void dw_flush(float* dW, const f32x4 (&acc)[OTL][ITL], const int g, const int c)
 {
 #pragma unroll
     for (int ot = 0; ot < OTL; ++ot)
 #pragma unroll
         for (int it = 0; it < ITL; ++it)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dW[(16 * ot + 4 * g + r) * P + 16 * it + c] += acc[ot][it][r];
+            for (int r = 0; r < 4; ++r) {
+                float* p = dW + (16 * ot + 4 * g + r) * INP + 16 * it + c;
+                if constexpr (FIRST) *p = acc[ot][it][r]; else *p += acc[ot][it][r];
+            }
 }
-
-template <int OTL>
+template <int OTL, bool FIRST>
 __device__ __forceinline__ void db_flush(float* dst, float (&db)[OTL], const int g, const int c)
 {
 #pragma unroll
     for (int ot = 0; ot < OTL; ++ot) {
         float v = db[ot];
         v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-        if (g == 0) dst[16 * ot + c] += v;
+        if (g == 0) { if constexpr (FIRST) dst[16 * ot + c] = v; else dst[16 * ot + c] += v; }
     }
 }
 
-// Compile-time LDS layout of the (T <= 32, OT <= 16, K <= 16) instantiation: every padded dimension is fixed
-// (IN_1 -> 32, OUT_9 -> 16, IN_5 -> 32), so all offsets / pitches fold into instruction immediates.
-struct CL {
-    static constexpr int P0 = 33, P1 = 65, P2 = 33, P3 = 17, P4 = 33, P5 = 17, P6 = 17, P7 = 33, P8 = 65;
-    static constexpr int W0 = 0,            B0 = W0 + 64 * P0;
-    static constexpr int W1 = B0 + 64,      B1 = W1 + 32 * P1;
-    static constexpr int W2 = B1 + 32,      B2 = W2 + 16 * P2;
-    static constexpr int W3 = B2 + 16,      B3 = W3 + 16 * P3;
-    static constexpr int W4 = B3 + 16,      B4 = W4 + 16 * P4;
-    static constexpr int W5 = B4 + 16,      B5 = W5 + 16 * P5;
-    static constexpr int W6 = B5 + 16,      B6 = W6 + 32 * P6;
-    static constexpr int W7 = B6 + 32,      B7 = W7 + 64 * P7;
-    static constexpr int W8 = B7 + 64,      B8 = W8 + 16 * P8;
-    static constexpr int TOTAL = (B8 + 16 + 3) / 4 * 4;
-};
-#define ST_SCHED_FENCE() do { if constexpr (!REG) __builtin_amdgcn_sched_barrier(0); } while (0)
-
-// Supported geometry of this instantiation: T <= 32, OT <= 16, K <= 16.
 // INNER (wide geometries, st_ae_wide.h): only layers 2..8 -- layers 1 and 9 are feature-major GEMMs.  Pointer roles then:
 //   mag / phs         -> H1 [64][R] of the two nets (layer-1 outputs, R = B*FP columns)
 //   mag_hat / phs_hat -> dH8 [64][R] = W9^T dA9 (the kernel applies ELU'(h8) itself: h8 is recomputed)
 //   dmag / dphs       -> dA1 [64][R] = (W2^T dA2) * ELU'(h1), consumed by the layer-1 weight/data-gradient GEMMs
 // and the partial gradients of layers 1 and 9 stay zero.
-template <int NW, bool REG, bool TIMED, bool INNER = false>   // REG: persistent register accumulators (1 wave/SIMD); else per-group LDS atomics (2 waves/SIMD)
-__global__ void __launch_bounds__(NW * 64, REG ? 1 : 2)
+constexpr int AE_BWD_SCR = (32 + 16 + 16) * SP + 2 * 4 * 320;      // per wave: V, Y, TAIL rows + two 4-tile transpose scratches (to_T)
+template <int NW, bool TIMED, bool INNER = false>
+__global__ void __launch_bounds__(NW * 64, 1)
 ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, const float* __restrict__ knobs,
               const float* __restrict__ ae_m, const float* __restrict__ ae_p, const AEOffsets go, const int PG,
               const float* __restrict__ mag_hat, const float* __restrict__ phs_hat, const float* __restrict__ dAA,
@@ -725,20 +502,16 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     const int ae = blockIdx.y;
     const bool timing = TIMED && (dbg & 256) && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x >> 6) == 0;
     unsigned long long t0_ = timing ? __builtin_amdgcn_s_memtime() : 0ull;
-    const AELds L = INNER ? ae_lds_layout(32, 16, K) : ae_lds_layout(T, OT, K);       // INNER: the CL layout with layers 1 / 9 left empty
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
-    float* lw = lds;                                   // weights (+bias), padded
-    float* dwl = lds + CL::TOTAL;                      // gradient accumulator, same layout
+    float* lw = lds;                                   // forward images + biases, then the dgrad images (CL)
     // wave-private scratch: V[32*SP] (input rows, transposed), Y[16*SP] (d a9 transposed), TAIL[16*SP]
-    constexpr int SCR = (32 + 16 + 16) * SP + 2 * 4 * 320;      // + two 4-tile transpose scratches (to_T)
-    float* Vs = lds + 2 * CL::TOTAL + wave * SCR;
+    float* Vs = lds + CL::BWD_TOTAL + wave * AE_BWD_SCR;
     float* Ys = Vs + 32 * SP;
     float* Ts = Ys + 16 * SP;
     float* XH = Ts + 16 * SP;                          // transposes of activations
     float* XD = XH + 4 * 320;                          // transposes of activation gradients
-    for (int e = tid; e < CL::TOTAL; e += NW * 64) dwl[e] = 0.f;
-    ae_load_lds(lw, L, ae ? ae_p : ae_m, go, tid, NW * 64, INNER ? 1 : 0, INNER ? 8 : NL);
+    ae_load_lds(lw, ae ? ae_p : ae_m, go, INNER ? 16 : T, INNER ? 16 : OT, K, tid, NW * 64, INNER ? 1 : 0, INNER ? 8 : NL, true);
     __syncthreads();
 
     const float* vin = ae ? phs : mag;
@@ -746,16 +519,9 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     float* dvout = ae ? dphs : dmag;
     const int FP = KP / 2, gpw = FP / 16;
     const int ngroups = B * gpw;
-    const int KS1 = (T + 3) / 4;
     const int gstride = gridDim.x * NW;
 
-    const float* const Wl[NL] = {lw + CL::W0, lw + CL::W1, lw + CL::W2, lw + CL::W3, lw + CL::W4, lw + CL::W5, lw + CL::W6, lw + CL::W7, lw + CL::W8};
-    const float* const Bl[NL] = {lw + CL::B0, lw + CL::B1, lw + CL::B2, lw + CL::B3, lw + CL::B4, lw + CL::B5, lw + CL::B6, lw + CL::B7, lw + CL::B8};
-    float* const Dl[NL] = {dwl + CL::W0, dwl + CL::W1, dwl + CL::W2, dwl + CL::W3, dwl + CL::W4, dwl + CL::W5, dwl + CL::W6, dwl + CL::W7, dwl + CL::W8};
-    float* const db1 = dwl + CL::B0; float* const db2 = dwl + CL::B1; float* const db3 = dwl + CL::B2;
-    float* const db4 = dwl + CL::B3; float* const db5 = dwl + CL::B4; float* const db6 = dwl + CL::B5;
-    float* const db7 = dwl + CL::B6; float* const db8 = dwl + CL::B7; float* const db9 = dwl + CL::B8;
-    // REG mode: 36 persistent 16x16 dW tiles (144 registers) + 17 bias-gradient registers
+    // 36 persistent 16x16 dW tiles (144 registers) + 17 bias-gradient registers
     f32x4 rW1[4][2], rW2[2][4], rW3[1][2], rW4[1][1], rW5[1][2], rW6[1][1], rW7[2][1], rW8[4][2], rW9[1][4];
     float rb1[4], rb2[2], rb3[1], rb4[1], rb5[1], rb6[1], rb7[2], rb8[4], rb9[1];
 #define ST_ZT(x, A, Bq) { _Pragma("unroll") for (int a_ = 0; a_ < A; ++a_) _Pragma("unroll") for (int b_ = 0; b_ < Bq; ++b_) x[a_][b_] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -765,27 +531,31 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
 #undef ST_ZT
 #undef ST_ZB
 
-    // input rows of the first group (prefetched one group ahead afterwards): t = 4 ks + g, row c
-    float vr[8];
+    // input rows of the first group (prefetched one group ahead afterwards), D layout: t = 16 it + 4g + r, row c
+    f32x4 vr[2];
     int grp = blockIdx.x * NW + wave;
     // Input rows of group gq as RAW loads from clamped (always valid) addresses; mask_v() zeroes the padding
     // rows/bins afterwards.  Keeping the select out of the load sequence (and the whole prefetch out of a
     // conditional block) matters: the `if (next < ngroups) { x = load; dst = ok ? x : 0; }` form compiled to
     // eight load / s_waitcnt vmcnt(0) pairs, i.e. eight serialized memory round trips per group.
-    auto load_v = [&](int gq, float (&dst)[8]) {
+    auto load_v = [&](int gq, f32x4 (&dst)[2]) {
         const int bq = gq / gpw, fq = (gq - bq * gpw) * 16 + c;
         const int fc = fq < F ? fq : 0;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const int t = 4 * ks + g;
-            dst[ks] = vin[((unsigned)bq * T + (t < T ? t : 0)) * F + fc];
-        }
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = 16 * it + 4 * g + r;
+                dst[it][r] = vin[((unsigned)bq * T + (t < T ? t : 0)) * F + fc];
+            }
     };
-    auto mask_v = [&](int gq, float (&dst)[8]) {
+    auto mask_v = [&](int gq, f32x4 (&dst)[2]) {
         const int bq = gq / gpw, fq = (gq - bq * gpw) * 16 + c;
         const bool ok0 = fq < F;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) dst[ks] = (ok0 && 4 * ks + g < T) ? dst[ks] : 0.f;
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[it][r] = (ok0 && 16 * it + 4 * g + r < T) ? dst[it][r] : 0.f;
     };
     if constexpr (!INNER) { if (grp < ngroups) { load_v(grp, vr); mask_v(grp, vr); } }
     const unsigned Rw = (unsigned)B * FP;              // INNER: columns of the feature-major buffers
@@ -821,8 +591,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         }
         }
         // INNER: layer-1 outputs in both layouts and the gradient entering layer 8's output, straight from the
-        // feature-major buffers (D layout: feature 16 tile + 4g + r at column col0 + c; T layout: feature 16 tile + c at
-        // columns col0 + 4g .. + 3 = one aligned float4)
+        // feature-major buffers (D layout: feature 16 tile + 4g + r at column col0 + c)
         f32x4 h1in[4], dh8[4];
         if constexpr (INNER) {
             const unsigned col0 = (unsigned)b * FP + (unsigned)(grp - b * gpw) * 16;
@@ -836,11 +605,11 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             }
         }
         // knob values: D-layout feature tile (16 + 4g + r) and T-layout feature lane (16 + c)
-        f32x4 kn[1]; float knT;
+        f32x4 kn; float knT;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int kidx = 4 * g + r; const float x = knobs[(unsigned)b * K + (kidx < K ? kidx : 0)]; kn[0][r] = kidx < K ? x : 0.f; }
+        for (int r = 0; r < 4; ++r) { const int kidx = 4 * g + r; const float x = knobs[(unsigned)b * K + (kidx < K ? kidx : 0)]; kn[r] = kidx < K ? x : 0.f; }
         { const float x = knobs[(unsigned)b * K + (c < K ? c : 0)]; knT = c < K ? x : 0.f; }
-        float vn[8];
+        f32x4 vn[2];
         const int gnext = grp + gstride < ngroups ? grp + gstride : grp;      // last iteration: harmless reload of this group
         if constexpr (!INNER) load_v(gnext, vn);
         ST_T(0);
@@ -851,57 +620,32 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
 #pragma unroll
             for (int ot = 0; ot < 4; ++ot) h1[ot] = h1in[ot];
         } else {
-            f32x4 acc[4];
+            f32x4 fr[4 * 2]; frags_fwd<4, 2, CL::O0>(fr, lw + CL::A0, g, c);
 #pragma unroll
-            for (int ot = 0; ot < 4; ++ot) acc[ot] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int P1 = CL::P0;
-            float ff[4 * 8];
+            for (int it = 0; it < 2; ++it)
 #pragma unroll
-            for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) ff[ot * 8 + ks] = Wl[0][(16 * ot + c) * P1 + 4 * ks + g];
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) Vs[(4 * ks + g) * SP + c] = vr[ks];   // [feature t][row c]: read back transposed for the layer-1 wgrad
+                for (int r = 0; r < 4; ++r) Vs[(16 * it + 4 * g + r) * SP + c] = vr[it][r];   // [feature t][row c]: read back transposed for the layer-1 wgrad
             ST_FENCE();
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
-                if (ks < KS1) {
-#pragma unroll
-                    for (int ot = 0; ot < 4; ++ot) acc[ot] = ST_MFMA16(ff[ot * 8 + ks], vr[ks], acc[ot]);
-                }
-#pragma unroll
-            for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) h1[ot][r] = elu_f(acc[ot][r] + Bl[0][16 * ot + 4 * g + r]);
+            fwdD_fr<4, 2>(fr, lw + CL::B0, vr, h1, g);
         }
         ST_T(1);
-        { float fr[2 * 4 * 4]; frags_fwd<2, 4>(fr, Wl[1], CL::P1, g, c); ST_FENCE(); fwdD_fr<2, 4>(fr, Bl[1], h1, h2, g); }
+        { f32x4 fr[2 * 4]; frags_fwd<2, 4, CL::O1>(fr, lw + CL::A1, g, c); ST_FENCE(); fwdD_fr<2, 4>(fr, lw + CL::B1, h1, h2, g); }
         ST_T(2);
-        { float fr[1 * 2 * 4]; frags_fwd<1, 2>(fr, Wl[2], CL::P2, g, c); ST_FENCE(); fwdD_fr<1, 2>(fr, Bl[2], h2, h3, g); }
-        { float fr[1 * 1 * 4]; frags_fwd<1, 1>(fr, Wl[3], CL::P3, g, c); ST_FENCE(); fwdD_fr<1, 1>(fr, Bl[3], h3, h4, g); }
+        { f32x4 fr[1 * 2]; frags_fwd<1, 2, CL::O2>(fr, lw + CL::A2, g, c); ST_FENCE(); fwdD_fr<1, 2>(fr, lw + CL::B2, h2, h3, g); }
+        { f32x4 fr[1 * 1]; frags_fwd<1, 1, CL::O3>(fr, lw + CL::A3, g, c); ST_FENCE(); fwdD_fr<1, 1>(fr, lw + CL::B3, h3, h4, g); }
         {
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int P5 = CL::P4;
-            float fa[4], fb[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { fa[r] = Wl[4][c * P5 + 4 * g + r]; fb[r] = Wl[4][c * P5 + 16 + 4 * g + r]; }
-            ST_FENCE();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc = ST_MFMA16(fa[r], h4[0][r], acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc = ST_MFMA16(fb[r], kn[0][r], acc);   // knob features 16 + 4g + r
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h5[0][r] = elu_f(acc[r] + Bl[4][4 * g + r]);
+            f32x4 fr[1 * 2]; frags_fwd<1, 2, CL::O4>(fr, lw + CL::A4, g, c); ST_FENCE();
+            const f32x4 hk[2] = {h4[0], kn};                                 // knob features 16 + 4g + r
+            fwdD_fr<1, 2>(fr, lw + CL::B4, hk, h5, g);
         }
         ST_T(3);
-        { float fr[1 * 1 * 4]; frags_fwd<1, 1>(fr, Wl[5], CL::P5, g, c); ST_FENCE(); fwdD_fr<1, 1>(fr, Bl[5], h5, h6, g); }
-        { float fr[2 * 1 * 4]; frags_fwd<2, 1>(fr, Wl[6], CL::P6, g, c); ST_FENCE(); fwdD_fr<2, 1>(fr, Bl[6], h6, h7, g); }
+        { f32x4 fr[1 * 1]; frags_fwd<1, 1, CL::O5>(fr, lw + CL::A5, g, c); ST_FENCE(); fwdD_fr<1, 1>(fr, lw + CL::B5, h5, h6, g); }
+        { f32x4 fr[2 * 1]; frags_fwd<2, 1, CL::O6>(fr, lw + CL::A6, g, c); ST_FENCE(); fwdD_fr<2, 1>(fr, lw + CL::B6, h6, h7, g); }
         ST_T(4);
-        { float fr[4 * 2 * 4]; frags_fwd<4, 2>(fr, Wl[7], CL::P7, g, c); ST_FENCE(); fwdD_fr<4, 2>(fr, Bl[7], h7, h8, g); }
+        { f32x4 fr[4 * 2]; frags_fwd<4, 2, CL::O7>(fr, lw + CL::A7, g, c); ST_FENCE(); fwdD_fr<4, 2>(fr, lw + CL::B7, h7, h8, g); }
         ST_T(5);
-        if constexpr (!INNER) { float fr[1 * 4 * 4]; frags_fwd<1, 4>(fr, Wl[8], CL::P8, g, c); ST_FENCE(); fwdD_fr<1, 4>(fr, Bl[8], h8, e9, g); }
+        if constexpr (!INNER) { f32x4 fr[1 * 4]; frags_fwd<1, 4, CL::O8>(fr, lw + CL::A8, g, c); ST_FENCE(); fwdD_fr<1, 4>(fr, lw + CL::B8, h8, e9, g); }
         ST_T(6);
-        ST_SCHED_FENCE();
         // ------------------------------------------------------------------ d out  (D layout: t' = 4g + r)
         f32x4 da9[1];
         if constexpr (!INNER) {
@@ -932,11 +676,9 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         // ------------------------------------------------------------------ backward through the layers
         // T layout: lane (g,c), reg r  <->  row 4g + r, feature 16*tile + c
         f32x4 daT9[1];
-        if constexpr (!INNER) { const float4 v = *reinterpret_cast<const float4*>(Ys + c * SP + 4 * g); daT9[0] = (f32x4){v.x, v.y, v.z, v.w}; }
-#define ST_WG(O_, I_, D_, P_, RW_, RB_, DB_, DAT_, HT_) \
-        if constexpr (REG) wgrad_reg<O_, I_>(RW_, RB_, DAT_, HT_); else wgrad_lds<O_, I_>(D_, P_, DAT_, HT_, DB_, g, c);
+        if constexpr (!INNER) daT9[0] = *reinterpret_cast<const f32x4*>(Ys + c * SP + 4 * g);
         ST_T(7);
-        // layer 9 (64 -> OT): needs h8^T (layer-8 forward fragments) and W9 in dgrad order
+        // layer 9 (64 -> OT): needs h8^T and W9 in dgrad order
         f32x4 hT8[4], da8[4], daT8[4];
         if constexpr (INNER) {                     // dH8 arrives from the layer-9 data-gradient GEMM; h8^T is still needed for ELU' and dW8
             to_T<4>(XH, h8, hT8, g, c);
@@ -944,106 +686,103 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             for (int ot = 0; ot < 4; ++ot) da8[ot] = dh8[ot];
             mul_elu_grad<4>(da8, h8); to_T<4>(XD, da8, daT8, g, c);
         } else {
-            float fd[1 * 4 * 4];
-            frags_dgrad<1, 4>(fd, Wl[8], CL::P8, g, c); ST_FENCE();
+            f32x4 fd[4 * 1];
+            frags_dgrad<1, 4, CL::I8>(fd, lw + CL::G8, g, c); ST_FENCE();
             to_T<4>(XH, h8, hT8, g, c);
-            ST_WG(1, 4, Dl[8], CL::P8, rW9, rb9, db9, daT9, hT8)
+            wgrad_reg<1, 4>(rW9, rb9, daT9, hT8);
             dgradD_fr<1, 4>(fd, da9, da8); mul_elu_grad<4>(da8, h8); to_T<4>(XD, da8, daT8, g, c);
         }
         ST_T(8);
         // layer 8 (32 -> 64)
         f32x4 hT7[2], da7[2], daT7[2];
         {
-            float fd[4 * 2 * 4];
-            frags_dgrad<4, 2>(fd, Wl[7], CL::P7, g, c); ST_FENCE();
+            f32x4 fd[2 * 4];
+            frags_dgrad<4, 2, CL::I7>(fd, lw + CL::G7, g, c); ST_FENCE();
             to_T<2>(XH, h7, hT7, g, c);
-            ST_WG(4, 2, Dl[7], CL::P7, rW8, rb8, db8, daT8, hT7)
+            wgrad_reg<4, 2>(rW8, rb8, daT8, hT7);
             dgradD_fr<4, 2>(fd, da8, da7); mul_elu_grad<2>(da7, h7); to_T<2>(XD, da7, daT7, g, c);
         }
         ST_T(9);
         // layer 7 (16 -> 32)
         f32x4 hT6[1], da6[1], daT6[1];
         {
-            float fd[2 * 1 * 4];
-            frags_dgrad<2, 1>(fd, Wl[6], CL::P6, g, c); ST_FENCE();
+            f32x4 fd[1 * 2];
+            frags_dgrad<2, 1, CL::I6>(fd, lw + CL::G6, g, c); ST_FENCE();
             to_T<1>(XH, h6, hT6, g, c);
-            ST_WG(2, 1, Dl[6], CL::P6, rW7, rb7, db7, daT7, hT6)
+            wgrad_reg<2, 1>(rW7, rb7, daT7, hT6);
             dgradD_fr<2, 1>(fd, da7, da6); mul_elu_grad<1>(da6, h6); to_T<1>(XD, da6, daT6, g, c);
         }
         ST_T(10);
         // layer 6 (16 -> 16)
         f32x4 hT5[1], da5[1], daT5[1];
         {
-            float fd[1 * 1 * 4];
-            frags_dgrad<1, 1>(fd, Wl[5], CL::P5, g, c); ST_FENCE();
+            f32x4 fd[1 * 1];
+            frags_dgrad<1, 1, CL::I5>(fd, lw + CL::G5, g, c); ST_FENCE();
             to_T<1>(XH, h5, hT5, g, c);
-            ST_WG(1, 1, Dl[5], CL::P5, rW6, rb6, db6, daT6, hT5)
+            wgrad_reg<1, 1>(rW6, rb6, daT6, hT5);
             dgradD_fr<1, 1>(fd, da6, da5); mul_elu_grad<1>(da5, h5); to_T<1>(XD, da5, daT5, g, c);
         }
         // layer 5 ([h4 ; knobs] -> 16): weight gradient over both input tiles, data gradient to h4 only
         f32x4 hT4[1], hT4k[2], da4[1], daT4[1];
         {
-            float fd[1 * 1 * 4];
-            frags_dgrad<1, 1>(fd, Wl[4], CL::P4, g, c); ST_FENCE();
+            f32x4 fd[1 * 1];
+            frags_dgrad<1, 1, CL::I4>(fd, lw + CL::G4, g, c); ST_FENCE();
             to_T<1>(XH, h4, hT4, g, c);
             hT4k[0] = hT4[0];
             hT4k[1] = (f32x4){knT, knT, knT, knT};                   // features 16 + c = knob c, every row
-            ST_WG(1, 2, Dl[4], CL::P4, rW5, rb5, db5, daT5, hT4k)
+            wgrad_reg<1, 2>(rW5, rb5, daT5, hT4k);
             dgradD_fr<1, 1>(fd, da5, da4); mul_elu_grad<1>(da4, h4); to_T<1>(XD, da4, daT4, g, c);
         }
         // layer 4 (16 -> 16)
         f32x4 hT3[1], da3[1], daT3[1];
         {
-            float fd[1 * 1 * 4];
-            frags_dgrad<1, 1>(fd, Wl[3], CL::P3, g, c); ST_FENCE();
+            f32x4 fd[1 * 1];
+            frags_dgrad<1, 1, CL::I3>(fd, lw + CL::G3, g, c); ST_FENCE();
             to_T<1>(XH, h3, hT3, g, c);
-            ST_WG(1, 1, Dl[3], CL::P3, rW4, rb4, db4, daT4, hT3)
+            wgrad_reg<1, 1>(rW4, rb4, daT4, hT3);
             dgradD_fr<1, 1>(fd, da4, da3); mul_elu_grad<1>(da3, h3); to_T<1>(XD, da3, daT3, g, c);
         }
         ST_T(11);
         // layer 3 (32 -> 16)
         f32x4 hT2[2], da2[2], daT2[2];
         {
-            float fd[1 * 2 * 4];
-            frags_dgrad<1, 2>(fd, Wl[2], CL::P2, g, c); ST_FENCE();
+            f32x4 fd[2 * 1];
+            frags_dgrad<1, 2, CL::I2>(fd, lw + CL::G2, g, c); ST_FENCE();
             to_T<2>(XH, h2, hT2, g, c);
-            ST_WG(1, 2, Dl[2], CL::P2, rW3, rb3, db3, daT3, hT2)
+            wgrad_reg<1, 2>(rW3, rb3, daT3, hT2);
             dgradD_fr<1, 2>(fd, da3, da2); mul_elu_grad<2>(da2, h2); to_T<2>(XD, da2, daT2, g, c);
         }
         ST_T(12);
-        // layer 2 (64 -> 32); h1^T from the input rows
+        // layer 2 (64 -> 32)
         f32x4 hT1[4], da1[4], daT1[4];
-        if constexpr (INNER) {                     // dA1 goes back to memory for the layer-1 GEMMs
-            float fd[2 * 4 * 4];
-            frags_dgrad<2, 4>(fd, Wl[1], CL::P1, g, c); ST_FENCE();
+        {
+            f32x4 fd[4 * 2];
+            frags_dgrad<2, 4, CL::I1>(fd, lw + CL::G1, g, c); ST_FENCE();
             to_T<4>(XH, h1, hT1, g, c);
-            ST_WG(2, 4, Dl[1], CL::P1, rW2, rb2, db2, daT2, hT1)
+            wgrad_reg<2, 4>(rW2, rb2, daT2, hT1);
             dgradD_fr<2, 4>(fd, da2, da1); mul_elu_grad<4>(da1, h1);
-            const unsigned col0 = (unsigned)b * FP + (unsigned)(grp - b * gpw) * 16;
+            if constexpr (INNER) {                 // dA1 goes back to memory for the layer-1 GEMMs
+                const unsigned col0 = (unsigned)b * FP + (unsigned)(grp - b * gpw) * 16;
 #pragma unroll
-            for (int ot = 0; ot < 4; ++ot)
+                for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dvout[(unsigned)(16 * ot + 4 * g + r) * Rw + col0 + c] = da1[ot][r];
-        } else {
-            float fd[2 * 4 * 4];
-            frags_dgrad<2, 4>(fd, Wl[1], CL::P1, g, c); ST_FENCE();
-            to_T<4>(XH, h1, hT1, g, c);
-            ST_WG(2, 4, Dl[1], CL::P1, rW2, rb2, db2, daT2, hT1)
-            dgradD_fr<2, 4>(fd, da2, da1); mul_elu_grad<4>(da1, h1); to_T<4>(XD, da1, daT1, g, c);
+                    for (int r = 0; r < 4; ++r) dvout[(unsigned)(16 * ot + 4 * g + r) * Rw + col0 + c] = da1[ot][r];
+            } else {
+                to_T<4>(XD, da1, daT1, g, c);
+            }
         }
         ST_T(13);
         // layer 1 (T -> 64): input rows transposed through the wave's scratch
         f32x4 vT[2], dv[2];
         if constexpr (!INNER) {
-            float fd[4 * 2 * 4];
-            frags_dgrad<4, 2>(fd, Wl[0], CL::P0, g, c);
+            f32x4 fd[2 * 4];
+            frags_dgrad<4, 2, CL::I0>(fd, lw + CL::G0, g, c);
 #pragma unroll
-            for (int it = 0; it < 2; ++it) { const float4 v = *reinterpret_cast<const float4*>(Vs + (16 * it + c) * SP + 4 * g); vT[it] = (f32x4){v.x, v.y, v.z, v.w}; }
+            for (int it = 0; it < 2; ++it) vT[it] = *reinterpret_cast<const f32x4*>(Vs + (16 * it + c) * SP + 4 * g);
             ST_FENCE();
-            ST_WG(4, 2, Dl[0], CL::P0, rW1, rb1, db1, daT1, vT)
+            wgrad_reg<4, 2>(rW1, rb1, daT1, vT);
             dgradD_fr<4, 2>(fd, da1, dv);
         }
-#undef ST_WG
         ST_T(14);
         // ------------------------------------------------------------------ d input rows (+ skip / residual tails)
         if constexpr (!INNER) {
@@ -1070,32 +809,43 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         ST_T(15);
         if constexpr (!INNER) {
             mask_v(gnext, vn);
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) vr[ks] = vn[ks];
+            vr[0] = vn[0]; vr[1] = vn[1];
         }
     }
     // ---------------------------------------------------------------------- workgroup partial gradients
-    if constexpr (REG) {
-        for (int wv = 0; wv < NW; ++wv) {          // ordered, non-atomic: run-to-run identical bits
-            if (wave == wv) {
-                if constexpr (!INNER) { dw_flush<4, 2>(Dl[0], CL::P0, rW1, g, c); dw_flush<1, 4>(Dl[8], CL::P8, rW9, g, c); db_flush<4>(db1, rb1, g, c); db_flush<1>(db9, rb9, g, c); }
-                dw_flush<2, 4>(Dl[1], CL::P1, rW2, g, c); dw_flush<1, 2>(Dl[2], CL::P2, rW3, g, c);
-                dw_flush<1, 1>(Dl[3], CL::P3, rW4, g, c); dw_flush<1, 2>(Dl[4], CL::P4, rW5, g, c); dw_flush<1, 1>(Dl[5], CL::P5, rW6, g, c);
-                dw_flush<2, 1>(Dl[6], CL::P6, rW7, g, c); dw_flush<4, 2>(Dl[7], CL::P7, rW8, g, c);
-                db_flush<2>(db2, rb2, g, c); db_flush<1>(db3, rb3, g, c); db_flush<1>(db4, rb4, g, c);
-                db_flush<1>(db5, rb5, g, c); db_flush<1>(db6, rb6, g, c); db_flush<2>(db7, rb7, g, c); db_flush<4>(db8, rb8, g, c);
-            }
-            __syncthreads();
-        }
-    }
+    // The forward images are dead now: their region becomes the workgroup's gradient image, dW_l as [o][INp] at CL::A_l and
+    // db_l at CL::B_l.  Ordered, non-atomic: wave 0 stores, the others add in turn -> run-to-run identical bits.
     __syncthreads();
+    float* dwl = lds;
+#define ST_FLUSH(FIRST_) do { \
+        if constexpr (!INNER) { dw_flush<4, 2, CL::I0, FIRST_>(dwl + CL::A0, rW1, g, c); dw_flush<1, 4, CL::I8, FIRST_>(dwl + CL::A8, rW9, g, c); \
+                                db_flush<4, FIRST_>(dwl + CL::B0, rb1, g, c); db_flush<1, FIRST_>(dwl + CL::B8, rb9, g, c); } \
+        dw_flush<2, 4, CL::I1, FIRST_>(dwl + CL::A1, rW2, g, c); dw_flush<1, 2, CL::I2, FIRST_>(dwl + CL::A2, rW3, g, c); \
+        dw_flush<1, 1, CL::I3, FIRST_>(dwl + CL::A3, rW4, g, c); dw_flush<1, 2, CL::I4, FIRST_>(dwl + CL::A4, rW5, g, c); \
+        dw_flush<1, 1, CL::I5, FIRST_>(dwl + CL::A5, rW6, g, c); dw_flush<2, 1, CL::I6, FIRST_>(dwl + CL::A6, rW7, g, c); \
+        dw_flush<4, 2, CL::I7, FIRST_>(dwl + CL::A7, rW8, g, c); \
+        db_flush<2, FIRST_>(dwl + CL::B1, rb2, g, c); db_flush<1, FIRST_>(dwl + CL::B2, rb3, g, c); db_flush<1, FIRST_>(dwl + CL::B3, rb4, g, c); \
+        db_flush<1, FIRST_>(dwl + CL::B4, rb5, g, c); db_flush<1, FIRST_>(dwl + CL::B5, rb6, g, c); db_flush<2, FIRST_>(dwl + CL::B6, rb7, g, c); \
+        db_flush<4, FIRST_>(dwl + CL::B7, rb8, g, c); } while (0)
+    if (wave == 0) ST_FLUSH(true);
+    __syncthreads();
+    for (int wv = 1; wv < NW; ++wv) {
+        if (wave == wv) ST_FLUSH(false);
+        __syncthreads();
+    }
+#undef ST_FLUSH
     float* base = ws + ((size_t)blockIdx.x * 2 + ae) * PG;
     for (int i = tid; i < PG; i += NW * 64) base[i] = 0.f;                 // alignment pads
     __syncthreads();
+    const int out[NL] = {64, 32, 16, 16, 16, 16, 32, 64, OT};
+    const int in[NL] = {T, 64, 32, 16, 16 + K, 16, 16, 32, 64};
+    const int inp[NL] = {CL::I0, CL::I1, CL::I2, CL::I3, CL::I4, CL::I5, CL::I6, CL::I7, CL::I8};
+    const int ao[NL] = {CL::A0, CL::A1, CL::A2, CL::A3, CL::A4, CL::A5, CL::A6, CL::A7, CL::A8};
+    const int bo[NL] = {CL::B0, CL::B1, CL::B2, CL::B3, CL::B4, CL::B5, CL::B6, CL::B7, CL::B8};
     for (int l = INNER ? 1 : 0; l < (INNER ? 8 : NL); ++l) {       // INNER: layers 1 and 9 come from the GEMM path
-        const int P = L.P[l], IN = L.IN[l], n = L.OUT[l] * IN;
-        for (int e = tid; e < n; e += NW * 64) { const int o = e / IN; base[go.w[l] + e] = dwl[L.w[l] + o * P + (e - o * IN)]; }
-        if (tid < L.OUT[l]) base[go.b[l] + tid] = dwl[L.b[l] + tid];
+        const int IN = in[l], n = out[l] * IN;
+        for (int e = tid; e < n; e += NW * 64) { const int o = e / IN; base[go.w[l] + e] = dwl[ao[l] + o * inp[l] + (e - o * IN)]; }
+        if (tid < out[l]) base[go.b[l] + tid] = dwl[bo[l] + tid];
     }
 }
 

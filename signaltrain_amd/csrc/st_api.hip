@@ -181,7 +181,6 @@ static int g_wg_mode_set(int v) { g_wg_mode = v; return ST_OK; }
 #define ST_GEMM_WG(...) do { if (g_wg_mode == 1 && g_prec == 0) stg::launch<1, 16, 3>(__VA_ARGS__, g_dbg); \
                              else if (g_wg_mode == 2 && g_prec == 0) stg::launch<3, 16, 1, true>(__VA_ARGS__, g_dbg); else ST_GEMM(3, __VA_ARGS__); } while (0)
 static const int AE_FWD_NW = 8, AE_BWD_NW = 4;
-static const bool AE_BWD_REG = true;     // persistent register accumulators, 1 wave/SIMD (LDS float atomics per group measured 3x slower)
 static int synth_live_rows(const st_dims* d);
 static int ae_fwd_grid(const st_dims* d) { int g = (d->B * (st_kp_of(d->F) / 32) + AE_FWD_NW - 1) / AE_FWD_NW; int c = num_cus(); return g < c ? g : c; }
 static int ae_bwd_grid(const st_dims* d) { int groups = d->B * (st_kp_of(d->F) / 32); int g = (groups + AE_BWD_NW - 1) / AE_BWD_NW; int c = num_cus() / 2; if (c < 1) c = 1; return g < c ? g : c; }
@@ -305,24 +304,16 @@ extern "C" int st_ae_fwd(const st_dims* d, const float* mag, const float* phs, c
         WideWS w; wide_carve(d, ws, &w);
         return ae_wide_fwd(d, L, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, AA, reg_partial, w, stream);
     }
-    const sta::AELds ll = sta::ae_lds_layout(d->T, d->OT, d->K);
-    const size_t lds = (size_t)2 * ll.total * sizeof(float);
-    ST_REQ(lds <= 160 * 1024, "st_ae_fwd: geometry needs %zu B of LDS (>160 KiB)", lds);
+    const size_t lds = (size_t)2 * sta::CL::FWD_TOTAL * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_fwd_kernel<AE_FWD_NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_fwd_kernel<AE_FWD_NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_fwd_kernel<AE_FWD_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
     const float expfac = (float)(7.0 / d->F);
-    if (d->T <= 32 && d->OT <= 16)
-        hipLaunchKernelGGL((sta::ae_fwd_kernel<AE_FWD_NW, true>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, st_stream(stream),
-                           mag, phs, knobs, ae_m, ae_p, L.go, mag_hat, phs_hat, AA, reg_partial,
-                           d->B, d->T, d->OT, d->F, d->K, L.KP, expfac);
-    else
-        hipLaunchKernelGGL((sta::ae_fwd_kernel<AE_FWD_NW, false>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, st_stream(stream),
-                           mag, phs, knobs, ae_m, ae_p, L.go, mag_hat, phs_hat, AA, reg_partial,
-                           d->B, d->T, d->OT, d->F, d->K, L.KP, expfac);
+    hipLaunchKernelGGL((sta::ae_fwd_kernel<AE_FWD_NW>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, st_stream(stream),
+                       mag, phs, knobs, ae_m, ae_p, L.go, mag_hat, phs_hat, AA, reg_partial,
+                       d->B, d->T, d->OT, d->F, d->K, L.KP, expfac);
     ST_LAUNCHED("ae_fwd"); return ST_OK;
 }
 
@@ -454,8 +445,7 @@ static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, cons
         }
     }
     if (g_wide_fused) {
-        const sta::AELds ll = sta::ae_lds_layout(16, 16, d->K);
-        const size_t lds = (size_t)2 * ll.total * sizeof(float);
+        const size_t lds = (size_t)2 * sta::CL::FWD_TOTAL * sizeof(float);
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_inner_fwd_kernel<AE_FWD_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
         hipLaunchKernelGGL((sta::ae_inner_fwd_kernel<AE_FWD_NW>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, s,
@@ -539,12 +529,11 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
         // layer 9 as GEMMs, layers 8..2 in one fused kernel (both nets), layer 1 as GEMMs
         for (int a = 0; a < 2; ++a) { wide_wgrad(d, w, a, 8, out, in, s); dgrad(a, 8, true); }
         {
-            const sta::AELds ll = sta::ae_lds_layout(32, 16, d->K);
-            const size_t lds = ((size_t)2 * ll.total + (size_t)AE_BWD_NW * ((32 + 16 + 16) * sta::SP + 2 * 4 * 320)) * sizeof(float);
+            const size_t lds = ((size_t)sta::CL::BWD_TOTAL + (size_t)AE_BWD_NW * sta::AE_BWD_SCR) * sizeof(float);
             static bool attr = false;
-            if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
             const int grid = ae_bwd_grid(d);
-            hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, true, false, true>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, s,
+            hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, false, true>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, s,
                                (const float*)w.H[0][0], (const float*)w.H[1][0], knobs, ae_m, ae_p, L.go, L.PG,
                                (const float*)w.DA[0][7], (const float*)w.DA[1][7], (const float*)nullptr, (const float*)nullptr, 0.f, 0.f,
                                w.DA[0][0], w.DA[1][0], w.inner_ws, d->B, T, OT, F, d->K, L.KP, 0, 0, 1, (size_t)0, 0);
@@ -579,21 +568,20 @@ static int ae_bwd_impl(const st_dims* d, const float* mag, const float* phs, con
         WideWS w; wide_carve(d, ws, &w);
         return ae_wide_bwd(d, L, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, dmag, dphs, w, g_m, g_p, have_fwd, stream);
     }
-    const sta::AELds ll = sta::ae_lds_layout(d->T, d->OT, d->K);
-    const size_t lds = ((size_t)2 * ll.total + (size_t)AE_BWD_NW * ((32 + 16 + 16) * sta::SP + 2 * 4 * 320)) * sizeof(float);
-    ST_REQ(lds <= 160 * 1024, "st_ae_bwd: needs %zu B of LDS", lds);
+    const size_t lds = ((size_t)sta::CL::BWD_TOTAL + (size_t)AE_BWD_NW * sta::AE_BWD_SCR) * sizeof(float);
+    static_assert(((size_t)sta::CL::BWD_TOTAL + (size_t)AE_BWD_NW * sta::AE_BWD_SCR) * sizeof(float) <= 160 * 1024, "ae_bwd LDS budget");
     ST_REQ((size_t)st_synth_slabs(d) * d->B * d->OT * L.KP < ((size_t)1 << 31) && (size_t)d->B * d->T * L.KP < ((size_t)1 << 31),
            "st_ae_bwd: batch too large for the kernel's 32-bit element offsets (B=%d)", d->B);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, AE_BWD_REG, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, AE_BWD_REG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
     const float expfac = (float)(7.0 / d->F);
     const int grid = ae_bwd_grid(d);
 #define ST_AE_BWD_LAUNCH(TIMED_) \
-    hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, AE_BWD_REG, TIMED_>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, st_stream(stream), \
+    hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, TIMED_>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, st_stream(stream), \
                        mag, phs, knobs, ae_m, ae_p, L.go, L.PG, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, expfac, \
                        dmag, dphs, ws, d->B, d->T, d->OT, d->F, d->K, L.KP, synth_live(d).t_lo, synth_live(d).t_lo + synth_live(d).Tv - 1, st_synth_slabs(d), (size_t)d->B * d->OT * L.KP, g_dbg)
     if (g_dbg & 256) ST_AE_BWD_LAUNCH(true);      // stage-timer build (tools/ae_stage_times.py)
