@@ -92,6 +92,19 @@ __device__ inline void ae_load_lds(float* lds, const float* __restrict__ ae, con
 
 #define ST_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// Global accesses by 32-bit ELEMENT offset from a wave-uniform base (the host checks that every buffer is < 2^30 elements):
+// they compile to the saddr + 32-bit voffset form, i.e. no 64-bit address arithmetic per access (3-4 VALU instructions
+// each, ~60 accesses per row group in the backward kernel).  ST_MUL24: offsets are products of small indices.
+__device__ __forceinline__ float ldg32(const float* __restrict__ base, const unsigned elem)
+{
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)(elem << 2));
+}
+__device__ __forceinline__ void stg32(float* __restrict__ base, const unsigned elem, const float v)
+{
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (size_t)(elem << 2)) = v;
+}
+#define ST_MUL24(a, b) __umul24((unsigned)(a), (unsigned)(b))
+
 // One 16x16 tile of A operands (k-steps r = 0..3) from a forward image: W[o = 16 ot + c][i = 16 it + 4 g + r].
 template <int OUTP>
 __device__ __forceinline__ f32x4 frag_fwd(const float* img, const int ot, const int it, const int g, const int c)
@@ -174,21 +187,21 @@ __device__ __forceinline__ void fwd_load(FwdIn& in, const float* __restrict__ ma
                                          const int b, const int f, const bool fv, const int T, const int OT, const int F, const int g)
 {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { const int kn = 4 * q + g; in.kn[q] = knobs[(unsigned)b * K + (kn < K ? kn : 0)]; }
-    const unsigned base = (unsigned)b * T * F + (fv ? f : 0);
+    for (int q = 0; q < 4; ++q) { const int kn = 4 * q + g; in.kn[q] = ldg32(knobs, ST_MUL24(b, K) + (unsigned)(kn < K ? kn : 0)); }
+    const unsigned base = ST_MUL24(ST_MUL24(b, T), F) + (unsigned)(fv ? f : 0);
 #pragma unroll
     for (int it = 0; it < 2; ++it)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int t = 16 * it + 4 * g + r;
-            const unsigned o = base + (unsigned)(t < T ? t : 0) * F;
-            in.v[0][it][r] = mag[o]; in.v[1][it][r] = phs[o];
+            const unsigned o = base + ST_MUL24(t < T ? t : 0, F);
+            in.v[0][it][r] = ldg32(mag, o); in.v[1][it][r] = ldg32(phs, o);
         }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int to = 4 * g + r;
-        const unsigned o = base + (unsigned)(to < OT ? T - OT + to : 0) * F;
-        in.tl[0][r] = mag[o]; in.tl[1][r] = phs[o];
+        const unsigned o = base + ST_MUL24(to < OT ? T - OT + to : 0, F);
+        in.tl[0][r] = ldg32(mag, o); in.tl[1][r] = ldg32(phs, o);
     }
 }
 __device__ __forceinline__ void fwd_mask(FwdIn& in, const int K, const bool fv, const int T, const int OT, const int g)
@@ -263,18 +276,18 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         for (int r = 0; r < 4; ++r) {
             const int to = 4 * g + r;
             if (to < OT) {
-                const size_t ro = (size_t)b * OT + to;
+                const unsigned ro = ST_MUL24(b, OT) + (unsigned)to;
                 float mh = 0.f, ph = 0.f, sn = 0.f, cs = 1.f;
                 if (fv) {
                     mh = e9[0][0][r] * cur.tl[0][r];               // 'sf' skip-filter
                     ph = e9[1][0][r] + cur.tl[1][r];               // phase residual
                     st_sincos(ph, sn, cs);
-                    mag_hat[ro * F + f] = mh;
-                    phs_hat[ro * F + f] = ph;
+                    stg32(mag_hat, ST_MUL24(ro, F) + (unsigned)f, mh);
+                    stg32(phs_hat, ST_MUL24(ro, F) + (unsigned)f, ph);
                     reg += fabsf(mh * wf);
                 }
-                AA[ro * KP + f] = mh * cs;                          // f < FP always: pads get zeros
-                AA[ro * KP + FP + f] = mh * sn;
+                stg32(AA, ST_MUL24(ro, KP) + (unsigned)f, mh * cs);           // f < FP always: pads get zeros
+                stg32(AA, ST_MUL24(ro, KP) + (unsigned)(FP + f), mh * sn);
             }
         }
         fwd_mask(nxt, K, fn < F, T, OT, g); cur = nxt;
@@ -540,13 +553,13 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     // eight load / s_waitcnt vmcnt(0) pairs, i.e. eight serialized memory round trips per group.
     auto load_v = [&](int gq, f32x4 (&dst)[2]) {
         const int bq = gq / gpw, fq = (gq - bq * gpw) * 16 + c;
-        const int fc = fq < F ? fq : 0;
+        const unsigned base = ST_MUL24(ST_MUL24(bq, T), F) + (unsigned)(fq < F ? fq : 0);
 #pragma unroll
         for (int it = 0; it < 2; ++it)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int t = 16 * it + 4 * g + r;
-                dst[it][r] = vin[((unsigned)bq * T + (t < T ? t : 0)) * F + fc];
+                dst[it][r] = ldg32(vin, base + ST_MUL24(t < T ? t : 0, F));
             }
     };
     auto mask_v = [&](int gq, f32x4 (&dst)[2]) {
@@ -558,6 +571,22 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             for (int r = 0; r < 4; ++r) dst[it][r] = (ok0 && 16 * it + 4 * g + r < T) ? dst[it][r] : 0.f;
     };
     if constexpr (!INNER) { if (grp < ngroups) { load_v(grp, vr); mask_v(grp, vr); } }
+    // knob values of a group's window, also one group ahead (a select right behind their loads at the top of the loop body
+    // made the wave wait there for ALL the loads just issued -- the memory counter is in-order -- i.e. one full memory
+    // latency per group): D-layout feature tile (16 + 4g + r) and T-layout feature lane (16 + c)
+    f32x4 kn = (f32x4){0.f, 0.f, 0.f, 0.f}; float knT = 0.f;
+    auto load_kn = [&](int gq, f32x4& d4, float& dT) {
+        const unsigned kb = ST_MUL24(gq / gpw, K);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int kidx = 4 * g + r; d4[r] = ldg32(knobs, kb + (unsigned)(kidx < K ? kidx : 0)); }
+        dT = ldg32(knobs, kb + (unsigned)(c < K ? c : 0));
+    };
+    auto mask_kn = [&](f32x4& d4, float& dT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d4[r] = (4 * g + r) < K ? d4[r] : 0.f;
+        dT = c < K ? dT : 0.f;
+    };
+    if (grp < ngroups) { load_kn(grp, kn, knT); mask_kn(kn, knT); }
     const unsigned Rw = (unsigned)B * FP;              // INNER: columns of the feature-major buffers
 
     for (; grp < ngroups; grp += gstride) {
@@ -567,28 +596,28 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         const int fq = fv ? f : 0;
         // ---- d-out inputs for this group (D layout: t' = 4g + r), issued early.  (Slicing these 53 loads between the
         // forward stages to overlap their issue with MFMA execution was measured: no gain.)
-        float q_gre[4], q_gim[4], q_ph[4], q_mh[4], q_mt[4], q_gm[4];
+        // Raw values only: the slab sums and masks are formed in the d-out stage -- arithmetic on a loaded value up here
+        // makes the wave wait in the middle of the burst (the memory counter is in-order).
+        float q_x[4][3], q_y[4][3], q_ph[4], q_mh[4], q_mt[4], q_gm[4];
         const float* gmp = g_mag_hat ? g_mag_hat : mag_hat;
         if constexpr (!INNER) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int to = 4 * g + r;
-            const bool ok = fv && to < OT;
-            const bool lv = ok && to >= to_lo && to <= to_hi;
-            const unsigned ro = (unsigned)b * OT + (ok ? to : 0);      // 32-bit offsets throughout (host checks the sizes): saddr + voffset loads
-            // up to 3 split-K slabs: all six loads are issued together, then summed (a runtime-trip-count loop here
-            // serialised ~12 memory round trips per group)
-            const unsigned p0 = (lv ? ro : 0u) * KP + fq;
             const unsigned o1 = nslab > 1 ? (unsigned)slab : 0u, o2 = nslab > 2 ? 2u * (unsigned)slab : 0u;
-            const float x0 = dAA[p0], x1 = dAA[p0 + o1], x2 = dAA[p0 + o2];
-            const float y0 = dAA[p0 + FP], y1 = dAA[p0 + o1 + FP], y2 = dAA[p0 + o2 + FP];
-            const float a0 = x0 + (nslab > 1 ? x1 : 0.f) + (nslab > 2 ? x2 : 0.f);
-            const float a1 = y0 + (nslab > 1 ? y1 : 0.f) + (nslab > 2 ? y2 : 0.f);
-            q_gre[r] = lv ? a0 : 0.f; q_gim[r] = lv ? a1 : 0.f;
-            q_ph[r] = phs_hat[ro * F + fq]; q_mh[r] = mag_hat[ro * F + fq];
-            q_mt[r] = vin[((unsigned)b * T + (ok ? T - OT + to : 0)) * F + fq];
-            { const float x = gmp[ro * F + fq]; q_gm[r] = (g_mag_hat && ok) ? x : 0.f; }      // branch-free (see load_v)
-        }
+            const unsigned bOT = ST_MUL24(b, OT), btF = ST_MUL24(ST_MUL24(b, T), F) + (unsigned)fq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int to = 4 * g + r;
+                const bool ok = fv && to < OT;
+                const bool lv = ok && to >= to_lo && to <= to_hi;
+                const unsigned ro = bOT + (unsigned)(ok ? to : 0);
+                // up to 3 split-K slabs: all six loads are issued together (a runtime-trip-count loop here serialised ~12
+                // memory round trips per group)
+                const unsigned p0 = ST_MUL24(lv ? ro : 0u, KP) + (unsigned)fq;
+                q_x[r][0] = ldg32(dAA, p0); q_x[r][1] = ldg32(dAA, p0 + o1); q_x[r][2] = ldg32(dAA, p0 + o2);
+                q_y[r][0] = ldg32(dAA, p0 + FP); q_y[r][1] = ldg32(dAA, p0 + o1 + FP); q_y[r][2] = ldg32(dAA, p0 + o2 + FP);
+                const unsigned pF = ST_MUL24(ro, F) + (unsigned)fq;
+                q_ph[r] = ldg32(phs_hat, pF); q_mh[r] = ldg32(mag_hat, pF); q_gm[r] = ldg32(gmp, pF);
+                q_mt[r] = ldg32(vin, btF + ST_MUL24(ok ? T - OT + to : 0, F));
+            }
         }
         // INNER: layer-1 outputs in both layouts and the gradient entering layer 8's output, straight from the
         // feature-major buffers (D layout: feature 16 tile + 4g + r at column col0 + c)
@@ -599,19 +628,15 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             for (int ot = 0; ot < 4; ++ot) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    h1in[ot][r] = vin[(unsigned)(16 * ot + 4 * g + r) * Rw + col0 + c];
-                    dh8[ot][r] = dh8in[(unsigned)(16 * ot + 4 * g + r) * Rw + col0 + c];
+                    h1in[ot][r] = ldg32(vin, (unsigned)(16 * ot + 4 * g + r) * Rw + col0 + c);
+                    dh8[ot][r] = ldg32(dh8in, (unsigned)(16 * ot + 4 * g + r) * Rw + col0 + c);
                 }
             }
         }
-        // knob values: D-layout feature tile (16 + 4g + r) and T-layout feature lane (16 + c)
-        f32x4 kn; float knT;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int kidx = 4 * g + r; const float x = knobs[(unsigned)b * K + (kidx < K ? kidx : 0)]; kn[r] = kidx < K ? x : 0.f; }
-        { const float x = knobs[(unsigned)b * K + (c < K ? c : 0)]; knT = c < K ? x : 0.f; }
-        f32x4 vn[2];
+        f32x4 vn[2], knn; float knTn;
         const int gnext = grp + gstride < ngroups ? grp + gstride : grp;      // last iteration: harmless reload of this group
         if constexpr (!INNER) load_v(gnext, vn);
+        load_kn(gnext, knn, knTn);
         ST_T(0);
 
         // ------------------------------------------------------------------ forward recompute (D layout)
@@ -652,22 +677,24 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             const float wf = fv ? expf(expfac * (float)f) : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                // Branch-free on purpose: with the loads' only uses inside an `if (fv && to < OT)` block the compiler SANK ten
+                // of them from the top of the loop body into that block, where they became three serialized memory round trips.
                 const int to = 4 * g + r;
-                float d9 = 0.f, tail = 0.f;
-                if (fv && to < OT) {
-                    const float gre = q_gre[r], gim = q_gim[r], ph = q_ph[r], mh = q_mh[r];
-                    float sn, cs; st_sincos(ph, sn, cs);
-                    if (ae == 0) {
-                        const float sg = mh > 0.f ? 1.f : (mh < 0.f ? -1.f : 0.f);
-                        const float dmh = gre * cs + gim * sn + reg_coef * sg * wf + q_gm[r];
-                        d9 = dmh * q_mt[r] * elu_grad_from_out(e9[0][r]);
-                        tail = dmh * e9[0][r];
-                    } else {
-                        const float dph = mh * (gim * cs - gre * sn);
-                        d9 = dph * elu_grad_from_out(e9[0][r]);
-                        tail = dph;
-                    }
-                }
+                const bool ok = fv && to < OT;
+                const bool lv = ok && to >= to_lo && to <= to_hi;
+                const float gre = lv ? q_x[r][0] + (nslab > 1 ? q_x[r][1] : 0.f) + (nslab > 2 ? q_x[r][2] : 0.f) : 0.f;
+                const float gim = lv ? q_y[r][0] + (nslab > 1 ? q_y[r][1] : 0.f) + (nslab > 2 ? q_y[r][2] : 0.f) : 0.f;
+                const float ph = q_ph[r], mh = q_mh[r];
+                asm volatile("" :: "v"(q_mt[r]));       // second use: a single-use load feeding a select is turned into a branch with the load sunk into it
+                float sn, cs; st_sincos(ph, sn, cs);
+                const float eg = elu_grad_from_out(e9[0][r]);
+                const float sg = mh > 0.f ? 1.f : (mh < 0.f ? -1.f : 0.f);
+                const float dmh = gre * cs + gim * sn + reg_coef * sg * wf + (g_mag_hat ? q_gm[r] : 0.f);
+                const float dph = mh * (gim * cs - gre * sn);
+                // one formula for both nets (x * 1.0f is exact): magnitude d9 = dmh * mag_tail * ELU', tail = dmh * e9; phase d9 = dph * ELU', tail = dph
+                const float dx = ae == 0 ? dmh : dph, mt1 = ae == 0 ? q_mt[r] : 1.f, e1 = ae == 0 ? e9[0][r] : 1.f;
+                const float d9 = ok ? dx * mt1 * eg : 0.f;
+                const float tail = ok ? dx * e1 : 0.f;
                 da9[0][r] = d9;
                 Ts[to * SP + c] = tail;
                 Ys[to * SP + c] = d9;                      // [feature t'][row c] -> read back transposed below
@@ -766,7 +793,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
 #pragma unroll
                 for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dvout[(unsigned)(16 * ot + 4 * g + r) * Rw + col0 + c] = da1[ot][r];
+                    for (int r = 0; r < 4; ++r) stg32(dvout, (unsigned)(16 * ot + 4 * g + r) * Rw + col0 + c, da1[ot][r]);
             } else {
                 to_T<4>(XD, da1, daT1, g, c);
             }
@@ -802,7 +829,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
                 if (fv && t < T) {
                     float v = dvs[it][r];
                     if (t >= T - OT) v += Ts[(t - (T - OT)) * SP + c];
-                    dvout[((unsigned)b * T + t) * F + f] = v;
+                    stg32(dvout, ST_MUL24(ST_MUL24(b, T) + (unsigned)t, F) + (unsigned)f, v);
                 }
             }
         }
@@ -811,6 +838,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             mask_v(gnext, vn);
             vr[0] = vn[0]; vr[1] = vn[1];
         }
+        mask_kn(knn, knTn); kn = knn; knT = knTn;
     }
     // ---------------------------------------------------------------------- workgroup partial gradients
     // The forward images are dead now: their region becomes the workgroup's gradient image, dW_l as [o][INp] at CL::A_l and

@@ -304,6 +304,8 @@ extern "C" int st_ae_fwd(const st_dims* d, const float* mag, const float* phs, c
         WideWS w; wide_carve(d, ws, &w);
         return ae_wide_fwd(d, L, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, AA, reg_partial, w, stream);
     }
+    ST_REQ((size_t)d->B * d->T * d->F < ((size_t)1 << 30) && (size_t)d->B * d->OT * L.KP < ((size_t)1 << 30),
+           "st_ae_fwd: batch too large for the kernel's 32-bit element offsets (B=%d)", d->B);
     const size_t lds = (size_t)2 * sta::CL::FWD_TOTAL * sizeof(float);
     static bool attr = false;
     if (!attr) {
@@ -420,7 +422,7 @@ static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, cons
 {
     hipStream_t s = st_stream(stream);
     const int FP = L.KP / 2, F = d->F, T = d->T, OT = d->OT, R = (int)w.R, Tp = w.Tp;
-    ST_REQ(w.R * (size_t)(T > 64 ? T : 64) < ((size_t)1 << 31), "wide autoencoder path: batch too large (B=%d)", d->B);
+    ST_REQ(w.R * (size_t)(T > 64 ? T : 64) < ((size_t)1 << 30), "wide autoencoder path: batch too large (B=%d)", d->B);
     const stg::RowMap id = stg::all_frames(1);
     int out[9], in[9]; ae_shapes(d, out, in);
     for (int a = 0; a < 2; ++a) {
@@ -570,7 +572,7 @@ static int ae_bwd_impl(const st_dims* d, const float* mag, const float* phs, con
     }
     const size_t lds = ((size_t)sta::CL::BWD_TOTAL + (size_t)AE_BWD_NW * sta::AE_BWD_SCR) * sizeof(float);
     static_assert(((size_t)sta::CL::BWD_TOTAL + (size_t)AE_BWD_NW * sta::AE_BWD_SCR) * sizeof(float) <= 160 * 1024, "ae_bwd LDS budget");
-    ST_REQ((size_t)st_synth_slabs(d) * d->B * d->OT * L.KP < ((size_t)1 << 31) && (size_t)d->B * d->T * L.KP < ((size_t)1 << 31),
+    ST_REQ((size_t)st_synth_slabs(d) * d->B * d->OT * L.KP < ((size_t)1 << 30) && (size_t)d->B * d->T * L.KP < ((size_t)1 << 30),
            "st_ae_bwd: batch too large for the kernel's 32-bit element offsets (B=%d)", d->B);
     static bool attr = false;
     if (!attr) {
