@@ -612,10 +612,17 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
                 // up to 3 split-K slabs: all six loads are issued together (a runtime-trip-count loop here serialised ~12
                 // memory round trips per group)
                 const unsigned p0 = ST_MUL24(lv ? ro : 0u, KP) + (unsigned)fq;
+#ifdef ST_AE_NOQ   // timing experiment only
+                q_x[r][0] = ldg32(dAA, p0); q_x[r][1] = 0.f; q_x[r][2] = 0.f;
+                q_y[r][0] = ldg32(dAA, p0 + FP); q_y[r][1] = 0.f; q_y[r][2] = 0.f;
+                const unsigned pF = ST_MUL24(ro, F) + (unsigned)fq;
+                q_ph[r] = 0.3f; q_mh[r] = 0.7f; q_gm[r] = 0.f;
+#else
                 q_x[r][0] = ldg32(dAA, p0); q_x[r][1] = ldg32(dAA, p0 + o1); q_x[r][2] = ldg32(dAA, p0 + o2);
                 q_y[r][0] = ldg32(dAA, p0 + FP); q_y[r][1] = ldg32(dAA, p0 + o1 + FP); q_y[r][2] = ldg32(dAA, p0 + o2 + FP);
                 const unsigned pF = ST_MUL24(ro, F) + (unsigned)fq;
                 q_ph[r] = ldg32(phs_hat, pF); q_mh[r] = ldg32(mag_hat, pF); q_gm[r] = ldg32(gmp, pF);
+#endif
                 q_mt[r] = ldg32(vin, btF + ST_MUL24(ok ? T - OT + to : 0, F));
             }
         }
@@ -701,115 +708,89 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             }
         }
         // ------------------------------------------------------------------ backward through the layers
-        // T layout: lane (g,c), reg r  <->  row 4g + r, feature 16*tile + c
-        f32x4 daT9[1];
-        if constexpr (!INNER) daT9[0] = *reinterpret_cast<const f32x4*>(Ys + c * SP + 4 * g);
-        ST_T(7);
-        // layer 9 (64 -> OT): needs h8^T and W9 in dgrad order
-        f32x4 hT8[4], da8[4], daT8[4];
+        // T layout: lane (g,c), reg r  <->  row 4g + r, feature 16*tile + c.
+        // Every stage l runs in the order   [hT_{l-1} = to_T(h_{l-1})]  ->  data gradient MFMAs (fragments fd_l were fetched
+        // during the previous stage)  ->  ELU' and the to_T of da_{l-1} + the fragment fetch of stage l-1 ISSUED  ->  weight
+        // gradient MFMAs of layer l.  The weight-gradient MFMAs depend on nothing issued in this stage except hT, so their
+        // ~1k cycles in the MFMA pipe cover the LDS round trips of the transposes and the next fragments (with one wave per
+        // SIMD nothing else would).
+#define ST_BWD_STAGE(O_, I_, FD_, DA_, DAT_, HP_, HTP_, DAP_, DATP_, RW_, RB_, NEXT_) \
+        to_T<I_>(XH, HP_, HTP_, g, c); ST_FENCE(); \
+        dgradD_fr<O_, I_>(FD_, DA_, DAP_); mul_elu_grad<I_>(DAP_, HP_); \
+        to_T<I_>(XD, DAP_, DATP_, g, c); NEXT_; ST_FENCE(); \
+        wgrad_reg<O_, I_>(RW_, RB_, DAT_, HTP_);
+        f32x4 hT8[4], da8[4], daT8[4], fd8[2 * 4];
         if constexpr (INNER) {                     // dH8 arrives from the layer-9 data-gradient GEMM; h8^T is still needed for ELU' and dW8
+            frags_dgrad<4, 2, CL::I7>(fd8, lw + CL::G7, g, c);
             to_T<4>(XH, h8, hT8, g, c);
 #pragma unroll
             for (int ot = 0; ot < 4; ++ot) da8[ot] = dh8[ot];
             mul_elu_grad<4>(da8, h8); to_T<4>(XD, da8, daT8, g, c);
+            ST_T(7);
         } else {
-            f32x4 fd[4 * 1];
-            frags_dgrad<1, 4, CL::I8>(fd, lw + CL::G8, g, c); ST_FENCE();
-            to_T<4>(XH, h8, hT8, g, c);
-            wgrad_reg<1, 4>(rW9, rb9, daT9, hT8);
-            dgradD_fr<1, 4>(fd, da9, da8); mul_elu_grad<4>(da8, h8); to_T<4>(XD, da8, daT8, g, c);
+            // layer 9 (64 -> OT): d a9 transposed through the wave's scratch
+            f32x4 daT9[1], fd9[4 * 1];
+            frags_dgrad<1, 4, CL::I8>(fd9, lw + CL::G8, g, c);
+            daT9[0] = *reinterpret_cast<const f32x4*>(Ys + c * SP + 4 * g);
+            ST_T(7);
+            ST_BWD_STAGE(1, 4, fd9, da9, daT9, h8, hT8, da8, daT8, rW9, rb9, (frags_dgrad<4, 2, CL::I7>(fd8, lw + CL::G7, g, c)))
         }
         ST_T(8);
         // layer 8 (32 -> 64)
-        f32x4 hT7[2], da7[2], daT7[2];
-        {
-            f32x4 fd[2 * 4];
-            frags_dgrad<4, 2, CL::I7>(fd, lw + CL::G7, g, c); ST_FENCE();
-            to_T<2>(XH, h7, hT7, g, c);
-            wgrad_reg<4, 2>(rW8, rb8, daT8, hT7);
-            dgradD_fr<4, 2>(fd, da8, da7); mul_elu_grad<2>(da7, h7); to_T<2>(XD, da7, daT7, g, c);
-        }
+        f32x4 hT7[2], da7[2], daT7[2], fd7[1 * 2];
+        ST_BWD_STAGE(4, 2, fd8, da8, daT8, h7, hT7, da7, daT7, rW8, rb8, (frags_dgrad<2, 1, CL::I6>(fd7, lw + CL::G6, g, c)))
         ST_T(9);
         // layer 7 (16 -> 32)
-        f32x4 hT6[1], da6[1], daT6[1];
-        {
-            f32x4 fd[1 * 2];
-            frags_dgrad<2, 1, CL::I6>(fd, lw + CL::G6, g, c); ST_FENCE();
-            to_T<1>(XH, h6, hT6, g, c);
-            wgrad_reg<2, 1>(rW7, rb7, daT7, hT6);
-            dgradD_fr<2, 1>(fd, da7, da6); mul_elu_grad<1>(da6, h6); to_T<1>(XD, da6, daT6, g, c);
-        }
+        f32x4 hT6[1], da6[1], daT6[1], fd6[1];
+        ST_BWD_STAGE(2, 1, fd7, da7, daT7, h6, hT6, da6, daT6, rW7, rb7, (frags_dgrad<1, 1, CL::I5>(fd6, lw + CL::G5, g, c)))
         ST_T(10);
         // layer 6 (16 -> 16)
-        f32x4 hT5[1], da5[1], daT5[1];
-        {
-            f32x4 fd[1 * 1];
-            frags_dgrad<1, 1, CL::I5>(fd, lw + CL::G5, g, c); ST_FENCE();
-            to_T<1>(XH, h5, hT5, g, c);
-            wgrad_reg<1, 1>(rW6, rb6, daT6, hT5);
-            dgradD_fr<1, 1>(fd, da6, da5); mul_elu_grad<1>(da5, h5); to_T<1>(XD, da5, daT5, g, c);
-        }
+        f32x4 hT5[1], da5[1], daT5[1], fd5[1];
+        ST_BWD_STAGE(1, 1, fd6, da6, daT6, h5, hT5, da5, daT5, rW6, rb6, (frags_dgrad<1, 1, CL::I4>(fd5, lw + CL::G4, g, c)))
         // layer 5 ([h4 ; knobs] -> 16): weight gradient over both input tiles, data gradient to h4 only
-        f32x4 hT4[1], hT4k[2], da4[1], daT4[1];
+        f32x4 hT4[1], hT4k[2], da4[1], daT4[1], fd4[1];
         {
-            f32x4 fd[1 * 1];
-            frags_dgrad<1, 1, CL::I4>(fd, lw + CL::G4, g, c); ST_FENCE();
-            to_T<1>(XH, h4, hT4, g, c);
+            to_T<1>(XH, h4, hT4, g, c); ST_FENCE();
+            dgradD_fr<1, 1>(fd5, da5, da4); mul_elu_grad<1>(da4, h4);
+            to_T<1>(XD, da4, daT4, g, c); frags_dgrad<1, 1, CL::I3>(fd4, lw + CL::G3, g, c); ST_FENCE();
             hT4k[0] = hT4[0];
             hT4k[1] = (f32x4){knT, knT, knT, knT};                   // features 16 + c = knob c, every row
             wgrad_reg<1, 2>(rW5, rb5, daT5, hT4k);
-            dgradD_fr<1, 1>(fd, da5, da4); mul_elu_grad<1>(da4, h4); to_T<1>(XD, da4, daT4, g, c);
         }
         // layer 4 (16 -> 16)
-        f32x4 hT3[1], da3[1], daT3[1];
-        {
-            f32x4 fd[1 * 1];
-            frags_dgrad<1, 1, CL::I3>(fd, lw + CL::G3, g, c); ST_FENCE();
-            to_T<1>(XH, h3, hT3, g, c);
-            wgrad_reg<1, 1>(rW4, rb4, daT4, hT3);
-            dgradD_fr<1, 1>(fd, da4, da3); mul_elu_grad<1>(da3, h3); to_T<1>(XD, da3, daT3, g, c);
-        }
+        f32x4 hT3[1], da3[1], daT3[1], fd3[2 * 1];
+        ST_BWD_STAGE(1, 1, fd4, da4, daT4, h3, hT3, da3, daT3, rW4, rb4, (frags_dgrad<1, 2, CL::I2>(fd3, lw + CL::G2, g, c)))
         ST_T(11);
         // layer 3 (32 -> 16)
-        f32x4 hT2[2], da2[2], daT2[2];
-        {
-            f32x4 fd[2 * 1];
-            frags_dgrad<1, 2, CL::I2>(fd, lw + CL::G2, g, c); ST_FENCE();
-            to_T<2>(XH, h2, hT2, g, c);
-            wgrad_reg<1, 2>(rW3, rb3, daT3, hT2);
-            dgradD_fr<1, 2>(fd, da3, da2); mul_elu_grad<2>(da2, h2); to_T<2>(XD, da2, daT2, g, c);
-        }
+        f32x4 hT2[2], da2[2], daT2[2], fd2[4 * 2];
+        ST_BWD_STAGE(1, 2, fd3, da3, daT3, h2, hT2, da2, daT2, rW3, rb3, (frags_dgrad<2, 4, CL::I1>(fd2, lw + CL::G1, g, c)))
         ST_T(12);
         // layer 2 (64 -> 32)
-        f32x4 hT1[4], da1[4], daT1[4];
-        {
-            f32x4 fd[4 * 2];
-            frags_dgrad<2, 4, CL::I1>(fd, lw + CL::G1, g, c); ST_FENCE();
-            to_T<4>(XH, h1, hT1, g, c);
+        f32x4 hT1[4], da1[4], daT1[4], fd1[2 * 4];
+        if constexpr (INNER) {                     // dA1 goes back to memory for the layer-1 GEMMs
+            to_T<4>(XH, h1, hT1, g, c); ST_FENCE();
+            dgradD_fr<2, 4>(fd2, da2, da1); mul_elu_grad<4>(da1, h1);
+            const unsigned col0 = (unsigned)b * FP + (unsigned)(grp - b * gpw) * 16;
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stg32(dvout, (unsigned)(16 * ot + 4 * g + r) * Rw + col0 + c, da1[ot][r]);
+            ST_FENCE();
             wgrad_reg<2, 4>(rW2, rb2, daT2, hT1);
-            dgradD_fr<2, 4>(fd, da2, da1); mul_elu_grad<4>(da1, h1);
-            if constexpr (INNER) {                 // dA1 goes back to memory for the layer-1 GEMMs
-                const unsigned col0 = (unsigned)b * FP + (unsigned)(grp - b * gpw) * 16;
-#pragma unroll
-                for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) stg32(dvout, (unsigned)(16 * ot + 4 * g + r) * Rw + col0 + c, da1[ot][r]);
-            } else {
-                to_T<4>(XD, da1, daT1, g, c);
-            }
+        } else {
+            ST_BWD_STAGE(2, 4, fd2, da2, daT2, h1, hT1, da1, daT1, rW2, rb2, (frags_dgrad<4, 2, CL::I0>(fd1, lw + CL::G0, g, c)))
         }
         ST_T(13);
         // layer 1 (T -> 64): input rows transposed through the wave's scratch
         f32x4 vT[2], dv[2];
         if constexpr (!INNER) {
-            f32x4 fd[2 * 4];
-            frags_dgrad<4, 2, CL::I0>(fd, lw + CL::G0, g, c);
 #pragma unroll
             for (int it = 0; it < 2; ++it) vT[it] = *reinterpret_cast<const f32x4*>(Vs + (16 * it + c) * SP + 4 * g);
             ST_FENCE();
+            dgradD_fr<4, 2>(fd1, da1, dv);
             wgrad_reg<4, 2>(rW1, rb1, daT1, vT);
-            dgradD_fr<4, 2>(fd, da1, dv);
         }
+#undef ST_BWD_STAGE
         ST_T(14);
         // ------------------------------------------------------------------ d input rows (+ skip / residual tails)
         if constexpr (!INNER) {
