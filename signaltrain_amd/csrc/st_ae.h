@@ -647,36 +647,43 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         ST_T(0);
 
         // ------------------------------------------------------------------ forward recompute (D layout)
+        // Rolling fragment prefetch: each stage first issues the LDS reads of the NEXT layer's fragments, then runs its own
+        // MFMA chain, so no stage starts by waiting for an LDS round trip (one wave per SIMD: nothing else would hide it).
         f32x4 h1[4], h2[2], h3[1], h4[1], h5[1], h6[1], h7[2], h8[4], e9[1];
+        f32x4 fr2[2 * 4];
         if constexpr (INNER) {
 #pragma unroll
             for (int ot = 0; ot < 4; ++ot) h1[ot] = h1in[ot];
+            frags_fwd<2, 4, CL::O1>(fr2, lw + CL::A1, g, c);
         } else {
-            f32x4 fr[4 * 2]; frags_fwd<4, 2, CL::O0>(fr, lw + CL::A0, g, c);
+            f32x4 fr1[4 * 2]; frags_fwd<4, 2, CL::O0>(fr1, lw + CL::A0, g, c);
+            frags_fwd<2, 4, CL::O1>(fr2, lw + CL::A1, g, c);
 #pragma unroll
             for (int it = 0; it < 2; ++it)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Vs[(16 * it + 4 * g + r) * SP + c] = vr[it][r];   // [feature t][row c]: read back transposed for the layer-1 wgrad
             ST_FENCE();
-            fwdD_fr<4, 2>(fr, lw + CL::B0, vr, h1, g);
+            fwdD_fr<4, 2>(fr1, lw + CL::B0, vr, h1, g);
         }
         ST_T(1);
-        { f32x4 fr[2 * 4]; frags_fwd<2, 4, CL::O1>(fr, lw + CL::A1, g, c); ST_FENCE(); fwdD_fr<2, 4>(fr, lw + CL::B1, h1, h2, g); }
+        f32x4 fr3[1 * 2]; frags_fwd<1, 2, CL::O2>(fr3, lw + CL::A2, g, c); ST_FENCE(); fwdD_fr<2, 4>(fr2, lw + CL::B1, h1, h2, g);
         ST_T(2);
-        { f32x4 fr[1 * 2]; frags_fwd<1, 2, CL::O2>(fr, lw + CL::A2, g, c); ST_FENCE(); fwdD_fr<1, 2>(fr, lw + CL::B2, h2, h3, g); }
-        { f32x4 fr[1 * 1]; frags_fwd<1, 1, CL::O3>(fr, lw + CL::A3, g, c); ST_FENCE(); fwdD_fr<1, 1>(fr, lw + CL::B3, h3, h4, g); }
+        f32x4 fr4[1 * 1]; frags_fwd<1, 1, CL::O3>(fr4, lw + CL::A3, g, c); ST_FENCE(); fwdD_fr<1, 2>(fr3, lw + CL::B2, h2, h3, g);
+        f32x4 fr5[1 * 2]; frags_fwd<1, 2, CL::O4>(fr5, lw + CL::A4, g, c); ST_FENCE(); fwdD_fr<1, 1>(fr4, lw + CL::B3, h3, h4, g);
+        f32x4 fr6[1 * 1]; frags_fwd<1, 1, CL::O5>(fr6, lw + CL::A5, g, c); ST_FENCE();
         {
-            f32x4 fr[1 * 2]; frags_fwd<1, 2, CL::O4>(fr, lw + CL::A4, g, c); ST_FENCE();
             const f32x4 hk[2] = {h4[0], kn};                                 // knob features 16 + 4g + r
-            fwdD_fr<1, 2>(fr, lw + CL::B4, hk, h5, g);
+            fwdD_fr<1, 2>(fr5, lw + CL::B4, hk, h5, g);
         }
         ST_T(3);
-        { f32x4 fr[1 * 1]; frags_fwd<1, 1, CL::O5>(fr, lw + CL::A5, g, c); ST_FENCE(); fwdD_fr<1, 1>(fr, lw + CL::B5, h5, h6, g); }
-        { f32x4 fr[2 * 1]; frags_fwd<2, 1, CL::O6>(fr, lw + CL::A6, g, c); ST_FENCE(); fwdD_fr<2, 1>(fr, lw + CL::B6, h6, h7, g); }
+        f32x4 fr7[2 * 1]; frags_fwd<2, 1, CL::O6>(fr7, lw + CL::A6, g, c); ST_FENCE(); fwdD_fr<1, 1>(fr6, lw + CL::B5, h5, h6, g);
+        f32x4 fr8[4 * 2]; frags_fwd<4, 2, CL::O7>(fr8, lw + CL::A7, g, c); ST_FENCE(); fwdD_fr<2, 1>(fr7, lw + CL::B6, h6, h7, g);
         ST_T(4);
-        { f32x4 fr[4 * 2]; frags_fwd<4, 2, CL::O7>(fr, lw + CL::A7, g, c); ST_FENCE(); fwdD_fr<4, 2>(fr, lw + CL::B7, h7, h8, g); }
+        f32x4 fr9[1 * 4];
+        if constexpr (!INNER) frags_fwd<1, 4, CL::O8>(fr9, lw + CL::A8, g, c);
+        ST_FENCE(); fwdD_fr<4, 2>(fr8, lw + CL::B7, h7, h8, g);
         ST_T(5);
-        if constexpr (!INNER) { f32x4 fr[1 * 4]; frags_fwd<1, 4, CL::O8>(fr, lw + CL::A8, g, c); ST_FENCE(); fwdD_fr<1, 4>(fr, lw + CL::B8, h8, e9, g); }
+        if constexpr (!INNER) { ST_FENCE(); fwdD_fr<1, 4>(fr9, lw + CL::B8, h8, e9, g); }
         ST_T(6);
         // ------------------------------------------------------------------ d out  (D layout: t' = 4g + r)
         f32x4 da9[1];
@@ -714,11 +721,21 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         // gradient MFMAs of layer l.  The weight-gradient MFMAs depend on nothing issued in this stage except hT, so their
         // ~1k cycles in the MFMA pipe cover the LDS round trips of the transposes and the next fragments (with one wave per
         // SIMD nothing else would).
+// Scheduling recipe of one backward stage (everything between its two fences): the N data-gradient MFMAs first, two
+// weight-gradient MFMAs of slack for their results to land, then one weight-gradient MFMA per pair of VALU / LDS
+// instructions (ELU', transposes, next fragments), so that the latter issue while the MFMA pipe is busy.
+#define ST_PIPE(N_) do { \
+        __builtin_amdgcn_sched_group_barrier(0x008, (N_) + 2, 0); \
+        _Pragma("unroll") for (int p_ = 0; p_ < (N_) - 2; ++p_) { \
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); __builtin_amdgcn_sched_group_barrier(0x300, 1, 0); \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); } \
+        ST_FENCE(); } while (0)
 #define ST_BWD_STAGE(O_, I_, FD_, DA_, DAT_, HP_, HTP_, DAP_, DATP_, RW_, RB_, NEXT_) \
         to_T<I_>(XH, HP_, HTP_, g, c); ST_FENCE(); \
         dgradD_fr<O_, I_>(FD_, DA_, DAP_); mul_elu_grad<I_>(DAP_, HP_); \
-        to_T<I_>(XD, DAP_, DATP_, g, c); NEXT_; ST_FENCE(); \
-        wgrad_reg<O_, I_>(RW_, RB_, DAT_, HTP_);
+        to_T<I_>(XD, DAP_, DATP_, g, c); NEXT_; \
+        wgrad_reg<O_, I_>(RW_, RB_, DAT_, HTP_); \
+        ST_PIPE(O_ * I_ * 4);
         f32x4 hT8[4], da8[4], daT8[4], fd8[2 * 4];
         if constexpr (INNER) {                     // dH8 arrives from the layer-9 data-gradient GEMM; h8^T is still needed for ELU' and dW8
             frags_dgrad<4, 2, CL::I7>(fd8, lw + CL::G7, g, c);
@@ -797,21 +814,23 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         // Materialise the accumulators in VGPRs HERE, in the block of the MFMAs that produce them: the stores below sit in
         // conditional blocks, and an accumulator first read behind a skipped block would be read before the MFMA has
         // finished (the hazard class tools/check_mfma_hazards.py scans for).
-        float dvs[2][4];
+        float dvs[2][4], tls[2][4];
 #pragma unroll
         for (int it = 0; it < 2; ++it)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { dvs[it][r] = dv[it][r]; asm volatile("" : "+v"(dvs[it][r])); }
+            for (int r = 0; r < 4; ++r) {
+                dvs[it][r] = dv[it][r]; asm volatile("" : "+v"(dvs[it][r]));
+                const int ti = 16 * it + 4 * g + r - (T - OT);                 // all eight tail reads up front: one LDS round trip, not one per store
+                tls[it][r] = Ts[(ti >= 0 && ti < OT ? ti : 0) * SP + c];
+            }
+        const unsigned dv0 = ST_MUL24(ST_MUL24(b, T), F) + (unsigned)f;
 #pragma unroll
         for (int it = 0; it < 2; ++it)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int t = 16 * it + 4 * g + r;
-                if (fv && t < T) {
-                    float v = dvs[it][r];
-                    if (t >= T - OT) v += Ts[(t - (T - OT)) * SP + c];
-                    stg32(dvout, ST_MUL24(ST_MUL24(b, T) + (unsigned)t, F) + (unsigned)f, v);
-                }
+                const float v = dvs[it][r] + (t >= T - OT ? tls[it][r] : 0.f);
+                if (fv && t < T) stg32(dvout, dv0 + ST_MUL24(t, F), v);
             }
         }
         ST_T(15);
