@@ -601,7 +601,10 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         float q_x[4][3], q_y[4][3], q_ph[4], q_mh[4], q_mt[4], q_gm[4];
         const float* gmp = g_mag_hat ? g_mag_hat : mag_hat;
         if constexpr (!INNER) {
-            const unsigned o1 = nslab > 1 ? (unsigned)slab : 0u, o2 = nslab > 2 ? 2u * (unsigned)slab : 0u;
+            // wave-uniform base pointers for the slabs and the imaginary half: the six dAA loads of a row share ONE offset register
+            const size_t o1 = nslab > 1 ? slab : 0, o2 = nslab > 2 ? 2 * slab : 0;
+            const float* const dA0 = dAA, * const dA1 = dAA + o1, * const dA2 = dAA + o2;
+            const float* const dB0 = dA0 + FP, * const dB1 = dA1 + FP, * const dB2 = dA2 + FP;
             const unsigned bOT = ST_MUL24(b, OT), btF = ST_MUL24(ST_MUL24(b, T), F) + (unsigned)fq;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -612,17 +615,10 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
                 // up to 3 split-K slabs: all six loads are issued together (a runtime-trip-count loop here serialised ~12
                 // memory round trips per group)
                 const unsigned p0 = ST_MUL24(lv ? ro : 0u, KP) + (unsigned)fq;
-#ifdef ST_AE_NOQ   // timing experiment only
-                q_x[r][0] = ldg32(dAA, p0); q_x[r][1] = 0.f; q_x[r][2] = 0.f;
-                q_y[r][0] = ldg32(dAA, p0 + FP); q_y[r][1] = 0.f; q_y[r][2] = 0.f;
-                const unsigned pF = ST_MUL24(ro, F) + (unsigned)fq;
-                q_ph[r] = 0.3f; q_mh[r] = 0.7f; q_gm[r] = 0.f;
-#else
-                q_x[r][0] = ldg32(dAA, p0); q_x[r][1] = ldg32(dAA, p0 + o1); q_x[r][2] = ldg32(dAA, p0 + o2);
-                q_y[r][0] = ldg32(dAA, p0 + FP); q_y[r][1] = ldg32(dAA, p0 + o1 + FP); q_y[r][2] = ldg32(dAA, p0 + o2 + FP);
+                q_x[r][0] = ldg32(dA0, p0); q_x[r][1] = ldg32(dA1, p0); q_x[r][2] = ldg32(dA2, p0);
+                q_y[r][0] = ldg32(dB0, p0); q_y[r][1] = ldg32(dB1, p0); q_y[r][2] = ldg32(dB2, p0);
                 const unsigned pF = ST_MUL24(ro, F) + (unsigned)fq;
                 q_ph[r] = ldg32(phs_hat, pF); q_mh[r] = ldg32(mag_hat, pF); q_gm[r] = ldg32(gmp, pF);
-#endif
                 q_mt[r] = ldg32(vin, btF + ST_MUL24(ok ? T - OT + to : 0, F));
             }
         }
