@@ -103,6 +103,10 @@ static int check_dims(const st_dims* d)
     ST_REQ(d->y == (d->OT - 1) * d->H - d->N && d->y > 0 && d->y <= d->L, "y must equal (OT-1)*H-N");
     ST_REQ(d->OT <= d->T, "OT must be <= T");
     ST_REQ(d->K <= 16, "at most 16 knobs");
+    // the kernels address every operand with 32-bit element offsets from a wave-uniform base and index rows with 24-bit
+    // multiplies: rows (B*T) < 2^24, the largest per-batch operands (B*T x KP spectra, B x (L + 2N) padded signals) < 2^30 elements
+    ST_REQ((size_t)d->B * d->T < ((size_t)1 << 24) && (size_t)d->B * d->T * st_kp_of(d->F) < ((size_t)1 << 30) &&
+           (size_t)d->B * ((size_t)d->L + 2 * (size_t)d->N) < ((size_t)1 << 30), "batch too large for 32-bit element offsets (B=%d)", d->B);
     return ST_OK;
 }
 

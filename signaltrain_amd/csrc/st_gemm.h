@@ -35,12 +35,19 @@ constexpr int NJ = BN / 32;   // MFMA column tiles per wave
 constexpr int PK = BK + 4;    // row pitch (floats) of an NT tile in LDS
 
 // Compact row index r' (live frames only) -> (window b, frame t); full row = b*T + t.
+// r / Tv by multiply-high with magic = floor(2^32 / Tv) + 1 (exact for r < 2^32 / Tv; the host keeps row counts below
+// 2^24): the loaders call this once per global load inside the k-loop, where a run-time integer division costs ~20 VALU
+// instructions -- it was most of the 8 VALU-per-MFMA of the weight-gradient GEMMs.  magic = 0 means Tv = 1.
 struct RowMap {
-    int Tv, t_lo, T;
+    int Tv, t_lo, T; unsigned magic;
     __host__ __device__ int rows(int B) const { return B * Tv; }
-    __device__ void split(int r, int& b, int& t) const { b = r / Tv; t = t_lo + (r - b * Tv); }
-    __device__ int full(int r) const { int b, t; split(r, b, t); return b * T + t; }
+    __device__ void split(int r, int& b, int& t) const {
+        b = magic ? (int)__umulhi((unsigned)r, magic) : r;
+        t = t_lo + (r - (int)__umul24((unsigned)b, (unsigned)Tv));
+    }
+    __device__ int full(int r) const { int b, t; split(r, b, t); return (int)__umul24((unsigned)b, (unsigned)T) + t; }
 };
+static inline unsigned rowmap_magic(int Tv) { return Tv > 1 ? (unsigned)(((unsigned long long)1 << 32) / (unsigned)Tv) + 1u : 0u; }
 // Frames t with a non-empty intersection [H t - pad, H t - pad + N) x [0, Ls)
 static inline RowMap live_frames(int T, int H, int N, int pad, int Ls)
 {
@@ -49,9 +56,17 @@ static inline RowMap live_frames(int T, int H, int N, int pad, int Ls)
     while (hi >= lo && H * hi - pad >= Ls) --hi;
     RowMap m; m.t_lo = lo; m.Tv = hi - lo + 1; m.T = T;
     if (m.Tv <= 0) { m.Tv = T; m.t_lo = 0; }
+    m.magic = rowmap_magic(m.Tv);
     return m;
 }
-static inline RowMap all_frames(int T) { RowMap m; m.Tv = T; m.t_lo = 0; m.T = T; return m; }
+static inline RowMap all_frames(int T) { RowMap m; m.Tv = T; m.t_lo = 0; m.T = T; m.magic = rowmap_magic(T); return m; }
+
+// float4 at a 32-bit ELEMENT offset from a wave-uniform base: saddr + voffset addressing, no 64-bit arithmetic per load
+// (the host keeps every operand below 2^30 elements).
+__device__ __forceinline__ float4 ldg128(const float* __restrict__ base, const unsigned elem)
+{
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + (size_t)(elem << 2));
+}
 
 struct Src { const float* p; bool ok; };
 
@@ -120,6 +135,18 @@ struct FramedTN {
         }
         return s;
     }
+    // element offset from dummy() of (row r, tap n); ok = the load is valid (else the caller loads offset 0 and zeroes)
+    __device__ unsigned off(int r, int n, bool& ok) const {
+        int b, t;
+        map.split(r < R ? r : 0, b, t);
+        if (PADDED) {
+            ok = true;
+            return __umul24((unsigned)b, (unsigned)(Ls + 2 * pad)) + __umul24((unsigned)H, (unsigned)t) + (unsigned)n;
+        }
+        const int pos = H * t - pad + n;
+        ok = r < R && n < Kw && pos >= 0 && pos < Ls;
+        return ok ? __umul24((unsigned)b, (unsigned)Ls) + (unsigned)pos : 0u;
+    }
     __device__ float4 post(float4 v) const {
         if (!PADDED) { v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; }
         return v;
@@ -151,6 +178,10 @@ struct PlainTN {
     __device__ Src src(int k, int c) const {
         const bool ok = k < K && c < cols;
         return Src{base + (size_t)(ok ? map.full(k) : 0) * ld + c, ok};
+    }
+    __device__ unsigned off(int k, int c, bool& ok) const {
+        ok = k < K && c < cols;
+        return ok ? __umul24((unsigned)map.full(k), (unsigned)ld) + (unsigned)c : 0u;
     }
     __device__ float4 post(float4 v) const { return v; }
 };
@@ -351,19 +382,23 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
         for (int p = 0; p < A_IT; ++p)
 #pragma unroll
             for (int q = 0; q < A_LD; ++q) {
-                Src s;
-                if constexpr (AL::kTN) s = al.src(kt + a_k[p] + q, m_blk + a_i[p]); else s = al.src(a_st[p], kt + a_k[p]);
-                if constexpr (AL::kCheck) { oa[p][q] = s.ok; ra[p][q] = *reinterpret_cast<const float4*>(s.ok ? s.p : al.dummy()); }
-                else { oa[p][q] = true; ra[p][q] = *reinterpret_cast<const float4*>(s.p); }
+                if constexpr (AL::kTN) { bool ok; const unsigned o = al.off(kt + a_k[p] + q, m_blk + a_i[p], ok); oa[p][q] = ok; ra[p][q] = ldg128(al.dummy(), o); }
+                else {
+                    const Src s = al.src(a_st[p], kt + a_k[p]);
+                    if constexpr (AL::kCheck) { oa[p][q] = s.ok; ra[p][q] = *reinterpret_cast<const float4*>(s.ok ? s.p : al.dummy()); }
+                    else { oa[p][q] = true; ra[p][q] = *reinterpret_cast<const float4*>(s.p); }
+                }
             }
 #pragma unroll
         for (int p = 0; p < B_IT; ++p)
 #pragma unroll
             for (int q = 0; q < B_LD; ++q) {
-                Src s;
-                if constexpr (BL::kTN) s = bl.src(kt + b_k[p] + q, n_blk + b_i[p]); else s = bl.src(b_st[p], kt + b_k[p]);
-                if constexpr (BL::kCheck) { ob[p][q] = s.ok; rb[p][q] = *reinterpret_cast<const float4*>(s.ok ? s.p : bl.dummy()); }
-                else { ob[p][q] = true; rb[p][q] = *reinterpret_cast<const float4*>(s.p); }
+                if constexpr (BL::kTN) { bool ok; const unsigned o = bl.off(kt + b_k[p] + q, n_blk + b_i[p], ok); ob[p][q] = ok; rb[p][q] = ldg128(bl.dummy(), o); }
+                else {
+                    const Src s = bl.src(b_st[p], kt + b_k[p]);
+                    if constexpr (BL::kCheck) { ob[p][q] = s.ok; rb[p][q] = *reinterpret_cast<const float4*>(s.ok ? s.p : bl.dummy()); }
+                    else { ob[p][q] = true; rb[p][q] = *reinterpret_cast<const float4*>(s.p); }
+                }
             }
     };
     auto lstore = [&](int buf) {
@@ -533,19 +568,23 @@ gemm_bf16_kernel(const AL al, const BL bl, const EPI epi, const int K, const int
         for (int p = 0; p < A_IT; ++p)
 #pragma unroll
             for (int q = 0; q < A_LDS; ++q) {
-                Src s;
-                if constexpr (AL::kTN) s = al.src(kt + a_k[p] + q, m_blk + a_i[p]); else s = al.src(a_st[p], kt + a_k[p]);
-                if constexpr (AL::kCheck) { oa[p][q] = s.ok; ra[p][q] = *reinterpret_cast<const float4*>(s.ok ? s.p : al.dummy()); }
-                else { oa[p][q] = true; ra[p][q] = *reinterpret_cast<const float4*>(s.p); }
+                if constexpr (AL::kTN) { bool ok; const unsigned o = al.off(kt + a_k[p] + q, m_blk + a_i[p], ok); oa[p][q] = ok; ra[p][q] = ldg128(al.dummy(), o); }
+                else {
+                    const Src s = al.src(a_st[p], kt + a_k[p]);
+                    if constexpr (AL::kCheck) { oa[p][q] = s.ok; ra[p][q] = *reinterpret_cast<const float4*>(s.ok ? s.p : al.dummy()); }
+                    else { oa[p][q] = true; ra[p][q] = *reinterpret_cast<const float4*>(s.p); }
+                }
             }
 #pragma unroll
         for (int p = 0; p < B_IT; ++p)
 #pragma unroll
             for (int q = 0; q < B_LDS; ++q) {
-                Src s;
-                if constexpr (BL::kTN) s = bl.src(kt + b_k[p] + q, n_blk + b_i[p]); else s = bl.src(b_st[p], kt + b_k[p]);
-                if constexpr (BL::kCheck) { ob[p][q] = s.ok; rb[p][q] = *reinterpret_cast<const float4*>(s.ok ? s.p : bl.dummy()); }
-                else { ob[p][q] = true; rb[p][q] = *reinterpret_cast<const float4*>(s.p); }
+                if constexpr (BL::kTN) { bool ok; const unsigned o = bl.off(kt + b_k[p] + q, n_blk + b_i[p], ok); ob[p][q] = ok; rb[p][q] = ldg128(bl.dummy(), o); }
+                else {
+                    const Src s = bl.src(b_st[p], kt + b_k[p]);
+                    if constexpr (BL::kCheck) { ob[p][q] = s.ok; rb[p][q] = *reinterpret_cast<const float4*>(s.ok ? s.p : bl.dummy()); }
+                    else { ob[p][q] = true; rb[p][q] = *reinterpret_cast<const float4*>(s.p); }
+                }
             }
     };
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
