@@ -72,6 +72,7 @@ struct Src { const float* p; bool ok; };
 
 struct RowState {
     const float* p;   // element k of this row lives at p[k] (only dereferenced for lo <= k < hi)
+    unsigned o;       // the same as a 32-bit element offset from the loader's dummy() base (loaders with kOff; may wrap below zero for k < lo)
     int lo, hi;
 };
 
@@ -88,17 +89,20 @@ template <bool PADDED>
 struct FramedNT {
     static constexpr bool kTN = false;
     static constexpr bool kCheck = !PADDED;
+    static constexpr bool kOff = true;
     const float* sig; int Ls, H, pad, R, Kw; float scale; RowMap map;
     __device__ const float* dummy() const { return sig; }
     __device__ RowState row_state(int r) const {
-        RowState s; s.p = sig; s.lo = 0; s.hi = 0;
+        RowState s; s.p = sig; s.o = 0; s.lo = 0; s.hi = 0;
         if (PADDED) {
             int b, t; map.split(r < R ? r : 0, b, t);         // rows >= R: clamped, their outputs are masked
-            s.p = sig + (size_t)b * (Ls + 2 * pad) + H * t;   // padded coordinate of frame start (bit-exact contract: H*t - pad + pad)
+            s.o = __umul24((unsigned)b, (unsigned)(Ls + 2 * pad)) + __umul24((unsigned)H, (unsigned)t);   // padded coordinate of frame start (bit-exact contract: H*t - pad + pad)
+            s.p = sig + s.o;
             s.hi = Kw;
         } else if (r < R) {
             int b, t; map.split(r, b, t);
             const int start = H * t - pad;                    // frame start in the unpadded signal
+            s.o = __umul24((unsigned)b, (unsigned)Ls) + (unsigned)start;
             s.p = sig + (size_t)b * Ls + start;
             s.lo = start < 0 ? -start : 0;
             s.hi = (Ls - start) < Kw ? (Ls - start) : Kw;
@@ -119,6 +123,7 @@ template <bool PADDED>
 struct FramedTN {
     static constexpr bool kTN = true;
     static constexpr bool kCheck = !PADDED;
+    static constexpr bool kOff = true;
     const float* sig; int Ls, H, pad, R, Kw; float scale; RowMap map;
     __device__ const float* dummy() const { return sig; }
     __device__ Src src(int r, int n) const {
@@ -158,11 +163,13 @@ struct FramedTN {
 struct PlainNT {
     static constexpr bool kTN = false;
     static constexpr bool kCheck = false;
+    static constexpr bool kOff = true;
     const float* base; int R, ld, K; RowMap map;
     __device__ const float* dummy() const { return base; }
     __device__ RowState row_state(int r) const {
         RowState s; s.lo = 0; s.hi = K;
-        s.p = base + (size_t)map.full(r < R ? r : 0) * ld;
+        s.o = __umul24((unsigned)map.full(r < R ? r : 0), (unsigned)ld);
+        s.p = base + s.o;
         return s;
     }
     __device__ Src src(const RowState& s, int k) const { return Src{s.p + k, true}; }
@@ -173,6 +180,7 @@ struct PlainNT {
 struct PlainTN {
     static constexpr bool kTN = true;
     static constexpr bool kCheck = true;
+    static constexpr bool kOff = true;
     const float* base; int K, ld, cols; RowMap map;
     __device__ const float* dummy() const { return base; }
     __device__ Src src(int k, int c) const {
@@ -192,11 +200,12 @@ struct PlainTN {
 struct AnalysisW {
     static constexpr bool kTN = false;
     static constexpr bool kCheck = false;
+    static constexpr bool kOff = false;     // two independent base pointers: rows keep 64-bit addresses
     const float* Wr; const float* Wi; int F, N;
     __device__ const float* dummy() const { return Wr; }
     __device__ RowState row_state(int j) const {
         const int bin = j >> 1;
-        RowState s; s.lo = 0; s.hi = N;
+        RowState s; s.lo = 0; s.hi = N; s.o = 0;
         s.p = ((j & 1) ? Wi : Wr) + (size_t)(bin < F ? bin : 0) * N;
         return s;
     }
@@ -383,7 +392,11 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
 #pragma unroll
             for (int q = 0; q < A_LD; ++q) {
                 if constexpr (AL::kTN) { bool ok; const unsigned o = al.off(kt + a_k[p] + q, m_blk + a_i[p], ok); oa[p][q] = ok; ra[p][q] = ldg128(al.dummy(), o); }
-                else {
+                else if constexpr (AL::kOff) {
+                    const int k = kt + a_k[p];
+                    const bool ok = !AL::kCheck || (k >= a_st[p].lo && k < a_st[p].hi);
+                    oa[p][q] = ok; ra[p][q] = ldg128(al.dummy(), ok ? a_st[p].o + (unsigned)k : 0u);
+                } else {
                     const Src s = al.src(a_st[p], kt + a_k[p]);
                     if constexpr (AL::kCheck) { oa[p][q] = s.ok; ra[p][q] = *reinterpret_cast<const float4*>(s.ok ? s.p : al.dummy()); }
                     else { oa[p][q] = true; ra[p][q] = *reinterpret_cast<const float4*>(s.p); }
@@ -394,7 +407,11 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
 #pragma unroll
             for (int q = 0; q < B_LD; ++q) {
                 if constexpr (BL::kTN) { bool ok; const unsigned o = bl.off(kt + b_k[p] + q, n_blk + b_i[p], ok); ob[p][q] = ok; rb[p][q] = ldg128(bl.dummy(), o); }
-                else {
+                else if constexpr (BL::kOff) {
+                    const int k = kt + b_k[p];
+                    const bool ok = !BL::kCheck || (k >= b_st[p].lo && k < b_st[p].hi);
+                    ob[p][q] = ok; rb[p][q] = ldg128(bl.dummy(), ok ? b_st[p].o + (unsigned)k : 0u);
+                } else {
                     const Src s = bl.src(b_st[p], kt + b_k[p]);
                     if constexpr (BL::kCheck) { ob[p][q] = s.ok; rb[p][q] = *reinterpret_cast<const float4*>(s.ok ? s.p : bl.dummy()); }
                     else { ob[p][q] = true; rb[p][q] = *reinterpret_cast<const float4*>(s.p); }
@@ -518,9 +535,13 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
 // four 8-byte k-quads.  One k-tile = 32 = two MFMA k-steps; a lane's fragment is 8 consecutive k (k = 16 s + 8 (lane/32) + i)
 // for both operands, so the reduction order inside a step is whatever the hardware uses -- identically for A and B.
 typedef __bf16 st_bf16x8 __attribute__((ext_vector_type(8)));
+// v_cvt_pk_bf16_f32 (round to nearest even) as volatile asm: left to the compiler, the conversions were (1) vectorised as
+// (x,z)/(y,w) pairs and re-shuffled with four extra VALU instructions per float4, and (2) hoisted above the MFMA phase of
+// the k-loop -- the sched_barrier only orders machine instructions -- so the wave waited for its prefetch right after
+// issuing it.  A volatile asm stays where lstore() puts it, behind the MFMAs.
 __device__ __forceinline__ unsigned st_pack_bf16(float a, float b)
 {
-    union { __bf16 h[2]; unsigned u; } p; p.h[0] = (__bf16)a; p.h[1] = (__bf16)b; return p.u;
+    unsigned r; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
 }
 
 template <int WAVES_M, class AL, class BL, class EPI>
@@ -569,7 +590,11 @@ gemm_bf16_kernel(const AL al, const BL bl, const EPI epi, const int K, const int
 #pragma unroll
             for (int q = 0; q < A_LDS; ++q) {
                 if constexpr (AL::kTN) { bool ok; const unsigned o = al.off(kt + a_k[p] + q, m_blk + a_i[p], ok); oa[p][q] = ok; ra[p][q] = ldg128(al.dummy(), o); }
-                else {
+                else if constexpr (AL::kOff) {
+                    const int k = kt + a_k[p];
+                    const bool ok = !AL::kCheck || (k >= a_st[p].lo && k < a_st[p].hi);
+                    oa[p][q] = ok; ra[p][q] = ldg128(al.dummy(), ok ? a_st[p].o + (unsigned)k : 0u);
+                } else {
                     const Src s = al.src(a_st[p], kt + a_k[p]);
                     if constexpr (AL::kCheck) { oa[p][q] = s.ok; ra[p][q] = *reinterpret_cast<const float4*>(s.ok ? s.p : al.dummy()); }
                     else { oa[p][q] = true; ra[p][q] = *reinterpret_cast<const float4*>(s.p); }
@@ -580,7 +605,11 @@ gemm_bf16_kernel(const AL al, const BL bl, const EPI epi, const int K, const int
 #pragma unroll
             for (int q = 0; q < B_LDS; ++q) {
                 if constexpr (BL::kTN) { bool ok; const unsigned o = bl.off(kt + b_k[p] + q, n_blk + b_i[p], ok); ob[p][q] = ok; rb[p][q] = ldg128(bl.dummy(), o); }
-                else {
+                else if constexpr (BL::kOff) {
+                    const int k = kt + b_k[p];
+                    const bool ok = !BL::kCheck || (k >= b_st[p].lo && k < b_st[p].hi);
+                    ob[p][q] = ok; rb[p][q] = ldg128(bl.dummy(), ok ? b_st[p].o + (unsigned)k : 0u);
+                } else {
                     const Src s = bl.src(b_st[p], kt + b_k[p]);
                     if constexpr (BL::kCheck) { ob[p][q] = s.ok; rb[p][q] = *reinterpret_cast<const float4*>(s.ok ? s.p : bl.dummy()); }
                     else { ob[p][q] = true; rb[p][q] = *reinterpret_cast<const float4*>(s.p); }
