@@ -662,15 +662,24 @@ extern "C" int st_finalize_scalars(const st_dims* d, const float* loss_partial, 
     ST_TRY(check_dims(d)); ST_REQ(scalars, "st_finalize_scalars: null pointer");
     const float inv_y = 1.0f / ((float)d->B * (float)d->y);
     const float reg_scale = (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);   // loss_functions.py:36
-    hipLaunchKernelGGL(stm::finalize_kernel, dim3(1), dim3(256), 0, st_stream(stream),
-                       loss_partial, st_ola_loss_partials(d), reg_partial, st_ae_fwd_partials(d),
-                       norm_a, st_norm_partials(d), norm_s, st_norm_partials(d), inv_y, reg_scale, inv_world, scalars);
+    const stm::FinArgs f{loss_partial, st_ola_loss_partials(d), reg_partial, st_ae_fwd_partials(d),
+                         norm_a, st_norm_partials(d), norm_s, st_norm_partials(d), inv_y, reg_scale, inv_world};
+    hipLaunchKernelGGL(stm::finalize_kernel, dim3(1), dim3(256), 0, st_stream(stream), f, scalars);
     ST_LAUNCHED("finalize_scalars"); return ST_OK;
 }
+static stm::FinArgs fin_args(const st_dims* d, const float* loss_partial, const float* reg_partial, const float* norm_a, const float* norm_s, float norm_scale)
+{
+    const float inv_y = 1.0f / ((float)d->B * (float)d->y);
+    const float reg_scale = (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);   // loss_functions.py:36
+    return stm::FinArgs{loss_partial, st_ola_loss_partials(d), reg_partial, st_ae_fwd_partials(d),
+                        norm_a, st_norm_partials(d), norm_s, norm_s ? st_norm_partials(d) : 0, inv_y, reg_scale, norm_scale};
+}
 
-extern "C" int st_clip_adam(float* params, float* grads, float* m, float* v, int64_t n_total, int64_t n_stft,
-                            const float* scalars, float grad_scale, float lr, float beta1, float beta2, float eps, int step,
-                            void* stream)
+// fin != nullptr: the clip coefficient (and, if fin->loss_partial, the loss scalars) are derived inside the kernel from
+// the partial sums -- no separate finalize launch; `scalars` is then an output.
+static int clip_adam_impl(float* params, float* grads, float* m, float* v, int64_t n_total, int64_t n_stft,
+                          float* scalars, float grad_scale, float lr, float beta1, float beta2, float eps, int step,
+                          const stm::FinArgs* fin, void* stream)
 {
     ST_REQ(params && grads && m && v && scalars, "st_clip_adam: null pointer");
     ST_REQ(n_total % 4 == 0 && n_stft % 4 == 0 && n_stft <= n_total && step >= 1, "st_clip_adam: bad sizes/step");
@@ -679,9 +688,19 @@ extern "C" int st_clip_adam(float* params, float* grads, float* m, float* v, int
     const float bc2s = (float)sqrt(bc2);
     const float w1 = (float)(1.0 - (double)beta1), w2 = (float)(1.0 - (double)beta2);
     int grid = (int)((n_total / 4 + 255) / 256); if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(stm::clip_adam_kernel, dim3(grid), dim3(256), 0, st_stream(stream),
-                       params, grads, m, v, n_total / 4, n_stft / 4, scalars, grad_scale, neg_step, w1, beta2, w2, bc2s, eps);
+    if (fin)
+        hipLaunchKernelGGL(stm::clip_adam_kernel<true>, dim3(grid), dim3(256), 0, st_stream(stream),
+                           params, grads, m, v, n_total / 4, n_stft / 4, scalars, grad_scale, neg_step, w1, beta2, w2, bc2s, eps, *fin);
+    else
+        hipLaunchKernelGGL(stm::clip_adam_kernel<false>, dim3(grid), dim3(256), 0, st_stream(stream),
+                           params, grads, m, v, n_total / 4, n_stft / 4, scalars, grad_scale, neg_step, w1, beta2, w2, bc2s, eps, stm::FinArgs{});
     ST_LAUNCHED("clip_adam"); return ST_OK;
+}
+extern "C" int st_clip_adam(float* params, float* grads, float* m, float* v, int64_t n_total, int64_t n_stft,
+                            const float* scalars, float grad_scale, float lr, float beta1, float beta2, float eps, int step,
+                            void* stream)
+{
+    return clip_adam_impl(params, grads, m, v, n_total, n_stft, const_cast<float*>(scalars), grad_scale, lr, beta1, beta2, eps, step, nullptr, stream);
 }
 
 extern "C" int st_debug_read_stage_cycles(unsigned long long* out32)
@@ -867,8 +886,15 @@ extern "C" int st_train_step(const st_dims* d, float* params, float* grads, floa
                              float lr, float beta1, float beta2, float eps, int step, void* stream)
 {
     Layout L; ST_TRY(make_layout(d, &L));
-    ST_TRY(st_loss_backward(d, params, grads, x, knobs, y_true, nullptr, nullptr, nullptr, ws, scalars, stream));
-    return st_clip_adam(params, grads, m, v, L.total, L.n_stft, scalars, 1.0f, lr, beta1, beta2, eps, step, stream);
+    ST_REQ(params && grads && x && knobs && y_true && ws && scalars, "st_train_step: null pointer");
+    WS w; carve(d, ws, &w);
+    prof_mark("begin", stream);
+    ST_TRY(forward_impl(d, L, params, x, knobs, y_true, nullptr, nullptr, nullptr, w, true, stream));
+    const float reg_coef = (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);   // loss_functions.py:36
+    ST_TRY(backward_impl(d, L, params, grads, x, knobs, nullptr, nullptr, reg_coef, w, stream));
+    // loss scalars + clip coefficient inside the optimizer kernel (st_loss_backward + st_clip_adam minus one launch)
+    const stm::FinArgs f = fin_args(d, w.loss_p, w.reg_p, w.norm_a, w.norm_s, 1.0f);
+    return clip_adam_impl(params, grads, m, v, L.total, L.n_stft, scalars, 1.0f, lr, beta1, beta2, eps, step, &f, stream);
 }
 
 extern "C" int st_dp_clip_adam(const st_dims* d, float* params, float* grads, float* m, float* v, void* ws,
@@ -883,11 +909,8 @@ extern "C" int st_dp_clip_adam(const st_dims* d, float* params, float* grads, fl
     hipLaunchKernelGGL(stm::l1_partial_kernel, dim3(np), dim3(256), 0, st_stream(stream),
                        grads, L.n_stft, grad_scale, w.norm_a);
     ST_LAUNCHED("l1_partial");
-    hipLaunchKernelGGL(stm::finalize_kernel, dim3(1), dim3(256), 0, st_stream(stream),
-                       (const float*)nullptr, 0, (const float*)nullptr, 0, (const float*)w.norm_a, np, (const float*)nullptr, 0,
-                       0.f, 0.f, 1.0f, scalars);
-    ST_LAUNCHED("finalize(dp)");
-    return st_clip_adam(params, grads, m, v, L.total, L.n_stft, scalars, grad_scale, lr, beta1, beta2, eps, step, stream);
+    const stm::FinArgs f{nullptr, 0, nullptr, 0, w.norm_a, np, nullptr, 0, 0.f, 0.f, 1.0f};     // norm of the reduced gradient only: the loss scalars stay as the last stage left them
+    return clip_adam_impl(params, grads, m, v, L.total, L.n_stft, scalars, grad_scale, lr, beta1, beta2, eps, step, &f, stream);
 }
 
 // ------------------------------------------------------------------------------ device-side data feed

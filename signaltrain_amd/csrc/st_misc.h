@@ -226,27 +226,38 @@ ae_grad_reduce_kernel(const float* __restrict__ ws, int nparts, int PG, float* _
 // ---------------------------------------------------------------- scalars
 // scalars: [0]=loss [1]=mean logcosh [2]=reg term [3]=L1 norm of STFT grads [4]=clip coef
 // (torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm/(norm+1e-6)), nn_proc.py:299-302)
+struct FinArgs {
+    const float* loss_partial; int n_loss; const float* reg_partial; int n_reg;
+    const float* norm_a; int n_na; const float* norm_s; int n_ns;
+    float inv_ycount, reg_scale, norm_scale;
+};
+// Block-wide: the loss terms (if want_loss) and the clip coefficient from the partial sums; every thread returns the
+// coefficient, thread 0 also gets the loss terms.  One summation order, so any block that evaluates this gets the same bits.
+__device__ __forceinline__ float finalize_block(const FinArgs& f, const bool want_loss, float* red, float& lc, float& rg, float& nrm)
+{
+    float a = 0.f, b = 0.f, c = 0.f;
+    if (want_loss && f.loss_partial) for (int i = threadIdx.x; i < f.n_loss; i += 256) a += f.loss_partial[i];
+    if (want_loss && f.reg_partial) for (int i = threadIdx.x; i < f.n_reg; i += 256) b += f.reg_partial[i];
+    if (f.norm_a) for (int i = threadIdx.x; i < f.n_na; i += 256) c += f.norm_a[i];
+    if (f.norm_s) for (int i = threadIdx.x; i < f.n_ns; i += 256) c += f.norm_s[i];
+    if (want_loss) { a = block_sum<4>(a, red); b = block_sum<4>(b, red); }
+    c = block_sum<4>(c, red);
+    __shared__ float bc;
+    if (threadIdx.x == 0) bc = c;
+    __syncthreads();
+    lc = a * f.inv_ycount; rg = b * f.reg_scale; nrm = bc * f.norm_scale;
+    const float coef = 1.0f / (nrm + 1e-6f);
+    return coef < 1.0f ? coef : 1.0f;
+}
 __global__ void __launch_bounds__(256)
-finalize_kernel(const float* __restrict__ loss_partial, int n_loss, const float* __restrict__ reg_partial, int n_reg,
-                const float* __restrict__ norm_a, int n_na, const float* __restrict__ norm_s, int n_ns,
-                float inv_ycount, float reg_scale, float norm_scale, float* __restrict__ scalars)
+finalize_kernel(const FinArgs f, float* __restrict__ scalars)
 {
     __shared__ float red[4];
-    float a = 0.f, b = 0.f, c = 0.f;
-    if (loss_partial) for (int i = threadIdx.x; i < n_loss; i += 256) a += loss_partial[i];
-    if (reg_partial) for (int i = threadIdx.x; i < n_reg; i += 256) b += reg_partial[i];
-    if (norm_a) for (int i = threadIdx.x; i < n_na; i += 256) c += norm_a[i];
-    if (norm_s) for (int i = threadIdx.x; i < n_ns; i += 256) c += norm_s[i];
-    a = block_sum<4>(a, red); b = block_sum<4>(b, red); c = block_sum<4>(c, red);
+    float lc, rg, nrm;
+    const float coef = finalize_block(f, true, red, lc, rg, nrm);
     if (threadIdx.x == 0) {
-        const float lc = a * inv_ycount, rg = b * reg_scale;
-        if (loss_partial) { scalars[1] = lc; scalars[2] = rg; scalars[0] = lc + rg; }
-        if (norm_a || norm_s) {
-            const float nrm = c * norm_scale;
-            scalars[3] = nrm;
-            const float coef = 1.0f / (nrm + 1e-6f);
-            scalars[4] = coef < 1.0f ? coef : 1.0f;
-        }
+        if (f.loss_partial) { scalars[1] = lc; scalars[2] = rg; scalars[0] = lc + rg; }
+        if (f.norm_a || f.norm_s) { scalars[3] = nrm; scalars[4] = coef; }
     }
 }
 
@@ -254,12 +265,26 @@ finalize_kernel(const float* __restrict__ loss_partial, int n_loss, const float*
 // torch.optim.Adam (single-tensor path): m.lerp_(g, 1-b1); v = v*b2 + (1-b2)*g*g;
 // denom = sqrt(v)/sqrt(bc2) + eps ; p += (-lr/bc1) * m / denom.   STFT range [0,n_stft) is scaled by
 // the clip coefficient first; every gradient is pre-scaled by grad_scale (1/world in data parallel).
+// FIN: the scalars are not ready yet -- every block derives the clip coefficient from the partial sums itself (2k floats out
+// of L2) and block 0 publishes the loss scalars: saves the single-block finalize launch (9 us) in the fused train step.
+template <bool FIN>
 __global__ void __launch_bounds__(256)
 clip_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                 int64_t n4_total, int64_t n4_stft, const float* __restrict__ scalars, float grad_scale,
-                 float neg_step_size, float w1, float b2, float w2, float bc2_sqrt, float eps)
+                 int64_t n4_total, int64_t n4_stft, float* __restrict__ scalars, float grad_scale,
+                 float neg_step_size, float w1, float b2, float w2, float bc2_sqrt, float eps, const FinArgs fin)
 {
-    const float coef = scalars[4];
+    float coef;
+    if constexpr (FIN) {
+        __shared__ float red[4];
+        float lc, rg, nrm;
+        coef = finalize_block(fin, blockIdx.x == 0, red, lc, rg, nrm);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (fin.loss_partial) { scalars[1] = lc; scalars[2] = rg; scalars[0] = lc + rg; }
+            scalars[3] = nrm; scalars[4] = coef;
+        }
+    } else {
+        coef = scalars[4];
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4_total; i += (int64_t)gridDim.x * 256) {
         const float sc = (i < n4_stft) ? grad_scale * coef : grad_scale;
         float4 G = reinterpret_cast<float4*>(g)[i];
