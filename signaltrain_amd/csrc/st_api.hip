@@ -158,6 +158,7 @@ extern "C" int st_set_debug(int v) { g_dbg = v; return ST_OK; }
 namespace sta { extern __device__ unsigned long long g_ae_stage_cycles[32]; }
 // Diagnostics: read (and clear) the per-stage s_memtime accumulators of ae_bwd_kernel (st_set_debug(256)).
 extern "C" int st_debug_read_stage_cycles(unsigned long long* out32);
+static int g_an_bk = 32;   // k-tile depth of the analysis forward GEMM (see ST_GEMM_AN)
 static int g_bk = 16;   // k-tile depth of the GEMM family (16: 36 KB LDS/WG -> 4 WGs/CU; 32: 64 KB -> 2 WGs/CU)
 static int g_wg_mode_set(int v);
 static int g_wsplit_max = 16, g_wsplit_div = 200, g_an_waves = 4, g_syn_split = 3, g_frs_split = 3, g_wide_fused = 1, g_wsplit_half = 0;      // frames: 3, 4 measured equal, 6 slower (only 66 k-tiles to split)
@@ -171,7 +172,7 @@ extern "C" int st_set_tuning(int bk)
     if (bk >= 1000) { g_wsplit_div = bk - 1000; return ST_OK; }  // 1000 + n: rows per weight-gradient k-slice (diagnostics)
     if (bk >= 200) { g_wsplit_max = bk - 200; return ST_OK; }      // 200 + n: cap of the weight-gradient split-K (diagnostics)
     if (bk >= 100) return g_wg_mode_set(bk - 100);           // 100 / 101: weight-gradient tile mode (diagnostics)
-    if (bk != 16 && bk != 32) return st_fail(ST_ERR_ARG, "bk must be 16 or 32"); g_bk = bk; return ST_OK;
+    if (bk != 16 && bk != 32) return st_fail(ST_ERR_ARG, "bk must be 16 or 32"); g_bk = bk; g_an_bk = bk; return ST_OK;
 }
 // g_prec: arithmetic of the STFT GEMMs -- 0 = fp32 MFMA (default, the parity path), 1 = bf16 operands / fp32 accumulation
 static int g_prec = 0;
@@ -179,6 +180,10 @@ extern "C" int st_set_precision(int bf16) { g_prec = bf16 ? 1 : 0; return ST_OK;
 extern "C" int st_get_precision(void) { return g_prec; }
 #define ST_GEMM(W_, ...) do { if (g_prec == 1) stg::launch_bf16<W_>(__VA_ARGS__); \
                               else if (g_bk == 16) stg::launch<W_, 16>(__VA_ARGS__, g_dbg); else stg::launch<W_, 32>(__VA_ARGS__, g_dbg); } while (0)
+// the analysis forward GEMM (K = N = 1024, two 4-wave workgroups per CU either way) runs 5 % faster with 32-deep k-tiles
+// (half the barriers); every other GEMM of the step is faster with 16 (more workgroups per CU)
+#define ST_GEMM_AN(W_, ...) do { if (g_prec == 1) stg::launch_bf16<W_>(__VA_ARGS__); \
+                                 else if (g_an_bk == 16) stg::launch<W_, 16>(__VA_ARGS__, g_dbg); else stg::launch<W_, 32>(__VA_ARGS__, g_dbg); } while (0)
 // weight-gradient GEMMs: g_wg_mode 0 = three waves share a 96x96 tile (32x96 strips), 1 = one wave per 96x96 tile
 static int g_wg_mode = 0;
 static int g_wg_mode_set(int v) { g_wg_mode = v; return ST_OK; }
@@ -271,9 +276,9 @@ static int analysis_fwd_impl(const st_dims* d, const float* sig, bool padded, co
     stg::PolarStore ep{re, im, mag, phs, R, d->F, map};
     if (padded) {
         stg::FramedNT<true> al{sig, d->L, d->H, d->N, R, d->N, 1.0f, map};
-        if (g_an_waves == 2) ST_GEMM(2, al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream));
-        else if (g_an_waves == 3) ST_GEMM(3, al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream));
-        else ST_GEMM(4, al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream));
+        if (g_an_waves == 2) ST_GEMM_AN(2, al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream));
+        else if (g_an_waves == 3) ST_GEMM_AN(3, al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream));
+        else ST_GEMM_AN(4, al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream));
     }
     else { stg::FramedNT<false> al{sig, d->L, d->H, d->N, R, d->N, in_scale, map}; ST_GEMM(4, al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream)); }
     ST_LAUNCHED("analysis_fwd");
