@@ -290,6 +290,10 @@ clip_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict
         float4 G = reinterpret_cast<float4*>(g)[i];
         float4 M = reinterpret_cast<float4*>(m)[i];
         float4 V = reinterpret_cast<float4*>(v)[i];
+        // g = m = v = 0 is a fixed point of the update (m, v stay 0, p += 0): the 2 x 511 structurally-zero rows of the analysis
+        // bases -- a quarter of all parameters -- skip the parameter read and all four writes
+        if (G.x == 0.f && G.y == 0.f && G.z == 0.f && G.w == 0.f && M.x == 0.f && M.y == 0.f && M.z == 0.f && M.w == 0.f &&
+            V.x == 0.f && V.y == 0.f && V.z == 0.f && V.w == 0.f) continue;
         float4 P = reinterpret_cast<float4*>(p)[i];
 #define ST_ADAM1(c)                                                        \
         {                                                                  \
