@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--bk", type=int, default=0, help="GEMM k-tile depth override (16/32)")
+    ap.add_argument("--dp-schedule", choices=["staged", "two_bucket"], default="staged", help="all-reduce schedule of the data-parallel step (signaltrain_amd/dp.py)")
     ap.add_argument("--force-dp", action="store_true", help="run the N > 1 code path (bucketed RCCL all-reduce, st_dp_clip_adam) "
                                                             "even with one rank, to measure its overhead on one GPU")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
@@ -88,7 +89,7 @@ def main():
     model = nn_proc.st_model(scale_factor=args.scale, shrink_factor=4, num_knobs=4)
     eng = StepEngine(d, dev, compute_dtype=args.dtype)
     eng.load_state_dict(model.state_dict())
-    dp = DataParallel(eng, force_collectives=args.force_dp)
+    dp = DataParallel(eng, force_collectives=args.force_dp, schedule=args.dp_schedule)
     dp.broadcast_parameters()
     np.random.seed(218 + 1000 * (rank + 1))
     ds = datasets.SynthAudioDataSet(d.L, audio.Compressor_4c(), y_size=d.y, augment=True)

@@ -21,7 +21,11 @@ import torch.distributed as dist
 class DataParallel:
     """Wraps an engine exposing N_STAGES, loss_backward_stage(), stage_bucket(), clip_adam(), scalars."""
 
-    def __init__(self, engine, process_group=None, force_collectives=False):
+    def __init__(self, engine, process_group=None, force_collectives=False, schedule="staged"):
+        """schedule: "staged" (four stages / four ranges, the default) or "two_bucket" ([synthesis + autoencoders] under
+        the analysis weight gradient, then one contiguous analysis range: fewer collectives, larger exposed tail)."""
+        assert schedule in ("staged", "two_bucket"), schedule
+        self.schedule = schedule
         self.engine = engine
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -36,6 +40,14 @@ class DataParallel:
         eng = self.engine
         if self.world == 1 and not self.force:
             return eng.train_step(x, knobs, y, lr, **kw)
+        if self.schedule == "two_bucket":
+            eng.loss_backward_p1(x, knobs, y)
+            b = eng.grad_buckets()
+            h0 = dist.all_reduce(b[0], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            eng.loss_backward_p2()
+            h1 = dist.all_reduce(b[1], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            h0.wait(); h1.wait()
+            return eng.clip_adam(lr, grad_scale=1.0 / self.world, **kw)
         handles = []
         for s in range(eng.N_STAGES):
             eng.loss_backward_stage(s, x, knobs, y)

@@ -81,13 +81,13 @@ def _case():
     return geo, P, X, Y, KN
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, schedule="staged"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from signaltrain_amd.dp import DataParallel
     geo, P, X, Y, KN = _case()
     eng = OracleEngine(P, geo)
-    dp = DataParallel(eng)
+    dp = DataParallel(eng, schedule=schedule)
     dp.broadcast_parameters()
     sh = slice(rank * 2, rank * 2 + 2)                      # each rank takes its shard of the global batch
     for it in range(2):
@@ -99,11 +99,12 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_dp_world2_equals_single_process_on_global_batch():
+@pytest.mark.parametrize("schedule", ["staged", "two_bucket"])
+def test_dp_world2_equals_single_process_on_global_batch(schedule):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + (7 if schedule == "two_bucket" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, schedule)) for r in range(2)]
     for p in procs:
         p.start()
     got, loss2 = q.get(timeout=240)
