@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--bk", type=int, default=0, help="GEMM k-tile depth override (16/32)")
-    ap.add_argument("--dp-schedule", choices=["staged", "two_bucket"], default="staged", help="all-reduce schedule of the data-parallel step (signaltrain_amd/dp.py)")
+    ap.add_argument("--dp-schedule", choices=["two_bucket", "staged"], default="two_bucket", help="all-reduce schedule of the data-parallel step (signaltrain_amd/dp.py)")
     ap.add_argument("--force-dp", action="store_true", help="run the N > 1 code path (bucketed RCCL all-reduce, st_dp_clip_adam) "
                                                             "even with one rank, to measure its overhead on one GPU")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",

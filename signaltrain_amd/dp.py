@@ -3,15 +3,17 @@
 The reference's only multi-GPU mechanism is a disabled nn.DataParallel stub (train.py:259-263).  Here each
 rank runs the fused step on its shard of the minibatch with identical parameters; the flat fp32 gradient buffer is
 sum-all-reduced range by range, in the order the backward makes the ranges final, each collective running under the
-next stage's kernels (engine.loss_backward_stage / stage_bucket):
+following kernels.  Two schedules (DataParallel(schedule=...)):
 
-    stage 0  forward + loss + synthesis backward   -> all-reduce the two synthesis bases (4.2 MB)   || stage 1 (autoencoders)
-    stage 1  autoencoder + polar backward          -> all-reduce both autoencoders (67 KB)          || stage 2
-    stage 2  analysis wgrad, real basis            -> all-reduce its 513 live rows (2.1 MB)         || stage 3
-    stage 3  analysis wgrad, imaginary basis       -> all-reduce its 513 live rows (2.1 MB)  -- the only exposed one
+  "two_bucket" (default)   phase 1 = forward + loss + synthesis / autoencoder / polar backward
+                             -> all-reduce [synthesis bases + autoencoders] (8.45 MB)   || phase 2 = analysis weight gradient
+                             -> all-reduce the contiguous range holding the 513 live rows of both analysis bases (6.3 MB, exposed)
+  "staged"                 four stages (engine.loss_backward_stage / stage_bucket): synthesis bases 4.2 MB || autoencoder
+                             backward; autoencoders 67 KB; real analysis basis 2.1 MB || imaginary-basis GEMM; imaginary
+                             basis 2.1 MB (the only exposed one) -- 10.6 MB instead of 14.7 MB on the wire, at a measured fixed
+                             cost of two more collectives and two smaller GEMMs
 
-10.6 MB move per step instead of the 16.8 MB buffer (rows >= 513 of the analysis tensors are structurally zero).  The
-reduced gradient is scaled by 1/world and only then L1-clipped (the norm is a function of the reduced gradient, so it is
+The reduced gradient is scaled by 1/world and only then L1-clipped (the norm is a function of the reduced gradient, so it is
 identical on every rank and needs no second collective) and fed to the replicated Adam.
 """
 import torch
@@ -21,9 +23,10 @@ import torch.distributed as dist
 class DataParallel:
     """Wraps an engine exposing N_STAGES, loss_backward_stage(), stage_bucket(), clip_adam(), scalars."""
 
-    def __init__(self, engine, process_group=None, force_collectives=False, schedule="staged"):
-        """schedule: "staged" (four stages / four ranges, the default) or "two_bucket" ([synthesis + autoencoders] under
-        the analysis weight gradient, then one contiguous analysis range: fewer collectives, larger exposed tail)."""
+    def __init__(self, engine, process_group=None, force_collectives=False, schedule="two_bucket"):
+        """schedule: "two_bucket" (default: [synthesis + autoencoders] 8.45 MB under the analysis weight gradient, then one
+        contiguous 6.3 MB analysis range) or "staged" (four stages / four ranges, only the last 2.1 MB exposed, but +55..85 us
+        of fixed cost measured on one GPU: two more collectives and the per-basis analysis GEMMs -- see DESIGN.md section 6)."""
         assert schedule in ("staged", "two_bucket"), schedule
         self.schedule = schedule
         self.engine = engine

@@ -81,7 +81,7 @@ def _case():
     return geo, P, X, Y, KN
 
 
-def _worker(rank, world, port, q, schedule="staged"):
+def _worker(rank, world, port, q, schedule="two_bucket"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from signaltrain_amd.dp import DataParallel

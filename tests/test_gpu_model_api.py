@@ -132,9 +132,10 @@ def test_scale8_golden_forward(golden_dir):
         assert e <= 1e-4 * np.abs(ref).max(), (name, e)
 
 
-def test_dp_collective_path_single_rank():
-    """The N > 1 step (four backward stages, each followed by the RCCL all-reduce of the range it finalised, running under
-    the next stage -> st_dp_clip_adam) executed on ONE GPU with a single-rank RCCL group must reproduce the fused single-GPU step."""
+@pytest.mark.parametrize("schedule", ["two_bucket", "staged"])
+def test_dp_collective_path_single_rank(schedule):
+    """The N > 1 step (backward phases / stages, each followed by the RCCL all-reduce of the range it finalised, running under
+    the next one -> st_dp_clip_adam) executed on ONE GPU with a single-rank RCCL group must reproduce the fused single-GPU step."""
     import socket
     import torch.distributed as dist
     from tests import gpu_checks as G
@@ -148,7 +149,7 @@ def test_dp_collective_path_single_rank():
     try:
         e1 = StepEngine(d, G.DEV); e1.load_state_dict(P)
         e2 = StepEngine(d, G.DEV); e2.load_state_dict(P)
-        dp = DataParallel(e2, force_collectives=True)
+        dp = DataParallel(e2, force_collectives=True, schedule=schedule)
         dp.broadcast_parameters()
         x, kn, y = G.t(X), G.t(KN), G.t(Y)
         for it in range(3):
