@@ -171,6 +171,11 @@ int st_loss_backward(const st_dims* d, const float* params, float* grads, const 
 int st_loss_backward_p1(const st_dims* d, const float* params, float* grads, const float* x, const float* knobs,
                         const float* y_true, void* ws, void* stream);
 int st_loss_backward_p2(const st_dims* d, float* grads, const float* x, void* ws, float* scalars, void* stream);
+/* p2 with a packed copy of the 2F live analysis rows in `stage` [2F][N] (caller-owned): the buffer the data-parallel
+ * all-reduce moves instead of the contiguous range spanning the structurally-zero rows; st_unstage_analysis copies the
+ * reduced rows back into grads (rows [0,F) of tensors 0 and 1).  No reference counterpart (see st_loss_backward_stage). */
+int st_loss_backward_p2_staged(const st_dims* d, float* grads, float* stage, const float* x, void* ws, float* scalars, void* stream);
+int st_unstage_analysis(const st_dims* d, float* grads, const float* stage, void* stream);
 
 /* Finer split of the same step for data parallel (no reference counterpart: train.py:259-263 is a disabled
  * nn.DataParallel stub).  Call stage = 0, 1, 2, 3 in order on one stream; after stage s one gradient range is final

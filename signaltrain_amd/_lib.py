@@ -73,6 +73,8 @@ SIGNATURES = {
     "st_loss_backward": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "st_loss_backward_p1": (_i, [_D, _p, _p, _p, _p, _p, _p, _p]),
     "st_loss_backward_p2": (_i, [_D, _p, _p, _p, _p, _p]),
+    "st_loss_backward_p2_staged": (_i, [_D, _p, _p, _p, _p, _p, _p]),
+    "st_unstage_analysis": (_i, [_D, _p, _p, _p]),
     "st_loss_backward_stage": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "st_train_step": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _p]),
     "st_dp_clip_adam": (_i, [_D, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _i, _p]),

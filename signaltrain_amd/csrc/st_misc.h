@@ -152,7 +152,7 @@ polar_bwd_kernel(const float* __restrict__ re, const float* __restrict__ im, con
 // mode 1 (synthesis): additionally mirror to row N-k with sign +1 (real) / -1 (imag)  (SURVEY.md 8a' "unfold").
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ ws, int nz, float* __restrict__ gRe, float* __restrict__ gIm,
-                    float* __restrict__ norm_partial, int N, int F, int KP, int mode, int row0)
+                    float* __restrict__ norm_partial, int N, int F, int KP, int mode, int row0, float* __restrict__ stage)
 {
     __shared__ float red[4];
     const int row = blockIdx.x + row0;                // 0 .. 2F-1 : [0,F) real rows, [F,2F) imag rows (row0: imag half only)
@@ -171,6 +171,7 @@ wgrad_reduce_kernel(const float* __restrict__ ws, int nz, float* __restrict__ gR
             v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
         }
         reinterpret_cast<float4*>(g + (size_t)k * N)[n4] = v;
+        if (stage) reinterpret_cast<float4*>(stage + (size_t)row * N)[n4] = v;      // packed copy [2F][N] of the live rows (data-parallel all-reduce buffer)
         float a = fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
         if (mirror) {
             reinterpret_cast<float4*>(g + (size_t)(N - k) * N)[n4] = make_float4(sgn * v.x, sgn * v.y, sgn * v.z, sgn * v.w);

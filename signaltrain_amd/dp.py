@@ -7,7 +7,7 @@ following kernels.  Two schedules (DataParallel(schedule=...)):
 
   "two_bucket" (default)   phase 1 = forward + loss + synthesis / autoencoder / polar backward
                              -> all-reduce [synthesis bases + autoencoders] (8.45 MB)   || phase 2 = analysis weight gradient
-                             -> all-reduce the contiguous range holding the 513 live rows of both analysis bases (6.3 MB, exposed)
+                             -> all-reduce the packed copy of the 513 live rows of both analysis bases (4.2 MB, exposed), copy back
   "staged"                 four stages (engine.loss_backward_stage / stage_bucket): synthesis bases 4.2 MB || autoencoder
                              backward; autoencoders 67 KB; real analysis basis 2.1 MB || imaginary-basis GEMM; imaginary
                              basis 2.1 MB (the only exposed one) -- 10.6 MB instead of 14.7 MB on the wire, at a measured fixed
@@ -24,8 +24,8 @@ class DataParallel:
     """Wraps an engine exposing N_STAGES, loss_backward_stage(), stage_bucket(), clip_adam(), scalars."""
 
     def __init__(self, engine, process_group=None, force_collectives=False, schedule="two_bucket"):
-        """schedule: "two_bucket" (default: [synthesis + autoencoders] 8.45 MB under the analysis weight gradient, then one
-        contiguous 6.3 MB analysis range) or "staged" (four stages / four ranges, only the last 2.1 MB exposed, but +55..85 us
+        """schedule: "two_bucket" (default: [synthesis + autoencoders] 8.45 MB under the analysis weight gradient, then the
+        packed 4.2 MB of live analysis rows) or "staged" (four stages / four ranges, only the last 2.1 MB exposed, but +55..85 us
         of fixed cost measured on one GPU: two more collectives and the per-basis analysis GEMMs -- see DESIGN.md section 6)."""
         assert schedule in ("staged", "two_bucket"), schedule
         self.schedule = schedule
@@ -50,6 +50,7 @@ class DataParallel:
             eng.loss_backward_p2()
             h1 = dist.all_reduce(b[1], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             h0.wait(); h1.wait()
+            eng.finish_buckets()
             return eng.clip_adam(lr, grad_scale=1.0 / self.world, **kw)
         handles = []
         for s in range(eng.N_STAGES):

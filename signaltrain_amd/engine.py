@@ -81,6 +81,7 @@ class StepEngine:
         dmax = dims.with_batch(self.max_batch)
         self.ws = torch.zeros(self.lib.st_workspace_bytes(C.byref(dmax)), dtype=torch.uint8, device=self.device)
         self.scalars = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self.stage = None            # packed live analysis gradient rows (data parallel, allocated on first use)
         self.named = self.layout.views(self.params)
         self.named_grads = self.layout.views(self.grads)
         self.step_count = 0
@@ -159,9 +160,16 @@ class StepEngine:
                                                 _lib.ptr(knobs), _lib.ptr(y), _lib.ptr(self.ws), self._stream()), "st_loss_backward_p1")
 
     def loss_backward_p2(self):
+        """Analysis weight gradient + loss scalars; the 2F live rows also land packed in self.stage (see grad_buckets)."""
         d, x = self._pending[:2]
-        _lib.check(self.lib.st_loss_backward_p2(C.byref(d), _lib.ptr(self.grads), _lib.ptr(x), _lib.ptr(self.ws),
-                                                _lib.ptr(self.scalars), self._stream()), "st_loss_backward_p2")
+        if self.stage is None:
+            self.stage = torch.zeros(2 * self.dims.F * self.dims.N, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.st_loss_backward_p2_staged(C.byref(d), _lib.ptr(self.grads), _lib.ptr(self.stage), _lib.ptr(x),
+                                                       _lib.ptr(self.ws), _lib.ptr(self.scalars), self._stream()), "st_loss_backward_p2_staged")
+
+    def finish_buckets(self):
+        """After the all-reduce of grad_buckets(): copy the reduced analysis rows from the packed staging buffer back into grads."""
+        _lib.check(self.lib.st_unstage_analysis(C.byref(self.dims), _lib.ptr(self.grads), _lib.ptr(self.stage), self._stream()), "st_unstage_analysis")
 
     N_STAGES = 4
 
@@ -183,14 +191,13 @@ class StepEngine:
         return (self.grads[o[2]:o[4]], self.grads[o[4]:], self.grads[o[0]:o[0] + live], self.grads[o[1]:o[1] + live])[stage]
 
     def grad_buckets(self):
-        """Two-phase form (loss_backward_p1 / _p2; dp.DataParallel uses the finer loss_backward_stage / stage_bucket).
-        Gradient ranges in the order they become final: [synthesis + autoencoders] after phase 1, then ONE contiguous
-        range covering the live rows [0,F) of both analysis tensors (it spans the structurally-zero rows [F,N) of the
-        first tensor: 2 MB of zeros is cheaper than the ~25 us fixed cost of a third collective; rows >= F of the second
-        tensor never move)."""
-        o, d = self.layout.offsets, self.dims
-        live = d.F * d.N
-        return [self.grads[o[2]:], self.grads[o[0]:o[1] + live]]
+        """Two-phase form (loss_backward_p1 / _p2): the buffers to all-reduce, in the order they become final --
+        [synthesis + autoencoders] = grads[offs[2]:] after phase 1, then the packed staging copy [2F][N] of the live analysis
+        rows written by phase 2 (4.2 MB; the contiguous range of grads holding them would span 2 MB of structurally-zero rows).
+        Call finish_buckets() after the second all-reduce."""
+        if self.stage is None:
+            self.stage = torch.zeros(2 * self.dims.F * self.dims.N, dtype=torch.float32, device=self.device)
+        return [self.grads[self.layout.offsets[2]:], self.stage]
 
     def train_step(self, x, knobs, y, lr, betas=(0.9, 0.999), eps=1e-8):
         """One optimisation step (train.py:112-151).  `lr` is the value sitting in param_groups at step

@@ -53,8 +53,13 @@ class OracleEngine:
         return (self.grads[2 * n:4 * n], self.grads[4 * n:e], self.grads[0:live], self.grads[n:n + live])[stage]   # as StepEngine.stage_bucket
 
     def grad_buckets(self):
-        n = 1 << 20
-        return [self.grads[2 * n:], self.grads[0:n + 513 * 1024]]            # same two ranges as StepEngine.grad_buckets()
+        n, live = 1 << 20, 513 * 1024                                        # as StepEngine.grad_buckets(): a packed staging copy of the live analysis rows
+        self.stage = torch.cat([self.grads[0:live], self.grads[n:n + live]]).clone()
+        return [self.grads[2 * n:], self.stage]
+
+    def finish_buckets(self):
+        n, live = 1 << 20, 513 * 1024
+        self.grads[0:live] = self.stage[:live]; self.grads[n:n + live] = self.stage[live:]
 
     def clip_adam(self, lr, grad_scale=1.0, **kw):
         self.step_count += 1

@@ -27,7 +27,7 @@ def stages_ar_sync():
 def two_bucket():
     eng.loss_backward_p1(x, k, y); b = eng.grad_buckets()
     h0 = dist.all_reduce(b[0], async_op=True); eng.loss_backward_p2(); h1 = dist.all_reduce(b[1], async_op=True)
-    h0.wait(); h1.wait(); eng.clip_adam(1e-4)
+    h0.wait(); h1.wait(); eng.finish_buckets(); eng.clip_adam(1e-4)
 def last_only():
     for s in range(4): eng.loss_backward_stage(s, x, k, y)
     dist.all_reduce(eng.stage_bucket(3)); eng.clip_adam(1e-4)
