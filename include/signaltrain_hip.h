@@ -173,7 +173,8 @@ int st_loss_backward_p1(const st_dims* d, const float* params, float* grads, con
 int st_loss_backward_p2(const st_dims* d, float* grads, const float* x, void* ws, float* scalars, void* stream);
 /* p2 with a packed copy of the 2F live analysis rows in `stage` [2F][N] (caller-owned): the buffer the data-parallel
  * all-reduce moves instead of the contiguous range spanning the structurally-zero rows; st_unstage_analysis copies the
- * reduced rows back into grads (rows [0,F) of tensors 0 and 1).  No reference counterpart (see st_loss_backward_stage). */
+ * reduced rows back into grads (rows [0,F) of tensors 0 and 1).  The loss scalars are NOT written here: st_dp_clip_adam
+ * publishes them together with the norm of the reduced gradient.  No reference counterpart (see st_loss_backward_stage). */
 int st_loss_backward_p2_staged(const st_dims* d, float* grads, float* stage, const float* x, void* ws, float* scalars, void* stream);
 int st_unstage_analysis(const st_dims* d, float* grads, const float* stage, void* stream);
 

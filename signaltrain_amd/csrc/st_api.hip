@@ -865,8 +865,8 @@ extern "C" int st_loss_backward_p2_staged(const st_dims* d, float* grads, float*
     Layout L; ST_TRY(make_layout(d, &L));
     ST_REQ(grads && stage && x && ws && scalars, "st_loss_backward_p2_staged: null pointer");
     WS w; carve(d, ws, &w);
-    ST_TRY(backward_p2(d, L, grads, x, w, stream, stage));
-    return st_finalize_scalars(d, w.loss_p, w.reg_p, w.norm_a, w.norm_s, 1.0f, scalars, stream);
+    (void)scalars;      // the loss scalars are published by st_dp_clip_adam (no single-block finalize between this GEMM and the all-reduce)
+    return backward_p2(d, L, grads, x, w, stream, stage);
 }
 extern "C" int st_unstage_analysis(const st_dims* d, float* grads, const float* stage, void* stream)
 {
@@ -936,7 +936,8 @@ extern "C" int st_dp_clip_adam(const st_dims* d, float* params, float* grads, fl
     hipLaunchKernelGGL(stm::l1_partial_kernel, dim3(np), dim3(256), 0, st_stream(stream),
                        grads, L.n_stft, grad_scale, w.norm_a);
     ST_LAUNCHED("l1_partial");
-    const stm::FinArgs f{nullptr, 0, nullptr, 0, w.norm_a, np, nullptr, 0, 0.f, 0.f, 1.0f};     // norm of the reduced gradient only: the loss scalars stay as the last stage left them
+    stm::FinArgs f = fin_args(d, w.loss_p, w.reg_p, w.norm_a, nullptr, 1.0f);     // this rank's loss terms + the norm of the REDUCED gradient (l1 partials above)
+    f.n_na = np;
     return clip_adam_impl(params, grads, m, v, L.total, L.n_stft, scalars, grad_scale, lr, beta1, beta2, eps, step, &f, stream);
 }
 
