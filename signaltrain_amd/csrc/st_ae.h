@@ -804,6 +804,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             wgrad_reg<4, 2>(rW1, rb1, daT1, vT);
         }
 #undef ST_BWD_STAGE
+#undef ST_PIPE
         ST_T(14);
         // ------------------------------------------------------------------ d input rows (+ skip / residual tails)
         if constexpr (!INNER) {
