@@ -55,8 +55,8 @@ def main():
     ap.add_argument("--dp-schedule", choices=["two_bucket", "staged"], default="two_bucket", help="all-reduce schedule of the data-parallel step (signaltrain_amd/dp.py)")
     ap.add_argument("--force-dp", action="store_true", help="run the N > 1 code path (bucketed RCCL all-reduce, st_dp_clip_adam) "
                                                             "even with one rank, to measure its overhead on one GPU")
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
-                    help="f32 = the headline / parity configuration; bf16 = bf16 operands with fp32 accumulation in the STFT GEMMs "
+    ap.add_argument("--dtype", choices=("f32", "bf16", "bf16_all"), default="f32",
+                    help="f32 = the headline / parity configuration; bf16 = bf16 operands with fp32 accumulation in the STFT GEMMs; bf16_all = also in the autoencoder layers "
                          "(arithmetic of BASELINE configs[2], [3]; informational, never the headline number)")
     ap.add_argument("--scale", type=int, default=1, help="window scale factor (8 = the 65536-sample window of BASELINE configs[4], "
                                                           "fp32 here; informational -- the headline workload is scale 1)")
@@ -128,7 +128,7 @@ def main():
         out = {"metric": METRIC, "value": windows_s * d.T, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": (f"comp_4c synthetic, 8192-sample windows, batch {B}/GPU, {'fp32 (BASELINE configs[1])' if args.dtype == 'f32' else 'bf16 GEMM operands / fp32 accumulate (arithmetic of BASELINE configs[2])'}" if args.scale == 1 else
+               "config": {"workload": (f"comp_4c synthetic, 8192-sample windows, batch {B}/GPU, {'fp32 (BASELINE configs[1])' if args.dtype == 'f32' else ('bf16 GEMM operands / fp32 accumulate (arithmetic of BASELINE configs[2])' if args.dtype == 'bf16' else 'bf16 operands in the STFT GEMMs and the autoencoder layers / fp32 accumulate (arithmetic of BASELINE configs[2])')}" if args.scale == 1 else
                                        f"comp_4c synthetic, {d.L}-sample windows, batch {B}/GPU, fp32 (geometry of BASELINE configs[4])"),
                           "window": d.L, "frames_per_window": d.T, "global_batch": B * world, "parallelism": f"dp{world}"},
                "windows_per_s": windows_s, "samples_per_s": windows_s * d.L, "loss": loss,

@@ -205,8 +205,12 @@ int st_dp_clip_adam(const st_dims* d, float* params, float* grads, float* m, flo
  * 1: bf16 operands, fp32 accumulation (BASELINE.json configs[2], [3]): both operands of the analysis / synthesis GEMMs
  *    and of their data / weight gradients are rounded to bf16 (RNE) as they are staged; parameters, activations,
  *    gradients, the autoencoders, the loss and Adam stay fp32.  Equals the reference run with those conv operands
- *    rounded to bf16 (the oracle has the same switch), not the fp32 reference. */
-int st_set_precision(int bf16);
+ *    rounded to bf16 (the oracle has the same switch), not the fp32 reference.
+ * 2: additionally the nine Linear layers of both autoencoders (nn_proc.py:84-117 and their autograd): weights and layer
+ *    inputs / incoming gradients are rounded to bf16, one v_mfma_f32_16x16x16_bf16 per 16x16 tile with fp32 accumulation;
+ *    bias, ELU, ELU', the skip / residual epilogue stay fp32.  Fused-kernel geometries (T <= 32, OT <= 16) only: wide
+ *    geometries keep fp32 autoencoders at level 2. */
+int st_set_precision(int level);
 int st_get_precision(void);
 
 /* ---- device-side data feed -------------------------------------------------------------------

@@ -45,6 +45,15 @@ def _r(a):
     return a if GEMM_ROUND is None else GEMM_ROUND(a)
 
 
+# AE_ROUND = bf16_round: weights and layer inputs of the nine Linear layers of both autoencoders (forward, data gradient,
+# weight gradient) are rounded to bfloat16 first -- the arithmetic of st_set_precision(2) (the BF instantiations of st_ae.h).
+AE_ROUND = None
+
+
+def _ra(a):
+    return a if AE_ROUND is None else AE_ROUND(a)
+
+
 def geometry(scale_factor=1, shrink_factor=4, scale_scheme="lean"):
     """st_model.__init__ geometry, nn_proc.py:357-385.  All integer, exact."""
     chunk = int(8192 * scale_factor)
@@ -217,7 +226,7 @@ def ae_fwd(v, knobs, P, prefix, mode):
             kn = np.broadcast_to(knobs[:, None, :].astype(dt), (B, F, knobs.shape[1]))
             h = np.concatenate([h, kn], axis=2)
             hs[-1] = h                                       # input of this layer incl. knobs
-        a = h @ W.T + b
+        a = _ra(h) @ _ra(W).T + b
         h = elu(a)
         hs.append(h)
     OT = h.shape[2]
@@ -321,9 +330,9 @@ def _ae_bwd(dout, v, knobs, P, prefix, mode, hs):
         h_out, h_in = hs[li + 1], hs[li]
         da = dh * elu_grad_from_out(h_out[:, :, :dh.shape[2]])   # hs[4] also carries the knob columns
         da2 = da.reshape(-1, da.shape[2])
-        grads[f"{prefix}.{name}.weight"] = da2.T @ h_in.reshape(-1, h_in.shape[2])
+        grads[f"{prefix}.{name}.weight"] = _ra(da2).T @ _ra(h_in.reshape(-1, h_in.shape[2]))
         grads[f"{prefix}.{name}.bias"] = da2.sum(0)
-        dh = da @ W
+        dh = _ra(da) @ _ra(W)
         if name == "fnn_addknobs":
             dh = dh[:, :, :W.shape[0]]                       # drop the knob columns (no grad to knobs)
     dv += dh

@@ -105,6 +105,22 @@ __device__ __forceinline__ void stg32(float* __restrict__ base, const unsigned e
 }
 #define ST_MUL24(a, b) __umul24((unsigned)(a), (unsigned)(b))
 
+// bf16-operand arithmetic of the forward kernels (st_set_precision(2)): weights and layer inputs rounded to bfloat16 (RNE),
+// one v_mfma_f32_16x16x16_bf16 per 16x16 tile (k = the 16 features 4g + r of a tile, i.e. a packed D-layout register set IS
+// the B operand) instead of four v_mfma_f32_16x16x4_f32; accumulation, bias, ELU and epilogue stay fp32.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+#define ST_MFMA16B(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ s16x4 pack_bf16x4(const f32x4 v)
+{
+    union { bf16x4_t h; s16x4 s; } p; p.h = __builtin_convertvector(v, bf16x4_t); return p.s;
+}
+__device__ __forceinline__ float bf16_rne(const float v)
+{
+    union { __bf16 h; unsigned short u; } p; p.h = (__bf16)v;
+    union { unsigned u; float f; } q; q.u = (unsigned)p.u << 16; return q.f;
+}
+
 // One 16x16 tile of A operands (k-steps r = 0..3) from a forward image: W[o = 16 ot + c][i = 16 it + 4 g + r].
 template <int OUTP>
 __device__ __forceinline__ f32x4 frag_fwd(const float* img, const int ot, const int it, const int g, const int c)
@@ -120,10 +136,17 @@ __device__ __forceinline__ f32x4 frag_dgrad(const float* img, const int ot, cons
 
 // Hidden layer for NC interleaved chains: hout[ch][ot] = ELU(W[ch] * hin[ch] + bias[ch]), weights fetched just in time
 // (the forward kernels run two waves per SIMD, which hides the LDS latency).
-template <int NC, int OTL, int ITL, int OUTP>
+template <int NC, int OTL, int ITL, int OUTP, bool BF = false>
 __device__ __forceinline__ void layer_fwd(const float* const (&W)[NC], const float* const (&bias)[NC],
                                           const f32x4 (&hin)[NC][ITL], f32x4 (&hout)[NC][OTL], const int g, const int c)
 {
+    s16x4 ph[NC][ITL];
+    if constexpr (BF) {
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch)
+#pragma unroll
+            for (int it = 0; it < ITL; ++it) ph[ch][it] = pack_bf16x4(hin[ch][it]);
+    }
 #pragma unroll
     for (int ot = 0; ot < OTL; ++ot) {
         f32x4 acc[NC];
@@ -134,10 +157,15 @@ __device__ __forceinline__ void layer_fwd(const float* const (&W)[NC], const flo
             f32x4 w[NC];
 #pragma unroll
             for (int ch = 0; ch < NC; ++ch) w[ch] = frag_fwd<OUTP>(W[ch], ot, it, g, c);
+            if constexpr (BF) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int ch = 0; ch < NC; ++ch) acc[ch] = ST_MFMA16B(pack_bf16x4(w[ch]), ph[ch][it], acc[ch]);
+            } else {
 #pragma unroll
-                for (int ch = 0; ch < NC; ++ch) acc[ch] = ST_MFMA16(w[ch][r], hin[ch][it][r], acc[ch]);
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ch = 0; ch < NC; ++ch) acc[ch] = ST_MFMA16(w[ch][r], hin[ch][it][r], acc[ch]);
+            }
         }
 #pragma unroll
         for (int ch = 0; ch < NC; ++ch)
@@ -148,23 +176,32 @@ __device__ __forceinline__ void layer_fwd(const float* const (&W)[NC], const flo
 
 // Layer 5 of NC chains: [h4 ; knobs] -> 16 (nn_proc.py:92-96).  The knob block uses its own k-step order (step q: lane
 // group g carries knob 4q + g), so K <= 4 knobs cost one MFMA per chain instead of four.
-template <int NC>
+template <int NC, bool BF = false>
 __device__ __forceinline__ void layer5_fwd(const float* const (&lw)[NC], const f32x4 (&h4)[NC][1], const float (&kn)[4], const int KQ,
                                            f32x4 (&h5)[NC][1], const int g, const int c)
 {
     f32x4 acc[NC], w[NC];
 #pragma unroll
     for (int ch = 0; ch < NC; ++ch) { acc[ch] = *reinterpret_cast<const f32x4*>(lw[ch] + CL::B4 + 4 * g); w[ch] = frag_fwd<CL::O4>(lw[ch] + CL::A4, 0, 0, g, c); }
+    if constexpr (BF) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+        for (int ch = 0; ch < NC; ++ch) acc[ch] = ST_MFMA16B(pack_bf16x4(w[ch]), pack_bf16x4(h4[ch][0]), acc[ch]);
+    } else {
 #pragma unroll
-        for (int ch = 0; ch < NC; ++ch) acc[ch] = ST_MFMA16(w[ch][r], h4[ch][0][r], acc[ch]);
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ch = 0; ch < NC; ++ch) acc[ch] = ST_MFMA16(w[ch][r], h4[ch][0][r], acc[ch]);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         if (q < KQ) {
 #pragma unroll
-            for (int ch = 0; ch < NC; ++ch)
-                acc[ch] = ST_MFMA16(lw[ch][CL::A4 + (((4 + q) * CL::O4 + c) << 2) + g], kn[q], acc[ch]);      // W5[o = c][i = 16 + 4q + g]
+            for (int ch = 0; ch < NC; ++ch) {
+                const float wk = lw[ch][CL::A4 + (((4 + q) * CL::O4 + c) << 2) + g];                  // W5[o = c][i = 16 + 4q + g]
+                // BF: the knob block keeps its own k-step order on the fp32 MFMA, with both operands rounded to bf16 first
+                // (products of bf16 values are exact in fp32, so this IS the bf16 arithmetic)
+                acc[ch] = ST_MFMA16(BF ? bf16_rne(wk) : wk, BF ? bf16_rne(kn[q]) : kn[q], acc[ch]);
+            }
         }
 #pragma unroll
     for (int ch = 0; ch < NC; ++ch)
@@ -220,7 +257,7 @@ __device__ __forceinline__ void fwd_mask(FwdIn& in, const int K, const bool fv, 
 }
 
 // grid.x workgroups of NW waves; each wave walks 16-row groups: group id = b*(FP/16) + fg.  Requires T <= 32, OT <= 16, K <= 16.
-template <int NW>
+template <int NW, bool BF = false>      // BF: bf16 operands in the nine Linear layers (st_set_precision(2))
 __global__ void __launch_bounds__(NW * 64)
 ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, const float* __restrict__ knobs,
               const float* __restrict__ ae_m, const float* __restrict__ ae_p, const AEOffsets go,
@@ -261,15 +298,15 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         fwd_load(nxt, mag, phs, knobs, K, bn, fn, fn < F, T, OT, F, g);
 
         f32x4 h1[2][4], h2[2][2], h3[2][1], h4[2][1], h5[2][1], h6[2][1], h7[2][2], h8[2][4], e9[2][1];
-        { const float* const W[2] = ST_W2(CL::A0); const float* const bb[2] = ST_W2(CL::B0); layer_fwd<2, 4, 2, CL::O0>(W, bb, cur.v, h1, g, c); }
-        { const float* const W[2] = ST_W2(CL::A1); const float* const bb[2] = ST_W2(CL::B1); layer_fwd<2, 2, 4, CL::O1>(W, bb, h1, h2, g, c); }
-        { const float* const W[2] = ST_W2(CL::A2); const float* const bb[2] = ST_W2(CL::B2); layer_fwd<2, 1, 2, CL::O2>(W, bb, h2, h3, g, c); }
-        { const float* const W[2] = ST_W2(CL::A3); const float* const bb[2] = ST_W2(CL::B3); layer_fwd<2, 1, 1, CL::O3>(W, bb, h3, h4, g, c); }
-        layer5_fwd<2>(lw, h4, cur.kn, KQ, h5, g, c);
-        { const float* const W[2] = ST_W2(CL::A5); const float* const bb[2] = ST_W2(CL::B5); layer_fwd<2, 1, 1, CL::O5>(W, bb, h5, h6, g, c); }
-        { const float* const W[2] = ST_W2(CL::A6); const float* const bb[2] = ST_W2(CL::B6); layer_fwd<2, 2, 1, CL::O6>(W, bb, h6, h7, g, c); }
-        { const float* const W[2] = ST_W2(CL::A7); const float* const bb[2] = ST_W2(CL::B7); layer_fwd<2, 4, 2, CL::O7>(W, bb, h7, h8, g, c); }
-        { const float* const W[2] = ST_W2(CL::A8); const float* const bb[2] = ST_W2(CL::B8); layer_fwd<2, 1, 4, CL::O8>(W, bb, h8, e9, g, c); }
+        { const float* const W[2] = ST_W2(CL::A0); const float* const bb[2] = ST_W2(CL::B0); layer_fwd<2, 4, 2, CL::O0, BF>(W, bb, cur.v, h1, g, c); }
+        { const float* const W[2] = ST_W2(CL::A1); const float* const bb[2] = ST_W2(CL::B1); layer_fwd<2, 2, 4, CL::O1, BF>(W, bb, h1, h2, g, c); }
+        { const float* const W[2] = ST_W2(CL::A2); const float* const bb[2] = ST_W2(CL::B2); layer_fwd<2, 1, 2, CL::O2, BF>(W, bb, h2, h3, g, c); }
+        { const float* const W[2] = ST_W2(CL::A3); const float* const bb[2] = ST_W2(CL::B3); layer_fwd<2, 1, 1, CL::O3, BF>(W, bb, h3, h4, g, c); }
+        layer5_fwd<2, BF>(lw, h4, cur.kn, KQ, h5, g, c);
+        { const float* const W[2] = ST_W2(CL::A5); const float* const bb[2] = ST_W2(CL::B5); layer_fwd<2, 1, 1, CL::O5, BF>(W, bb, h5, h6, g, c); }
+        { const float* const W[2] = ST_W2(CL::A6); const float* const bb[2] = ST_W2(CL::B6); layer_fwd<2, 2, 1, CL::O6, BF>(W, bb, h6, h7, g, c); }
+        { const float* const W[2] = ST_W2(CL::A7); const float* const bb[2] = ST_W2(CL::B7); layer_fwd<2, 4, 2, CL::O7, BF>(W, bb, h7, h8, g, c); }
+        { const float* const W[2] = ST_W2(CL::A8); const float* const bb[2] = ST_W2(CL::B8); layer_fwd<2, 1, 4, CL::O8, BF>(W, bb, h8, e9, g, c); }
         // ---- epilogue (nn_proc.py:115,117,322-326)
         const float wf = fv ? expf(expfac * (float)f) : 0.f;     // train.py:115-117 frequency weight
 #pragma unroll
@@ -400,17 +437,26 @@ __device__ __forceinline__ void frags_dgrad(f32x4 (&fr)[ITL * OTL], const float*
 }
 #define ST_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <int OTL, int ITL>
+template <int OTL, int ITL, bool BF = false>
 __device__ __forceinline__ void fwdD_fr(const f32x4 (&fr)[OTL * ITL], const float* bias, const f32x4 (&hin)[ITL],
                                         f32x4 (&hout)[OTL], const int g)
 {
+    s16x4 ph[ITL];
+    if constexpr (BF) {
+#pragma unroll
+        for (int it = 0; it < ITL; ++it) ph[it] = pack_bf16x4(hin[it]);
+    }
 #pragma unroll
     for (int ot = 0; ot < OTL; ++ot) {
         f32x4 acc = *reinterpret_cast<const f32x4*>(bias + 16 * ot + 4 * g);   // accumulator starts at the bias (D layout: o = 16 ot + 4 g + r)
 #pragma unroll
-        for (int it = 0; it < ITL; ++it)
+        for (int it = 0; it < ITL; ++it) {
+            if constexpr (BF) acc = ST_MFMA16B(pack_bf16x4(fr[ot * ITL + it]), ph[it], acc);
+            else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc = ST_MFMA16(fr[ot * ITL + it][r], hin[it][r], acc);
+                for (int r = 0; r < 4; ++r) acc = ST_MFMA16(fr[ot * ITL + it][r], hin[it][r], acc);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) hout[ot][r] = elu_f(acc[r]);
     }
@@ -430,16 +476,25 @@ __device__ __forceinline__ void to_T(float* scr, const f32x4 (&d)[TL], f32x4 (&t
         for (int r = 0; r < 4; ++r) t[k][r] = scr[k * 320 + (4 * g + r) * 20 + c];
 }
 
-template <int OTL, int ITL>
+template <int OTL, int ITL, bool BF = false>
 __device__ __forceinline__ void dgradD_fr(const f32x4 (&fr)[ITL * OTL], const f32x4 (&da)[OTL], f32x4 (&dh)[ITL])
 {
+    s16x4 pd[OTL];
+    if constexpr (BF) {
+#pragma unroll
+        for (int ot = 0; ot < OTL; ++ot) pd[ot] = pack_bf16x4(da[ot]);
+    }
 #pragma unroll
     for (int it = 0; it < ITL; ++it) {
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ot = 0; ot < OTL; ++ot)
+        for (int ot = 0; ot < OTL; ++ot) {
+            if constexpr (BF) acc = ST_MFMA16B(pack_bf16x4(fr[it * OTL + ot]), pd[ot], acc);
+            else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc = ST_MFMA16(fr[it * OTL + ot][r], da[ot][r], acc);
+                for (int r = 0; r < 4; ++r) acc = ST_MFMA16(fr[it * OTL + ot][r], da[ot][r], acc);
+            }
+        }
         dh[it] = acc;
     }
 }
@@ -455,15 +510,26 @@ __device__ __forceinline__ void mul_elu_grad(f32x4 (&d)[TL], const f32x4 (&h)[TL
 
 // dW_l tile(ot,it) += sum_rows daT[ot] (x) hT[it] (result in D layout: o = 16ot+4g+r, i = 16it+c); db_l (lane c <-> o = 16 ot + c)
 // accumulates the row sums of daT.  Tiles and sums persist in registers for the whole kernel.
-template <int OTL, int ITL>
+template <int OTL, int ITL, bool BF = false>
 __device__ __forceinline__ void wgrad_reg(f32x4 (&dW)[OTL][ITL], float (&db)[OTL], const f32x4 (&daT)[OTL], const f32x4 (&hT)[ITL])
 {
+    s16x4 pht[ITL];
+    if constexpr (BF) {
+#pragma unroll
+        for (int it = 0; it < ITL; ++it) pht[it] = pack_bf16x4(hT[it]);      // k = the four rows 4g + r of this lane group
+    }
 #pragma unroll
     for (int ot = 0; ot < OTL; ++ot) {
+        s16x4 pdt;
+        if constexpr (BF) pdt = pack_bf16x4(daT[ot]);
 #pragma unroll
-        for (int it = 0; it < ITL; ++it)
+        for (int it = 0; it < ITL; ++it) {
+            if constexpr (BF) dW[ot][it] = ST_MFMA16B(pdt, pht[it], dW[ot][it]);
+            else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dW[ot][it] = ST_MFMA16(daT[ot][r], hT[it][r], dW[ot][it]);
+                for (int r = 0; r < 4; ++r) dW[ot][it] = ST_MFMA16(daT[ot][r], hT[it][r], dW[ot][it]);
+            }
+        }
         db[ot] += (daT[ot][0] + daT[ot][1]) + (daT[ot][2] + daT[ot][3]);
     }
 }
@@ -499,7 +565,7 @@ __device__ __forceinline__ void db_flush(float* dst, float (&db)[OTL], const int
 //   dmag / dphs       -> dA1 [64][R] = (W2^T dA2) * ELU'(h1), consumed by the layer-1 weight/data-gradient GEMMs
 // and the partial gradients of layers 1 and 9 stay zero.
 constexpr int AE_BWD_SCR = (32 + 16 + 16) * SP + 2 * 4 * 320;      // per wave: V, Y, TAIL rows + two 4-tile transpose scratches (to_T)
-template <int NW, bool TIMED, bool INNER = false>
+template <int NW, bool TIMED, bool INNER = false, bool BF = false>      // BF: bf16 operands in all Linear-layer products (st_set_precision(2))
 __global__ void __launch_bounds__(NW * 64, 1)
 ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, const float* __restrict__ knobs,
               const float* __restrict__ ae_m, const float* __restrict__ ae_p, const AEOffsets go, const int PG,
@@ -659,27 +725,27 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Vs[(16 * it + 4 * g + r) * SP + c] = vr[it][r];   // [feature t][row c]: read back transposed for the layer-1 wgrad
             ST_FENCE();
-            fwdD_fr<4, 2>(fr1, lw + CL::B0, vr, h1, g);
+            fwdD_fr<4, 2, BF>(fr1, lw + CL::B0, vr, h1, g);
         }
         ST_T(1);
-        f32x4 fr3[1 * 2]; frags_fwd<1, 2, CL::O2>(fr3, lw + CL::A2, g, c); ST_FENCE(); fwdD_fr<2, 4>(fr2, lw + CL::B1, h1, h2, g);
+        f32x4 fr3[1 * 2]; frags_fwd<1, 2, CL::O2>(fr3, lw + CL::A2, g, c); ST_FENCE(); fwdD_fr<2, 4, BF>(fr2, lw + CL::B1, h1, h2, g);
         ST_T(2);
-        f32x4 fr4[1 * 1]; frags_fwd<1, 1, CL::O3>(fr4, lw + CL::A3, g, c); ST_FENCE(); fwdD_fr<1, 2>(fr3, lw + CL::B2, h2, h3, g);
-        f32x4 fr5[1 * 2]; frags_fwd<1, 2, CL::O4>(fr5, lw + CL::A4, g, c); ST_FENCE(); fwdD_fr<1, 1>(fr4, lw + CL::B3, h3, h4, g);
+        f32x4 fr4[1 * 1]; frags_fwd<1, 1, CL::O3>(fr4, lw + CL::A3, g, c); ST_FENCE(); fwdD_fr<1, 2, BF>(fr3, lw + CL::B2, h2, h3, g);
+        f32x4 fr5[1 * 2]; frags_fwd<1, 2, CL::O4>(fr5, lw + CL::A4, g, c); ST_FENCE(); fwdD_fr<1, 1, BF>(fr4, lw + CL::B3, h3, h4, g);
         f32x4 fr6[1 * 1]; frags_fwd<1, 1, CL::O5>(fr6, lw + CL::A5, g, c); ST_FENCE();
         {
             const f32x4 hk[2] = {h4[0], kn};                                 // knob features 16 + 4g + r
-            fwdD_fr<1, 2>(fr5, lw + CL::B4, hk, h5, g);
+            fwdD_fr<1, 2, BF>(fr5, lw + CL::B4, hk, h5, g);
         }
         ST_T(3);
-        f32x4 fr7[2 * 1]; frags_fwd<2, 1, CL::O6>(fr7, lw + CL::A6, g, c); ST_FENCE(); fwdD_fr<1, 1>(fr6, lw + CL::B5, h5, h6, g);
-        f32x4 fr8[4 * 2]; frags_fwd<4, 2, CL::O7>(fr8, lw + CL::A7, g, c); ST_FENCE(); fwdD_fr<2, 1>(fr7, lw + CL::B6, h6, h7, g);
+        f32x4 fr7[2 * 1]; frags_fwd<2, 1, CL::O6>(fr7, lw + CL::A6, g, c); ST_FENCE(); fwdD_fr<1, 1, BF>(fr6, lw + CL::B5, h5, h6, g);
+        f32x4 fr8[4 * 2]; frags_fwd<4, 2, CL::O7>(fr8, lw + CL::A7, g, c); ST_FENCE(); fwdD_fr<2, 1, BF>(fr7, lw + CL::B6, h6, h7, g);
         ST_T(4);
         f32x4 fr9[1 * 4];
         if constexpr (!INNER) frags_fwd<1, 4, CL::O8>(fr9, lw + CL::A8, g, c);
-        ST_FENCE(); fwdD_fr<4, 2>(fr8, lw + CL::B7, h7, h8, g);
+        ST_FENCE(); fwdD_fr<4, 2, BF>(fr8, lw + CL::B7, h7, h8, g);
         ST_T(5);
-        if constexpr (!INNER) { ST_FENCE(); fwdD_fr<1, 4>(fr9, lw + CL::B8, h8, e9, g); }
+        if constexpr (!INNER) { ST_FENCE(); fwdD_fr<1, 4, BF>(fr9, lw + CL::B8, h8, e9, g); }
         ST_T(6);
         // ------------------------------------------------------------------ d out  (D layout: t' = 4g + r)
         f32x4 da9[1];
@@ -728,10 +794,10 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         ST_FENCE(); } while (0)
 #define ST_BWD_STAGE(O_, I_, FD_, DA_, DAT_, HP_, HTP_, DAP_, DATP_, RW_, RB_, NEXT_) \
         to_T<I_>(XH, HP_, HTP_, g, c); ST_FENCE(); \
-        dgradD_fr<O_, I_>(FD_, DA_, DAP_); mul_elu_grad<I_>(DAP_, HP_); \
+        dgradD_fr<O_, I_, BF>(FD_, DA_, DAP_); mul_elu_grad<I_>(DAP_, HP_); \
         to_T<I_>(XD, DAP_, DATP_, g, c); NEXT_; \
-        wgrad_reg<O_, I_>(RW_, RB_, DAT_, HTP_); \
-        ST_PIPE(O_ * I_ * 4);
+        wgrad_reg<O_, I_, BF>(RW_, RB_, DAT_, HTP_); \
+        ST_PIPE(BF ? O_ * I_ : O_ * I_ * 4);
         f32x4 hT8[4], da8[4], daT8[4], fd8[2 * 4];
         if constexpr (INNER) {                     // dH8 arrives from the layer-9 data-gradient GEMM; h8^T is still needed for ELU' and dW8
             frags_dgrad<4, 2, CL::I7>(fd8, lw + CL::G7, g, c);
@@ -764,11 +830,11 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         f32x4 hT4[1], hT4k[2], da4[1], daT4[1], fd4[1];
         {
             to_T<1>(XH, h4, hT4, g, c); ST_FENCE();
-            dgradD_fr<1, 1>(fd5, da5, da4); mul_elu_grad<1>(da4, h4);
+            dgradD_fr<1, 1, BF>(fd5, da5, da4); mul_elu_grad<1>(da4, h4);
             to_T<1>(XD, da4, daT4, g, c); frags_dgrad<1, 1, CL::I3>(fd4, lw + CL::G3, g, c); ST_FENCE();
             hT4k[0] = hT4[0];
             hT4k[1] = (f32x4){knT, knT, knT, knT};                   // features 16 + c = knob c, every row
-            wgrad_reg<1, 2>(rW5, rb5, daT5, hT4k);
+            wgrad_reg<1, 2, BF>(rW5, rb5, daT5, hT4k);
         }
         // layer 4 (16 -> 16)
         f32x4 hT3[1], da3[1], daT3[1], fd3[2 * 1];
@@ -782,14 +848,14 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         f32x4 hT1[4], da1[4], daT1[4], fd1[2 * 4];
         if constexpr (INNER) {                     // dA1 goes back to memory for the layer-1 GEMMs
             to_T<4>(XH, h1, hT1, g, c); ST_FENCE();
-            dgradD_fr<2, 4>(fd2, da2, da1); mul_elu_grad<4>(da1, h1);
+            dgradD_fr<2, 4, BF>(fd2, da2, da1); mul_elu_grad<4>(da1, h1);
             const unsigned col0 = (unsigned)b * FP + (unsigned)(grp - b * gpw) * 16;
 #pragma unroll
             for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) stg32(dvout, (unsigned)(16 * ot + 4 * g + r) * Rw + col0 + c, da1[ot][r]);
             ST_FENCE();
-            wgrad_reg<2, 4>(rW2, rb2, daT2, hT1);
+            wgrad_reg<2, 4, BF>(rW2, rb2, daT2, hT1);
         } else {
             ST_BWD_STAGE(2, 4, fd2, da2, daT2, h1, hT1, da1, daT1, rW2, rb2, (frags_dgrad<4, 2, CL::I0>(fd1, lw + CL::G0, g, c)))
         }
@@ -800,8 +866,8 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
 #pragma unroll
             for (int it = 0; it < 2; ++it) vT[it] = *reinterpret_cast<const f32x4*>(Vs + (16 * it + c) * SP + 4 * g);
             ST_FENCE();
-            dgradD_fr<4, 2>(fd1, da1, dv);
-            wgrad_reg<4, 2>(rW1, rb1, daT1, vT);
+            dgradD_fr<4, 2, BF>(fd1, da1, dv);
+            wgrad_reg<4, 2, BF>(rW1, rb1, daT1, vT);
         }
 #undef ST_BWD_STAGE
 #undef ST_PIPE

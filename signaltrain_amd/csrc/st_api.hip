@@ -175,14 +175,14 @@ extern "C" int st_set_tuning(int bk)
     if (bk != 16 && bk != 32) return st_fail(ST_ERR_ARG, "bk must be 16 or 32"); g_bk = bk; g_an_bk = bk; return ST_OK;
 }
 // g_prec: arithmetic of the STFT GEMMs -- 0 = fp32 MFMA (default, the parity path), 1 = bf16 operands / fp32 accumulation
-static int g_prec = 0;
-extern "C" int st_set_precision(int bf16) { g_prec = bf16 ? 1 : 0; return ST_OK; }
+static int g_prec = 0;      // 2: bf16 operands also in the forward autoencoder kernel
+extern "C" int st_set_precision(int level) { g_prec = level < 0 ? 0 : (level > 2 ? 2 : level); return ST_OK; }
 extern "C" int st_get_precision(void) { return g_prec; }
-#define ST_GEMM(W_, ...) do { if (g_prec == 1) stg::launch_bf16<W_>(__VA_ARGS__); \
+#define ST_GEMM(W_, ...) do { if (g_prec >= 1) stg::launch_bf16<W_>(__VA_ARGS__); \
                               else if (g_bk == 16) stg::launch<W_, 16>(__VA_ARGS__, g_dbg); else stg::launch<W_, 32>(__VA_ARGS__, g_dbg); } while (0)
 // the analysis forward GEMM (K = N = 1024, two 4-wave workgroups per CU either way) runs 5 % faster with 32-deep k-tiles
 // (half the barriers); every other GEMM of the step is faster with 16 (more workgroups per CU)
-#define ST_GEMM_AN(W_, ...) do { if (g_prec == 1) stg::launch_bf16<W_>(__VA_ARGS__); \
+#define ST_GEMM_AN(W_, ...) do { if (g_prec >= 1) stg::launch_bf16<W_>(__VA_ARGS__); \
                                  else if (g_an_bk == 16) stg::launch<W_, 16>(__VA_ARGS__, g_dbg); else stg::launch<W_, 32>(__VA_ARGS__, g_dbg); } while (0)
 // weight-gradient GEMMs: g_wg_mode 0 = three waves share a 96x96 tile (32x96 strips), 1 = one wave per 96x96 tile
 static int g_wg_mode = 0;
@@ -322,6 +322,13 @@ extern "C" int st_ae_fwd(const st_dims* d, const float* mag, const float* phs, c
         attr = true;
     }
     const float expfac = (float)(7.0 / d->F);
+    if (g_prec == 2) {
+        static bool battr = false;
+        if (!battr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_fwd_kernel<AE_FWD_NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); battr = true; }
+        hipLaunchKernelGGL((sta::ae_fwd_kernel<AE_FWD_NW, true>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, st_stream(stream),
+                           mag, phs, knobs, ae_m, ae_p, L.go, mag_hat, phs_hat, AA, reg_partial,
+                           d->B, d->T, d->OT, d->F, d->K, L.KP, expfac);
+    } else
     hipLaunchKernelGGL((sta::ae_fwd_kernel<AE_FWD_NW>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, st_stream(stream),
                        mag, phs, knobs, ae_m, ae_p, L.go, mag_hat, phs_hat, AA, reg_partial,
                        d->B, d->T, d->OT, d->F, d->K, L.KP, expfac);
@@ -596,6 +603,13 @@ static int ae_bwd_impl(const st_dims* d, const float* mag, const float* phs, con
                        mag, phs, knobs, ae_m, ae_p, L.go, L.PG, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, expfac, \
                        dmag, dphs, ws, d->B, d->T, d->OT, d->F, d->K, L.KP, synth_live(d).t_lo, synth_live(d).t_lo + synth_live(d).Tv - 1, st_synth_slabs(d), (size_t)d->B * d->OT * L.KP, g_dbg)
     if (g_dbg & 256) ST_AE_BWD_LAUNCH(true);      // stage-timer build (tools/ae_stage_times.py)
+    else if (g_prec == 2) {
+        static bool battr = false;
+        if (!battr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); battr = true; }
+        hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, false, false, true>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, st_stream(stream),
+                           mag, phs, knobs, ae_m, ae_p, L.go, L.PG, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, expfac,
+                           dmag, dphs, ws, d->B, d->T, d->OT, d->F, d->K, L.KP, synth_live(d).t_lo, synth_live(d).t_lo + synth_live(d).Tv - 1, st_synth_slabs(d), (size_t)d->B * d->OT * L.KP, g_dbg);
+    }
     else ST_AE_BWD_LAUNCH(false);
 #undef ST_AE_BWD_LAUNCH
     ST_LAUNCHED("ae_bwd");

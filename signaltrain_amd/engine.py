@@ -65,8 +65,8 @@ class StepEngine:
     def __init__(self, dims, device="cuda:0", max_batch=None, compute_dtype="f32"):
         """compute_dtype: "f32" (default, the parity path) or "bf16" = bf16 operands / fp32 accumulation in the STFT GEMMs
         (BASELINE configs[2], [3]); parameters, gradients, autoencoders, loss and Adam are fp32 either way."""
-        if compute_dtype not in ("f32", "bf16"):
-            raise ValueError("compute_dtype must be 'f32' or 'bf16'")
+        if compute_dtype not in ("f32", "bf16", "bf16_all"):
+            raise ValueError("compute_dtype must be 'f32', 'bf16' (STFT GEMMs) or 'bf16_all' (GEMMs + autoencoder layers)")
         self.compute_dtype = compute_dtype
         self.lib = _lib.load()
         self.device = torch.device(device)
@@ -103,7 +103,7 @@ class StepEngine:
 
     def _stream(self):
         # every entry point fetches the stream right before its C call: the (process-wide) precision switch rides along
-        self.lib.st_set_precision(1 if self.compute_dtype == "bf16" else 0)
+        self.lib.st_set_precision({"f32": 0, "bf16": 1, "bf16_all": 2}[self.compute_dtype])
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def _prep(self, x, knobs, y=None):

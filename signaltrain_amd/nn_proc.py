@@ -156,9 +156,10 @@ class AsymMPAEC(nn.Module):
         return [sd[k] for k in param_names()]
 
     def set_compute_dtype(self, dtype):
-        """'f32' (default) or 'bf16' (bf16 operands / fp32 accumulation in the STFT GEMMs, StepEngine.compute_dtype)."""
-        if dtype not in ("f32", "bf16"):
-            raise ValueError("compute dtype must be 'f32' or 'bf16'")
+        """'f32' (default), 'bf16' (bf16 operands / fp32 accumulation in the STFT GEMMs) or 'bf16_all' (also in the nine Linear
+        layers of both autoencoders) -- StepEngine.compute_dtype."""
+        if dtype not in ("f32", "bf16", "bf16_all"):
+            raise ValueError("compute dtype must be 'f32', 'bf16' or 'bf16_all'")
         self.compute_dtype = dtype
         if self._engine is not None:
             self._engine.compute_dtype = dtype
@@ -238,7 +239,7 @@ class st_model(nn.Module):
         self.mpaec.clip_grad_norm_()
 
     def set_compute_dtype(self, dtype):
-        """Mixed precision of the accelerated path: 'f32' (default) | 'bf16' (see AsymMPAEC.set_compute_dtype)."""
+        """Mixed precision of the accelerated path: 'f32' (default) | 'bf16' | 'bf16_all' (see AsymMPAEC.set_compute_dtype)."""
         self.mpaec.set_compute_dtype(dtype)
 
     def forward(self, x_cuda, knobs_cuda, return_acts=False):

@@ -69,17 +69,24 @@ ENGINE_DTYPE = "f32"     # compute_dtype of the StepEngines the checks create
 
 
 class bf16_mode:
-    """Context: HIP library in bf16-operand mode + the oracle's matching bf16 rounding of the GEMM operands.  Tolerances are
-    widened 10x: both sides round the SAME quantities, but an operand that differs by 1e-6 between the two can land on
-    the other side of a bf16 rounding boundary (1 in ~4000 elements does, each then differs by 0.4 %)."""
+    """Context: HIP library in bf16-operand mode + the oracle's matching bf16 rounding.  level 1: the STFT GEMMs; level 2:
+    also the nine Linear layers of both autoencoders (BF instantiations of st_ae.h / oracle.AE_ROUND; fused-kernel
+    geometries only).  Tolerances are widened (10x / 20x): both sides round the SAME quantities, but an operand that differs
+    by 1e-6 between the two can land on the other side of a bf16 rounding boundary (1 in ~4000 elements does, each then
+    differs by 0.4 %), and at level 2 those flips propagate through nine layers."""
+
+    def __init__(self, level=1):
+        self.level = level
 
     def __enter__(self):
         global TOL_SCALE, ENGINE_DTYPE
-        _lib.check(_lib.load().st_set_precision(1), "st_set_precision"); O.GEMM_ROUND = O.bf16_round; TOL_SCALE = 10.0; ENGINE_DTYPE = "bf16"
+        _lib.check(_lib.load().st_set_precision(self.level), "st_set_precision"); O.GEMM_ROUND = O.bf16_round
+        O.AE_ROUND = O.bf16_round if self.level >= 2 else None
+        TOL_SCALE = 10.0 if self.level == 1 else 20.0; ENGINE_DTYPE = "bf16" if self.level == 1 else "bf16_all"
 
     def __exit__(self, *a):
         global TOL_SCALE, ENGINE_DTYPE
-        _lib.load().st_set_precision(0); O.GEMM_ROUND = None; TOL_SCALE = 1.0; ENGINE_DTYPE = "f32"
+        _lib.load().st_set_precision(0); O.GEMM_ROUND = None; O.AE_ROUND = None; TOL_SCALE = 1.0; ENGINE_DTYPE = "f32"
 
 
 def err(name, got, ref, tol=TOL, scale=None):

@@ -146,3 +146,32 @@ def test_bf16_mode_scale8():
     with G.bf16_mode():
         _assert_ok(G.run_all(B=1, seed=3, K=4, scale=8))
         _assert_ok(G.run_fused(B=2, seed=5, K=4, steps=2, scale=8))
+
+
+@pytest.mark.parametrize("B,seed,K", [(3, 0, 4), (2, 5, 7), (1, 9, 16)])
+def test_bf16_all_mode_per_op(B, seed, K):
+    """st_set_precision(2): bf16 operands also in the nine Linear layers of both autoencoders (forward, data gradient, weight
+    gradient: the BF instantiations of st_ae.h, one v_mfma_f32_16x16x16_bf16 per tile) against the oracle with the same
+    operands rounded to bfloat16 (oracle.AE_ROUND)."""
+    from tests import gpu_checks as G
+    with G.bf16_mode(2):
+        _assert_ok(G.run_all(B=B, seed=seed, K=K))
+
+
+def test_bf16_all_mode_fused_step_differs_from_bf16_gemm_mode():
+    import torch
+    from tests import gpu_checks as G
+    from signaltrain_amd.engine import StepEngine
+    B, K = 3, 4
+    with G.bf16_mode(2):
+        _assert_ok(G.run_fused(B=B, seed=1, K=K, steps=2))
+    geo, X, Y, KN, P = G.make_case(B, 1, K=K)
+    d = G.dims_of(geo, B, K)
+    e1 = StepEngine(d, G.DEV, compute_dtype="bf16"); e1.load_state_dict(P)
+    e2 = StepEngine(d, G.DEV, compute_dtype="bf16_all"); e2.load_state_dict(P)
+    x, kn, y = G.t(X), G.t(KN), G.t(Y)
+    e1.loss_backward(x, kn, y); e2.loss_backward(x, kn, y)
+    torch.cuda.synchronize()
+    o = e1.layout.offsets
+    rel = (e1.grads[o[4]:] - e2.grads[o[4]:]).abs().max().item() / e1.grads[o[4]:].abs().max().item()
+    assert 1e-5 < rel < 5e-2, rel                                    # the autoencoder gradients really went through bf16 products
