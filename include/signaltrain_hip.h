@@ -208,8 +208,9 @@ int st_dp_clip_adam(const st_dims* d, float* params, float* grads, float* m, flo
  *    rounded to bf16 (the oracle has the same switch), not the fp32 reference.
  * 2: additionally the nine Linear layers of both autoencoders (nn_proc.py:84-117 and their autograd): weights and layer
  *    inputs / incoming gradients are rounded to bf16, one v_mfma_f32_16x16x16_bf16 per 16x16 tile with fp32 accumulation;
- *    bias, ELU, ELU', the skip / residual epilogue stay fp32.  Fused-kernel geometries (T <= 32, OT <= 16) only: wide
- *    geometries keep fp32 autoencoders at level 2. */
+ *    bias, ELU, ELU', the skip / residual epilogue stay fp32.  Wide geometries (T > 32): the layer-1 / layer-9 GEMMs run
+ *    on the bf16 GEMM kernel and the fused inner layers likewise, provided B * roundup(F,16) is a multiple of 32 (even B
+ *    at F = 513); otherwise their autoencoders stay fp32. */
 int st_set_precision(int level);
 int st_get_precision(void);
 

@@ -340,7 +340,7 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
 // column = b*FP + f); this kernel fuses layers 2..8 (64 -> 32 -> 16 -> 16 -> [+knobs] 16 -> 16 -> 32 -> 64) for both
 // autoencoders: H1 [64][R] -> H8 [64][R], activations in registers exactly as in ae_fwd_kernel.  A 16-column group never
 // straddles windows (FP % 16 == 0), so the knobs stay wave-uniform.  Pad columns (f >= F) are written as zeros.
-template <int NW>
+template <int NW, bool BF = false>
 __global__ void __launch_bounds__(NW * 64)
 ae_inner_fwd_kernel(const float* __restrict__ H1m, const float* __restrict__ H1p, const float* __restrict__ knobs,
                     const float* __restrict__ ae_m, const float* __restrict__ ae_p, const AEOffsets go,
@@ -373,13 +373,13 @@ ae_inner_fwd_kernel(const float* __restrict__ H1m, const float* __restrict__ H1p
 #pragma unroll
         for (int q = 0; q < 4; ++q) { const int k = 4 * q + g; const float x = knobs[(size_t)b * K + (k < K ? k : 0)]; kn[q] = k < K ? x : 0.f; }
         f32x4 h2[2][2], h3[2][1], h4[2][1], h5[2][1], h6[2][1], h7[2][2], h8[2][4];
-        { const float* const W[2] = ST_W2(CL::A1); const float* const bb[2] = ST_W2(CL::B1); layer_fwd<2, 2, 4, CL::O1>(W, bb, h1, h2, g, c); }
-        { const float* const W[2] = ST_W2(CL::A2); const float* const bb[2] = ST_W2(CL::B2); layer_fwd<2, 1, 2, CL::O2>(W, bb, h2, h3, g, c); }
-        { const float* const W[2] = ST_W2(CL::A3); const float* const bb[2] = ST_W2(CL::B3); layer_fwd<2, 1, 1, CL::O3>(W, bb, h3, h4, g, c); }
-        layer5_fwd<2>(lw, h4, kn, KQ, h5, g, c);
-        { const float* const W[2] = ST_W2(CL::A5); const float* const bb[2] = ST_W2(CL::B5); layer_fwd<2, 1, 1, CL::O5>(W, bb, h5, h6, g, c); }
-        { const float* const W[2] = ST_W2(CL::A6); const float* const bb[2] = ST_W2(CL::B6); layer_fwd<2, 2, 1, CL::O6>(W, bb, h6, h7, g, c); }
-        { const float* const W[2] = ST_W2(CL::A7); const float* const bb[2] = ST_W2(CL::B7); layer_fwd<2, 4, 2, CL::O7>(W, bb, h7, h8, g, c); }
+        { const float* const W[2] = ST_W2(CL::A1); const float* const bb[2] = ST_W2(CL::B1); layer_fwd<2, 2, 4, CL::O1, BF>(W, bb, h1, h2, g, c); }
+        { const float* const W[2] = ST_W2(CL::A2); const float* const bb[2] = ST_W2(CL::B2); layer_fwd<2, 1, 2, CL::O2, BF>(W, bb, h2, h3, g, c); }
+        { const float* const W[2] = ST_W2(CL::A3); const float* const bb[2] = ST_W2(CL::B3); layer_fwd<2, 1, 1, CL::O3, BF>(W, bb, h3, h4, g, c); }
+        layer5_fwd<2, BF>(lw, h4, kn, KQ, h5, g, c);
+        { const float* const W[2] = ST_W2(CL::A5); const float* const bb[2] = ST_W2(CL::B5); layer_fwd<2, 1, 1, CL::O5, BF>(W, bb, h5, h6, g, c); }
+        { const float* const W[2] = ST_W2(CL::A6); const float* const bb[2] = ST_W2(CL::B6); layer_fwd<2, 2, 1, CL::O6, BF>(W, bb, h6, h7, g, c); }
+        { const float* const W[2] = ST_W2(CL::A7); const float* const bb[2] = ST_W2(CL::B7); layer_fwd<2, 4, 2, CL::O7, BF>(W, bb, h7, h8, g, c); }
         const bool fv = f < F;
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch)

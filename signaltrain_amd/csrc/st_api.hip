@@ -228,7 +228,7 @@ static void wide_carve(const st_dims* d, float* base, WideWS* w)
     const int hrows[8] = {64, 32, 16, 16 + d->K, 16, 16, 32, 64};
     const int drows[9] = {64, 32, 16, 16, 16, 16, 32, 64, d->OT};
     int out[9], in[9]; ae_shapes(d, out, in);
-    w->R = R; w->Tp = st_round_up(d->T, 16);
+    w->R = R; w->Tp = st_round_up(d->T, 32);      // 32: k-tile of the bf16 GEMM kernel (level-2 precision)
     { long ns = (long)(R / 128); w->nsplit = (int)(ns < 1 ? 1 : (ns > 256 ? 256 : ns)); }   // wgrad K = R: short k-chains on many workgroups
     w->so[0] = 0;
     for (int l = 0; l < 9; ++l) w->so[l + 1] = w->so[l] + st_round_up(out[l] * (in[l] + 1), 64);
@@ -431,13 +431,17 @@ extern "C" int st_synthesis_wgrad(const st_dims* d, const float* AA, const float
 
 
 // ------------------------------------------------------------------------------ wide-geometry autoencoders (st_ae_wide.h)
-#define ST_WGEMM(...) stg::launch<2, 16>(__VA_ARGS__, g_dbg)          // BM = 64, k-tile 16 (every K below is a multiple of 16 or checked)
+// BM = 64, k-tile 16 (every K below is a multiple of 16 or checked).  Level-2 precision: the bf16 kernel (k-tile 32: W1 is
+// padded to a multiple of 32 columns and K = R operands need R % 32 == 0, else the whole wide path stays fp32 -- g_wide_bf)
+static bool g_wide_bf = false;
+#define ST_WGEMM(...) do { if (g_wide_bf) stg::launch_bf16<2>(__VA_ARGS__); else stg::launch<2, 16>(__VA_ARGS__, g_dbg); } while (0)
 static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, const float* phs, const float* knobs,
                        const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA, float* reg_partial,
                        WideWS& w, void* stream)
 {
     hipStream_t s = st_stream(stream);
     const int FP = L.KP / 2, F = d->F, T = d->T, OT = d->OT, R = (int)w.R, Tp = w.Tp;
+    g_wide_bf = g_prec == 2 && R % 32 == 0;
     ST_REQ(w.R * (size_t)(T > 64 ? T : 64) < ((size_t)1 << 30), "wide autoencoder path: batch too large (B=%d)", d->B);
     const stg::RowMap id = stg::all_frames(1);
     int out[9], in[9]; ae_shapes(d, out, in);
@@ -465,7 +469,15 @@ static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, cons
     if (g_wide_fused) {
         const size_t lds = (size_t)2 * sta::CL::FWD_TOTAL * sizeof(float);
         static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_inner_fwd_kernel<AE_FWD_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_inner_fwd_kernel<AE_FWD_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_inner_fwd_kernel<AE_FWD_NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr = true;
+        }
+        if (g_wide_bf)
+            hipLaunchKernelGGL((sta::ae_inner_fwd_kernel<AE_FWD_NW, true>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, s,
+                               w.H[0][0], w.H[1][0], knobs, ae_m, ae_p, L.go, w.H[0][7], w.H[1][7], d->B, F, d->K, L.KP);
+        else
         hipLaunchKernelGGL((sta::ae_inner_fwd_kernel<AE_FWD_NW>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, s,
                            w.H[0][0], w.H[1][0], knobs, ae_m, ae_p, L.go, w.H[0][7], w.H[1][7], d->B, F, d->K, L.KP);
     }
@@ -505,6 +517,7 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
 {
     hipStream_t s = st_stream(stream);
     const int FP = L.KP / 2, F = d->F, T = d->T, OT = d->OT, R = (int)w.R, Tp = w.Tp;
+    g_wide_bf = g_prec == 2 && R % 32 == 0;
     const stg::RowMap id = stg::all_frames(1);
     int out[9], in[9]; ae_shapes(d, out, in);
     // forward state (activations + ELU outputs of layer 9): recomputed into the workspace unless the fused step's own
@@ -549,8 +562,18 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
         {
             const size_t lds = ((size_t)sta::CL::BWD_TOTAL + (size_t)AE_BWD_NW * sta::AE_BWD_SCR) * sizeof(float);
             static bool attr = false;
-            if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            if (!attr) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr = true;
+            }
             const int grid = ae_bwd_grid(d);
+            if (g_wide_bf)
+                hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, false, true, true>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, s,
+                                   (const float*)w.H[0][0], (const float*)w.H[1][0], knobs, ae_m, ae_p, L.go, L.PG,
+                                   (const float*)w.DA[0][7], (const float*)w.DA[1][7], (const float*)nullptr, (const float*)nullptr, 0.f, 0.f,
+                                   w.DA[0][0], w.DA[1][0], w.inner_ws, d->B, T, OT, F, d->K, L.KP, 0, 0, 1, (size_t)0, 0);
+            else
             hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, false, true>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, s,
                                (const float*)w.H[0][0], (const float*)w.H[1][0], knobs, ae_m, ae_p, L.go, L.PG,
                                (const float*)w.DA[0][7], (const float*)w.DA[1][7], (const float*)nullptr, (const float*)nullptr, 0.f, 0.f,

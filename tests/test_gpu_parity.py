@@ -175,3 +175,16 @@ def test_bf16_all_mode_fused_step_differs_from_bf16_gemm_mode():
     o = e1.layout.offsets
     rel = (e1.grads[o[4]:] - e2.grads[o[4]:]).abs().max().item() / e1.grads[o[4]:].abs().max().item()
     assert 1e-5 < rel < 5e-2, rel                                    # the autoencoder gradients really went through bf16 products
+
+
+def test_bf16_all_mode_scale8():
+    """Level-2 precision at the 65536-sample geometry (BASELINE configs[4]): the wide autoencoder path runs its layer-1 / layer-9
+    GEMMs on the bf16 kernel and the fused inner layers in their BF instantiation (needs an even batch: K = R operands must be
+    a multiple of the 32-deep bf16 k-tile, otherwise the wide path stays fp32).  Per-op against the oracle with the same
+    roundings; the fused step at 1e-2 -- with 174-frame rows a rounding-boundary flip somewhere in a sum is the rule, and the
+    bias gradients of layers 1 / 9 come out of the GEMM with rounded dA where the oracle sums unrounded values."""
+    from tests import gpu_checks as G
+    with G.bf16_mode(2):
+        _assert_ok(G.run_all(B=2, seed=3, K=4, scale=8))
+    with G.bf16_mode(2, tol_scale=100.0):
+        _assert_ok(G.run_fused(B=2, seed=1, K=4, steps=2, scale=8))
