@@ -4,7 +4,10 @@ for a fixed wall-clock budget.  Not part of the pytest suite (its coverage is fi
 "soft" lines are analysis-basis gradient outliers (atan2 conditioning at near-zero bins, judged separately by the
 weighted checks in the suite).  In bf16 mode with B = 1 a single operand landing on the other side of a bf16 rounding
 boundary is 0.4 % of one of only OT = 9 summands, so an occasional 2-4e-3 max-relative outlier there is rounding, not a bug.
-Round-1 result: 260 configurations in 150 s, 0 hard failures in fp32, 1 such bf16 B=1 outlier."""
+Round-1 result: 260 configurations in 150 s, 0 hard failures in fp32, 1 such bf16 B=1 outlier.
+With the bf16 levels drawn at random (1 = STFT GEMMs, 2 = also the autoencoder layers; fused tolerances 3e-3 / 2e-2 = the
+noise floors of tools/bf16_noise_floor.py): 254 configurations, fp32 all green, 2 level-2 outliers of 4-5e-2 at B <= 3 --
+a fused bf16 step is chaotic at that level (one flipped rounding per few thousand values, nine layers of amplification)."""
 import sys, time, random; sys.path.insert(0, '.')
 from tests import gpu_checks as G
 random.seed(1234)
@@ -14,11 +17,13 @@ while time.time() - t0 < 150:
     shrink = random.choice([1, 2, 4, 4, 8]) if scale == 1 else 4
     B = random.choice([1, 2, 3, 4, 5, 6, 9, 13]) if scale == 1 else random.choice([1, 2, 3])
     K = random.choice([1, 2, 3, 4, 4, 5, 8, 12, 16]); seed = random.randrange(1000)
-    bf = random.random() < 0.3
+    bf = random.choice([0, 0, 0, 0, 1, 1, 2, 2])           # 0 = fp32, 1 = bf16 GEMMs, 2 = bf16 GEMMs + autoencoder layers
+    if bf == 2 and scale == 8 and B % 2: B += 1          # the wide path takes level 2 only for even batches
     kw = dict(B=B, seed=seed, K=K, steps=1, scale=scale, scheme=scheme, shrink=shrink)
     try:
+        kw["B"] = B
         if bf:
-            with G.bf16_mode(): res = G.run_fused(**kw)
+            with G.bf16_mode(bf, tol_scale=G.bf16_mode.FUSED_TOL[bf]): res = G.run_fused(**kw)
         else:
             res = G.run_fused(**kw)
         bad = [r for r in res if not r["ok"] and "conv_analysis" not in r["name"]]      # analysis-gradient outliers = atan2 conditioning, checked separately
@@ -27,5 +32,5 @@ while time.time() - t0 < 150:
         bad = [dict(name="EXC " + str(e)[:160], rel=0)]; soft = []
     n += 1; nbad += bool(bad)
     if bad or soft:
-        print(("BAD " if bad else "soft"), kw, "bf16" if bf else "f32", [(r['name'], f"{r['rel']:.1e}") for r in (bad + soft)[:4]], flush=True)
+        print(("BAD " if bad else "soft"), kw, ("f32", "bf16", "bf16_all")[bf], [(r['name'], f"{r['rel']:.1e}") for r in (bad + soft)[:4]], flush=True)
 print(f"{n} random configurations, {nbad} with hard failures, {time.time()-t0:.0f} s")
