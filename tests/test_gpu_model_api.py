@@ -395,3 +395,24 @@ def test_train_driver_device_feed(tmp_path):
         assert len(lines) >= 3 and all(np.isfinite(float(l[-1])) for l in lines)
     finally:
         os.chdir(cwd)
+
+
+def test_train_driver_bf16_all(tmp_path):
+    """train.train(compute_dtype="bf16_all"): the mixed-precision step (bf16 operands in the STFT GEMMs and the autoencoder
+    layers, fp32 master weights / optimizer) through the driver, device-resident data: its validation-loss trajectory over four
+    epochs stays within 5 % of the fp32 run from the same seeds."""
+    from signaltrain_amd import train, audio, nn_proc
+    nn_proc._QUIET = True
+    cwd = os.getcwd()
+    traj = {}
+    try:
+        for dt in ("f32", "bf16_all"):
+            sub = tmp_path / dt; sub.mkdir(); os.chdir(sub)
+            torch.manual_seed(0); np.random.seed(0)
+            train.train(effect=audio.Compressor_4c(), epochs=4, n_data_points=512, batch_size=32,
+                        device=torch.device("cuda:0"), num_workers=2, device_feed=True, lr_max=2e-4, compute_dtype=dt)
+            traj[dt] = np.array([float(l.split()[-1]) for l in open("vl_avg_out.dat").read().strip().splitlines()])
+    finally:
+        os.chdir(cwd)
+    assert len(traj["f32"]) >= 4 and np.all(np.isfinite(traj["bf16_all"]))
+    assert np.all(np.abs(traj["bf16_all"] - traj["f32"]) <= 0.05 * np.abs(traj["f32"])), traj
