@@ -64,6 +64,8 @@ def from_kp(a, F):
     return a[:, :F], a[:, KP // 2:KP // 2 + F]
 
 
+PREC_LEVEL = 0           # st_set_precision level the checks run under (bf16_mode sets it); re-asserted at the start of every run_*:
+                         # the switch is process-wide, and an engine created by another test may have left it elsewhere
 TOL_SCALE = 1.0          # multiplies every tolerance (mixed-precision runs: see bf16_mode)
 ENGINE_DTYPE = "f32"     # compute_dtype of the StepEngines the checks create
 
@@ -83,13 +85,15 @@ class bf16_mode:
         self.tol_scale = tol_scale          # override, e.g. the 65536-sample geometry at level 2 (174-frame rows: more flips per sum)
 
     def __enter__(self):
-        global TOL_SCALE, ENGINE_DTYPE
+        global TOL_SCALE, ENGINE_DTYPE, PREC_LEVEL
+        PREC_LEVEL = self.level
         _lib.check(_lib.load().st_set_precision(self.level), "st_set_precision"); O.GEMM_ROUND = O.bf16_round
         O.AE_ROUND = O.bf16_round if self.level >= 2 else None
         TOL_SCALE = self.tol_scale if self.tol_scale else (10.0 if self.level == 1 else 20.0); ENGINE_DTYPE = "bf16" if self.level == 1 else "bf16_all"
 
     def __exit__(self, *a):
-        global TOL_SCALE, ENGINE_DTYPE
+        global TOL_SCALE, ENGINE_DTYPE, PREC_LEVEL
+        PREC_LEVEL = 0
         _lib.load().st_set_precision(0); O.GEMM_ROUND = None; O.AE_ROUND = None; TOL_SCALE = 1.0; ENGINE_DTYPE = "f32"
 
 
@@ -123,6 +127,7 @@ def phase_err(name, got, ref, mag, tol=TOL):
 def run_all(B=3, seed=0, K=4, verbose=False, scale=1, scheme="lean", shrink=4):
     """Run every per-op entry point on oracle-provided inputs; returns list of result dicts."""
     lib = _lib.load()
+    lib.st_set_precision(PREC_LEVEL)
     geo, X, Y, KN, P = make_case(B, seed, K=K, scale=scale, scheme=scheme, shrink=shrink)
     d = dims_of(geo, B, K)
     KP = lib.st_kp(d.F); F, T, OT, N = d.F, d.T, d.OT, d.N

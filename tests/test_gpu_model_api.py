@@ -414,5 +414,7 @@ def test_train_driver_bf16_all(tmp_path):
             traj[dt] = np.array([float(l.split()[-1]) for l in open("vl_avg_out.dat").read().strip().splitlines()])
     finally:
         os.chdir(cwd)
+        from signaltrain_amd import _lib
+        _lib.load().st_set_precision(0)               # the switch is process-wide: do not leak bf16 into the tests that follow
     assert len(traj["f32"]) >= 4 and np.all(np.isfinite(traj["bf16_all"]))
     assert np.all(np.abs(traj["bf16_all"] - traj["f32"]) <= 0.05 * np.abs(traj["f32"])), traj
