@@ -514,6 +514,16 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
                         for (int j = 0; j < NJ; ++j)
                             acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[j], acc[mi][j], 0, 0, 0);
                 }
+                if constexpr (A_K && B_K && MI == 1) {
+                    // k-major operands: one scalar A and NJ scalar B fragments per k-step.  Recipe: the LDS reads of step k+1 are
+                    // issued before the MFMAs of step k (left alone the compiler emits ds_read / s_waitcnt / MFMA triplets).
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                    for (int kk = 0; kk < HK; ++kk) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, MI * NJ, 0);
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (!ST_DBG(1)) lstore(cur ^ 1);
