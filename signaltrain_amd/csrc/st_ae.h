@@ -52,16 +52,18 @@ struct CL {
     static_assert(FWD_TOTAL % 4 == 0 && BWD_TOTAL % 4 == 0, "16-byte aligned regions");
 };
 
-// Cooperative load of one autoencoder's parameters into its LDS images (zero padded): zero-fill, then a coalesced read
-// of the packed global tensors with 8 independent loads in flight per thread (a dependent load->store loop costs
-// ~40 serialized L2 round trips per workgroup, i.e. tens of microseconds before the first MFMA) scattered to the image
-// positions.  Layers [l0, l1) only (the wide path keeps 1..7).  The caller synchronises afterwards.
+// Cooperative load of one autoencoder's parameters into its LDS images (zero padded).  ALL global loads of a thread -- every
+// layer's weights (coalesced reads of the packed tensors) and biases -- are issued back to back before anything is consumed:
+// one memory round trip for the whole parameter block.  (Layer by layer, as a run-time loop, it was nine dependent round
+// trips -- ~15 us of a workgroup's life before its first MFMA, at one wave per SIMD nothing hides that.)  The LDS zero-fill
+// runs while the loads are in flight, then the values are scattered to their image positions.  Layers [l0, l1) only (the
+// wide path keeps 1..7).  The caller synchronises afterwards.
+constexpr int ae_max_elems(int l) { return l == 0 ? 64 * 32 : l == 1 ? 32 * 64 : l == 2 ? 16 * 32 : l == 3 ? 16 * 16 : l == 4 ? 16 * 32 :
+                                           l == 5 ? 16 * 16 : l == 6 ? 32 * 16 : l == 7 ? 64 * 32 : 16 * 64; }
+template <int NT>
 __device__ inline void ae_load_lds(float* lds, const float* __restrict__ ae, const AEOffsets& go, const int T, const int OT, const int K,
-                                   const int tid, const int nthreads, const int l0, const int l1, const bool dgrad_images)
+                                   const int tid, const int l0, const int l1, const bool dgrad_images)
 {
-    const int total = dgrad_images ? CL::BWD_TOTAL : CL::FWD_TOTAL;
-    for (int e = tid; e < total; e += nthreads) lds[e] = 0.f;
-    __syncthreads();
     const int out[NL] = {64, 32, 16, 16, 16, 16, 32, 64, OT};
     const int in[NL] = {T, 64, 32, 16, 16 + K, 16, 16, 32, 64};
     const int outp[NL] = {CL::O0, CL::O1, CL::O2, CL::O3, CL::O4, CL::O5, CL::O6, CL::O7, CL::O8};
@@ -69,24 +71,34 @@ __device__ inline void ae_load_lds(float* lds, const float* __restrict__ ae, con
     const int ao[NL] = {CL::A0, CL::A1, CL::A2, CL::A3, CL::A4, CL::A5, CL::A6, CL::A7, CL::A8};
     const int bo[NL] = {CL::B0, CL::B1, CL::B2, CL::B3, CL::B4, CL::B5, CL::B6, CL::B7, CL::B8};
     const int gi[NL] = {CL::G0, CL::G1, CL::G2, CL::G3, CL::G4, CL::G5, CL::G6, CL::G7, CL::G8};
-    for (int l = l0; l < l1; ++l) {
-        const int IN = in[l], n = out[l] * IN, OP = outp[l], IP = inp[l];
+    constexpr int MAXU = (64 * 32 + NT - 1) / NT;             // elements per thread of the largest layer
+    float v[NL][MAXU], bv[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const bool on = l >= l0 && l < l1;
+        const int n = on ? out[l] * in[l] : 0;
         const float* src = ae + go.w[l];
-        for (int e0 = tid; e0 < n; e0 += 8 * nthreads) {
-            float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int e = e0 + u * nthreads; v[u] = src[e < n ? e : 0]; }
+        for (int u = 0; u < (ae_max_elems(l) + NT - 1) / NT; ++u) { const int e = tid + u * NT; v[l][u] = src[e < n ? e : 0]; }
+        bv[l] = ae[go.b[l] + (tid < out[l] ? tid : 0)];
+    }
+    const int total = dgrad_images ? CL::BWD_TOTAL : CL::FWD_TOTAL;
+    for (int e = tid; e < total; e += NT) lds[e] = 0.f;
+    __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = e0 + u * nthreads;
-                if (e < n) {
-                    const int o = e / IN, i = e - o * IN;
-                    lds[ao[l] + (((i >> 2) * OP + o) << 2) + (i & 3)] = v[u];
-                    if (dgrad_images) lds[gi[l] + (((o >> 2) * IP + i) << 2) + (o & 3)] = v[u];
-                }
+    for (int l = 0; l < NL; ++l) {
+        const bool on = l >= l0 && l < l1;
+        const int IN = in[l], n = on ? out[l] * IN : 0, OP = outp[l], IP = inp[l];
+#pragma unroll
+        for (int u = 0; u < (ae_max_elems(l) + NT - 1) / NT; ++u) {
+            const int e = tid + u * NT;
+            if (e < n) {
+                const int o = e / IN, i = e - o * IN;
+                lds[ao[l] + (((i >> 2) * OP + o) << 2) + (i & 3)] = v[l][u];
+                if (dgrad_images) lds[gi[l] + (((o >> 2) * IP + i) << 2) + (o & 3)] = v[l][u];
             }
         }
-        if (tid < out[l]) lds[bo[l] + tid] = ae[go.b[l] + tid];
+        if (on && tid < out[l]) lds[bo[l] + tid] = bv[l];
     }
 }
 
@@ -269,8 +281,8 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
     const float* const lw[2] = {lds, lds + CL::FWD_TOTAL};
-    ae_load_lds(lds, ae_m, go, T, OT, K, tid, NW * 64, 0, NL, false);
-    ae_load_lds(lds + CL::FWD_TOTAL, ae_p, go, T, OT, K, tid, NW * 64, 0, NL, false);
+    ae_load_lds<NW * 64>(lds, ae_m, go, T, OT, K, tid, 0, NL, false);
+    ae_load_lds<NW * 64>(lds + CL::FWD_TOTAL, ae_p, go, T, OT, K, tid, 0, NL, false);
     __syncthreads();
 
     const int FP = KP / 2, gpw = FP / 16;              // groups per window
@@ -350,8 +362,8 @@ ae_inner_fwd_kernel(const float* __restrict__ H1m, const float* __restrict__ H1p
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
     const float* const lw[2] = {lds, lds + CL::FWD_TOTAL};
-    ae_load_lds(lds, ae_m, go, 16, 16, K, tid, NW * 64, 1, 8, false);
-    ae_load_lds(lds + CL::FWD_TOTAL, ae_p, go, 16, 16, K, tid, NW * 64, 1, 8, false);
+    ae_load_lds<NW * 64>(lds, ae_m, go, 16, 16, K, tid, 1, 8, false);
+    ae_load_lds<NW * 64>(lds + CL::FWD_TOTAL, ae_p, go, 16, 16, K, tid, 1, 8, false);
     __syncthreads();
     const int FP = KP / 2, gpw = FP / 16, ngroups = B * gpw;
     const size_t R = (size_t)B * FP;
@@ -590,7 +602,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     float* Ts = Ys + 16 * SP;
     float* XH = Ts + 16 * SP;                          // transposes of activations
     float* XD = XH + 4 * 320;                          // transposes of activation gradients
-    ae_load_lds(lw, ae ? ae_p : ae_m, go, INNER ? 16 : T, INNER ? 16 : OT, K, tid, NW * 64, INNER ? 1 : 0, INNER ? 8 : NL, true);
+    ae_load_lds<NW * 64>(lw, ae ? ae_p : ae_m, go, INNER ? 16 : T, INNER ? 16 : OT, K, tid, INNER ? 1 : 0, INNER ? 8 : NL, true);
     __syncthreads();
 
     const float* vin = ae ? phs : mag;
