@@ -577,6 +577,8 @@ __device__ __forceinline__ void db_flush(float* dst, float (&db)[OTL], const int
 //   dmag / dphs       -> dA1 [64][R] = (W2^T dA2) * ELU'(h1), consumed by the layer-1 weight/data-gradient GEMMs
 // and the partial gradients of layers 1 and 9 stay zero.
 constexpr int AE_BWD_SCR = (32 + 16 + 16) * SP + 2 * 4 * 320;      // per wave: V, Y, TAIL rows + two 4-tile transpose scratches (to_T)
+// LDS of the backward kernel (floats): images + per-wave scratch during the loop, four per-wave gradient images at the end
+constexpr int ae_bwd_lds_floats(int nw) { return (CL::BWD_TOTAL + nw * AE_BWD_SCR) > nw * CL::FWD_TOTAL ? (CL::BWD_TOTAL + nw * AE_BWD_SCR) : nw * CL::FWD_TOTAL; }
 template <int NW, bool TIMED, bool INNER = false, bool BF = false>      // BF: bf16 operands in all Linear-layer products (st_set_precision(2))
 __global__ void __launch_bounds__(NW * 64, 1)
 ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, const float* __restrict__ knobs,
@@ -916,39 +918,47 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         mask_kn(knn, knTn); kn = knn; knT = knTn;
     }
     // ---------------------------------------------------------------------- workgroup partial gradients
-    // The forward images are dead now: their region becomes the workgroup's gradient image, dW_l as [o][INp] at CL::A_l and
-    // db_l at CL::B_l.  Ordered, non-atomic: wave 0 stores, the others add in turn -> run-to-run identical bits.
+    // All LDS contents are dead now.  Every wave stores its accumulators into ITS OWN gradient image (dW_l as [o][INp] at
+    // CL::A_l, db_l at CL::B_l, images CL::FWD_TOTAL floats apart), all four in parallel, and the store pass below sums the
+    // images in a fixed order ((0 + 1) + (2 + 3)): run-to-run identical bits without the serialised wave-by-wave
+    // read-modify-write flush the first versions used (three extra barrier-separated LDS passes).
     __syncthreads();
-    float* dwl = lds;
-#define ST_FLUSH(FIRST_) do { \
-        if constexpr (!INNER) { dw_flush<4, 2, CL::I0, FIRST_>(dwl + CL::A0, rW1, g, c); dw_flush<1, 4, CL::I8, FIRST_>(dwl + CL::A8, rW9, g, c); \
-                                db_flush<4, FIRST_>(dwl + CL::B0, rb1, g, c); db_flush<1, FIRST_>(dwl + CL::B8, rb9, g, c); } \
-        dw_flush<2, 4, CL::I1, FIRST_>(dwl + CL::A1, rW2, g, c); dw_flush<1, 2, CL::I2, FIRST_>(dwl + CL::A2, rW3, g, c); \
-        dw_flush<1, 1, CL::I3, FIRST_>(dwl + CL::A3, rW4, g, c); dw_flush<1, 2, CL::I4, FIRST_>(dwl + CL::A4, rW5, g, c); \
-        dw_flush<1, 1, CL::I5, FIRST_>(dwl + CL::A5, rW6, g, c); dw_flush<2, 1, CL::I6, FIRST_>(dwl + CL::A6, rW7, g, c); \
-        dw_flush<4, 2, CL::I7, FIRST_>(dwl + CL::A7, rW8, g, c); \
-        db_flush<2, FIRST_>(dwl + CL::B1, rb2, g, c); db_flush<1, FIRST_>(dwl + CL::B2, rb3, g, c); db_flush<1, FIRST_>(dwl + CL::B3, rb4, g, c); \
-        db_flush<1, FIRST_>(dwl + CL::B4, rb5, g, c); db_flush<1, FIRST_>(dwl + CL::B5, rb6, g, c); db_flush<2, FIRST_>(dwl + CL::B6, rb7, g, c); \
-        db_flush<4, FIRST_>(dwl + CL::B7, rb8, g, c); } while (0)
-    if (wave == 0) ST_FLUSH(true);
+    static_assert(NW == 4, "the store pass sums exactly four per-wave images");
+    float* dwl = lds + wave * CL::FWD_TOTAL;
+    if constexpr (!INNER) { dw_flush<4, 2, CL::I0, true>(dwl + CL::A0, rW1, g, c); dw_flush<1, 4, CL::I8, true>(dwl + CL::A8, rW9, g, c);
+                            db_flush<4, true>(dwl + CL::B0, rb1, g, c); db_flush<1, true>(dwl + CL::B8, rb9, g, c); }
+    dw_flush<2, 4, CL::I1, true>(dwl + CL::A1, rW2, g, c); dw_flush<1, 2, CL::I2, true>(dwl + CL::A2, rW3, g, c);
+    dw_flush<1, 1, CL::I3, true>(dwl + CL::A3, rW4, g, c); dw_flush<1, 2, CL::I4, true>(dwl + CL::A4, rW5, g, c);
+    dw_flush<1, 1, CL::I5, true>(dwl + CL::A5, rW6, g, c); dw_flush<2, 1, CL::I6, true>(dwl + CL::A6, rW7, g, c);
+    dw_flush<4, 2, CL::I7, true>(dwl + CL::A7, rW8, g, c);
+    db_flush<2, true>(dwl + CL::B1, rb2, g, c); db_flush<1, true>(dwl + CL::B2, rb3, g, c); db_flush<1, true>(dwl + CL::B3, rb4, g, c);
+    db_flush<1, true>(dwl + CL::B4, rb5, g, c); db_flush<1, true>(dwl + CL::B5, rb6, g, c); db_flush<2, true>(dwl + CL::B6, rb7, g, c);
+    db_flush<4, true>(dwl + CL::B7, rb8, g, c);
     __syncthreads();
-    for (int wv = 1; wv < NW; ++wv) {
-        if (wave == wv) ST_FLUSH(false);
-        __syncthreads();
-    }
-#undef ST_FLUSH
+    auto sum4 = [&](int idx) { return (lds[idx] + lds[CL::FWD_TOTAL + idx]) + (lds[2 * CL::FWD_TOTAL + idx] + lds[3 * CL::FWD_TOTAL + idx]); };
+    // Packed partial gradient of this workgroup (layout of the parameter block).  One unrolled pass: every layer's elements per
+    // thread are compile-time bounded, so the LDS reads batch up and the index arithmetic folds (the first version zeroed the
+    // whole block, synchronised, then ran nine run-time loops with a run-time division per element: 14-22 us per launch).
     float* base = ws + ((size_t)blockIdx.x * 2 + ae) * PG;
-    for (int i = tid; i < PG; i += NW * 64) base[i] = 0.f;                 // alignment pads
-    __syncthreads();
     const int out[NL] = {64, 32, 16, 16, 16, 16, 32, 64, OT};
     const int in[NL] = {T, 64, 32, 16, 16 + K, 16, 16, 32, 64};
     const int inp[NL] = {CL::I0, CL::I1, CL::I2, CL::I3, CL::I4, CL::I5, CL::I6, CL::I7, CL::I8};
     const int ao[NL] = {CL::A0, CL::A1, CL::A2, CL::A3, CL::A4, CL::A5, CL::A6, CL::A7, CL::A8};
     const int bo[NL] = {CL::B0, CL::B1, CL::B2, CL::B3, CL::B4, CL::B5, CL::B6, CL::B7, CL::B8};
-    for (int l = INNER ? 1 : 0; l < (INNER ? 8 : NL); ++l) {       // INNER: layers 1 and 9 come from the GEMM path
+    constexpr int NT = NW * 64;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const bool have = !INNER || (l >= 1 && l < 8);                  // INNER: layers 1 and 9 come from the GEMM path, their partials stay zero
         const int IN = in[l], n = out[l] * IN;
-        for (int e = tid; e < n; e += NW * 64) { const int o = e / IN; base[go.w[l] + e] = dwl[ao[l] + o * inp[l] + (e - o * IN)]; }
-        if (tid < out[l]) base[go.b[l] + tid] = dwl[bo[l] + tid];
+#pragma unroll
+        for (int u = 0; u < (ae_max_elems(l) + NT - 1) / NT; ++u) {
+            const int e = tid + u * NT;
+            if (e < n) { const int o = e / IN, i = e - o * IN; base[go.w[l] + e] = have ? sum4(ao[l] + o * inp[l] + i) : 0.f; }
+        }
+        if (tid < out[l]) base[go.b[l] + tid] = have ? sum4(bo[l] + tid) : 0.f;
+        // alignment pads behind the weight and the bias tensor
+        { const int p0 = go.w[l] + n, np = go.b[l] - p0; if (tid < np) base[p0 + tid] = 0.f; }
+        { const int p0 = go.b[l] + out[l], np = (l + 1 < NL ? go.w[l + 1] : PG) - p0; if (tid < np) base[p0 + tid] = 0.f; }
     }
 }
 

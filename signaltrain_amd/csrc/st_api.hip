@@ -560,7 +560,7 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
         // layer 9 as GEMMs, layers 8..2 in one fused kernel (both nets), layer 1 as GEMMs
         for (int a = 0; a < 2; ++a) { wide_wgrad(d, w, a, 8, out, in, s); dgrad(a, 8, true); }
         {
-            const size_t lds = ((size_t)sta::CL::BWD_TOTAL + (size_t)AE_BWD_NW * sta::AE_BWD_SCR) * sizeof(float);
+            const size_t lds = (size_t)sta::ae_bwd_lds_floats(AE_BWD_NW) * sizeof(float);
             static bool attr = false;
             if (!attr) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -609,8 +609,8 @@ static int ae_bwd_impl(const st_dims* d, const float* mag, const float* phs, con
         WideWS w; wide_carve(d, ws, &w);
         return ae_wide_bwd(d, L, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, dmag, dphs, w, g_m, g_p, have_fwd, stream);
     }
-    const size_t lds = ((size_t)sta::CL::BWD_TOTAL + (size_t)AE_BWD_NW * sta::AE_BWD_SCR) * sizeof(float);
-    static_assert(((size_t)sta::CL::BWD_TOTAL + (size_t)AE_BWD_NW * sta::AE_BWD_SCR) * sizeof(float) <= 160 * 1024, "ae_bwd LDS budget");
+    const size_t lds = (size_t)sta::ae_bwd_lds_floats(AE_BWD_NW) * sizeof(float);
+    static_assert((size_t)sta::ae_bwd_lds_floats(AE_BWD_NW) * sizeof(float) <= 160 * 1024, "ae_bwd LDS budget");
     ST_REQ((size_t)st_synth_slabs(d) * d->B * d->OT * L.KP < ((size_t)1 << 30) && (size_t)d->B * d->T * L.KP < ((size_t)1 << 30),
            "st_ae_bwd: batch too large for the kernel's 32-bit element offsets (B=%d)", d->B);
     static bool attr = false;
