@@ -61,8 +61,27 @@ struct CL {
 constexpr int ae_max_elems(int l) { return l == 0 ? 64 * 32 : l == 1 ? 32 * 64 : l == 2 ? 16 * 32 : l == 3 ? 16 * 16 : l == 4 ? 16 * 32 :
                                            l == 5 ? 16 * 16 : l == 6 ? 32 * 16 : l == 7 ? 64 * 32 : 16 * 64; }
 template <int NT>
-__device__ inline void ae_load_lds(float* lds, const float* __restrict__ ae, const AEOffsets& go, const int T, const int OT, const int K,
-                                   const int tid, const int l0, const int l1, const bool dgrad_images)
+struct AEParamRegs { float v[NL][(64 * 32 + NT - 1) / NT]; float bv[NL]; };      // one thread's share of an autoencoder's parameters
+
+template <int NT>
+__device__ __forceinline__ void ae_params_issue(AEParamRegs<NT>& r, const float* __restrict__ ae, const AEOffsets& go,
+                                                const int T, const int OT, const int K, const int tid, const int l0, const int l1)
+{
+    const int out[NL] = {64, 32, 16, 16, 16, 16, 32, 64, OT};
+    const int in[NL] = {T, 64, 32, 16, 16 + K, 16, 16, 32, 64};
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const bool on = l >= l0 && l < l1;
+        const int n = on ? out[l] * in[l] : 0;
+        const float* src = ae + go.w[l];
+#pragma unroll
+        for (int u = 0; u < (ae_max_elems(l) + NT - 1) / NT; ++u) { const int e = tid + u * NT; r.v[l][u] = src[e < n ? e : 0]; }
+        r.bv[l] = ae[go.b[l] + (tid < out[l] ? tid : 0)];
+    }
+}
+template <int NT>
+__device__ __forceinline__ void ae_params_scatter(float* lds, const AEParamRegs<NT>& r, const int T, const int OT, const int K,
+                                                  const int tid, const int l0, const int l1, const bool dgrad_images)
 {
     const int out[NL] = {64, 32, 16, 16, 16, 16, 32, 64, OT};
     const int in[NL] = {T, 64, 32, 16, 16 + K, 16, 16, 32, 64};
@@ -71,20 +90,6 @@ __device__ inline void ae_load_lds(float* lds, const float* __restrict__ ae, con
     const int ao[NL] = {CL::A0, CL::A1, CL::A2, CL::A3, CL::A4, CL::A5, CL::A6, CL::A7, CL::A8};
     const int bo[NL] = {CL::B0, CL::B1, CL::B2, CL::B3, CL::B4, CL::B5, CL::B6, CL::B7, CL::B8};
     const int gi[NL] = {CL::G0, CL::G1, CL::G2, CL::G3, CL::G4, CL::G5, CL::G6, CL::G7, CL::G8};
-    constexpr int MAXU = (64 * 32 + NT - 1) / NT;             // elements per thread of the largest layer
-    float v[NL][MAXU], bv[NL];
-#pragma unroll
-    for (int l = 0; l < NL; ++l) {
-        const bool on = l >= l0 && l < l1;
-        const int n = on ? out[l] * in[l] : 0;
-        const float* src = ae + go.w[l];
-#pragma unroll
-        for (int u = 0; u < (ae_max_elems(l) + NT - 1) / NT; ++u) { const int e = tid + u * NT; v[l][u] = src[e < n ? e : 0]; }
-        bv[l] = ae[go.b[l] + (tid < out[l] ? tid : 0)];
-    }
-    const int total = dgrad_images ? CL::BWD_TOTAL : CL::FWD_TOTAL;
-    for (int e = tid; e < total; e += NT) lds[e] = 0.f;
-    __syncthreads();
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
         const bool on = l >= l0 && l < l1;
@@ -94,12 +99,37 @@ __device__ inline void ae_load_lds(float* lds, const float* __restrict__ ae, con
             const int e = tid + u * NT;
             if (e < n) {
                 const int o = e / IN, i = e - o * IN;
-                lds[ao[l] + (((i >> 2) * OP + o) << 2) + (i & 3)] = v[l][u];
-                if (dgrad_images) lds[gi[l] + (((o >> 2) * IP + i) << 2) + (o & 3)] = v[l][u];
+                lds[ao[l] + (((i >> 2) * OP + o) << 2) + (i & 3)] = r.v[l][u];
+                if (dgrad_images) lds[gi[l] + (((o >> 2) * IP + i) << 2) + (o & 3)] = r.v[l][u];
             }
         }
-        if (on && tid < out[l]) lds[bo[l] + tid] = bv[l];
+        if (on && tid < out[l]) lds[bo[l] + tid] = r.bv[l];
     }
+}
+// One autoencoder (backward kernel: forward + dgrad images) ...
+template <int NT>
+__device__ inline void ae_load_lds(float* lds, const float* __restrict__ ae, const AEOffsets& go, const int T, const int OT, const int K,
+                                   const int tid, const int l0, const int l1, const bool dgrad_images)
+{
+    AEParamRegs<NT> r;
+    ae_params_issue<NT>(r, ae, go, T, OT, K, tid, l0, l1);
+    const int total = dgrad_images ? CL::BWD_TOTAL : CL::FWD_TOTAL;
+    for (int e = tid; e < total; e += NT) lds[e] = 0.f;
+    __syncthreads();
+    ae_params_scatter<NT>(lds, r, T, OT, K, tid, l0, l1, dgrad_images);
+}
+// ... or both (forward kernels: two forward images CL::FWD_TOTAL floats apart), still one round trip.
+template <int NT>
+__device__ inline void ae_load_lds2(float* lds, const float* __restrict__ ae_m, const float* __restrict__ ae_p, const AEOffsets& go,
+                                    const int T, const int OT, const int K, const int tid, const int l0, const int l1)
+{
+    AEParamRegs<NT> rm, rp;
+    ae_params_issue<NT>(rm, ae_m, go, T, OT, K, tid, l0, l1);
+    ae_params_issue<NT>(rp, ae_p, go, T, OT, K, tid, l0, l1);
+    for (int e = tid; e < 2 * CL::FWD_TOTAL; e += NT) lds[e] = 0.f;
+    __syncthreads();
+    ae_params_scatter<NT>(lds, rm, T, OT, K, tid, l0, l1, false);
+    ae_params_scatter<NT>(lds + CL::FWD_TOTAL, rp, T, OT, K, tid, l0, l1, false);
 }
 
 #define ST_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -281,8 +311,7 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
     const float* const lw[2] = {lds, lds + CL::FWD_TOTAL};
-    ae_load_lds<NW * 64>(lds, ae_m, go, T, OT, K, tid, 0, NL, false);
-    ae_load_lds<NW * 64>(lds + CL::FWD_TOTAL, ae_p, go, T, OT, K, tid, 0, NL, false);
+    ae_load_lds2<NW * 64>(lds, ae_m, ae_p, go, T, OT, K, tid, 0, NL);
     __syncthreads();
 
     const int FP = KP / 2, gpw = FP / 16;              // groups per window
@@ -362,8 +391,7 @@ ae_inner_fwd_kernel(const float* __restrict__ H1m, const float* __restrict__ H1p
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
     const float* const lw[2] = {lds, lds + CL::FWD_TOTAL};
-    ae_load_lds<NW * 64>(lds, ae_m, go, 16, 16, K, tid, 1, 8, false);
-    ae_load_lds<NW * 64>(lds + CL::FWD_TOTAL, ae_p, go, 16, 16, K, tid, 1, 8, false);
+    ae_load_lds2<NW * 64>(lds, ae_m, ae_p, go, 16, 16, K, tid, 1, 8);
     __syncthreads();
     const int FP = KP / 2, gpw = FP / 16, ngroups = B * gpw;
     const size_t R = (size_t)B * FP;
