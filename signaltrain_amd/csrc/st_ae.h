@@ -441,9 +441,9 @@ ae_inner_fwd_kernel(const float* __restrict__ H1m, const float* __restrict__ H1p
 //      ("T layout": lane (g,c), reg r <-> row 4g + r, feature 16*tile + c): they come from wave-private LDS transposes
 //      (to_T: one ds_write_b128 + four ds_read_b32 per tile, no barrier);
 //   4. accumulates the 36 dW tiles and the bias row sums in registers for the whole kernel.
-// At the end the four waves add their accumulators into an LDS gradient image IN WAVE ORDER with plain adds (fixed
-// summation order: run-to-run identical bits), over the no-longer-needed forward image, and the workgroup stores its
-// partial dW/db (packed like the parameters); ae_grad_reduce_kernel sums the workgroups.
+// At the end every wave stores its accumulators into its own LDS gradient image (all four in parallel, over the no-longer
+// needed weight images and scratch) and one unrolled pass sums the four images in a fixed order into the workgroup's partial
+// dW/db (packed like the parameters): run-to-run identical bits; ae_grad_reduce_kernel sums the workgroups.
 constexpr int SP = 20;                 // scratch pitch (floats): 16 rows + 4, keeps rows 16-B aligned
 
 // Diagnostics only (st_set_debug bit 8): wave 0 of workgroup (0,0) accumulates s_memtime deltas per kernel stage.
