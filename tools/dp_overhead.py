@@ -10,7 +10,8 @@ geo, X, Y, KN, P = G.make_case(B, 3, K=4)
 d = G.dims_of(geo, B, 4)
 eng = StepEngine(d, G.DEV); eng.load_state_dict(P)
 x, k, y = (torch.from_numpy(a).to(G.DEV) for a in (X, KN, Y))
-dp = DataParallel(eng, force_collectives=True)
+dp = DataParallel(eng, force_collectives=True, schedule="staged")
+dp2 = DataParallel(eng, force_collectives=True, schedule="two_bucket")
 def run(fn, n=50):
     for _ in range(10): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -32,6 +33,6 @@ def last_only():
     for s in range(4): eng.loss_backward_stage(s, x, k, y)
     dist.all_reduce(eng.stage_bucket(3)); eng.clip_adam(1e-4)
 for name, fn in (("fused train_step", lambda: eng.train_step(x, k, y, 1e-4)), ("4 stages, no collectives", stages_only),
-                 ("4 stages + 4 async all-reduce (dp)", lambda: dp.train_step(x, k, y, 1e-4)), ("4 stages + 4 in-stream all-reduce", stages_ar_sync),
+                 ("DataParallel staged (4 stages + 4 async all-reduce)", lambda: dp.train_step(x, k, y, 1e-4)), ("DataParallel two_bucket (default)", lambda: dp2.train_step(x, k, y, 1e-4)), ("4 stages + 4 in-stream all-reduce", stages_ar_sync),
                  ("p1/p2 + 2 async all-reduce (old)", two_bucket), ("4 stages + 1 all-reduce", last_only)):
-    h, t = run(fn); print(f"{name:40s} host issue {h:.3f} ms/step   total {t:.3f} ms/step", flush=True)
+    h, t = run(fn); print(f"{name:52s} host issue {h:.3f} ms/step   total {t:.3f} ms/step", flush=True)
