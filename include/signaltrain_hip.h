@@ -25,7 +25,29 @@ extern "C" {
 #define ST_ERR_LAUNCH (-2)   /* HIP launch error */
 #define ST_ERR_UNSUPPORTED (-3)
 
-/* Geometry of one model instance (nn_proc.py:357-385). */
+/* Arithmetic of a call (st_dims.prec).  Carried per call: two engines of different precision can share a process.
+ *   ST_PREC_F32       fp32 MFMA everywhere -- the parity path (<= 1e-4 of the fp32 reference).
+ *   ST_PREC_BF16      bf16 operands, fp32 accumulation in the analysis / synthesis GEMMs and their data / weight gradients
+ *                     (BASELINE.json configs[2], [3]); operands are rounded (RNE) as they are staged, parameters,
+ *                     activations, gradients, autoencoders, loss and Adam stay fp32.
+ *   ST_PREC_BF16_ALL  additionally the nine Linear layers of both autoencoders (nn_proc.py:84-117 and their autograd):
+ *                     weights and layer inputs / incoming gradients rounded to bf16, fp32 accumulation; bias, ELU, ELU',
+ *                     skip / residual epilogue fp32.
+ *   ST_PREC_F16, ST_PREC_F16_ALL   the same two levels with IEEE float16 operands (BASELINE.json configs[4], the
+ *                     reference's Apex amp path, train.py:254-255), meant to run with st_dims.loss_scale > 1
+ *                     (train.py:134-135 amp.scale_loss).  Conversion is IEEE: an out-of-range operand becomes inf, the
+ *                     gradient norm turns non-finite and st_train_step / st_dp_clip_adam SKIP the update and count it in
+ *                     scalars[5] (Apex's overflow handling; the host lowers the scale).  The polar backward (fp32, 1e7-sized
+ *                     sub-gradients on silent frames) saturates its output to the fp16 range; loss and Adam fp32.
+ * Each level equals the reference computed with those operands rounded the same way (the oracle has the same switches),
+ * not the fp32 reference. */
+#define ST_PREC_F32 0
+#define ST_PREC_BF16 1
+#define ST_PREC_BF16_ALL 2
+#define ST_PREC_F16 3
+#define ST_PREC_F16_ALL 4
+
+/* Geometry (nn_proc.py:357-385) and arithmetic of one call. */
 typedef struct st_dims {
     int B;   /* windows in this (per-GPU) minibatch                         */
     int L;   /* samples per input window  (8192*scale)                      */
@@ -36,6 +58,12 @@ typedef struct st_dims {
     int F;   /* N/2+1                                                       */
     int K;   /* knobs                                                       */
     int y;   /* output samples = (OT-1)*H - N                               */
+    int prec;          /* ST_PREC_* (0 = fp32)                                                                   */
+    float loss_scale;  /* static loss scale S of the mixed-precision step (0 or 1: none).  The fused entry points
+                          multiply d loss by S before the backward and divide the gradients by S in the optimizer
+                          (train.py:134-135); the per-op backward entries are linear and simply pass S through.   */
+    int clip_all;      /* 0: L1 clip over the 4 STFT tensors only (nn_proc.py:299-302, the default path);
+                          1: over ALL parameters (train.py:136, what the reference does when Apex amp is on)      */
 } st_dims;
 
 /* Internal padded spectral pitch: re bins at [0,F), im bins at [KP/2, KP/2+F). */
@@ -141,7 +169,7 @@ int st_norm_partials(const st_dims* d);
  * torch.optim.Adam.step (train.py:147).  scalars: device float[8] written by st_finalize_scalars. */
 int st_finalize_scalars(const st_dims* d, const float* loss_partial, const float* reg_partial,
                         const float* norm_partial_a, const float* norm_partial_s, float inv_world,
-                        float* scalars /* [0]=loss [1]=logcosh [2]=reg [3]=l1norm [4]=clip_coef */, void* stream);
+                        float* scalars /* [0]=loss [1]=logcosh [2]=reg [3]=l1norm [4]=clip_coef [5]=overflow */, void* stream);
 int st_clip_adam(float* params, float* grads, float* m, float* v, int64_t n_total, int64_t n_stft,
                  const float* scalars, float grad_scale, float lr, float beta1, float beta2, float eps, int step,
                  void* stream);
@@ -194,25 +222,39 @@ int st_train_step(const st_dims* d, float* params, float* grads, float* m, float
                   const float* knobs, const float* y_true, void* ws, float* scalars,
                   float lr, float beta1, float beta2, float eps, int step, void* stream);
 
-/* After an external all-reduce of `grads` (data parallel): recompute the STFT L1 norm of the
- * reduced, scaled gradient, clip and Adam.  grad_scale = 1/world. */
+/* After an external all-reduce of `grads` (data parallel): recompute the L1 norm of the reduced, scaled gradient (over the
+ * STFT tensors, or over everything with st_dims.clip_all), clip and Adam.  grad_scale = 1/world (the loss scale of
+ * st_dims.loss_scale, if any, is removed here as well). */
 int st_dp_clip_adam(const st_dims* d, float* params, float* grads, float* m, float* v, void* ws,
                     float* scalars, float grad_scale, float lr, float beta1, float beta2, float eps,
                     int step, void* stream);
 
-/* ---- arithmetic of the STFT GEMMs (process-wide switch) -------------------------------------------------------------
- * 0 (default): fp32 MFMA -- the parity path (<= 1e-4 of the fp32 reference).
- * 1: bf16 operands, fp32 accumulation (BASELINE.json configs[2], [3]): both operands of the analysis / synthesis GEMMs
- *    and of their data / weight gradients are rounded to bf16 (RNE) as they are staged; parameters, activations,
- *    gradients, the autoencoders, the loss and Adam stay fp32.  Equals the reference run with those conv operands
- *    rounded to bf16 (the oracle has the same switch), not the fp32 reference.
- * 2: additionally the nine Linear layers of both autoencoders (nn_proc.py:84-117 and their autograd): weights and layer
- *    inputs / incoming gradients are rounded to bf16, one v_mfma_f32_16x16x16_bf16 per 16x16 tile with fp32 accumulation;
- *    bias, ELU, ELU', the skip / residual epilogue stay fp32.  Wide geometries (T > 32): the layer-1 / layer-9 GEMMs run
- *    on the bf16 GEMM kernel and the fused inner layers likewise, provided B * roundup(F,16) is a multiple of 32 (even B
- *    at F = 513); otherwise their autoencoders stay fp32. */
-int st_set_precision(int level);
-int st_get_precision(void);
+/* ---- data parallel inside the library: RCCL over xGMI -------------------------------------------
+ * Replaces the reference's disabled nn.DataParallel stub (train.py:259-263) by one process per GPU + an explicit exchange
+ * step.  The communicator handle is the only state the library owns; RCCL is bound with dlopen at st_dp_init (a process
+ * that already carries librccl -- PyTorch-ROCm does -- shares that copy).
+ *   st_dp_unique_id   rank 0: fills 128 bytes; the host hands them to every rank (any bootstrap channel).
+ *   st_dp_init        collective over all ranks (ncclCommInitRank); creates the communicator stream and ordering events.
+ *   st_dp_allreduce   in-place SUM of n floats on the communicator stream, ordered after the work issued so far on `stream`;
+ *                     returns at once, so the caller's next kernels overlap the collective.
+ *   st_dp_broadcast   same ordering, root's buffer to all (initial parameters).
+ *   st_dp_sync        `stream` waits for every collective issued so far.
+ *   st_dp_train_step  one whole data-parallel optimisation step driven from C (no host code between the buckets):
+ *                     st_loss_backward_p1 -> all-reduce grads[offs[2]..) || st_loss_backward_p2_staged -> all-reduce the
+ *                     packed live analysis rows (`stage`, 2*F*N floats, caller-owned) -> st_unstage_analysis ->
+ *                     st_dp_clip_adam(1/world).  p == NULL or world == 1 (and !force_exchange): plain st_train_step. */
+typedef struct st_dp st_dp;
+int st_dp_unique_id(void* id128);
+int st_dp_init(const void* id128, int rank, int world, st_dp** out);
+int st_dp_destroy(st_dp* p);
+int st_dp_rank(const st_dp* p);
+int st_dp_world(const st_dp* p);
+int st_dp_allreduce(st_dp* p, float* buf, int64_t n, void* stream);
+int st_dp_broadcast(st_dp* p, float* buf, int64_t n, int root, void* stream);
+int st_dp_sync(st_dp* p, void* stream);
+int st_dp_train_step(st_dp* p, const st_dims* d, float* params, float* grads, float* m, float* v, float* stage,
+                     const float* x, const float* knobs, const float* y_true, void* ws, float* scalars,
+                     float lr, float beta1, float beta2, float eps, int step, int force_exchange, void* stream);
 
 /* ---- device-side data feed -------------------------------------------------------------------
  * audio.compressor_4controls (signaltrain/audio.py:380-426), the effect of the synthetic comp_4c task

@@ -41,8 +41,24 @@ def bf16_round(a):
     return r.view(np.float32).astype(a.dtype).reshape(a.shape)
 
 
+def fp16_round(a):
+    """Round-to-nearest-even to IEEE float16 (out-of-range -> inf, as under the reference's Apex amp), returned in the input
+    dtype: the operand conversion of the HIP library's ST_PREC_F16* levels (st_pack_f16 / pack_h4<2>)."""
+    a = np.asarray(a)
+    with np.errstate(over="ignore"):
+        return a.astype(np.float16).astype(a.dtype)
+
+
 def _r(a):
     return a if GEMM_ROUND is None else GEMM_ROUND(a)
+
+
+# LOSS_SCALE = S: d loss is multiplied by S before the backward (Apex amp.scale_loss, train.py:134-135), so every gradient
+# returned by model_loss_bwd carries S (what the rounding of the fp16 gradient operands sees); train_step divides it out
+# before the clip, like the library's optimizer kernel.  Powers of two keep the scaling itself exact.
+LOSS_SCALE = 1.0
+# CLIP_ALL: the L1 clip runs over ALL parameters (train.py:136, the reference's Apex branch) instead of the 4 STFT tensors.
+CLIP_ALL = False
 
 
 # AE_ROUND = bf16_round: weights and layer inputs of the nine Linear layers of both autoencoders (forward, data gradient,
@@ -347,9 +363,9 @@ def model_loss_bwd(x, knobs, y_true, P, geo, scale_by_freq=True):
     out, mag, mag_hat, c = model_fwd(x, knobs, P, geo, return_all=True)
     w = freq_weights(F, dt) if scale_by_freq else None
     loss = calc_loss(out, y_true.astype(dt), mag_hat, w)
-    lam = dt.type(L1_LAMBDA / 10 if scale_by_freq else L1_LAMBDA)
-    # d loss / d out
-    dy = -np.tanh(y_true.astype(dt) - out) / dt.type(B * ysz)
+    lam = dt.type((L1_LAMBDA / 10 if scale_by_freq else L1_LAMBDA) * LOSS_SCALE)
+    # d loss / d out (times the loss scale, if any)
+    dy = -np.tanh(y_true.astype(dt) - out) / dt.type(B * ysz) * dt.type(LOSS_SCALE)
     dsyn = 2 * dy
     dfull = np.zeros((B, (OT - 1) * H + N), dt)
     dfull[:, N:N + ysz] = dsyn
@@ -380,6 +396,10 @@ def model_loss_bwd(x, knobs, y_true, P, geo, scale_by_freq=True):
     inv = np.where(c["mag"] > 0, 1 / safe, 0)                # norm subgradient 0 at the origin
     dre = dmag * re * inv - dphs * im / den
     dim = dmag * im * inv + dphs * rp / den
+    if GEMM_ROUND is fp16_round:
+        # fp16 configurations: the polar backward (fp32) saturates its result to the fp16 range before the weight-gradient GEMM
+        # narrows it -- d atan2 ~ 1e7 on silent frames times the loss scale, and inf x 0 (the silent frame) would be NaN
+        dre, dim = np.clip(dre, -65504.0, 65504.0), np.clip(dim, -65504.0, 65504.0)
     fr = frames(x / 2, N, H, T).reshape(-1, N)
     gWr = np.zeros((N, N), dt); gWi = np.zeros((N, N), dt)
     gWr[:F] = _r(dre.reshape(-1, F).T) @ _r(fr)
@@ -393,14 +413,16 @@ def model_loss_bwd(x, knobs, y_true, P, geo, scale_by_freq=True):
 
 
 # ----------------------------------------------------------------------------- optimiser
-def clip_l1_stft(grads, max_norm=1.0):
+def clip_l1_stft(grads, max_norm=1.0, all_params=None):
     """AsymMPAEC.clip_grad_norm_ (nn_proc.py:299-302): L1 norm over the 4 STFT tensors only,
-    torch.nn.utils.clip_grad_norm_ semantics: coef = max_norm/(norm+1e-6), applied if < 1."""
-    n = sum(np.abs(grads[k].astype(np.float64)).sum() for k in STFT_KEYS)
+    torch.nn.utils.clip_grad_norm_ semantics: coef = max_norm/(norm+1e-6), applied if < 1.
+    all_params (default: CLIP_ALL): the Apex branch instead, train.py:136 -- the same clip over every parameter."""
+    keys = list(grads.keys()) if (CLIP_ALL if all_params is None else all_params) else STFT_KEYS
+    n = sum(np.abs(grads[k].astype(np.float64)).sum() for k in keys)
     n32 = np.float32(n)
     coef = np.float32(max_norm) / (n32 + np.float32(1e-6))
     if coef < 1:
-        for k in STFT_KEYS:
+        for k in keys:
             grads[k] = grads[k] * grads[k].dtype.type(coef)
     return float(n32), float(min(coef, np.float32(1.0)))
 
@@ -442,6 +464,8 @@ def train_step(x, knobs, y_true, P, M, V, step, lr, geo):
     """One optimisation step in the order of train.py:112-151 (forward, loss, backward,
     L1 clip of STFT grads, Adam).  `lr` is the value in param_groups at step time."""
     loss, grads, _ = model_loss_bwd(x, knobs, y_true, P, geo)
+    if LOSS_SCALE != 1.0:
+        grads = {k: g * g.dtype.type(1.0 / LOSS_SCALE) for k, g in grads.items()}      # amp unscales before the clip
     norm, coef = clip_l1_stft(grads)
     adam_step(P, grads, M, V, step, lr)
     return float(loss), norm, coef

@@ -9,7 +9,15 @@ import torch
 if __name__ == "__main__":
     np.random.seed(218); torch.manual_seed(218)                      # run_train.py:20-21
     p = argparse.ArgumentParser(description="trains SignalTrain network", formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    p.add_argument('--apex', help="accepted for compatibility (no Apex on ROCm; fp32 engine)", default="O0")
+    p.add_argument('--apex', help="mixed precision optimization level as in the reference: O0 = fp32; O1/O2/O3 = float16 operands, "
+                   "fp32 accumulation, loss scaling, clip over all parameters (the library's f16_all arithmetic; there is no Apex on ROCm)",
+                   default="O0", choices=["O0", "O1", "O2", "O3"])
+    p.add_argument('--dtype', help="arithmetic of the accelerated step, overrides --apex: f32 | bf16 | bf16_all | f16 | f16_all",
+                   default=None, choices=["f32", "bf16", "bf16_all", "f16", "f16_all"])
+    p.add_argument('--gpus', type=int, default=None, help="data-parallel world size this job is meant to run on; launch with "
+                   "`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 run_train.py --gpus N ...` "
+                   "(one process per GPU); checked against WORLD_SIZE")
+    p.add_argument('--device-feed', action='store_true', help="keep a recycled synthetic dataset in HBM instead of the 10-worker CPU DataLoader")
     p.add_argument('-b', '--batch', type=int, help="batch size (per GPU)", default=200)
     p.add_argument('--checkpoint', help='name of checkpoint .tar file to start from', default='modelcheckpoint.tar')
     p.add_argument('-c', '--compand', help='accepted for compatibility', action='store_true')
@@ -26,14 +34,20 @@ if __name__ == "__main__":
 
     import torch.distributed as dist
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus is not None and args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one process per GPU with\n  python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29500 run_train.py --gpus {args.gpus} ...")
     torch.cuda.set_device(local)
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # bootstrap channel only (RCCL unique id, logging): the gradient exchange runs on the library's own RCCL communicator
+        dist.init_process_group("gloo")
     from signaltrain_amd import audio, train
     effect = audio.Compressor_4c() if args.effect == 'comp_4c' else audio.Compressor_4c_Large()
     train.train(epochs=args.epochs, n_data_points=args.num, batch_size=args.batch, device=torch.device("cuda", local),
                 effect=effect, datapath=args.path, scale_factor=args.scale, shrink_factor=args.shrink, apex_opt=args.apex,
-                target_type=args.target, lr_max=args.lrmax, in_checkpointname=args.checkpoint, compand=args.compand)
+                target_type=args.target, lr_max=args.lrmax, in_checkpointname=args.checkpoint, compand=args.compand,
+                compute_dtype=args.dtype, device_feed=args.device_feed)
     if dist.is_initialized():
         dist.destroy_process_group()

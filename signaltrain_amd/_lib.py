@@ -12,10 +12,18 @@ LIB_PATH = os.path.join(_HERE, "libsignaltrain_hip.so")
 
 class st_dims(C.Structure):
     """Mirror of `struct st_dims` (include/signaltrain_hip.h)."""
-    _fields_ = [(n, C.c_int) for n in ("B", "L", "N", "H", "T", "OT", "F", "K", "y")]
+    _fields_ = [(n, C.c_int) for n in ("B", "L", "N", "H", "T", "OT", "F", "K", "y")] + \
+               [("prec", C.c_int), ("loss_scale", C.c_float), ("clip_all", C.c_int)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+    def with_arith(self, prec=None, loss_scale=None, clip_all=None):
+        d = st_dims(); C.memmove(C.byref(d), C.byref(self), C.sizeof(st_dims))
+        if prec is not None: d.prec = int(prec)
+        if loss_scale is not None: d.loss_scale = float(loss_scale)
+        if clip_all is not None: d.clip_all = int(bool(clip_all))
+        return d
 
     def with_batch(self, B):
         d = st_dims(); C.memmove(C.byref(d), C.byref(self), C.sizeof(st_dims)); d.B = int(B); return d
@@ -42,8 +50,6 @@ SIGNATURES = {
     "st_analysis_fwd": (_i, [_D, _p, _p, _p, _f, _p, _p, _p, _p, _p]),
     "st_ae_fwd": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "st_ae_fwd_ws_floats": (C.c_size_t, [_D]),
-    "st_set_precision": (_i, [C.c_int]),
-    "st_get_precision": (_i, []),
     "st_compressor_4c": (_i, [_p, _p, C.c_float, C.c_int, C.c_int, C.c_int, _p, _p]),
     "st_fe_frames": (_i, [C.c_int] * 4),
     "st_fe_ws_floats": (C.c_size_t, [C.c_int] * 6),
@@ -78,7 +84,19 @@ SIGNATURES = {
     "st_loss_backward_stage": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "st_train_step": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _p]),
     "st_dp_clip_adam": (_i, [_D, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _i, _p]),
+    "st_dp_unique_id": (_i, [_p]),
+    "st_dp_init": (_i, [_p, _i, _i, C.POINTER(_p)]),
+    "st_dp_destroy": (_i, [_p]),
+    "st_dp_rank": (_i, [_p]),
+    "st_dp_world": (_i, [_p]),
+    "st_dp_allreduce": (_i, [_p, _p, C.c_int64, _p]),
+    "st_dp_broadcast": (_i, [_p, _p, C.c_int64, _i, _p]),
+    "st_dp_sync": (_i, [_p, _p]),
+    "st_dp_train_step": (_i, [_p, _D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _i, _p]),
 }
+
+# st_dims.prec levels (include/signaltrain_hip.h ST_PREC_*) by the names the Python surface uses
+PREC = {"f32": 0, "bf16": 1, "bf16_all": 2, "f16": 3, "f16_all": 4}
 
 _lib = None
 
@@ -113,6 +131,22 @@ def ptr(t):
         return None
     assert t.is_contiguous(), "signaltrain_amd: tensor must be contiguous"
     return C.c_void_p(t.data_ptr())
+
+
+def on_arg_device(fn):
+    """Decorator for the static forward / backward of the autograd Functions: run with the device of the first tensor argument
+    current, so that torch.cuda.current_stream() inside is THAT device's stream and the library (which launches on the current
+    device) works for modules living on cuda:1 while cuda:0 is current."""
+    import functools
+    import torch
+
+    @functools.wraps(fn)
+    def wrapped(ctx, first, *rest):
+        if torch.is_tensor(first) and first.is_cuda:
+            with torch.cuda.device(first.device):
+                return fn(ctx, first, *rest)
+        return fn(ctx, first, *rest)
+    return wrapped
 
 
 def geometry(scale_factor=1, shrink_factor=4, num_knobs=4, batch=1, scale_scheme="lean"):

@@ -191,8 +191,9 @@ class Compressor_4c(Effect):
         hi = torch.as_tensor(self.knob_ranges[:, 1], dtype=torch.float32, device=x.device)
         kw = (lo + (knobs_nn.to(torch.float32) + 0.5) * (hi - lo)).contiguous()          # Effect.knobs_wc, audio.py:455
         y = torch.empty(B, y_size, dtype=torch.float32, device=x.device)
-        _lib.check(_lib.load().st_compressor_4c(_lib.ptr(x), _lib.ptr(kw), float(self.sr), B, L, y_size, _lib.ptr(y),
-                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "st_compressor_4c")
+        with torch.cuda.device(x.device):             # the library launches on the current device
+            _lib.check(_lib.load().st_compressor_4c(_lib.ptr(x), _lib.ptr(kw), float(self.sr), B, L, y_size, _lib.ptr(y),
+                                                    C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "st_compressor_4c")
         return y
 
 

@@ -40,6 +40,7 @@ class _Conv(nn.Module):
 
 class _AnalysisFn(torch.autograd.Function):
     @staticmethod
+    @_lib.on_arg_device
     def forward(ctx, wave, W, bias, hop, pad):
         lib = _lib.load()
         x = wave.contiguous().float(); B, L = x.shape
@@ -53,6 +54,7 @@ class _AnalysisFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_lib.on_arg_device
     def backward(ctx, g_out):
         lib = _lib.load()
         x, W = ctx.saved_tensors; hop, pad, has_bias = ctx.geom
@@ -68,6 +70,7 @@ class _AnalysisFn(torch.autograd.Function):
 
 class _SynthesisFn(torch.autograd.Function):
     @staticmethod
+    @_lib.on_arg_device
     def forward(ctx, x_ft, W, hop, crop):
         lib = _lib.load()
         xf = x_ft.contiguous().float(); B, T, Cn = xf.shape
@@ -82,6 +85,7 @@ class _SynthesisFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_lib.on_arg_device
     def backward(ctx, g_wave):
         lib = _lib.load()
         xf, W = ctx.saved_tensors; hop, crop = ctx.geom

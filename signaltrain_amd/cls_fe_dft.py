@@ -41,6 +41,7 @@ def _stream():
 
 class _AnalysisFn(torch.autograd.Function):
     @staticmethod
+    @_lib.on_arg_device
     def forward(ctx, wave, Wr, Wi, N, H):
         lib = _lib.load()
         B, L = wave.shape
@@ -55,8 +56,12 @@ class _AnalysisFn(torch.autograd.Function):
         return re, im
 
     @staticmethod
+    @_lib.on_arg_device
     def backward(ctx, g_re, g_im):
         lib = _lib.load()
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("signaltrain_amd.Analysis: the gradient w.r.t. the input waveform is not built (the model never "
+                                      "needs it: the waveform is data); detach the input, or use cls_fe_dct_bases.Analysis, whose backward returns it")
         (x,) = ctx.saved_tensors
         B, L, N, H, T = ctx.geom
         d = _relax(_dims(B, L, N, H, T, 1))
@@ -99,6 +104,7 @@ class Analysis(nn.Module):
 
 class _SynthesisFn(torch.autograd.Function):
     @staticmethod
+    @_lib.on_arg_device
     def forward(ctx, real, imag, Sr, Si, N, H):
         lib = _lib.load()
         B, OT, F = real.shape
@@ -116,6 +122,7 @@ class _SynthesisFn(torch.autograd.Function):
         return wave
 
     @staticmethod
+    @_lib.on_arg_device
     def backward(ctx, g_wave):
         lib = _lib.load()
         AA, Sfold = ctx.saved_tensors

@@ -150,18 +150,38 @@ __device__ __forceinline__ void stg32(float* __restrict__ base, const unsigned e
 // bf16-operand arithmetic of the forward kernels (st_set_precision(2)): weights and layer inputs rounded to bfloat16 (RNE),
 // one v_mfma_f32_16x16x16_bf16 per 16x16 tile (k = the 16 features 4g + r of a tile, i.e. a packed D-layout register set IS
 // the B operand) instead of four v_mfma_f32_16x16x4_f32; accumulation, bias, ELU and epilogue stay fp32.
+// BF template parameter of everything below: 0 = fp32 MFMA, 1 = bfloat16 operands, 2 = float16 operands (BASELINE configs[4];
+// IEEE conversion: out-of-range values become inf and the optimizer kernel skips the step, as under Apex amp).
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-#define ST_MFMA16B(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
-__device__ __forceinline__ s16x4 pack_bf16x4(const f32x4 v)
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+template <int BF>
+__device__ __forceinline__ f32x4 mfma16h(const s16x4 a, const s16x4 b, const f32x4 c)
 {
-    union { bf16x4_t h; s16x4 s; } p; p.h = __builtin_convertvector(v, bf16x4_t); return p.s;
+    if constexpr (BF == 2) {
+        union { s16x4 s; f16x4_t h; } pa, pb; pa.s = a; pb.s = b;
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(pa.h, pb.h, c, 0, 0, 0);
+    } else return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ float bf16_rne(const float v)
+#define ST_MFMA16B(a, b, c) mfma16h<BF>((a), (b), (c))
+template <int BF>
+__device__ __forceinline__ s16x4 pack_h4(f32x4 v)
 {
-    union { __bf16 h; unsigned short u; } p; p.h = (__bf16)v;
-    union { unsigned u; float f; } q; q.u = (unsigned)p.u << 16; return q.f;
+    if constexpr (BF == 2) {
+        union { f16x4_t h; s16x4 s; } p; p.h = __builtin_convertvector(v, f16x4_t); return p.s;
+    } else { union { bf16x4_t h; s16x4 s; } p; p.h = __builtin_convertvector(v, bf16x4_t); return p.s; }
 }
+#define pack_bf16x4(v) pack_h4<BF>(v)
+template <int BF>
+__device__ __forceinline__ float round_h(const float v)
+{
+    if constexpr (BF == 2) return (float)(_Float16)v;
+    else {
+        union { __bf16 h; unsigned short u; } p; p.h = (__bf16)v;
+        union { unsigned u; float f; } q; q.u = (unsigned)p.u << 16; return q.f;
+    }
+}
+#define bf16_rne(v) round_h<BF>(v)
 
 // One 16x16 tile of A operands (k-steps r = 0..3) from a forward image: W[o = 16 ot + c][i = 16 it + 4 g + r].
 template <int OUTP>
@@ -178,7 +198,7 @@ __device__ __forceinline__ f32x4 frag_dgrad(const float* img, const int ot, cons
 
 // Hidden layer for NC interleaved chains: hout[ch][ot] = ELU(W[ch] * hin[ch] + bias[ch]), weights fetched just in time
 // (the forward kernels run two waves per SIMD, which hides the LDS latency).
-template <int NC, int OTL, int ITL, int OUTP, bool BF = false>
+template <int NC, int OTL, int ITL, int OUTP, int BF = 0>
 __device__ __forceinline__ void layer_fwd(const float* const (&W)[NC], const float* const (&bias)[NC],
                                           const f32x4 (&hin)[NC][ITL], f32x4 (&hout)[NC][OTL], const int g, const int c)
 {
@@ -218,7 +238,7 @@ __device__ __forceinline__ void layer_fwd(const float* const (&W)[NC], const flo
 
 // Layer 5 of NC chains: [h4 ; knobs] -> 16 (nn_proc.py:92-96).  The knob block uses its own k-step order (step q: lane
 // group g carries knob 4q + g), so K <= 4 knobs cost one MFMA per chain instead of four.
-template <int NC, bool BF = false>
+template <int NC, int BF = 0>
 __device__ __forceinline__ void layer5_fwd(const float* const (&lw)[NC], const f32x4 (&h4)[NC][1], const float (&kn)[4], const int KQ,
                                            f32x4 (&h5)[NC][1], const int g, const int c)
 {
@@ -299,7 +319,7 @@ __device__ __forceinline__ void fwd_mask(FwdIn& in, const int K, const bool fv, 
 }
 
 // grid.x workgroups of NW waves; each wave walks 16-row groups: group id = b*(FP/16) + fg.  Requires T <= 32, OT <= 16, K <= 16.
-template <int NW, bool BF = false>      // BF: bf16 operands in the nine Linear layers (st_set_precision(2))
+template <int NW, int BF = 0>      // BF: bf16 operands in the nine Linear layers (st_set_precision(2))
 __global__ void __launch_bounds__(NW * 64)
 ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, const float* __restrict__ knobs,
               const float* __restrict__ ae_m, const float* __restrict__ ae_p, const AEOffsets go,
@@ -381,7 +401,7 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
 // column = b*FP + f); this kernel fuses layers 2..8 (64 -> 32 -> 16 -> 16 -> [+knobs] 16 -> 16 -> 32 -> 64) for both
 // autoencoders: H1 [64][R] -> H8 [64][R], activations in registers exactly as in ae_fwd_kernel.  A 16-column group never
 // straddles windows (FP % 16 == 0), so the knobs stay wave-uniform.  Pad columns (f >= F) are written as zeros.
-template <int NW, bool BF = false>
+template <int NW, int BF = 0>
 __global__ void __launch_bounds__(NW * 64)
 ae_inner_fwd_kernel(const float* __restrict__ H1m, const float* __restrict__ H1p, const float* __restrict__ knobs,
                     const float* __restrict__ ae_m, const float* __restrict__ ae_p, const AEOffsets go,
@@ -477,7 +497,7 @@ __device__ __forceinline__ void frags_dgrad(f32x4 (&fr)[ITL * OTL], const float*
 }
 #define ST_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <int OTL, int ITL, bool BF = false>
+template <int OTL, int ITL, int BF = 0>
 __device__ __forceinline__ void fwdD_fr(const f32x4 (&fr)[OTL * ITL], const float* bias, const f32x4 (&hin)[ITL],
                                         f32x4 (&hout)[OTL], const int g)
 {
@@ -516,7 +536,7 @@ __device__ __forceinline__ void to_T(float* scr, const f32x4 (&d)[TL], f32x4 (&t
         for (int r = 0; r < 4; ++r) t[k][r] = scr[k * 320 + (4 * g + r) * 20 + c];
 }
 
-template <int OTL, int ITL, bool BF = false>
+template <int OTL, int ITL, int BF = 0>
 __device__ __forceinline__ void dgradD_fr(const f32x4 (&fr)[ITL * OTL], const f32x4 (&da)[OTL], f32x4 (&dh)[ITL])
 {
     s16x4 pd[OTL];
@@ -550,7 +570,7 @@ __device__ __forceinline__ void mul_elu_grad(f32x4 (&d)[TL], const f32x4 (&h)[TL
 
 // dW_l tile(ot,it) += sum_rows daT[ot] (x) hT[it] (result in D layout: o = 16ot+4g+r, i = 16it+c); db_l (lane c <-> o = 16 ot + c)
 // accumulates the row sums of daT.  Tiles and sums persist in registers for the whole kernel.
-template <int OTL, int ITL, bool BF = false>
+template <int OTL, int ITL, int BF = 0>
 __device__ __forceinline__ void wgrad_reg(f32x4 (&dW)[OTL][ITL], float (&db)[OTL], const f32x4 (&daT)[OTL], const f32x4 (&hT)[ITL])
 {
     s16x4 pht[ITL];
@@ -607,7 +627,7 @@ __device__ __forceinline__ void db_flush(float* dst, float (&db)[OTL], const int
 constexpr int AE_BWD_SCR = (32 + 16 + 16) * SP + 2 * 4 * 320;      // per wave: V, Y, TAIL rows + two 4-tile transpose scratches (to_T)
 // LDS of the backward kernel (floats): images + per-wave scratch during the loop, four per-wave gradient images at the end
 constexpr int ae_bwd_lds_floats(int nw) { return (CL::BWD_TOTAL + nw * AE_BWD_SCR) > nw * CL::FWD_TOTAL ? (CL::BWD_TOTAL + nw * AE_BWD_SCR) : nw * CL::FWD_TOTAL; }
-template <int NW, bool TIMED, bool INNER = false, bool BF = false>      // BF: bf16 operands in all Linear-layer products (st_set_precision(2))
+template <int NW, bool TIMED, bool INNER = false, int BF = 0>      // BF: bf16 operands in all Linear-layer products (st_set_precision(2))
 __global__ void __launch_bounds__(NW * 64, 1)
 ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, const float* __restrict__ knobs,
               const float* __restrict__ ae_m, const float* __restrict__ ae_p, const AEOffsets go, const int PG,

@@ -5,11 +5,15 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <mutex>
+#include <set>
+#include <utility>
 #include "st_common.h"
 #include "st_gemm.h"
 #include "st_misc.h"
 #include "st_ae.h"
 #include "st_ae_wide.h"
+#include "st_dp.h"
 
 // ------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -103,6 +107,8 @@ static int check_dims(const st_dims* d)
     ST_REQ(d->y == (d->OT - 1) * d->H - d->N && d->y > 0 && d->y <= d->L, "y must equal (OT-1)*H-N");
     ST_REQ(d->OT <= d->T, "OT must be <= T");
     ST_REQ(d->K <= 16, "at most 16 knobs");
+    ST_REQ(d->prec >= ST_PREC_F32 && d->prec <= ST_PREC_F16_ALL, "st_dims.prec = %d is not an ST_PREC_* level", d->prec);
+    ST_REQ(d->loss_scale >= 0.f && d->loss_scale <= 3.0e38f, "st_dims.loss_scale must be 0 (none) or a positive finite scale");
     // the kernels address every operand with 32-bit element offsets from a wave-uniform base and index rows with 24-bit
     // multiplies: rows (B*T) < 2^24, the largest per-batch operands (B*T x KP spectra, B x (L + 2N) padded signals) < 2^30 elements
     ST_REQ((size_t)d->B * d->T < ((size_t)1 << 24) && (size_t)d->B * d->T * st_kp_of(d->F) < ((size_t)1 << 30) &&
@@ -174,21 +180,38 @@ extern "C" int st_set_tuning(int bk)
     if (bk >= 100) return g_wg_mode_set(bk - 100);           // 100 / 101: weight-gradient tile mode (diagnostics)
     if (bk != 16 && bk != 32) return st_fail(ST_ERR_ARG, "bk must be 16 or 32"); g_bk = bk; g_an_bk = bk; return ST_OK;
 }
-// g_prec: arithmetic of the STFT GEMMs -- 0 = fp32 MFMA (default, the parity path), 1 = bf16 operands / fp32 accumulation
-static int g_prec = 0;      // 2: bf16 operands also in the forward autoencoder kernel
-extern "C" int st_set_precision(int level) { g_prec = level < 0 ? 0 : (level > 2 ? 2 : level); return ST_OK; }
-extern "C" int st_get_precision(void) { return g_prec; }
-#define ST_GEMM(W_, ...) do { if (g_prec >= 1) stg::launch_bf16<W_>(__VA_ARGS__); \
-                              else if (g_bk == 16) stg::launch<W_, 16>(__VA_ARGS__, g_dbg); else stg::launch<W_, 32>(__VA_ARGS__, g_dbg); } while (0)
+// Arithmetic of a call = st_dims::prec (ST_PREC_*; round 1 had a process-wide switch here, which raced between engines):
+// half type (0 none / 1 bfloat16 / 2 float16) of the STFT GEMM operands and of the autoencoder layers.
+static inline int gemm_ht(int prec) { return (prec == ST_PREC_BF16 || prec == ST_PREC_BF16_ALL) ? 1 : ((prec == ST_PREC_F16 || prec == ST_PREC_F16_ALL) ? 2 : 0); }
+static inline int ae_ht(int prec) { return prec == ST_PREC_BF16_ALL ? 1 : (prec == ST_PREC_F16_ALL ? 2 : 0); }
+static inline float loss_scale_of(const st_dims* d) { return d->loss_scale > 0.f ? d->loss_scale : 1.0f; }
+// every ST_GEMM* user has `d` (const st_dims*) in scope
+#define ST_GEMM_BK(BK_, W_, ...) do { const int ht_ = gemm_ht(d->prec); \
+                              if (ht_ == 1) stg::launch_half<W_, 1>(__VA_ARGS__); else if (ht_ == 2) stg::launch_half<W_, 2>(__VA_ARGS__); \
+                              else if ((BK_) == 16) stg::launch<W_, 16>(__VA_ARGS__, g_dbg); else stg::launch<W_, 32>(__VA_ARGS__, g_dbg); } while (0)
+#define ST_GEMM(W_, ...) ST_GEMM_BK(g_bk, W_, __VA_ARGS__)
 // the analysis forward GEMM (K = N = 1024, two 4-wave workgroups per CU either way) runs 5 % faster with 32-deep k-tiles
 // (half the barriers); every other GEMM of the step is faster with 16 (more workgroups per CU)
-#define ST_GEMM_AN(W_, ...) do { if (g_prec >= 1) stg::launch_bf16<W_>(__VA_ARGS__); \
-                                 else if (g_an_bk == 16) stg::launch<W_, 16>(__VA_ARGS__, g_dbg); else stg::launch<W_, 32>(__VA_ARGS__, g_dbg); } while (0)
+#define ST_GEMM_AN(W_, ...) ST_GEMM_BK(g_an_bk, W_, __VA_ARGS__)
 // weight-gradient GEMMs: g_wg_mode 0 = three waves share a 96x96 tile (32x96 strips), 1 = one wave per 96x96 tile
 static int g_wg_mode = 0;
 static int g_wg_mode_set(int v) { g_wg_mode = v; return ST_OK; }
-#define ST_GEMM_WG(...) do { if (g_wg_mode == 1 && g_prec == 0) stg::launch<1, 16, 3>(__VA_ARGS__, g_dbg); \
-                             else if (g_wg_mode == 2 && g_prec == 0) stg::launch<3, 16, 1, true>(__VA_ARGS__, g_dbg); else ST_GEMM(3, __VA_ARGS__); } while (0)
+#define ST_GEMM_WG(...) do { if (g_wg_mode == 1 && gemm_ht(d->prec) == 0) stg::launch<1, 16, 3>(__VA_ARGS__, g_dbg); \
+                             else if (g_wg_mode == 2 && gemm_ht(d->prec) == 0) stg::launch<3, 16, 1, true>(__VA_ARGS__, g_dbg); else ST_GEMM(3, __VA_ARGS__); } while (0)
+// Kernels with > 64 KB of dynamic LDS need the attribute once per (device, kernel); the result is checked (round 1 discarded
+// it behind non-atomic flags: a failure surfaced later as an opaque launch error).
+static int ensure_dyn_lds(const void* fn, const char* name)
+{
+    static std::mutex mu; static std::set<std::pair<int, const void*>> done;
+    int dev = 0; (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({dev, fn})) return ST_OK;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return st_fail(ST_ERR_LAUNCH, "hipFuncSetAttribute(%s, 160 KB dynamic LDS): %s", name, hipGetErrorString(e));
+    done.insert({dev, fn});
+    return ST_OK;
+}
+#define ST_DYN_LDS(kernel_) ST_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&kernel_), #kernel_))
 static const int AE_FWD_NW = 8, AE_BWD_NW = 4;
 static int synth_live_rows(const st_dims* d);
 static int ae_fwd_grid(const st_dims* d) { int g = (d->B * (st_kp_of(d->F) / 32) + AE_FWD_NW - 1) / AE_FWD_NW; int c = num_cus(); return g < c ? g : c; }
@@ -316,22 +339,13 @@ extern "C" int st_ae_fwd(const st_dims* d, const float* mag, const float* phs, c
     ST_REQ((size_t)d->B * d->T * d->F < ((size_t)1 << 30) && (size_t)d->B * d->OT * L.KP < ((size_t)1 << 30),
            "st_ae_fwd: batch too large for the kernel's 32-bit element offsets (B=%d)", d->B);
     const size_t lds = (size_t)2 * sta::CL::FWD_TOTAL * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_fwd_kernel<AE_FWD_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
     const float expfac = (float)(7.0 / d->F);
-    if (g_prec == 2) {
-        static bool battr = false;
-        if (!battr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_fwd_kernel<AE_FWD_NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); battr = true; }
-        hipLaunchKernelGGL((sta::ae_fwd_kernel<AE_FWD_NW, true>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, st_stream(stream),
-                           mag, phs, knobs, ae_m, ae_p, L.go, mag_hat, phs_hat, AA, reg_partial,
-                           d->B, d->T, d->OT, d->F, d->K, L.KP, expfac);
-    } else
-    hipLaunchKernelGGL((sta::ae_fwd_kernel<AE_FWD_NW>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, st_stream(stream),
-                       mag, phs, knobs, ae_m, ae_p, L.go, mag_hat, phs_hat, AA, reg_partial,
-                       d->B, d->T, d->OT, d->F, d->K, L.KP, expfac);
+#define ST_AE_FWD_LAUNCH(HT_) do { ST_DYN_LDS((sta::ae_fwd_kernel<AE_FWD_NW, HT_>)); \
+        hipLaunchKernelGGL((sta::ae_fwd_kernel<AE_FWD_NW, HT_>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, st_stream(stream), \
+                           mag, phs, knobs, ae_m, ae_p, L.go, mag_hat, phs_hat, AA, reg_partial, \
+                           d->B, d->T, d->OT, d->F, d->K, L.KP, expfac); } while (0)
+    switch (ae_ht(d->prec)) { case 1: ST_AE_FWD_LAUNCH(1); break; case 2: ST_AE_FWD_LAUNCH(2); break; default: ST_AE_FWD_LAUNCH(0); }
+#undef ST_AE_FWD_LAUNCH
     ST_LAUNCHED("ae_fwd"); return ST_OK;
 }
 
@@ -364,7 +378,7 @@ extern "C" int st_synthesis_frames(const st_dims* d, const float* AA, const floa
 static int ola_loss_impl(const st_dims* d, const float* frs, const float* x, const float* y_true,
                          float* y_hat, float* dsyn, int dsyn_pad, float* loss_partial, void* stream)
 {
-    const float inv = 1.0f / ((float)d->B * (float)d->y);
+    const float inv = loss_scale_of(d) / ((float)d->B * (float)d->y);     // d loss / d y_hat, times the loss scale (train.py:134-135)
     hipLaunchKernelGGL(stm::ola_loss_kernel, dim3((d->y + 255) / 256, d->B), dim3(256), 0, st_stream(stream),
                        frs, x, y_true, y_hat, dsyn, loss_partial, d->L, d->N, d->H, d->OT, d->y, inv,
                        st_synth_frame_slabs(d), (size_t)d->B * d->OT * d->N, dsyn_pad);
@@ -432,16 +446,18 @@ extern "C" int st_synthesis_wgrad(const st_dims* d, const float* AA, const float
 
 // ------------------------------------------------------------------------------ wide-geometry autoencoders (st_ae_wide.h)
 // BM = 64, k-tile 16 (every K below is a multiple of 16 or checked).  Level-2 precision: the bf16 kernel (k-tile 32: W1 is
-// padded to a multiple of 32 columns and K = R operands need R % 32 == 0, else the whole wide path stays fp32 -- g_wide_bf)
-static bool g_wide_bf = false;
-#define ST_WGEMM(...) do { if (g_wide_bf) stg::launch_bf16<2>(__VA_ARGS__); else stg::launch<2, 16>(__VA_ARGS__, g_dbg); } while (0)
+// padded to a multiple of 32 columns and K = R operands need R % 32 == 0, else the whole wide path stays fp32 -- wide_ht,
+// a local of every user of ST_WGEMM: 0 fp32 / 1 bf16 / 2 fp16)
+static inline int wide_half_type(const st_dims* d, int R) { return R % 32 == 0 ? ae_ht(d->prec) : 0; }
+#define ST_WGEMM(...) do { if (wide_ht == 1) stg::launch_half<2, 1>(__VA_ARGS__); else if (wide_ht == 2) stg::launch_half<2, 2>(__VA_ARGS__); \
+                           else stg::launch<2, 16>(__VA_ARGS__, g_dbg); } while (0)
 static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, const float* phs, const float* knobs,
                        const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA, float* reg_partial,
                        WideWS& w, void* stream)
 {
     hipStream_t s = st_stream(stream);
     const int FP = L.KP / 2, F = d->F, T = d->T, OT = d->OT, R = (int)w.R, Tp = w.Tp;
-    g_wide_bf = g_prec == 2 && R % 32 == 0;
+    const int wide_ht = wide_half_type(d, R);
     ST_REQ(w.R * (size_t)(T > 64 ? T : 64) < ((size_t)1 << 30), "wide autoencoder path: batch too large (B=%d)", d->B);
     const stg::RowMap id = stg::all_frames(1);
     int out[9], in[9]; ae_shapes(d, out, in);
@@ -468,18 +484,11 @@ static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, cons
     }
     if (g_wide_fused) {
         const size_t lds = (size_t)2 * sta::CL::FWD_TOTAL * sizeof(float);
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_inner_fwd_kernel<AE_FWD_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_inner_fwd_kernel<AE_FWD_NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr = true;
-        }
-        if (g_wide_bf)
-            hipLaunchKernelGGL((sta::ae_inner_fwd_kernel<AE_FWD_NW, true>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, s,
-                               w.H[0][0], w.H[1][0], knobs, ae_m, ae_p, L.go, w.H[0][7], w.H[1][7], d->B, F, d->K, L.KP);
-        else
-        hipLaunchKernelGGL((sta::ae_inner_fwd_kernel<AE_FWD_NW>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, s,
-                           w.H[0][0], w.H[1][0], knobs, ae_m, ae_p, L.go, w.H[0][7], w.H[1][7], d->B, F, d->K, L.KP);
+#define ST_AE_INNER_FWD(HT_) do { ST_DYN_LDS((sta::ae_inner_fwd_kernel<AE_FWD_NW, HT_>)); \
+            hipLaunchKernelGGL((sta::ae_inner_fwd_kernel<AE_FWD_NW, HT_>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, s, \
+                               w.H[0][0], w.H[1][0], knobs, ae_m, ae_p, L.go, w.H[0][7], w.H[1][7], d->B, F, d->K, L.KP); } while (0)
+        switch (wide_ht) { case 1: ST_AE_INNER_FWD(1); break; case 2: ST_AE_INNER_FWD(2); break; default: ST_AE_INNER_FWD(0); }
+#undef ST_AE_INNER_FWD
     }
     for (int a = 0; a < 2; ++a) {
         const float* ae = a ? ae_p : ae_m;
@@ -499,7 +508,7 @@ static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, cons
 }
 
 // one weight-gradient GEMM of the wide path: dW_l (+ bias via the ones row) as split-K slabs of net a
-static void wide_wgrad(const st_dims* d, WideWS& w, int a, int l, const int* out, const int* in, hipStream_t s)
+static void wide_wgrad(const st_dims* d, WideWS& w, int a, int l, const int* out, const int* in, hipStream_t s, const int wide_ht)
 {
     const int R = (int)w.R;
     const stg::RowMap id = stg::all_frames(1);
@@ -517,7 +526,7 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
 {
     hipStream_t s = st_stream(stream);
     const int FP = L.KP / 2, F = d->F, T = d->T, OT = d->OT, R = (int)w.R, Tp = w.Tp;
-    g_wide_bf = g_prec == 2 && R % 32 == 0;
+    const int wide_ht = wide_half_type(d, R);
     const stg::RowMap id = stg::all_frames(1);
     int out[9], in[9]; ae_shapes(d, out, in);
     // forward state (activations + ELU outputs of layer 9): recomputed into the workspace unless the fused step's own
@@ -558,37 +567,28 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
     tab.so[9] = w.so[9];
     if (g_wide_fused) {
         // layer 9 as GEMMs, layers 8..2 in one fused kernel (both nets), layer 1 as GEMMs
-        for (int a = 0; a < 2; ++a) { wide_wgrad(d, w, a, 8, out, in, s); dgrad(a, 8, true); }
+        for (int a = 0; a < 2; ++a) { wide_wgrad(d, w, a, 8, out, in, s, wide_ht); dgrad(a, 8, true); }
         {
             const size_t lds = (size_t)sta::ae_bwd_lds_floats(AE_BWD_NW) * sizeof(float);
-            static bool attr = false;
-            if (!attr) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr = true;
-            }
             const int grid = ae_bwd_grid(d);
-            if (g_wide_bf)
-                hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, false, true, true>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, s,
-                                   (const float*)w.H[0][0], (const float*)w.H[1][0], knobs, ae_m, ae_p, L.go, L.PG,
-                                   (const float*)w.DA[0][7], (const float*)w.DA[1][7], (const float*)nullptr, (const float*)nullptr, 0.f, 0.f,
-                                   w.DA[0][0], w.DA[1][0], w.inner_ws, d->B, T, OT, F, d->K, L.KP, 0, 0, 1, (size_t)0, 0);
-            else
-            hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, false, true>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, s,
-                               (const float*)w.H[0][0], (const float*)w.H[1][0], knobs, ae_m, ae_p, L.go, L.PG,
-                               (const float*)w.DA[0][7], (const float*)w.DA[1][7], (const float*)nullptr, (const float*)nullptr, 0.f, 0.f,
-                               w.DA[0][0], w.DA[1][0], w.inner_ws, d->B, T, OT, F, d->K, L.KP, 0, 0, 1, (size_t)0, 0);
+#define ST_AE_INNER_BWD(HT_) do { ST_DYN_LDS((sta::ae_bwd_kernel<AE_BWD_NW, false, true, HT_>)); \
+                hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, false, true, HT_>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, s, \
+                                   (const float*)w.H[0][0], (const float*)w.H[1][0], knobs, ae_m, ae_p, L.go, L.PG, \
+                                   (const float*)w.DA[0][7], (const float*)w.DA[1][7], (const float*)nullptr, (const float*)nullptr, 0.f, 0.f, \
+                                   w.DA[0][0], w.DA[1][0], w.inner_ws, d->B, T, OT, F, d->K, L.KP, 0, 0, 1, (size_t)0, 0); } while (0)
+            switch (wide_ht) { case 1: ST_AE_INNER_BWD(1); break; case 2: ST_AE_INNER_BWD(2); break; default: ST_AE_INNER_BWD(0); }
+#undef ST_AE_INNER_BWD
             hipLaunchKernelGGL(stm::ae_grad_reduce_kernel, dim3((L.PG + 63) / 64, 2), dim3(256), 0, s, w.inner_ws, grid, L.PG, g_m, g_p);
         }
         for (int l = 1; l < 8; ++l) tab.out[l] = 0;                 // the finish kernel only scatters layers 1 and 9
         for (int a = 0; a < 2; ++a) {
-            wide_wgrad(d, w, a, 0, out, in, s); dgrad(a, 0, false);
+            wide_wgrad(d, w, a, 0, out, in, s, wide_ht); dgrad(a, 0, false);
             hipLaunchKernelGGL(stw::wide_grad_finish_kernel, dim3((w.so[9] + 255) / 256), dim3(256), 0, s,
                                w.slabs + (size_t)a * w.nsplit * w.SL, w.nsplit, w.SL, tab, a ? g_p : g_m);
         }
     } else {
         for (int a = 0; a < 2; ++a) {
-            for (int l = 8; l >= 0; --l) { wide_wgrad(d, w, a, l, out, in, s); dgrad(a, l, false); }
+            for (int l = 8; l >= 0; --l) { wide_wgrad(d, w, a, l, out, in, s, wide_ht); dgrad(a, l, false); }
             hipLaunchKernelGGL(stw::wide_grad_finish_kernel, dim3((w.so[9] + 255) / 256), dim3(256), 0, s,
                                w.slabs + (size_t)a * w.nsplit * w.SL, w.nsplit, w.SL, tab, a ? g_p : g_m);
         }
@@ -613,27 +613,15 @@ static int ae_bwd_impl(const st_dims* d, const float* mag, const float* phs, con
     static_assert((size_t)sta::ae_bwd_lds_floats(AE_BWD_NW) * sizeof(float) <= 160 * 1024, "ae_bwd LDS budget");
     ST_REQ((size_t)st_synth_slabs(d) * d->B * d->OT * L.KP < ((size_t)1 << 30) && (size_t)d->B * d->T * L.KP < ((size_t)1 << 30),
            "st_ae_bwd: batch too large for the kernel's 32-bit element offsets (B=%d)", d->B);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
     const float expfac = (float)(7.0 / d->F);
     const int grid = ae_bwd_grid(d);
-#define ST_AE_BWD_LAUNCH(TIMED_) \
-    hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, TIMED_>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, st_stream(stream), \
+    const stg::RowMap live = synth_live(d);
+#define ST_AE_BWD_LAUNCH(TIMED_, HT_) do { ST_DYN_LDS((sta::ae_bwd_kernel<AE_BWD_NW, TIMED_, false, HT_>)); \
+    hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, TIMED_, false, HT_>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, st_stream(stream), \
                        mag, phs, knobs, ae_m, ae_p, L.go, L.PG, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, expfac, \
-                       dmag, dphs, ws, d->B, d->T, d->OT, d->F, d->K, L.KP, synth_live(d).t_lo, synth_live(d).t_lo + synth_live(d).Tv - 1, st_synth_slabs(d), (size_t)d->B * d->OT * L.KP, g_dbg)
-    if (g_dbg & 256) ST_AE_BWD_LAUNCH(true);      // stage-timer build (tools/ae_stage_times.py)
-    else if (g_prec == 2) {
-        static bool battr = false;
-        if (!battr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sta::ae_bwd_kernel<AE_BWD_NW, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); battr = true; }
-        hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, false, false, true>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, st_stream(stream),
-                           mag, phs, knobs, ae_m, ae_p, L.go, L.PG, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, expfac,
-                           dmag, dphs, ws, d->B, d->T, d->OT, d->F, d->K, L.KP, synth_live(d).t_lo, synth_live(d).t_lo + synth_live(d).Tv - 1, st_synth_slabs(d), (size_t)d->B * d->OT * L.KP, g_dbg);
-    }
-    else ST_AE_BWD_LAUNCH(false);
+                       dmag, dphs, ws, d->B, d->T, d->OT, d->F, d->K, L.KP, live.t_lo, live.t_lo + live.Tv - 1, st_synth_slabs(d), (size_t)d->B * d->OT * L.KP, g_dbg); } while (0)
+    if (g_dbg & 256) ST_AE_BWD_LAUNCH(true, 0);      // stage-timer build (tools/ae_stage_times.py)
+    else switch (ae_ht(d->prec)) { case 1: ST_AE_BWD_LAUNCH(false, 1); break; case 2: ST_AE_BWD_LAUNCH(false, 2); break; default: ST_AE_BWD_LAUNCH(false, 0); }
 #undef ST_AE_BWD_LAUNCH
     ST_LAUNCHED("ae_bwd");
     hipLaunchKernelGGL(stm::ae_grad_reduce_kernel, dim3((L.PG + 63) / 64, 2), dim3(256), 0, st_stream(stream),
@@ -654,7 +642,7 @@ extern "C" int st_polar_bwd(const st_dims* d, const float* re, const float* im, 
     ST_TRY(check_dims(d)); ST_REQ(re && im && dmag && dphs && dG, "st_polar_bwd: null pointer");
     const int R = d->B * d->T, KP = st_kp_of(d->F);
     hipLaunchKernelGGL(stm::polar_bwd_kernel, dim3((KP / 2 + 255) / 256, R), dim3(256), 0, st_stream(stream),
-                       re, im, dmag, dphs, g_mag, dG, R, d->F, KP);
+                       re, im, dmag, dphs, g_mag, dG, R, d->F, KP, gemm_ht(d->prec) == 2 ? 65504.0f : 0.0f);
     ST_LAUNCHED("polar_bwd"); return ST_OK;
 }
 
@@ -705,7 +693,7 @@ extern "C" int st_finalize_scalars(const st_dims* d, const float* loss_partial, 
     const float inv_y = 1.0f / ((float)d->B * (float)d->y);
     const float reg_scale = (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);   // loss_functions.py:36
     const stm::FinArgs f{loss_partial, st_ola_loss_partials(d), reg_partial, st_ae_fwd_partials(d),
-                         norm_a, st_norm_partials(d), norm_s, st_norm_partials(d), inv_y, reg_scale, inv_world};
+                         norm_a, st_norm_partials(d), norm_s, st_norm_partials(d), inv_y, reg_scale, inv_world, nullptr, 0};
     hipLaunchKernelGGL(stm::finalize_kernel, dim3(1), dim3(256), 0, st_stream(stream), f, scalars);
     ST_LAUNCHED("finalize_scalars"); return ST_OK;
 }
@@ -714,12 +702,12 @@ static stm::FinArgs fin_args(const st_dims* d, const float* loss_partial, const 
     const float inv_y = 1.0f / ((float)d->B * (float)d->y);
     const float reg_scale = (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);   // loss_functions.py:36
     return stm::FinArgs{loss_partial, st_ola_loss_partials(d), reg_partial, st_ae_fwd_partials(d),
-                        norm_a, st_norm_partials(d), norm_s, norm_s ? st_norm_partials(d) : 0, inv_y, reg_scale, norm_scale};
+                        norm_a, st_norm_partials(d), norm_s, norm_s ? st_norm_partials(d) : 0, inv_y, reg_scale, norm_scale, nullptr, 0};
 }
 
 // fin != nullptr: the clip coefficient (and, if fin->loss_partial, the loss scalars) are derived inside the kernel from
 // the partial sums -- no separate finalize launch; `scalars` is then an output.
-static int clip_adam_impl(float* params, float* grads, float* m, float* v, int64_t n_total, int64_t n_stft,
+static int clip_adam_impl(float* params, float* grads, float* m, float* v, int64_t n_total, int64_t n_stft /* clipped range */,
                           float* scalars, float grad_scale, float lr, float beta1, float beta2, float eps, int step,
                           const stm::FinArgs* fin, void* stream)
 {
@@ -754,9 +742,10 @@ extern "C" int st_debug_read_stage_cycles(unsigned long long* out32)
 }
 
 // ------------------------------------------------------------------------------ workspace
+static const int NORM_E_PARTIALS = 32;     // |g| partials of the autoencoder gradient range (st_dims.clip_all)
 struct WS {
     float *re, *im, *mag, *phs, *mag_hat, *phs_hat, *AA, *dAA, *Sfold, *frs, *y_hat, *dsyn, *dmag, *dphs, *dG, *xp;
-    float *wg, *aews, *loss_p, *reg_p, *norm_a, *norm_s;
+    float *wg, *aews, *loss_p, *reg_p, *norm_a, *norm_s, *norm_e;
     size_t bytes;
 };
 static void carve(const st_dims* d, void* base, WS* w)
@@ -774,7 +763,7 @@ static void carve(const st_dims* d, void* base, WS* w)
     w->dmag = take(RT * F); w->dphs = take(RT * F); w->dG = take(RT * KP);
     w->wg = take(st_wgrad_ws_floats(d)); w->aews = take(st_ae_bwd_ws_floats(d));
     w->loss_p = take(st_ola_loss_partials(d)); w->reg_p = take(st_ae_fwd_partials(d));
-    w->norm_a = take(st_norm_partials(d)); w->norm_s = take(st_norm_partials(d));
+    w->norm_a = take(st_norm_partials(d)); w->norm_s = take(st_norm_partials(d)); w->norm_e = take(NORM_E_PARTIALS);
     w->bytes = off * sizeof(float);
 }
 extern "C" size_t st_workspace_bytes(const st_dims* d)
@@ -866,9 +855,10 @@ extern "C" int st_loss_backward(const st_dims* d, const float* params, float* gr
     WS w; carve(d, ws, &w);
     prof_mark("begin", stream);
     ST_TRY(forward_impl(d, L, params, x, knobs, y_true, y_hat, mag, mag_hat, w, true, stream));
-    const float reg_coef = (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);   // loss_functions.py:36
+    const float reg_coef = loss_scale_of(d) * (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);   // loss_functions.py:36
     ST_TRY(backward_impl(d, L, params, grads, x, knobs, nullptr, nullptr, reg_coef, w, stream));
-    ST_TRY(st_finalize_scalars(d, w.loss_p, w.reg_p, w.norm_a, w.norm_s, 1.0f, scalars, stream));
+    // grads carry the loss scale (if any); the published norm is that of the unscaled gradient
+    ST_TRY(st_finalize_scalars(d, w.loss_p, w.reg_p, w.norm_a, w.norm_s, 1.0f / loss_scale_of(d), scalars, stream));
     return ST_OK;
 }
 
@@ -882,7 +872,7 @@ extern "C" int st_loss_backward_p1(const st_dims* d, const float* params, float*
     WS w; carve(d, ws, &w);
     prof_mark("begin", stream);
     ST_TRY(forward_impl(d, L, params, x, knobs, y_true, nullptr, nullptr, nullptr, w, true, stream));
-    const float reg_coef = (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);
+    const float reg_coef = loss_scale_of(d) * (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);
     return backward_p1(d, L, params, grads, knobs, nullptr, nullptr, reg_coef, w, stream);
 }
 extern "C" int st_loss_backward_p2(const st_dims* d, float* grads, const float* x, void* ws, float* scalars, void* stream)
@@ -891,7 +881,7 @@ extern "C" int st_loss_backward_p2(const st_dims* d, float* grads, const float* 
     ST_REQ(grads && x && ws && scalars, "st_loss_backward_p2: null pointer");
     WS w; carve(d, ws, &w);
     ST_TRY(backward_p2(d, L, grads, x, w, stream));
-    return st_finalize_scalars(d, w.loss_p, w.reg_p, w.norm_a, w.norm_s, 1.0f, scalars, stream);
+    return st_finalize_scalars(d, w.loss_p, w.reg_p, w.norm_a, w.norm_s, 1.0f / loss_scale_of(d), scalars, stream);
 }
 
 // As st_loss_backward_p2, and the 2F live rows of the two analysis gradients are ALSO written packed into `stage` [2F][N]:
@@ -929,7 +919,7 @@ extern "C" int st_loss_backward_stage(const st_dims* d, const float* params, flo
     ST_REQ(params && grads && x && knobs && y_true && ws && scalars, "st_loss_backward_stage: null pointer");
     ST_REQ(stage >= 0 && stage < 4, "st_loss_backward_stage: stage %d not in 0..3", stage);
     WS w; carve(d, ws, &w);
-    const float reg_coef = (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);
+    const float reg_coef = loss_scale_of(d) * (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);
     switch (stage) {
     case 0:
         prof_mark("begin", stream);
@@ -941,7 +931,7 @@ extern "C" int st_loss_backward_stage(const st_dims* d, const float* params, flo
         return analysis_wgrad_impl(d, w.dG, w.xp, true, 1.0f, w.wg, grads + L.offs[0], grads + L.offs[1], w.norm_a, stream, 0);
     default:
         ST_TRY(analysis_wgrad_impl(d, w.dG, w.xp, true, 1.0f, w.wg, grads + L.offs[0], grads + L.offs[1], w.norm_a, stream, 1));
-        return st_finalize_scalars(d, w.loss_p, w.reg_p, w.norm_a, w.norm_s, 1.0f, scalars, stream);
+        return st_finalize_scalars(d, w.loss_p, w.reg_p, w.norm_a, w.norm_s, 1.0f / loss_scale_of(d), scalars, stream);
     }
 }
 
@@ -954,11 +944,18 @@ extern "C" int st_train_step(const st_dims* d, float* params, float* grads, floa
     WS w; carve(d, ws, &w);
     prof_mark("begin", stream);
     ST_TRY(forward_impl(d, L, params, x, knobs, y_true, nullptr, nullptr, nullptr, w, true, stream));
-    const float reg_coef = (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);   // loss_functions.py:36
+    const float reg_coef = loss_scale_of(d) * (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);   // loss_functions.py:36
     ST_TRY(backward_impl(d, L, params, grads, x, knobs, nullptr, nullptr, reg_coef, w, stream));
     // loss scalars + clip coefficient inside the optimizer kernel (st_loss_backward + st_clip_adam minus one launch)
-    const stm::FinArgs f = fin_args(d, w.loss_p, w.reg_p, w.norm_a, w.norm_s, 1.0f);
-    return clip_adam_impl(params, grads, m, v, L.total, L.n_stft, scalars, 1.0f, lr, beta1, beta2, eps, step, &f, stream);
+    const float inv_s = 1.0f / loss_scale_of(d);            // the gradients carry the loss scale: unscale inside the optimizer
+    stm::FinArgs f = fin_args(d, w.loss_p, w.reg_p, w.norm_a, w.norm_s, inv_s);
+    if (d->clip_all) {                                       // train.py:136: the norm runs over every parameter
+        hipLaunchKernelGGL(stm::l1_partial_kernel, dim3(NORM_E_PARTIALS), dim3(256), 0, st_stream(stream),
+                           grads + L.n_stft, L.total - L.n_stft, 1.0f, w.norm_e);
+        ST_LAUNCHED("l1_partial_ae");
+        f.norm_e = w.norm_e; f.n_ne = NORM_E_PARTIALS;
+    }
+    return clip_adam_impl(params, grads, m, v, L.total, d->clip_all ? L.total : L.n_stft, scalars, inv_s, lr, beta1, beta2, eps, step, &f, stream);
 }
 
 extern "C" int st_dp_clip_adam(const st_dims* d, float* params, float* grads, float* m, float* v, void* ws,
@@ -970,12 +967,14 @@ extern "C" int st_dp_clip_adam(const st_dims* d, float* params, float* grads, fl
     WS w; carve(d, ws, &w);
     // L1 norm of the all-reduced, 1/world-scaled STFT gradient: identical on every rank, no second collective
     const int np = st_norm_partials(d);
+    const int64_t n_clip = d->clip_all ? L.total : L.n_stft;
+    const float gs = grad_scale / loss_scale_of(d);          // 1/world and the loss scale leave the gradient together
     hipLaunchKernelGGL(stm::l1_partial_kernel, dim3(np), dim3(256), 0, st_stream(stream),
-                       grads, L.n_stft, grad_scale, w.norm_a);
+                       grads, n_clip, gs, w.norm_a);
     ST_LAUNCHED("l1_partial");
     stm::FinArgs f = fin_args(d, w.loss_p, w.reg_p, w.norm_a, nullptr, 1.0f);     // this rank's loss terms + the norm of the REDUCED gradient (l1 partials above)
     f.n_na = np;
-    return clip_adam_impl(params, grads, m, v, L.total, L.n_stft, scalars, grad_scale, lr, beta1, beta2, eps, step, &f, stream);
+    return clip_adam_impl(params, grads, m, v, L.total, n_clip, scalars, gs, lr, beta1, beta2, eps, step, &f, stream);
 }
 
 // ------------------------------------------------------------------------------ device-side data feed
@@ -1085,4 +1084,99 @@ extern "C" int st_fe_synthesis_bwd(const float* xft, int B, int T, const float* 
         hipLaunchKernelGGL(stm::sum_slabs_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st_stream(stream), slabs, ns, n, gW);
     }
     ST_LAUNCHED("fe_synthesis_bwd"); return ST_OK;
+}
+
+// ------------------------------------------------------------------------------ data parallel (st_dp.h): RCCL inside the library
+extern "C" int st_dp_unique_id(void* id128)
+{
+    ST_REQ(id128, "st_dp_unique_id: null buffer");
+    st_dp tmp; memset(&tmp, 0, sizeof(tmp));
+    ST_TRY(stdp::bind(&tmp));
+    ncclUniqueId id;
+    ST_NCCL(&tmp, tmp.GetUniqueId(&id), "ncclGetUniqueId");
+    static_assert(sizeof(id) == 128, "RCCL unique id is 128 bytes");
+    memcpy(id128, &id, sizeof(id));
+    return ST_OK;
+}
+
+extern "C" int st_dp_init(const void* id128, int rank, int world, st_dp** out)
+{
+    ST_REQ(id128 && out && world >= 1 && rank >= 0 && rank < world, "st_dp_init: bad arguments (rank %d of %d)", rank, world);
+    st_dp* p = new st_dp; memset(p, 0, sizeof(*p));
+    int rc = stdp::bind(p);
+    if (rc != ST_OK) { delete p; return rc; }
+    ncclUniqueId id; memcpy(&id, id128, sizeof(id));
+    p->rank = rank; p->world = world;
+    const ncclResult_t r = p->CommInitRank(&p->comm, world, id, rank);       // collective over all ranks: every rank must call this
+    if (r != ncclSuccess) { rc = st_fail(ST_ERR_LAUNCH, "st_dp ncclCommInitRank(rank %d of %d): %s", rank, world, p->GetErrorString(r)); delete p; return rc; }
+    hipError_t e = hipStreamCreateWithFlags(&p->cs, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ready[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->done, hipEventDisableTiming);
+    if (e != hipSuccess) { rc = st_fail(ST_ERR_LAUNCH, "st_dp_init: stream/event creation: %s", hipGetErrorString(e)); (void)p->CommDestroy(p->comm); delete p; return rc; }
+    *out = p;
+    return ST_OK;
+}
+
+extern "C" int st_dp_destroy(st_dp* p)
+{
+    if (!p) return ST_OK;
+    (void)hipStreamSynchronize(p->cs);
+    if (p->comm) (void)p->CommDestroy(p->comm);
+    for (int i = 0; i < 4; ++i) if (p->ready[i]) (void)hipEventDestroy(p->ready[i]);
+    if (p->done) (void)hipEventDestroy(p->done);
+    if (p->cs) (void)hipStreamDestroy(p->cs);
+    delete p;
+    return ST_OK;
+}
+extern "C" int st_dp_rank(const st_dp* p) { return p ? p->rank : -1; }
+extern "C" int st_dp_world(const st_dp* p) { return p ? p->world : -1; }
+
+// buf (n floats, in place, SUM) is all-reduced on the communicator stream once everything issued so far on `stream` has
+// finished; returns at once.  st_dp_sync makes `stream` wait for all collectives issued since the last sync.
+extern "C" int st_dp_allreduce(st_dp* p, float* buf, int64_t n, void* stream)
+{
+    ST_REQ(p && buf && n > 0, "st_dp_allreduce: bad arguments");
+    hipEvent_t ev = p->ready[p->n_issued & 3]; p->n_issued++;
+    ST_HIP(hipEventRecord(ev, st_stream(stream)), "event record");
+    ST_HIP(hipStreamWaitEvent(p->cs, ev, 0), "stream wait");
+    ST_NCCL(p, p->AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, p->comm, p->cs), "ncclAllReduce");
+    return ST_OK;
+}
+extern "C" int st_dp_broadcast(st_dp* p, float* buf, int64_t n, int root, void* stream)
+{
+    ST_REQ(p && buf && n > 0 && root >= 0 && root < p->world, "st_dp_broadcast: bad arguments");
+    hipEvent_t ev = p->ready[p->n_issued & 3]; p->n_issued++;
+    ST_HIP(hipEventRecord(ev, st_stream(stream)), "event record");
+    ST_HIP(hipStreamWaitEvent(p->cs, ev, 0), "stream wait");
+    ST_NCCL(p, p->Broadcast(buf, buf, (size_t)n, ncclFloat32, root, p->comm, p->cs), "ncclBroadcast");
+    return ST_OK;
+}
+extern "C" int st_dp_sync(st_dp* p, void* stream)
+{
+    ST_REQ(p, "st_dp_sync: null communicator");
+    ST_HIP(hipEventRecord(p->done, p->cs), "event record");
+    ST_HIP(hipStreamWaitEvent(st_stream(stream), p->done, 0), "stream wait");
+    return ST_OK;
+}
+
+// One data-parallel optimisation step (train.py:112-151 on this rank's shard + the exchange of SURVEY.md 8e), all from C:
+//   phase 1 (forward ... autoencoder / polar backward)            -> all-reduce grads[offs[2], total)  (8.45 MB)  || phase 2
+//   phase 2 (analysis weight gradient, live rows packed in stage) -> all-reduce stage [2F][N]          (4.2 MB, exposed)
+//   copy the reduced rows back, L1 norm of the reduced gradient, clip, Adam with grad_scale = 1/world.
+// `stage`: caller-owned 2*F*N floats.  p == NULL or world == 1 falls through to st_train_step (no exchange).
+extern "C" int st_dp_train_step(st_dp* p, const st_dims* d, float* params, float* grads, float* m, float* v, float* stage,
+                                const float* x, const float* knobs, const float* y_true, void* ws, float* scalars,
+                                float lr, float beta1, float beta2, float eps, int step, int force_exchange, void* stream)
+{
+    if (!p || (p->world == 1 && !force_exchange))
+        return st_train_step(d, params, grads, m, v, x, knobs, y_true, ws, scalars, lr, beta1, beta2, eps, step, stream);
+    Layout L; ST_TRY(make_layout(d, &L));
+    ST_REQ(stage, "st_dp_train_step: null staging buffer");
+    ST_TRY(st_loss_backward_p1(d, params, grads, x, knobs, y_true, ws, stream));
+    ST_TRY(st_dp_allreduce(p, grads + L.offs[2], L.total - L.offs[2], stream));
+    ST_TRY(st_loss_backward_p2_staged(d, grads, stage, x, ws, scalars, stream));
+    ST_TRY(st_dp_allreduce(p, stage, (int64_t)2 * d->F * d->N, stream));
+    ST_TRY(st_dp_sync(p, stream));
+    ST_TRY(st_unstage_analysis(d, grads, stage, stream));
+    return st_dp_clip_adam(d, params, grads, m, v, ws, scalars, 1.0f / (float)p->world, lr, beta1, beta2, eps, step, stream);
 }

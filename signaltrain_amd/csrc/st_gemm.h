@@ -545,6 +545,7 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
 // four 8-byte k-quads.  One k-tile = 32 = two MFMA k-steps; a lane's fragment is 8 consecutive k (k = 16 s + 8 (lane/32) + i)
 // for both operands, so the reduction order inside a step is whatever the hardware uses -- identically for A and B.
 typedef __bf16 st_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 st_f16x8 __attribute__((ext_vector_type(8)));
 // v_cvt_pk_bf16_f32 (round to nearest even) as volatile asm: left to the compiler, the conversions were (1) vectorised as
 // (x,z)/(y,w) pairs and re-shuffled with four extra VALU instructions per float4, and (2) hoisted above the MFMA phase of
 // the k-loop -- the sched_barrier only orders machine instructions -- so the wave waited for its prefetch right after
@@ -553,10 +554,20 @@ __device__ __forceinline__ unsigned st_pack_bf16(float a, float b)
 {
     unsigned r; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
 }
+// fp16 (HT = 2, BASELINE configs[4] "fp16 mixed precision"): IEEE round to nearest even; a value beyond the fp16 range becomes
+// inf, exactly as under the reference's Apex amp -- the non-finite gradient norm then makes the optimizer kernel skip the step
+// (clip_adam_kernel) and the host lowers the loss scale.  The one operand that is saturated at its source instead is the
+// polar backward's output (polar_bwd_kernel: 1e7-sized sub-gradients on silent frames).
+__device__ __forceinline__ unsigned st_pack_f16(float a, float b)
+{
+    unsigned r; asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+template <int HT> __device__ __forceinline__ unsigned st_pack_h(float a, float b) { if constexpr (HT == 2) return st_pack_f16(a, b); else return st_pack_bf16(a, b); }
 
-template <int WAVES_M, class AL, class BL, class EPI>
+// HT: 1 = bfloat16 operands (v_mfma_f32_32x32x16_bf16), 2 = float16 operands (v_mfma_f32_32x32x16_f16); same rate, same layout.
+template <int WAVES_M, int HT, class AL, class BL, class EPI>
 __global__ void __launch_bounds__(WAVES_M * 64)
-gemm_bf16_kernel(const AL al, const BL bl, const EPI epi, const int K, const int ksplit)
+gemm_half_kernel(const AL al, const BL bl, const EPI epi, const int K, const int ksplit)
 {
     constexpr int BKH = 32;
     constexpr int BM = 32 * WAVES_M, NT = 64 * WAVES_M;
@@ -639,13 +650,13 @@ gemm_bf16_kernel(const AL al, const BL bl, const EPI epi, const int K, const int
                 for (int q = 0; q < 4; ++q) v[q] = oa[p][q] ? al.post(ra[p][q]) : zero4;
                 const float m0[4] = {v[0].x, v[1].x, v[2].x, v[3].x}, m1[4] = {v[0].y, v[1].y, v[2].y, v[3].y};
                 const float m2[4] = {v[0].z, v[1].z, v[2].z, v[3].z}, m3[4] = {v[0].w, v[1].w, v[2].w, v[3].w};
-                *reinterpret_cast<uint2*>(as + (a_i[p] + 0) * LD + a_k[p]) = make_uint2(st_pack_bf16(m0[0], m0[1]), st_pack_bf16(m0[2], m0[3]));
-                *reinterpret_cast<uint2*>(as + (a_i[p] + 1) * LD + a_k[p]) = make_uint2(st_pack_bf16(m1[0], m1[1]), st_pack_bf16(m1[2], m1[3]));
-                *reinterpret_cast<uint2*>(as + (a_i[p] + 2) * LD + a_k[p]) = make_uint2(st_pack_bf16(m2[0], m2[1]), st_pack_bf16(m2[2], m2[3]));
-                *reinterpret_cast<uint2*>(as + (a_i[p] + 3) * LD + a_k[p]) = make_uint2(st_pack_bf16(m3[0], m3[1]), st_pack_bf16(m3[2], m3[3]));
+                *reinterpret_cast<uint2*>(as + (a_i[p] + 0) * LD + a_k[p]) = make_uint2(st_pack_h<HT>(m0[0], m0[1]), st_pack_h<HT>(m0[2], m0[3]));
+                *reinterpret_cast<uint2*>(as + (a_i[p] + 1) * LD + a_k[p]) = make_uint2(st_pack_h<HT>(m1[0], m1[1]), st_pack_h<HT>(m1[2], m1[3]));
+                *reinterpret_cast<uint2*>(as + (a_i[p] + 2) * LD + a_k[p]) = make_uint2(st_pack_h<HT>(m2[0], m2[1]), st_pack_h<HT>(m2[2], m2[3]));
+                *reinterpret_cast<uint2*>(as + (a_i[p] + 3) * LD + a_k[p]) = make_uint2(st_pack_h<HT>(m3[0], m3[1]), st_pack_h<HT>(m3[2], m3[3]));
             } else {
                 const float4 v = oa[p][0] ? al.post(ra[p][0]) : zero4;
-                *reinterpret_cast<uint2*>(as + a_i[p] * LD + a_k[p]) = make_uint2(st_pack_bf16(v.x, v.y), st_pack_bf16(v.z, v.w));
+                *reinterpret_cast<uint2*>(as + a_i[p] * LD + a_k[p]) = make_uint2(st_pack_h<HT>(v.x, v.y), st_pack_h<HT>(v.z, v.w));
             }
         }
 #pragma unroll
@@ -657,13 +668,13 @@ gemm_bf16_kernel(const AL al, const BL bl, const EPI epi, const int K, const int
                 for (int q = 0; q < 4; ++q) v[q] = ob[p][q] ? bl.post(rb[p][q]) : zero4;
                 const float m0[4] = {v[0].x, v[1].x, v[2].x, v[3].x}, m1[4] = {v[0].y, v[1].y, v[2].y, v[3].y};
                 const float m2[4] = {v[0].z, v[1].z, v[2].z, v[3].z}, m3[4] = {v[0].w, v[1].w, v[2].w, v[3].w};
-                *reinterpret_cast<uint2*>(bs + (b_i[p] + 0) * LD + b_k[p]) = make_uint2(st_pack_bf16(m0[0], m0[1]), st_pack_bf16(m0[2], m0[3]));
-                *reinterpret_cast<uint2*>(bs + (b_i[p] + 1) * LD + b_k[p]) = make_uint2(st_pack_bf16(m1[0], m1[1]), st_pack_bf16(m1[2], m1[3]));
-                *reinterpret_cast<uint2*>(bs + (b_i[p] + 2) * LD + b_k[p]) = make_uint2(st_pack_bf16(m2[0], m2[1]), st_pack_bf16(m2[2], m2[3]));
-                *reinterpret_cast<uint2*>(bs + (b_i[p] + 3) * LD + b_k[p]) = make_uint2(st_pack_bf16(m3[0], m3[1]), st_pack_bf16(m3[2], m3[3]));
+                *reinterpret_cast<uint2*>(bs + (b_i[p] + 0) * LD + b_k[p]) = make_uint2(st_pack_h<HT>(m0[0], m0[1]), st_pack_h<HT>(m0[2], m0[3]));
+                *reinterpret_cast<uint2*>(bs + (b_i[p] + 1) * LD + b_k[p]) = make_uint2(st_pack_h<HT>(m1[0], m1[1]), st_pack_h<HT>(m1[2], m1[3]));
+                *reinterpret_cast<uint2*>(bs + (b_i[p] + 2) * LD + b_k[p]) = make_uint2(st_pack_h<HT>(m2[0], m2[1]), st_pack_h<HT>(m2[2], m2[3]));
+                *reinterpret_cast<uint2*>(bs + (b_i[p] + 3) * LD + b_k[p]) = make_uint2(st_pack_h<HT>(m3[0], m3[1]), st_pack_h<HT>(m3[2], m3[3]));
             } else {
                 const float4 v = ob[p][0] ? bl.post(rb[p][0]) : zero4;
-                *reinterpret_cast<uint2*>(bs + b_i[p] * LD + b_k[p]) = make_uint2(st_pack_bf16(v.x, v.y), st_pack_bf16(v.z, v.w));
+                *reinterpret_cast<uint2*>(bs + b_i[p] * LD + b_k[p]) = make_uint2(st_pack_h<HT>(v.x, v.y), st_pack_h<HT>(v.z, v.w));
             }
         }
     };
@@ -690,11 +701,20 @@ gemm_bf16_kernel(const AL al, const BL bl, const EPI epi, const int K, const int
             const unsigned short* bs = Bs + cur * B_SZ + b_off;
 #pragma unroll
             for (int ks = 0; ks < BKH / 16; ++ks) {
-                const st_bf16x8 a = *reinterpret_cast<const st_bf16x8*>(as + 16 * ks);
+                if constexpr (HT == 2) {
+                    const st_f16x8 a = *reinterpret_cast<const st_f16x8*>(as + 16 * ks);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const st_bf16x8 b = *reinterpret_cast<const st_bf16x8*>(bs + 32 * j * LD + 16 * ks);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+                    for (int j = 0; j < NJ; ++j) {
+                        const st_f16x8 b = *reinterpret_cast<const st_f16x8*>(bs + 32 * j * LD + 16 * ks);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[j], 0, 0, 0);
+                    }
+                } else {
+                    const st_bf16x8 a = *reinterpret_cast<const st_bf16x8*>(as + 16 * ks);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const st_bf16x8 b = *reinterpret_cast<const st_bf16x8*>(bs + 32 * j * LD + 16 * ks);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -706,14 +726,14 @@ gemm_bf16_kernel(const AL al, const BL bl, const EPI epi, const int K, const int
     epi(m_blk + wave * 32, n_blk, acc);
 }
 
-template <int WAVES_M, class AL, class BL, class EPI>
-static inline void launch_bf16(const AL& al, const BL& bl, const EPI& epi, int M, int Nc, int K, int nsplit, hipStream_t s)
+template <int WAVES_M, int HT = 1, class AL, class BL, class EPI>
+static inline void launch_half(const AL& al, const BL& bl, const EPI& epi, int M, int Nc, int K, int nsplit, hipStream_t s)
 {
     constexpr int BM = 32 * WAVES_M;
     int ksplit = K;
     if (nsplit > 1) ksplit = st_round_up((K + nsplit - 1) / nsplit, 32);
     dim3 grid((Nc + BN - 1) / BN, (M + BM - 1) / BM, nsplit > 1 ? nsplit : 1);
-    hipLaunchKernelGGL((gemm_bf16_kernel<WAVES_M, AL, BL, EPI>), grid, dim3(WAVES_M * 64), 0, s, al, bl, epi, K, ksplit);
+    hipLaunchKernelGGL((gemm_half_kernel<WAVES_M, HT, AL, BL, EPI>), grid, dim3(WAVES_M * 64), 0, s, al, bl, epi, K, ksplit);
 }
 
 template <int WAVES_M, int BKT, int MI = 1, bool XT = false, class AL, class BL, class EPI>

@@ -126,7 +126,8 @@ scale_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, f
 // Output dG[R,KP]: d re at [0,F), d im at [KP/2,KP/2+F), pads written as zeros.
 __global__ void __launch_bounds__(256)
 polar_bwd_kernel(const float* __restrict__ re, const float* __restrict__ im, const float* __restrict__ dmag,
-                 const float* __restrict__ dphs, const float* __restrict__ g_mag, float* __restrict__ dG, int R, int F, int KP)
+                 const float* __restrict__ dphs, const float* __restrict__ g_mag, float* __restrict__ dG, int R, int F, int KP,
+                 const float sat)      // > 0: saturate the result to +-sat (the consumer GEMM narrows it to fp16, see below)
 {
     const int half = KP / 2;
     const int r = blockIdx.y;
@@ -142,6 +143,10 @@ polar_bwd_kernel(const float* __restrict__ re, const float* __restrict__ im, con
         const float den = rp * rp + bb * bb;
         gre = dm * a * inv - dp * bb / den;
         gim = dm * bb * inv + dp * rp / den;
+        // fp16 configurations: d atan2 is ~1e7 x dphs on (near-)silent frames; times the loss scale that leaves the
+        // fp16 range, and inf x 0 (the silent frame itself, the other GEMM operand) would poison the weight gradient with NaN.
+        // The sub-gradient is computed in fp32 as always and saturated HERE, before the consumer narrows it.
+        if (sat > 0.f) { gre = __builtin_amdgcn_fmed3f(gre, -sat, sat); gim = __builtin_amdgcn_fmed3f(gim, -sat, sat); }
     }
     dG[(size_t)r * KP + c] = gre;
     dG[(size_t)r * KP + half + c] = gim;
@@ -231,6 +236,7 @@ struct FinArgs {
     const float* loss_partial; int n_loss; const float* reg_partial; int n_reg;
     const float* norm_a; int n_na; const float* norm_s; int n_ns;
     float inv_ycount, reg_scale, norm_scale;
+    const float* norm_e; int n_ne;        // clip over ALL parameters (st_dims.clip_all): |g| partials of the autoencoder range
 };
 // Block-wide: the loss terms (if want_loss) and the clip coefficient from the partial sums; every thread returns the
 // coefficient, thread 0 also gets the loss terms.  One summation order, so any block that evaluates this gets the same bits.
@@ -241,6 +247,7 @@ __device__ __forceinline__ float finalize_block(const FinArgs& f, const bool wan
     if (want_loss && f.reg_partial) for (int i = threadIdx.x; i < f.n_reg; i += 256) b += f.reg_partial[i];
     if (f.norm_a) for (int i = threadIdx.x; i < f.n_na; i += 256) c += f.norm_a[i];
     if (f.norm_s) for (int i = threadIdx.x; i < f.n_ns; i += 256) c += f.norm_s[i];
+    if (f.norm_e) for (int i = threadIdx.x; i < f.n_ne; i += 256) c += f.norm_e[i];
     if (want_loss) { a = block_sum<4>(a, red); b = block_sum<4>(b, red); }
     c = block_sum<4>(c, red);
     __shared__ float bc;
@@ -258,7 +265,7 @@ finalize_kernel(const FinArgs f, float* __restrict__ scalars)
     const float coef = finalize_block(f, true, red, lc, rg, nrm);
     if (threadIdx.x == 0) {
         if (f.loss_partial) { scalars[1] = lc; scalars[2] = rg; scalars[0] = lc + rg; }
-        if (f.norm_a || f.norm_s) { scalars[3] = nrm; scalars[4] = coef; }
+        if (f.norm_a || f.norm_s || f.norm_e) { scalars[3] = nrm; scalars[4] = coef; }
     }
 }
 
@@ -268,26 +275,34 @@ finalize_kernel(const FinArgs f, float* __restrict__ scalars)
 // the clip coefficient first; every gradient is pre-scaled by grad_scale (1/world in data parallel).
 // FIN: the scalars are not ready yet -- every block derives the clip coefficient from the partial sums itself (2k floats out
 // of L2) and block 0 publishes the loss scalars: saves the single-block finalize launch (9 us) in the fused train step.
+// [0, n4_clip) is the clipped range: the 4 STFT tensors (nn_proc.py:299-302) or everything (train.py:136, st_dims.clip_all).
+// Mixed precision: a non-finite norm (a gradient overflowed under the loss scale) SKIPS the update on every block -- parameters
+// and moments stay untouched -- and scalars[5] counts the skipped steps for the host's loss-scale policy (what Apex's dynamic
+// scaler does with its overflow flag, train.py:134-135).
 template <bool FIN>
 __global__ void __launch_bounds__(256)
 clip_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                 int64_t n4_total, int64_t n4_stft, float* __restrict__ scalars, float grad_scale,
+                 int64_t n4_total, int64_t n4_clip, float* __restrict__ scalars, float grad_scale,
                  float neg_step_size, float w1, float b2, float w2, float bc2_sqrt, float eps, const FinArgs fin)
 {
-    float coef;
+    float coef, nrm;
     if constexpr (FIN) {
         __shared__ float red[4];
-        float lc, rg, nrm;
+        float lc, rg;
         coef = finalize_block(fin, blockIdx.x == 0, red, lc, rg, nrm);
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             if (fin.loss_partial) { scalars[1] = lc; scalars[2] = rg; scalars[0] = lc + rg; }
             scalars[3] = nrm; scalars[4] = coef;
         }
     } else {
-        coef = scalars[4];
+        coef = scalars[4]; nrm = scalars[3];
+    }
+    if (!(nrm <= 3.0e38f)) {                         // inf or NaN: overflow under the loss scale -> skip this step everywhere
+        if (blockIdx.x == 0 && threadIdx.x == 0) scalars[5] = scalars[5] + 1.0f;
+        return;
     }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4_total; i += (int64_t)gridDim.x * 256) {
-        const float sc = (i < n4_stft) ? grad_scale * coef : grad_scale;
+        const float sc = (i < n4_clip) ? grad_scale * coef : grad_scale;
         float4 G = reinterpret_cast<float4*>(g)[i];
         float4 M = reinterpret_cast<float4*>(m)[i];
         float4 V = reinterpret_cast<float4*>(v)[i];

@@ -21,6 +21,7 @@ STFT_KEYS = ("mpaec.dft_analysis.conv_analysis_real.weight",
              "mpaec.dft_analysis.conv_analysis_imag.weight",
              "mpaec.dft_synthesis.conv_synthesis_real.weight",
              "mpaec.dft_synthesis.conv_synthesis_imag.weight")
+COMPUTE_DTYPES = tuple(_lib.PREC)       # "f32", "bf16", "bf16_all", "f16", "f16_all"
 
 
 def param_names():
@@ -59,19 +60,32 @@ class ParamLayout:
         return out
 
 
+class _OptimizerView:
+    """What misc.save_checkpoint needs from an optimizer: state_dict() in torch.optim.Adam's layout (train.py:228)."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def state_dict(self):
+        return self.engine.optimizer_state_dict()
+
+
 class StepEngine:
     """Holds device state for one model replica and drives the HIP step."""
 
-    def __init__(self, dims, device="cuda:0", max_batch=None, compute_dtype="f32"):
-        """compute_dtype: "f32" (default, the parity path) or "bf16" = bf16 operands / fp32 accumulation in the STFT GEMMs
-        (BASELINE configs[2], [3]); parameters, gradients, autoencoders, loss and Adam are fp32 either way."""
-        if compute_dtype not in ("f32", "bf16", "bf16_all"):
-            raise ValueError("compute_dtype must be 'f32', 'bf16' (STFT GEMMs) or 'bf16_all' (GEMMs + autoencoder layers)")
-        self.compute_dtype = compute_dtype
+    def __init__(self, dims, device="cuda:0", max_batch=None, compute_dtype="f32", loss_scale=None, clip_all=None):
+        """compute_dtype: "f32" (default, the parity path); "bf16" / "f16" = 16-bit operands with fp32 accumulation in the STFT
+        GEMMs (BASELINE configs[2], [3] / [4]); "bf16_all" / "f16_all" = also in the autoencoder layers.  Parameters, gradients,
+        loss and Adam are fp32 in every mode.  loss_scale: static loss scale of the step (default: 1 except 2**12 for the f16
+        modes -- Apex's amp.scale_loss, train.py:134-135); clip_all: L1 clip over all parameters instead of the STFT tensors
+        (train.py:136, what the reference does with Apex on; default: only in the f16 modes)."""
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("signaltrain_amd.StepEngine needs a ROCm device (there is no CPU fallback)")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.set_arithmetic(compute_dtype, loss_scale, clip_all)
         self.dims = dims
         self.max_batch = int(max_batch or dims.B)
         self.layout = ParamLayout(dims)
@@ -85,8 +99,19 @@ class StepEngine:
         self.named = self.layout.views(self.params)
         self.named_grads = self.layout.views(self.grads)
         self.step_count = 0
+        self.generation = 0          # bumped by every call that overwrites the saved-for-backward state in the workspace
+        self.dp = None               # st_dp* of the library-owned RCCL communicator (dp.DataParallel attaches it)
+        self._pending = None
 
-    # ---------------------------------------------------------------- parameters
+    def set_arithmetic(self, compute_dtype, loss_scale=None, clip_all=None):
+        if compute_dtype not in _lib.PREC:
+            raise ValueError(f"compute_dtype must be one of {COMPUTE_DTYPES}")
+        self.compute_dtype = compute_dtype
+        half = compute_dtype.startswith("f16")
+        self.loss_scale = float(loss_scale) if loss_scale is not None else (4096.0 if half else 1.0)
+        self.clip_all = bool(half if clip_all is None else clip_all)
+
+    # ---------------------------------------------------------------- parameters / optimizer state
     def load_state_dict(self, sd):
         for k, v in self.named.items():
             src = sd[k]
@@ -96,15 +121,53 @@ class StepEngine:
     def state_dict(self):
         return OrderedDict((k, v.detach().clone()) for k, v in self.named.items())
 
+    def optimizer_view(self):
+        return _OptimizerView(self)
+
+    def optimizer_state_dict(self, lr=None):
+        """Adam state in torch.optim.Adam.state_dict() layout (40 per-parameter entries keyed by index, views of the flat
+        moment buffers copied to the host) -- what the reference writes into its checkpoints (misc.py:28)."""
+        from . import misc
+        m, v = self.layout.views(self.m.detach().cpu()), self.layout.views(self.v.detach().cpu())
+        return misc.adam_state_dict(self.step_count, self.lr if lr is None else lr,
+                                    [t.clone() for t in m.values()], [t.clone() for t in v.values()])
+
+    def load_optimizer_state_dict(self, osd):
+        """Restore exp_avg / exp_avg_sq / step from a torch.optim.Adam state_dict (the reference's 'optimizer' checkpoint entry;
+        the reference itself never reads it back, train.py:229).  Returns the restored learning rate, or None if `osd` is not
+        in that layout (nothing is changed then)."""
+        from . import misc
+        flat = misc.flatten_optimizer_state(osd, self.layout.shapes)
+        if flat is None:
+            return None
+        for buf, key in ((self.m, "exp_avg"), (self.v, "exp_avg_sq")):
+            for view, src in zip(self.layout.views(buf).values(), flat[key]):
+                view.copy_(torch.from_numpy(src).to(self.device).reshape(view.shape))
+        self.step_count = int(flat["step"])
+        self.lr = float(flat["lr"])
+        return self.lr
+
+    lr = 0.0        # last learning rate handed to train_step (recorded for optimizer_state_dict)
+
+    # ---------------------------------------------------------------- plumbing
     def _dims(self, B):
+        """The geometry for a batch of B windows + this engine's arithmetic: precision, loss scale and clip scope travel in
+        st_dims with every call (there is no process-wide switch)."""
         if B > self.max_batch:
             raise RuntimeError(f"batch {B} exceeds the engine's workspace (max_batch={self.max_batch})")
-        return self.dims if B == self.dims.B else self.dims.with_batch(B)
+        d = self.dims.with_batch(B)
+        d.prec, d.loss_scale, d.clip_all = _lib.PREC[self.compute_dtype], self.loss_scale, int(self.clip_all)
+        return d
 
     def _stream(self):
-        # every entry point fetches the stream right before its C call: the (process-wide) precision switch rides along
-        self.lib.st_set_precision({"f32": 0, "bf16": 1, "bf16_all": 2}[self.compute_dtype])
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        """The current stream OF THIS ENGINE'S DEVICE (not of whatever device happens to be current)."""
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _call(self, name, *args):
+        """One C-ABI call with this engine's device current: the library launches on the device that is current at call time
+        (it never calls hipSetDevice itself), so an engine on cuda:1 must not depend on the caller's current device."""
+        with torch.cuda.device(self.device):
+            _lib.check(getattr(self.lib, name)(*args), name)
 
     def _prep(self, x, knobs, y=None):
         f = lambda t: None if t is None else t.to(device=self.device, dtype=torch.float32).contiguous()
@@ -122,54 +185,58 @@ class StepEngine:
         y_hat = torch.empty(d.B, d.y, dtype=torch.float32, device=self.device)
         mag = torch.empty(d.B, d.T, d.F, dtype=torch.float32, device=self.device)
         mag_hat = torch.empty(d.B, d.OT, d.F, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.st_model_fwd(C.byref(d), _lib.ptr(self.params), _lib.ptr(x), _lib.ptr(knobs),
-                                         _lib.ptr(y_hat), _lib.ptr(mag), _lib.ptr(mag_hat), _lib.ptr(self.ws),
-                                         1 if save_for_backward else 0, self._stream()), "st_model_fwd")
+        self.generation += 1
+        self._call("st_model_fwd", C.byref(d), _lib.ptr(self.params), _lib.ptr(x), _lib.ptr(knobs),
+                   _lib.ptr(y_hat), _lib.ptr(mag), _lib.ptr(mag_hat), _lib.ptr(self.ws), 1 if save_for_backward else 0, self._stream())
         return y_hat, mag, mag_hat
 
     def backward(self, x, knobs, g_y_hat, g_mag_hat=None, g_mag=None):
         """Autograd backward for arbitrary upstream gradients (after forward(save_for_backward=True))."""
         d, x, knobs, _ = self._prep(x, knobs)
+        d.loss_scale = 0.0                 # the upstream gradient is whatever autograd hands over: no loss scale of ours in it
         f = lambda t: None if t is None else t.to(device=self.device, dtype=torch.float32).contiguous()
         g_y_hat, g_mag_hat, g_mag = f(g_y_hat), f(g_mag_hat), f(g_mag)
-        _lib.check(self.lib.st_model_bwd(C.byref(d), _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(x),
-                                         _lib.ptr(knobs), _lib.ptr(g_y_hat), _lib.ptr(g_mag_hat), _lib.ptr(g_mag),
-                                         _lib.ptr(self.ws), self._stream()), "st_model_bwd")
+        self._call("st_model_bwd", C.byref(d), _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(x),
+                   _lib.ptr(knobs), _lib.ptr(g_y_hat), _lib.ptr(g_mag_hat), _lib.ptr(g_mag), _lib.ptr(self.ws), self._stream())
         return self.grads
 
     def loss_backward(self, x, knobs, y, want_outputs=False):
-        """forward + calc_loss (loss_functions.py:26-36 with scale_by_freq) + backward; fills self.grads.
-        self.scalars[0..4] = loss, mean log-cosh, L1 term, L1 norm of STFT grads, clip coefficient."""
+        """forward + calc_loss (loss_functions.py:26-36 with scale_by_freq) + backward; fills self.grads (times the loss
+        scale, if one is set).  self.scalars[0..4] = loss, mean log-cosh, L1 term, L1 norm of the (unscaled) STFT grads, clip coefficient."""
         d, x, knobs, y = self._prep(x, knobs, y)
         outs = (None, None, None)
         if want_outputs:
             outs = (torch.empty(d.B, d.y, dtype=torch.float32, device=self.device),
                     torch.empty(d.B, d.T, d.F, dtype=torch.float32, device=self.device),
                     torch.empty(d.B, d.OT, d.F, dtype=torch.float32, device=self.device))
-        _lib.check(self.lib.st_loss_backward(C.byref(d), _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(x),
-                                             _lib.ptr(knobs), _lib.ptr(y), _lib.ptr(outs[0]), _lib.ptr(outs[1]),
-                                             _lib.ptr(outs[2]), _lib.ptr(self.ws), _lib.ptr(self.scalars),
-                                             self._stream()), "st_loss_backward")
+        self.generation += 1
+        self._call("st_loss_backward", C.byref(d), _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(x),
+                   _lib.ptr(knobs), _lib.ptr(y), _lib.ptr(outs[0]), _lib.ptr(outs[1]), _lib.ptr(outs[2]), _lib.ptr(self.ws),
+                   _lib.ptr(self.scalars), self._stream())
         return outs
+
+    def _stage_buf(self):
+        if self.stage is None:
+            self.stage = torch.zeros(2 * self.dims.F * self.dims.N, dtype=torch.float32, device=self.device)
+        return self.stage
 
     def loss_backward_p1(self, x, knobs, y):
         """Forward + backward up to (excluding) the analysis weight gradient; see dp.DataParallel."""
         d, x, knobs, y = self._prep(x, knobs, y)
         self._pending = (d, x, knobs, y)
-        _lib.check(self.lib.st_loss_backward_p1(C.byref(d), _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(x),
-                                                _lib.ptr(knobs), _lib.ptr(y), _lib.ptr(self.ws), self._stream()), "st_loss_backward_p1")
+        self.generation += 1
+        self._call("st_loss_backward_p1", C.byref(d), _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(x),
+                   _lib.ptr(knobs), _lib.ptr(y), _lib.ptr(self.ws), self._stream())
 
     def loss_backward_p2(self):
-        """Analysis weight gradient + loss scalars; the 2F live rows also land packed in self.stage (see grad_buckets)."""
+        """Analysis weight gradient; the 2F live rows also land packed in self.stage (see grad_buckets)."""
         d, x = self._pending[:2]
-        if self.stage is None:
-            self.stage = torch.zeros(2 * self.dims.F * self.dims.N, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.st_loss_backward_p2_staged(C.byref(d), _lib.ptr(self.grads), _lib.ptr(self.stage), _lib.ptr(x),
-                                                       _lib.ptr(self.ws), _lib.ptr(self.scalars), self._stream()), "st_loss_backward_p2_staged")
+        self._call("st_loss_backward_p2_staged", C.byref(d), _lib.ptr(self.grads), _lib.ptr(self._stage_buf()), _lib.ptr(x),
+                   _lib.ptr(self.ws), _lib.ptr(self.scalars), self._stream())
 
     def finish_buckets(self):
         """After the all-reduce of grad_buckets(): copy the reduced analysis rows from the packed staging buffer back into grads."""
-        _lib.check(self.lib.st_unstage_analysis(C.byref(self.dims), _lib.ptr(self.grads), _lib.ptr(self.stage), self._stream()), "st_unstage_analysis")
+        self._call("st_unstage_analysis", C.byref(self._pending[0]), _lib.ptr(self.grads), _lib.ptr(self.stage), self._stream())
 
     N_STAGES = 4
 
@@ -178,10 +245,10 @@ class StepEngine:
         range stage_bucket(s) of self.grads is final (st_loss_backward_stage in include/signaltrain_hip.h)."""
         if stage == 0:
             self._pending = self._prep(x, knobs, y)
+            self.generation += 1
         d, x, knobs, y = self._pending
-        _lib.check(self.lib.st_loss_backward_stage(C.byref(d), _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(x),
-                                                   _lib.ptr(knobs), _lib.ptr(y), _lib.ptr(self.ws), _lib.ptr(self.scalars),
-                                                   int(stage), self._stream()), "st_loss_backward_stage")
+        self._call("st_loss_backward_stage", C.byref(d), _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(x),
+                   _lib.ptr(knobs), _lib.ptr(y), _lib.ptr(self.ws), _lib.ptr(self.scalars), int(stage), self._stream())
 
     def stage_bucket(self, stage):
         """Gradient range that is final after loss_backward_stage(stage): synthesis bases (4.2 MB at N=1024), both
@@ -195,31 +262,49 @@ class StepEngine:
         [synthesis + autoencoders] = grads[offs[2]:] after phase 1, then the packed staging copy [2F][N] of the live analysis
         rows written by phase 2 (4.2 MB; the contiguous range of grads holding them would span 2 MB of structurally-zero rows).
         Call finish_buckets() after the second all-reduce."""
-        if self.stage is None:
-            self.stage = torch.zeros(2 * self.dims.F * self.dims.N, dtype=torch.float32, device=self.device)
-        return [self.grads[self.layout.offsets[2]:], self.stage]
+        return [self.grads[self.layout.offsets[2]:], self._stage_buf()]
 
     def train_step(self, x, knobs, y, lr, betas=(0.9, 0.999), eps=1e-8):
         """One optimisation step (train.py:112-151).  `lr` is the value sitting in param_groups at step
         time, i.e. lr_sched[max(i-1,0)] in the reference loop (train.py:150).  No host sync."""
         d, x, knobs, y = self._prep(x, knobs, y)
-        self.step_count += 1
-        _lib.check(self.lib.st_train_step(C.byref(d), _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.m),
-                                          _lib.ptr(self.v), _lib.ptr(x), _lib.ptr(knobs), _lib.ptr(y), _lib.ptr(self.ws),
-                                          _lib.ptr(self.scalars), float(lr), float(betas[0]), float(betas[1]), float(eps),
-                                          int(self.step_count), self._stream()), "st_train_step")
+        self.step_count += 1; self.generation += 1; self.lr = float(lr)
+        self._call("st_train_step", C.byref(d), _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.m),
+                   _lib.ptr(self.v), _lib.ptr(x), _lib.ptr(knobs), _lib.ptr(y), _lib.ptr(self.ws),
+                   _lib.ptr(self.scalars), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                   int(self.step_count), self._stream())
+        return self.scalars
+
+    def dp_train_step(self, x, knobs, y, lr, betas=(0.9, 0.999), eps=1e-8, force_exchange=False):
+        """The data-parallel step driven from C (st_dp_train_step): this rank's shard, both gradient buckets all-reduced on the
+        library's RCCL communicator under the backward, clip after the reduction, replicated Adam."""
+        d, x, knobs, y = self._prep(x, knobs, y)
+        self.step_count += 1; self.generation += 1; self.lr = float(lr)
+        self._call("st_dp_train_step", self.dp, C.byref(d), _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.m),
+                   _lib.ptr(self.v), _lib.ptr(self._stage_buf()), _lib.ptr(x), _lib.ptr(knobs), _lib.ptr(y), _lib.ptr(self.ws),
+                   _lib.ptr(self.scalars), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                   int(self.step_count), 1 if force_exchange else 0, self._stream())
         return self.scalars
 
     def clip_adam(self, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
         """L1 clip + Adam on the current self.grads (data parallel: call after the all-reduce with
         grad_scale = 1/world; the norm is recomputed on the reduced gradient, identically on all ranks)."""
-        self.step_count += 1
-        _lib.check(self.lib.st_dp_clip_adam(C.byref(self.dims), _lib.ptr(self.params), _lib.ptr(self.grads),
-                                            _lib.ptr(self.m), _lib.ptr(self.v), _lib.ptr(self.ws), _lib.ptr(self.scalars),
-                                            float(grad_scale), float(lr), float(betas[0]), float(betas[1]), float(eps),
-                                            int(self.step_count), self._stream()), "st_dp_clip_adam")
+        self.step_count += 1; self.lr = float(lr)
+        d = self._pending[0] if self._pending is not None else self._dims(self.dims.B)     # the STEP's dims: its partial-sum counts carve the workspace
+        self._call("st_dp_clip_adam", C.byref(d), _lib.ptr(self.params), _lib.ptr(self.grads),
+                   _lib.ptr(self.m), _lib.ptr(self.v), _lib.ptr(self.ws), _lib.ptr(self.scalars),
+                   float(grad_scale), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                   int(self.step_count), self._stream())
         return self.scalars
 
     def loss(self):
         """Host copy of the last loss (device->host sync; the reference does this every 10 iterations)."""
         return float(self.scalars[0].item())
+
+    def overflow_steps(self, reset=True):
+        """Steps skipped so far because a gradient overflowed under the loss scale (scalars[5]; device->host sync).  The
+        caller's loss-scale policy (train.train halves the scale, like Apex's dynamic scaler) acts on it."""
+        n = int(self.scalars[5].item())
+        if reset and n:
+            self.scalars[5] = 0.0
+        return n

@@ -95,23 +95,29 @@ class AsymAutoEncoder(nn.Module):
         KP = lib.st_kp(F)
         mh = torch.empty(B, self._OT, F, device=x.device); ph = torch.empty_like(mh)
         AA = torch.empty(B * self._OT, KP, device=x.device)
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         nws = int(lib.st_ae_fwd_ws_floats(C.byref(d)))                 # 0 unless the geometry is wide (T > 32 or OT > 16)
         ws = torch.empty(nws, device=x.device) if nws else None
-        _lib.check(lib.st_ae_fwd(C.byref(d), _lib.ptr(x), _lib.ptr(x), _lib.ptr(kn), _lib.ptr(packed), _lib.ptr(packed),
-                                 _lib.ptr(mh), _lib.ptr(ph), _lib.ptr(AA), None, _lib.ptr(ws), st), "st_ae_fwd")
+        with torch.cuda.device(x.device):                             # the library launches on the current device
+            st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+            _lib.check(lib.st_ae_fwd(C.byref(d), _lib.ptr(x), _lib.ptr(x), _lib.ptr(kn), _lib.ptr(packed), _lib.ptr(packed),
+                                     _lib.ptr(mh), _lib.ptr(ph), _lib.ptr(AA), None, _lib.ptr(ws), st), "st_ae_fwd")
         out = mh if skip_connections == 'sf' else ph - x[:, T - self._OT:, :]
         return out, (self.acts_reference(x_input, knobs, skip_connections) if return_acts else [])
 
 
 class _STModelFn(torch.autograd.Function):
-    """forward/backward of the whole model through the fused HIP entry points."""
+    """forward/backward of the whole model through the fused HIP entry points.
+
+    The saved-for-backward state (re, im, mag, phs, AA, ...) lives in the engine's ONE workspace, not in ctx: a second
+    forward (a validation batch, another micro-batch) before `backward()` overwrites it.  The forward stamps the engine's
+    generation counter into ctx; a stale stamp makes the backward RECOMPUTE the forward from the saved inputs (correct
+    gradients, one extra forward) instead of silently differentiating the wrong activations."""
 
     @staticmethod
     def forward(ctx, model, x, knobs, *params):
         eng = model._engine
         y_hat, mag, mag_hat = eng.forward(x, knobs, save_for_backward=True)
-        ctx.model = model
+        ctx.model, ctx.generation, ctx.engine = model, eng.generation, eng
         ctx.save_for_backward(x, knobs)
         return y_hat, mag, mag_hat
 
@@ -119,10 +125,18 @@ class _STModelFn(torch.autograd.Function):
     def backward(ctx, g_y, g_mag, g_mh):
         x, knobs = ctx.saved_tensors
         eng = ctx.model._engine
+        if eng is not ctx.engine or eng.generation != ctx.generation:
+            eng.forward(x, knobs, save_for_backward=True)          # the workspace was reused since this graph's forward: rebuild its state
         if g_y is None:
             g_y = torch.zeros(x.shape[0], eng.dims.y, device=x.device)
         eng.backward(x, knobs, g_y, g_mh, g_mag)
-        grads = tuple(g.clone() for g in eng.named_grads.values())
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise NotImplementedError("signaltrain_amd.st_model: gradients w.r.t. the input waveform / knobs are not built "
+                                      "(the reference's training never needs them: x and knobs are data)")
+        # one flat clone, then per-parameter views of it: autograd accumulates into .grad, so the engine's gradient buffer
+        # (overwritten by the next backward) must not be handed out itself
+        flat = eng.grads.clone()
+        grads = tuple(eng.layout.views(flat).values())
         return (None, None, None) + grads
 
 
@@ -156,20 +170,21 @@ class AsymMPAEC(nn.Module):
         return [sd[k] for k in param_names()]
 
     def set_compute_dtype(self, dtype):
-        """'f32' (default), 'bf16' (bf16 operands / fp32 accumulation in the STFT GEMMs) or 'bf16_all' (also in the nine Linear
-        layers of both autoencoders) -- StepEngine.compute_dtype."""
-        if dtype not in ("f32", "bf16", "bf16_all"):
-            raise ValueError("compute dtype must be 'f32', 'bf16' or 'bf16_all'")
+        """'f32' (default), 'bf16' / 'f16' (16-bit operands, fp32 accumulation in the STFT GEMMs) or 'bf16_all' / 'f16_all' (also in
+        the nine Linear layers of both autoencoders) -- StepEngine.compute_dtype."""
+        if dtype not in _lib.PREC:
+            raise ValueError(f"compute dtype must be one of {tuple(_lib.PREC)}")
         self.compute_dtype = dtype
         if self._engine is not None:
-            self._engine.compute_dtype = dtype
+            self._engine.set_arithmetic(dtype)
 
     def _ensure_engine(self, x):
         """Flatten the 40 parameters into the engine's buffer (parameters become views of it)."""
         B = x.shape[0]
         eng = self._engine
         ps = self._ordered_params()
-        if eng is not None and eng.device == x.device and B <= eng.max_batch and \
+        xdev = x.device if x.device.index is not None else torch.device("cuda", torch.cuda.current_device())
+        if eng is not None and eng.device == xdev and B <= eng.max_batch and \
                 all(p.data_ptr() == v.data_ptr() for p, v in zip(ps, eng.named.values())):
             return eng
         d = _lib.st_dims()
@@ -239,7 +254,7 @@ class st_model(nn.Module):
         self.mpaec.clip_grad_norm_()
 
     def set_compute_dtype(self, dtype):
-        """Mixed precision of the accelerated path: 'f32' (default) | 'bf16' | 'bf16_all' (see AsymMPAEC.set_compute_dtype)."""
+        """Mixed precision of the accelerated path: 'f32' (default) | 'bf16' | 'bf16_all' | 'f16' | 'f16_all' (see AsymMPAEC.set_compute_dtype)."""
         self.mpaec.set_compute_dtype(dtype)
 
     def forward(self, x_cuda, knobs_cuda, return_acts=False):

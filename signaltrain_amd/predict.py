@@ -1,4 +1,5 @@
-"""Long-file inference -- mirror of utils/predict_long.py:30-79 (predict_long) and :82-99 (calc_ct).
+"""Long-file inference -- mirror of utils/predict_long.py:30-79 (predict_long).  (The plotting helper calc_ct, :82-99, runs the
+CPU effect chunk by chunk and is not part of the accelerated path: it is not mirrored.)
 
 The reference windows the signal on the host (audio.sliding_window, audio.py:23-49), ships every batch of
 overlapping windows to the device and appends the outputs on the host.  Here the (zero-padded) signal is uploaded
@@ -9,7 +10,6 @@ Same arguments, same return value: a 1-D float32 numpy array of len(signal) - (c
 import numpy as np
 import torch
 
-from . import audio
 
 
 def predict_long(signal, knobs_nn, model, chunk_size, out_chunk_size, sr=44100, effect=None, device=None, compand=False,
@@ -50,21 +50,3 @@ def predict_long(signal, knobs_nn, model, chunk_size, out_chunk_size, sr=44100, 
     out = y_pred.cpu().numpy()
     return out[0:-num_extra] if num_extra > 0 else out
 
-
-def calc_ct(signal, effect, knobs_wc, out_chunk_size, chunk_size, sr=44100):
-    """'Chunked target': the effect applied chunk by chunk with the same lookback the model sees (predict_long.py:82-99)."""
-    lookback_size = chunk_size - out_chunk_size
-    y_ct = None
-    if lookback_size >= 0:
-        padded_sig = np.concatenate((np.zeros(lookback_size, dtype=np.float32), signal))
-        y_ct = np.zeros(len(padded_sig))
-        for i in np.arange(0, len(padded_sig), out_chunk_size):
-            iend = min(i + chunk_size, len(padded_sig))
-            in_chunk = padded_sig[i:iend]
-            out_chunk, _ = effect.go_wc(in_chunk, knobs_wc)
-            if len(out_chunk) > out_chunk_size:
-                out_chunk = out_chunk[-out_chunk_size:]
-            itbgn, itend = iend - len(out_chunk), iend
-            y_ct[itbgn:itend] = out_chunk
-        y_ct = y_ct[lookback_size:]
-    return y_ct

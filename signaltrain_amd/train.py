@@ -17,18 +17,6 @@ from . import audio, datasets, learningrate, loss_functions, misc, nn_proc
 from .dp import DataParallel
 
 
-class _AdamState:
-    """Minimal optimizer stand-in for misc.save_checkpoint (the reference saves but never restores it, train.py:229)."""
-
-    def __init__(self, engine, lr):
-        self.engine, self.lr = engine, lr
-
-    def state_dict(self):
-        e = self.engine
-        return {"state": {"step": e.step_count, "exp_avg": e.m.detach().cpu(), "exp_avg_sq": e.v.detach().cpu()},
-                "param_groups": [{"lr": self.lr, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0}]}
-
-
 def eval_status_save(model, engine, effect, epoch, epochs, lr, mom, device, dataloader_val, logfilename, first_time,
                      beta, vl_avg, out_checkpointname, parallel, optimizer, data_point, smoothed_loss, y_size, sr,
                      status_every, plot_every=10, cp_every=25, scale_by_freq=None, is_main=True):
@@ -61,19 +49,24 @@ def eval_status_save(model, engine, effect, epoch, epochs, lr, mom, device, data
 
 
 def train_loop(model, engine, effect, device, epochs, batch_size, lr_sched, mom_sched, dataloader, dataloader_val,
-               y_size, logfilename, out_checkpointname, plot_every=10, cp_every=25, sr=44100, lr_max=1e-4):
-    """train.py:84-164."""
+               y_size, logfilename, out_checkpointname, plot_every=10, cp_every=25, sr=44100, lr_max=1e-4,
+               start_epoch=0, start_iter=0, lr_resume=None):
+    """train.py:84-164.  start_epoch / start_iter / lr_resume: position restored from a checkpoint (epoch counter, optimizer
+    step count = position in the 1-cycle table, the learning rate that sat in the optimizer) -- the reference restarts all
+    three at zero on resume (train.py:229 TODO)."""
     dp = DataParallel(engine)
     dp.broadcast_parameters()
     is_main = (not dist.is_initialized()) or dist.get_rank() == 0
-    iter_count, batch_num, status_every = 0, 0, 10
+    iter_count, batch_num, status_every = int(start_iter), 0, 10
     avg_loss, vl_avg, beta = 0.0, 0.0, 0.98
     smoothed_loss = float("nan")          # the reference leaves this unbound for epochs shorter than 10 batches (SURVEY.md 7)
     first_time = time.time()
-    lr_in_optimizer = lr_sched[0]         # torch.optim.Adam(lr=lr_sched[0]), train.py:228
-    opt = _AdamState(engine, lr_in_optimizer)
+    lr_in_optimizer = lr_sched[0] if lr_resume is None else lr_resume      # torch.optim.Adam(lr=lr_sched[0]), train.py:228
+    engine.lr = float(lr_in_optimizer)
+    opt = engine.optimizer_view()         # state_dict() in torch.optim.Adam's layout for misc.save_checkpoint
     windows, t_train = 0, 0.0
-    for epoch in range(epochs):
+    clean_steps = 0
+    for epoch in range(int(start_epoch), epochs):
         if is_main:
             print("")
         data_point = 0
@@ -90,11 +83,20 @@ def train_loop(model, engine, effect, device, epochs, batch_size, lr_sched, mom_
             if 0 == batch_num % status_every:                        # train.py:124-129 (the only device->host sync)
                 avg_loss = beta * avg_loss + (1 - beta) * dp.mean_loss()
                 smoothed_loss = avg_loss / (1 - beta ** batch_num)
+                if engine.loss_scale != 1.0:
+                    # loss-scale policy of Apex's dynamic scaler at this loop's only sync point: halve on overflow (the kernel
+                    # already skipped those steps), double after 2000 clean steps
+                    if engine.overflow_steps():
+                        engine.loss_scale = max(engine.loss_scale / 2.0, 1.0); clean_steps = 0
+                    else:
+                        clean_steps += status_every
+                        if clean_steps >= 2000:
+                            engine.loss_scale = min(engine.loss_scale * 2.0, 2.0 ** 24); clean_steps = 0
                 if is_main:
                     print(f"\repoch {epoch+1}/{epochs}, time: {time.time()-first_time:.2f}: lr={lr:.2e},mom={mom:.3f}, "
                           f"data_point {data_point}: loss: {smoothed_loss:.3e}   ", end="")
             lr_in_optimizer = lr                                     # train.py:150: takes effect on the next step
-            opt.lr = lr
+            engine.lr = float(lr)                                    # what optimizer.state_dict() reports, as in the reference
             iter_count += 1
             windows += batch_size
         torch.cuda.synchronize()
@@ -111,12 +113,19 @@ def train_loop(model, engine, effect, device, epochs, batch_size, lr_sched, mom_
 
 def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=None, plot_every=10, cp_every=25, sr=44100,
           datapath=None, scale_factor=1, shrink_factor=4, apex_opt="O0", target_type="stream", lr_max=1e-4,
-          in_checkpointname='modelcheckpoint.tar', compand=False, num_workers=10, device_feed=False, compute_dtype="f32"):
-    """train.py:167-278.  apex_opt / target_type / compand are accepted for signature compatibility;
-    datapath (AudioFileDataSet) is not built yet -- the synthetic feed is.
-    Two extra keywords (not in the reference): device_feed=True keeps a recycled synthetic dataset in HBM
-    (datasets.DeviceRecycledDataSet: generated once, effect computed on the GPU) instead of the 10-worker CPU DataLoader,
-    which otherwise caps training far below the GPU step rate; compute_dtype="bf16" selects the mixed-precision GEMMs."""
+          in_checkpointname='modelcheckpoint.tar', compand=False, num_workers=10, device_feed=False, compute_dtype=None,
+          resume_optimizer=True):
+    """train.py:167-278.  target_type / compand are accepted for signature compatibility; datapath (AudioFileDataSet) is not
+    built yet -- the synthetic feed is.
+    apex_opt: "O0" = fp32 (the parity path); "O1" / "O2" / "O3" = the reference's Apex mixed precision (train.py:254-255),
+    here float16 operands with fp32 accumulation, a loss scale and the L1 clip over all parameters (train.py:133-136) --
+    compute_dtype "f16_all".  Extra keywords (not in the reference): compute_dtype overrides the arithmetic ("f32", "bf16",
+    "bf16_all", "f16", "f16_all"; bf16 is the MI355X-native choice and needs no loss scale); device_feed=True keeps a recycled
+    synthetic dataset in HBM (datasets.DeviceRecycledDataSet) instead of the 10-worker CPU DataLoader, which otherwise caps
+    training far below the GPU step rate; resume_optimizer=True restores Adam's moments, the step count (= position in the
+    1-cycle table) and the epoch counter from the checkpoint, which the reference saves but never reads back (train.py:229)."""
+    if compute_dtype is None:
+        compute_dtype = "f32" if str(apex_opt).upper() in ("O0", "NONE", "") else "f16_all"
     effect = audio.Compressor_4c() if effect is None else effect
     device = torch.device("cuda:0") if device is None else torch.device(device)
     if datapath is not None:
@@ -137,6 +146,12 @@ def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=N
     model.to(device)
     model.set_compute_dtype(compute_dtype)
     engine = model.engine(torch.zeros(batch_size, chunk_size, device=device))     # parameters become views of the engine's flat buffer
+    start_epoch, start_iter, lr_resume = 0, 0, None
+    if state_dict != {} and resume_optimizer and rv.get('optimizer'):
+        lr_resume = engine.load_optimizer_state_dict(rv['optimizer'])
+        if lr_resume is not None:
+            start_epoch, start_iter = int(rv.get('epoch', 0)), engine.step_count
+            print(f"Optimizer state restored: {start_iter} steps done, resuming at epoch {start_epoch + 1} with lr = {lr_resume:.3e}")
     lr_sched, mom_sched = learningrate.get_1cycle_schedule(lr_max=lr_max, n_data_points=n_data_points, epochs=epochs, batch_size=batch_size)
     dataset = datasets.SynthAudioDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points, y_size=out_chunk_size, augment=True)
     dataset_val = datasets.SynthAudioDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points // 4, recycle=True,
@@ -157,5 +172,6 @@ def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=N
     logfilename = "vl_avg_out.dat"
     open(logfilename, "a").close()
     train_loop(model, engine, effect, device, epochs, batch_size, lr_sched, mom_sched, dataloader, dataloader_val,
-               out_chunk_size, logfilename, "modelcheckpoint.tar", sr=sr, lr_max=lr_max)
+               out_chunk_size, logfilename, "modelcheckpoint.tar", sr=sr, lr_max=lr_max,
+               start_epoch=start_epoch, start_iter=start_iter, lr_resume=lr_resume)
     return model

@@ -11,19 +11,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """GPU-marked tests skip (instead of failing with 'No HIP GPUs') on a box without a GPU."""
+    try:
+        import torch
+        have = torch.cuda.is_available()
+    except Exception:
+        have = False
+    if have:
+        return
+    skip = pytest.mark.skip(reason="needs a ROCm GPU (torch.cuda.is_available() is False)")
+    for item in items:
+        if item.get_closest_marker("gpu") is not None:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
-
-
-@pytest.fixture(autouse=True)
-def _fp32_precision_after_gpu_test(request):
-    """st_set_precision is a process-wide switch of the HIP library: whatever a GPU test (or an engine it created) left it at,
-    the next test starts from the fp32 parity arithmetic again."""
-    yield
-    if request.node.get_closest_marker("gpu") is not None:
-        try:
-            from signaltrain_amd import _lib
-            _lib.load().st_set_precision(0)
-        except Exception:
-            pass

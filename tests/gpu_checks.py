@@ -46,8 +46,10 @@ def make_case(B=3, seed=0, scale=1, shrink=4, K=4, pert=7, scheme="lean"):
 
 
 def dims_of(geo, B, K):
+    """st_dims of the case; the arithmetic of the mode the checks currently run under (mixed_mode) travels in it."""
     d = _lib.st_dims()
     d.B, d.L, d.N, d.H, d.T, d.OT, d.F, d.K, d.y = B, geo["L"], geo["N"], geo["H"], geo["T"], geo["OT"], geo["F"], K, geo["y"]
+    d.prec, d.loss_scale, d.clip_all = PREC_LEVEL, LOSS_SCALE, int(CLIP_ALL)
     return d
 
 
@@ -64,37 +66,58 @@ def from_kp(a, F):
     return a[:, :F], a[:, KP // 2:KP // 2 + F]
 
 
-PREC_LEVEL = 0           # st_set_precision level the checks run under (bf16_mode sets it); re-asserted at the start of every run_*:
-                         # the switch is process-wide, and an engine created by another test may have left it elsewhere
-TOL_SCALE = 1.0          # multiplies every tolerance (mixed-precision runs: see bf16_mode)
+PREC_LEVEL = 0           # st_dims.prec the checks run under (mixed_mode sets it); carried per call, nothing process-wide
+LOSS_SCALE = 0.0         # st_dims.loss_scale (0 = none)
+CLIP_ALL = False         # st_dims.clip_all
+TOL_SCALE = 1.0          # multiplies every tolerance (mixed-precision runs: see mixed_mode)
 ENGINE_DTYPE = "f32"     # compute_dtype of the StepEngines the checks create
 
 
-class bf16_mode:
-    """Context: HIP library in bf16-operand mode + the oracle's matching bf16 rounding.  level 1: the STFT GEMMs; level 2:
-    also the nine Linear layers of both autoencoders (BF instantiations of st_ae.h / oracle.AE_ROUND; fused-kernel
-    geometries only).  Tolerances are widened (10x / 20x): both sides round the SAME quantities, but an operand that differs
-    by 1e-6 between the two can land on the other side of a bf16 rounding boundary (1 in ~4000 elements does, each then
-    differs by 0.4 %), and at level 2 those flips propagate through nine layers.  FUSED runs (device and oracle each consume
-    their own intermediates) need more: the oracle against itself under a 1e-6 perturbation differs by up to 1.4e-2 at level 2
-    (tools/bf16_noise_floor.py) -- FUSED_TOL below."""
-    FUSED_TOL = {1: 30.0, 2: 200.0}          # tol_scale for run_fused under the two levels (3e-3 / 2e-2)
+class mixed_mode:
+    """Context: the checks run with 16-bit operands in the HIP library (st_dims.prec) + the oracle's matching rounding.
+    level 1: the STFT GEMMs; level 2: also the nine Linear layers of both autoencoders (the BF instantiations of st_ae.h /
+    oracle.AE_ROUND).  half = "bf16" (BASELINE configs[2], [3]) or "f16" (configs[4]; runs with a loss scale and, like the
+    reference's Apex branch train.py:136, the clip over all parameters).  Tolerances are widened (10x / 20x): both sides round
+    the SAME quantities, but an operand that differs by 1e-6 between the two can land on the other side of a rounding boundary
+    (bf16: 1 in ~4000 elements does, each then differs by 0.4 %; fp16 has 3 more mantissa bits: 0.05 %), and at level 2 those
+    flips propagate through nine layers.  FUSED runs (device and oracle each consume their own intermediates) need more: the
+    oracle against itself under a 1e-6 perturbation differs by up to 1.4e-2 at bf16 level 2 (tools/bf16_noise_floor.py) --
+    FUSED_TOL below."""
+    FUSED_TOL = {1: 30.0, 2: 200.0}          # tol_scale for run_fused under the two levels (3e-3 / 2e-2), bf16
+    FUSED_TOL_F16 = {1: 10.0, 2: 40.0}       # fp16: 8x finer rounding
 
-    def __init__(self, level=1, tol_scale=None):
-        self.level = level
+    def __init__(self, level=1, tol_scale=None, half="bf16", loss_scale=None, clip_all=None):
+        assert half in ("bf16", "f16") and level in (1, 2)
+        self.level, self.half = level, half
         self.tol_scale = tol_scale          # override, e.g. the 65536-sample geometry at level 2 (174-frame rows: more flips per sum)
+        self.loss_scale = (4096.0 if half == "f16" else 0.0) if loss_scale is None else float(loss_scale)
+        self.clip_all = (half == "f16") if clip_all is None else bool(clip_all)
 
     def __enter__(self):
-        global TOL_SCALE, ENGINE_DTYPE, PREC_LEVEL
-        PREC_LEVEL = self.level
-        _lib.check(_lib.load().st_set_precision(self.level), "st_set_precision"); O.GEMM_ROUND = O.bf16_round
-        O.AE_ROUND = O.bf16_round if self.level >= 2 else None
-        TOL_SCALE = self.tol_scale if self.tol_scale else (10.0 if self.level == 1 else 20.0); ENGINE_DTYPE = "bf16" if self.level == 1 else "bf16_all"
+        global TOL_SCALE, ENGINE_DTYPE, PREC_LEVEL, LOSS_SCALE, CLIP_ALL
+        rnd = O.bf16_round if self.half == "bf16" else O.fp16_round
+        PREC_LEVEL = {("bf16", 1): 1, ("bf16", 2): 2, ("f16", 1): 3, ("f16", 2): 4}[(self.half, self.level)]
+        LOSS_SCALE, CLIP_ALL = self.loss_scale, self.clip_all
+        O.GEMM_ROUND = rnd
+        O.AE_ROUND = rnd if self.level >= 2 else None
+        O.LOSS_SCALE = self.loss_scale if self.loss_scale > 0 else 1.0
+        O.CLIP_ALL = self.clip_all
+        base = (10.0 if self.level == 1 else 20.0) if self.half == "bf16" else (3.0 if self.level == 1 else 6.0)
+        TOL_SCALE = self.tol_scale if self.tol_scale else base
+        ENGINE_DTYPE = self.half + ("" if self.level == 1 else "_all")
 
     def __exit__(self, *a):
-        global TOL_SCALE, ENGINE_DTYPE, PREC_LEVEL
-        PREC_LEVEL = 0
-        _lib.load().st_set_precision(0); O.GEMM_ROUND = None; O.AE_ROUND = None; TOL_SCALE = 1.0; ENGINE_DTYPE = "f32"
+        global TOL_SCALE, ENGINE_DTYPE, PREC_LEVEL, LOSS_SCALE, CLIP_ALL
+        PREC_LEVEL, LOSS_SCALE, CLIP_ALL = 0, 0.0, False
+        O.GEMM_ROUND = None; O.AE_ROUND = None; O.LOSS_SCALE = 1.0; O.CLIP_ALL = False; TOL_SCALE = 1.0; ENGINE_DTYPE = "f32"
+
+
+bf16_mode = mixed_mode       # round-1 name
+
+
+def new_engine(d, **kw):
+    """A StepEngine with the arithmetic of the current mode."""
+    return StepEngine(d, DEV, compute_dtype=ENGINE_DTYPE, loss_scale=(LOSS_SCALE if LOSS_SCALE > 0 else 1.0), clip_all=CLIP_ALL, **kw)
 
 
 def err(name, got, ref, tol=TOL, scale=None):
@@ -127,7 +150,6 @@ def phase_err(name, got, ref, mag, tol=TOL):
 def run_all(B=3, seed=0, K=4, verbose=False, scale=1, scheme="lean", shrink=4):
     """Run every per-op entry point on oracle-provided inputs; returns list of result dicts."""
     lib = _lib.load()
-    lib.st_set_precision(PREC_LEVEL)
     geo, X, Y, KN, P = make_case(B, seed, K=K, scale=scale, scheme=scheme, shrink=shrink)
     d = dims_of(geo, B, K)
     KP = lib.st_kp(d.F); F, T, OT, N = d.F, d.T, d.OT, d.N
@@ -220,7 +242,7 @@ def run_all(B=3, seed=0, K=4, verbose=False, scale=1, scheme="lean", shrink=4):
     dmag, dphs = z(B, T, F), z(B, T, F)
     aews = z(lib.st_ae_bwd_ws_floats(C.byref(d)))
     g_m, g_p = z(PG), z(lay.total - lay.offsets[22])
-    reg_coef = (2e-5 / 10) / (B * OT * F)
+    reg_coef = O.LOSS_SCALE * (2e-5 / 10) / (B * OT * F)            # the L1 term's gradient carries the loss scale like every other gradient
     _lib.check(lib.st_ae_bwd(C.byref(d), _lib.ptr(mag_o), _lib.ptr(phs_o), _lib.ptr(kn), _lib.ptr(ae_m), _lib.ptr(ae_p),
                              _lib.ptr(mh_o), _lib.ptr(ph_o), _lib.ptr(dAAo), None, reg_coef, _lib.ptr(dmag), _lib.ptr(dphs),
                              _lib.ptr(aews), _lib.ptr(g_m), _lib.ptr(g_p), stream()), "ae_bwd")
@@ -263,7 +285,7 @@ def run_fused(B=3, seed=1, K=4, steps=3, scale=1, scheme="lean", shrink=4):
     """Fused entry points: st_model_fwd, st_loss_backward, st_train_step x steps vs the oracle."""
     geo, X, Y, KN, P = make_case(B, seed, K=K, scale=scale, scheme=scheme, shrink=shrink)
     d = dims_of(geo, B, K)
-    eng = StepEngine(d, DEV, compute_dtype=ENGINE_DTYPE)
+    eng = new_engine(d)
     eng.load_state_dict(P)
     res = []
     P64 = {k: v.astype(np.float64) for k, v in P.items()}
@@ -279,10 +301,10 @@ def run_fused(B=3, seed=1, K=4, steps=3, scale=1, scheme="lean", shrink=4):
     for k in eng.layout.names:
         scale = ss["an"] if k in STFT_KEYS[:2] else ss["sy"] if k in STFT_KEYS[2:] else None
         res.append(err("grad." + k.replace("mpaec.", ""), n(g[k]), G[k], tol=2e-4, scale=scale))
-    l1 = sum(np.abs(G[k]).sum() for k in STFT_KEYS)
+    l1 = sum(np.abs(G[k]).sum() for k in STFT_KEYS) / O.LOSS_SCALE       # the published norm is that of the unscaled gradient
     res.append(err("step.l1norm", sc[3], l1, tol=1e-3))
     # training steps (train.py:131-151 ordering) vs oracle in float32 arithmetic
-    eng2 = StepEngine(d, DEV, compute_dtype=ENGINE_DTYPE); eng2.load_state_dict(P)
+    eng2 = new_engine(d); eng2.load_state_dict(P)
     Pq = {k: P[k].copy() for k in O.param_order()}
     Mq = {k: np.zeros_like(v) for k, v in Pq.items()}; Vq = {k: np.zeros_like(v) for k, v in Pq.items()}
     lrs, _ = O.get_1cycle_schedule(lr_max=1e-3, n_data_points=200, epochs=1, batch_size=2)

@@ -1,7 +1,11 @@
 """CPU, world_size 2, gloo: the data-parallel step (dp.DataParallel) -- shard, bucketed sum all-reduce of the flat
 gradient, 1/world scaling, clip AFTER the reduction, replicated Adam -- gives the same parameters as one process
-on the global batch.  The per-rank 'engine' here is the oracle (no GPU in this container); the HIP engine exposes
-the same four methods and is exercised by the driver's multi-GPU bench."""
+on the global batch.  The per-rank 'engine' here is the oracle (no GPU in this container) behind the SAME protocol as
+signaltrain_amd.engine.StepEngine: phase 1 publishes only the ranges that are final after it (synthesis bases + autoencoders),
+phase 2 the analysis weight gradient -- into grads AND packed into the staging buffer the second all-reduce moves -- and
+finish_buckets copies the reduced rows back; a range that is all-reduced before its phase has run, or a missing copy-back,
+changes the result.  The HIP engine runs the same protocol on the GPU (test_dp_collective_path_single_rank) and from C
+(st_dp_train_step)."""
 import os
 import numpy as np
 import pytest
@@ -31,34 +35,54 @@ class OracleEngine:
             out[k] = flat[o:o + n].numpy().reshape(shp) if shp else flat[o:o + n].numpy(); o += n
         return out
 
-    def loss_backward_p1(self, x, knobs, y):
+    N2, LIVE = 1 << 20, 513 * 1024
+
+    def _backward(self, x, knobs, y):
         P = self._dict(self.params)
         shapes = {k: v.shape for k, v in O.init_params(self.geo, 4).items()}
         P = {k: P[k].reshape(shapes[k]) for k in P}
         loss, G, _ = O.model_loss_bwd(x.numpy(), knobs.numpy(), y.numpy(), P, self.geo)
-        self.grads.copy_(torch.from_numpy(np.concatenate([G[k].ravel() for k in self.keys]).astype(np.float32)))
         self.scalars[0] = float(loss)
+        return torch.from_numpy(np.concatenate([G[k].ravel() for k in self.keys]).astype(np.float32))
+
+    def loss_backward_p1(self, x, knobs, y):
+        """Forward + backward up to (excluding) the analysis weight gradient: only grads[2 N^2:] is final afterwards; the
+        analysis range holds garbage until phase 2 (as on the device, where it still holds the previous step's values)."""
+        full = self._backward(x, knobs, y)
+        self._analysis = full[:2 * self.N2].clone()
+        self.grads[2 * self.N2:] = full[2 * self.N2:]
+        self.grads[:2 * self.N2] = float("nan")
 
     def loss_backward_p2(self):
-        pass
+        """Analysis weight gradient: rows [0,F) of both bases into grads and packed into the staging buffer [2F][N]."""
+        n, live = self.N2, self.LIVE
+        self.grads[:2 * n] = self._analysis
+        if getattr(self, "stage", None) is None:
+            self.stage = torch.zeros(2 * live)
+        self.stage[:live] = self.grads[0:live]; self.stage[live:] = self.grads[n:n + live]
 
     N_STAGES = 4
 
     def loss_backward_stage(self, stage, x=None, knobs=None, y=None):
-        if stage == 0:                                  # the oracle has no stages: everything is final after the first
-            self.loss_backward_p1(x, knobs, y)
+        """Four stages, each leaving stage_bucket(stage) final (the others are poisoned until their stage has run)."""
+        n, live = self.N2, self.LIVE
+        if stage == 0:
+            self._full = self._backward(x, knobs, y)
+            self.grads[:] = float("nan")
+        lo, hi = ((2 * n, 4 * n), (4 * n, self.grads.numel()), (0, n), (n, 2 * n))[stage]
+        self.grads[lo:hi] = self._full[lo:hi]
 
     def stage_bucket(self, stage):
-        n, live, e = 1 << 20, 513 * 1024, self.grads.numel()
+        n, live, e = self.N2, self.LIVE, self.grads.numel()
         return (self.grads[2 * n:4 * n], self.grads[4 * n:e], self.grads[0:live], self.grads[n:n + live])[stage]   # as StepEngine.stage_bucket
 
     def grad_buckets(self):
-        n, live = 1 << 20, 513 * 1024                                        # as StepEngine.grad_buckets(): a packed staging copy of the live analysis rows
-        self.stage = torch.cat([self.grads[0:live], self.grads[n:n + live]]).clone()
-        return [self.grads[2 * n:], self.stage]
+        if getattr(self, "stage", None) is None:
+            self.stage = torch.zeros(2 * self.LIVE)
+        return [self.grads[2 * self.N2:], self.stage]                       # as StepEngine.grad_buckets(): [synthesis + autoencoders], packed live analysis rows
 
     def finish_buckets(self):
-        n, live = 1 << 20, 513 * 1024
+        n, live = self.N2, self.LIVE
         self.grads[0:live] = self.stage[:live]; self.grads[n:n + live] = self.stage[live:]
 
     def clip_adam(self, lr, grad_scale=1.0, **kw):
@@ -121,4 +145,5 @@ def test_dp_world2_equals_single_process_on_global_batch(schedule):
         ref.train_step(torch.from_numpy(X), torch.from_numpy(KN), torch.from_numpy(Y), 1e-3)
     # fp32 reassociation tolerance: <= 1e-5 on the parameters after the steps
     assert np.abs(got - ref.params.numpy()).max() < 1e-5
-    assert abs(loss2 - float(ref.scalars[0])) < 1e-4 * abs(float(ref.scalars[0])) + 1e-7 or True
+    # mean_loss() = the global-batch loss of the LAST step = the single-process loss on the global batch (both terms are means over equal shards)
+    assert abs(loss2 - float(ref.scalars[0])) < 1e-4 * abs(float(ref.scalars[0])) + 1e-7, (loss2, float(ref.scalars[0]))

@@ -58,8 +58,111 @@ def test_autograd_matches_golden_backward(golden_dir):
         sc = np.abs(g4["rows_" + k]).max()
         assert np.abs(gk[SAMPLE_ROWS] - g4["rows_" + k]).max() <= 2e-4 * sc
         assert np.abs(PROJ @ gk - g4["proj_" + k]).max() <= 2e-4 * np.abs(g4["proj_" + k]).max()
-    m.clip_grad_norm_()                                              # nn_proc.py:299-302 on the torch side
-    n = sum(float(m.state_dict()[k].new_tensor(0)) for k in [])      # no-op; the call above must simply work
+    # nn_proc.py:299-302 on the torch side: G4's norm is 0.216 (< 1), so the clip must leave the gradients untouched
+    l1 = sum(float(dict(m.named_parameters())[k].grad.abs().sum()) for k in STFT_KEYS)
+    assert abs(l1 - float(g4["clip_norm"])) <= 1e-3 * float(g4["clip_norm"])
+    before = {k: dict(m.named_parameters())[k].grad.clone() for k in STFT_KEYS}
+    m.clip_grad_norm_()
+    for k in STFT_KEYS:
+        assert torch.equal(dict(m.named_parameters())[k].grad, before[k]), k
+
+
+def test_autograd_and_torch_clip_match_golden_active_clip(golden_dir):
+    """Golden G4b (captured from the reference with clip_grad_norm_ ACTIVE: norm 2.71 -> coefficient 0.369): loss.backward()
+    through the drop-in model, then model.clip_grad_norm_() (nn_proc.py:299-302) -- the clipped .grad of the four STFT tensors
+    against the reference's clipped gradients, the autoencoder gradients untouched."""
+    from signaltrain_amd import loss_functions
+    from tests.golden_util import ae_keys, projections, SAMPLE_ROWS, STFT_KEYS
+    m, g, P, geo = _golden_model(golden_dir)
+    gb = np.load(os.path.join(golden_dir, "g4b_backward_clip.npz"))
+    x, kn, yt = (torch.from_numpy(gb[k]).cuda() for k in ("x", "knobs", "y"))
+    y, mag, mag_hat = m.forward(x, kn)
+    sbf = torch.exp((7. / 513) * torch.arange(0., 513, device="cuda")).expand_as(mag_hat).float()
+    loss = loss_functions.calc_loss(y, yt, mag_hat, scale_by_freq=sbf)
+    loss.backward()
+    assert abs(loss.item() - float(gb["loss"])) <= 1e-4 * abs(float(gb["loss"]))
+    named = dict(m.named_parameters())
+    l1 = sum(float(named[k].grad.abs().sum()) for k in STFT_KEYS)
+    assert abs(l1 - float(gb["clip_norm"])) <= 1e-3 * float(gb["clip_norm"]) and l1 > 1.5
+    m.clip_grad_norm_()
+    PROJ = projections(seed=11)
+    for k in STFT_KEYS:
+        gk = named[k].grad.detach().cpu().numpy().astype(np.float64)[:, 0, :]
+        sc = np.abs(gb["clipped_rows_" + k]).max()
+        assert np.abs(gk[SAMPLE_ROWS] - gb["clipped_rows_" + k]).max() <= 1e-3 * sc, k
+        assert np.abs(PROJ @ gk - gb["clipped_proj_" + k]).max() <= 1e-3 * np.abs(gb["clipped_proj_" + k]).max(), k
+    l1c = sum(float(named[k].grad.abs().sum()) for k in STFT_KEYS)
+    assert abs(l1c - 1.0) <= 2e-3                                    # clipped to max_norm = 1
+    for k in ae_keys():
+        ref = gb["g_" + k]
+        assert np.abs(named[k].grad.detach().cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-12, k
+
+
+def test_fused_step_matches_golden_active_clip(golden_dir):
+    """Goldens G4b / G5b through the FUSED step (st_train_step: clip coefficient and Adam inside clip_adam_kernel): the norm and
+    coefficient the kernel derived, and the parameters after each of three steps, against the reference's own run."""
+    from signaltrain_amd.engine import StepEngine
+    from tests.golden_util import ae_keys, projections, SAMPLE_ROWS, STFT_KEYS
+    m, g, P, geo = _golden_model(golden_dir)
+    gb = np.load(os.path.join(golden_dir, "g4b_backward_clip.npz")); g5 = np.load(os.path.join(golden_dir, "g5b_adam_clip.npz"))
+    eng = StepEngine(m.engine(torch.zeros(3, 8192, device="cuda")).dims, "cuda:0"); eng.load_state_dict(P)
+    kn = torch.from_numpy(gb["knobs"]).cuda()
+    PROJ = projections(seed=11)
+    for it in range(3):
+        Xi = np.roll(gb["x"], 23 * it, axis=1).copy(); Yi = np.roll(gb["y"], 23 * it, axis=1).copy()
+        eng.train_step(torch.from_numpy(Xi).cuda(), kn, torch.from_numpy(Yi).cuda(), float(g5[f"lr_used{it}"]))
+        sc = eng.scalars.cpu().numpy()
+        assert abs(sc[0] - float(g5[f"loss{it}"])) <= 1e-4 * abs(float(g5[f"loss{it}"])), it
+        nref = float(g5[f"clip_norm{it}"])
+        assert abs(sc[3] - nref) <= 1e-3 * nref and abs(sc[4] - 1.0 / (nref + 1e-6)) <= 1e-3 and sc[4] < 0.9, (it, sc[3], nref)
+        if it == 0:
+            assert abs(sc[3] - float(gb["clip_norm"])) <= 1e-3 * float(gb["clip_norm"]) and abs(sc[4] - float(gb["clip_coef"])) <= 1e-3
+            # the clipped gradient is observable in the reference (p.grad after clip_grad_norm_): the fused step leaves it in grads
+            for k in STFT_KEYS:
+                gk = eng.named_grads[k].cpu().numpy().astype(np.float64)[:, 0, :]
+                assert np.abs(gk[SAMPLE_ROWS] - gb["clipped_rows_" + k]).max() <= 1e-3 * np.abs(gb["clipped_rows_" + k]).max(), k
+        for k in ae_keys():
+            assert np.abs(eng.named[k].cpu().numpy() - g5[f"s{it}_" + k]).max() <= 5e-6, (it, k)
+        for k in STFT_KEYS:
+            w = eng.named[k].cpu().numpy()
+            assert np.abs(w[SAMPLE_ROWS, 0, :] - g5[f"s{it}_rows_" + k]).max() <= 5e-6, (it, k)
+            ref = g5[f"s{it}_proj_" + k]
+            assert np.abs(PROJ @ w[:, 0, :].astype(np.float64) - ref).max() <= 1e-5 * np.abs(ref).max(), (it, k)
+
+
+def test_second_forward_before_backward_is_safe(golden_dir):
+    """the saved-for-backward state lives in the engine's single workspace; a validation forward (or another
+    micro-batch) between forward and backward must not corrupt the gradients -- the stale stamp makes backward recompute."""
+    from signaltrain_amd import loss_functions
+    m, g, P, geo = _golden_model(golden_dir)
+    x, kn, yt = (torch.from_numpy(g[k]).cuda() for k in ("x", "knobs", "y"))
+    sbf = None
+    def run(disturb):
+        m.zero_grad()
+        y, mag, mag_hat = m.forward(x, kn)
+        if disturb:
+            with torch.no_grad():
+                m.forward(torch.flip(x, dims=[1]) * 0.3, -kn)        # another forward reuses the workspace
+        sb = torch.exp((7. / 513) * torch.arange(0., 513, device="cuda")).expand_as(mag_hat).float()
+        loss_functions.calc_loss(y, yt, mag_hat, scale_by_freq=sb).backward()
+        return {k: p.grad.clone() for k, p in m.named_parameters()}
+    a, b = run(False), run(True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    # gradient accumulation over two micro-batches == the sum of the separate gradients
+    m.zero_grad()
+    outs = [m.forward(x[i:i + 1], kn[i:i + 1]) for i in range(2)]
+    tot = sum((o[0] * (i + 1.0)).sum() for i, o in enumerate(outs))
+    tot.backward()
+    acc = {k: p.grad.clone() for k, p in m.named_parameters()}
+    ref = None
+    for i in range(2):
+        m.zero_grad()
+        (m.forward(x[i:i + 1], kn[i:i + 1])[0] * (i + 1.0)).sum().backward()
+        cur = {k: p.grad.clone() for k, p in m.named_parameters()}
+        ref = cur if ref is None else {k: ref[k] + cur[k] for k in cur}
+    for k in acc:
+        assert (acc[k] - ref[k]).abs().max().item() <= 1e-6 * max(ref[k].abs().max().item(), 1e-12), k
 
 
 def test_reference_style_loop_equals_fused_step(golden_dir):
@@ -108,6 +211,20 @@ def test_train_driver_short_run(tmp_path):
         sd, rv = misc.load_checkpoint("modelcheckpoint.tar", device="cpu")
         assert len(sd) == 40 and rv["in_chunk_size"] == 8192 and rv["out_chunk_size"] == 2048
         assert all(torch.isfinite(v).all() for v in sd.values())
+        # the 'optimizer' entry is a torch.optim.Adam state_dict (the reference's layout): torch loads it, and it is restored on resume
+        ref_opt = torch.optim.Adam(model.parameters(), lr=1.0)
+        ref_opt.load_state_dict(rv["optimizer"])
+        steps0 = int(float(rv["optimizer"]["state"][0]["step"]))
+        assert steps0 == 256 // 32 and rv["epoch"] == 1
+        eng = model.engine(torch.zeros(32, 8192, device="cuda"))
+        m_before = eng.m.clone()
+        assert float(m_before.abs().max()) > 0
+        model2 = train.train(effect=audio.Compressor_4c(), epochs=2, n_data_points=256, batch_size=32,
+                             device=torch.device("cuda:0"), num_workers=2)        # resumes from modelcheckpoint.tar
+        eng2 = model2.engine(torch.zeros(32, 8192, device="cuda"))
+        assert eng2.step_count == 2 * steps0                          # epoch 2 only: optimizer step count and epoch counter continued
+        sd2, rv2 = misc.load_checkpoint("modelcheckpoint.tar", device="cpu")
+        assert rv2["epoch"] == 2 and int(float(rv2["optimizer"]["state"][0]["step"])) == 2 * steps0
     finally:
         os.chdir(cwd)
 
@@ -414,7 +531,5 @@ def test_train_driver_bf16_all(tmp_path):
             traj[dt] = np.array([float(l.split()[-1]) for l in open("vl_avg_out.dat").read().strip().splitlines()])
     finally:
         os.chdir(cwd)
-        from signaltrain_amd import _lib
-        _lib.load().st_set_precision(0)               # the switch is process-wide: do not leak bf16 into the tests that follow
     assert len(traj["f32"]) >= 4 and np.all(np.isfinite(traj["bf16_all"]))
     assert np.all(np.abs(traj["bf16_all"] - traj["f32"]) <= 0.05 * np.abs(traj["f32"])), traj

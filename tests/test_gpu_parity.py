@@ -114,7 +114,7 @@ def test_full_size_batch_properties():
 
 @pytest.mark.parametrize("B,seed,K", [(3, 0, 4), (5, 2, 3)])
 def test_bf16_mode_per_op(B, seed, K):
-    """st_set_precision(1): bf16 operands / fp32 accumulation in the STFT GEMMs (BASELINE configs[2], [3]) against the
+    """st_dims.prec = ST_PREC_BF16: bf16 operands / fp32 accumulation in the STFT GEMMs (BASELINE configs[2], [3]) against the
     oracle with the SAME operands rounded to bfloat16 (oracle.GEMM_ROUND): per-op agreement stays at the 1e-6 level
     because both sides round identical inputs."""
     from tests import gpu_checks as G
@@ -140,8 +140,8 @@ def test_bf16_mode_fused_step_and_differs_from_fp32():
 
 
 def test_bf16_mode_scale8():
-    """Geometry of BASELINE configs[4] (65536-sample window) with 16-bit GEMM operands: bf16 is the MI355X-native 16-bit type
-    (same MFMA rate as fp16, no loss scaling needed), so it stands in for that configuration's fp16 mixed precision."""
+    """Geometry of BASELINE configs[4] (65536-sample window) with bf16 GEMM operands (the fp16 arithmetic that configuration
+    names is test_f16_*_scale8 below)."""
     from tests import gpu_checks as G
     with G.bf16_mode():
         _assert_ok(G.run_all(B=1, seed=3, K=4, scale=8))
@@ -151,7 +151,7 @@ def test_bf16_mode_scale8():
 
 @pytest.mark.parametrize("B,seed,K", [(3, 0, 4), (2, 5, 7), (1, 9, 16)])
 def test_bf16_all_mode_per_op(B, seed, K):
-    """st_set_precision(2): bf16 operands also in the nine Linear layers of both autoencoders (forward, data gradient, weight
+    """st_dims.prec = ST_PREC_BF16_ALL: bf16 operands also in the nine Linear layers of both autoencoders (forward, data gradient, weight
     gradient: the BF instantiations of st_ae.h, one v_mfma_f32_16x16x16_bf16 per tile) against the oracle with the same
     operands rounded to bfloat16 (oracle.AE_ROUND)."""
     from tests import gpu_checks as G
@@ -189,3 +189,100 @@ def test_bf16_all_mode_scale8():
         _assert_ok(G.run_all(B=2, seed=3, K=4, scale=8))
     with G.bf16_mode(2, tol_scale=G.bf16_mode.FUSED_TOL[2]):
         _assert_ok(G.run_fused(B=2, seed=1, K=4, steps=2, scale=8))
+
+
+# ------------------------------------------------------------------------------------------------ fp16 (BASELINE configs[4])
+@pytest.mark.parametrize("level,B,seed,K,scale", [(1, 3, 0, 4, 1), (2, 3, 0, 4, 1), (2, 2, 5, 7, 1), (1, 1, 3, 4, 8), (2, 2, 3, 4, 8)])
+def test_f16_mode_per_op(level, B, seed, K, scale):
+    """st_dims.prec = ST_PREC_F16 / ST_PREC_F16_ALL with loss scale 4096: float16 operands (saturating conversion), fp32
+    accumulation -- every per-op entry point against the oracle with the same operands rounded to IEEE half
+    (oracle.fp16_round) and the same loss scale on the gradient operands; scale 8 = the 65536-sample window of configs[4]."""
+    from tests import gpu_checks as G
+    with G.mixed_mode(level, half="f16"):
+        _assert_ok(G.run_all(B=B, seed=seed, K=K, scale=scale))
+
+
+@pytest.mark.parametrize("level,scale,B", [(1, 1, 3), (2, 1, 3), (2, 8, 2)])
+def test_f16_fused_step_with_loss_scale(level, scale, B):
+    """The mixed-precision train step as the reference runs it under Apex (train.py:133-136): loss scaled by S = 4096 before
+    the backward, gradients unscaled inside the optimizer kernel, L1 clip over ALL parameters -- against the oracle doing the
+    same; no step may be skipped (overflow counter stays 0)."""
+    import torch
+    from tests import gpu_checks as G
+    with G.mixed_mode(level, half="f16", tol_scale=G.mixed_mode.FUSED_TOL_F16[level] * (2.0 if scale == 8 else 1.0)):
+        _assert_ok(G.run_fused(B=B, seed=1, K=4, steps=2, scale=scale))
+
+
+def test_f16_overflow_skips_the_step_and_counts_it():
+    """A loss scale large enough to overflow the fp16 gradient operands (inf -> non-finite L1 norm) must leave parameters and moments untouched and bump
+    the overflow counter (scalars[5]) -- the signal Apex's dynamic loss scaler acts on; with a sane scale the step goes through
+    and the result does not depend on the scale beyond rounding."""
+    import torch
+    from tests import gpu_checks as G
+    from signaltrain_amd.engine import StepEngine
+    geo, X, Y, KN, P = G.make_case(3, 2, K=4)
+    d = G.dims_of(geo, 3, 4)
+    x, kn, y = G.t(X), G.t(KN), G.t(Y)
+    eng = StepEngine(d, G.DEV, compute_dtype="f16_all", loss_scale=3.0e38); eng.load_state_dict(P)
+    before = eng.params.clone()
+    eng.train_step(x, kn, y, 1e-3); torch.cuda.synchronize()
+    assert eng.overflow_steps(reset=False) == 1
+    assert torch.equal(eng.params, before) and float(eng.m.abs().max()) == 0.0 and float(eng.v.abs().max()) == 0.0
+    assert eng.overflow_steps() == 1 and eng.overflow_steps() == 0
+    outs = []
+    for S in (1024.0, 8192.0):
+        e = StepEngine(d, G.DEV, compute_dtype="f16_all", loss_scale=S); e.load_state_dict(P)
+        e.train_step(x, kn, y, 1e-3); torch.cuda.synchronize()
+        assert e.overflow_steps() == 0 and torch.isfinite(e.params).all()
+        outs.append(e.params.clone())
+    assert (outs[0] - before).abs().max().item() > 1e-5                       # a real update happened
+    assert (outs[0] - outs[1]).abs().max().item() <= 2e-4                     # Adam turns rounding-level differences into fractions of lr at worst
+
+
+def test_engines_of_different_precision_coexist():
+    """Precision is carried per call (st_dims.prec), not process-wide: interleaving a bf16_all, an f16_all and an f32 engine
+    leaves the f32 engine's results bit-identical to running alone."""
+    import torch
+    from tests import gpu_checks as G
+    from signaltrain_amd.engine import StepEngine
+    geo, X, Y, KN, P = G.make_case(3, 4, K=4)
+    d = G.dims_of(geo, 3, 4)
+    x, kn, y = G.t(X), G.t(KN), G.t(Y)
+    alone = StepEngine(d, G.DEV); alone.load_state_dict(P)
+    for _ in range(2):
+        alone.train_step(x, kn, y, 1e-3)
+    e32 = StepEngine(d, G.DEV); e32.load_state_dict(P)
+    eb = StepEngine(d, G.DEV, compute_dtype="bf16_all"); eb.load_state_dict(P)
+    eh = StepEngine(d, G.DEV, compute_dtype="f16_all"); eh.load_state_dict(P)
+    for _ in range(2):
+        eb.train_step(x, kn, y, 1e-3); e32.train_step(x, kn, y, 1e-3); eh.train_step(x, kn, y, 1e-3)
+    torch.cuda.synchronize()
+    assert torch.equal(alone.params, e32.params) and torch.equal(alone.scalars[:5], e32.scalars[:5])
+    assert not torch.equal(eb.params, e32.params) and not torch.equal(eh.params, e32.params) and not torch.equal(eh.params, eb.params)
+
+
+def test_engine_on_a_non_current_device_or_stream():
+    """The engine launches on ITS device's current stream whatever device is current: with one GPU, a side stream
+    made current for the engine's device must carry the work (the default stream stays idle, results identical); with two GPUs
+    an engine on cuda:1 works while cuda:0 is current."""
+    import torch
+    from tests import gpu_checks as G
+    from signaltrain_amd.engine import StepEngine
+    geo, X, Y, KN, P = G.make_case(2, 6, K=4)
+    d = G.dims_of(geo, 2, 4)
+    ref = StepEngine(d, G.DEV); ref.load_state_dict(P)
+    ref.train_step(G.t(X), G.t(KN), G.t(Y), 1e-3); torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=G.DEV)
+    e = StepEngine(d, G.DEV); e.load_state_dict(P)
+    x, kn, y = G.t(X), G.t(KN), G.t(Y)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        e.train_step(x, kn, y, 1e-3)
+    side.synchronize()
+    assert torch.equal(e.params, ref.params)
+    if torch.cuda.device_count() >= 2:
+        e1 = StepEngine(d, "cuda:1"); e1.load_state_dict(P)
+        assert torch.cuda.current_device() == 0
+        e1.train_step(torch.from_numpy(X).to("cuda:1"), torch.from_numpy(KN).to("cuda:1"), torch.from_numpy(Y).to("cuda:1"), 1e-3)
+        torch.cuda.synchronize("cuda:1")
+        assert torch.equal(e1.params.cpu(), ref.params.cpu())

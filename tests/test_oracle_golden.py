@@ -202,3 +202,141 @@ def test_perfect_reconstruction_at_init():
     re, im = O.analysis_fwd(x, P[STFT_KEYS[0]], P[STFT_KEYS[1]], geo)
     syn = O.synthesis_fwd(re[:, geo["T"] - geo["OT"]:], im[:, geo["T"] - geo["OT"]:], P[STFT_KEYS[2]], P[STFT_KEYS[3]], geo)
     assert np.max(np.abs(syn - x[:, geo["L"] - geo["y"]:])) < 5e-6
+
+
+# ------------------------------------------------------------------------------------------------ round-2 goldens
+def test_g4b_backward_with_active_clip(golden_dir):
+    """The reference's clip_grad_norm_ with n > 1 (nn_proc.py:299-302; norm 2.71 -> coefficient 0.369): the oracle's clip
+    branch against the reference's own clipped gradients (G4 ran with coefficient 1.0)."""
+    g = load(golden_dir, "g4b_backward_clip.npz")
+    assert float(g["clip_norm"]) > 1.5 and float(g["clip_coef"]) < 0.7
+    geo = O.geometry(1, 4)
+    P = golden_params(golden_dir, geo)
+    loss, G, _ = O.model_loss_bwd(g["x"].astype(np.float64), g["knobs"].astype(np.float64), g["y"].astype(np.float64), P, geo)
+    close(loss, g["loss"], 3e-5, "loss")
+    for k in ae_keys():
+        close(G[k], g["g_" + k], 2e-5, k)
+    PROJ = projections(seed=11)
+    for k in STFT_KEYS:
+        close(G[k][SAMPLE_ROWS, 0, :], g["rows_" + k], 2e-5, "rows " + k)
+        close(PROJ @ G[k][:, 0, :], g["proj_" + k], 2e-5, "proj " + k)
+    G32 = {k: v.astype(np.float32) for k, v in G.items()}
+    n, coef = O.clip_l1_stft(G32)
+    # sum |g| over 4 M fp32 values depends on the summation order at ~1.5e-4 (torch's fp32 reduction vs a float64 sum)
+    close(n, g["clip_norm"], 1e-3, "clip norm"); close(coef, g["clip_coef"], 1e-3, "clip coef")
+    for k in STFT_KEYS:
+        close(G32[k][SAMPLE_ROWS, 0, :], g["clipped_rows_" + k], 1e-3, "clipped rows " + k)
+        close(PROJ @ G32[k][:, 0, :].astype(np.float64), g["clipped_proj_" + k], 1e-3, "clipped proj " + k)
+        close(np.abs(G32[k]).sum(), g["clipped_l1_" + k], 1e-3, "clipped l1 " + k)
+    for k in ae_keys():                                            # the autoencoder gradients are NOT clipped on this path
+        np.testing.assert_array_equal(G32[k], G[k].astype(np.float32))
+
+
+def test_g5b_adam_steps_with_active_clip(golden_dir):
+    g4b = load(golden_dir, "g4b_backward_clip.npz"); g = load(golden_dir, "g5b_adam_clip.npz")
+    geo = O.geometry(1, 4)
+    P = golden_params(golden_dir, geo)
+    P = {k: P[k].copy() for k in O.param_order()}
+    M = {k: np.zeros_like(v) for k, v in P.items()}; V = {k: np.zeros_like(v) for k, v in P.items()}
+    lrs, _ = O.get_1cycle_schedule(lr_max=1e-3, n_data_points=300, epochs=1, batch_size=3)
+    np.testing.assert_allclose(lrs[:4], g["lrs"], rtol=1e-14)
+    PROJ = projections(seed=11)
+    lr = lrs[0]
+    for it in range(3):
+        Xi = np.roll(g4b["x"], 23 * it, axis=1).copy(); Yi = np.roll(g4b["y"], 23 * it, axis=1).copy()
+        assert lr == g[f"lr_used{it}"]
+        loss, norm, coef = O.train_step(Xi, g4b["knobs"], Yi, P, M, V, it + 1, lr, geo)
+        lr = lrs[it]
+        assert float(g[f"clip_norm{it}"]) > 1.2 and coef < 0.9                   # the clip acts on every step
+        close(loss, g[f"loss{it}"], 3e-5, f"loss{it}"); close(norm, g[f"clip_norm{it}"], 1e-3, f"norm{it}")
+        for k in ae_keys():
+            np.testing.assert_allclose(P[k], g[f"s{it}_" + k], rtol=0, atol=3e-6, err_msg=k)
+        for k in STFT_KEYS:
+            np.testing.assert_allclose(P[k][SAMPLE_ROWS, 0, :], g[f"s{it}_rows_" + k], rtol=0, atol=3e-6)
+            close(PROJ @ P[k][:, 0, :].astype(np.float64), g[f"s{it}_proj_" + k], 1e-5, "proj")
+
+
+def test_mixed_precision_switches_of_the_oracle():
+    """fp16 operand rounding is IEEE (overflow -> inf, like Apex amp); the loss scale multiplies every gradient and train_step removes it;
+    CLIP_ALL widens the clip to every parameter (train.py:136)."""
+    a = np.array([1e6, -1e6, 0.1, 65504.0, 1e-9], np.float32)
+    r = O.fp16_round(a)
+    assert np.isposinf(r[0]) and np.isneginf(r[1]) and r[3] == 65504 and abs(r[2] - 0.1) < 1e-4 and r[4] == 0
+    geo = O.geometry(1, 4)
+    rng = np.random.default_rng(5)
+    P = O.init_params(geo, 4, rng); perturb_stft(P, seed=3)
+    X, Y, KN = O.synth_comp4c_batch(1, geo["L"], geo["y"], rng)
+    l0, G0, _ = O.model_loss_bwd(X, KN, Y, P, geo)
+    try:
+        O.LOSS_SCALE = 1024.0
+        l1, G1, _ = O.model_loss_bwd(X, KN, Y, P, geo)
+    finally:
+        O.LOSS_SCALE = 1.0
+    assert l1 == l0
+    for k in G0:
+        close(G1[k] / 1024.0, G0[k], 1e-5, k)
+    Gc = {k: v.copy() * 50 for k, v in G0.items()}
+    n_stft, _ = O.clip_l1_stft({k: v.copy() for k, v in Gc.items()})
+    n_all, c_all = O.clip_l1_stft(Gc, all_params=True)
+    assert n_all > n_stft and c_all < 1
+    k = "mpaec.aenc.fnn_enc.weight"
+    close(Gc[k], G0[k] * 50 * np.float32(c_all), 1e-6, "AE gradient clipped under all_params")
+
+
+def test_g10_reference_checkpoint_layout(golden_dir, tmp_path):
+    """A checkpoint with exactly the layout the reference's misc.save_checkpoint wrote (header G10: top-level keys, the 40
+    state_dict tensors, torch.optim.Adam's per-parameter state) loads through signaltrain_amd.misc and st_model.load_state_dict,
+    the optimizer state converts to the engine's flat moments and back, and a checkpoint written by signaltrain_amd.misc has the
+    same layout.  (The reference-written 50 MB file itself was read by these functions in tools/capture_golden_r2.py.)"""
+    import torch
+    from signaltrain_amd import misc, nn_proc
+    nn_proc._QUIET = True
+    g = load(golden_dir, "g10_checkpoint.npz")
+    assert tuple(g["top_keys"]) == misc.CKPT_KEYS
+    assert list(g["opt_top_keys"]) == ["state", "param_groups"] and list(g["opt_state_keys"]) == ["step", "exp_avg", "exp_avg_sq"]
+    geo = O.geometry(1, 4)
+    names = [str(k) for k in g["sd_keys"]]
+    assert names == O.param_order() and len(names) == 40 and set(g["sd_dtypes"]) == {"torch.float32"}
+    # rebuild the file in the reference's layout: sampled tensors from the fixture, the 4 MB bases regenerated
+    P = golden_params(golden_dir, geo)
+    shapes = [tuple(int(v) for v in s.split(",")) for s in g["sd_shapes"]]
+    sd, st = {}, {}
+    for i, (k, shp) in enumerate(zip(names, shapes)):
+        if k in STFT_KEYS:
+            w = P[k].copy(); m = np.zeros(shp, np.float32); v = np.zeros(shp, np.float32)
+            m[SAMPLE_ROWS, 0, :] = g["m_rows_" + k]; v[SAMPLE_ROWS, 0, :] = g["v_rows_" + k]
+        else:
+            w, m, v = g["p_" + k], g["m_" + k], g["v_" + k]
+        assert w.shape == shp and tuple(g["opt_state_shapes"][i].split(",")) == tuple(str(s) for s in shp)
+        sd[k] = torch.from_numpy(np.ascontiguousarray(w))
+        st[i] = {"step": torch.tensor(float(g["opt_step"])), "exp_avg": torch.from_numpy(m), "exp_avg_sq": torch.from_numpy(v)}
+    group = {k: None for k in g["opt_group_keys"]}
+    group.update(lr=float(g["opt_lr"]), betas=tuple(g["opt_betas"]), eps=float(g["opt_eps"]), params=[int(i) for i in g["opt_group_params"]])
+    blob = {"epoch": int(g["epoch"]), "state_dict": sd, "optimizer": {"state": st, "param_groups": [group]},
+            "effect_name": str(g["effect_name"]), "knob_names": [str(s) for s in g["knob_names"]], "knob_ranges": g["knob_ranges"],
+            "scale_factor": int(g["scale_factor"]), "shrink_factor": int(g["shrink_factor"]), "in_chunk_size": int(g["in_chunk_size"]),
+            "out_chunk_size": int(g["out_chunk_size"]), "sr": int(g["sr"])}
+    f = str(tmp_path / "modelcheckpoint.tar")
+    torch.save(blob, f)
+    sd2, rv = misc.load_checkpoint(f, device="cpu")
+    assert rv["epoch"] == 42 and rv["in_chunk_size"] == 8192 and rv["out_chunk_size"] == 2048 and rv["knob_ranges"].shape == (4, 2)
+    model = nn_proc.st_model(scale_factor=rv["scale_factor"], shrink_factor=rv["shrink_factor"], num_knobs=len(rv["knob_names"]), sr=rv["sr"])
+    model.load_state_dict(sd2)                                       # strict: all 40 keys, shapes of the reference
+    flat = misc.flatten_optimizer_state(rv["optimizer"], shapes)
+    assert flat is not None and flat["step"] == 3 and flat["lr"] == float(g["opt_lr"]) and len(flat["exp_avg"]) == 40
+    k = "mpaec.phs_aenc.fnn_dec.weight"
+    np.testing.assert_array_equal(flat["exp_avg"][names.index(k)], g["m_" + k].ravel())
+    # ... and back: torch.optim.Adam accepts what the engine side emits
+    osd = misc.adam_state_dict(flat["step"], flat["lr"], [torch.from_numpy(a.reshape(s)) for a, s in zip(flat["exp_avg"], shapes)],
+                               [torch.from_numpy(a.reshape(s)) for a, s in zip(flat["exp_avg_sq"], shapes)])
+    opt = torch.optim.Adam(model.parameters(), lr=1.0)
+    opt.load_state_dict(osd)
+    assert opt.param_groups[0]["lr"] == float(g["opt_lr"]) and float(opt.state[list(model.parameters())[5]]["step"]) == 3
+    assert misc.flatten_optimizer_state({"state": {"step": 3}, "param_groups": []}, shapes) is None       # the round-1 stand-in layout is rejected
+    # a checkpoint written by this package carries the reference's keys
+    class _Eff: name = "comp_4c"; knob_names = rv["knob_names"]; knob_ranges = rv["knob_ranges"]
+    f2 = str(tmp_path / "mine.tar")
+    misc.save_checkpoint(f2, model, 41, False, opt, _Eff, 44100)
+    raw = torch.load(f2, weights_only=False)
+    assert tuple(raw.keys()) == tuple(g["top_keys"]) and list(raw["state_dict"].keys()) == names
+    assert sorted(raw["optimizer"]["param_groups"][0].keys()) == sorted(k for k in g["opt_group_keys"] if k != "momentum")
