@@ -23,6 +23,31 @@ import numpy as np
 import torch
 
 PEAK_FP32_MFMA_TF = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense fp32
+PEAK_HALF_MFMA_TF = 2500.0         # MI355X_MICROARCH.md: bf16 / fp16 MFMA, DENSE (the 5 PF headline figure is 2:1 sparsity)
+GEMM_KERNELS = ("analysis_fwd", "analysis_wgrad", "synthesis_frames", "synthesis_dgrad", "synthesis_wgrad")
+
+
+def kernel_peak(name, dtype):
+    """MFMA peak that bounds kernel `name` under --dtype: the STFT GEMMs run 16-bit operands in every mixed mode, the
+    autoencoder kernels only in the *_all modes."""
+    if dtype == "f32":
+        return PEAK_FP32_MFMA_TF
+    if name in GEMM_KERNELS or dtype.endswith("_all"):
+        return PEAK_HALF_MFMA_TF
+    return PEAK_FP32_MFMA_TF
+
+
+DTYPE_TEXT = {"f32": "fp32", "bf16": "bf16 GEMM operands / fp32 accumulate", "bf16_all": "bf16 operands in the STFT GEMMs and the autoencoder layers / fp32 accumulate",
+              "f16": "fp16 GEMM operands / fp32 accumulate, loss scale 4096", "f16_all": "fp16 mixed precision: fp16 operands in the STFT GEMMs and the autoencoder layers / fp32 accumulate, "
+                                                                                         "loss scale 4096, clip over all parameters"}
+
+
+def workload_text(d, B, dtype, scale):
+    cfg = {(1, "f32"): "BASELINE configs[1]", (1, "bf16"): "arithmetic of BASELINE configs[2]", (1, "bf16_all"): "arithmetic of BASELINE configs[2]",
+           (8, "f16"): "BASELINE configs[4] per GPU", (8, "f16_all"): "BASELINE configs[4] per GPU"}.get((scale, dtype))
+    if cfg is None:
+        cfg = "geometry of BASELINE configs[4]" if scale == 8 else "informational"
+    return f"comp_4c synthetic, {d.L}-sample windows, batch {B}/GPU, {DTYPE_TEXT[dtype]} ({cfg})"
 METRIC = "audio-frames/sec (train step) comp_4c 8192-sample windows @ 1/2/4/8 GPUs"
 
 
@@ -55,25 +80,34 @@ def main():
     ap.add_argument("--dp-schedule", choices=["two_bucket", "staged"], default="two_bucket", help="all-reduce schedule of the data-parallel step (signaltrain_amd/dp.py)")
     ap.add_argument("--force-dp", action="store_true", help="run the N > 1 code path (bucketed RCCL all-reduce, st_dp_clip_adam) "
                                                             "even with one rank, to measure its overhead on one GPU")
-    ap.add_argument("--dtype", choices=("f32", "bf16", "bf16_all"), default="f32",
-                    help="f32 = the headline / parity configuration; bf16 = bf16 operands with fp32 accumulation in the STFT GEMMs; bf16_all = also in the autoencoder layers "
-                         "(arithmetic of BASELINE configs[2], [3]; informational, never the headline number)")
-    ap.add_argument("--scale", type=int, default=1, help="window scale factor (8 = the 65536-sample window of BASELINE configs[4], "
-                                                          "fp32 here; informational -- the headline workload is scale 1)")
+    ap.add_argument("--dtype", choices=("f32", "bf16", "bf16_all", "f16", "f16_all"), default="f32",
+                    help="f32 = the headline / parity configuration; bf16 / f16 = 16-bit operands with fp32 accumulation in the STFT GEMMs; *_all = also in the autoencoder layers "
+                         "(bf16*: arithmetic of BASELINE configs[2], [3]; f16* with --scale 8 --batch 64: configs[4]; informational, never the headline number)")
+    ap.add_argument("--scale", type=int, default=1, help="window scale factor (8 = the 65536-sample window of BASELINE configs[4]; "
+                                                          "informational -- the headline workload is scale 1)")
+    ap.add_argument("--dp-backend", choices=("lib", "torch"), default="lib",
+                    help="N > 1: lib = the exchange inside libsignaltrain_hip.so (its own RCCL communicator, one C call per step; torch.distributed/gloo "
+                         "only bootstraps the unique id); torch = torch.distributed collectives on RCCL driven from Python")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run for N>1")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}.  N > 1 runs one process per GPU:\n  python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus {args.gpus} "
+                         f"--steps {args.steps} --warmup {args.warmup}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (there is no CPU fallback of the product path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
+    dp_backend = args.dp_backend if args.dp_schedule == "two_bucket" else "torch"
     if world > 1 or args.force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dp_backend == "lib":
+            dist.init_process_group("gloo", rank=rank, world_size=world)      # bootstrap + timing fence only; gradients move on the library's RCCL communicator
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from signaltrain_amd import _lib, nn_proc, audio, datasets, learningrate
     from signaltrain_amd.engine import StepEngine
@@ -89,7 +123,25 @@ def main():
     model = nn_proc.st_model(scale_factor=args.scale, shrink_factor=4, num_knobs=4)
     eng = StepEngine(d, dev, compute_dtype=args.dtype)
     eng.load_state_dict(model.state_dict())
-    dp = DataParallel(eng, force_collectives=args.force_dp, schedule=args.dp_schedule)
+    dp_note = None
+    try:
+        dp = DataParallel(eng, force_collectives=args.force_dp, schedule=args.dp_schedule, backend=dp_backend if (world > 1 or args.force_dp) else None)
+        ok = 1
+    except Exception as e:                       # the library could not bring up its communicator
+        dp, ok, dp_note = None, 0, f"{type(e).__name__}: {e}"
+    if (world > 1 or args.force_dp) and dp_backend == "lib":
+        flag = torch.tensor([ok]); dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank takes the same branch
+        if int(flag.item()) == 0:
+            # LOUD, recorded in the JSON line: same protocol over torch.distributed's RCCL collectives instead
+            print(f"bench.py: library-owned RCCL communicator unavailable ({dp_note}); using torch.distributed collectives", file=sys.stderr)
+            if eng.dp is not None:
+                _lib.load().st_dp_destroy(eng.dp); eng.dp = None
+            dist.destroy_process_group()
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dp_backend = "torch"; dp_note = "fallback from lib: " + str(dp_note)
+            dp = DataParallel(eng, force_collectives=args.force_dp, schedule=args.dp_schedule, backend="torch")
+    elif dp is None:
+        raise RuntimeError(dp_note)
     dp.broadcast_parameters()
     np.random.seed(218 + 1000 * (rank + 1))
     ds = datasets.SynthAudioDataSet(d.L, audio.Compressor_4c(), y_size=d.y, augment=True)
@@ -115,7 +167,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], dtype=torch.float64) if dist.get_backend() == "gloo" else torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     loss = dp.mean_loss()
@@ -128,12 +180,15 @@ def main():
         out = {"metric": METRIC, "value": windows_s * d.T, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": (f"comp_4c synthetic, 8192-sample windows, batch {B}/GPU, {'fp32 (BASELINE configs[1])' if args.dtype == 'f32' else ('bf16 GEMM operands / fp32 accumulate (arithmetic of BASELINE configs[2])' if args.dtype == 'bf16' else 'bf16 operands in the STFT GEMMs and the autoencoder layers / fp32 accumulate (arithmetic of BASELINE configs[2])')}" if args.scale == 1 else
-                                       f"comp_4c synthetic, {d.L}-sample windows, batch {B}/GPU, fp32 (geometry of BASELINE configs[4])"),
-                          "window": d.L, "frames_per_window": d.T, "global_batch": B * world, "parallelism": f"dp{world}"},
+               "config": {"workload": workload_text(d, B, args.dtype, args.scale),
+                          "window": d.L, "frames_per_window": d.T, "global_batch": B * world, "parallelism": f"dp{world}",
+                          **({"dp_backend": dp_backend, "dp_schedule": args.dp_schedule} if (world > 1 or args.force_dp) else {}),
+                          **({"dp_note": dp_note} if dp_note else {})},
                "windows_per_s": windows_s, "samples_per_s": windows_s * d.L, "loss": loss,
                "step_tflops": flops_step / (ms * 1e-3) / 1e12 * world,
                "step_frac_of_fp32_mfma_peak": flops_step / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TF}
+        if args.dtype != "f32":
+            out["step_frac_of_16bit_mfma_peak"] = flops_step / (ms * 1e-3) / 1e12 / PEAK_HALF_MFMA_TF
 
     # ------------------------------------------------------------------ roofline leg (outside the timed region)
     if not args.no_roofline:
@@ -155,6 +210,7 @@ def main():
                         **({"tflops": flops_k[k] / (v[0] * 1e-3) / 1e12} if k in flops_k else {})} for k, v in rows.items()}
             dom = max((k for k in rows if k in flops_k), key=lambda k: rows[k][0])
             ach = flops_k[dom] / (rows[dom][0] * 1e-3) / 1e12
+            peak = kernel_peak(dom, args.dtype)
             # HBM-side bytes per launch of that kernel: PMC counters cannot be collected from inside this process, so
             # the value is quoted from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
             # command (tools/profile_gpu.sh -> profiles/*_pmc_traffic.json); null when there is no such file.
@@ -162,7 +218,7 @@ def main():
             try:
                 import glob
                 cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-                if cand and args.scale == 1 and B == 256:
+                if cand and args.scale == 1 and B == 256 and args.dtype == "f32":
                     tj = json.load(open(cand[-1]))
                     key = {"ae_bwd": "ae_bwd_kernel", "ae_fwd": "ae_fwd_kernel"}.get(dom)
                     hit = [v for k, v in tj.items() if key and key in k]
@@ -171,8 +227,8 @@ def main():
                         tsrc = os.path.basename(cand[-1]) + " (FETCH_SIZE + WRITE_SIZE, KB per dispatch, uncorrected: dword accesses)"
             except Exception:
                 traffic, tsrc = None, None
-            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_FP32_MFMA_TF, "traffic": traffic, "traffic_source": tsrc,
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                               "frac": ach / peak, "traffic": traffic, "traffic_source": tsrc,
                                "algorithmic_flops_per_launch": flops_k[dom], "avg_launch_us": rows[dom][0] * 1e3}
             out["kernels"] = kern
 
@@ -204,6 +260,7 @@ def main():
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or args.force_dp:
+        dp.close()
         dist.destroy_process_group()
 
 

@@ -102,7 +102,7 @@ class mixed_mode:
         O.AE_ROUND = rnd if self.level >= 2 else None
         O.LOSS_SCALE = self.loss_scale if self.loss_scale > 0 else 1.0
         O.CLIP_ALL = self.clip_all
-        base = (10.0 if self.level == 1 else 20.0) if self.half == "bf16" else (3.0 if self.level == 1 else 6.0)
+        base = (10.0 if self.level == 1 else 20.0) if self.half == "bf16" else (3.0 if self.level == 1 else 10.0)
         TOL_SCALE = self.tol_scale if self.tol_scale else base
         ENGINE_DTYPE = self.half + ("" if self.level == 1 else "_all")
 
