@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--bk", type=int, default=0, help="GEMM k-tile depth override (16/32)")
+    ap.add_argument("--tune", type=int, nargs="*", default=[], help="diagnostics: st_set_tuning codes applied before the run")
     ap.add_argument("--dp-schedule", choices=["two_bucket", "staged"], default="two_bucket", help="all-reduce schedule of the data-parallel step (signaltrain_amd/dp.py)")
     ap.add_argument("--force-dp", action="store_true", help="run the N > 1 code path (bucketed RCCL all-reduce, st_dp_clip_adam) "
                                                             "even with one rank, to measure its overhead on one GPU")
@@ -117,6 +118,8 @@ def main():
     B = args.batch
     if args.bk:
         _lib.check(_lib.load().st_set_tuning(args.bk), 'st_set_tuning')
+    for code in args.tune:
+        _lib.check(_lib.load().st_set_tuning(int(code)), 'st_set_tuning')
     d = _lib.geometry(args.scale, 4, 4, B)
     # identical init on every rank (run_train.py:20-21 seeds 218), distinct data per rank
     torch.manual_seed(218); np.random.seed(218)

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsignaltrain_hip.so")
+LIB_PATH = os.environ.get("ST_LIB_PATH") or os.path.join(_HERE, "libsignaltrain_hip.so")     # ST_LIB_PATH: diagnostics (ablation builds, tools/ae_ablate.sh)
 
 
 class st_dims(C.Structure):

@@ -29,6 +29,12 @@
 namespace sta {
 
 constexpr int NL = 9;
+// Timing-only ablation build of ae_bwd_kernel (tools/ae_ablate.sh; results are INVALID when non-zero; never set in the product build):
+// 1 no d-out global loads | 2 no dv stores | 4 no weight-gradient MFMAs | 8 ELU without the transcendental | 16 no LDS transposes |
+// 32 no forward-recompute MFMAs | 64 no next-group prefetch loads
+#ifndef ST_AE_ABLATE
+#define ST_AE_ABLATE 0
+#endif
 
 // Global-memory description of one autoencoder inside the flat parameter buffer (float offsets from
 // the autoencoder base: weight l at w[l], bias at b[l]); same for the gradient buffer.
@@ -511,14 +517,24 @@ __device__ __forceinline__ void fwdD_fr(const f32x4 (&fr)[OTL * ITL], const floa
         f32x4 acc = *reinterpret_cast<const f32x4*>(bias + 16 * ot + 4 * g);   // accumulator starts at the bias (D layout: o = 16 ot + 4 g + r)
 #pragma unroll
         for (int it = 0; it < ITL; ++it) {
+#if ST_AE_ABLATE & 32
+            acc[0] += fr[ot * ITL + it][0] * hin[it][0];
+#else
             if constexpr (BF) acc = ST_MFMA16B(pack_bf16x4(fr[ot * ITL + it]), ph[it], acc);
             else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc = ST_MFMA16(fr[ot * ITL + it][r], hin[it][r], acc);
             }
+#endif
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hout[ot][r] = elu_f(acc[r]);
+        for (int r = 0; r < 4; ++r) {
+#if ST_AE_ABLATE & 8
+            hout[ot][r] = fmaxf(acc[r], 0.1f * acc[r]);
+#else
+            hout[ot][r] = elu_f(acc[r]);
+#endif
+        }
     }
 }
 // D layout -> T layout of TL 16x16 tiles through a wave-private LDS scratch ([tile][row 16][feature 16, pitch 20]): one
@@ -528,6 +544,11 @@ __device__ __forceinline__ void fwdD_fr(const f32x4 (&fr)[OTL * ITL], const floa
 template <int TL>
 __device__ __forceinline__ void to_T(float* scr, const f32x4 (&d)[TL], f32x4 (&t)[TL], const int g, const int c)
 {
+#if ST_AE_ABLATE & 16
+#pragma unroll
+    for (int k = 0; k < TL; ++k) t[k] = d[k];
+    return;
+#endif
 #pragma unroll
     for (int k = 0; k < TL; ++k) *reinterpret_cast<f32x4*>(scr + k * 320 + c * 20 + 4 * g) = d[k];
 #pragma unroll
@@ -584,11 +605,15 @@ __device__ __forceinline__ void wgrad_reg(f32x4 (&dW)[OTL][ITL], float (&db)[OTL
         if constexpr (BF) pdt = pack_bf16x4(daT[ot]);
 #pragma unroll
         for (int it = 0; it < ITL; ++it) {
+#if ST_AE_ABLATE & 4
+            dW[ot][it][0] += daT[ot][0] * hT[it][0];
+#else
             if constexpr (BF) dW[ot][it] = ST_MFMA16B(pdt, pht[it], dW[ot][it]);
             else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dW[ot][it] = ST_MFMA16(daT[ot][r], hT[it][r], dW[ot][it]);
             }
+#endif
         }
         db[ot] += (daT[ot][0] + daT[ot][1]) + (daT[ot][2] + daT[ot][3]);
     }
@@ -627,7 +652,11 @@ __device__ __forceinline__ void db_flush(float* dst, float (&db)[OTL], const int
 constexpr int AE_BWD_SCR = (32 + 16 + 16) * SP + 2 * 4 * 320;      // per wave: V, Y, TAIL rows + two 4-tile transpose scratches (to_T)
 // LDS of the backward kernel (floats): images + per-wave scratch during the loop, four per-wave gradient images at the end
 constexpr int ae_bwd_lds_floats(int nw) { return (CL::BWD_TOTAL + nw * AE_BWD_SCR) > nw * CL::FWD_TOTAL ? (CL::BWD_TOTAL + nw * AE_BWD_SCR) : nw * CL::FWD_TOTAL; }
-template <int NW, bool TIMED, bool INNER = false, int BF = 0>      // BF: bf16 operands in all Linear-layer products (st_set_precision(2))
+// VAR (fused geometries only): bit 0 = an upstream gradient w.r.t. mag_hat arrives (g_mag_hat, the autograd entry);
+// bit 1 = T - OT == 16 (the default geometry): the skip-filter tails mag[b, T-OT+t', f] ARE the second input tile already in
+// registers.  Both exist to cut global-load INSTRUCTIONS: the four waves of a workgroup issue their ~50 scattered dword loads
+// per group at the same moment and queue at the CU's one address path (the "loads issue" stage was 11 % of a group).
+template <int NW, bool TIMED, bool INNER = false, int BF = 0, int VAR = 1>      // BF: 16-bit operands in all Linear-layer products (ST_PREC_*_ALL)
 __global__ void __launch_bounds__(NW * 64, 1)
 ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, const float* __restrict__ knobs,
               const float* __restrict__ ae_m, const float* __restrict__ ae_p, const AEOffsets go, const int PG,
@@ -726,8 +755,8 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         // forward stages to overlap their issue with MFMA execution was measured: no gain.)
         // Raw values only: the slab sums and masks are formed in the d-out stage -- arithmetic on a loaded value up here
         // makes the wave wait in the middle of the burst (the memory counter is in-order).
+        constexpr bool GM = (VAR & 1) != 0, TAIL16 = (VAR & 2) != 0;
         float q_x[4][3], q_y[4][3], q_ph[4], q_mh[4], q_mt[4], q_gm[4];
-        const float* gmp = g_mag_hat ? g_mag_hat : mag_hat;
         if constexpr (!INNER) {
             // wave-uniform base pointers for the slabs and the imaginary half: the six dAA loads of a row share ONE offset register
             const size_t o1 = nslab > 1 ? slab : 0, o2 = nslab > 2 ? 2 * slab : 0;
@@ -743,11 +772,17 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
                 // up to 3 split-K slabs: all six loads are issued together (a runtime-trip-count loop here serialised ~12
                 // memory round trips per group)
                 const unsigned p0 = ST_MUL24(lv ? ro : 0u, KP) + (unsigned)fq;
+                const unsigned pF = ST_MUL24(ro, F) + (unsigned)fq;
+#if ST_AE_ABLATE & 1
+                q_x[r][0] = q_x[r][1] = q_x[r][2] = q_y[r][0] = q_y[r][1] = q_y[r][2] = 1e-3f * (float)(p0 & 7); q_ph[r] = 0.3f; q_mh[r] = 0.2f + 1e-3f * (float)(pF & 3);
+#else
                 q_x[r][0] = ldg32(dA0, p0); q_x[r][1] = ldg32(dA1, p0); q_x[r][2] = ldg32(dA2, p0);
                 q_y[r][0] = ldg32(dB0, p0); q_y[r][1] = ldg32(dB1, p0); q_y[r][2] = ldg32(dB2, p0);
-                const unsigned pF = ST_MUL24(ro, F) + (unsigned)fq;
-                q_ph[r] = ldg32(phs_hat, pF); q_mh[r] = ldg32(mag_hat, pF); q_gm[r] = ldg32(gmp, pF);
-                q_mt[r] = ldg32(vin, btF + ST_MUL24(ok ? T - OT + to : 0, F));
+                q_ph[r] = ldg32(phs_hat, pF); q_mh[r] = ldg32(mag_hat, pF);
+#endif
+                if constexpr (GM) q_gm[r] = ldg32(g_mag_hat, pF); else q_gm[r] = 0.f;
+                if constexpr (TAIL16) q_mt[r] = vr[1][r];          // t = T - OT + 4g + r = 16 + 4g + r: input tile 1 of this lane (already masked)
+                else q_mt[r] = ldg32(vin, btF + ST_MUL24(ok ? T - OT + to : 0, F));
             }
         }
         // INNER: layer-1 outputs in both layouts and the gradient entering layer 8's output, straight from the
@@ -766,8 +801,12 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         }
         f32x4 vn[2], knn; float knTn;
         const int gnext = grp + gstride < ngroups ? grp + gstride : grp;      // last iteration: harmless reload of this group
+#if ST_AE_ABLATE & 64
+        vn[0] = vr[0]; vn[1] = vr[1]; knn = kn; knTn = knT;
+#else
         if constexpr (!INNER) load_v(gnext, vn);
         load_kn(gnext, knn, knTn);
+#endif
         ST_T(0);
 
         // ------------------------------------------------------------------ forward recompute (D layout)
@@ -807,11 +846,13 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         if constexpr (!INNER) frags_fwd<1, 4, CL::O8>(fr9, lw + CL::A8, g, c);
         ST_FENCE(); fwdD_fr<4, 2, BF>(fr8, lw + CL::B7, h7, h8, g);
         ST_T(5);
-        if constexpr (!INNER) { ST_FENCE(); fwdD_fr<1, 4, BF>(fr9, lw + CL::B8, h8, e9, g); }
-        ST_T(6);
-        // ------------------------------------------------------------------ d out  (D layout: t' = 4g + r)
+        // ---- d out (D layout: t' = 4g + r), part A: everything that does not need e9 -- polar->rect backward of nn_proc.py:322-326 and
+        // the L1 term of loss_functions.py:36 -- sits in the SAME scheduling region as the layer-9 MFMAs (one dependent chain of 16,
+        // 512 cycles of matrix pipe with nothing else to issue) and is paced into their shadows: one MFMA, then seven VALU.
         f32x4 da9[1];
+        float dxA[4], mtA[4];
         if constexpr (!INNER) {
+            ST_FENCE();
             const float wf = fv ? expf(expfac * (float)f) : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -823,16 +864,32 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
                 const float gre = lv ? q_x[r][0] + (nslab > 1 ? q_x[r][1] : 0.f) + (nslab > 2 ? q_x[r][2] : 0.f) : 0.f;
                 const float gim = lv ? q_y[r][0] + (nslab > 1 ? q_y[r][1] : 0.f) + (nslab > 2 ? q_y[r][2] : 0.f) : 0.f;
                 const float ph = q_ph[r], mh = q_mh[r];
-                asm volatile("" :: "v"(q_mt[r]));       // second use: a single-use load feeding a select is turned into a branch with the load sunk into it
+                if constexpr (!TAIL16) asm volatile("" :: "v"(q_mt[r]));       // second use: a single-use load feeding a select is turned into a branch with the load sunk into it
                 float sn, cs; st_sincos(ph, sn, cs);
-                const float eg = elu_grad_from_out(e9[0][r]);
                 const float sg = mh > 0.f ? 1.f : (mh < 0.f ? -1.f : 0.f);
-                const float dmh = gre * cs + gim * sn + reg_coef * sg * wf + (g_mag_hat ? q_gm[r] : 0.f);
+                const float dmh = gre * cs + gim * sn + reg_coef * sg * wf + (GM ? q_gm[r] : 0.f);
                 const float dph = mh * (gim * cs - gre * sn);
                 // one formula for both nets (x * 1.0f is exact): magnitude d9 = dmh * mag_tail * ELU', tail = dmh * e9; phase d9 = dph * ELU', tail = dph
-                const float dx = ae == 0 ? dmh : dph, mt1 = ae == 0 ? q_mt[r] : 1.f, e1 = ae == 0 ? e9[0][r] : 1.f;
-                const float d9 = ok ? dx * mt1 * eg : 0.f;
-                const float tail = ok ? dx * e1 : 0.f;
+                dxA[r] = ok ? (ae == 0 ? dmh : dph) : 0.f;
+                mtA[r] = ae == 0 ? q_mt[r] : 1.f;
+            }
+            fwdD_fr<1, 4, BF>(fr9, lw + CL::B8, h8, e9, g);
+            if constexpr (BF == 0) {
+#pragma unroll
+                for (int p_ = 0; p_ < 16; ++p_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 7, 0); }
+            }
+            ST_FENCE();
+        }
+        ST_T(6);
+        // ---- d out, part B: ELU'(a9) and the skip / residual tails
+        if constexpr (!INNER) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int to = 4 * g + r;
+                const float eg = elu_grad_from_out(e9[0][r]);
+                const float e1 = ae == 0 ? e9[0][r] : 1.f;
+                const float d9 = dxA[r] * mtA[r] * eg;             // dxA is already zero outside the valid rows / frames
+                const float tail = dxA[r] * e1;
                 da9[0][r] = d9;
                 Ts[to * SP + c] = tail;
                 Ys[to * SP + c] = d9;                      // [feature t'][row c] -> read back transposed below
@@ -955,7 +1012,11 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             for (int r = 0; r < 4; ++r) {
                 const int t = 16 * it + 4 * g + r;
                 const float v = dvs[it][r] + (t >= T - OT ? tls[it][r] : 0.f);
+#if ST_AE_ABLATE & 2
+                asm volatile("" :: "v"(v));
+#else
                 if (fv && t < T) stg32(dvout, dv0 + ST_MUL24(t, F), v);
+#endif
             }
         }
         ST_T(15);

@@ -164,12 +164,16 @@ extern "C" int st_set_debug(int v) { g_dbg = v; return ST_OK; }
 namespace sta { extern __device__ unsigned long long g_ae_stage_cycles[32]; }
 // Diagnostics: read (and clear) the per-stage s_memtime accumulators of ae_bwd_kernel (st_set_debug(256)).
 extern "C" int st_debug_read_stage_cycles(unsigned long long* out32);
+static int g_xt = 0;       // 1: M/N-contiguous operands staged k-quad-major (st_gemm.h XT; st_set_tuning(7001), diagnostics).  MEASURED SLOWER at B=256 although
+                           // conflict-free with a third fewer LDS cycles: analysis wgrad 173 vs 145 us, synthesis frames 63 vs 60 us (16 more prefetch
+                           // registers -> 4 instead of 4.5 waves per SIMD, and 16 v_mov per micro-tile): the k-major staging stays the default
 static int g_an_bk = 32;   // k-tile depth of the analysis forward GEMM (see ST_GEMM_AN)
 static int g_bk = 16;   // k-tile depth of the GEMM family (16: 36 KB LDS/WG -> 4 WGs/CU; 32: 64 KB -> 2 WGs/CU)
 static int g_wg_mode_set(int v);
 static int g_wsplit_max = 16, g_wsplit_div = 200, g_an_waves = 4, g_syn_split = 3, g_frs_split = 3, g_wide_fused = 1, g_wsplit_half = 0;      // frames: 3, 4 measured equal, 6 slower (only 66 k-tiles to split)
 extern "C" int st_set_tuning(int bk)
 {
+    if (bk >= 7000) { g_xt = bk - 7000; return ST_OK; }
     if (bk >= 6000) { g_wsplit_half = bk - 6000; return ST_OK; }  // 6000 + n: split-K of the half (one-basis) analysis weight-gradient GEMMs of st_loss_backward_stage (0: as the full GEMM)
     if (bk >= 5000) { g_wide_fused = bk - 5000; return ST_OK; }   // 5000 / 5001: wide AE path all-GEMM / fused inner layers
     if (bk >= 4000) { g_frs_split = bk - 4000; return (g_frs_split >= 1 && g_frs_split <= 6) ? ST_OK : st_fail(ST_ERR_ARG, "frames split must be 1..6"); }
@@ -188,6 +192,7 @@ static inline float loss_scale_of(const st_dims* d) { return d->loss_scale > 0.f
 // every ST_GEMM* user has `d` (const st_dims*) in scope
 #define ST_GEMM_BK(BK_, W_, ...) do { const int ht_ = gemm_ht(d->prec); \
                               if (ht_ == 1) stg::launch_half<W_, 1>(__VA_ARGS__); else if (ht_ == 2) stg::launch_half<W_, 2>(__VA_ARGS__); \
+                              else if (g_xt) { if ((BK_) == 16) stg::launch<W_, 16, 1, true>(__VA_ARGS__, g_dbg); else stg::launch<W_, 32, 1, true>(__VA_ARGS__, g_dbg); } \
                               else if ((BK_) == 16) stg::launch<W_, 16>(__VA_ARGS__, g_dbg); else stg::launch<W_, 32>(__VA_ARGS__, g_dbg); } while (0)
 #define ST_GEMM(W_, ...) ST_GEMM_BK(g_bk, W_, __VA_ARGS__)
 // the analysis forward GEMM (K = N = 1024, two 4-wave workgroups per CU either way) runs 5 % faster with 32-deep k-tiles
@@ -291,7 +296,7 @@ static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, cons
 // ------------------------------------------------------------------------------ per-op entry points
 // `padded`: sig is the workspace copy [B][N + L + N] (zero margins, input scale applied) written by pad_scale_kernel.
 static int analysis_fwd_impl(const st_dims* d, const float* sig, bool padded, const float* Wr, const float* Wi, float in_scale,
-                             float* re, float* im, float* mag, float* phs, void* stream)
+                             float* re, float* im, float* mag, float* phs, void* stream, bool dead_frames_done = false)
 {
     const stg::RowMap map = stg::live_frames(d->T, d->H, d->N, d->N, d->L);   // frames entirely inside the Conv1d padding are skipped
     const int R = map.rows(d->B);
@@ -305,7 +310,7 @@ static int analysis_fwd_impl(const st_dims* d, const float* sig, bool padded, co
     }
     else { stg::FramedNT<false> al{sig, d->L, d->H, d->N, R, d->N, in_scale, map}; ST_GEMM(4, al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream)); }
     ST_LAUNCHED("analysis_fwd");
-    if (map.Tv < d->T) {                   // ... and are exact zeros (re=im=mag=0, phs=atan2(0,1e-7)=0)
+    if (map.Tv < d->T && !dead_frames_done) {   // ... and are exact zeros (re=im=mag=0, phs=atan2(0,1e-7)=0)
         hipLaunchKernelGGL(stm::zero_dead_frames_kernel, dim3(d->B * (d->T - map.Tv)), dim3(256), 0, st_stream(stream),
                            re, im, mag, phs, d->T, d->F, map.t_lo, map.Tv);
         ST_LAUNCHED("zero_dead_frames");
@@ -571,8 +576,8 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
         {
             const size_t lds = (size_t)sta::ae_bwd_lds_floats(AE_BWD_NW) * sizeof(float);
             const int grid = ae_bwd_grid(d);
-#define ST_AE_INNER_BWD(HT_) do { ST_DYN_LDS((sta::ae_bwd_kernel<AE_BWD_NW, false, true, HT_>)); \
-                hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, false, true, HT_>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, s, \
+#define ST_AE_INNER_BWD(HT_) do { ST_DYN_LDS((sta::ae_bwd_kernel<AE_BWD_NW, false, true, HT_, 0>)); \
+                hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, false, true, HT_, 0>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, s, \
                                    (const float*)w.H[0][0], (const float*)w.H[1][0], knobs, ae_m, ae_p, L.go, L.PG, \
                                    (const float*)w.DA[0][7], (const float*)w.DA[1][7], (const float*)nullptr, (const float*)nullptr, 0.f, 0.f, \
                                    w.DA[0][0], w.DA[1][0], w.inner_ws, d->B, T, OT, F, d->K, L.KP, 0, 0, 1, (size_t)0, 0); } while (0)
@@ -601,11 +606,14 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
 static int ae_bwd_impl(const st_dims* d, const float* mag, const float* phs, const float* knobs,
                        const float* ae_m, const float* ae_p, const float* mag_hat, const float* phs_hat,
                        const float* dAA, const float* g_mag_hat, float reg_coef, float* dmag, float* dphs, float* ws,
-                       float* g_m, float* g_p, bool have_fwd, void* stream)
+                       float* g_m, float* g_p, bool have_fwd, void* stream, bool* defer_reduce = nullptr)
 {
+    // defer_reduce: in -> the caller will sum the workgroup partials itself (post_ae_kernel, together with the polar backward);
+    // out -> false if this geometry's path already reduced them (wide geometries)
     Layout L; ST_TRY(make_layout(d, &L));
     ST_REQ(mag && phs && knobs && ae_m && ae_p && mag_hat && phs_hat && dAA && dmag && dphs && ws && g_m && g_p, "st_ae_bwd: null pointer");
     if (ae_is_wide(d)) {
+        if (defer_reduce) *defer_reduce = false;
         WideWS w; wide_carve(d, ws, &w);
         return ae_wide_bwd(d, L, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, dmag, dphs, w, g_m, g_p, have_fwd, stream);
     }
@@ -616,14 +624,22 @@ static int ae_bwd_impl(const st_dims* d, const float* mag, const float* phs, con
     const float expfac = (float)(7.0 / d->F);
     const int grid = ae_bwd_grid(d);
     const stg::RowMap live = synth_live(d);
-#define ST_AE_BWD_LAUNCH(TIMED_, HT_) do { ST_DYN_LDS((sta::ae_bwd_kernel<AE_BWD_NW, TIMED_, false, HT_>)); \
-    hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, TIMED_, false, HT_>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, st_stream(stream), \
+#define ST_AE_BWD_LAUNCH(TIMED_, HT_, VAR_) do { ST_DYN_LDS((sta::ae_bwd_kernel<AE_BWD_NW, TIMED_, false, HT_, VAR_>)); \
+    hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, TIMED_, false, HT_, VAR_>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, st_stream(stream), \
                        mag, phs, knobs, ae_m, ae_p, L.go, L.PG, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, expfac, \
                        dmag, dphs, ws, d->B, d->T, d->OT, d->F, d->K, L.KP, live.t_lo, live.t_lo + live.Tv - 1, st_synth_slabs(d), (size_t)d->B * d->OT * L.KP, g_dbg); } while (0)
-    if (g_dbg & 256) ST_AE_BWD_LAUNCH(true, 0);      // stage-timer build (tools/ae_stage_times.py)
-    else switch (ae_ht(d->prec)) { case 1: ST_AE_BWD_LAUNCH(false, 1); break; case 2: ST_AE_BWD_LAUNCH(false, 2); break; default: ST_AE_BWD_LAUNCH(false, 0); }
+    // kernel variant: 1 = an upstream d/d mag_hat arrives (autograd entry), 2 = T - OT == 16 (tails already in registers), 0 = neither
+    const int var = g_mag_hat ? 1 : (d->T - d->OT == 16 ? 2 : 0);
+#define ST_AE_BWD_VARS(HT_) do { if (var == 1) ST_AE_BWD_LAUNCH(false, HT_, 1); else if (var == 2) ST_AE_BWD_LAUNCH(false, HT_, 2); else ST_AE_BWD_LAUNCH(false, HT_, 0); } while (0)
+    if (g_dbg & 256) {                               // stage-timer build (tools/ae_stage_times.py): the default-geometry training variant
+        ST_REQ(var == 2 && ae_ht(d->prec) == 0, "the stage-timer build covers the fp32 training step at T - OT == 16 only");
+        ST_AE_BWD_LAUNCH(true, 0, 2);
+    }
+    else switch (ae_ht(d->prec)) { case 1: ST_AE_BWD_VARS(1); break; case 2: ST_AE_BWD_VARS(2); break; default: ST_AE_BWD_VARS(0); }
+#undef ST_AE_BWD_VARS
 #undef ST_AE_BWD_LAUNCH
     ST_LAUNCHED("ae_bwd");
+    if (defer_reduce && *defer_reduce) return ST_OK;
     hipLaunchKernelGGL(stm::ae_grad_reduce_kernel, dim3((L.PG + 63) / 64, 2), dim3(256), 0, st_stream(stream),
                        ws, grid, L.PG, g_m, g_p);
     ST_LAUNCHED("ae_grad_reduce"); return ST_OK;
@@ -780,10 +796,20 @@ static int forward_impl(const st_dims* d, const Layout& L, const float* params, 
     const float* Sr = params + L.offs[2]; const float* Si = params + L.offs[3];
     const float* ae_m = params + L.offs[4]; const float* ae_p = params + L.offs[22];
     // saved-for-backward state always lives in the workspace; user-visible outputs are copies
-    ST_TRY(pad_scale(x, w.xp, d->B, d->L, d->N, 0.5f, stream));                 // x/2 (nn_proc.py:307) + Conv1d padding, once
-    ST_TRY(analysis_fwd_impl(d, w.xp, true, Wr, Wi, 1.0f, save ? w.re : nullptr, save ? w.im : nullptr, w.mag, w.phs, stream));
+    {   // one launch: x/2 (nn_proc.py:307) with the Conv1d padding materialised, the Hermitian fold of the synthesis bases
+        // (cls_fe_dft.py:109-110 on the weights) and the exact zeros of the frames that lie wholly in the padding
+        const stg::RowMap map = stg::live_frames(d->T, d->H, d->N, d->N, d->L);
+        stm::PrepArgs a;
+        a.x = x; a.xp = w.xp; a.Ls = d->L; a.pad = d->N; a.scale = 0.5f;
+        a.nbx = ((d->L + 2 * d->N) / 4 + 255) / 256; a.n_pad = a.nbx * d->B;
+        a.Sr = Sr; a.Si = Si; a.Sfold = w.Sfold; a.N = d->N; a.F = d->F; a.KP = L.KP;
+        a.re = save ? w.re : nullptr; a.im = save ? w.im : nullptr; a.mag = w.mag; a.phs = w.phs; a.T = d->T; a.t_lo = map.t_lo; a.Tv = map.Tv;
+        const int n_dead = d->B * (d->T - map.Tv);
+        hipLaunchKernelGGL(stm::prep_kernel, dim3(a.n_pad + L.KP + n_dead), dim3(256), 0, st_stream(stream), a);
+        ST_LAUNCHED("prep");
+    }
+    ST_TRY(analysis_fwd_impl(d, w.xp, true, Wr, Wi, 1.0f, save ? w.re : nullptr, save ? w.im : nullptr, w.mag, w.phs, stream, true));
     ST_TRY(st_ae_fwd(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.AA, w.reg_p, w.aews, stream));
-    ST_TRY(st_synth_fold(d, Sr, Si, w.Sfold, stream));
     ST_TRY(st_synthesis_frames(d, w.AA, w.Sfold, w.frs, stream));
     ST_TRY(ola_loss_impl(d, w.frs, x, y_true, y_hat ? y_hat : w.y_hat, (save && y_true) ? w.dsyn : nullptr, d->N,
                          y_true ? w.loss_p : nullptr, stream));
@@ -805,9 +831,18 @@ static int backward_ae(const st_dims* d, const Layout& L, const float* params, f
                        const float* knobs, const float* g_mag_hat, const float* g_mag, float reg_coef, WS& w, void* stream)
 {
     const float* ae_m = params + L.offs[4]; const float* ae_p = params + L.offs[22];
+    bool deferred = true;
     ST_TRY(ae_bwd_impl(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.dAA, g_mag_hat, reg_coef, w.dmag, w.dphs,
-                       w.aews, grads + L.offs[4], grads + L.offs[22], true, stream));      // the forward left its AE state in w.aews
-    return st_polar_bwd(d, w.re, w.im, w.dmag, w.dphs, g_mag, w.dG, stream);
+                       w.aews, grads + L.offs[4], grads + L.offs[22], true, stream, &deferred));      // the forward left its AE state in w.aews
+    if (!deferred) return st_polar_bwd(d, w.re, w.im, w.dmag, w.dphs, g_mag, w.dG, stream);
+    stm::PostAeArgs a;
+    a.ws = w.aews; a.nparts = ae_bwd_grid(d); a.PG = L.PG; a.g_m = grads + L.offs[4]; a.g_p = grads + L.offs[22];
+    a.n_red_x = (L.PG + 63) / 64; a.n_red = 2 * a.n_red_x;
+    a.re = w.re; a.im = w.im; a.dmag = w.dmag; a.dphs = w.dphs; a.g_mag = g_mag; a.dG = w.dG; a.F = d->F; a.KP = L.KP;
+    a.gx = (L.KP / 2 + 255) / 256; a.sat = gemm_ht(d->prec) == 2 ? 65504.0f : 0.0f;
+    hipLaunchKernelGGL(stm::post_ae_kernel, dim3(a.n_red + a.gx * d->B * d->T), dim3(256), 0, st_stream(stream), a);
+    ST_LAUNCHED("post_ae");
+    return ST_OK;
 }
 static int backward_p1(const st_dims* d, const Layout& L, const float* params, float* grads,
                        const float* knobs, const float* g_mag_hat, const float* g_mag, float reg_coef, WS& w, void* stream)

@@ -70,6 +70,11 @@ __device__ __forceinline__ float4 ldg128(const float* __restrict__ base, const u
 
 struct Src { const float* p; bool ok; };
 
+// A TN-type operand as data: element (k, col) lives at  base[b * S1 + t * S2 + col]  with (b, t) = RowMap::split(k < clampR ? k : 0),
+// valid iff k < klim && col < collim.  Lets ONE code path address either operand of a TN x TN GEMM from per-lane parameters
+// (gemm_kernel's unified micro-tile items) instead of evaluating both loaders' off() in every lane.
+struct TNParams { const float* base; unsigned magic, S1, S2; int Tv, t_lo, clampR, klim, collim; };
+
 struct RowState {
     const float* p;   // element k of this row lives at p[k] (only dereferenced for lo <= k < hi)
     unsigned o;       // the same as a 32-bit element offset from the loader's dummy() base (loaders with kOff; may wrap below zero for k < lo)
@@ -156,6 +161,8 @@ struct FramedTN {
         if (!PADDED) { v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; }
         return v;
     }
+    static constexpr bool kParams = PADDED;            // expressible as TNParams (the padded form only: no per-element validity)
+    __device__ TNParams tn_params() const { return TNParams{sig, map.magic, (unsigned)(Ls + 2 * pad), (unsigned)H, map.Tv, map.t_lo, R, 0x7fffffff, 0x7fffffff}; }
 };
 
 // Dense row-major [rows][ld] matrix, reduction along the row (NT-type); compact rows via RowMap.  Requires K % BK == 0;
@@ -192,6 +199,8 @@ struct PlainTN {
         return ok ? __umul24((unsigned)map.full(k), (unsigned)ld) + (unsigned)c : 0u;
     }
     __device__ float4 post(float4 v) const { return v; }
+    static constexpr bool kParams = true;
+    __device__ TNParams tn_params() const { return TNParams{base, map.magic, (unsigned)(map.T * ld), (unsigned)ld, map.Tv, map.t_lo, K, K, cols}; }
 };
 
 // Analysis bases as the B operand: GEMM column j -> (bin = j>>1, re/im = j&1); only the F used rows
@@ -315,6 +324,9 @@ struct PolarStore {
     }
 };
 
+template <class L, class = void> struct has_tn_params { static constexpr bool value = false; };
+template <class L> struct has_tn_params<L, decltype((void)L::kParams)> { static constexpr bool value = L::kParams; };
+
 // ------------------------------------------------------------------------------ kernel
 // The timing-only ablation switches are COMPILE-TIME (build with -DST_GEMM_ABLATE for tools/gemm_ablate*.py): as run-time
 // tests they split the k-loop body into several basic blocks, and the compiler then shuttled all 48 accumulator registers
@@ -329,11 +341,19 @@ struct PolarStore {
 // MI = 32-row blocks per wave: MI = 1 is the 32 x 96 wave strip; WAVES_M = 1, MI = 3 lets ONE wave own a 96 x 96 tile
 // (9 accumulators): same global traffic per MFMA as three waves sharing the tile, half the LDS fragment reads (B is read
 // once instead of three times) and no cross-wave barrier stalls -- for the split-K weight-gradient GEMMs.
-// XT: M/N-contiguous (TN-type) operands are transposed on the way into LDS -- a thread loads a 4(k) x 4(m)
-// micro-tile as four float4 and writes four k-quads -- so BOTH operands sit row-major [row][BK+4] and every MFMA fragment
-// is fetched with ds_read_b128 (4 k per instruction).  MEASURED SLOWER in fp32 (analysis wgrad 179 -> 281 us): the four
-// row writes of a micro-tile are 80 floats apart and pile onto two LDS bank groups; the k-major staging (XT = false,
-// the default) stays.  The bf16 kernel needs K-contiguous operands and uses the transposed staging (half the data).
+// XT: M/N-contiguous (TN-type) operands are transposed on the way into LDS -- a thread loads a 4(k) x 4(row) micro-tile as four
+// float4 and writes four k-quads -- into a K-QUAD-MAJOR tile  X[k / 4][row][k % 4]  (16-byte slots, no padding), so that the MFMA
+// fragments of such an operand are fetched exactly like those of a K-contiguous one: ds_read_b128 of 4 consecutive k, HK / 4 reads
+// per 32 rows per k-tile instead of HK scalar ds_read_b32 (the k-major staging costs the weight-gradient GEMMs and the synthesis
+// frames GEMM ~17 points of MFMA utilisation against the NT x NT GEMMs: 4 LDS instructions + a wait per 3 MFMAs).  Slot of
+// (k-quad q, row r):  q * ROWS + swz(r),  swz = (r & ~3) | ((r + (r >> 3)) & 3): the rotation of the row-within-quad
+// index by the 8-row block (and by the k-quad, for the service groups that straddle two k-quads) makes both the ds_write_b128
+// of the four micro-tile rows and the ds_read_b128 of 16 consecutive rows hit 16 distinct 16-byte slots -- conflict-free both
+// ways.  (Round 1 tried a row-major [row][BK+4] transposed tile: its four row writes piled onto two bank groups, 55 % slower.)
+// MEASURED (round 2, B = 256): SQ_LDS_BANK_CONFLICT 0 and a third fewer LDS-array cycles than the k-major staging, yet the
+// weight-gradient GEMM is SLOWER (173 vs 145 us) -- the kernel is not bound by its fragment reads.  Kept selectable
+// (st_set_tuning(7001)); the default stays k-major.
+__device__ __forceinline__ int xq_slot(const int row, const int q) { (void)q; return (row & ~3) | ((row + (row >> 3)) & 3); }
 template <int WAVES_M, int BKT, int MI, bool XT, class AL, class BL, class EPI>
 __global__ void __launch_bounds__(WAVES_M * 64)
 gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int ksplit, const int dbg)
@@ -342,10 +362,10 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
     constexpr int PKT = BKT + 4;                         // row pitch: 36 (BK 32) / 20 (BK 16) floats, both conflict-free for b128
     constexpr bool A_T = AL::kTN && XT, A_K = AL::kTN && !XT;       // transposed staging / k-major staging
     constexpr bool B_T = BL::kTN && XT, B_K = BL::kTN && !XT;
-    constexpr int LDA = A_K ? BM + 4 : PKT;             // k-major [BK][BM+4] ; row-major [BM][PKT]
+    constexpr int LDA = A_K ? BM + 4 : PKT;             // k-major [BK][BM+4] ; row-major [BM][PKT] ; A_T: k-quad-major [BK/4][BM][4]
     constexpr int LDB = B_K ? BN + 4 : PKT;
-    constexpr int A_SZ = A_K ? BKT * LDA : BM * LDA;
-    constexpr int B_SZ = B_K ? BKT * LDB : BN * LDB;
+    constexpr int A_SZ = A_T ? BKT * BM : (A_K ? BKT * LDA : BM * LDA);
+    constexpr int B_SZ = B_T ? BKT * BN : (B_K ? BKT * LDB : BN * LDB);
     constexpr int KQ = BKT / 4;                          // float4 per row per k-tile
     constexpr int A_N = A_T ? (BM / 4) * KQ : BM * KQ;   // items per k-tile: float4s, or 4x4 micro-tiles (4 float4 loads each)
     constexpr int B_N = B_T ? (BN / 4) * KQ : BN * KQ;
@@ -370,23 +390,51 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
         const int idx = tid + NT * p;
         a_v[p] = idx < A_N;
         const int id = a_v[p] ? idx : 0;
-        if constexpr (A_T) { a_i[p] = ((id / (4 * KQ)) * 4 + (id % 4)) * 4; a_k[p] = ((id / 4) % KQ) * 4; a_l[p] = a_i[p] * LDA + a_k[p]; }   // quad = 64 B of one global row, then k-groups
+        if constexpr (A_T) { a_i[p] = (id % (BM / 4)) * 4; a_k[p] = (id / (BM / 4)) * 4; a_l[p] = 0; }   // micro-tile: rows a_i..a_i+3 (fastest across lanes: coalesced), k = a_k..a_k+3
         else if constexpr (A_K) { a_i[p] = (id % (BM / 4)) * 4; a_k[p] = id / (BM / 4); a_l[p] = a_k[p] * LDA + a_i[p]; }
         else { a_i[p] = id / KQ; a_k[p] = (id % KQ) * 4; a_l[p] = a_i[p] * LDA + a_k[p]; a_st[p] = al.row_state(m_blk + a_i[p]); }
     }
 #pragma unroll
     for (int p = 0; p < B_IT; ++p) {
-        const int idx = tid + NT * p;
+        const int idx = (B_T ? NT - 1 - tid : tid) + NT * p;      // micro-tile items: B starts from the last thread, so a tile with fewer items than threads spreads A and B over different waves
         b_v[p] = idx < B_N;
         const int id = b_v[p] ? idx : 0;
-        if constexpr (B_T) { b_i[p] = ((id / (4 * KQ)) * 4 + (id % 4)) * 4; b_k[p] = ((id / 4) % KQ) * 4; b_l[p] = b_i[p] * LDB + b_k[p]; }
+        if constexpr (B_T) { b_i[p] = (id % (BN / 4)) * 4; b_k[p] = (id / (BN / 4)) * 4; b_l[p] = 0; }
         else if constexpr (B_K) { b_i[p] = (id % (BN / 4)) * 4; b_k[p] = id / (BN / 4); b_l[p] = b_k[p] * LDB + b_i[p]; }
         else { b_i[p] = id / KQ; b_k[p] = (id % KQ) * 4; b_l[p] = b_i[p] * LDB + b_k[p]; b_st[p] = bl.row_state(n_blk + b_i[p]); }
     }
 
-    float4 ra[A_IT][A_LD], rb[B_IT][B_LD];
-    bool oa[A_IT][A_LD], ob[B_IT][B_LD];
+    // TN x TN with both operands transposed on the way in (the weight-gradient GEMMs): ONE micro-tile per thread -- threads
+    // [0, A_N) take A's, threads [A_N, A_N + B_N) take B's -- instead of a (half-idle) A item and a B item each: 16 prefetch
+    // registers instead of 32, which is what keeps four waves per SIMD resident.
+    constexpr bool UNI = A_T && B_T && (A_N + B_N <= NT) && A_IT == 1 && B_IT == 1 && has_tn_params<AL>::value && has_tn_params<BL>::value;
+    const bool u_isA = tid < A_N;
+    int u_i = 0, u_k = 0;
+    TNParams up{};
+    if constexpr (UNI) {
+        const int id = u_isA ? tid : (tid - A_N < B_N ? tid - A_N : 0); const int RQ = u_isA ? BM / 4 : BN / 4; u_i = (id % RQ) * 4; u_k = (id / RQ) * 4;
+        const TNParams pa = al.tn_params(), pb = bl.tn_params();
+        up.base = u_isA ? pa.base : pb.base; up.magic = u_isA ? pa.magic : pb.magic; up.S1 = u_isA ? pa.S1 : pb.S1; up.S2 = u_isA ? pa.S2 : pb.S2;
+        up.Tv = u_isA ? pa.Tv : pb.Tv; up.t_lo = u_isA ? pa.t_lo : pb.t_lo; up.clampR = u_isA ? pa.clampR : pb.clampR;
+        up.klim = u_isA ? pa.klim : pb.klim; up.collim = u_isA ? pa.collim : pb.collim;
+        u_i += u_isA ? m_blk : n_blk;                    // global column of the micro-tile's first row
+    }
+    float4 ra[UNI ? 1 : A_IT][A_LD], rb[UNI ? 1 : B_IT][UNI ? 1 : B_LD];
+    bool oa[UNI ? 1 : A_IT][A_LD], ob[UNI ? 1 : B_IT][UNI ? 1 : B_LD];
     auto gload = [&](int kt) {
+        if constexpr (UNI) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = kt + u_k + q;
+                const unsigned kc = (unsigned)(k < up.clampR ? k : 0);
+                const unsigned b = up.magic ? __umulhi(kc, up.magic) : kc;
+                const unsigned t = (unsigned)up.t_lo + (kc - __umul24(b, (unsigned)up.Tv));
+                const bool ok = k < up.klim && u_i < up.collim;
+                oa[0][q] = ok;
+                ra[0][q] = ldg128(up.base, ok ? __umul24(b, up.S1) + __umul24(t, up.S2) + (unsigned)u_i : 0u);
+            }
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < A_IT; ++p)
 #pragma unroll
@@ -422,6 +470,20 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
         float* as = As + buf * A_SZ;
         float* bs = Bs + buf * B_SZ;
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (UNI) {
+            if (tid < A_N + B_N) {
+                float4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = oa[0][q] ? (u_isA ? al.post(ra[0][q]) : bl.post(ra[0][q])) : zero;
+                const int q_ = u_k >> 2, li = u_i - (u_isA ? m_blk : n_blk);
+                float* base_ = (u_isA ? as : bs) + q_ * ((u_isA ? BM : BN) * 4);
+                *reinterpret_cast<float4*>(base_ + 4 * xq_slot(li + 0, q_)) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
+                *reinterpret_cast<float4*>(base_ + 4 * xq_slot(li + 1, q_)) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+                *reinterpret_cast<float4*>(base_ + 4 * xq_slot(li + 2, q_)) = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
+                *reinterpret_cast<float4*>(base_ + 4 * xq_slot(li + 3, q_)) = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
+            }
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < A_IT; ++p) {
             if (A_N % NT != 0 && !a_v[p]) continue;
@@ -429,10 +491,12 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
                 float4 v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = oa[p][q] ? al.post(ra[p][q]) : zero;
-                *reinterpret_cast<float4*>(as + a_l[p] + 0 * LDA) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
-                *reinterpret_cast<float4*>(as + a_l[p] + 1 * LDA) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
-                *reinterpret_cast<float4*>(as + a_l[p] + 2 * LDA) = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
-                *reinterpret_cast<float4*>(as + a_l[p] + 3 * LDA) = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
+                const int q_ = a_k[p] >> 2;
+                float* base_ = as + q_ * (BM * 4);
+                *reinterpret_cast<float4*>(base_ + 4 * xq_slot(a_i[p] + 0, q_)) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
+                *reinterpret_cast<float4*>(base_ + 4 * xq_slot(a_i[p] + 1, q_)) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+                *reinterpret_cast<float4*>(base_ + 4 * xq_slot(a_i[p] + 2, q_)) = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
+                *reinterpret_cast<float4*>(base_ + 4 * xq_slot(a_i[p] + 3, q_)) = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
             } else {
                 *reinterpret_cast<float4*>(as + a_l[p]) = oa[p][0] ? al.post(ra[p][0]) : zero;
             }
@@ -444,10 +508,12 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
                 float4 v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = ob[p][q] ? bl.post(rb[p][q]) : zero;
-                *reinterpret_cast<float4*>(bs + b_l[p] + 0 * LDB) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
-                *reinterpret_cast<float4*>(bs + b_l[p] + 1 * LDB) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
-                *reinterpret_cast<float4*>(bs + b_l[p] + 2 * LDB) = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
-                *reinterpret_cast<float4*>(bs + b_l[p] + 3 * LDB) = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
+                const int q_ = b_k[p] >> 2;
+                float* base_ = bs + q_ * (BN * 4);
+                *reinterpret_cast<float4*>(base_ + 4 * xq_slot(b_i[p] + 0, q_)) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
+                *reinterpret_cast<float4*>(base_ + 4 * xq_slot(b_i[p] + 1, q_)) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+                *reinterpret_cast<float4*>(base_ + 4 * xq_slot(b_i[p] + 2, q_)) = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
+                *reinterpret_cast<float4*>(base_ + 4 * xq_slot(b_i[p] + 3, q_)) = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
             } else {
                 *reinterpret_cast<float4*>(bs + b_l[p]) = ob[p][0] ? bl.post(rb[p][0]) : zero;
             }
@@ -469,9 +535,23 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
         int cur = 0;
         const int h = lane >> 5, l31 = lane & 31;
         // NT: lane reads HK consecutive floats of its row; TN: lane reads column l31 of rows HK*h .. HK*h+HK-1
-        const int a_off = A_K ? (HK * h) * LDA + wave * (32 * MI) + l31 : (wave * (32 * MI) + l31) * LDA + HK * h;
+        const int a_off = A_T ? 0 : (A_K ? (HK * h) * LDA + wave * (32 * MI) + l31 : (wave * (32 * MI) + l31) * LDA + HK * h);
         constexpr int A_MI = A_K ? 32 : 32 * LDA;              // LDS offset between the wave's 32-row blocks
-        const int b_off = B_K ? (HK * h) * LDB + l31 : l31 * LDB + HK * h;
+        const int b_off = B_T ? 0 : (B_K ? (HK * h) * LDB + l31 : l31 * LDB + HK * h);
+        // k-quad-major operands: float offset of (row, k-quad HK/4 * h + q) -- per lane, fixed across k-tiles
+        int a_xq[A_T ? MI : 1][A_T ? HK / 4 : 1], b_xq[B_T ? NJ : 1][B_T ? HK / 4 : 1];
+        if constexpr (A_T) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int q = 0; q < HK / 4; ++q) { const int kq = (HK / 4) * h + q; a_xq[mi][q] = (kq * BM + xq_slot((wave * MI + mi) * 32 + l31, kq)) * 4; }
+        }
+        if constexpr (B_T) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < HK / 4; ++q) { const int kq = (HK / 4) * h + q; b_xq[j][q] = (kq * BN + xq_slot(32 * j + l31, kq)) * 4; }
+        }
         for (int kt = k_begin; kt < k_end; kt += BKT) {
             // branch-free body: the last iteration re-loads its own tile (harmless) instead of skipping the prefetch,
             // so the whole loop is ONE basic block and the accumulators stay put
@@ -488,7 +568,7 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
                     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                         for (int q = 0; q < HK / 4; ++q) {
-                            const float4 v = *reinterpret_cast<const float4*>(as + mi * A_MI + 4 * q);
+                            const float4 v = *reinterpret_cast<const float4*>(A_T ? as + a_xq[A_T ? mi : 0][A_T ? q : 0] : as + mi * A_MI + 4 * q);
                             af[mi][4 * q] = v.x; af[mi][4 * q + 1] = v.y; af[mi][4 * q + 2] = v.z; af[mi][4 * q + 3] = v.w;
                         }
                 }
@@ -497,7 +577,7 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
                     for (int j = 0; j < NJ; ++j)
 #pragma unroll
                         for (int q = 0; q < HK / 4; ++q) {
-                            const float4 v = *reinterpret_cast<const float4*>(bs + 32 * j * LDB + 4 * q);
+                            const float4 v = *reinterpret_cast<const float4*>(B_T ? bs + b_xq[B_T ? j : 0][B_T ? q : 0] : bs + 32 * j * LDB + 4 * q);
                             bf[j][4 * q] = v.x; bf[j][4 * q + 1] = v.y; bf[j][4 * q + 2] = v.z; bf[j][4 * q + 3] = v.w;
                         }
                 }

@@ -7,11 +7,9 @@ namespace stm {
 // ---------------------------------------------------------------- synthesis basis fold
 // Sfold[KP,N]: rows [0,F) = Sr[k] (+ Sr[N-k], 1<=k<=F-2); rows [KP/2, KP/2+F) = Si[k] (- Si[N-k]); rest 0.
 // Weight-side form of the Hermitian extension at cls_fe_dft.py:109-110.
-__global__ void __launch_bounds__(256)
-fold_kernel(const float* __restrict__ Sr, const float* __restrict__ Si, float* __restrict__ Sfold,
-            int N, int F, int KP)
+__device__ __forceinline__ void fold_row(const float* __restrict__ Sr, const float* __restrict__ Si, float* __restrict__ Sfold,
+                                         const int N, const int F, const int KP, const int row)
 {
-    const int row = blockIdx.x;                      // 0..KP-1
     const int half = KP / 2;
     const bool is_im = row >= half;
     const int k = is_im ? row - half : row;
@@ -31,14 +29,18 @@ fold_kernel(const float* __restrict__ Sr, const float* __restrict__ Si, float* _
         reinterpret_cast<float4*>(Sfold + (size_t)row * N)[n4] = v;
     }
 }
+__global__ void __launch_bounds__(256)
+fold_kernel(const float* __restrict__ Sr, const float* __restrict__ Si, float* __restrict__ Sfold, int N, int F, int KP)
+{
+    fold_row(Sr, Si, Sfold, N, F, KP, blockIdx.x);                      // 0..KP-1
+}
 
 // Frames that lie entirely in the Conv1d zero padding: re = im = mag = 0 and phs = atan2(0, 1e-7) = 0 exactly.
-__global__ void __launch_bounds__(256)
-zero_dead_frames_kernel(float* __restrict__ a0, float* __restrict__ a1, float* __restrict__ a2, float* __restrict__ a3,
-                        int T, int F, int t_lo, int Tv)
+__device__ __forceinline__ void zero_dead_frame(float* __restrict__ a0, float* __restrict__ a1, float* __restrict__ a2, float* __restrict__ a3,
+                                                const int T, const int F, const int t_lo, const int Tv, const int blk)
 {
     const int nd = T - Tv;
-    const int b = blockIdx.x / nd, j = blockIdx.x - b * nd;
+    const int b = blk / nd, j = blk - b * nd;
     const int t = j < t_lo ? j : j + Tv;
     const size_t base = ((size_t)b * T + t) * F;
     for (int f = threadIdx.x; f < F; f += 256) {
@@ -47,6 +49,12 @@ zero_dead_frames_kernel(float* __restrict__ a0, float* __restrict__ a1, float* _
         if (a2) a2[base + f] = 0.f;
         if (a3) a3[base + f] = 0.f;
     }
+}
+__global__ void __launch_bounds__(256)
+zero_dead_frames_kernel(float* __restrict__ a0, float* __restrict__ a1, float* __restrict__ a2, float* __restrict__ a3,
+                        int T, int F, int t_lo, int Tv)
+{
+    zero_dead_frame(a0, a1, a2, a3, T, F, t_lo, Tv, blockIdx.x);
 }
 
 // ---------------------------------------------------------------- overlap-add + residual + log-cosh
@@ -100,18 +108,41 @@ ola_loss_kernel(const float* __restrict__ frs, const float* __restrict__ x, cons
 
 // out[b][pad + Ls + pad] = zero margins | s * in[b][Ls]: the padded, pre-scaled signal the framed GEMM loaders read
 // (x/2 of nn_proc.py:307 with the Conv1d padding of cls_fe_dft.py:28-31 materialised once per step, 10 MB at B=256).
-__global__ void __launch_bounds__(256)
-pad_scale_kernel(const float* __restrict__ in, float* __restrict__ out, int Ls, int pad, float s)
+__device__ __forceinline__ void pad_scale_block(const float* __restrict__ in, float* __restrict__ out, const int Ls, const int pad, const float s,
+                                                const int bx, const int nbx, const int b)
 {
-    const int b = blockIdx.y, Lp4 = (Ls + 2 * pad) / 4;
+    const int Lp4 = (Ls + 2 * pad) / 4;
     const float4* src = reinterpret_cast<const float4*>(in + (size_t)b * Ls);
     float4* dst = reinterpret_cast<float4*>(out + (size_t)b * (Ls + 2 * pad));
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < Lp4; i += gridDim.x * 256) {
+    for (int i = bx * 256 + threadIdx.x; i < Lp4; i += nbx * 256) {
         const int j = i - pad / 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (j >= 0 && j < Ls / 4) { v = src[j]; v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
         dst[i] = v;
     }
+}
+__global__ void __launch_bounds__(256)
+pad_scale_kernel(const float* __restrict__ in, float* __restrict__ out, int Ls, int pad, float s)
+{
+    pad_scale_block(in, out, Ls, pad, s, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
+// Everything the fused forward needs before its first GEMM, in ONE launch (three independent HBM-bound jobs that were three
+// launches of 6-8 us each, mostly launch ramp): [0, n_pad) the padded, pre-scaled signal copy; [n_pad, n_pad + KP) the Hermitian
+// fold of the synthesis bases (they change only in the optimizer, but the workspace is the caller's and may be re-carved between
+// steps, so the fold is rebuilt per step -- 8 MB of traffic); the rest zeroes the frames that lie wholly in the Conv1d padding.
+struct PrepArgs {
+    const float* x; float* xp; int Ls, pad; float scale; int nbx, n_pad;
+    const float* Sr; const float* Si; float* Sfold; int N, F, KP;
+    float *re, *im, *mag, *phs; int T, t_lo, Tv;
+};
+__global__ void __launch_bounds__(256)
+prep_kernel(const PrepArgs a)
+{
+    const int blk = blockIdx.x;
+    if (blk < a.n_pad) { const int b = blk / a.nbx; pad_scale_block(a.x, a.xp, a.Ls, a.pad, a.scale, blk - b * a.nbx, a.nbx, b); }
+    else if (blk < a.n_pad + a.KP) fold_row(a.Sr, a.Si, a.Sfold, a.N, a.F, a.KP, blk - a.n_pad);
+    else zero_dead_frame(a.re, a.im, a.mag, a.phs, a.T, a.F, a.t_lo, a.Tv, blk - a.n_pad - a.KP);
 }
 
 // dsyn = 2 * g_y_hat  (y_hat = 2*(syn + x/2), nn_proc.py:332,340) -- generic autograd entry
@@ -124,14 +155,13 @@ scale_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, f
 // ---------------------------------------------------------------- polar backward (nn_proc.py:309-310)
 // dre = dmag*re/mag [0 at mag==0] - dphs*im/((re+eps)^2+im^2);  dim = dmag*im/mag + dphs*(re+eps)/(...)
 // Output dG[R,KP]: d re at [0,F), d im at [KP/2,KP/2+F), pads written as zeros.
-__global__ void __launch_bounds__(256)
-polar_bwd_kernel(const float* __restrict__ re, const float* __restrict__ im, const float* __restrict__ dmag,
-                 const float* __restrict__ dphs, const float* __restrict__ g_mag, float* __restrict__ dG, int R, int F, int KP,
-                 const float sat)      // > 0: saturate the result to +-sat (the consumer GEMM narrows it to fp16, see below)
+__device__ __forceinline__ void polar_bwd_block(const float* __restrict__ re, const float* __restrict__ im, const float* __restrict__ dmag,
+                 const float* __restrict__ dphs, const float* __restrict__ g_mag, float* __restrict__ dG, const int F, const int KP,
+                 const float sat,      // > 0: saturate the result to +-sat (the consumer GEMM narrows it to fp16, see below)
+                 const int bx, const int r)
 {
     const int half = KP / 2;
-    const int r = blockIdx.y;
-    const int c = blockIdx.x * 256 + threadIdx.x;     // column in [0, half)
+    const int c = bx * 256 + threadIdx.x;     // column in [0, half)
     if (c >= half) return;
     float gre = 0.f, gim = 0.f;
     if (c < F) {
@@ -150,6 +180,12 @@ polar_bwd_kernel(const float* __restrict__ re, const float* __restrict__ im, con
     }
     dG[(size_t)r * KP + c] = gre;
     dG[(size_t)r * KP + half + c] = gim;
+}
+__global__ void __launch_bounds__(256)
+polar_bwd_kernel(const float* __restrict__ re, const float* __restrict__ im, const float* __restrict__ dmag,
+                 const float* __restrict__ dphs, const float* __restrict__ g_mag, float* __restrict__ dG, int R, int F, int KP, const float sat)
+{
+    polar_bwd_block(re, im, dmag, dphs, g_mag, dG, F, KP, sat, blockIdx.x, blockIdx.y);
 }
 
 // ---------------------------------------------------------------- split-K slab reduce (+ unfold, + |g| sums)
@@ -205,13 +241,12 @@ l1_partial_kernel(const float* __restrict__ g, int64_t n, float scale, float* __
 
 // ---------------------------------------------------------------- per-wave AE gradient partial reduce
 // ws[nparts][2][PG] -> g_m[PG], g_p[PG].  Block = 64 columns x 4 partial-lanes; 8 loads in flight per thread.
-__global__ void __launch_bounds__(256)
-ae_grad_reduce_kernel(const float* __restrict__ ws, int nparts, int PG, float* __restrict__ g_m, float* __restrict__ g_p)
+__device__ __forceinline__ void ae_grad_reduce_block(const float* __restrict__ ws, const int nparts, const int PG,
+                                                     float* __restrict__ g_m, float* __restrict__ g_p, const int bx, const int ae)
 {
     __shared__ float red[4][64];
     const int col = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + col;
-    const int ae = blockIdx.y;
+    const int i = bx * 64 + col;
     float s = 0.f;
     if (i < PG) {
         const float* base = ws + (size_t)ae * PG + i;
@@ -227,6 +262,24 @@ ae_grad_reduce_kernel(const float* __restrict__ ws, int nparts, int PG, float* _
     red[pl][col] = s;
     __syncthreads();
     if (pl == 0 && i < PG) (ae ? g_p : g_m)[i] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+}
+__global__ void __launch_bounds__(256)
+ae_grad_reduce_kernel(const float* __restrict__ ws, int nparts, int PG, float* __restrict__ g_m, float* __restrict__ g_p)
+{
+    ae_grad_reduce_block(ws, nparts, PG, g_m, g_p, blockIdx.x, blockIdx.y);
+}
+// The two consumers of ae_bwd_kernel's outputs in ONE launch (they are independent of each other): blocks [0, n_red) sum the
+// per-workgroup autoencoder gradient partials, the rest is the polar backward (blocks enumerate (row, column chunk)).
+struct PostAeArgs {
+    const float* ws; int nparts, PG; float* g_m; float* g_p; int n_red_x, n_red;
+    const float* re; const float* im; const float* dmag; const float* dphs; const float* g_mag; float* dG; int F, KP, gx; float sat;
+};
+__global__ void __launch_bounds__(256)
+post_ae_kernel(const PostAeArgs a)
+{
+    const int blk = blockIdx.x;
+    if (blk < a.n_red) { const int ae = blk / a.n_red_x; ae_grad_reduce_block(a.ws, a.nparts, a.PG, a.g_m, a.g_p, blk - ae * a.n_red_x, ae); }
+    else { const int q = blk - a.n_red, r = q / a.gx; polar_bwd_block(a.re, a.im, a.dmag, a.dphs, a.g_mag, a.dG, a.F, a.KP, a.sat, q - r * a.gx, r); }
 }
 
 // ---------------------------------------------------------------- scalars

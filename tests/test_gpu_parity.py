@@ -234,9 +234,13 @@ def test_f16_overflow_skips_the_step_and_counts_it():
         e = StepEngine(d, G.DEV, compute_dtype="f16_all", loss_scale=S); e.load_state_dict(P)
         e.train_step(x, kn, y, 1e-3); torch.cuda.synchronize()
         assert e.overflow_steps() == 0 and torch.isfinite(e.params).all()
-        outs.append(e.params.clone())
-    assert (outs[0] - before).abs().max().item() > 1e-5                       # a real update happened
-    assert (outs[0] - outs[1]).abs().max().item() <= 2e-4                     # Adam turns rounding-level differences into fractions of lr at worst
+        outs.append((e.params.clone(), e.grads.clone()))
+    assert (outs[0][0] - before).abs().max().item() > 1e-5                    # a real update happened
+    # the unscaled, clipped gradient does not depend on the scale beyond fp16 rounding of the scaled operands (the first Adam
+    # step itself is lr * sign(g): a noise-level element that changes sign moves its parameter by 2 lr, so parameters are compared loosely)
+    g0, g1 = outs[0][1], outs[1][1]
+    assert (g0 - g1).abs().max().item() <= 3e-3 * g0.abs().max().item()
+    assert ((outs[0][0] - outs[1][0]).abs() > 2e-4).float().mean().item() < 2e-2
 
 
 def test_engines_of_different_precision_coexist():
