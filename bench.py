@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--bk", type=int, default=0, help="GEMM k-tile depth override (16/32)")
+    ap.add_argument("--no-graph", action="store_true", help="N = 1: skip the HIP-graph replay measurement (ms_per_step_graph)")
     ap.add_argument("--tune", type=int, nargs="*", default=[], help="diagnostics: st_set_tuning codes applied before the run")
     ap.add_argument("--dp-schedule", choices=["two_bucket", "staged"], default="two_bucket", help="all-reduce schedule of the data-parallel step (signaltrain_amd/dp.py)")
     ap.add_argument("--force-dp", action="store_true", help="run the N > 1 code path (bucketed RCCL all-reduce, st_dp_clip_adam) "
@@ -175,6 +176,22 @@ def main():
         dt = float(tt.item())
     loss = dp.mean_loss()
     ms = dt / args.steps * 1e3
+    # the same step replayed from ONE captured HIP graph (st_graph_*: step counter and learning rate on the device): reported
+    # beside the eager number; `value` stays the eager one (the graph removes host launch work, which the asynchronous eager
+    # loop already hides at this step length -- the GPU-side kernel boundaries cost the same either way)
+    ms_graph = None
+    if world == 1 and not args.force_dp and not args.no_graph:
+        eng.graph_capture(B, lrs)
+        eng.gx.copy_(x); eng.gk.copy_(kn); eng.gy.copy_(y)
+        for i in range(args.warmup):
+            eng.graph_step()
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            eng.graph_step()
+        fence()
+        ms_graph = (time.perf_counter() - t0) / args.steps * 1e3
+        eng.graph_destroy()
     windows_s = B * world / (ms * 1e-3)
 
     out = None
@@ -187,7 +204,7 @@ def main():
                           "window": d.L, "frames_per_window": d.T, "global_batch": B * world, "parallelism": f"dp{world}",
                           **({"dp_backend": dp_backend, "dp_schedule": args.dp_schedule} if (world > 1 or args.force_dp) else {}),
                           **({"dp_note": dp_note} if dp_note else {})},
-               "windows_per_s": windows_s, "samples_per_s": windows_s * d.L, "loss": loss,
+               "windows_per_s": windows_s, "samples_per_s": windows_s * d.L, "loss": loss, "ms_per_step_graph": ms_graph,
                "step_tflops": flops_step / (ms * 1e-3) / 1e12 * world,
                "step_frac_of_fp32_mfma_peak": flops_step / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TF}
         if args.dtype != "f32":

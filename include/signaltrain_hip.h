@@ -256,6 +256,20 @@ int st_dp_train_step(st_dp* p, const st_dims* d, float* params, float* grads, fl
                      const float* x, const float* knobs, const float* y_true, void* ws, float* scalars,
                      float lr, float beta1, float beta2, float eps, int step, int force_exchange, void* stream);
 
+/* ---- the whole optimisation step as ONE HIP graph -----------------------------------------------------------------------
+ * st_graph_create captures st_train_step (every kernel of train.py:112-151) on `stream` -- which must not be the legacy
+ * default stream -- with the per-iteration quantities on the device: scalars[6] = step counter (0 before the first step;
+ * restore it together with m / v when resuming), scalars[7] = learning rate of the step, looked up by the graph's head
+ * node in lr_table (device float[n_lr] = the 1-cycle table, learningrate.py:14-52) as lr_sched[max(i - 1, 0)] for the
+ * 0-based iteration i (train.py:150).  The graph reads the minibatch from the x / knobs / y_true buffers it was captured
+ * with: refill them before each st_graph_launch.  All pointers must stay valid for the graph's lifetime. */
+typedef struct st_graph st_graph;
+int st_graph_create(const st_dims* d, float* params, float* grads, float* m, float* v, const float* x,
+                    const float* knobs, const float* y_true, void* ws, float* scalars,
+                    const float* lr_table, int n_lr, float beta1, float beta2, float eps, void* stream, st_graph** out);
+int st_graph_launch(st_graph* g, void* stream);
+int st_graph_destroy(st_graph* g);
+
 /* ---- device-side data feed -------------------------------------------------------------------
  * audio.compressor_4controls (signaltrain/audio.py:380-426), the effect of the synthetic comp_4c task
  * (SynthAudioDataSet, datasets.py:312-334), for a batch of device-resident windows:

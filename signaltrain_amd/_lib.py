@@ -84,6 +84,9 @@ SIGNATURES = {
     "st_loss_backward_stage": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "st_train_step": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _p]),
     "st_dp_clip_adam": (_i, [_D, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _i, _p]),
+    "st_graph_create": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _p, C.POINTER(_p)]),
+    "st_graph_launch": (_i, [_p, _p]),
+    "st_graph_destroy": (_i, [_p]),
     "st_dp_unique_id": (_i, [_p]),
     "st_dp_init": (_i, [_p, _i, _i, C.POINTER(_p)]),
     "st_dp_destroy": (_i, [_p]),

@@ -725,7 +725,7 @@ static stm::FinArgs fin_args(const st_dims* d, const float* loss_partial, const 
 // the partial sums -- no separate finalize launch; `scalars` is then an output.
 static int clip_adam_impl(float* params, float* grads, float* m, float* v, int64_t n_total, int64_t n_stft /* clipped range */,
                           float* scalars, float grad_scale, float lr, float beta1, float beta2, float eps, int step,
-                          const stm::FinArgs* fin, void* stream)
+                          const stm::FinArgs* fin, void* stream, bool dev_hyper = false)
 {
     ST_REQ(params && grads && m && v && scalars, "st_clip_adam: null pointer");
     ST_REQ(n_total % 4 == 0 && n_stft % 4 == 0 && n_stft <= n_total && step >= 1, "st_clip_adam: bad sizes/step");
@@ -734,7 +734,11 @@ static int clip_adam_impl(float* params, float* grads, float* m, float* v, int64
     const float bc2s = (float)sqrt(bc2);
     const float w1 = (float)(1.0 - (double)beta1), w2 = (float)(1.0 - (double)beta2);
     int grid = (int)((n_total / 4 + 255) / 256); if (grid > 2048) grid = 2048;
-    if (fin)
+    if (dev_hyper) {          // step number and learning rate from scalars[6], scalars[7] (captured step, st_graph_*)
+        ST_REQ(fin, "device-side hyper-parameters need the fused finalize");
+        hipLaunchKernelGGL((stm::clip_adam_kernel<true, true>), dim3(grid), dim3(256), 0, st_stream(stream),
+                           params, grads, m, v, n_total / 4, n_stft / 4, scalars, grad_scale, 0.f, w1, beta2, w2, 1.f, eps, *fin, beta1);
+    } else if (fin)
         hipLaunchKernelGGL(stm::clip_adam_kernel<true>, dim3(grid), dim3(256), 0, st_stream(stream),
                            params, grads, m, v, n_total / 4, n_stft / 4, scalars, grad_scale, neg_step, w1, beta2, w2, bc2s, eps, *fin);
     else
@@ -970,9 +974,18 @@ extern "C" int st_loss_backward_stage(const st_dims* d, const float* params, flo
     }
 }
 
+static int train_step_impl(const st_dims* d, float* params, float* grads, float* m, float* v, const float* x,
+                           const float* knobs, const float* y_true, void* ws, float* scalars,
+                           float lr, float beta1, float beta2, float eps, int step, void* stream, bool dev_hyper);
 extern "C" int st_train_step(const st_dims* d, float* params, float* grads, float* m, float* v, const float* x,
                              const float* knobs, const float* y_true, void* ws, float* scalars,
                              float lr, float beta1, float beta2, float eps, int step, void* stream)
+{
+    return train_step_impl(d, params, grads, m, v, x, knobs, y_true, ws, scalars, lr, beta1, beta2, eps, step, stream, false);
+}
+static int train_step_impl(const st_dims* d, float* params, float* grads, float* m, float* v, const float* x,
+                           const float* knobs, const float* y_true, void* ws, float* scalars,
+                           float lr, float beta1, float beta2, float eps, int step, void* stream, bool dev_hyper)
 {
     Layout L; ST_TRY(make_layout(d, &L));
     ST_REQ(params && grads && x && knobs && y_true && ws && scalars, "st_train_step: null pointer");
@@ -990,7 +1003,7 @@ extern "C" int st_train_step(const st_dims* d, float* params, float* grads, floa
         ST_LAUNCHED("l1_partial_ae");
         f.norm_e = w.norm_e; f.n_ne = NORM_E_PARTIALS;
     }
-    return clip_adam_impl(params, grads, m, v, L.total, d->clip_all ? L.total : L.n_stft, scalars, inv_s, lr, beta1, beta2, eps, step, &f, stream);
+    return clip_adam_impl(params, grads, m, v, L.total, d->clip_all ? L.total : L.n_stft, scalars, inv_s, lr, beta1, beta2, eps, step, &f, stream, dev_hyper);
 }
 
 extern "C" int st_dp_clip_adam(const st_dims* d, float* params, float* grads, float* m, float* v, void* ws,
@@ -1214,4 +1227,71 @@ extern "C" int st_dp_train_step(st_dp* p, const st_dims* d, float* params, float
     ST_TRY(st_dp_sync(p, stream));
     ST_TRY(st_unstage_analysis(d, grads, stage, stream));
     return st_dp_clip_adam(d, params, grads, m, v, ws, scalars, 1.0f / (float)p->world, lr, beta1, beta2, eps, step, stream);
+}
+
+
+// ------------------------------------------------------------------------------ the whole step as one HIP graph
+// st_train_step captured once and replayed: 11 kernel nodes + the step-tick head.  What changes from iteration to iteration --
+// the step number (Adam's bias corrections) and the learning rate (1-cycle table, train.py:108,150) -- lives on the device
+// (scalars[6], scalars[7]; the table is a caller-owned device array), so the graph needs no per-step update; the minibatch is read
+// from the fixed device buffers x / knobs / y_true the graph was captured with (the caller refills them, e.g. by an index gather
+// from a device-resident dataset).  On this path the launch work of a step is one hipGraphLaunch; the GPU-side cost of the
+// kernel boundaries themselves is the same as for eager launches (MI355X_MICROARCH.md "boundary": eager == hipGraph).
+struct st_graph { hipGraph_t graph; hipGraphExec_t exec; };
+
+static int attr_prepare(const st_dims* d)
+{
+    // hipFuncSetAttribute is not a capturable call: make sure every >64 KB-LDS kernel this geometry / precision uses has its
+    // attribute before the capture starts (ensure_dyn_lds is then a table hit inside the captured calls)
+    const int ht = ae_ht(d->prec);
+#define ST_PREP3(K0_, K1_, K2_) do { if (ht == 1) ST_DYN_LDS(K1_); else if (ht == 2) ST_DYN_LDS(K2_); else ST_DYN_LDS(K0_); } while (0)
+    if (ae_is_wide(d)) {
+        ST_PREP3((sta::ae_inner_fwd_kernel<AE_FWD_NW, 0>), (sta::ae_inner_fwd_kernel<AE_FWD_NW, 1>), (sta::ae_inner_fwd_kernel<AE_FWD_NW, 2>));
+        ST_PREP3((sta::ae_bwd_kernel<AE_BWD_NW, false, true, 0, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, true, 1, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, true, 2, 0>));
+    } else {
+        ST_PREP3((sta::ae_fwd_kernel<AE_FWD_NW, 0>), (sta::ae_fwd_kernel<AE_FWD_NW, 1>), (sta::ae_fwd_kernel<AE_FWD_NW, 2>));
+        if (d->T - d->OT == 16) ST_PREP3((sta::ae_bwd_kernel<AE_BWD_NW, false, false, 0, 2>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 1, 2>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 2, 2>));
+        else ST_PREP3((sta::ae_bwd_kernel<AE_BWD_NW, false, false, 0, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 1, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 2, 0>));
+    }
+#undef ST_PREP3
+    (void)num_cus();
+    return ST_OK;
+}
+
+extern "C" int st_graph_create(const st_dims* d, float* params, float* grads, float* m, float* v, const float* x,
+                               const float* knobs, const float* y_true, void* ws, float* scalars,
+                               const float* lr_table, int n_lr, float beta1, float beta2, float eps, void* stream, st_graph** out)
+{
+    Layout L; ST_TRY(make_layout(d, &L));
+    ST_REQ(params && grads && m && v && x && knobs && y_true && ws && scalars && lr_table && n_lr > 0 && out, "st_graph_create: bad arguments");
+    ST_REQ(!g_prof, "st_graph_create: switch the event profiling off first (event records would be captured)");
+    ST_TRY(attr_prepare(d));
+    hipStream_t s = st_stream(stream);
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return st_fail(ST_ERR_LAUNCH, "st_graph_create: hipStreamBeginCapture failed (is `stream` the legacy default stream?)");
+    hipLaunchKernelGGL(stm::step_tick_kernel, dim3(1), dim3(64), 0, s, scalars, lr_table, n_lr);
+    int rc = train_step_impl(d, params, grads, m, v, x, knobs, y_true, ws, scalars, 0.f, beta1, beta2, eps, 1, stream, true);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(s, &g);
+    if (rc != ST_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess || !g) return st_fail(ST_ERR_LAUNCH, "st_graph_create: capture failed: %s", hipGetErrorString(e));
+    hipGraphExec_t ex = nullptr;
+    if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(g); return st_fail(ST_ERR_LAUNCH, "st_graph_create: hipGraphInstantiate failed"); }
+    st_graph* p = new st_graph{g, ex};
+    *out = p;
+    return ST_OK;
+}
+extern "C" int st_graph_launch(st_graph* g, void* stream)
+{
+    ST_REQ(g && g->exec, "st_graph_launch: null graph");
+    const hipError_t e = hipGraphLaunch(g->exec, st_stream(stream));
+    if (e != hipSuccess) return st_fail(ST_ERR_LAUNCH, "hipGraphLaunch: %s", hipGetErrorString(e));
+    return ST_OK;
+}
+extern "C" int st_graph_destroy(st_graph* g)
+{
+    if (!g) return ST_OK;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return ST_OK;
 }

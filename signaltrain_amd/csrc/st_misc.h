@@ -332,12 +332,25 @@ finalize_kernel(const FinArgs f, float* __restrict__ scalars)
 // Mixed precision: a non-finite norm (a gradient overflowed under the loss scale) SKIPS the update on every block -- parameters
 // and moments stay untouched -- and scalars[5] counts the skipped steps for the host's loss-scale policy (what Apex's dynamic
 // scaler does with its overflow flag, train.py:134-135).
-template <bool FIN>
+// DEV (the HIP-graph form of the step, st_graph_*): the step number and the learning rate are read from device memory
+// (scalars[6], scalars[7], written by step_tick_kernel at the head of the graph) and the bias corrections are formed here, in
+// double like the host does, so that ONE captured graph replays every iteration of a run.
+template <bool FIN, bool DEV = false>
 __global__ void __launch_bounds__(256)
 clip_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                  int64_t n4_total, int64_t n4_clip, float* __restrict__ scalars, float grad_scale,
-                 float neg_step_size, float w1, float b2, float w2, float bc2_sqrt, float eps, const FinArgs fin)
+                 float neg_step_size, float w1, float b2, float w2, float bc2_sqrt, float eps, const FinArgs fin, const float b1 = 0.f)
 {
+    if constexpr (DEV) {
+        __shared__ float hs[2];
+        if (threadIdx.x == 0) {
+            const double st = (double)scalars[6];
+            hs[0] = (float)(-(double)scalars[7] / (1.0 - pow((double)b1, st)));
+            hs[1] = (float)sqrt(1.0 - pow((double)b2, st));
+        }
+        __syncthreads();
+        neg_step_size = hs[0]; bc2_sqrt = hs[1];
+    }
     float coef, nrm;
     if constexpr (FIN) {
         __shared__ float red[4];
@@ -382,6 +395,17 @@ clip_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict
     }
 }
 
+
+// Head of the captured step (st_graph_*): advance the device-side step counter and look the learning rate up in the device copy
+// of the 1-cycle table -- iteration i (0-based) runs with lr_sched[max(i - 1, 0)] (train.py:150 writes the rate AFTER the step),
+// i.e. step t = i + 1 uses entry max(t - 2, 0).
+__global__ void step_tick_kernel(float* __restrict__ scalars, const float* __restrict__ lr_table, const int n_lr)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float t = scalars[6] + 1.0f;
+    int idx = (int)t - 2; idx = idx < 0 ? 0 : (idx >= n_lr ? n_lr - 1 : idx);
+    scalars[6] = t; scalars[7] = lr_table[idx];
+}
 
 // ------------------------------------------------------------------------------ device-side data feed
 // audio.compressor_4controls (audio.py:380-426) for a batch of windows: static gain curve (parallel), switched one-pole

@@ -57,24 +57,64 @@ class SynthAudioDataSet(Dataset):
         xs, ys, ks = zip(*(self.gen_single_chunk() for _ in range(B)))
         return (np.stack(xs).astype(np.float32), np.stack(ys).astype(np.float32), np.stack(ks).astype(np.float32))
 
-    def batch_device(self, B, device="cuda:0"):
-        """Device-resident minibatch with the effect computed ON the GPU: the input signals and
-        knob settings come from the same numpy generators as batch(); the sequential compressor -- the expensive
-        part of the CPU feed -- runs as one HIP launch for the whole batch.  Returns (x, y, knobs) torch tensors."""
+    def batch_device(self, B, device="cuda:0", generator=None, host_signals=False):
+        """Device-resident minibatch generated ON the GPU: input signals and knob settings by the batched
+        device generators of audio_device.py (counter-free device RNG, no host loop), the sequential compressor as one HIP launch
+        for the whole batch (st_compressor_4c).  host_signals=True keeps the numpy signal generators of batch() and only runs
+        the effect on the GPU (round-1 behaviour; ~10 ms per window on the host).  Returns (x, y, knobs) torch tensors."""
         import torch
-        xs = np.stack([audio.synth_input_sample(self.t, np.random.choice([0, 1, 2, 4, 6, 7])) for _ in range(B)]).astype(np.float32)
-        ks = np.stack([audio.random_ends(len(self.effect.knob_ranges)) - 0.5 for _ in range(B)]).astype(np.float32)
-        x = torch.from_numpy(xs).to(device); kn = torch.from_numpy(ks).to(device)
+        from . import audio_device
+        device = torch.device(device)
+        if host_signals:
+            xs = np.stack([audio.synth_input_sample(self.t, np.random.choice([0, 1, 2, 4, 6, 7])) for _ in range(B)]).astype(np.float32)
+            ks = np.stack([audio.random_ends(len(self.effect.knob_ranges)) - 0.5 for _ in range(B)]).astype(np.float32)
+            x = torch.from_numpy(xs).to(device); kn = torch.from_numpy(ks).to(device)
+            gen = None
+        else:
+            gen = generator
+            if gen is None:
+                gen = getattr(self, "_dev_gen", None)
+                if gen is None or gen.device != device:
+                    gen = torch.Generator(device=device); gen.manual_seed(int(np.random.randint(0, 2 ** 31 - 1)))    # follows np.random.seed(...) of the run
+                    self._dev_gen = gen
+            x, _ = audio_device.synth_input_batch(B, self.chunk_size, self.sr, gen, device)
+            kn = audio_device.random_ends(B, len(self.effect.knob_ranges), gen, device) - 0.5
         y = self.effect.go_device(x, kn, self.y_size)
         if self.augment:                                   # do_augment: random polarity flip of the pair (datasets.py:27-29)
-            sgn = torch.where(torch.rand(B, 1, device=x.device) < 0.5, -1.0, 1.0)
+            sgn = torch.where(torch.rand(B, 1, device=device, generator=gen) < 0.5, -1.0, 1.0)
             x, y = x * sgn, y * sgn
         return x, y, kn
 
 
+class DeviceSynthLoader:
+    """The reference's TRAINING feed (SynthAudioDataSet without recycling behind a shuffling DataLoader, train.py:233-248:
+    every item is generated on the fly) moved onto the GPU: each iteration yields a freshly generated (x, y, knobs) minibatch,
+    `datapoints // batch_size` batches per epoch.  Nothing is stored; generation runs at a few hundred thousand windows per
+    second, i.e. at the step rate of the fp32 train step instead of the ~100 windows/s/core of the CPU workers."""
+
+    def __init__(self, dataset, batch_size, device="cuda:0", gen_windows=2048):
+        """gen_windows: windows generated per call of the device generators (a few dozen small launches whatever the count:
+        2048 at a time costs ~4.5 ms, i.e. 0.56 ms per 256-window minibatch -- below the fp32 step; 256 at a time costs 2.9 ms)."""
+        self.ds, self.batch_size, self.device = dataset, int(batch_size), device
+        self.per_call = max(1, int(gen_windows) // self.batch_size)
+
+    def __len__(self):
+        return self.ds.datapoints // self.batch_size
+
+    def __iter__(self):
+        left = len(self)
+        while left > 0:
+            k = min(self.per_call, left)
+            x, y, kn = self.ds.batch_device(k * self.batch_size, self.device)
+            for i in range(k):
+                sl = slice(i * self.batch_size, (i + 1) * self.batch_size)
+                yield x[sl], y[sl], kn[sl]
+            left -= k
+
+
 class DeviceRecycledDataSet:
     """Device-resident counterpart of SynthAudioDataSet(recycle=True) (datasets.py:286-296): `datapoints` windows are
-    generated ONCE -- input signals and knob settings by the numpy generators, the effect on the GPU (st_compressor_4c) --
+    generated ONCE -- input signals, knob settings and the effect all on the GPU (audio_device.py, st_compressor_4c) --
     and kept in HBM (x: datapoints x chunk floats, 6.5 GB for the reference's 200 000 x 8192); minibatches are then random
     index gathers on the device, so the training loop never waits for CPU workers.  iterate with batches(batch_size)."""
 

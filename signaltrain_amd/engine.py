@@ -275,6 +275,44 @@ class StepEngine:
                    int(self.step_count), self._stream())
         return self.scalars
 
+    # ---------------------------------------------------------------- the step as one HIP graph
+    def graph_capture(self, batch, lr_table, betas=(0.9, 0.999), eps=1e-8):
+        """Capture st_train_step for `batch` windows into a HIP graph (st_graph_create).  The step counter and the learning rate
+        live on the device (scalars[6], scalars[7]; `lr_table` = the 1-cycle table, uploaded once): graph_step() then needs no
+        per-step arguments.  The minibatch is read from the fixed buffers self.gx / self.gk / self.gy."""
+        d = self._dims(int(batch))
+        dev = self.device
+        self.gx = torch.zeros(d.B, d.L, dtype=torch.float32, device=dev)
+        self.gk = torch.zeros(d.B, d.K, dtype=torch.float32, device=dev)
+        self.gy = torch.zeros(d.B, d.y, dtype=torch.float32, device=dev)
+        self.g_lr = torch.as_tensor(np.asarray(lr_table, dtype=np.float32), device=dev).contiguous()
+        self.scalars[6] = float(self.step_count)
+        self._graph_dims = d
+        handle = C.c_void_p()
+        side = torch.cuda.Stream(device=dev)             # capture needs a non-default stream
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.st_graph_create(C.byref(d), _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.m), _lib.ptr(self.v),
+                                                _lib.ptr(self.gx), _lib.ptr(self.gk), _lib.ptr(self.gy), _lib.ptr(self.ws), _lib.ptr(self.scalars),
+                                                _lib.ptr(self.g_lr), int(self.g_lr.numel()), float(betas[0]), float(betas[1]), float(eps),
+                                                C.c_void_p(side.cuda_stream), C.byref(handle)), "st_graph_create")
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = handle
+        return handle
+
+    def graph_step(self, x=None, knobs=None, y=None):
+        """One optimisation step = one hipGraphLaunch on the current stream.  x / knobs / y (optional) are copied into the
+        graph's input buffers first; with all three None the buffers are used as they are (device-resident data)."""
+        if x is not None:
+            self.gx.copy_(x); self.gk.copy_(knobs); self.gy.copy_(y)
+        self.step_count += 1; self.generation += 1
+        self._call("st_graph_launch", self.graph, self._stream())
+        return self.scalars
+
+    def graph_destroy(self):
+        if getattr(self, "graph", None) is not None:
+            self._call("st_graph_destroy", self.graph); self.graph = None
+
     def dp_train_step(self, x, knobs, y, lr, betas=(0.9, 0.999), eps=1e-8, force_exchange=False):
         """The data-parallel step driven from C (st_dp_train_step): this rank's shard, both gradient buckets all-reduced on the
         library's RCCL communicator under the backward, clip after the reduction, replicated Adam."""

@@ -120,9 +120,10 @@ def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=N
     apex_opt: "O0" = fp32 (the parity path); "O1" / "O2" / "O3" = the reference's Apex mixed precision (train.py:254-255),
     here float16 operands with fp32 accumulation, a loss scale and the L1 clip over all parameters (train.py:133-136) --
     compute_dtype "f16_all".  Extra keywords (not in the reference): compute_dtype overrides the arithmetic ("f32", "bf16",
-    "bf16_all", "f16", "f16_all"; bf16 is the MI355X-native choice and needs no loss scale); device_feed=True keeps a recycled
-    synthetic dataset in HBM (datasets.DeviceRecycledDataSet) instead of the 10-worker CPU DataLoader, which otherwise caps
-    training far below the GPU step rate; resume_optimizer=True restores Adam's moments, the step count (= position in the
+    "bf16_all", "f16", "f16_all"; bf16 is the MI355X-native choice and needs no loss scale); device_feed=True generates every
+    training minibatch on the GPU (signals: audio_device.py, effect: st_compressor_4c) and keeps the validation set in HBM
+    instead of the 10-worker CPU DataLoader, which otherwise caps training far below the GPU step rate ("recycle": one
+    device-resident training set re-sampled each epoch); resume_optimizer=True restores Adam's moments, the step count (= position in the
     1-cycle table) and the epoch counter from the checkpoint, which the reference saves but never reads back (train.py:229)."""
     if compute_dtype is None:
         compute_dtype = "f32" if str(apex_opt).upper() in ("O0", "NONE", "") else "f16_all"
@@ -154,21 +155,33 @@ def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=N
             print(f"Optimizer state restored: {start_iter} steps done, resuming at epoch {start_epoch + 1} with lr = {lr_resume:.3e}")
     lr_sched, mom_sched = learningrate.get_1cycle_schedule(lr_max=lr_max, n_data_points=n_data_points, epochs=epochs, batch_size=batch_size)
     dataset = datasets.SynthAudioDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points, y_size=out_chunk_size, augment=True)
-    dataset_val = datasets.SynthAudioDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points // 4, recycle=True,
-                                             y_size=out_chunk_size, augment=False)
     if device_feed:
+        # training: every minibatch generated on the fly ON the GPU, as the reference's non-recycled dataset does on its CPU workers
+        # (device_feed="recycle": one dataset generated up front and re-sampled by index each epoch, the reference's recycle=True mode);
+        # validation: the reference's recycled set (train.py:237-238), resident in HBM
         t0 = time.time()
-        dev_ds = datasets.DeviceRecycledDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points, y_size=out_chunk_size, augment=True, device=device)
-        print(f"device-resident dataset: {n_data_points} windows generated in {time.time() - t0:.1f} s")
+        if device_feed == "recycle":
+            dev_ds = datasets.DeviceRecycledDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points, y_size=out_chunk_size, augment=True, device=device)
 
-        class _DevLoader:                      # iterable with the DataLoader's per-epoch semantics
+            class _DevLoader:                      # iterable with the DataLoader's per-epoch semantics
+                def __iter__(self_inner):
+                    return dev_ds.batches(batch_size, shuffle=True)
+            dataloader = _DevLoader()
+        else:
+            dataloader = datasets.DeviceSynthLoader(dataset, batch_size, device)
+        val_ds = datasets.DeviceRecycledDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points // 4, y_size=out_chunk_size, augment=False, device=device)
+
+        class _ValLoader:
             def __iter__(self_inner):
-                return dev_ds.batches(batch_size, shuffle=True)
-        dataloader = _DevLoader()
+                return val_ds.batches(batch_size, shuffle=False)
+        dataloader_val = _ValLoader()
+        print(f"device-side data feed ready in {time.time() - t0:.1f} s ({n_data_points // 4} validation windows resident in HBM)")
     else:
+        dataset_val = datasets.SynthAudioDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points // 4, recycle=True,
+                                                 y_size=out_chunk_size, augment=False)
         dataloader = DataLoader(dataset, batch_size=batch_size, num_workers=num_workers, shuffle=True, worker_init_fn=datasets.worker_init,
                                 drop_last=True)
-    dataloader_val = DataLoader(dataset_val, batch_size=batch_size, num_workers=num_workers, shuffle=False, drop_last=True)
+        dataloader_val = DataLoader(dataset_val, batch_size=batch_size, num_workers=num_workers, shuffle=False, drop_last=True)
     logfilename = "vl_avg_out.dat"
     open(logfilename, "a").close()
     train_loop(model, engine, effect, device, epochs, batch_size, lr_sched, mom_sched, dataloader, dataloader_val,

@@ -527,9 +527,34 @@ def test_train_driver_bf16_all(tmp_path):
             sub = tmp_path / dt; sub.mkdir(); os.chdir(sub)
             torch.manual_seed(0); np.random.seed(0)
             train.train(effect=audio.Compressor_4c(), epochs=4, n_data_points=512, batch_size=32,
-                        device=torch.device("cuda:0"), num_workers=2, device_feed=True, lr_max=2e-4, compute_dtype=dt)
+                        device=torch.device("cuda:0"), num_workers=2, device_feed="recycle", lr_max=2e-4, compute_dtype=dt)
             traj[dt] = np.array([float(l.split()[-1]) for l in open("vl_avg_out.dat").read().strip().splitlines()])
     finally:
         os.chdir(cwd)
     assert len(traj["f32"]) >= 4 and np.all(np.isfinite(traj["bf16_all"]))
     assert np.all(np.abs(traj["bf16_all"] - traj["f32"]) <= 0.05 * np.abs(traj["f32"])), traj
+
+
+def test_graph_step_equals_eager_steps(golden_dir):
+    """st_graph_*: the whole optimisation step captured once as a HIP graph (step counter and learning rate on the device, looked
+    up in the device copy of the 1-cycle table as lr_sched[max(i-1, 0)], train.py:150) and replayed == the same steps launched
+    eagerly with the host passing step and learning rate."""
+    from signaltrain_amd.engine import StepEngine
+    from signaltrain_amd import learningrate
+    m, g, P, geo = _golden_model(golden_dir)
+    gb = np.load(os.path.join(golden_dir, "g4b_backward_clip.npz"))
+    d = m.engine(torch.zeros(3, 8192, device="cuda")).dims
+    lrs, _ = learningrate.get_1cycle_schedule(lr_max=1e-3, n_data_points=30, epochs=1, batch_size=3)
+    e1 = StepEngine(d, "cuda:0"); e1.load_state_dict(P)
+    e2 = StepEngine(d, "cuda:0"); e2.load_state_dict(P)
+    kn = torch.from_numpy(gb["knobs"]).cuda()
+    e2.graph_capture(3, lrs)
+    for it in range(5):
+        Xi = torch.from_numpy(np.roll(gb["x"], 23 * it, axis=1).copy()).cuda(); Yi = torch.from_numpy(np.roll(gb["y"], 23 * it, axis=1).copy()).cuda()
+        e1.train_step(Xi, kn, Yi, float(lrs[max(it - 1, 0)]))
+        e2.graph_step(Xi, kn, Yi)
+        torch.cuda.synchronize()
+        assert float(e2.scalars[6]) == it + 1 and abs(float(e2.scalars[7]) - np.float32(lrs[max(it - 1, 0)])) <= 1e-12
+        assert torch.equal(e1.scalars[:5], e2.scalars[:5]), it
+        assert (e1.params - e2.params).abs().max().item() <= 1e-7, it          # bias corrections: device double pow vs host double pow
+    e2.graph_destroy()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""End-to-end training-loop throughput of train.train() on one GPU: CPU DataLoader feed vs the device-resident recycled
-dataset (datasets.DeviceRecycledDataSet).  Prints windows/s of the whole loop (data feed + step + the driver's bookkeeping)."""
+"""End-to-end training-loop throughput of train.train() on one GPU: the device feed (every minibatch generated on the GPU),
+the device-resident recycled dataset (datasets.DeviceRecycledDataSet) and the reference-style CPU DataLoader feed.  Prints windows/s of the whole loop (data feed + step + the driver's bookkeeping)."""
 import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
@@ -8,11 +8,11 @@ from signaltrain_amd import train, audio, nn_proc
 nn_proc._QUIET = True
 os.chdir(tempfile.mkdtemp())
 B = 256
-for feed, npts, workers in (("device", 256 * 64, 2), ("cpu", 256 * 16, 10)):
+for feed, npts, workers in (("device", 256 * 64, 2), ("recycle", 256 * 64, 2), ("cpu", 256 * 16, 10)):
     torch.manual_seed(0); np.random.seed(0)
     t0 = time.time()
     train.train(effect=audio.Compressor_4c(), epochs=2, n_data_points=npts, batch_size=B, device=torch.device("cuda:0"),
-                num_workers=workers, device_feed=(feed == "device"))
+                num_workers=workers, device_feed={"device": True, "recycle": "recycle", "cpu": False}[feed])
     print(f"==> feed={feed}: total wall {time.time() - t0:.1f} s for {2 * npts} training windows (see the loop's own windows/s line above)")
     for f in ("modelcheckpoint.tar", "vl_avg_out.dat", "val_err_mae.dat"):
         if os.path.exists(f): os.remove(f)
