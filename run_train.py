@@ -21,11 +21,11 @@ if __name__ == "__main__":
     p.add_argument('-b', '--batch', type=int, help="batch size (per GPU)", default=200)
     p.add_argument('--checkpoint', help='name of checkpoint .tar file to start from', default='modelcheckpoint.tar')
     p.add_argument('-c', '--compand', help='accepted for compatibility', action='store_true')
-    p.add_argument('--effect', help='effect to learn', default='comp_4c', choices=['comp_4c', 'comp_4c_large'])
+    p.add_argument('--effect', help='effect to learn', default='comp_4c', choices=['comp_4c', 'comp_4c_large', 'files'])
     p.add_argument('--epochs', type=int, default=1000)
     p.add_argument('--lrmax', type=float, help="maximum learning rate", default=1e-4)
     p.add_argument('-n', '--num', type=int, help='number of data points per epoch', default=200000)
-    p.add_argument('--path', help='dataset directory (file datasets are not built yet)', default=None)
+    p.add_argument('--path', help='dataset directory with Train/, Val/ wav pairs and effect_info.ini (use with --effect files)', default=None)
     p.add_argument('--sr', type=int, default=44100)
     p.add_argument('--scale', type=float, help='scale factor (of input size & whole model)', default=1.0)
     p.add_argument('--shrink', type=int, help='shrink output chunk relative to input by this divisor', default=4)
@@ -44,9 +44,9 @@ if __name__ == "__main__":
         # bootstrap channel only (RCCL unique id, logging): the gradient exchange runs on the library's own RCCL communicator
         dist.init_process_group("gloo")
     from signaltrain_amd import audio, train
-    effect = audio.Compressor_4c() if args.effect == 'comp_4c' else audio.Compressor_4c_Large()
+    effect = audio.FileEffect(args.path, sr=args.sr) if args.effect == 'files' else (audio.Compressor_4c() if args.effect == 'comp_4c' else audio.Compressor_4c_Large())
     train.train(epochs=args.epochs, n_data_points=args.num, batch_size=args.batch, device=torch.device("cuda", local),
-                effect=effect, datapath=args.path, scale_factor=args.scale, shrink_factor=args.shrink, apex_opt=args.apex,
+                effect=effect, datapath=(args.path if args.effect == 'files' else None), sr=args.sr, scale_factor=args.scale, shrink_factor=args.shrink, apex_opt=args.apex,
                 target_type=args.target, lr_max=args.lrmax, in_checkpointname=args.checkpoint, compand=args.compand,
                 compute_dtype=args.dtype, device_feed=args.device_feed)
     if dist.is_initialized():

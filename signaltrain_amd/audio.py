@@ -204,3 +204,53 @@ class Compressor_4c_Large(Compressor_4c):
         super().__init__(**kwargs)
         self.name = 'Compressor_4c_Large'
         self.knob_ranges = np.array([[-50, 0], [1.5, 10], [1e-3, 1], [1e-3, 1]])
+
+
+# ------------------------------------------------------------------------------------------------ wav files + file-defined effects
+def read_audio_file(filename, sr=44100, mono=True, norm=False, dtype=np.float32, **_ignored):
+    """audio.py:207-255: a wav file as float in [-1, 1] (int16 / 32767), first channel if `mono`; other sample rates are refused
+    (the reference resamples them through librosa, which is not part of this feed)."""
+    from scipy.io import wavfile
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        read_sr, signal = wavfile.read(filename)
+    if mono and signal.ndim > 1:
+        signal = signal[:, 0]
+    if signal.dtype == np.int16:
+        signal = np.array(signal / 32767.0, dtype=dtype)
+    if read_sr != int(sr):
+        raise NotImplementedError(f"{filename}: sample rate {read_sr} Hz, expected {sr} Hz (resample the dataset first)")
+    signal = signal.astype(dtype, copy=False)
+    if norm:
+        m = np.max(np.abs(signal))
+        signal = signal / m if m > 0 else signal
+    return signal, sr
+
+
+def write_audio_file(filename, data, sr=44100):
+    """audio.py:258-262."""
+    from scipy.io import wavfile
+    wavfile.write(filename, sr, data)
+
+
+class FileEffect(Effect):
+    """audio.py:624-670: an effect that exists only as recordings -- <path>/Train, <path>/Val with input_* / target_* pairs and
+    <path>/effect_info.ini ([effect] name, knob_names, knob_ranges [, inverse]); e.g. the LA2A of BASELINE configs[3]."""
+
+    def __init__(self, path, sr=44100):
+        super().__init__(sr=sr)
+        import ast
+        import configparser
+        import glob
+        if path is None or not glob.glob(path + "/Train/target*") or not glob.glob(path + "/Val/target*") or not glob.glob(path + "/effect_info.ini"):
+            raise FileNotFoundError(f"FileEffect: no Train/ + Val/ target files or effect_info.ini under {path}")
+        cfg = configparser.ConfigParser(); cfg.read(path + "/effect_info.ini")
+        self.name = cfg["effect"]["name"].strip("'\"") + "(files)"
+        self.knob_names = list(ast.literal_eval(cfg.get("effect", "knob_names")))       # literal_eval instead of the reference's eval
+        self.knob_ranges = np.array(ast.literal_eval(cfg.get("effect", "knob_ranges")), dtype=np.float64)
+        if cfg["effect"].get("inverse"):
+            self.is_inverse = True; self.name = "De-" + self.name
+
+    def go_wc(self, x, knobs_w):
+        return None                      # there is no plugin to call: the targets are recordings

@@ -146,3 +146,100 @@ class DeviceRecycledDataSet:
                 sgn = torch.where(torch.rand(batch_size, 1, device=self.device) < 0.5, -1.0, 1.0)
                 x, y = x * sgn, y * sgn
             yield x, y, k
+
+
+# ------------------------------------------------------------------------------------------------ pre-recorded audio pairs
+def parse_knob_string(name, ext=".wav", dtype=np.float32):
+    """Knob settings from a target file name (datasets.py:178-186): everything after the first double underscore, e.g.
+    'target_9400_Compressor_4c__-10.95__3.428__0.005043__0.01308.wav' -> [-10.95, 3.428, 0.005043, 0.01308] (world units)."""
+    return np.array([float(v) for v in name.replace(ext, "").split("__")[1:]], dtype=dtype)
+
+
+class AudioFileDataSet(Dataset):
+    """Windows cut from pre-recorded input / target wav pairs -- the contract of signaltrain/datasets.py:64-259 (the feed of
+    BASELINE configs[3], an LA2A recorded with 2-3 knobs): files `input_<n>_.wav` / `target_<n>_<effect>__k1__k2....wav` in
+    `path`, sorted together; every item is a random `chunk_size` window of a random file pair, the target cropped to its last
+    `y_size` samples, the knob settings parsed from the target's name and normalised to [-0.5, 0.5] with the effect's ranges,
+    random polarity flip when `augment`.  Audio is preloaded (the reference's default).  `device_batches()` serves the same
+    items from a device-resident copy of the audio as whole minibatches (gather by index on the GPU, no CPU workers)."""
+
+    def __init__(self, chunk_size, effect, sr=44100, path="./Train/", datapoints=8000, dtype=np.float32, preload=True, rerun=False,
+                 y_size=None, augment=True, align_end=True, view_of=None, compand=False):
+        super().__init__()
+        import glob
+        import os
+        if not preload or compand or view_of is not None:
+            raise NotImplementedError("signaltrain_amd.AudioFileDataSet: only preload=True, compand=False, view_of=None are built")
+        self.chunk_size, self.effect, self.sr, self.path, self.dtype = chunk_size, effect, sr, path, dtype
+        self.datapoints, self.rerun_effect, self.augment, self.align_end = datapoints, rerun, augment, align_end
+        self.y_size = chunk_size if y_size is None else y_size
+        self.input_filenames = sorted(glob.glob(os.path.join(path, "input_*")))
+        self.target_filenames = sorted(glob.glob(os.path.join(path, "target_*")))
+        print("AudioFileDataSet: Found", len(self.input_filenames), "input files and", len(self.target_filenames), "target files in path", path)
+        assert len(self.input_filenames) == len(self.target_filenames) and self.input_filenames, "input_* / target_* files must pair up"
+        self.x, self.y, knobs = [], [], []
+        for fi, ft in zip(self.input_filenames, self.target_filenames):
+            a, b = audio.read_audio_file(fi, sr=sr)[0], audio.read_audio_file(ft, sr=sr)[0]
+            if len(a) != len(b) and align_end:                     # some recordings are aligned at their ends only (datasets.py:128-136)
+                n = min(len(a), len(b)); a, b = a[-n:], b[-n:]
+            if getattr(effect, "is_inverse", False):
+                a, b = b, a
+            assert len(a) > chunk_size, f"{fi}: {len(a)} samples, need more than chunk_size = {chunk_size}"
+            self.x.append(a.astype(dtype, copy=False)); self.y.append(b.astype(dtype, copy=False))
+            knobs.append(parse_knob_string(os.path.basename(ft), dtype=dtype))
+        self.knobs = np.stack(knobs)
+        self.num_knobs = self.knobs.shape[1]
+        assert self.num_knobs == len(effect.knob_ranges), "knob count in the file names must match the effect's knob_ranges"
+        self._dev = None
+
+    def __len__(self):
+        return self.datapoints
+
+    def knobs_nn(self, knobs_wc):
+        kr = np.asarray(self.effect.knob_ranges, dtype=np.float64)
+        return ((knobs_wc - kr[:, 0]) / (kr[:, 1] - kr[:, 0]) - 0.5).astype(self.dtype)
+
+    def get_single_chunk(self):
+        i = np.random.randint(0, high=len(self.x))
+        xa, ya, kw = self.x[i], self.y[i], self.knobs[i]
+        ibgn = np.random.randint(0, len(xa) - self.chunk_size)
+        x_item, y_item = xa[ibgn:ibgn + self.chunk_size], ya[ibgn:ibgn + self.chunk_size]
+        if self.rerun_effect:
+            y_item, x_item = self.effect.go_wc(x_item, kw)
+        y_item = y_item[-self.y_size:]
+        if self.augment:
+            x_item, y_item = do_augment(x_item, y_item)
+        return x_item.astype(self.dtype, copy=False), y_item.astype(self.dtype, copy=False), self.knobs_nn(kw)
+
+    def __getitem__(self, idx):
+        return self.get_single_chunk()
+
+    # ---- the same items as device minibatches
+    def _to_device(self, device):
+        import torch
+        if self._dev is None or self._dev["x"].device != torch.device(device):
+            off = np.cumsum([0] + [len(a) for a in self.x])
+            self._dev = {"x": torch.from_numpy(np.concatenate(self.x)).to(device), "y": torch.from_numpy(np.concatenate(self.y)).to(device),
+                         "off": torch.from_numpy(off[:-1]).to(device), "len": torch.tensor([len(a) for a in self.x], device=device),
+                         "kn": torch.from_numpy(np.stack([self.knobs_nn(k) for k in self.knobs])).to(device)}
+        return self._dev
+
+    def batch_device(self, B, device="cuda:0"):
+        """B items as device tensors: random file, random window start, gathered from the device-resident audio."""
+        import torch
+        if self.rerun_effect:
+            raise NotImplementedError("rerun=True (target_type='chunk') re-runs a host effect per window: use the CPU loader")
+        d = self._to_device(device)
+        fi = torch.randint(0, len(self.x), (B,), device=device)
+        start = d["off"][fi] + (torch.rand(B, device=device) * (d["len"][fi] - self.chunk_size).float()).long()
+        ar = torch.arange(self.chunk_size, device=device)
+        x = d["x"][start[:, None] + ar[None, :]]
+        y = d["y"][start[:, None] + ar[None, self.chunk_size - self.y_size:]]
+        if self.augment:
+            sgn = torch.where(torch.rand(B, 1, device=device) < 0.5, -1.0, 1.0)
+            x, y = x * sgn, y * sgn
+        return x, y, d["kn"][fi]
+
+    def device_batches(self, batch_size, device="cuda:0"):
+        for _ in range(self.datapoints // batch_size):
+            yield self.batch_device(batch_size, device)

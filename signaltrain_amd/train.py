@@ -115,8 +115,8 @@ def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=N
           datapath=None, scale_factor=1, shrink_factor=4, apex_opt="O0", target_type="stream", lr_max=1e-4,
           in_checkpointname='modelcheckpoint.tar', compand=False, num_workers=10, device_feed=False, compute_dtype=None,
           resume_optimizer=True):
-    """train.py:167-278.  target_type / compand are accepted for signature compatibility; datapath (AudioFileDataSet) is not
-    built yet -- the synthetic feed is.
+    """train.py:167-278.  datapath: directory with Train/ and Val/ wav pairs (datasets.AudioFileDataSet, the reference's
+    file feed, e.g. the LA2A set of BASELINE configs[3]; pass effect=audio.FileEffect(datapath)); compand is refused by that dataset.
     apex_opt: "O0" = fp32 (the parity path); "O1" / "O2" / "O3" = the reference's Apex mixed precision (train.py:254-255),
     here float16 operands with fp32 accumulation, a loss scale and the L1 clip over all parameters (train.py:133-136) --
     compute_dtype "f16_all".  Extra keywords (not in the reference): compute_dtype overrides the arithmetic ("f32", "bf16",
@@ -129,8 +129,6 @@ def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=N
         compute_dtype = "f32" if str(apex_opt).upper() in ("O0", "NONE", "") else "f16_all"
     effect = audio.Compressor_4c() if effect is None else effect
     device = torch.device("cuda:0") if device is None else torch.device(device)
-    if datapath is not None:
-        raise NotImplementedError("signaltrain_amd.train: file datasets (datapath=...) are not built; use the synthetic feed")
     print(f'SignalTrain (MI355X) training execution began at {time.ctime()}. Options:')
     print(f'    epochs = {epochs}, n_data_points = {n_data_points}, batch_size = {batch_size}')
     print(f'    scale_factor = {scale_factor}, shrink_factor = {shrink_factor}')
@@ -154,8 +152,22 @@ def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=N
             start_epoch, start_iter = int(rv.get('epoch', 0)), engine.step_count
             print(f"Optimizer state restored: {start_iter} steps done, resuming at epoch {start_epoch + 1} with lr = {lr_resume:.3e}")
     lr_sched, mom_sched = learningrate.get_1cycle_schedule(lr_max=lr_max, n_data_points=n_data_points, epochs=epochs, batch_size=batch_size)
-    dataset = datasets.SynthAudioDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points, y_size=out_chunk_size, augment=True)
-    if device_feed:
+    if datapath is not None:
+        # pre-recorded input / target pairs (train.py:241-246; BASELINE configs[3]): windows gathered on the device from the preloaded audio
+        dataset = datasets.AudioFileDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points, path=datapath + "/Train/", y_size=out_chunk_size,
+                                            rerun=(target_type != "stream"), augment=True, preload=True, compand=compand)
+        dataset_val = datasets.AudioFileDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points // 4, path=datapath + "/Val/", y_size=out_chunk_size,
+                                                rerun=(target_type != "stream"), augment=False, compand=compand)
+        if device_feed and target_type == "stream":
+            class _FileLoader:
+                def __init__(self_inner, ds): self_inner.ds = ds
+                def __iter__(self_inner): return self_inner.ds.device_batches(batch_size, device)
+            dataloader, dataloader_val = _FileLoader(dataset), _FileLoader(dataset_val)
+        else:
+            dataloader = DataLoader(dataset, batch_size=batch_size, num_workers=num_workers, shuffle=True, worker_init_fn=datasets.worker_init, drop_last=True)
+            dataloader_val = DataLoader(dataset_val, batch_size=batch_size, num_workers=num_workers, shuffle=False, drop_last=True)
+    elif device_feed:
+        dataset = datasets.SynthAudioDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points, y_size=out_chunk_size, augment=True)
         # training: every minibatch generated on the fly ON the GPU, as the reference's non-recycled dataset does on its CPU workers
         # (device_feed="recycle": one dataset generated up front and re-sampled by index each epoch, the reference's recycle=True mode);
         # validation: the reference's recycled set (train.py:237-238), resident in HBM
@@ -177,6 +189,7 @@ def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=N
         dataloader_val = _ValLoader()
         print(f"device-side data feed ready in {time.time() - t0:.1f} s ({n_data_points // 4} validation windows resident in HBM)")
     else:
+        dataset = datasets.SynthAudioDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points, y_size=out_chunk_size, augment=True)
         dataset_val = datasets.SynthAudioDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points // 4, recycle=True,
                                                  y_size=out_chunk_size, augment=False)
         dataloader = DataLoader(dataset, batch_size=batch_size, num_workers=num_workers, shuffle=True, worker_init_fn=datasets.worker_init,

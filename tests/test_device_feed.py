@@ -78,3 +78,47 @@ def test_random_ends_is_beta_08():
     ref = np.random.beta(0.8, 0.8, size=k.shape)
     for q in (0.05, 0.25, 0.5, 0.75, 0.95):
         assert abs(np.quantile(k, q) - np.quantile(ref, q)) < 0.015, q
+
+
+def make_file_dataset(root, n_train=3, n_val=2, seconds=0.6, sr=44100, seed=0):
+    """A tiny pre-recorded dataset in the reference's on-disk convention (gen_dataset.py / datasets.py:178-186): Train/ and Val/
+    with input_<n>_.wav + target_<n>_<effect>__k1__k2__k3.wav (int16) and effect_info.ini -- an 'LA2A_3c'-shaped effect (3
+    knobs, audio.py:645-646) whose recordings are made here with the 4-control compressor at knob-dependent settings."""
+    import os
+    rng = np.random.default_rng(seed)
+    n = int(seconds * sr)
+    for sub, cnt in (("Train", n_train), ("Val", n_val)):
+        os.makedirs(os.path.join(root, sub), exist_ok=True)
+        for i in range(cnt):
+            t = np.arange(n) / sr
+            x = (0.5 * np.sin(2 * np.pi * (110 + 50 * i) * t) * (0.3 + 0.7 * (np.sin(2 * np.pi * 3 * t) > 0)) + 0.02 * rng.standard_normal(n)).astype(np.float32)
+            kn = np.array([float(i % 2), round(float(rng.uniform(20, 80)), 2), round(float(rng.uniform(10, 90)), 2)])
+            y = audio.compressor_4controls(x, thresh=-30 + 0.2 * kn[2], ratio=2 + 2 * kn[0], attackTime=0.005, releaseTime=0.02) * (kn[1] / 50.0)
+            audio.write_audio_file(os.path.join(root, sub, f"input_{i}_.wav"), (x * 32767).astype(np.int16), sr)
+            audio.write_audio_file(os.path.join(root, sub, f"target_{i}_LA2A_3c__{kn[0]:g}__{kn[1]:g}__{kn[2]:g}.wav"), (np.clip(y, -1, 1) * 32767).astype(np.int16), sr)
+    with open(os.path.join(root, "effect_info.ini"), "w") as f:
+        f.write("[effect]\nname = 'LA2A_3c'\nknob_names = ['Limit/Comp', 'Gain', 'Gain Reduction']\nknob_ranges = [[0,1], [0,100], [0,100]]\n")
+    return root
+
+
+def test_audio_file_dataset_contract(tmp_path):
+    """datasets.AudioFileDataSet / audio.FileEffect on a 3-knob recorded dataset (the shape of BASELINE configs[3]): knob parsing
+    from target names, normalisation with the ini ranges, items that are windows of the files with the target cropped to y_size."""
+    from signaltrain_amd import datasets
+    root = make_file_dataset(str(tmp_path / "la2a"))
+    fx = audio.FileEffect(root)
+    assert fx.knob_names == ['Limit/Comp', 'Gain', 'Gain Reduction'] and fx.knob_ranges.shape == (3, 2) and fx.name.endswith("(files)")
+    np.testing.assert_allclose(datasets.parse_knob_string("target_9400_Compressor_4c__-10.95__3.428__0.005043__0.01308.wav"),
+                               [-10.95, 3.428, 0.005043, 0.01308], rtol=1e-6)         # the reference's own example (datasets.py:183)
+    ds = datasets.AudioFileDataSet(8192, fx, path=root + "/Train/", datapoints=64, y_size=2048, augment=False)
+    assert len(ds) == 64 and ds.num_knobs == 3 and len(ds.x) == 3
+    np.random.seed(1)
+    for _ in range(8):
+        x, y, k = ds[0]
+        assert x.shape == (8192,) and y.shape == (2048,) and k.shape == (3,) and x.dtype == np.float32
+        assert np.all(k >= -0.5) and np.all(k <= 0.5)
+        hit = [i for i in range(3) if np.allclose(ds.knobs_nn(ds.knobs[i]), k)]
+        assert hit
+        src_x, src_y = ds.x[hit[0]], ds.y[hit[0]]
+        pos = [p for p in range(0, len(src_x) - 8192) if src_x[p] == x[0] and np.array_equal(src_x[p:p + 8192], x)]
+        assert pos and np.array_equal(src_y[pos[0] + 8192 - 2048:pos[0] + 8192], y)      # target = the LAST y_size samples of the same window

@@ -558,3 +558,38 @@ def test_graph_step_equals_eager_steps(golden_dir):
         assert torch.equal(e1.scalars[:5], e2.scalars[:5]), it
         assert (e1.params - e2.params).abs().max().item() <= 1e-7, it          # bias corrections: device double pow vs host double pow
     e2.graph_destroy()
+
+
+def test_train_driver_file_dataset_three_knobs(tmp_path):
+    """BASELINE configs[3] shape: train.train(datapath=...) on pre-recorded wav pairs with 3 knobs (audio.FileEffect +
+    datasets.AudioFileDataSet, windows gathered on the device), K = 3 kernels, bf16 arithmetic; loss finite and decreasing-ish,
+    the checkpoint records the file effect's knob names / ranges."""
+    from tests.test_device_feed import make_file_dataset
+    from signaltrain_amd import train, audio, nn_proc, misc, datasets
+    nn_proc._QUIET = True
+    root = make_file_dataset(str(tmp_path / "la2a"), n_train=4, n_val=2, seconds=1.0)
+    fx = audio.FileEffect(root)
+    ds = datasets.AudioFileDataSet(8192, fx, path=root + "/Train/", datapoints=64, y_size=2048, augment=True)
+    x, y, k = ds.batch_device(16)
+    assert x.shape == (16, 8192) and y.shape == (16, 2048) and k.shape == (16, 3) and x.is_cuda
+    # a device item is a window of one of the files, target = last y_size samples of the same window (up to the polarity flip)
+    xs = x[0].cpu().numpy(); ys = y[0].cpu().numpy(); found = False
+    for a, b in zip(ds.x, ds.y):
+        for sgn in (1.0, -1.0):
+            idx = np.where(np.isclose(a[:len(a) - 8192], sgn * xs[0], atol=1e-7))[0]
+            for p in idx:
+                if np.allclose(a[p:p + 8192], sgn * xs, atol=1e-7) and np.allclose(b[p + 8192 - 2048:p + 8192], sgn * ys, atol=1e-7):
+                    found = True
+    assert found
+    cwd = os.getcwd(); os.chdir(tmp_path)
+    try:
+        model = train.train(effect=fx, epochs=2, n_data_points=256, batch_size=32, device=torch.device("cuda:0"), datapath=root,
+                            device_feed=True, compute_dtype="bf16_all", lr_max=2e-4)
+        assert model.num_knobs == 3
+        sd, rv = misc.load_checkpoint("modelcheckpoint.tar", device="cpu")
+        assert rv["knob_names"] == ['Limit/Comp', 'Gain', 'Gain Reduction'] and np.asarray(rv["knob_ranges"]).shape == (3, 2)
+        assert sd["mpaec.aenc.fnn_addknobs.weight"].shape == (16, 19)
+        vals = [float(l.split()[-1]) for l in open("vl_avg_out.dat").read().strip().splitlines()]
+        assert len(vals) == 2 and all(np.isfinite(vals))
+    finally:
+        os.chdir(cwd)
