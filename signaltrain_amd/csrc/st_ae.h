@@ -175,7 +175,16 @@ __device__ __forceinline__ s16x4 pack_h4(f32x4 v)
 {
     if constexpr (BF == 2) {
         union { f16x4_t h; s16x4 s; } p; p.h = __builtin_convertvector(v, f16x4_t); return p.s;
-    } else { union { bf16x4_t h; s16x4 s; } p; p.h = __builtin_convertvector(v, bf16x4_t); return p.s; }
+    } else {
+        // two 2-element conversions = two v_cvt_pk_bf16_f32: the 4-element form was legalised element by element inside these
+        // kernels (569 single conversions + 285 v_perm_b32 per loop body against 285 v_cvt_pk_f16_f32 for fp16)
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        union { bf16x2_t h; unsigned u; } lo, hi;
+        lo.h = __builtin_convertvector((f32x2_t){v[0], v[1]}, bf16x2_t);
+        hi.h = __builtin_convertvector((f32x2_t){v[2], v[3]}, bf16x2_t);
+        union { unsigned u[2]; s16x4 s; } r; r.u[0] = lo.u; r.u[1] = hi.u; return r.s;
+    }
 }
 #define pack_bf16x4(v) pack_h4<BF>(v)
 template <int BF>
@@ -331,7 +340,9 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
               const float* __restrict__ ae_m, const float* __restrict__ ae_p, const AEOffsets go,
               float* __restrict__ mag_hat, float* __restrict__ phs_hat, float* __restrict__ AA,
               float* __restrict__ reg_partial,
-              const int B, const int T, const int OT, const int F, const int K, const int KP, const float expfac)
+              const int B, const int T, const int OT, const int F, const int K, const int KP, const float expfac,
+              float* __restrict__ h4x = nullptr)      // optional: the 16-wide code h4 of both nets, [net][group][lane] float4 in D layout, for
+                                                      // the split backward (st_ae_split.h); mag_hat == NULL: h4 only (no other output is written)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -369,6 +380,12 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         { const float* const W[2] = ST_W2(CL::A1); const float* const bb[2] = ST_W2(CL::B1); layer_fwd<2, 2, 4, CL::O1, BF>(W, bb, h1, h2, g, c); }
         { const float* const W[2] = ST_W2(CL::A2); const float* const bb[2] = ST_W2(CL::B2); layer_fwd<2, 1, 2, CL::O2, BF>(W, bb, h2, h3, g, c); }
         { const float* const W[2] = ST_W2(CL::A3); const float* const bb[2] = ST_W2(CL::B3); layer_fwd<2, 1, 1, CL::O3, BF>(W, bb, h3, h4, g, c); }
+        if (h4x) {
+            float4* hv = reinterpret_cast<float4*>(h4x);
+            hv[(size_t)grp * 64 + lane] = make_float4(h4[0][0][0], h4[0][0][1], h4[0][0][2], h4[0][0][3]);
+            hv[((size_t)ngroups + grp) * 64 + lane] = make_float4(h4[1][0][0], h4[1][0][1], h4[1][0][2], h4[1][0][3]);
+        }
+        if (!mag_hat) { fwd_mask(nxt, K, fn < F, T, OT, g); cur = nxt; continue; }     // h4-only pass (wave-uniform)
         layer5_fwd<2, BF>(lw, h4, cur.kn, KQ, h5, g, c);
         { const float* const W[2] = ST_W2(CL::A5); const float* const bb[2] = ST_W2(CL::B5); layer_fwd<2, 1, 1, CL::O5, BF>(W, bb, h5, h6, g, c); }
         { const float* const W[2] = ST_W2(CL::A6); const float* const bb[2] = ST_W2(CL::B6); layer_fwd<2, 2, 1, CL::O6, BF>(W, bb, h6, h7, g, c); }

@@ -13,6 +13,7 @@
 #include "st_misc.h"
 #include "st_ae.h"
 #include "st_ae_wide.h"
+#include "st_ae_split.h"
 #include "st_dp.h"
 
 // ------------------------------------------------------------------------------ errors
@@ -164,6 +165,7 @@ extern "C" int st_set_debug(int v) { g_dbg = v; return ST_OK; }
 namespace sta { extern __device__ unsigned long long g_ae_stage_cycles[32]; }
 // Diagnostics: read (and clear) the per-stage s_memtime accumulators of ae_bwd_kernel (st_set_debug(256)).
 extern "C" int st_debug_read_stage_cycles(unsigned long long* out32);
+static int g_ae_split = 1;   // autoencoder backward of the fused geometries: 1 = two kernels at two waves per SIMD (st_ae_split.h), 0 = the single kernel
 static int g_xt = 0;       // 1: M/N-contiguous operands staged k-quad-major (st_gemm.h XT; st_set_tuning(7001), diagnostics).  MEASURED SLOWER at B=256 although
                            // conflict-free with a third fewer LDS cycles: analysis wgrad 173 vs 145 us, synthesis frames 63 vs 60 us (16 more prefetch
                            // registers -> 4 instead of 4.5 waves per SIMD, and 16 v_mov per micro-tile): the k-major staging stays the default
@@ -173,6 +175,7 @@ static int g_wg_mode_set(int v);
 static int g_wsplit_max = 16, g_wsplit_div = 200, g_an_waves = 4, g_syn_split = 3, g_frs_split = 3, g_wide_fused = 1, g_wsplit_half = 0;      // frames: 3, 4 measured equal, 6 slower (only 66 k-tiles to split)
 extern "C" int st_set_tuning(int bk)
 {
+    if (bk >= 8000) { g_ae_split = bk - 8000; return ST_OK; }     // 8000 / 8001: single-kernel / split autoencoder backward
     if (bk >= 7000) { g_xt = bk - 7000; return ST_OK; }
     if (bk >= 6000) { g_wsplit_half = bk - 6000; return ST_OK; }  // 6000 + n: split-K of the half (one-basis) analysis weight-gradient GEMMs of st_loss_backward_stage (0: as the full GEMM)
     if (bk >= 5000) { g_wide_fused = bk - 5000; return ST_OK; }   // 5000 / 5001: wide AE path all-GEMM / fused inner layers
@@ -219,7 +222,20 @@ static int ensure_dyn_lds(const void* fn, const char* name)
 #define ST_DYN_LDS(kernel_) ST_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&kernel_), #kernel_))
 static const int AE_FWD_NW = 8, AE_BWD_NW = 4;
 static int synth_live_rows(const st_dims* d);
-static int ae_fwd_grid(const st_dims* d) { int g = (d->B * (st_kp_of(d->F) / 32) + AE_FWD_NW - 1) / AE_FWD_NW; int c = num_cus(); return g < c ? g : c; }
+static bool ae_is_wide(const st_dims* d);
+// Waves per workgroup of the fused forward kernel: 8, or 11 where that removes the tail round.  A wave walks whole 16-row groups,
+// one workgroup per CU: at B = 256 there are 8448 = 256 * 33 groups -- 4.125 per wave with 8 waves (five rounds, the fifth 12 %
+// full), exactly 3 per wave with 11 (2.75 waves per SIMD, the fp32 kernel's 152 registers allow 3).  Time goes with
+// rounds x waves sharing a SIMD: 5 x 8 against 3 x 11.  The 16-bit instantiations (176 registers) stay at 8.
+static int ae_fwd_groups(const st_dims* d) { return d->B * (st_kp_of(d->F) / 32); }
+static int ae_fwd_nw(const st_dims* d)
+{
+    if (ae_is_wide(d) || ae_ht(d->prec) != 0) return AE_FWD_NW;
+    const int groups = ae_fwd_groups(d), c = num_cus();
+    auto cost = [&](int nw) { int grid = (groups + nw - 1) / nw; if (grid > c) grid = c; const int rounds = (groups + grid * nw - 1) / (grid * nw); return rounds * nw; };
+    return cost(11) < cost(AE_FWD_NW) ? 11 : AE_FWD_NW;
+}
+static int ae_fwd_grid(const st_dims* d) { const int nw = ae_fwd_nw(d); int g = (ae_fwd_groups(d) + nw - 1) / nw; int c = num_cus(); return g < c ? g : c; }
 static int ae_bwd_grid(const st_dims* d) { int groups = d->B * (st_kp_of(d->F) / 32); int g = (groups + AE_BWD_NW - 1) / AE_BWD_NW; int c = num_cus() / 2; if (c < 1) c = 1; return g < c ? g : c; }
 // split-K factors.  fp32 MFMA tiles are long serial chains (48 MFMAs x 64 cycles per k-tile per wave), so a GEMM
 // needs >= ~2 waves per SIMD (2048 waves) to overlap its load/LDS phases; the small-M synthesis GEMMs and the
@@ -227,7 +243,7 @@ static int ae_bwd_grid(const st_dims* d) { int groups = d->B * (st_kp_of(d->F) /
 static int wgrad_split(int R) { int s = R / g_wsplit_div; if (s < 1) s = 1; if (s > g_wsplit_max) s = g_wsplit_max; return s; }
 static int synth_split(int R) { return R >= 4096 ? 1 : g_syn_split; }   // consumers (ola_loss_kernel, ae_bwd_kernel) sum at most 3 slabs
 
-extern "C" int st_ae_fwd_partials(const st_dims* d) { return ae_fwd_grid(d) * AE_FWD_NW; }
+extern "C" int st_ae_fwd_partials(const st_dims* d) { return ae_fwd_grid(d) * ae_fwd_nw(d); }
 extern "C" int st_ola_loss_partials(const st_dims* d) { return d->B * ((d->y + 255) / 256); }
 extern "C" int st_norm_partials(const st_dims* d) { return 2 * d->F; }
 extern "C" size_t st_wgrad_ws_floats(const st_dims* d)
@@ -278,16 +294,28 @@ static void wide_carve(const st_dims* d, float* base, WideWS* w)
     { Layout L; if (make_layout(d, &L) == ST_OK) w->inner_ws = take((size_t)ae_bwd_grid(d) * 2 * L.PG); else w->inner_ws = nullptr; }
     w->floats = off;
 }
+// Fused geometries: the autoencoder workspace is [h4 exchange | d a4 exchange | workgroup gradient partials]; the first two are the
+// 16-wide code of both nets and its gradient, [net][group][lane] float4 each, that connect the forward kernel and the two halves
+// of the split backward (st_ae_split.h).  g_ae_split = 0 runs the single-kernel backward (st_set_tuning(8000), diagnostics).
+static const int AE_SPLIT_NW = 8;
+static size_t ae_h4_floats(const st_dims* d) { return (size_t)2 * ae_fwd_groups(d) * 256; }
+static int ae_split_grid(const st_dims* d) { int g = (ae_fwd_groups(d) + AE_SPLIT_NW - 1) / AE_SPLIT_NW; int c = num_cus() / 2; if (c < 1) c = 1; return g < c ? g : c; }
+// The split form pays where the MFMAs are long (fp32: measured 181 vs 188 us at B = 256); with 16-bit operands the matrix time is a
+// few microseconds, the kernel is all instruction issue, and two kernels only add a second prologue (bf16_all: 128 vs 124 us): those
+// precisions keep the single kernel.
+static bool ae_use_split(const st_dims* d) { return g_ae_split && !ae_is_wide(d) && ae_ht(d->prec) == 0 && !(g_dbg & 256); }
 extern "C" size_t st_ae_fwd_ws_floats(const st_dims* d)
 {
-    if (check_dims(d) != ST_OK || !ae_is_wide(d)) return 0;
+    if (check_dims(d) != ST_OK) return 0;
+    if (!ae_is_wide(d)) return ae_h4_floats(d);             // optional for the forward alone (ws may be NULL: h4 is then not kept)
     WideWS w; wide_carve(d, nullptr, &w); return w.fwd_floats;
 }
 extern "C" size_t st_ae_bwd_ws_floats(const st_dims* d)
 {
     Layout L; if (make_layout(d, &L) != ST_OK) return 0;
     if (ae_is_wide(d)) { WideWS w; wide_carve(d, nullptr, &w); return w.floats; }
-    return (size_t)ae_bwd_grid(d) * 2 * L.PG;
+    const int parts = ae_split_grid(d) > ae_bwd_grid(d) ? ae_split_grid(d) : ae_bwd_grid(d);
+    return 2 * ae_h4_floats(d) + (size_t)parts * 2 * L.PG;
 }
 static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, const float* phs, const float* knobs,
                        const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA, float* reg_partial,
@@ -335,8 +363,9 @@ extern "C" int st_ae_fwd(const st_dims* d, const float* mag, const float* phs, c
                          float* reg_partial, float* ws, void* stream)
 {
     Layout L; ST_TRY(make_layout(d, &L));
-    ST_REQ(mag && phs && knobs && ae_m && ae_p && mag_hat && phs_hat && AA, "st_ae_fwd: null pointer");
+    ST_REQ(mag && phs && knobs && ae_m && ae_p && ((mag_hat && phs_hat && AA) || (!mag_hat && !phs_hat && !AA && ws)), "st_ae_fwd: null pointer");
     if (ae_is_wide(d)) {
+        ST_REQ(mag_hat, "st_ae_fwd: the code-only pass exists for the fused geometries only");
         ST_REQ(ws, "st_ae_fwd: this geometry (T=%d, OT=%d) needs st_ae_fwd_ws_floats() floats of workspace", d->T, d->OT);
         WideWS w; wide_carve(d, ws, &w);
         return ae_wide_fwd(d, L, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, AA, reg_partial, w, stream);
@@ -348,8 +377,17 @@ extern "C" int st_ae_fwd(const st_dims* d, const float* mag, const float* phs, c
 #define ST_AE_FWD_LAUNCH(HT_) do { ST_DYN_LDS((sta::ae_fwd_kernel<AE_FWD_NW, HT_>)); \
         hipLaunchKernelGGL((sta::ae_fwd_kernel<AE_FWD_NW, HT_>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, st_stream(stream), \
                            mag, phs, knobs, ae_m, ae_p, L.go, mag_hat, phs_hat, AA, reg_partial, \
-                           d->B, d->T, d->OT, d->F, d->K, L.KP, expfac); } while (0)
-    switch (ae_ht(d->prec)) { case 1: ST_AE_FWD_LAUNCH(1); break; case 2: ST_AE_FWD_LAUNCH(2); break; default: ST_AE_FWD_LAUNCH(0); }
+                           d->B, d->T, d->OT, d->F, d->K, L.KP, expfac, ws); } while (0)
+    switch (ae_ht(d->prec)) {
+    case 1: ST_AE_FWD_LAUNCH(1); break;
+    case 2: ST_AE_FWD_LAUNCH(2); break;
+    default:
+        if (ae_fwd_nw(d) == 11) {
+            ST_DYN_LDS((sta::ae_fwd_kernel<11, 0>));
+            hipLaunchKernelGGL((sta::ae_fwd_kernel<11, 0>), dim3(ae_fwd_grid(d)), dim3(11 * 64), lds, st_stream(stream),
+                               mag, phs, knobs, ae_m, ae_p, L.go, mag_hat, phs_hat, AA, reg_partial, d->B, d->T, d->OT, d->F, d->K, L.KP, expfac, ws);
+        } else ST_AE_FWD_LAUNCH(0);
+    }
 #undef ST_AE_FWD_LAUNCH
     ST_LAUNCHED("ae_fwd"); return ST_OK;
 }
@@ -622,12 +660,39 @@ static int ae_bwd_impl(const st_dims* d, const float* mag, const float* phs, con
     ST_REQ((size_t)st_synth_slabs(d) * d->B * d->OT * L.KP < ((size_t)1 << 30) && (size_t)d->B * d->T * L.KP < ((size_t)1 << 30),
            "st_ae_bwd: batch too large for the kernel's 32-bit element offsets (B=%d)", d->B);
     const float expfac = (float)(7.0 / d->F);
-    const int grid = ae_bwd_grid(d);
     const stg::RowMap live = synth_live(d);
+    float* h4x = ws;                                      // workspace: [h4 | d a4 | workgroup partials] (st_ae_bwd_ws_floats)
+    float* da4x = ws + ae_h4_floats(d);
+    float* parts = ws + 2 * ae_h4_floats(d);
+    int grid = ae_bwd_grid(d);
+    if (ae_use_split(d)) {
+        // two kernels at two waves per SIMD (st_ae_split.h): decoder half (layers 5..9, from the code h4 the forward kernel kept),
+        // then encoder half (layers 1..4, from d a4 and the tails the first one left)
+        if (!have_fwd) {                                   // per-op entry without a preceding forward in this workspace: code-only forward pass
+            st_dims dd = *d; dd.prec = d->prec;
+            ST_TRY(st_ae_fwd(&dd, mag, phs, knobs, ae_m, ae_p, nullptr, nullptr, nullptr, nullptr, h4x, stream));
+        }
+        grid = ae_split_grid(d);
+        static_assert((size_t)sta::ae_split_lds_floats<1>(AE_SPLIT_NW) * sizeof(float) <= 160 * 1024 && (size_t)sta::ae_split_lds_floats<2>(AE_SPLIT_NW) * sizeof(float) <= 160 * 1024, "split ae_bwd LDS budget");
+#define ST_AE_PART(PART_, HT_, GM_) do { ST_DYN_LDS((sta::ae_bwd_part_kernel<AE_SPLIT_NW, PART_, HT_, GM_>)); \
+        hipLaunchKernelGGL((sta::ae_bwd_part_kernel<AE_SPLIT_NW, PART_, HT_, GM_>), dim3(grid, 2), dim3(AE_SPLIT_NW * 64), \
+                           (size_t)sta::ae_split_lds_floats<PART_>(AE_SPLIT_NW) * sizeof(float), st_stream(stream), \
+                           mag, phs, knobs, ae_m, ae_p, L.go, L.PG, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, expfac, dmag, dphs, parts, \
+                           (const float*)h4x, da4x, d->B, d->T, d->OT, d->F, d->K, L.KP, live.t_lo, live.t_lo + live.Tv - 1, st_synth_slabs(d), \
+                           (size_t)d->B * d->OT * L.KP); } while (0)
+        if (g_mag_hat) ST_AE_PART(1, 0, true); else ST_AE_PART(1, 0, false);
+        ST_LAUNCHED("ae_bwd_dec");
+        ST_AE_PART(2, 0, false);
+        ST_LAUNCHED("ae_bwd_enc");
+#undef ST_AE_PART
+        if (defer_reduce && *defer_reduce) return ST_OK;
+        hipLaunchKernelGGL(stm::ae_grad_reduce_kernel, dim3((L.PG + 63) / 64, 2), dim3(256), 0, st_stream(stream), parts, grid, L.PG, g_m, g_p);
+        ST_LAUNCHED("ae_grad_reduce"); return ST_OK;
+    }
 #define ST_AE_BWD_LAUNCH(TIMED_, HT_, VAR_) do { ST_DYN_LDS((sta::ae_bwd_kernel<AE_BWD_NW, TIMED_, false, HT_, VAR_>)); \
     hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, TIMED_, false, HT_, VAR_>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, st_stream(stream), \
                        mag, phs, knobs, ae_m, ae_p, L.go, L.PG, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, expfac, \
-                       dmag, dphs, ws, d->B, d->T, d->OT, d->F, d->K, L.KP, live.t_lo, live.t_lo + live.Tv - 1, st_synth_slabs(d), (size_t)d->B * d->OT * L.KP, g_dbg); } while (0)
+                       dmag, dphs, parts, d->B, d->T, d->OT, d->F, d->K, L.KP, live.t_lo, live.t_lo + live.Tv - 1, st_synth_slabs(d), (size_t)d->B * d->OT * L.KP, g_dbg); } while (0)
     // kernel variant: 1 = an upstream d/d mag_hat arrives (autograd entry), 2 = T - OT == 16 (tails already in registers), 0 = neither
     const int var = g_mag_hat ? 1 : (d->T - d->OT == 16 ? 2 : 0);
 #define ST_AE_BWD_VARS(HT_) do { if (var == 1) ST_AE_BWD_LAUNCH(false, HT_, 1); else if (var == 2) ST_AE_BWD_LAUNCH(false, HT_, 2); else ST_AE_BWD_LAUNCH(false, HT_, 0); } while (0)
@@ -641,7 +706,7 @@ static int ae_bwd_impl(const st_dims* d, const float* mag, const float* phs, con
     ST_LAUNCHED("ae_bwd");
     if (defer_reduce && *defer_reduce) return ST_OK;
     hipLaunchKernelGGL(stm::ae_grad_reduce_kernel, dim3((L.PG + 63) / 64, 2), dim3(256), 0, st_stream(stream),
-                       ws, grid, L.PG, g_m, g_p);
+                       parts, grid, L.PG, g_m, g_p);
     ST_LAUNCHED("ae_grad_reduce"); return ST_OK;
 }
 extern "C" int st_ae_bwd(const st_dims* d, const float* mag, const float* phs, const float* knobs,
@@ -813,7 +878,8 @@ static int forward_impl(const st_dims* d, const Layout& L, const float* params, 
         ST_LAUNCHED("prep");
     }
     ST_TRY(analysis_fwd_impl(d, w.xp, true, Wr, Wi, 1.0f, save ? w.re : nullptr, save ? w.im : nullptr, w.mag, w.phs, stream, true));
-    ST_TRY(st_ae_fwd(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.AA, w.reg_p, w.aews, stream));
+    ST_TRY(st_ae_fwd(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.AA, w.reg_p,
+                     (ae_is_wide(d) || (save && ae_use_split(d))) ? w.aews : nullptr, stream));     // fused geometries: the code h4 is kept for the split backward
     ST_TRY(st_synthesis_frames(d, w.AA, w.Sfold, w.frs, stream));
     ST_TRY(ola_loss_impl(d, w.frs, x, y_true, y_hat ? y_hat : w.y_hat, (save && y_true) ? w.dsyn : nullptr, d->N,
                          y_true ? w.loss_p : nullptr, stream));
@@ -840,7 +906,7 @@ static int backward_ae(const st_dims* d, const Layout& L, const float* params, f
                        w.aews, grads + L.offs[4], grads + L.offs[22], true, stream, &deferred));      // the forward left its AE state in w.aews
     if (!deferred) return st_polar_bwd(d, w.re, w.im, w.dmag, w.dphs, g_mag, w.dG, stream);
     stm::PostAeArgs a;
-    a.ws = w.aews; a.nparts = ae_bwd_grid(d); a.PG = L.PG; a.g_m = grads + L.offs[4]; a.g_p = grads + L.offs[22];
+    a.ws = w.aews + 2 * ae_h4_floats(d); a.nparts = ae_use_split(d) ? ae_split_grid(d) : ae_bwd_grid(d); a.PG = L.PG; a.g_m = grads + L.offs[4]; a.g_p = grads + L.offs[22];
     a.n_red_x = (L.PG + 63) / 64; a.n_red = 2 * a.n_red_x;
     a.re = w.re; a.im = w.im; a.dmag = w.dmag; a.dphs = w.dphs; a.g_mag = g_mag; a.dG = w.dG; a.F = d->F; a.KP = L.KP;
     a.gx = (L.KP / 2 + 255) / 256; a.sat = gemm_ht(d->prec) == 2 ? 65504.0f : 0.0f;
@@ -1250,6 +1316,8 @@ static int attr_prepare(const st_dims* d)
         ST_PREP3((sta::ae_bwd_kernel<AE_BWD_NW, false, true, 0, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, true, 1, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, true, 2, 0>));
     } else {
         ST_PREP3((sta::ae_fwd_kernel<AE_FWD_NW, 0>), (sta::ae_fwd_kernel<AE_FWD_NW, 1>), (sta::ae_fwd_kernel<AE_FWD_NW, 2>));
+        if (ht == 0) ST_DYN_LDS((sta::ae_fwd_kernel<11, 0>));
+        if (ht == 0) { ST_DYN_LDS((sta::ae_bwd_part_kernel<AE_SPLIT_NW, 1, 0, false>)); ST_DYN_LDS((sta::ae_bwd_part_kernel<AE_SPLIT_NW, 2, 0, false>)); }
         if (d->T - d->OT == 16) ST_PREP3((sta::ae_bwd_kernel<AE_BWD_NW, false, false, 0, 2>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 1, 2>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 2, 2>));
         else ST_PREP3((sta::ae_bwd_kernel<AE_BWD_NW, false, false, 0, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 1, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 2, 0>));
     }

@@ -13,7 +13,7 @@ if [ "$1" = "build" ]; then
 else
   mkdir -p $REPO/gpurun_out/ablate
   for v in $VARIANTS; do
-    ST_LIB_PATH=$REPO/gpurun_in/libst_ablate_$v.so python $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys; d=json.load(sys.stdin); k=d['kernels']; print('ablate %4d  ae_bwd %.1f us   step %.3f ms' % ($v, k['ae_bwd']['avg_us'], d['ms_per_step']))" | tee -a $REPO/gpurun_out/ablate/ae_ablate.txt
+    ST_LIB_PATH=$REPO/gpurun_in/libst_ablate_$v.so python $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-graph $BENCH_EXTRA 2>/dev/null | python -c "
+import json,sys; d=json.load(sys.stdin); k=d['kernels']; print('ablate %4d  %s   step %.3f ms' % ($v, '  '.join('%s %.1f us' % (n, k[n]['avg_us']) for n in k if n.startswith('ae_')), d['ms_per_step']))" | tee -a $REPO/gpurun_out/ablate/ae_ablate.txt
   done
 fi
