@@ -249,10 +249,11 @@ def test_scale8_golden_forward(golden_dir):
         assert e <= 1e-4 * np.abs(ref).max(), (name, e)
 
 
-@pytest.mark.parametrize("schedule", ["two_bucket", "staged"])
-def test_dp_collective_path_single_rank(schedule):
+@pytest.mark.parametrize("schedule,backend", [("two_bucket", "lib"), ("two_bucket", "torch"), ("staged", "torch")])
+def test_dp_collective_path_single_rank(schedule, backend):
     """The N > 1 step (backward phases / stages, each followed by the RCCL all-reduce of the range it finalised, running under
-    the next one -> st_dp_clip_adam) executed on ONE GPU with a single-rank RCCL group must reproduce the fused single-GPU step."""
+    the next one -> st_dp_clip_adam) executed on ONE GPU with a single-rank RCCL communicator must reproduce the fused single-GPU
+    step: through the library-owned communicator (st_dp_train_step, one C call) and through torch.distributed's collectives."""
     import socket
     import torch.distributed as dist
     from tests import gpu_checks as G
@@ -266,7 +267,8 @@ def test_dp_collective_path_single_rank(schedule):
     try:
         e1 = StepEngine(d, G.DEV); e1.load_state_dict(P)
         e2 = StepEngine(d, G.DEV); e2.load_state_dict(P)
-        dp = DataParallel(e2, force_collectives=True, schedule=schedule)
+        dp = DataParallel(e2, force_collectives=True, schedule=schedule, backend=backend)
+        assert dp.backend == backend
         dp.broadcast_parameters()
         x, kn, y = G.t(X), G.t(KN), G.t(Y)
         for it in range(3):
@@ -277,6 +279,7 @@ def test_dp_collective_path_single_rank(schedule):
             assert abs(l1 - l2) <= 1e-5 * abs(l1), (it, l1, l2)
             err = (e1.params - e2.params).abs().max().item()
             assert err <= 2e-5, (it, err)          # same tolerance as the fused-vs-oracle parameter check (Adam amplifies ulp noise)
+        dp.close()
     finally:
         dist.destroy_process_group()
 

@@ -7,13 +7,14 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline"
+CMD="python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-graph"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o st -- $CMD > $OUT/trace_stdout.txt 2>&1
 # counters in their own runs (no tracing domains besides kernel-trace)
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc1 -o st -- $CMD > $OUT/pmc1_stdout.txt 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc2 -o st -- $CMD > $OUT/pmc2_stdout.txt 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -o st -- $CMD > $OUT/pmc3_stdout.txt 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -o st -- $CMD > $OUT/pmc4_stdout.txt 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmc5 -o st -- $CMD > $OUT/pmc5_stdout.txt 2>&1
 find $OUT -name "*.csv" | head -30
 python $REPO/tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
