@@ -166,6 +166,7 @@ namespace sta { extern __device__ unsigned long long g_ae_stage_cycles[32]; }
 // Diagnostics: read (and clear) the per-stage s_memtime accumulators of ae_bwd_kernel (st_set_debug(256)).
 extern "C" int st_debug_read_stage_cycles(unsigned long long* out32);
 static int g_ae_split = 1;   // autoencoder backward of the fused geometries: 1 = two kernels at two waves per SIMD (st_ae_split.h), 0 = the single kernel
+static int g_frs_nt = 1;     // synthesis frames GEMM against the transposed fold (both operands K-contiguous); 0 = the k-major form (st_set_tuning(9000), diagnostics)
 static int g_xt = 0;       // 1: M/N-contiguous operands staged k-quad-major (st_gemm.h XT; st_set_tuning(7001), diagnostics).  MEASURED SLOWER at B=256 although
                            // conflict-free with a third fewer LDS cycles: analysis wgrad 173 vs 145 us, synthesis frames 63 vs 60 us (16 more prefetch
                            // registers -> 4 instead of 4.5 waves per SIMD, and 16 v_mov per micro-tile): the k-major staging stays the default
@@ -175,6 +176,7 @@ static int g_wg_mode_set(int v);
 static int g_wsplit_max = 16, g_wsplit_div = 200, g_an_waves = 4, g_syn_split = 3, g_frs_split = 3, g_wide_fused = 1, g_wsplit_half = 0;      // frames: 3, 4 measured equal, 6 slower (only 66 k-tiles to split)
 extern "C" int st_set_tuning(int bk)
 {
+    if (bk >= 9000) { g_frs_nt = bk - 9000; return ST_OK; }
     if (bk >= 8000) { g_ae_split = bk - 8000; return ST_OK; }     // 8000 / 8001: single-kernel / split autoencoder backward
     if (bk >= 7000) { g_xt = bk - 7000; return ST_OK; }
     if (bk >= 6000) { g_wsplit_half = bk - 6000; return ST_OK; }  // 6000 + n: split-K of the half (one-basis) analysis weight-gradient GEMMs of st_loss_backward_stage (0: as the full GEMM)
@@ -241,6 +243,17 @@ static int ae_bwd_grid(const st_dims* d) { int groups = d->B * (st_kp_of(d->F) /
 // needs >= ~2 waves per SIMD (2048 waves) to overlap its load/LDS phases; the small-M synthesis GEMMs and the
 // 121-tile weight-gradient GEMMs get there by splitting K and summing the slabs in the consumer kernel.
 static int wgrad_split(int R) { int s = R / g_wsplit_div; if (s < 1) s = 1; if (s > g_wsplit_max) s = g_wsplit_max; return s; }
+// ... and never more k-slices than keep all workgroups co-resident: the 3-wave weight-gradient workgroup (25 KB of LDS, 95 registers)
+// fits six to a CU, and a second, partly filled round costs more than the shorter k-chains save (measured sawtooth at B = 256,
+// 121 tiles: 10 / 12 / 16 slices -> 151 / 153 / 160 us incl. the slab reduce; 11, 13 -> 160, 169)
+static int wgrad_split_tiles(int R, int M, int Nc)
+{
+    int s = wgrad_split(R);
+    const int tiles = ((M + 95) / 96) * ((Nc + 95) / 96), slots = 6 * num_cus();
+    int fit = slots / (tiles > 0 ? tiles : 1); if (fit < 1) fit = 1;
+    if (fit >= 2) fit &= ~1;                       // even slice counts: odd ones leave a ragged last slice (k-slices are multiples of 32 rows)
+    return s < fit ? s : fit;
+}
 static int synth_split(int R) { return R >= 4096 ? 1 : g_syn_split; }   // consumers (ola_loss_kernel, ae_bwd_kernel) sum at most 3 slabs
 
 extern "C" int st_ae_fwd_partials(const st_dims* d) { return ae_fwd_grid(d) * ae_fwd_nw(d); }
@@ -248,7 +261,7 @@ extern "C" int st_ola_loss_partials(const st_dims* d) { return d->B * ((d->y + 2
 extern "C" int st_norm_partials(const st_dims* d) { return 2 * d->F; }
 extern "C" size_t st_wgrad_ws_floats(const st_dims* d)
 {
-    const int s = wgrad_split(d->B * d->T);
+    const int s = wgrad_split_tiles(d->B * d->T, st_kp_of(d->F), d->N);
     return (size_t)s * st_kp_of(d->F) * d->N;
 }
 extern "C" int st_synth_slabs(const st_dims* d) { return synth_split(synth_live_rows(d)); }
@@ -403,9 +416,15 @@ extern "C" int st_synth_fold(const st_dims* d, const float* Sr, const float* Si,
 static stg::RowMap synth_live(const st_dims* d) { return stg::live_frames(d->OT, d->H, d->N, d->N, d->y); }
 static int synth_live_rows(const st_dims* d) { return synth_live(d).rows(d->B); }
 
+// SfoldT != NULL: the transposed fold [N][KP] the fused forward builds (prep_kernel) -- both operands K-contiguous
+static int synthesis_frames_impl(const st_dims* d, const float* AA, const float* Sfold, const float* SfoldT, float* frs, void* stream);
 extern "C" int st_synthesis_frames(const st_dims* d, const float* AA, const float* Sfold, float* frs, void* stream)
 {
     ST_TRY(check_dims(d)); ST_REQ(AA && Sfold && frs, "st_synthesis_frames: null pointer");
+    return synthesis_frames_impl(d, AA, Sfold, nullptr, frs, stream);
+}
+static int synthesis_frames_impl(const st_dims* d, const float* AA, const float* Sfold, const float* SfoldT, float* frs, void* stream)
+{
     const int KP = st_kp_of(d->F);
     const stg::RowMap ms = synth_live(d);      // output frames that land wholly in the cropped margins are never needed
     const int R = ms.rows(d->B);
@@ -413,7 +432,12 @@ extern "C" int st_synthesis_frames(const st_dims* d, const float* AA, const floa
     stg::PlainTN bl{Sfold, KP, d->N, d->N, stg::all_frames(1)};
     // frs holds st_synth_frame_slabs() split-K slabs [B*OT, N]; st_ola_loss sums them
     stg::StoreC ep{frs, R, d->N, d->N, (size_t)d->B * d->OT * d->N, ms};
-    if (R >= 4096) ST_GEMM(4, al, bl, ep, R, d->N, KP, 1, st_stream(stream));
+    if (SfoldT && g_frs_nt) {
+        stg::PlainNT bt{SfoldT, d->N, KP, KP, stg::all_frames(1)};
+        if (R >= 4096) ST_GEMM(4, al, bt, ep, R, d->N, KP, 1, st_stream(stream));
+        else ST_GEMM(2, al, bt, ep, R, d->N, KP, frames_split(R), st_stream(stream));
+    }
+    else if (R >= 4096) ST_GEMM(4, al, bl, ep, R, d->N, KP, 1, st_stream(stream));
     else ST_GEMM(2, al, bl, ep, R, d->N, KP, frames_split(R), st_stream(stream));
     ST_LAUNCHED("synthesis_frames"); return ST_OK;
 }
@@ -468,7 +492,7 @@ static int synthesis_wgrad_impl(const st_dims* d, const float* AA, const float* 
     const int KP = st_kp_of(d->F);
     const stg::RowMap ms = synth_live(d);
     const int R = ms.rows(d->B);
-    const int ns = wgrad_split(R);
+    const int ns = wgrad_split_tiles(R, KP, d->N);
     stg::PlainTN al{AA, R, KP, KP, ms};
     stg::StoreC ep{ws, KP, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
     if (padded) { stg::FramedTN<true> bl{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms}; ST_GEMM_WG(al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
@@ -735,7 +759,7 @@ static int analysis_wgrad_impl(const st_dims* d, const float* dG, const float* s
     const int KP = st_kp_of(d->F);
     const stg::RowMap ma = stg::live_frames(d->T, d->H, d->N, d->N, d->L);   // all-zero frames contribute nothing
     const int R = ma.rows(d->B);
-    int ns = wgrad_split(R);
+    int ns = wgrad_split_tiles(R, KP, d->N);
     if (half >= 0) {
         // One-basis GEMM: 6 x 11 tiles of 96 x 96, one 3-wave workgroup per CU at a time, so the run time goes with
         // ceil(tiles * ns / CUs) / ns (measured sawtooth, B=256: ns = 7, 11, 15 are the minima, 8 / 12 / 16 cost +40..60 us).
@@ -829,7 +853,7 @@ extern "C" int st_debug_read_stage_cycles(unsigned long long* out32)
 // ------------------------------------------------------------------------------ workspace
 static const int NORM_E_PARTIALS = 32;     // |g| partials of the autoencoder gradient range (st_dims.clip_all)
 struct WS {
-    float *re, *im, *mag, *phs, *mag_hat, *phs_hat, *AA, *dAA, *Sfold, *frs, *y_hat, *dsyn, *dmag, *dphs, *dG, *xp;
+    float *re, *im, *mag, *phs, *mag_hat, *phs_hat, *AA, *dAA, *Sfold, *SfoldT, *frs, *y_hat, *dsyn, *dmag, *dphs, *dG, *xp;
     float *wg, *aews, *loss_p, *reg_p, *norm_a, *norm_s, *norm_e;
     size_t bytes;
 };
@@ -842,7 +866,7 @@ static void carve(const st_dims* d, void* base, WS* w)
     w->mag_hat = take(RO * F); w->phs_hat = take(RO * F);
     const size_t nsl = st_synth_slabs(d), nfs = st_synth_frame_slabs(d);
     w->AA = take(RO * KP); w->dAA = take(nsl * RO * KP);
-    w->Sfold = take(KP * N); w->frs = take(nfs * RO * N);
+    w->Sfold = take(KP * N); w->SfoldT = take(KP * N); w->frs = take(nfs * RO * N);
     w->y_hat = take((size_t)d->B * d->y); w->dsyn = take((size_t)d->B * (d->y + 2 * d->N));   // dsyn padded [B][N + y + N]
     w->xp = take((size_t)d->B * (d->L + 2 * d->N));                                               // x/2 padded  [B][N + L + N]
     w->dmag = take(RT * F); w->dphs = take(RT * F); w->dG = take(RT * KP);
@@ -871,16 +895,16 @@ static int forward_impl(const st_dims* d, const Layout& L, const float* params, 
         stm::PrepArgs a;
         a.x = x; a.xp = w.xp; a.Ls = d->L; a.pad = d->N; a.scale = 0.5f;
         a.nbx = ((d->L + 2 * d->N) / 4 + 255) / 256; a.n_pad = a.nbx * d->B;
-        a.Sr = Sr; a.Si = Si; a.Sfold = w.Sfold; a.N = d->N; a.F = d->F; a.KP = L.KP;
+        a.Sr = Sr; a.Si = Si; a.Sfold = w.Sfold; a.SfoldT = w.SfoldT; a.N = d->N; a.F = d->F; a.KP = L.KP; a.n_fold = (L.KP / 32) * (d->N / 32);
         a.re = save ? w.re : nullptr; a.im = save ? w.im : nullptr; a.mag = w.mag; a.phs = w.phs; a.T = d->T; a.t_lo = map.t_lo; a.Tv = map.Tv;
         const int n_dead = d->B * (d->T - map.Tv);
-        hipLaunchKernelGGL(stm::prep_kernel, dim3(a.n_pad + L.KP + n_dead), dim3(256), 0, st_stream(stream), a);
+        hipLaunchKernelGGL(stm::prep_kernel, dim3(a.n_pad + a.n_fold + n_dead), dim3(256), 0, st_stream(stream), a);
         ST_LAUNCHED("prep");
     }
     ST_TRY(analysis_fwd_impl(d, w.xp, true, Wr, Wi, 1.0f, save ? w.re : nullptr, save ? w.im : nullptr, w.mag, w.phs, stream, true));
     ST_TRY(st_ae_fwd(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.AA, w.reg_p,
                      (ae_is_wide(d) || (save && ae_use_split(d))) ? w.aews : nullptr, stream));     // fused geometries: the code h4 is kept for the split backward
-    ST_TRY(st_synthesis_frames(d, w.AA, w.Sfold, w.frs, stream));
+    ST_TRY(synthesis_frames_impl(d, w.AA, w.Sfold, w.SfoldT, w.frs, stream));
     ST_TRY(ola_loss_impl(d, w.frs, x, y_true, y_hat ? y_hat : w.y_hat, (save && y_true) ? w.dsyn : nullptr, d->N,
                          y_true ? w.loss_p : nullptr, stream));
     const size_t nm = (size_t)d->B * d->T * d->F * sizeof(float), nh = (size_t)d->B * d->OT * d->F * sizeof(float);

@@ -128,21 +128,52 @@ pad_scale_kernel(const float* __restrict__ in, float* __restrict__ out, int Ls, 
 }
 
 // Everything the fused forward needs before its first GEMM, in ONE launch (three independent HBM-bound jobs that were three
-// launches of 6-8 us each, mostly launch ramp): [0, n_pad) the padded, pre-scaled signal copy; [n_pad, n_pad + KP) the Hermitian
+// launches of 6-8 us each, mostly launch ramp): [0, n_pad) the padded, pre-scaled signal copy; [n_pad, n_pad + n_fold) the Hermitian
 // fold of the synthesis bases (they change only in the optimizer, but the workspace is the caller's and may be re-carved between
-// steps, so the fold is rebuilt per step -- 8 MB of traffic); the rest zeroes the frames that lie wholly in the Conv1d padding.
+// steps, so the fold is rebuilt per step -- 12 MB of traffic, as 32 x 32 tiles written in both orientations); the rest zeroes the frames that lie wholly in the Conv1d padding.
 struct PrepArgs {
     const float* x; float* xp; int Ls, pad; float scale; int nbx, n_pad;
-    const float* Sr; const float* Si; float* Sfold; int N, F, KP;
+    const float* Sr; const float* Si; float* Sfold; float* SfoldT; int N, F, KP, n_fold;
     float *re, *im, *mag, *phs; int T, t_lo, Tv;
 };
+// 32 x 32 tile of the folded synthesis bases, written twice: Sfold [KP][N] (rows k: the K-contiguous operand of the synthesis data-gradient
+// GEMM) and its transpose SfoldT [N][KP] (rows n: the K-contiguous operand of the synthesis FRAMES GEMM, which otherwise has to take
+// Sfold as an M/N-contiguous operand with scalar LDS fragment reads -- 52 % of the fp32 MFMA peak against 69 % for the NT x NT form).
+__device__ __forceinline__ void fold_tile(const float* __restrict__ Sr, const float* __restrict__ Si, float* __restrict__ Sfold,
+                                          float* __restrict__ SfoldT, const int N, const int F, const int KP, const int tile)
+{
+    __shared__ float tl[32][33];
+    const int ntn = N / 32, tk = tile / ntn, tn = tile - tk * ntn;
+    const int half = KP / 2;
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;          // 32 columns x 8 row-lanes
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = tk * 32 + ry + 8 * j, n = tn * 32 + cx;
+        const bool is_im = row >= half;
+        const int k = is_im ? row - half : row;
+        const float* S = is_im ? Si : Sr;
+        float v = 0.f;
+        if (k < F) {
+            v = S[(size_t)k * N + n];
+            if (k >= 1 && k <= F - 2) { const float u = S[(size_t)(N - k) * N + n]; v += is_im ? -u : u; }
+        }
+        Sfold[(size_t)row * N + n] = v;
+        tl[ry + 8 * j][cx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = tn * 32 + ry + 8 * j, row = tk * 32 + cx;
+        SfoldT[(size_t)n * KP + row] = tl[cx][ry + 8 * j];
+    }
+}
 __global__ void __launch_bounds__(256)
 prep_kernel(const PrepArgs a)
 {
     const int blk = blockIdx.x;
     if (blk < a.n_pad) { const int b = blk / a.nbx; pad_scale_block(a.x, a.xp, a.Ls, a.pad, a.scale, blk - b * a.nbx, a.nbx, b); }
-    else if (blk < a.n_pad + a.KP) fold_row(a.Sr, a.Si, a.Sfold, a.N, a.F, a.KP, blk - a.n_pad);
-    else zero_dead_frame(a.re, a.im, a.mag, a.phs, a.T, a.F, a.t_lo, a.Tv, blk - a.n_pad - a.KP);
+    else if (blk < a.n_pad + a.n_fold) fold_tile(a.Sr, a.Si, a.Sfold, a.SfoldT, a.N, a.F, a.KP, blk - a.n_pad);
+    else zero_dead_frame(a.re, a.im, a.mag, a.phs, a.T, a.F, a.t_lo, a.Tv, blk - a.n_pad - a.n_fold);
 }
 
 // dsyn = 2 * g_y_hat  (y_hat = 2*(syn + x/2), nn_proc.py:332,340) -- generic autograd entry
