@@ -112,9 +112,12 @@ int st_ae_fwd(const st_dims* d, const float* mag, const float* phs, const float*
               const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA,
               float* reg_partial, float* ws, void* stream);
 int st_ae_fwd_partials(const st_dims* d);
-/* Floats of workspace st_ae_fwd needs in `ws`: 0 (ws may be NULL) for the fused kernels (T <= 32 and OT <= 16); wide
- * geometries (e.g. the 65536-sample window: T = 174, OT = 46) run the layers as feature-major GEMMs and keep their
- * activations there.  st_ae_bwd_ws_floats() covers the backward of either path. */
+/* Floats of workspace st_ae_fwd uses in `ws`.  Fused kernels (T <= 32 and OT <= 16): OPTIONAL - when ws is given the
+ * forward keeps each net's 16-wide code h4 there ([net][group][lane] float4) so that a following st_ae_bwd on the SAME
+ * workspace starts its decoder half from it; ws may be NULL (h4 is then not kept and the backward recomputes it).  Wide
+ * geometries (e.g. the 65536-sample window: T = 174, OT = 46) run the layers as feature-major GEMMs, keep their
+ * activations there and REQUIRE it.  st_ae_bwd_ws_floats() covers the backward of either path (and contains the forward's
+ * part at offset 0). */
 size_t st_ae_fwd_ws_floats(const st_dims* d);
 
 /* Hermitian fold of the synthesis bases (cls_fe_dft.py:109-110 expressed on the weights):
