@@ -42,7 +42,10 @@ DTYPE_TEXT = {"f32": "fp32", "bf16": "bf16 GEMM operands / fp32 accumulate", "bf
                                                                                          "loss scale 4096, clip over all parameters"}
 
 
-def workload_text(d, B, dtype, scale):
+def workload_text(d, B, dtype, scale, scheme="lean"):
+    if scheme != "lean":
+        return (f"comp_4c synthetic, {d.L}-sample windows, legacy 'large-FFT' scheme (nn_proc.py:374-376: ft={d.N}, hop={d.H}, "
+                f"{4 * d.N * d.N / 1e6:.0f} M basis parameters), batch {B}/GPU, {DTYPE_TEXT[dtype]} (SURVEY 8(f)-4, informational)")
     cfg = {(1, "f32"): "BASELINE configs[1]", (1, "bf16"): "arithmetic of BASELINE configs[2]", (1, "bf16_all"): "arithmetic of BASELINE configs[2]",
            (8, "f16"): "BASELINE configs[4] per GPU", (8, "f16_all"): "BASELINE configs[4] per GPU"}.get((scale, dtype))
     if cfg is None:
@@ -81,12 +84,16 @@ def main():
     ap.add_argument("--bk", type=int, default=0, help="GEMM k-tile depth override (16/32)")
     ap.add_argument("--no-graph", action="store_true", help="N = 1: skip the HIP-graph replay measurement (ms_per_step_graph)")
     ap.add_argument("--tune", type=int, nargs="*", default=[], help="diagnostics: st_set_tuning codes applied before the run")
+    ap.add_argument("--ablate", type=int, default=0, help="diagnostics: st_set_debug bits for a library built with -DST_GEMM_ABLATE / -DST_AE_ABLATE "
+                                                          "(timing-only; the numbers of such a run are INVALID as results)")
     ap.add_argument("--dp-schedule", choices=["two_bucket", "staged"], default="two_bucket", help="all-reduce schedule of the data-parallel step (signaltrain_amd/dp.py)")
     ap.add_argument("--force-dp", action="store_true", help="run the N > 1 code path (bucketed RCCL all-reduce, st_dp_clip_adam) "
                                                             "even with one rank, to measure its overhead on one GPU")
     ap.add_argument("--dtype", choices=("f32", "bf16", "bf16_all", "f16", "f16_all"), default="f32",
                     help="f32 = the headline / parity configuration; bf16 / f16 = 16-bit operands with fp32 accumulation in the STFT GEMMs; *_all = also in the autoencoder layers "
                          "(bf16*: arithmetic of BASELINE configs[2], [3]; f16* with --scale 8 --batch 64: configs[4]; informational, never the headline number)")
+    ap.add_argument("--scheme", choices=["lean", "legacy"], default="lean", help="window scaling scheme (nn_proc.py:371-376): lean keeps ft=1024/hop=384, "
+                                                                                "legacy scales them with the window (scale 8: ft=8192, hop=3072, 268 M parameters)")
     ap.add_argument("--scale", type=int, default=1, help="window scale factor (8 = the 65536-sample window of BASELINE configs[4]; "
                                                           "informational -- the headline workload is scale 1)")
     ap.add_argument("--dp-backend", choices=("lib", "torch"), default="lib",
@@ -123,10 +130,12 @@ def main():
         _lib.check(_lib.load().st_set_tuning(args.bk), 'st_set_tuning')
     for code in args.tune:
         _lib.check(_lib.load().st_set_tuning(int(code)), 'st_set_tuning')
-    d = _lib.geometry(args.scale, 4, 4, B)
+    if args.ablate:
+        _lib.check(_lib.load().st_set_debug(int(args.ablate)), 'st_set_debug')
+    d = _lib.geometry(args.scale, 4, 4, B, scale_scheme=args.scheme)
     # identical init on every rank (run_train.py:20-21 seeds 218), distinct data per rank
     torch.manual_seed(218); np.random.seed(218)
-    model = nn_proc.st_model(scale_factor=args.scale, shrink_factor=4, num_knobs=4)
+    model = nn_proc.st_model(scale_factor=args.scale, shrink_factor=4, num_knobs=4, scale_scheme=args.scheme)
     eng = StepEngine(d, dev, compute_dtype=args.dtype)
     eng.load_state_dict(model.state_dict())
     dp_note = None
@@ -202,7 +211,7 @@ def main():
         out = {"metric": METRIC, "value": windows_s * d.T, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": workload_text(d, B, args.dtype, args.scale),
+               "config": {"workload": workload_text(d, B, args.dtype, args.scale, args.scheme),
                           "window": d.L, "frames_per_window": d.T, "global_batch": B * world, "parallelism": f"dp{world}",
                           **({"dp_backend": dp_backend, "dp_schedule": args.dp_schedule} if (world > 1 or args.force_dp) else {}),
                           **({"dp_note": dp_note} if dp_note else {})},

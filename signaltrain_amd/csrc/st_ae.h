@@ -245,9 +245,7 @@ __device__ __forceinline__ void layer_fwd(const float* const (&W)[NC], const flo
             }
         }
 #pragma unroll
-        for (int ch = 0; ch < NC; ++ch)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hout[ch][ot][r] = elu_f(acc[ch][r]);
+        for (int ch = 0; ch < NC; ++ch) hout[ch][ot] = elu4(acc[ch]);
     }
 }
 
@@ -281,9 +279,7 @@ __device__ __forceinline__ void layer5_fwd(const float* const (&lw)[NC], const f
             }
         }
 #pragma unroll
-    for (int ch = 0; ch < NC; ++ch)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h5[ch][0][r] = elu_f(acc[ch][r]);
+    for (int ch = 0; ch < NC; ++ch) h5[ch][0] = elu4(acc[ch]);
 }
 
 #define ST_W2(off_) {lw[0] + (off_), lw[1] + (off_)}
@@ -544,14 +540,12 @@ __device__ __forceinline__ void fwdD_fr(const f32x4 (&fr)[OTL * ITL], const floa
             }
 #endif
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
 #if ST_AE_ABLATE & 8
-            hout[ot][r] = fmaxf(acc[r], 0.1f * acc[r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hout[ot][r] = fmaxf(acc[r], 0.1f * acc[r]);
 #else
-            hout[ot][r] = elu_f(acc[r]);
+        hout[ot] = elu4(acc);
 #endif
-        }
     }
 }
 // D layout -> T layout of TL 16x16 tiles through a wave-private LDS scratch ([tile][row 16][feature 16, pitch 20]): one

@@ -46,6 +46,21 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // instructions and sits on the critical path of the issue-bound autoencoder kernels.
 __device__ __forceinline__ void st_sincos(float x, float& sn, float& cs) { sn = __sinf(x); cs = __cosf(x); }
 
-__device__ __forceinline__ float elu_f(float a) { return a > 0.f ? a : (__expf(a) - 1.0f); }
+// ELU(a) = a > 0 ? a : exp(a) - 1 (nn_proc.py:31, alpha = 1).  With u = exp(a) - 1:  u >= a for every a, and u <= 0 exactly when
+// a <= 0, so the value is the MEDIAN of {a, u, 0} -- one v_med3_f32 instead of a compare and a select (5 -> 4 instructions per
+// activation; 3 with the packed multiply / add of elu4).  Differs from the select form only where the fp32 rounding of exp()
+// puts u slightly below a small positive a (a < ~1e-3): by at most the rounding error of exp(a) - 1 itself, <= 1.2e-7 absolute.
+__device__ __forceinline__ float elu_f(float a) { return __builtin_amdgcn_fmed3f(a, __expf(a) - 1.0f, 0.f); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 elu4(const f32x4 a)
+{
+    // explicit register PAIRS: v_pk_mul_f32 / v_pk_add_f32 (the 4-wide form is scalarised); __expf(a) is exactly v_exp_f32(a * log2(e))
+    const f32x2 c = {1.44269504088896341f, 1.44269504088896341f}, one = {1.0f, 1.0f};
+    const f32x2 t0 = (f32x2){a[0], a[1]} * c, t1 = (f32x2){a[2], a[3]} * c;
+    const f32x2 e0 = {__builtin_amdgcn_exp2f(t0[0]), __builtin_amdgcn_exp2f(t0[1])}, e1 = {__builtin_amdgcn_exp2f(t1[0]), __builtin_amdgcn_exp2f(t1[1])};
+    const f32x2 u0 = e0 - one, u1 = e1 - one;
+    return (f32x4){__builtin_amdgcn_fmed3f(a[0], u0[0], 0.f), __builtin_amdgcn_fmed3f(a[1], u0[1], 0.f),
+                   __builtin_amdgcn_fmed3f(a[2], u1[0], 0.f), __builtin_amdgcn_fmed3f(a[3], u1[1], 0.f)};
+}
 // ELU'(a) through h = ELU(a):  1 if h > 0 else h + 1 (= exp(a)).
 __device__ __forceinline__ float elu_grad_from_out(float h) { return h > 0.f ? 1.0f : h + 1.0f; }

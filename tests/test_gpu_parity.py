@@ -37,6 +37,15 @@ def test_legacy_large_fft_scheme():
     _assert_ok(G.run_fused(B=3, seed=5, K=3, steps=2, scale=2, scheme="legacy"))
 
 
+def test_legacy_large_fft_scheme_scale8():
+    """SURVEY 8(f)-4 at the size it names: scale 8 of the legacy scheme = ft 8192, hop 3072, F 4097, T 25, OT 9 -- four
+    8192 x 8192 bases (268 M parameters, 1.07 GB; the gradient / moment / slab buffers follow).  Same kernels, every per-op
+    check and two fused steps against the oracle."""
+    from tests import gpu_checks as G
+    _assert_ok(G.run_all(B=1, seed=3, K=4, scale=8, scheme="legacy"))
+    _assert_ok(G.run_fused(B=2, seed=5, K=3, steps=2, scale=8, scheme="legacy"))
+
+
 @pytest.mark.parametrize("shrink,seed", [(2, 5), (1, 6), (8, 5)])
 def test_other_shrink_factors(shrink, seed):
     """st_model(shrink_factor=...) (nn_proc.py:358-380): shrink 2 -> OT = 14 (fused autoencoder kernels), shrink 1 -> OT = 25
