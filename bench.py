@@ -32,12 +32,16 @@ def kernel_peak(name, dtype):
     autoencoder kernels only in the *_all modes."""
     if dtype == "f32":
         return PEAK_FP32_MFMA_TF
+    if dtype == "f32x3":                   # six bf16 MFMAs per fp32-grade product block: the bf16 dense peak / 6
+        return PEAK_HALF_MFMA_TF / 6.0 if name in GEMM_KERNELS else PEAK_FP32_MFMA_TF
     if name in GEMM_KERNELS or dtype.endswith("_all"):
         return PEAK_HALF_MFMA_TF
     return PEAK_FP32_MFMA_TF
 
 
-DTYPE_TEXT = {"f32": "fp32", "bf16": "bf16 GEMM operands / fp32 accumulate", "bf16_all": "bf16 operands in the STFT GEMMs and the autoencoder layers / fp32 accumulate",
+DTYPE_TEXT = {"f32x3": "fp32 (STFT GEMM products from a three-way bfloat16 split of the fp32 operands: six partial products on the bf16 matrix pipe, "
+                       "fp32 accumulate; fp32-grade accuracy)",
+              "f32": "fp32", "bf16": "bf16 GEMM operands / fp32 accumulate", "bf16_all": "bf16 operands in the STFT GEMMs and the autoencoder layers / fp32 accumulate",
               "f16": "fp16 GEMM operands / fp32 accumulate, loss scale 4096", "f16_all": "fp16 mixed precision: fp16 operands in the STFT GEMMs and the autoencoder layers / fp32 accumulate, "
                                                                                          "loss scale 4096, clip over all parameters"}
 
@@ -89,7 +93,7 @@ def main():
     ap.add_argument("--dp-schedule", choices=["two_bucket", "staged"], default="two_bucket", help="all-reduce schedule of the data-parallel step (signaltrain_amd/dp.py)")
     ap.add_argument("--force-dp", action="store_true", help="run the N > 1 code path (bucketed RCCL all-reduce, st_dp_clip_adam) "
                                                             "even with one rank, to measure its overhead on one GPU")
-    ap.add_argument("--dtype", choices=("f32", "bf16", "bf16_all", "f16", "f16_all"), default="f32",
+    ap.add_argument("--dtype", choices=("f32", "f32x3", "bf16", "bf16_all", "f16", "f16_all"), default="f32",
                     help="f32 = the headline / parity configuration; bf16 / f16 = 16-bit operands with fp32 accumulation in the STFT GEMMs; *_all = also in the autoencoder layers "
                          "(bf16*: arithmetic of BASELINE configs[2], [3]; f16* with --scale 8 --batch 64: configs[4]; informational, never the headline number)")
     ap.add_argument("--scheme", choices=["lean", "legacy"], default="lean", help="window scaling scheme (nn_proc.py:371-376): lean keeps ft=1024/hop=384, "

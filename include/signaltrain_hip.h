@@ -39,13 +39,21 @@ extern "C" {
  *                     gradient norm turns non-finite and st_train_step / st_dp_clip_adam SKIP the update and count it in
  *                     scalars[5] (Apex's overflow handling; the host lowers the scale).  The polar backward (fp32, 1e7-sized
  *                     sub-gradients on silent frames) saturates its output to the fp16 range; loss and Adam fp32.
- * Each level equals the reference computed with those operands rounded the same way (the oracle has the same switches),
+ *   ST_PREC_F32X3     fp32 results from the bf16 MATRIX pipe: every operand of the analysis / synthesis GEMMs (forward, data and
+ *                     weight gradients) is split as it is staged into three bfloat16 planes x = x1 + x2 + x3 (24 significand bits,
+ *                     both remainders exact) and each product is the sum of the six partial products of order >= 2^-16, accumulated
+ *                     in fp32.  Accuracy is that of an fp32 GEMM (measured against float64: not worse than ST_PREC_F32); it is a
+ *                     different ROUNDING of the same arithmetic, so it is held to the fp32 reference with the fp32 tolerance.  On
+ *                     gfx950 the fp32 MFMA runs at the vector-ALU rate and does not overlap vector work; six bf16 MFMAs cost 3/8 of
+ *                     its cycles and run beside the VALU.  Autoencoders, polar maps, loss and Adam are as in ST_PREC_F32.
+ * Each 16-bit level equals the reference computed with those operands rounded the same way (the oracle has the same switches),
  * not the fp32 reference. */
 #define ST_PREC_F32 0
 #define ST_PREC_BF16 1
 #define ST_PREC_BF16_ALL 2
 #define ST_PREC_F16 3
 #define ST_PREC_F16_ALL 4
+#define ST_PREC_F32X3 5
 
 /* Geometry (nn_proc.py:357-385) and arithmetic of one call. */
 typedef struct st_dims {

@@ -99,7 +99,7 @@ SIGNATURES = {
 }
 
 # st_dims.prec levels (include/signaltrain_hip.h ST_PREC_*) by the names the Python surface uses
-PREC = {"f32": 0, "bf16": 1, "bf16_all": 2, "f16": 3, "f16_all": 4}
+PREC = {"f32": 0, "bf16": 1, "bf16_all": 2, "f16": 3, "f16_all": 4, "f32x3": 5}
 
 _lib = None
 

@@ -10,6 +10,7 @@
 #include <utility>
 #include "st_common.h"
 #include "st_gemm.h"
+#include "st_gemm_planes.h"
 #include "st_misc.h"
 #include "st_ae.h"
 #include "st_ae_wide.h"
@@ -108,7 +109,7 @@ static int check_dims(const st_dims* d)
     ST_REQ(d->y == (d->OT - 1) * d->H - d->N && d->y > 0 && d->y <= d->L, "y must equal (OT-1)*H-N");
     ST_REQ(d->OT <= d->T, "OT must be <= T");
     ST_REQ(d->K <= 16, "at most 16 knobs");
-    ST_REQ(d->prec >= ST_PREC_F32 && d->prec <= ST_PREC_F16_ALL, "st_dims.prec = %d is not an ST_PREC_* level", d->prec);
+    ST_REQ(d->prec >= ST_PREC_F32 && d->prec <= ST_PREC_F32X3, "st_dims.prec = %d is not an ST_PREC_* level", d->prec);
     ST_REQ(d->loss_scale >= 0.f && d->loss_scale <= 3.0e38f, "st_dims.loss_scale must be 0 (none) or a positive finite scale");
     // the kernels address every operand with 32-bit element offsets from a wave-uniform base and index rows with 24-bit
     // multiplies: rows (B*T) < 2^24, the largest per-batch operands (B*T x KP spectra, B x (L + 2N) padded signals) < 2^30 elements
@@ -166,6 +167,9 @@ namespace sta { extern __device__ unsigned long long g_ae_stage_cycles[32]; }
 // Diagnostics: read (and clear) the per-stage s_memtime accumulators of ae_bwd_kernel (st_set_debug(256)).
 extern "C" int st_debug_read_stage_cycles(unsigned long long* out32);
 static int g_ae_split = 1;   // autoencoder backward of the fused geometries: 1 = two kernels at two waves per SIMD (st_ae_split.h), 0 = the single kernel
+static int g_wg_split = 0;   // ST_PREC_F32X3: weight-gradient GEMMs on the in-kernel three-plane split instead of the fp32 MFMA kernel (see ST_GEMM_WG)   (st_set_tuning(9300 + n))
+static int g_pl_dgrad = 0;   // ST_PREC_F32X3: synthesis data gradient on the plane kernel (measured slower than the fp32 MFMA kernel at B = 256: 57 vs 45 us)   (st_set_tuning(9200 + n))
+static int g_pl_shape = 0;   // plane GEMM tile (ST_PREC_F32X3): 0 = 4 waves x (32 x 96), 1 = 2 waves x (64 x 96), 2 = 4 waves x (64 x 96)   (st_set_tuning(9100 + n))
 static int g_frs_nt = 1;     // synthesis frames GEMM against the transposed fold (both operands K-contiguous); 0 = the k-major form (st_set_tuning(9000), diagnostics)
 static int g_xt = 0;       // 1: M/N-contiguous operands staged k-quad-major (st_gemm.h XT; st_set_tuning(7001), diagnostics).  MEASURED SLOWER at B=256 although
                            // conflict-free with a third fewer LDS cycles: analysis wgrad 173 vs 145 us, synthesis frames 63 vs 60 us (16 more prefetch
@@ -176,6 +180,9 @@ static int g_wg_mode_set(int v);
 static int g_wsplit_max = 16, g_wsplit_div = 200, g_an_waves = 4, g_syn_split = 3, g_frs_split = 3, g_wide_fused = 1, g_wsplit_half = 0;      // frames: 3, 4 measured equal, 6 slower (only 66 k-tiles to split)
 extern "C" int st_set_tuning(int bk)
 {
+    if (bk >= 9300) { g_wg_split = bk - 9300; return ST_OK; }
+    if (bk >= 9200) { g_pl_dgrad = bk - 9200; return ST_OK; }
+    if (bk >= 9100) { g_pl_shape = bk - 9100; return ST_OK; }
     if (bk >= 9000) { g_frs_nt = bk - 9000; return ST_OK; }
     if (bk >= 8000) { g_ae_split = bk - 8000; return ST_OK; }     // 8000 / 8001: single-kernel / split autoencoder backward
     if (bk >= 7000) { g_xt = bk - 7000; return ST_OK; }
@@ -191,12 +198,14 @@ extern "C" int st_set_tuning(int bk)
 }
 // Arithmetic of a call = st_dims::prec (ST_PREC_*; round 1 had a process-wide switch here, which raced between engines):
 // half type (0 none / 1 bfloat16 / 2 float16) of the STFT GEMM operands and of the autoencoder layers.
-static inline int gemm_ht(int prec) { return (prec == ST_PREC_BF16 || prec == ST_PREC_BF16_ALL) ? 1 : ((prec == ST_PREC_F16 || prec == ST_PREC_F16_ALL) ? 2 : 0); }
+// gemm_ht: 3 = fp32 operands as three bfloat16 planes (ST_PREC_F32X3; st_gemm.h gemm_half_kernel PL = 3)
+static inline int gemm_ht(int prec) { return (prec == ST_PREC_BF16 || prec == ST_PREC_BF16_ALL) ? 1 : ((prec == ST_PREC_F16 || prec == ST_PREC_F16_ALL) ? 2 : (prec == ST_PREC_F32X3 ? 3 : 0)); }
 static inline int ae_ht(int prec) { return prec == ST_PREC_BF16_ALL ? 1 : (prec == ST_PREC_F16_ALL ? 2 : 0); }
 static inline float loss_scale_of(const st_dims* d) { return d->loss_scale > 0.f ? d->loss_scale : 1.0f; }
 // every ST_GEMM* user has `d` (const st_dims*) in scope
 #define ST_GEMM_BK(BK_, W_, ...) do { const int ht_ = gemm_ht(d->prec); \
                               if (ht_ == 1) stg::launch_half<W_, 1>(__VA_ARGS__); else if (ht_ == 2) stg::launch_half<W_, 2>(__VA_ARGS__); \
+                              else if (ht_ == 3) { ST_TRY((stg::launch_half<W_, 1, 3>(__VA_ARGS__))); } \
                               else if (g_xt) { if ((BK_) == 16) stg::launch<W_, 16, 1, true>(__VA_ARGS__, g_dbg); else stg::launch<W_, 32, 1, true>(__VA_ARGS__, g_dbg); } \
                               else if ((BK_) == 16) stg::launch<W_, 16>(__VA_ARGS__, g_dbg); else stg::launch<W_, 32>(__VA_ARGS__, g_dbg); } while (0)
 #define ST_GEMM(W_, ...) ST_GEMM_BK(g_bk, W_, __VA_ARGS__)
@@ -206,8 +215,12 @@ static inline float loss_scale_of(const st_dims* d) { return d->loss_scale > 0.f
 // weight-gradient GEMMs: g_wg_mode 0 = three waves share a 96x96 tile (32x96 strips), 1 = one wave per 96x96 tile
 static int g_wg_mode = 0;
 static int g_wg_mode_set(int v) { g_wg_mode = v; return ST_OK; }
+// ST_PREC_F32X3: the weight-gradient GEMMs reduce along the ROWS of both operands (k-major staging, 4x4 register transposes); their
+// in-kernel three-plane split measured slower than the fp32 MFMA kernel (176 vs 141 us, 62 vs 55 us at B = 256), so that precision
+// level keeps them on the fp32 kernel (st_set_tuning(9301) selects the split form).
 #define ST_GEMM_WG(...) do { if (g_wg_mode == 1 && gemm_ht(d->prec) == 0) stg::launch<1, 16, 3>(__VA_ARGS__, g_dbg); \
-                             else if (g_wg_mode == 2 && gemm_ht(d->prec) == 0) stg::launch<3, 16, 1, true>(__VA_ARGS__, g_dbg); else ST_GEMM(3, __VA_ARGS__); } while (0)
+                             else if (g_wg_mode == 2 && gemm_ht(d->prec) == 0) stg::launch<3, 16, 1, true>(__VA_ARGS__, g_dbg); \
+                             else if (gemm_ht(d->prec) == 3 && !g_wg_split) stg::launch<3, 16>(__VA_ARGS__, g_dbg); else ST_GEMM(3, __VA_ARGS__); } while (0)
 // Kernels with > 64 KB of dynamic LDS need the attribute once per (device, kernel); the result is checked (round 1 discarded
 // it behind non-atomic flags: a failure surfaced later as an opaque launch error).
 static int ensure_dyn_lds(const void* fn, const char* name)
@@ -855,6 +868,8 @@ static const int NORM_E_PARTIALS = 32;     // |g| partials of the autoencoder gr
 struct WS {
     float *re, *im, *mag, *phs, *mag_hat, *phs_hat, *AA, *dAA, *Sfold, *SfoldT, *frs, *y_hat, *dsyn, *dmag, *dphs, *dG, *xp;
     float *wg, *aews, *loss_p, *reg_p, *norm_a, *norm_s, *norm_e;
+    // bfloat16 planes of the operands that are written once per step (st_gemm_planes.h): [3][same layout as the fp32 tensor]
+    unsigned short *pl_W, *pl_Sfold, *pl_SfoldT;      // k-chunk-major: [K / 16][rows][3][16]
     size_t bytes;
 };
 static void carve(const st_dims* d, void* base, WS* w)
@@ -873,12 +888,73 @@ static void carve(const st_dims* d, void* base, WS* w)
     w->wg = take(st_wgrad_ws_floats(d)); w->aews = take(st_ae_bwd_ws_floats(d));
     w->loss_p = take(st_ola_loss_partials(d)); w->reg_p = take(st_ae_fwd_partials(d));
     w->norm_a = take(st_norm_partials(d)); w->norm_s = take(st_norm_partials(d)); w->norm_e = take(NORM_E_PARTIALS);
+    auto take16 = [&](size_t n) { return reinterpret_cast<unsigned short*>(take((n + 1) / 2)); };      // always sized for three planes: 19 MB
+    w->pl_W = take16((size_t)3 * 2 * F * N); w->pl_Sfold = take16((size_t)3 * KP * N); w->pl_SfoldT = take16((size_t)3 * KP * N);
     w->bytes = off * sizeof(float);
 }
 extern "C" size_t st_workspace_bytes(const st_dims* d)
 {
     if (check_dims(d) != ST_OK) return 0;
     WS w; carve(d, nullptr, &w); return w.bytes;
+}
+
+// ------------------------------------------------------------------------------ the plane GEMMs of the fused step (ST_PREC_F32X3)
+// Operands written once per step -- the padded waveform, the F used rows of the analysis bases, the folded synthesis bases in both
+// orientations -- become three bfloat16 planes in one elementwise launch; the spectra AA and d syn (one consumer each) are split as
+// their GEMM stages them.  The weight-gradient GEMMs (reduction along the rows of both operands) keep the fp32 MFMA kernel.
+static bool use_planes(const st_dims* d) { return gemm_ht(d->prec) == 3 && d->N % 16 == 0 && st_kp_of(d->F) % 16 == 0; }
+static int planes_prepare(const st_dims* d, const float* Wr, const float* Wi, WS& w, void* stream)
+{
+    const int KP = st_kp_of(d->F);
+    stg::WPlanesArgs a; a.njobs = 3;
+    a.job[0] = stg::WPlanesJob{Wr, Wi, w.pl_W, 2 * d->F, d->N, d->N};                 // rows (bin, re | im) interleaved
+    a.job[1] = stg::WPlanesJob{w.Sfold, nullptr, w.pl_Sfold, KP, d->N, d->N};
+    a.job[2] = stg::WPlanesJob{w.SfoldT, nullptr, w.pl_SfoldT, d->N, KP, KP};
+    a.job[3] = a.job[2];
+    unsigned blk = 0;
+    for (int j = 0; j < 3; ++j) { a.blk0[j] = blk; blk += (unsigned)(((size_t)a.job[j].rows * (a.job[j].K / 4) + 255) / 256); }
+    a.blk0[3] = blk; a.blk0[4] = blk;
+    hipLaunchKernelGGL(stg::wplanes_kernel<3>, dim3(blk), dim3(256), 0, st_stream(stream), a);
+    ST_LAUNCHED("planes");
+    return ST_OK;
+}
+static int analysis_fwd_planes(const st_dims* d, WS& w, float* re, float* im, float* mag, float* phs, void* stream)
+{
+    const stg::RowMap map = stg::live_frames(d->T, d->H, d->N, d->N, d->L);
+    const int R = map.rows(d->B);
+    stg::FramedNT<true> al{w.xp, d->L, d->H, d->N, R, d->N, 1.0f, map};
+    stg::ChunkP bl{w.pl_W, 2 * d->F};
+    stg::PolarStore ep{re, im, mag, phs, R, d->F, map};
+    if (g_pl_shape == 1) ST_TRY((stg::launch_planes<2, 3, 2>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream))));
+    else if (g_pl_shape == 2) ST_TRY((stg::launch_planes<4, 3, 2>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream))));
+    else ST_TRY((stg::launch_planes<4, 3>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream))));
+    ST_LAUNCHED("analysis_fwd");
+    return ST_OK;
+}
+static int synthesis_frames_planes(const st_dims* d, WS& w, void* stream)
+{
+    const int KP = st_kp_of(d->F);
+    const stg::RowMap ms = synth_live(d);
+    const int R = ms.rows(d->B);
+    stg::PlainNT al{w.AA, R, KP, KP, ms};
+    stg::ChunkP bt{w.pl_SfoldT, d->N};
+    stg::StoreC ep{w.frs, R, d->N, d->N, (size_t)d->B * d->OT * d->N, ms};
+    if (R >= 4096) ST_TRY((stg::launch_planes<4, 3>(al, bt, ep, R, d->N, KP, 1, st_stream(stream))));
+    else ST_TRY((stg::launch_planes<2, 3>(al, bt, ep, R, d->N, KP, frames_split(R), st_stream(stream))));
+    ST_LAUNCHED("synthesis_frames"); return ST_OK;
+}
+static int synthesis_dgrad_planes(const st_dims* d, WS& w, void* stream)
+{
+    const int KP = st_kp_of(d->F);
+    const stg::RowMap ms = synth_live(d);
+    const int R = ms.rows(d->B);
+    stg::FramedNT<true> al{w.dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms};
+    stg::ChunkP bl{w.pl_Sfold, KP};
+    stg::StoreC ep{w.dAA, R, KP, KP, (size_t)d->B * d->OT * KP, ms};
+    const int ns = R >= 4096 ? 1 : synth_split(R);
+    if (R >= 4096) ST_TRY((stg::launch_planes<4, 3>(al, bl, ep, R, KP, d->N, ns, st_stream(stream))));
+    else ST_TRY((stg::launch_planes<2, 3>(al, bl, ep, R, KP, d->N, ns, st_stream(stream))));
+    ST_LAUNCHED("synthesis_dgrad"); return ST_OK;
 }
 
 // ------------------------------------------------------------------------------ fused entry points
@@ -901,9 +977,15 @@ static int forward_impl(const st_dims* d, const Layout& L, const float* params, 
         hipLaunchKernelGGL(stm::prep_kernel, dim3(a.n_pad + a.n_fold + n_dead), dim3(256), 0, st_stream(stream), a);
         ST_LAUNCHED("prep");
     }
+    const bool planes = use_planes(d);
+    if (planes) {
+        ST_TRY(planes_prepare(d, Wr, Wi, w, stream));
+        ST_TRY(analysis_fwd_planes(d, w, save ? w.re : nullptr, save ? w.im : nullptr, w.mag, w.phs, stream));
+    } else
     ST_TRY(analysis_fwd_impl(d, w.xp, true, Wr, Wi, 1.0f, save ? w.re : nullptr, save ? w.im : nullptr, w.mag, w.phs, stream, true));
     ST_TRY(st_ae_fwd(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.AA, w.reg_p,
                      (ae_is_wide(d) || (save && ae_use_split(d))) ? w.aews : nullptr, stream));     // fused geometries: the code h4 is kept for the split backward
+    if (planes) ST_TRY(synthesis_frames_planes(d, w, stream)); else
     ST_TRY(synthesis_frames_impl(d, w.AA, w.Sfold, w.SfoldT, w.frs, stream));
     ST_TRY(ola_loss_impl(d, w.frs, x, y_true, y_hat ? y_hat : w.y_hat, (save && y_true) ? w.dsyn : nullptr, d->N,
                          y_true ? w.loss_p : nullptr, stream));
@@ -918,6 +1000,7 @@ static int forward_impl(const st_dims* d, const Layout& L, const float* params, 
 // phase 2 = analysis weight gradient (fills rows [0,F) of the first two tensors).
 static int backward_syn(const st_dims* d, const Layout& L, float* grads, WS& w, void* stream)
 {
+    if (use_planes(d) && g_pl_dgrad) ST_TRY(synthesis_dgrad_planes(d, w, stream)); else
     ST_TRY(synthesis_dgrad_impl(d, w.dsyn, true, w.Sfold, w.dAA, stream));
     return synthesis_wgrad_impl(d, w.AA, w.dsyn, true, w.wg, grads + L.offs[2], grads + L.offs[3], w.norm_s, stream);
 }

@@ -27,6 +27,8 @@
 #pragma once
 #include "st_common.h"
 
+// > 64 KB of dynamic LDS needs a per-(device, kernel) attribute: st_api.hip's checked, cached helper
+static int ensure_dyn_lds(const void* fn, const char* name);
 namespace stg {
 
 constexpr int BK = 32;
@@ -644,22 +646,53 @@ __device__ __forceinline__ unsigned st_pack_f16(float a, float b)
 }
 template <int HT> __device__ __forceinline__ unsigned st_pack_h(float a, float b) { if constexpr (HT == 2) return st_pack_f16(a, b); else return st_pack_bf16(a, b); }
 
+// fp32 operands as THREE bfloat16 planes (PL = 3):  x = x1 + x2 + x3,  x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)
+// (both differences are exact in fp32), 24 significand bits in all.  The product a*b is then formed from the six partial products of
+// order >= 2^-16 -- a1b3, a3b1, a2b2, a1b2, a2b1, a1b1, each exact in the fp32 accumulator's input -- and the three dropped ones
+// are below 2^-24 relative: fp32-grade products (measured against float64: not worse than the fp32 MFMA path, tests/test_gpu_split.py)
+// on the bf16 MATRIX pipe.  Why: on gfx950 v_mfma_f32_*_f32 runs at the vector-ALU fp32 rate (157 TF) and does not overlap vector
+// work at all (tools/ubench), while 6 x v_mfma_f32_32x32x16_bf16 cost 0.375 of the fp32 MFMA's cycles and run beside the VALU.
+__device__ __forceinline__ float st_bf16_lo(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float st_bf16_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+// (conversions through __builtin_convertvector, not the volatile asm of st_pack_bf16: the scheduler has to see them as VALU work it
+// may place between the MFMAs)
+__device__ __forceinline__ unsigned st_cvt_pk_bf16(const float a, const float b)
+{
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    union { bf16x2_t h; unsigned u; } r; r.h = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t); return r.u;
+}
+__device__ __forceinline__ void st_split3(const float x, const float y, const float z, const float w, uint2 (&pl)[3])
+{
+    float r[4] = {x, y, z, w};
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        pl[p] = make_uint2(st_cvt_pk_bf16(r[0], r[1]), st_cvt_pk_bf16(r[2], r[3]));
+        if (p < 2) { r[0] -= st_bf16_lo(pl[p].x); r[1] -= st_bf16_hi(pl[p].x); r[2] -= st_bf16_lo(pl[p].y); r[3] -= st_bf16_hi(pl[p].y); }
+    }
+}
 // HT: 1 = bfloat16 operands (v_mfma_f32_32x32x16_bf16), 2 = float16 operands (v_mfma_f32_32x32x16_f16); same rate, same layout.
-template <int WAVES_M, int HT, class AL, class BL, class EPI>
+// PL: 1 = operands rounded to HT; 3 = the three-plane bfloat16 split of fp32 operands (HT = 1).  BKH: k-tile depth (32 or 16).
+#ifndef ST_SPLIT_VALU_PER_MFMA
+#define ST_SPLIT_VALU_PER_MFMA 5
+#endif
+template <int WAVES_M, int HT, int PL, int BKH, class AL, class BL, class EPI>
 __global__ void __launch_bounds__(WAVES_M * 64)
 gemm_half_kernel(const AL al, const BL bl, const EPI epi, const int K, const int ksplit)
 {
-    constexpr int BKH = 32;
+    static_assert(PL == 1 || (PL == 3 && HT == 1), "the split needs the fp32 exponent range: bfloat16 planes only");
     constexpr int BM = 32 * WAVES_M, NT = 64 * WAVES_M;
     constexpr int LD = BKH + 8;                                   // bf16 elements per LDS row
-    constexpr int A_SZ = BM * LD, B_SZ = BN * LD;
+    constexpr int A_SZ = BM * LD, B_SZ = BN * LD;                 // one plane of one buffer
     constexpr int KQ = BKH / 4;
     constexpr int A_N = AL::kTN ? (BM / 4) * KQ : BM * KQ;       // items: float4 along k (NT) or 4x4 micro-tiles (TN)
     constexpr int B_N = BL::kTN ? (BN / 4) * KQ : BN * KQ;
     constexpr int A_IT = (A_N + NT - 1) / NT, B_IT = (B_N + NT - 1) / NT;
     constexpr int A_LDS = AL::kTN ? 4 : 1, B_LDS = BL::kTN ? 4 : 1;    // global float4 loads per item
-    __shared__ __attribute__((aligned(16))) unsigned short As[2 * A_SZ];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * B_SZ];
+    extern __shared__ __attribute__((aligned(16))) unsigned short half_lds[];      // [2 buffers][PL planes][A_SZ] | [2][PL][B_SZ] | PL = 3: a dump slot per thread
+    unsigned short* const As = half_lds;
+    unsigned short* const Bs = half_lds + 2 * PL * A_SZ;
+    unsigned short* const dump = half_lds + 2 * PL * (A_SZ + B_SZ) + 4 * threadIdx.x;   // threads without an item store there: no branch in the loop body
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int tbx, tby, tbz; xcd_tile(tbx, tby, tbz);
@@ -718,43 +751,51 @@ gemm_half_kernel(const AL al, const BL bl, const EPI epi, const int K, const int
             }
     };
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // four consecutive k of one row -> LDS: one 8-byte store per plane (plane p of a buffer sits p * SZ elements behind plane 0)
+    auto put4 = [&](unsigned short* dst, const int plane_sz, const float x, const float y, const float z, const float w) {
+        if constexpr (PL == 3) {
+            uint2 pl[3]; st_split3(x, y, z, w, pl);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(dst + p * plane_sz) = pl[p];
+        } else { (void)plane_sz; *reinterpret_cast<uint2*>(dst) = make_uint2(st_pack_h<HT>(x, y), st_pack_h<HT>(z, w)); }
+    };
     auto lstore = [&](int buf) {
-        unsigned short* as = As + buf * A_SZ;
-        unsigned short* bs = Bs + buf * B_SZ;
+        unsigned short* as = As + buf * PL * A_SZ;
+        unsigned short* bs = Bs + buf * PL * B_SZ;
 #pragma unroll
         for (int p = 0; p < A_IT; ++p) {
-            if (A_N % NT != 0 && !a_v[p]) continue;
+            const bool skip = A_N % NT != 0 && !a_v[p];
+            if (PL != 3 && skip) continue;
             if constexpr (AL::kTN) {
                 float4 v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = oa[p][q] ? al.post(ra[p][q]) : zero4;
-                const float m0[4] = {v[0].x, v[1].x, v[2].x, v[3].x}, m1[4] = {v[0].y, v[1].y, v[2].y, v[3].y};
-                const float m2[4] = {v[0].z, v[1].z, v[2].z, v[3].z}, m3[4] = {v[0].w, v[1].w, v[2].w, v[3].w};
-                *reinterpret_cast<uint2*>(as + (a_i[p] + 0) * LD + a_k[p]) = make_uint2(st_pack_h<HT>(m0[0], m0[1]), st_pack_h<HT>(m0[2], m0[3]));
-                *reinterpret_cast<uint2*>(as + (a_i[p] + 1) * LD + a_k[p]) = make_uint2(st_pack_h<HT>(m1[0], m1[1]), st_pack_h<HT>(m1[2], m1[3]));
-                *reinterpret_cast<uint2*>(as + (a_i[p] + 2) * LD + a_k[p]) = make_uint2(st_pack_h<HT>(m2[0], m2[1]), st_pack_h<HT>(m2[2], m2[3]));
-                *reinterpret_cast<uint2*>(as + (a_i[p] + 3) * LD + a_k[p]) = make_uint2(st_pack_h<HT>(m3[0], m3[1]), st_pack_h<HT>(m3[2], m3[3]));
+                unsigned short* const t = as + a_i[p] * LD + a_k[p];
+                put4(skip ? dump : t + 0 * LD, skip ? 0 : A_SZ, v[0].x, v[1].x, v[2].x, v[3].x);
+                put4(skip ? dump : t + 1 * LD, skip ? 0 : A_SZ, v[0].y, v[1].y, v[2].y, v[3].y);
+                put4(skip ? dump : t + 2 * LD, skip ? 0 : A_SZ, v[0].z, v[1].z, v[2].z, v[3].z);
+                put4(skip ? dump : t + 3 * LD, skip ? 0 : A_SZ, v[0].w, v[1].w, v[2].w, v[3].w);
             } else {
                 const float4 v = oa[p][0] ? al.post(ra[p][0]) : zero4;
-                *reinterpret_cast<uint2*>(as + a_i[p] * LD + a_k[p]) = make_uint2(st_pack_h<HT>(v.x, v.y), st_pack_h<HT>(v.z, v.w));
+                put4(skip ? dump : as + a_i[p] * LD + a_k[p], skip ? 0 : A_SZ, v.x, v.y, v.z, v.w);
             }
         }
 #pragma unroll
         for (int p = 0; p < B_IT; ++p) {
-            if (B_N % NT != 0 && !b_v[p]) continue;
+            const bool skip = B_N % NT != 0 && !b_v[p];
+            if (PL != 3 && skip) continue;
             if constexpr (BL::kTN) {
                 float4 v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = ob[p][q] ? bl.post(rb[p][q]) : zero4;
-                const float m0[4] = {v[0].x, v[1].x, v[2].x, v[3].x}, m1[4] = {v[0].y, v[1].y, v[2].y, v[3].y};
-                const float m2[4] = {v[0].z, v[1].z, v[2].z, v[3].z}, m3[4] = {v[0].w, v[1].w, v[2].w, v[3].w};
-                *reinterpret_cast<uint2*>(bs + (b_i[p] + 0) * LD + b_k[p]) = make_uint2(st_pack_h<HT>(m0[0], m0[1]), st_pack_h<HT>(m0[2], m0[3]));
-                *reinterpret_cast<uint2*>(bs + (b_i[p] + 1) * LD + b_k[p]) = make_uint2(st_pack_h<HT>(m1[0], m1[1]), st_pack_h<HT>(m1[2], m1[3]));
-                *reinterpret_cast<uint2*>(bs + (b_i[p] + 2) * LD + b_k[p]) = make_uint2(st_pack_h<HT>(m2[0], m2[1]), st_pack_h<HT>(m2[2], m2[3]));
-                *reinterpret_cast<uint2*>(bs + (b_i[p] + 3) * LD + b_k[p]) = make_uint2(st_pack_h<HT>(m3[0], m3[1]), st_pack_h<HT>(m3[2], m3[3]));
+                unsigned short* const t = bs + b_i[p] * LD + b_k[p];
+                put4(skip ? dump : t + 0 * LD, skip ? 0 : B_SZ, v[0].x, v[1].x, v[2].x, v[3].x);
+                put4(skip ? dump : t + 1 * LD, skip ? 0 : B_SZ, v[0].y, v[1].y, v[2].y, v[3].y);
+                put4(skip ? dump : t + 2 * LD, skip ? 0 : B_SZ, v[0].z, v[1].z, v[2].z, v[3].z);
+                put4(skip ? dump : t + 3 * LD, skip ? 0 : B_SZ, v[0].w, v[1].w, v[2].w, v[3].w);
             } else {
                 const float4 v = ob[p][0] ? bl.post(rb[p][0]) : zero4;
-                *reinterpret_cast<uint2*>(bs + b_i[p] * LD + b_k[p]) = make_uint2(st_pack_h<HT>(v.x, v.y), st_pack_h<HT>(v.z, v.w));
+                put4(skip ? dump : bs + b_i[p] * LD + b_k[p], skip ? 0 : B_SZ, v.x, v.y, v.z, v.w);
             }
         }
     };
@@ -765,6 +806,108 @@ gemm_half_kernel(const AL al, const BL bl, const EPI epi, const int K, const int
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
+    if constexpr (PL == 3) {
+        // Software pipeline, one basic block per k-tile:  fragments of tile t  |  the 6 * NJ MFMAs of tile t, term-major (consecutive
+        // MFMAs write different accumulators), each followed by ONE plane-stage of the split of tile t+1 (2 conversions, the 8-byte
+        // LDS store of that plane, the 8 instructions that form the next remainder) so that the vector work issues in the MFMA's
+        // shadow -- a dense MFMA run would stall the wave on the busy matrix pipe and serialise everything behind it (tools/ubench)
+        // |  global loads of tile t+2 (their registers were consumed by the stages)  |  barrier.  sched_barrier pins the order.
+        static_assert(BKH == 16, "PL == 3 runs one MFMA k-step per k-tile");
+        constexpr int A_U = A_IT * (AL::kTN ? 4 : 1), B_U = B_IT * (BL::kTN ? 4 : 1), NU = A_U + B_U, NS = 3 * NU, NM = 6 * NJ;
+        float sr[NU][4]; unsigned short* sdst[NU]; int ssz[NU];
+        auto stage_begin = [&](const int buf) {
+            unsigned short* as = As + buf * PL * A_SZ;
+            unsigned short* bs = Bs + buf * PL * B_SZ;
+#pragma unroll
+            for (int p = 0; p < A_IT; ++p) {
+                const bool skip = A_N % NT != 0 && !a_v[p];
+                if constexpr (AL::kTN) {
+                    float4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = oa[p][q] ? al.post(ra[p][q]) : zero4;
+                    const float m[4][4] = {{v[0].x, v[1].x, v[2].x, v[3].x}, {v[0].y, v[1].y, v[2].y, v[3].y}, {v[0].z, v[1].z, v[2].z, v[3].z}, {v[0].w, v[1].w, v[2].w, v[3].w}};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int u = 4 * p + i;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sr[u][e] = m[i][e];
+                        sdst[u] = skip ? dump : as + (a_i[p] + i) * LD + a_k[p]; ssz[u] = skip ? 0 : A_SZ;
+                    }
+                } else {
+                    const float4 v = oa[p][0] ? al.post(ra[p][0]) : zero4;
+                    sr[p][0] = v.x; sr[p][1] = v.y; sr[p][2] = v.z; sr[p][3] = v.w;
+                    sdst[p] = skip ? dump : as + a_i[p] * LD + a_k[p]; ssz[p] = skip ? 0 : A_SZ;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < B_IT; ++p) {
+                const bool skip = B_N % NT != 0 && !b_v[p];
+                if constexpr (BL::kTN) {
+                    float4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = ob[p][q] ? bl.post(rb[p][q]) : zero4;
+                    const float m[4][4] = {{v[0].x, v[1].x, v[2].x, v[3].x}, {v[0].y, v[1].y, v[2].y, v[3].y}, {v[0].z, v[1].z, v[2].z, v[3].z}, {v[0].w, v[1].w, v[2].w, v[3].w}};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int u = A_U + 4 * p + i;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sr[u][e] = m[i][e];
+                        sdst[u] = skip ? dump : bs + (b_i[p] + i) * LD + b_k[p]; ssz[u] = skip ? 0 : B_SZ;
+                    }
+                } else {
+                    const int u = A_U + p;
+                    const float4 v = ob[p][0] ? bl.post(rb[p][0]) : zero4;
+                    sr[u][0] = v.x; sr[u][1] = v.y; sr[u][2] = v.z; sr[u][3] = v.w;
+                    sdst[u] = skip ? dump : bs + b_i[p] * LD + b_k[p]; ssz[u] = skip ? 0 : B_SZ;
+                }
+            }
+        };
+        auto stage = [&](const int u, const int pp) {
+            const uint2 pl = make_uint2(st_cvt_pk_bf16(sr[u][0], sr[u][1]), st_cvt_pk_bf16(sr[u][2], sr[u][3]));
+            *reinterpret_cast<uint2*>(sdst[u] + pp * ssz[u]) = pl;
+            if (pp < 2) { sr[u][0] -= st_bf16_lo(pl.x); sr[u][1] -= st_bf16_hi(pl.x); sr[u][2] -= st_bf16_lo(pl.y); sr[u][3] -= st_bf16_hi(pl.y); }
+        };
+        if (k_begin < k_end) {
+            gload(k_begin);
+            lstore(0);
+            gload(k_begin + BKH < k_end ? k_begin + BKH : k_begin);
+            __syncthreads();
+            int cur = 0;
+            const int h = lane >> 5, l31 = lane & 31;
+            const int a_off = (wave * 32 + l31) * LD + 8 * h;
+            const int b_off = l31 * LD + 8 * h;
+            for (int kt = k_begin; kt < k_end; kt += BKH) {
+                const unsigned short* as = As + cur * PL * A_SZ + a_off;
+                const unsigned short* bs = Bs + cur * PL * B_SZ + b_off;
+                st_bf16x8 a[3], b[NJ][3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const st_bf16x8*>(as + p * A_SZ);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) b[j][p] = *reinterpret_cast<const st_bf16x8*>(bs + p * B_SZ + 32 * j * LD);
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};      // smallest partial products first
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    const int t = m / NJ, j = m % NJ;
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[t]], b[j][TB[t]], acc[j], 0, 0, 0);
+                    if (m == 0) {
+                        stage_begin(cur ^ 1);                    // tile t+1 (stale registers past the end: that buffer is not read again)
+                        const int k2 = kt + 2 * BKH;             // its registers are free now: tile t+2 has the whole iteration to arrive
+                        gload(k2 < k_end ? k2 : kt);
+                    }
+                    // stage s runs behind MFMA 1 + s * (NM - 1) / NS  (all stages spread over MFMAs 1 .. NM-1)
+#pragma unroll
+                    for (int sg = 0; sg < NS; ++sg)
+                        if (1 + (sg * (NM - 1)) / NS == m) stage(sg / 3, sg % 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+    } else
     if (k_begin < k_end) {
         gload(k_begin);
         lstore(0);
@@ -777,11 +920,28 @@ gemm_half_kernel(const AL al, const BL bl, const EPI epi, const int K, const int
             const bool more = kt + BKH < k_end;
             gload(more ? kt + BKH : kt);                     // branch-free body (see gemm_kernel)
             __builtin_amdgcn_sched_barrier(0);
-            const unsigned short* as = As + cur * A_SZ + a_off;
-            const unsigned short* bs = Bs + cur * B_SZ + b_off;
+            const unsigned short* as = As + cur * PL * A_SZ + a_off;
+            const unsigned short* bs = Bs + cur * PL * B_SZ + b_off;
 #pragma unroll
             for (int ks = 0; ks < BKH / 16; ++ks) {
-                if constexpr (HT == 2) {
+                if constexpr (PL == 3) {
+                    st_bf16x8 a[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const st_bf16x8*>(as + p * A_SZ + 16 * ks);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        st_bf16x8 b[3];
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const st_bf16x8*>(bs + p * B_SZ + 32 * j * LD + 16 * ks);
+                        // smallest partial products first
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[j], 0, 0, 0);
+                    }
+                } else if constexpr (HT == 2) {
                     const st_f16x8 a = *reinterpret_cast<const st_f16x8*>(as + 16 * ks);
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
@@ -806,14 +966,17 @@ gemm_half_kernel(const AL al, const BL bl, const EPI epi, const int K, const int
     epi(m_blk + wave * 32, n_blk, acc);
 }
 
-template <int WAVES_M, int HT = 1, class AL, class BL, class EPI>
-static inline void launch_half(const AL& al, const BL& bl, const EPI& epi, int M, int Nc, int K, int nsplit, hipStream_t s)
+template <int WAVES_M, int HT = 1, int PL = 1, int BKH = (PL == 3 ? 16 : 32), class AL, class BL, class EPI>
+static inline int launch_half(const AL& al, const BL& bl, const EPI& epi, int M, int Nc, int K, int nsplit, hipStream_t s)
 {
     constexpr int BM = 32 * WAVES_M;
+    constexpr size_t lds = ((size_t)2 * PL * (BM + BN) * (BKH + 8) + (PL == 3 ? 4 * 64 * WAVES_M : 0)) * sizeof(unsigned short);
     int ksplit = K;
     if (nsplit > 1) ksplit = st_round_up((K + nsplit - 1) / nsplit, 32);
     dim3 grid((Nc + BN - 1) / BN, (M + BM - 1) / BM, nsplit > 1 ? nsplit : 1);
-    hipLaunchKernelGGL((gemm_half_kernel<WAVES_M, HT, AL, BL, EPI>), grid, dim3(WAVES_M * 64), 0, s, al, bl, epi, K, ksplit);
+    if (lds > 65536) { const int rc = ::ensure_dyn_lds((const void*)gemm_half_kernel<WAVES_M, HT, PL, BKH, AL, BL, EPI>, "gemm_half_kernel"); if (rc) return rc; }
+    hipLaunchKernelGGL((gemm_half_kernel<WAVES_M, HT, PL, BKH, AL, BL, EPI>), grid, dim3(WAVES_M * 64), lds, s, al, bl, epi, K, ksplit);
+    return 0;
 }
 
 template <int WAVES_M, int BKT, int MI = 1, bool XT = false, class AL, class BL, class EPI>

@@ -115,6 +115,20 @@ class mixed_mode:
 bf16_mode = mixed_mode       # round-1 name
 
 
+class split_mode:
+    """Context: the checks run with st_dims.prec = ST_PREC_F32X3 (fp32 operands as three bfloat16 planes, six partial products
+    per product on the bf16 matrix pipe) against the UNMODIFIED fp32 oracle at the fp32 tolerances: the split is a different
+    rounding of fp32 arithmetic, not a lower precision."""
+
+    def __enter__(self):
+        global ENGINE_DTYPE, PREC_LEVEL
+        PREC_LEVEL, ENGINE_DTYPE = 5, "f32x3"
+
+    def __exit__(self, *a):
+        global ENGINE_DTYPE, PREC_LEVEL
+        PREC_LEVEL, ENGINE_DTYPE = 0, "f32"
+
+
 def new_engine(d, **kw):
     """A StepEngine with the arithmetic of the current mode."""
     return StepEngine(d, DEV, compute_dtype=ENGINE_DTYPE, loss_scale=(LOSS_SCALE if LOSS_SCALE > 0 else 1.0), clip_all=CLIP_ALL, **kw)
