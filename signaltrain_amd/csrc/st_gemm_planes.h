@@ -40,7 +40,7 @@ struct Stager {
     static_assert(!L::kTN, "the planes kernel takes K-contiguous operands");
     static constexpr int N = ROWS * 4, IT = (N + NT_ - 1) / NT_, NS = IT * PL;
     int row[IT], k4[IT]; bool valid[IT]; RowState st[IT];
-    float4 reg[IT]; bool ok[IT];
+    float4 reg[2][IT]; bool ok[2][IT];                  // two prefetch sets: tile t+2 is requested while tile t+1 is being staged
     float sr[IT][4]; unsigned short* dst[IT]; int psz[IT];
     __device__ __forceinline__ void init(const L& l, const int blk0, const int tid) {
 #pragma unroll
@@ -49,30 +49,30 @@ struct Stager {
             row[p] = id >> 2; k4[p] = (id & 3) * 4; st[p] = l.row_state(blk0 + row[p]);
         }
     }
-    __device__ __forceinline__ void gload(const L& l, const int kt) {
+    __device__ __forceinline__ void gload(const L& l, const int kt, const int set) {
 #pragma unroll
         for (int p = 0; p < IT; ++p) {
             const int k = kt + k4[p];
             if constexpr (L::kOff) {
                 const bool o = !L::kCheck || (k >= st[p].lo && k < st[p].hi);
-                ok[p] = o; reg[p] = ldg128(l.dummy(), o ? st[p].o + (unsigned)k : 0u);
+                ok[set][p] = o; reg[set][p] = ldg128(l.dummy(), o ? st[p].o + (unsigned)k : 0u);
             } else {
                 const Src s = l.src(st[p], k);
-                if constexpr (L::kCheck) { ok[p] = s.ok; reg[p] = *reinterpret_cast<const float4*>(s.ok ? s.p : l.dummy()); }
-                else { ok[p] = true; reg[p] = *reinterpret_cast<const float4*>(s.p); }
+                if constexpr (L::kCheck) { ok[set][p] = s.ok; reg[set][p] = *reinterpret_cast<const float4*>(s.ok ? s.p : l.dummy()); }
+                else { ok[set][p] = true; reg[set][p] = *reinterpret_cast<const float4*>(s.p); }
             }
         }
     }
-    __device__ __forceinline__ void begin(const L& l, unsigned short* tile, const int plane_sz, unsigned short* dump, const int LD) {
+    __device__ __forceinline__ void begin(const L& l, unsigned short* tile, const int plane_sz, unsigned short* dump, const int LD, const int set) {
 #pragma unroll
         for (int p = 0; p < IT; ++p) {
-            const float4 v = ok[p] ? l.post(reg[p]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v = ok[set][p] ? l.post(reg[set][p]) : make_float4(0.f, 0.f, 0.f, 0.f);
             sr[p][0] = v.x; sr[p][1] = v.y; sr[p][2] = v.z; sr[p][3] = v.w;
             const bool skip = N % NT_ != 0 && !valid[p];
             dst[p] = skip ? dump : tile + row[p] * LD + k4[p]; psz[p] = skip ? 0 : plane_sz;
         }
     }
-    __device__ __forceinline__ void stage(const int s) {         // s = item * PL + plane
+    __device__ __forceinline__ void stage(const int s, const int) {         // s = item * PL + plane
         const int u = s / PL, pp = s % PL;
         const uint2 pl = make_uint2(st_cvt_pk_bf16(sr[u][0], sr[u][1]), st_cvt_pk_bf16(sr[u][2], sr[u][3]));
         *reinterpret_cast<uint2*>(dst[u] + pp * psz[u]) = pl;
@@ -85,7 +85,7 @@ struct Stager<L, ROWS, NT_, PL, true> {
     static constexpr int PPR = 2 * PL;                       // pieces per row and k-chunk
     static constexpr int N = ROWS * PPR, IT = (N + NT_ - 1) / NT_, NS = IT;
     bool valid[IT]; const unsigned short* src[IT]; unsigned cstride;      // elements between k-chunks
-    uint4 reg[IT];
+    uint4 reg[2][IT];
     unsigned short* dst[IT]; int loff[IT];
     __device__ __forceinline__ void init(const L& l, const int blk0, const int tid) {
         cstride = (unsigned)l.rows * (16 * PL);
@@ -98,20 +98,25 @@ struct Stager<L, ROWS, NT_, PL, true> {
             loff[p] = (q >> 1) * (ROWS * 24 + 16) + r * 24 + 8 * (q & 1);      // LDS offset in the buffer: plane q / 2 (ROWS x 24 + 16 elements each), row r, k-half q % 2
         }
     }
-    __device__ __forceinline__ void gload(const L&, const int kt) {
+    __device__ __forceinline__ void gload(const L&, const int kt, const int set) {
 #pragma unroll
-        for (int p = 0; p < IT; ++p) reg[p] = *reinterpret_cast<const uint4*>(src[p] + (size_t)(kt >> 4) * cstride);
+        for (int p = 0; p < IT; ++p) reg[set][p] = *reinterpret_cast<const uint4*>(src[p] + (size_t)(kt >> 4) * cstride);
     }
-    __device__ __forceinline__ void begin(const L&, unsigned short* tile, const int plane_sz, unsigned short* dump, const int LD) {
+    __device__ __forceinline__ void begin(const L&, unsigned short* tile, const int plane_sz, unsigned short* dump, const int LD, const int) {
 #pragma unroll
         for (int p = 0; p < IT; ++p) {
             const bool skip = N % NT_ != 0 && !valid[p];
             dst[p] = skip ? dump : tile + loff[p];
         }
     }
-    __device__ __forceinline__ void stage(const int s) { *reinterpret_cast<uint4*>(dst[s]) = reg[s]; }
+    __device__ __forceinline__ void stage(const int s, const int set) { *reinterpret_cast<uint4*>(dst[s]) = reg[set][s]; }
 };
 
+// timing-only ablation (tools: build with -DST_PL_ABLATE=bits; results INVALID): 1 no global loads in the loop | 2 no barrier |
+// 4 no staging steps | 8 fragments read once | 16 no MFMAs
+#ifndef ST_PL_ABLATE
+#define ST_PL_ABLATE 0
+#endif
 template <int WAVES_M, int PL, int MI, class AL, class BL, class EPI>
 __global__ void __launch_bounds__(WAVES_M * 64)
 gemm_planes_kernel(const AL al, const BL bl, const EPI epi, const int K, const int ksplit)
@@ -146,22 +151,26 @@ gemm_planes_kernel(const AL al, const BL bl, const EPI epi, const int K, const i
             for (int i = 0; i < 16; ++i) acc[mi][j][i] = 0.f;
 
     if (k_begin < k_end) {
-        sa.gload(al, k_begin); sb.gload(bl, k_begin);
-        sa.begin(al, As, A_SZ, dump, LD); sb.begin(bl, Bs, B_SZ, dump, LD);
+        sa.gload(al, k_begin, 0); sb.gload(bl, k_begin, 0);
+        sa.begin(al, As, A_SZ, dump, LD, 0); sb.begin(bl, Bs, B_SZ, dump, LD, 0);
 #pragma unroll
-        for (int s = 0; s < NSA; ++s) sa.stage(s);
+        for (int s = 0; s < NSA; ++s) sa.stage(s, 0);
 #pragma unroll
-        for (int s = 0; s < NSB; ++s) sb.stage(s);
-        { const int k1 = k_begin + BKP < k_end ? k_begin + BKP : k_begin; sa.gload(al, k1); sb.gload(bl, k1); }
+        for (int s = 0; s < NSB; ++s) sb.stage(s, 0);
+        { const int k1 = k_begin + BKP < k_end ? k_begin + BKP : k_begin; sa.gload(al, k1, 1); sb.gload(bl, k1, 1); }     // tile 1 -> set 1
         __syncthreads();
-        int cur = 0;
         const int h = lane >> 5, l31 = lane & 31;
         const int a_off = (wave * 32 * MI + l31) * LD + 8 * h;
         const int b_off = l31 * LD + 8 * h;
-        for (int kt = k_begin; kt < k_end; kt += BKP) {
-            const unsigned short* as = As + cur * PL * A_SZ + a_off;
-            const unsigned short* bs = Bs + cur * PL * B_SZ + b_off;
-            st_bf16x8 a[MI][PL], b[NJ][PL];
+        st_bf16x8 a[MI][PL], b[NJ][PL];
+        // one k-tile: tile `kt` sits in LDS buffer CUR; the registers of set 1 - CUR hold tile kt + 16 (staged now), set CUR receives tile kt + 32
+        auto ktile = [&](const int kt, const int CUR) {
+            const unsigned short* as = As + CUR * PL * A_SZ + a_off;
+            const unsigned short* bs = Bs + CUR * PL * B_SZ + b_off;
+#if ST_PL_ABLATE & 8
+            if (kt == k_begin)
+#endif
+            {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -170,29 +179,42 @@ gemm_planes_kernel(const AL al, const BL bl, const EPI epi, const int K, const i
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int p = 0; p < PL; ++p) b[j][p] = *reinterpret_cast<const st_bf16x8*>(bs + p * B_SZ + 32 * j * LD);
+            }
             __builtin_amdgcn_sched_barrier(0);
             constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};      // smallest partial products first
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 const int t = m / (NJ * MI), j = (m / MI) % NJ, mi = m % MI;
+#if !(ST_PL_ABLATE & 16)
                 acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][PL == 3 ? TA[t] : 0], b[j][PL == 3 ? TB[t] : 0], acc[mi][j], 0, 0, 0);
+#else
+                acc[mi][j][0] += __builtin_bit_cast(float, (int)a[mi][0][0]) + __builtin_bit_cast(float, (int)b[j][0][0]);
+#endif
                 if (m == 0) {
-                    // tile t+1 leaves its registers (past the end: stale data into a buffer that is not read again) ...
-                    sa.begin(al, As + (cur ^ 1) * PL * A_SZ, A_SZ, dump, LD); sb.begin(bl, Bs + (cur ^ 1) * PL * B_SZ, B_SZ, dump, LD);
-                }
-                // ... one staging step behind each MFMA: step s behind MFMA s * NM / NS (several per MFMA when there are more steps)
-#pragma unroll
-                for (int s = 0; s < NS; ++s)
-                    if ((s * NM) / NS == m) { if (s < NSA) sa.stage(s); else sb.stage(s - NSA); }
-                if (m == NM - 1) {                              // ... and tile t+2 has a whole iteration to arrive
+                    // tile kt + 16 leaves its registers (past the end: stale data into a buffer that is not read again) ...
+                    sa.begin(al, As + (CUR ^ 1) * PL * A_SZ, A_SZ, dump, LD, CUR ^ 1); sb.begin(bl, Bs + (CUR ^ 1) * PL * B_SZ, B_SZ, dump, LD, CUR ^ 1);
+#if !(ST_PL_ABLATE & 1)
+                    // ... and tile kt + 32 is requested into the other set: a whole iteration to arrive
                     const int k2 = kt + 2 * BKP;
                     const int kl = k2 < k_end ? k2 : kt;
-                    sa.gload(al, kl); sb.gload(bl, kl);
+                    sa.gload(al, kl, CUR); sb.gload(bl, kl, CUR);
+#endif
                 }
+                // one staging step behind each MFMA: step s behind MFMA s * NM / NS (several per MFMA when there are more steps)
+#if !(ST_PL_ABLATE & 4)
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    if ((s * NM) / NS == m) { if (s < NSA) sa.stage(s, CUR ^ 1); else sb.stage(s - NSA, CUR ^ 1); }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
+#if !(ST_PL_ABLATE & 2)
             __syncthreads();
-            cur ^= 1;
+#endif
+        };
+        for (int kt = k_begin; kt < k_end; kt += 2 * BKP) {
+            ktile(kt, 0);
+            if (kt + BKP < k_end) ktile(kt + BKP, 1);
         }
     }
 #pragma unroll
