@@ -1429,6 +1429,11 @@ static int attr_prepare(const st_dims* d)
         else ST_PREP3((sta::ae_bwd_kernel<AE_BWD_NW, false, false, 0, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 1, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 2, 0>));
     }
 #undef ST_PREP3
+    if (use_planes(d)) {        // the 4-wave plane GEMM carries 67 KB of LDS (st_gemm_planes.h)
+        ST_DYN_LDS((stg::gemm_planes_kernel<4, 3, 1, stg::FramedNT<true>, stg::ChunkP, stg::PolarStore>));
+        ST_DYN_LDS((stg::gemm_planes_kernel<4, 3, 1, stg::PlainNT, stg::ChunkP, stg::StoreC>));
+        ST_DYN_LDS((stg::gemm_planes_kernel<4, 3, 1, stg::FramedNT<true>, stg::ChunkP, stg::StoreC>));
+    }
     (void)num_cus();
     return ST_OK;
 }

@@ -21,7 +21,7 @@ STFT_KEYS = ("mpaec.dft_analysis.conv_analysis_real.weight",
              "mpaec.dft_analysis.conv_analysis_imag.weight",
              "mpaec.dft_synthesis.conv_synthesis_real.weight",
              "mpaec.dft_synthesis.conv_synthesis_imag.weight")
-COMPUTE_DTYPES = tuple(_lib.PREC)       # "f32", "bf16", "bf16_all", "f16", "f16_all"
+COMPUTE_DTYPES = tuple(_lib.PREC)       # "f32", "bf16", "bf16_all", "f16", "f16_all", "f32x3"
 
 
 def param_names():
@@ -74,8 +74,9 @@ class StepEngine:
     """Holds device state for one model replica and drives the HIP step."""
 
     def __init__(self, dims, device="cuda:0", max_batch=None, compute_dtype="f32", loss_scale=None, clip_all=None):
-        """compute_dtype: "f32" (default, the parity path); "bf16" / "f16" = 16-bit operands with fp32 accumulation in the STFT
-        GEMMs (BASELINE configs[2], [3] / [4]); "bf16_all" / "f16_all" = also in the autoencoder layers.  Parameters, gradients,
+        """compute_dtype: "f32" (default, the parity path); "f32x3" = fp32-grade STFT GEMMs on the bf16 matrix pipe (operands as three
+        bfloat16 planes, six partial products, fp32 accumulation; same tolerance as "f32"); "bf16" / "f16" = 16-bit operands with fp32
+        accumulation in the STFT GEMMs (BASELINE configs[2], [3] / [4]); "bf16_all" / "f16_all" = also in the autoencoder layers.  Parameters, gradients,
         loss and Adam are fp32 in every mode.  loss_scale: static loss scale of the step (default: 1 except 2**12 for the f16
         modes -- Apex's amp.scale_loss, train.py:134-135); clip_all: L1 clip over all parameters instead of the STFT tensors
         (train.py:136, what the reference does with Apex on; default: only in the f16 modes)."""

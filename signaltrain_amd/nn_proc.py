@@ -254,7 +254,7 @@ class st_model(nn.Module):
         self.mpaec.clip_grad_norm_()
 
     def set_compute_dtype(self, dtype):
-        """Mixed precision of the accelerated path: 'f32' (default) | 'bf16' | 'bf16_all' | 'f16' | 'f16_all' (see AsymMPAEC.set_compute_dtype)."""
+        """Arithmetic of the accelerated path: 'f32' (default) | 'f32x3' | 'bf16' | 'bf16_all' | 'f16' | 'f16_all' (see AsymMPAEC.set_compute_dtype)."""
         self.mpaec.set_compute_dtype(dtype)
 
     def forward(self, x_cuda, knobs_cuda, return_acts=False):

@@ -538,7 +538,8 @@ def test_train_driver_bf16_all(tmp_path):
     assert np.all(np.abs(traj["bf16_all"] - traj["f32"]) <= 0.05 * np.abs(traj["f32"])), traj
 
 
-def test_graph_step_equals_eager_steps(golden_dir):
+@pytest.mark.parametrize("dtype", ["f32", "f32x3"])
+def test_graph_step_equals_eager_steps(golden_dir, dtype):
     """st_graph_*: the whole optimisation step captured once as a HIP graph (step counter and learning rate on the device, looked
     up in the device copy of the 1-cycle table as lr_sched[max(i-1, 0)], train.py:150) and replayed == the same steps launched
     eagerly with the host passing step and learning rate."""
@@ -548,8 +549,8 @@ def test_graph_step_equals_eager_steps(golden_dir):
     gb = np.load(os.path.join(golden_dir, "g4b_backward_clip.npz"))
     d = m.engine(torch.zeros(3, 8192, device="cuda")).dims
     lrs, _ = learningrate.get_1cycle_schedule(lr_max=1e-3, n_data_points=30, epochs=1, batch_size=3)
-    e1 = StepEngine(d, "cuda:0"); e1.load_state_dict(P)
-    e2 = StepEngine(d, "cuda:0"); e2.load_state_dict(P)
+    e1 = StepEngine(d, "cuda:0", compute_dtype=dtype); e1.load_state_dict(P)
+    e2 = StepEngine(d, "cuda:0", compute_dtype=dtype); e2.load_state_dict(P)      # f32x3: the capture includes the plane kernels (> 64 KB of LDS: attribute set before the capture)
     kn = torch.from_numpy(gb["knobs"]).cuda()
     e2.graph_capture(3, lrs)
     for it in range(5):
