@@ -46,6 +46,31 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // instructions and sits on the critical path of the issue-bound autoencoder kernels.
 __device__ __forceinline__ void st_sincos(float x, float& sn, float& cs) { sn = __sinf(x); cs = __cosf(x); }
 
+// atan2 for the polar epilogue of the analysis GEMM (nn_proc.py:310): odd minimax polynomial of degree 17 for atan on [0, 1] (max error
+// 1.1e-7 rad evaluated in fp32) on min/max of |x|, |y| through v_rcp_f32 (1 ulp), octant / quadrant fix-ups, the sign of y copied
+// (so atan2(-0, x < 0) = -pi as IEEE has it).  Total error <= 3e-7 rad against the 1e-4 parity tolerance: ~25 instructions instead
+// of the ~150 of the library atan2f -- the epilogue runs 24 of these per lane with nothing to overlap (fixed cost of the kernel).
+__device__ __forceinline__ float st_atan2f(const float y, const float x)
+{
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const float mx = __builtin_amdgcn_fmed3f(ax, ay, 3.0e38f), mn = __builtin_amdgcn_fmed3f(ax, ay, 0.f);     // max / min of two non-negative values
+    const float t = mn * __builtin_amdgcn_rcpf(__builtin_amdgcn_fmed3f(mx, 2.0e-38f, 3.0e38f));               // x = y = 0 -> 0
+    const float s = t * t;
+    float p = 0.0028340641874819994f;
+    p = __builtin_fmaf(p, s, -0.016005029901862144f);
+    p = __builtin_fmaf(p, s, 0.042587608098983765f);
+    p = __builtin_fmaf(p, s, -0.07495445758104324f);
+    p = __builtin_fmaf(p, s, 0.10636754333972931f);
+    p = __builtin_fmaf(p, s, -0.14202570915222168f);
+    p = __builtin_fmaf(p, s, 0.19992484152317047f);
+    p = __builtin_fmaf(p, s, -0.3333306610584259f);
+    p = __builtin_fmaf(p, s, 1.0f);
+    float r = t * p;
+    r = ay > ax ? 1.57079632679489662f - r : r;
+    r = x < 0.f ? 3.14159265358979324f - r : r;
+    return __builtin_copysignf(r, y);
+}
+
 // ELU(a) = a > 0 ? a : exp(a) - 1 (nn_proc.py:31, alpha = 1).  With u = exp(a) - 1:  u >= a for every a, and u <= 0 exactly when
 // a <= 0, so the value is the MEDIAN of {a, u, 0} -- one v_med3_f32 instead of a compare and a select (5 -> 4 instructions per
 // activation; 3 with the packed multiply / add of elu4).  Differs from the select form only where the fp32 rounding of exp()

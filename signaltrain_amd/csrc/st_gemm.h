@@ -318,8 +318,8 @@ struct PolarStore {
                     const size_t idx = rbase + bin;
                     if (re) re[idx] = vr;
                     if (im) im[idx] = vi;
-                    if (mag) mag[idx] = sqrtf(vr * vr + vi * vi);
-                    if (phs) phs[idx] = atan2f(vi, vr + 1e-7f);
+                    if (mag) mag[idx] = __builtin_amdgcn_sqrtf(vr * vr + vi * vi);      // v_sqrt_f32, 1 ulp
+                    if (phs) phs[idx] = st_atan2f(vi, vr + 1e-7f);
                 }
             }
         }
