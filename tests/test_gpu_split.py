@@ -63,3 +63,33 @@ def test_split_is_fp32_grade():
         assert e["f32x3"][q] <= 3.0 * e["f32"][q] + 5e-7, (q, e)      # same order (measured 0.6x .. 1.9x, tools/split_accuracy.py)
         assert e["f32x3"][q] < 2e-5, (q, e)
     assert not np.array_equal(out["f32"]["mag"], out["f32x3"]["mag"])      # really the other arithmetic
+
+
+def test_split_trains_like_fp32():
+    """End to end: 240 optimisation steps (B = 32, device-generated comp_4c windows, 1-cycle schedule) in f32 and in f32x3 from the same
+    weights and data end at the same loss (training is chaotic: fp32 against itself from weights perturbed by 1e-6 differs by a few
+    per cent at 1000 steps, tools/train_convergence.py / profiles/r02_train_convergence.txt)."""
+    import torch
+    from signaltrain_amd import _lib, nn_proc, audio, datasets, learningrate
+    from signaltrain_amd.engine import StepEngine
+    nn_proc._QUIET = True
+    dev = torch.device("cuda:0"); B, STEPS = 32, 240
+    torch.manual_seed(218); np.random.seed(218)
+    sd = {k: v.detach().clone() for k, v in nn_proc.st_model(scale_factor=1, shrink_factor=4, num_knobs=4).state_dict().items()}
+    ds = datasets.SynthAudioDataSet(8192, audio.Compressor_4c(), datapoints=STEPS * B, y_size=2048)
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    x, y, kn = ds.batch_device(STEPS * B, dev, generator=gen)
+    lrs, _ = learningrate.get_1cycle_schedule(lr_max=1e-3, n_data_points=STEPS * B, epochs=1, batch_size=B)
+    d = _lib.geometry(1, 4, 4, B)
+    tail = {}
+    for mode in ("f32", "f32x3"):
+        eng = StepEngine(d, dev, compute_dtype=mode); eng.load_state_dict(sd)
+        losses = torch.zeros(STEPS, device=dev)
+        for it in range(STEPS):
+            sl = slice(it * B, (it + 1) * B)
+            losses[it] = eng.train_step(x[sl], kn[sl], y[sl], float(lrs[max(it - 1, 0)]))[0]
+        torch.cuda.synchronize()
+        l = losses.cpu().numpy()
+        assert np.isfinite(l).all() and l[-60:].mean() < 0.5 * l[:10].mean(), (mode, l[:10].mean(), l[-60:].mean())     # it trains
+        tail[mode] = float(l[-60:].mean())
+    assert abs(tail["f32x3"] / tail["f32"] - 1.0) < 0.15, tail
