@@ -500,8 +500,8 @@ extern "C" int st_synthesis_dgrad(const st_dims* d, const float* dsyn, const flo
 }
 
 static int synthesis_wgrad_impl(const st_dims* d, const float* AA, const float* dsyn, bool padded, float* ws,
-                                float* gSr, float* gSi, float* norm_partial, void* stream)
-{
+                                float* gSr, float* gSi, float* norm_partial, void* stream, int* defer_slabs = nullptr)
+{   // defer_slabs: the caller sums the slabs itself (post_ae_kernel); receives the slab count
     const int KP = st_kp_of(d->F);
     const stg::RowMap ms = synth_live(d);
     const int R = ms.rows(d->B);
@@ -511,6 +511,7 @@ static int synthesis_wgrad_impl(const st_dims* d, const float* AA, const float* 
     if (padded) { stg::FramedTN<true> bl{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms}; ST_GEMM_WG(al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
     else { stg::FramedTN<false> bl{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms}; ST_GEMM_WG(al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
     ST_LAUNCHED("synthesis_wgrad");
+    if (defer_slabs) { *defer_slabs = ns; return ST_OK; }
     hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(2 * d->F), dim3(256), 0, st_stream(stream),
                        ws, ns, gSr, gSi, norm_partial, d->N, d->F, KP, 1, 0, (float*)nullptr);
     ST_LAUNCHED("synthesis_wgrad_reduce");
@@ -998,34 +999,40 @@ static int forward_impl(const st_dims* d, const Layout& L, const float* params, 
 // backward of everything behind d syn (workspace holds the forward state): autograd of train.py:138.
 // phase 1 = synthesis dgrad/wgrad + autoencoders + polar backward (fills grads[n_stft/2 ..));
 // phase 2 = analysis weight gradient (fills rows [0,F) of the first two tensors).
-static int backward_syn(const st_dims* d, const Layout& L, float* grads, WS& w, void* stream)
+static int backward_syn(const st_dims* d, const Layout& L, float* grads, WS& w, void* stream, int* defer_slabs = nullptr)
 {
     if (use_planes(d) && g_pl_dgrad) ST_TRY(synthesis_dgrad_planes(d, w, stream)); else
     ST_TRY(synthesis_dgrad_impl(d, w.dsyn, true, w.Sfold, w.dAA, stream));
-    return synthesis_wgrad_impl(d, w.AA, w.dsyn, true, w.wg, grads + L.offs[2], grads + L.offs[3], w.norm_s, stream);
+    return synthesis_wgrad_impl(d, w.AA, w.dsyn, true, w.wg, grads + L.offs[2], grads + L.offs[3], w.norm_s, stream, defer_slabs);
 }
 static int backward_ae(const st_dims* d, const Layout& L, const float* params, float* grads,
-                       const float* knobs, const float* g_mag_hat, const float* g_mag, float reg_coef, WS& w, void* stream)
-{
+                       const float* knobs, const float* g_mag_hat, const float* g_mag, float reg_coef, WS& w, void* stream, int syn_slabs = 0)
+{   // syn_slabs > 0: the synthesis weight-gradient slabs in w.wg are still to be summed (done by post_ae_kernel)
     const float* ae_m = params + L.offs[4]; const float* ae_p = params + L.offs[22];
     bool deferred = true;
     ST_TRY(ae_bwd_impl(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.dAA, g_mag_hat, reg_coef, w.dmag, w.dphs,
                        w.aews, grads + L.offs[4], grads + L.offs[22], true, stream, &deferred));      // the forward left its AE state in w.aews
-    if (!deferred) return st_polar_bwd(d, w.re, w.im, w.dmag, w.dphs, g_mag, w.dG, stream);
+    if (!deferred) {
+        ST_REQ(syn_slabs == 0, "internal: deferred synthesis slabs on a path without post_ae_kernel");
+        return st_polar_bwd(d, w.re, w.im, w.dmag, w.dphs, g_mag, w.dG, stream);
+    }
     stm::PostAeArgs a;
     a.ws = w.aews + 2 * ae_h4_floats(d); a.nparts = ae_use_split(d) ? ae_split_grid(d) : ae_bwd_grid(d); a.PG = L.PG; a.g_m = grads + L.offs[4]; a.g_p = grads + L.offs[22];
     a.n_red_x = (L.PG + 63) / 64; a.n_red = 2 * a.n_red_x;
     a.re = w.re; a.im = w.im; a.dmag = w.dmag; a.dphs = w.dphs; a.g_mag = g_mag; a.dG = w.dG; a.F = d->F; a.KP = L.KP;
     a.gx = (L.KP / 2 + 255) / 256; a.sat = gemm_ht(d->prec) == 2 ? 65504.0f : 0.0f;
-    hipLaunchKernelGGL(stm::post_ae_kernel, dim3(a.n_red + a.gx * d->B * d->T), dim3(256), 0, st_stream(stream), a);
+    a.n_polar = a.gx * d->B * d->T;
+    a.wg = w.wg; a.wg_nz = syn_slabs; a.gSr = grads + L.offs[2]; a.gSi = grads + L.offs[3]; a.norm_s = w.norm_s; a.N = d->N;
+    hipLaunchKernelGGL(stm::post_ae_kernel, dim3(a.n_red + a.n_polar + (syn_slabs > 0 ? 2 * d->F : 0)), dim3(256), 0, st_stream(stream), a);
     ST_LAUNCHED("post_ae");
     return ST_OK;
 }
 static int backward_p1(const st_dims* d, const Layout& L, const float* params, float* grads,
                        const float* knobs, const float* g_mag_hat, const float* g_mag, float reg_coef, WS& w, void* stream)
 {
-    ST_TRY(backward_syn(d, L, grads, w, stream));
-    return backward_ae(d, L, params, grads, knobs, g_mag_hat, g_mag, reg_coef, w, stream);
+    int syn_slabs = 0;
+    ST_TRY(backward_syn(d, L, grads, w, stream, ae_is_wide(d) ? nullptr : &syn_slabs));      // fused geometries: post_ae_kernel also sums the synthesis slabs
+    return backward_ae(d, L, params, grads, knobs, g_mag_hat, g_mag, reg_coef, w, stream, syn_slabs);
 }
 static int backward_p2(const st_dims* d, const Layout& L, float* grads, const float* x, WS& w, void* stream, float* stage = nullptr)
 {

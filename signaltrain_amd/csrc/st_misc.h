@@ -222,12 +222,11 @@ polar_bwd_kernel(const float* __restrict__ re, const float* __restrict__ im, con
 // ---------------------------------------------------------------- split-K slab reduce (+ unfold, + |g| sums)
 // ws[nz][KP][N] -> gradient tensors [N,N].  mode 0 (analysis): row k<F -> gRe[k], row half+k -> gIm[k].
 // mode 1 (synthesis): additionally mirror to row N-k with sign +1 (real) / -1 (imag)  (SURVEY.md 8a' "unfold").
-__global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(const float* __restrict__ ws, int nz, float* __restrict__ gRe, float* __restrict__ gIm,
-                    float* __restrict__ norm_partial, int N, int F, int KP, int mode, int row0, float* __restrict__ stage)
+__device__ __forceinline__ void
+wgrad_reduce_block(const float* __restrict__ ws, int nz, float* __restrict__ gRe, float* __restrict__ gIm,
+                   float* __restrict__ norm_partial, int N, int F, int KP, int mode, const int row, float* __restrict__ stage)
 {
-    __shared__ float red[4];
-    const int row = blockIdx.x + row0;                // 0 .. 2F-1 : [0,F) real rows, [F,2F) imag rows (row0: imag half only)
+    __shared__ float red[4];                          // row: 0 .. 2F-1 : [0,F) real rows, [F,2F) imag rows
     const bool is_im = row >= F;
     const int k = is_im ? row - F : row;
     const int src = is_im ? KP / 2 + k : k;
@@ -253,6 +252,12 @@ wgrad_reduce_kernel(const float* __restrict__ ws, int nz, float* __restrict__ gR
     }
     const float tot = block_sum<4>(na, red);
     if (threadIdx.x == 0) norm_partial[row] = tot;
+}
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ ws, int nz, float* __restrict__ gRe, float* __restrict__ gIm,
+                    float* __restrict__ norm_partial, int N, int F, int KP, int mode, int row0, float* __restrict__ stage)
+{
+    wgrad_reduce_block(ws, nz, gRe, gIm, norm_partial, N, F, KP, mode, blockIdx.x + row0, stage);       // row0: imag half only
 }
 
 // L1 norm partials of an arbitrary flat range (data-parallel path: norm of the *reduced* gradient).
@@ -304,13 +309,17 @@ ae_grad_reduce_kernel(const float* __restrict__ ws, int nparts, int PG, float* _
 struct PostAeArgs {
     const float* ws; int nparts, PG; float* g_m; float* g_p; int n_red_x, n_red;
     const float* re; const float* im; const float* dmag; const float* dphs; const float* g_mag; float* dG; int F, KP, gx; float sat;
+    // third role (fused step): the split-K slabs of the synthesis weight gradient, written before the autoencoder backward, are summed,
+    // un-folded and normed here instead of in a launch of their own
+    int n_polar; const float* wg; int wg_nz; float* gSr; float* gSi; float* norm_s; int N;
 };
 __global__ void __launch_bounds__(256)
 post_ae_kernel(const PostAeArgs a)
 {
     const int blk = blockIdx.x;
     if (blk < a.n_red) { const int ae = blk / a.n_red_x; ae_grad_reduce_block(a.ws, a.nparts, a.PG, a.g_m, a.g_p, blk - ae * a.n_red_x, ae); }
-    else { const int q = blk - a.n_red, r = q / a.gx; polar_bwd_block(a.re, a.im, a.dmag, a.dphs, a.g_mag, a.dG, a.F, a.KP, a.sat, q - r * a.gx, r); }
+    else if (blk < a.n_red + a.n_polar) { const int q = blk - a.n_red, r = q / a.gx; polar_bwd_block(a.re, a.im, a.dmag, a.dphs, a.g_mag, a.dG, a.F, a.KP, a.sat, q - r * a.gx, r); }
+    else wgrad_reduce_block(a.wg, a.wg_nz, a.gSr, a.gSi, a.norm_s, a.N, a.F, a.KP, 1, blk - a.n_red - a.n_polar, nullptr);
 }
 
 // ---------------------------------------------------------------- scalars
