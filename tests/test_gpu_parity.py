@@ -37,6 +37,14 @@ def test_legacy_large_fft_scheme():
     _assert_ok(G.run_fused(B=3, seed=5, K=3, steps=2, scale=2, scheme="legacy"))
 
 
+def test_legacy_large_fft_scheme_scale8_fp16():
+    """BASELINE configs[4] read as "65536-sample window, large front-end FFT" = the legacy scheme at scale 8 in fp16 mixed precision
+    (loss scale, clip over all parameters): two fused steps against the oracle with the same roundings."""
+    from tests import gpu_checks as G
+    with G.mixed_mode(2, half="f16", tol_scale=G.mixed_mode.FUSED_TOL_F16[2]):
+        _assert_ok(G.run_fused(B=2, seed=5, K=4, steps=2, scale=8, scheme="legacy"))
+
+
 def test_legacy_large_fft_scheme_scale8():
     """SURVEY 8(f)-4 at the size it names: scale 8 of the legacy scheme = ft 8192, hop 3072, F 4097, T 25, OT 9 -- four
     8192 x 8192 bases (268 M parameters, 1.07 GB; the gradient / moment / slab buffers follow).  Same kernels, every per-op
