@@ -120,6 +120,7 @@ def main():
     if world > 1 or args.force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         if dp_backend == "lib":
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")          # one node: gloo would otherwise look the host name up, which need not resolve on a GPU box
             dist.init_process_group("gloo", rank=rank, world_size=world)      # bootstrap + timing fence only; gradients move on the library's RCCL communicator
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)

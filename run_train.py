@@ -42,6 +42,7 @@ if __name__ == "__main__":
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # bootstrap channel only (RCCL unique id, logging): the gradient exchange runs on the library's own RCCL communicator
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")              # one node: do not depend on the host name resolving
         dist.init_process_group("gloo")
     from signaltrain_amd import audio, train
     effect = audio.FileEffect(args.path, sr=args.sr) if args.effect == 'files' else (audio.Compressor_4c() if args.effect == 'comp_4c' else audio.Compressor_4c_Large())

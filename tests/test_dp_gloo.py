@@ -112,6 +112,7 @@ def _case():
 
 def _worker(rank, world, port, q, schedule="two_bucket"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from signaltrain_amd.dp import DataParallel
     geo, P, X, Y, KN = _case()
