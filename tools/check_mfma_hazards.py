@@ -97,8 +97,8 @@ def scan_kernel(name, lines):
 def main():
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "st.s")
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-               "-S", "--cuda-device-only", "-o", out, SRC]
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1",      # the Makefile's code generation flags
+               "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", out, SRC]
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
         text = open(out).read().splitlines()
     kernels, cur, name = [], None, None
