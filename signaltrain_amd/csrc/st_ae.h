@@ -85,7 +85,20 @@ __device__ __forceinline__ void ae_params_issue(AEParamRegs<NT>& r, const float*
         r.bv[l] = ae[go.b[l] + (tid < out[l] ? tid : 0)];
     }
 }
-template <int NT>
+// BF != 0 (16-bit operand kernels): the weight images are written ALREADY ROUNDED to bfloat16 / float16, packed into the first half of
+// each layer's region (same element indexing, 2-byte elements): a fragment is then one 8-byte read and needs no conversion at its use
+// (the 16-bit backward kernel spent 144 of its 285 conversions per row group on weight fragments).  Biases stay fp32.
+template <int BF> __device__ __forceinline__ unsigned short st_half_bits(const float v)
+{
+    if constexpr (BF == 2) { union { _Float16 h; unsigned short u; } p; p.h = (_Float16)v; return p.u; }
+    else { union { __bf16 h; unsigned short u; } p; p.h = (__bf16)v; return p.u; }
+}
+template <int BF> __device__ __forceinline__ float st_half_to_float(const unsigned short b)
+{
+    if constexpr (BF == 2) { union { unsigned short u; _Float16 h; } p; p.u = b; return (float)p.h; }
+    else return __uint_as_float((unsigned)b << 16);
+}
+template <int NT, int BF = 0>
 __device__ __forceinline__ void ae_params_scatter(float* lds, const AEParamRegs<NT>& r, const int T, const int OT, const int K,
                                                   const int tid, const int l0, const int l1, const bool dgrad_images)
 {
@@ -105,15 +118,21 @@ __device__ __forceinline__ void ae_params_scatter(float* lds, const AEParamRegs<
             const int e = tid + u * NT;
             if (e < n) {
                 const int o = e / IN, i = e - o * IN;
+                if constexpr (BF) {
+                    const unsigned short hb = st_half_bits<BF>(r.v[l][u]);
+                    reinterpret_cast<unsigned short*>(lds + ao[l])[(((i >> 2) * OP + o) << 2) + (i & 3)] = hb;
+                    if (dgrad_images) reinterpret_cast<unsigned short*>(lds + gi[l])[(((o >> 2) * IP + i) << 2) + (o & 3)] = hb;
+                } else {
                 lds[ao[l] + (((i >> 2) * OP + o) << 2) + (i & 3)] = r.v[l][u];
                 if (dgrad_images) lds[gi[l] + (((o >> 2) * IP + i) << 2) + (o & 3)] = r.v[l][u];
+                }
             }
         }
         if (on && tid < out[l]) lds[bo[l] + tid] = r.bv[l];
     }
 }
 // One autoencoder (backward kernel: forward + dgrad images) ...
-template <int NT>
+template <int NT, int BF = 0>
 __device__ inline void ae_load_lds(float* lds, const float* __restrict__ ae, const AEOffsets& go, const int T, const int OT, const int K,
                                    const int tid, const int l0, const int l1, const bool dgrad_images)
 {
@@ -122,10 +141,10 @@ __device__ inline void ae_load_lds(float* lds, const float* __restrict__ ae, con
     const int total = dgrad_images ? CL::BWD_TOTAL : CL::FWD_TOTAL;
     for (int e = tid; e < total; e += NT) lds[e] = 0.f;
     __syncthreads();
-    ae_params_scatter<NT>(lds, r, T, OT, K, tid, l0, l1, dgrad_images);
+    ae_params_scatter<NT, BF>(lds, r, T, OT, K, tid, l0, l1, dgrad_images);
 }
 // ... or both (forward kernels: two forward images CL::FWD_TOTAL floats apart), still one round trip.
-template <int NT>
+template <int NT, int BF = 0>
 __device__ inline void ae_load_lds2(float* lds, const float* __restrict__ ae_m, const float* __restrict__ ae_p, const AEOffsets& go,
                                     const int T, const int OT, const int K, const int tid, const int l0, const int l1)
 {
@@ -134,8 +153,8 @@ __device__ inline void ae_load_lds2(float* lds, const float* __restrict__ ae_m, 
     ae_params_issue<NT>(rp, ae_p, go, T, OT, K, tid, l0, l1);
     for (int e = tid; e < 2 * CL::FWD_TOTAL; e += NT) lds[e] = 0.f;
     __syncthreads();
-    ae_params_scatter<NT>(lds, rm, T, OT, K, tid, l0, l1, false);
-    ae_params_scatter<NT>(lds + CL::FWD_TOTAL, rp, T, OT, K, tid, l0, l1, false);
+    ae_params_scatter<NT, BF>(lds, rm, T, OT, K, tid, l0, l1, false);
+    ae_params_scatter<NT, BF>(lds + CL::FWD_TOTAL, rp, T, OT, K, tid, l0, l1, false);
 }
 
 #define ST_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -199,16 +218,32 @@ __device__ __forceinline__ float round_h(const float v)
 #define bf16_rne(v) round_h<BF>(v)
 
 // One 16x16 tile of A operands (k-steps r = 0..3) from a forward image: W[o = 16 ot + c][i = 16 it + 4 g + r].
-template <int OUTP>
+// BF != 0: the image holds 16-bit values (ae_params_scatter); the four of a fragment arrive as ONE 8-byte read in the low half of the
+// returned vector (frag_bits() hands them to the MFMA, the upper half is never touched).
+template <int BF>
+__device__ __forceinline__ f32x4 frag_read(const float* img, const int idx)
+{
+    if constexpr (BF) {
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const f32x2_t lo = *reinterpret_cast<const f32x2_t*>(reinterpret_cast<const unsigned short*>(img) + idx);
+        return __builtin_shufflevector(lo, lo, 0, 1, -1, -1);
+    } else return *reinterpret_cast<const f32x4*>(img + idx);
+}
+__device__ __forceinline__ s16x4 frag_bits(const f32x4 v)
+{
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    union { f32x2_t f; s16x4 s; } p; p.f = __builtin_shufflevector(v, v, 0, 1); return p.s;
+}
+template <int OUTP, int BF = 0>
 __device__ __forceinline__ f32x4 frag_fwd(const float* img, const int ot, const int it, const int g, const int c)
 {
-    return *reinterpret_cast<const f32x4*>(img + (((4 * it + g) * OUTP + 16 * ot + c) << 2));
+    return frag_read<BF>(img, ((4 * it + g) * OUTP + 16 * ot + c) << 2);
 }
 // ... from a dgrad image: W[o = 16 ot + 4 g + r][i = 16 it + c].
-template <int INP>
+template <int INP, int BF = 0>
 __device__ __forceinline__ f32x4 frag_dgrad(const float* img, const int ot, const int it, const int g, const int c)
 {
-    return *reinterpret_cast<const f32x4*>(img + (((4 * ot + g) * INP + 16 * it + c) << 2));
+    return frag_read<BF>(img, ((4 * ot + g) * INP + 16 * it + c) << 2);
 }
 
 // Hidden layer for NC interleaved chains: hout[ch][ot] = ELU(W[ch] * hin[ch] + bias[ch]), weights fetched just in time
@@ -233,10 +268,10 @@ __device__ __forceinline__ void layer_fwd(const float* const (&W)[NC], const flo
         for (int it = 0; it < ITL; ++it) {
             f32x4 w[NC];
 #pragma unroll
-            for (int ch = 0; ch < NC; ++ch) w[ch] = frag_fwd<OUTP>(W[ch], ot, it, g, c);
+            for (int ch = 0; ch < NC; ++ch) w[ch] = frag_fwd<OUTP, BF>(W[ch], ot, it, g, c);
             if constexpr (BF) {
 #pragma unroll
-                for (int ch = 0; ch < NC; ++ch) acc[ch] = ST_MFMA16B(pack_bf16x4(w[ch]), ph[ch][it], acc[ch]);
+                for (int ch = 0; ch < NC; ++ch) acc[ch] = ST_MFMA16B(frag_bits(w[ch]), ph[ch][it], acc[ch]);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -257,10 +292,10 @@ __device__ __forceinline__ void layer5_fwd(const float* const (&lw)[NC], const f
 {
     f32x4 acc[NC], w[NC];
 #pragma unroll
-    for (int ch = 0; ch < NC; ++ch) { acc[ch] = *reinterpret_cast<const f32x4*>(lw[ch] + CL::B4 + 4 * g); w[ch] = frag_fwd<CL::O4>(lw[ch] + CL::A4, 0, 0, g, c); }
+    for (int ch = 0; ch < NC; ++ch) { acc[ch] = *reinterpret_cast<const f32x4*>(lw[ch] + CL::B4 + 4 * g); w[ch] = frag_fwd<CL::O4, BF>(lw[ch] + CL::A4, 0, 0, g, c); }
     if constexpr (BF) {
 #pragma unroll
-        for (int ch = 0; ch < NC; ++ch) acc[ch] = ST_MFMA16B(pack_bf16x4(w[ch]), pack_bf16x4(h4[ch][0]), acc[ch]);
+        for (int ch = 0; ch < NC; ++ch) acc[ch] = ST_MFMA16B(frag_bits(w[ch]), pack_bf16x4(h4[ch][0]), acc[ch]);
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -272,10 +307,12 @@ __device__ __forceinline__ void layer5_fwd(const float* const (&lw)[NC], const f
         if (q < KQ) {
 #pragma unroll
             for (int ch = 0; ch < NC; ++ch) {
-                const float wk = lw[ch][CL::A4 + (((4 + q) * CL::O4 + c) << 2) + g];                  // W5[o = c][i = 16 + 4q + g]
-                // BF: the knob block keeps its own k-step order on the fp32 MFMA, with both operands rounded to bf16 first
-                // (products of bf16 values are exact in fp32, so this IS the bf16 arithmetic)
-                acc[ch] = ST_MFMA16(BF ? bf16_rne(wk) : wk, BF ? bf16_rne(kn[q]) : kn[q], acc[ch]);
+                // W5[o = c][i = 16 + 4q + g].  BF: the knob block keeps its own k-step order on the fp32 MFMA, with both operands rounded
+                // to 16 bits first (the image already is; products of such values are exact in fp32, so this IS the 16-bit arithmetic)
+                float wk;
+                if constexpr (BF) wk = st_half_to_float<BF>(reinterpret_cast<const unsigned short*>(lw[ch] + CL::A4)[(((4 + q) * CL::O4 + c) << 2) + g]);
+                else wk = lw[ch][CL::A4 + (((4 + q) * CL::O4 + c) << 2) + g];
+                acc[ch] = ST_MFMA16(wk, BF ? bf16_rne(kn[q]) : kn[q], acc[ch]);
             }
         }
 #pragma unroll
@@ -344,7 +381,7 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
     const float* const lw[2] = {lds, lds + CL::FWD_TOTAL};
-    ae_load_lds2<NW * 64>(lds, ae_m, ae_p, go, T, OT, K, tid, 0, NL);
+    ae_load_lds2<NW * 64, BF>(lds, ae_m, ae_p, go, T, OT, K, tid, 0, NL);
     __syncthreads();
 
     const int FP = KP / 2, gpw = FP / 16;              // groups per window
@@ -430,7 +467,7 @@ ae_inner_fwd_kernel(const float* __restrict__ H1m, const float* __restrict__ H1p
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
     const float* const lw[2] = {lds, lds + CL::FWD_TOTAL};
-    ae_load_lds2<NW * 64>(lds, ae_m, ae_p, go, 16, 16, K, tid, 1, 8);
+    ae_load_lds2<NW * 64, BF>(lds, ae_m, ae_p, go, 16, 16, K, tid, 1, 8);
     __syncthreads();
     const int FP = KP / 2, gpw = FP / 16, ngroups = B * gpw;
     const size_t R = (size_t)B * FP;
@@ -498,21 +535,21 @@ __device__ unsigned long long g_ae_stage_cycles[32];
 // the MFMA (one s_waitcnt per MFMA: with one wave per SIMD the kernel was LDS-latency-bound).  These helpers burst-load
 // every fragment of a layer stage into a register array; the caller places a scheduling fence between the burst and
 // the MFMAs, so a stage pays one LDS round trip instead of one per MFMA.
-template <int OTL, int ITL, int OUTP>
+template <int OTL, int ITL, int OUTP, int BF = 0>
 __device__ __forceinline__ void frags_fwd(f32x4 (&fr)[OTL * ITL], const float* img, const int g, const int c)
 {
 #pragma unroll
     for (int ot = 0; ot < OTL; ++ot)
 #pragma unroll
-        for (int it = 0; it < ITL; ++it) fr[ot * ITL + it] = frag_fwd<OUTP>(img, ot, it, g, c);
+        for (int it = 0; it < ITL; ++it) fr[ot * ITL + it] = frag_fwd<OUTP, BF>(img, ot, it, g, c);
 }
-template <int OTL, int ITL, int INP>
+template <int OTL, int ITL, int INP, int BF = 0>
 __device__ __forceinline__ void frags_dgrad(f32x4 (&fr)[ITL * OTL], const float* img, const int g, const int c)
 {
 #pragma unroll
     for (int it = 0; it < ITL; ++it)
 #pragma unroll
-        for (int ot = 0; ot < OTL; ++ot) fr[it * OTL + ot] = frag_dgrad<INP>(img, ot, it, g, c);
+        for (int ot = 0; ot < OTL; ++ot) fr[it * OTL + ot] = frag_dgrad<INP, BF>(img, ot, it, g, c);
 }
 #define ST_FENCE() __builtin_amdgcn_sched_barrier(0)
 
@@ -533,7 +570,7 @@ __device__ __forceinline__ void fwdD_fr(const f32x4 (&fr)[OTL * ITL], const floa
 #if ST_AE_ABLATE & 32
             acc[0] += fr[ot * ITL + it][0] * hin[it][0];
 #else
-            if constexpr (BF) acc = ST_MFMA16B(pack_bf16x4(fr[ot * ITL + it]), ph[it], acc);
+            if constexpr (BF) acc = ST_MFMA16B(frag_bits(fr[ot * ITL + it]), ph[it], acc);
             else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc = ST_MFMA16(fr[ot * ITL + it][r], hin[it][r], acc);
@@ -581,7 +618,7 @@ __device__ __forceinline__ void dgradD_fr(const f32x4 (&fr)[ITL * OTL], const f3
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ot = 0; ot < OTL; ++ot) {
-            if constexpr (BF) acc = ST_MFMA16B(pack_bf16x4(fr[it * OTL + ot]), pd[ot], acc);
+            if constexpr (BF) acc = ST_MFMA16B(frag_bits(fr[it * OTL + ot]), pd[ot], acc);
             else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc = ST_MFMA16(fr[it * OTL + ot][r], da[ot][r], acc);
@@ -694,7 +731,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     float* Ts = Ys + 16 * SP;
     float* XH = Ts + 16 * SP;                          // transposes of activations
     float* XD = XH + 4 * 320;                          // transposes of activation gradients
-    ae_load_lds<NW * 64>(lw, ae ? ae_p : ae_m, go, INNER ? 16 : T, INNER ? 16 : OT, K, tid, INNER ? 1 : 0, INNER ? 8 : NL, true);
+    ae_load_lds<NW * 64, BF>(lw, ae ? ae_p : ae_m, go, INNER ? 16 : T, INNER ? 16 : OT, K, tid, INNER ? 1 : 0, INNER ? 8 : NL, true);
     __syncthreads();
 
     const float* vin = ae ? phs : mag;
@@ -830,10 +867,10 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         if constexpr (INNER) {
 #pragma unroll
             for (int ot = 0; ot < 4; ++ot) h1[ot] = h1in[ot];
-            frags_fwd<2, 4, CL::O1>(fr2, lw + CL::A1, g, c);
+            frags_fwd<2, 4, CL::O1, BF>(fr2, lw + CL::A1, g, c);
         } else {
-            f32x4 fr1[4 * 2]; frags_fwd<4, 2, CL::O0>(fr1, lw + CL::A0, g, c);
-            frags_fwd<2, 4, CL::O1>(fr2, lw + CL::A1, g, c);
+            f32x4 fr1[4 * 2]; frags_fwd<4, 2, CL::O0, BF>(fr1, lw + CL::A0, g, c);
+            frags_fwd<2, 4, CL::O1, BF>(fr2, lw + CL::A1, g, c);
 #pragma unroll
             for (int it = 0; it < 2; ++it)
 #pragma unroll
@@ -842,21 +879,21 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             fwdD_fr<4, 2, BF>(fr1, lw + CL::B0, vr, h1, g);
         }
         ST_T(1);
-        f32x4 fr3[1 * 2]; frags_fwd<1, 2, CL::O2>(fr3, lw + CL::A2, g, c); ST_FENCE(); fwdD_fr<2, 4, BF>(fr2, lw + CL::B1, h1, h2, g);
+        f32x4 fr3[1 * 2]; frags_fwd<1, 2, CL::O2, BF>(fr3, lw + CL::A2, g, c); ST_FENCE(); fwdD_fr<2, 4, BF>(fr2, lw + CL::B1, h1, h2, g);
         ST_T(2);
-        f32x4 fr4[1 * 1]; frags_fwd<1, 1, CL::O3>(fr4, lw + CL::A3, g, c); ST_FENCE(); fwdD_fr<1, 2, BF>(fr3, lw + CL::B2, h2, h3, g);
-        f32x4 fr5[1 * 2]; frags_fwd<1, 2, CL::O4>(fr5, lw + CL::A4, g, c); ST_FENCE(); fwdD_fr<1, 1, BF>(fr4, lw + CL::B3, h3, h4, g);
-        f32x4 fr6[1 * 1]; frags_fwd<1, 1, CL::O5>(fr6, lw + CL::A5, g, c); ST_FENCE();
+        f32x4 fr4[1 * 1]; frags_fwd<1, 1, CL::O3, BF>(fr4, lw + CL::A3, g, c); ST_FENCE(); fwdD_fr<1, 2, BF>(fr3, lw + CL::B2, h2, h3, g);
+        f32x4 fr5[1 * 2]; frags_fwd<1, 2, CL::O4, BF>(fr5, lw + CL::A4, g, c); ST_FENCE(); fwdD_fr<1, 1, BF>(fr4, lw + CL::B3, h3, h4, g);
+        f32x4 fr6[1 * 1]; frags_fwd<1, 1, CL::O5, BF>(fr6, lw + CL::A5, g, c); ST_FENCE();
         {
             const f32x4 hk[2] = {h4[0], kn};                                 // knob features 16 + 4g + r
             fwdD_fr<1, 2, BF>(fr5, lw + CL::B4, hk, h5, g);
         }
         ST_T(3);
-        f32x4 fr7[2 * 1]; frags_fwd<2, 1, CL::O6>(fr7, lw + CL::A6, g, c); ST_FENCE(); fwdD_fr<1, 1, BF>(fr6, lw + CL::B5, h5, h6, g);
-        f32x4 fr8[4 * 2]; frags_fwd<4, 2, CL::O7>(fr8, lw + CL::A7, g, c); ST_FENCE(); fwdD_fr<2, 1, BF>(fr7, lw + CL::B6, h6, h7, g);
+        f32x4 fr7[2 * 1]; frags_fwd<2, 1, CL::O6, BF>(fr7, lw + CL::A6, g, c); ST_FENCE(); fwdD_fr<1, 1, BF>(fr6, lw + CL::B5, h5, h6, g);
+        f32x4 fr8[4 * 2]; frags_fwd<4, 2, CL::O7, BF>(fr8, lw + CL::A7, g, c); ST_FENCE(); fwdD_fr<2, 1, BF>(fr7, lw + CL::B6, h6, h7, g);
         ST_T(4);
         f32x4 fr9[1 * 4];
-        if constexpr (!INNER) frags_fwd<1, 4, CL::O8>(fr9, lw + CL::A8, g, c);
+        if constexpr (!INNER) frags_fwd<1, 4, CL::O8, BF>(fr9, lw + CL::A8, g, c);
         ST_FENCE(); fwdD_fr<4, 2, BF>(fr8, lw + CL::B7, h7, h8, g);
         ST_T(5);
         // ---- d out (D layout: t' = 4g + r), part A: everything that does not need e9 -- polar->rect backward of nn_proc.py:322-326 and
@@ -932,7 +969,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         ST_PIPE(BF ? O_ * I_ : O_ * I_ * 4);
         f32x4 hT8[4], da8[4], daT8[4], fd8[2 * 4];
         if constexpr (INNER) {                     // dH8 arrives from the layer-9 data-gradient GEMM; h8^T is still needed for ELU' and dW8
-            frags_dgrad<4, 2, CL::I7>(fd8, lw + CL::G7, g, c);
+            frags_dgrad<4, 2, CL::I7, BF>(fd8, lw + CL::G7, g, c);
             to_T<4>(XH, h8, hT8, g, c);
 #pragma unroll
             for (int ot = 0; ot < 4; ++ot) da8[ot] = dh8[ot];
@@ -941,40 +978,40 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         } else {
             // layer 9 (64 -> OT): d a9 transposed through the wave's scratch
             f32x4 daT9[1], fd9[4 * 1];
-            frags_dgrad<1, 4, CL::I8>(fd9, lw + CL::G8, g, c);
+            frags_dgrad<1, 4, CL::I8, BF>(fd9, lw + CL::G8, g, c);
             daT9[0] = *reinterpret_cast<const f32x4*>(Ys + c * SP + 4 * g);
             ST_T(7);
-            ST_BWD_STAGE(1, 4, fd9, da9, daT9, h8, hT8, da8, daT8, rW9, rb9, (frags_dgrad<4, 2, CL::I7>(fd8, lw + CL::G7, g, c)))
+            ST_BWD_STAGE(1, 4, fd9, da9, daT9, h8, hT8, da8, daT8, rW9, rb9, (frags_dgrad<4, 2, CL::I7, BF>(fd8, lw + CL::G7, g, c)))
         }
         ST_T(8);
         // layer 8 (32 -> 64)
         f32x4 hT7[2], da7[2], daT7[2], fd7[1 * 2];
-        ST_BWD_STAGE(4, 2, fd8, da8, daT8, h7, hT7, da7, daT7, rW8, rb8, (frags_dgrad<2, 1, CL::I6>(fd7, lw + CL::G6, g, c)))
+        ST_BWD_STAGE(4, 2, fd8, da8, daT8, h7, hT7, da7, daT7, rW8, rb8, (frags_dgrad<2, 1, CL::I6, BF>(fd7, lw + CL::G6, g, c)))
         ST_T(9);
         // layer 7 (16 -> 32)
         f32x4 hT6[1], da6[1], daT6[1], fd6[1];
-        ST_BWD_STAGE(2, 1, fd7, da7, daT7, h6, hT6, da6, daT6, rW7, rb7, (frags_dgrad<1, 1, CL::I5>(fd6, lw + CL::G5, g, c)))
+        ST_BWD_STAGE(2, 1, fd7, da7, daT7, h6, hT6, da6, daT6, rW7, rb7, (frags_dgrad<1, 1, CL::I5, BF>(fd6, lw + CL::G5, g, c)))
         ST_T(10);
         // layer 6 (16 -> 16)
         f32x4 hT5[1], da5[1], daT5[1], fd5[1];
-        ST_BWD_STAGE(1, 1, fd6, da6, daT6, h5, hT5, da5, daT5, rW6, rb6, (frags_dgrad<1, 1, CL::I4>(fd5, lw + CL::G4, g, c)))
+        ST_BWD_STAGE(1, 1, fd6, da6, daT6, h5, hT5, da5, daT5, rW6, rb6, (frags_dgrad<1, 1, CL::I4, BF>(fd5, lw + CL::G4, g, c)))
         // layer 5 ([h4 ; knobs] -> 16): weight gradient over both input tiles, data gradient to h4 only
         f32x4 hT4[1], hT4k[2], da4[1], daT4[1], fd4[1];
         {
             to_T<1>(XH, h4, hT4, g, c); ST_FENCE();
             dgradD_fr<1, 1, BF>(fd5, da5, da4); mul_elu_grad<1>(da4, h4);
-            to_T<1>(XD, da4, daT4, g, c); frags_dgrad<1, 1, CL::I3>(fd4, lw + CL::G3, g, c); ST_FENCE();
+            to_T<1>(XD, da4, daT4, g, c); frags_dgrad<1, 1, CL::I3, BF>(fd4, lw + CL::G3, g, c); ST_FENCE();
             hT4k[0] = hT4[0];
             hT4k[1] = (f32x4){knT, knT, knT, knT};                   // features 16 + c = knob c, every row
             wgrad_reg<1, 2, BF>(rW5, rb5, daT5, hT4k);
         }
         // layer 4 (16 -> 16)
         f32x4 hT3[1], da3[1], daT3[1], fd3[2 * 1];
-        ST_BWD_STAGE(1, 1, fd4, da4, daT4, h3, hT3, da3, daT3, rW4, rb4, (frags_dgrad<1, 2, CL::I2>(fd3, lw + CL::G2, g, c)))
+        ST_BWD_STAGE(1, 1, fd4, da4, daT4, h3, hT3, da3, daT3, rW4, rb4, (frags_dgrad<1, 2, CL::I2, BF>(fd3, lw + CL::G2, g, c)))
         ST_T(11);
         // layer 3 (32 -> 16)
         f32x4 hT2[2], da2[2], daT2[2], fd2[4 * 2];
-        ST_BWD_STAGE(1, 2, fd3, da3, daT3, h2, hT2, da2, daT2, rW3, rb3, (frags_dgrad<2, 4, CL::I1>(fd2, lw + CL::G1, g, c)))
+        ST_BWD_STAGE(1, 2, fd3, da3, daT3, h2, hT2, da2, daT2, rW3, rb3, (frags_dgrad<2, 4, CL::I1, BF>(fd2, lw + CL::G1, g, c)))
         ST_T(12);
         // layer 2 (64 -> 32)
         f32x4 hT1[4], da1[4], daT1[4], fd1[2 * 4];
@@ -989,7 +1026,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             ST_FENCE();
             wgrad_reg<2, 4, BF>(rW2, rb2, daT2, hT1);
         } else {
-            ST_BWD_STAGE(2, 4, fd2, da2, daT2, h1, hT1, da1, daT1, rW2, rb2, (frags_dgrad<4, 2, CL::I0>(fd1, lw + CL::G0, g, c)))
+            ST_BWD_STAGE(2, 4, fd2, da2, daT2, h1, hT1, da1, daT1, rW2, rb2, (frags_dgrad<4, 2, CL::I0, BF>(fd1, lw + CL::G0, g, c)))
         }
         ST_T(13);
         // layer 1 (T -> 64): input rows transposed through the wave's scratch
