@@ -167,6 +167,8 @@ namespace sta { extern __device__ unsigned long long g_ae_stage_cycles[32]; }
 // Diagnostics: read (and clear) the per-stage s_memtime accumulators of ae_bwd_kernel (st_set_debug(256)).
 extern "C" int st_debug_read_stage_cycles(unsigned long long* out32);
 static int g_ae_split = 1;   // autoencoder backward of the fused geometries: 1 = two kernels at two waves per SIMD (st_ae_split.h), 0 = the single kernel
+static int g_pl_bf16 = 0;    // ST_PREC_BF16*: analysis / frames GEMMs on the plane kernel with ONE plane (bf16 copies of the bases, k-chunk-major).  MEASURED SLOWER at B = 256
+                             // (analysis 53.8 vs 49.8 us + 12 us for the copies): three MFMAs per 16-deep k-tile and barrier; needs a 64-deep tile   (st_set_tuning(9400 + n))
 static int g_wg_split = 0;   // ST_PREC_F32X3: weight-gradient GEMMs on the in-kernel three-plane split instead of the fp32 MFMA kernel (see ST_GEMM_WG)   (st_set_tuning(9300 + n))
 static int g_pl_dgrad = 0;   // ST_PREC_F32X3: synthesis data gradient on the plane kernel (measured slower than the fp32 MFMA kernel at B = 256: 57 vs 45 us)   (st_set_tuning(9200 + n))
 static int g_pl_shape = 0;   // plane GEMM tile (ST_PREC_F32X3): 0 = 4 waves x (32 x 96), 1 = 2 waves x (64 x 96), 2 = 4 waves x (64 x 96)   (st_set_tuning(9100 + n))
@@ -180,6 +182,7 @@ static int g_wg_mode_set(int v);
 static int g_wsplit_max = 16, g_wsplit_div = 200, g_an_waves = 4, g_syn_split = 3, g_frs_split = 3, g_wide_fused = 1, g_wsplit_half = 0;      // frames: 3, 4 measured equal, 6 slower (only 66 k-tiles to split)
 extern "C" int st_set_tuning(int bk)
 {
+    if (bk >= 9400) { g_pl_bf16 = bk - 9400; return ST_OK; }
     if (bk >= 9300) { g_wg_split = bk - 9300; return ST_OK; }
     if (bk >= 9200) { g_pl_dgrad = bk - 9200; return ST_OK; }
     if (bk >= 9100) { g_pl_shape = bk - 9100; return ST_OK; }
@@ -903,7 +906,8 @@ extern "C" size_t st_workspace_bytes(const st_dims* d)
 // Operands written once per step -- the padded waveform, the F used rows of the analysis bases, the folded synthesis bases in both
 // orientations -- become three bfloat16 planes in one elementwise launch; the spectra AA and d syn (one consumer each) are split as
 // their GEMM stages them.  The weight-gradient GEMMs (reduction along the rows of both operands) keep the fp32 MFMA kernel.
-static bool use_planes(const st_dims* d) { return gemm_ht(d->prec) == 3 && d->N % 16 == 0 && st_kp_of(d->F) % 16 == 0; }
+static bool use_planes(const st_dims* d) { return (gemm_ht(d->prec) == 3 || (gemm_ht(d->prec) == 1 && g_pl_bf16)) && d->N % 16 == 0 && st_kp_of(d->F) % 16 == 0; }
+static int planes_of(const st_dims* d) { return gemm_ht(d->prec) == 3 ? 3 : 1; }
 static int planes_prepare(const st_dims* d, const float* Wr, const float* Wi, WS& w, void* stream)
 {
     const int KP = st_kp_of(d->F);
@@ -915,7 +919,8 @@ static int planes_prepare(const st_dims* d, const float* Wr, const float* Wi, WS
     unsigned blk = 0;
     for (int j = 0; j < 3; ++j) { a.blk0[j] = blk; blk += (unsigned)(((size_t)a.job[j].rows * (a.job[j].K / 4) + 255) / 256); }
     a.blk0[3] = blk; a.blk0[4] = blk;
-    hipLaunchKernelGGL(stg::wplanes_kernel<3>, dim3(blk), dim3(256), 0, st_stream(stream), a);
+    if (planes_of(d) == 3) hipLaunchKernelGGL(stg::wplanes_kernel<3>, dim3(blk), dim3(256), 0, st_stream(stream), a);
+    else hipLaunchKernelGGL(stg::wplanes_kernel<1>, dim3(blk), dim3(256), 0, st_stream(stream), a);
     ST_LAUNCHED("planes");
     return ST_OK;
 }
@@ -926,7 +931,8 @@ static int analysis_fwd_planes(const st_dims* d, WS& w, float* re, float* im, fl
     stg::FramedNT<true> al{w.xp, d->L, d->H, d->N, R, d->N, 1.0f, map};
     stg::ChunkP bl{w.pl_W, 2 * d->F};
     stg::PolarStore ep{re, im, mag, phs, R, d->F, map};
-    if (g_pl_shape == 1) ST_TRY((stg::launch_planes<2, 3, 2>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream))));
+    if (planes_of(d) == 1) ST_TRY((stg::launch_planes<4, 1>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream))));
+    else if (g_pl_shape == 1) ST_TRY((stg::launch_planes<2, 3, 2>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream))));
     else if (g_pl_shape == 2) ST_TRY((stg::launch_planes<4, 3, 2>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream))));
     else ST_TRY((stg::launch_planes<4, 3>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream))));
     ST_LAUNCHED("analysis_fwd");
@@ -940,7 +946,11 @@ static int synthesis_frames_planes(const st_dims* d, WS& w, void* stream)
     stg::PlainNT al{w.AA, R, KP, KP, ms};
     stg::ChunkP bt{w.pl_SfoldT, d->N};
     stg::StoreC ep{w.frs, R, d->N, d->N, (size_t)d->B * d->OT * d->N, ms};
-    if (R >= 4096) ST_TRY((stg::launch_planes<4, 3>(al, bt, ep, R, d->N, KP, 1, st_stream(stream))));
+    if (planes_of(d) == 1) {
+        if (R >= 4096) ST_TRY((stg::launch_planes<4, 1>(al, bt, ep, R, d->N, KP, 1, st_stream(stream))));
+        else ST_TRY((stg::launch_planes<2, 1>(al, bt, ep, R, d->N, KP, frames_split(R), st_stream(stream))));
+    }
+    else if (R >= 4096) ST_TRY((stg::launch_planes<4, 3>(al, bt, ep, R, d->N, KP, 1, st_stream(stream))));
     else ST_TRY((stg::launch_planes<2, 3>(al, bt, ep, R, d->N, KP, frames_split(R), st_stream(stream))));
     ST_LAUNCHED("synthesis_frames"); return ST_OK;
 }
@@ -953,7 +963,11 @@ static int synthesis_dgrad_planes(const st_dims* d, WS& w, void* stream)
     stg::ChunkP bl{w.pl_Sfold, KP};
     stg::StoreC ep{w.dAA, R, KP, KP, (size_t)d->B * d->OT * KP, ms};
     const int ns = R >= 4096 ? 1 : synth_split(R);
-    if (R >= 4096) ST_TRY((stg::launch_planes<4, 3>(al, bl, ep, R, KP, d->N, ns, st_stream(stream))));
+    if (planes_of(d) == 1) {
+        if (R >= 4096) ST_TRY((stg::launch_planes<4, 1>(al, bl, ep, R, KP, d->N, ns, st_stream(stream))));
+        else ST_TRY((stg::launch_planes<2, 1>(al, bl, ep, R, KP, d->N, ns, st_stream(stream))));
+    }
+    else if (R >= 4096) ST_TRY((stg::launch_planes<4, 3>(al, bl, ep, R, KP, d->N, ns, st_stream(stream))));
     else ST_TRY((stg::launch_planes<2, 3>(al, bl, ep, R, KP, d->N, ns, st_stream(stream))));
     ST_LAUNCHED("synthesis_dgrad"); return ST_OK;
 }
