@@ -45,7 +45,7 @@ template <int PART> constexpr int ae_split_lds_floats(int nw)
 }
 
 // Parameters of layers [l0, l1) into the compact images of `tab` (cf. ae_load_lds).
-template <int NT>
+template <int NT, int BF = 0>
 __device__ inline void ae_load_lds_tab(float* lds, const int total, const AETab tab, const float* __restrict__ ae, const AEOffsets& go,
                                        const int T, const int OT, const int K, const int tid, const int l0, const int l1)
 {
@@ -66,8 +66,14 @@ __device__ inline void ae_load_lds_tab(float* lds, const int total, const AETab 
             const int e = tid + u * NT;
             if (e < n) {
                 const int o = e / IN, i = e - o * IN;
+                if constexpr (BF) {                       // 16-bit images, packed into the first half of each region (ae_params_scatter)
+                    const unsigned short hb = st_half_bits<BF>(r.v[l][u]);
+                    reinterpret_cast<unsigned short*>(lds + tab.ao[l])[(((i >> 2) * OP + o) << 2) + (i & 3)] = hb;
+                    reinterpret_cast<unsigned short*>(lds + tab.gi[l])[(((o >> 2) * IP + i) << 2) + (o & 3)] = hb;
+                } else {
                 lds[tab.ao[l] + (((i >> 2) * OP + o) << 2) + (i & 3)] = r.v[l][u];
                 lds[tab.gi[l] + (((o >> 2) * IP + i) << 2) + (o & 3)] = r.v[l][u];
+                }
             }
         }
         if (on && tid < out[l]) lds[tab.bo[l] + tid] = r.bv[l];
@@ -113,7 +119,7 @@ ae_bwd_part_kernel(const float* __restrict__ mag, const float* __restrict__ phs,
     float* S0 = scr;                                          // PART 1: Y rows (d a9 transposed); PART 2: V rows (input rows transposed)
     float* XH = scr + (PART == 1 ? 16 : 32) * SP;
     float* XD = XH + 4 * 320;
-    ae_load_lds_tab<NW * 64>(lw, P::TOTAL, P::tab(), ae ? ae_p : ae_m, go, T, OT, K, tid, P::L0, P::L1);
+    ae_load_lds_tab<NW * 64, BF>(lw, P::TOTAL, P::tab(), ae ? ae_p : ae_m, go, T, OT, K, tid, P::L0, P::L1);
     __syncthreads();
 
     const float* vin = ae ? phs : mag;
@@ -182,12 +188,12 @@ ae_bwd_part_kernel(const float* __restrict__ mag, const float* __restrict__ phs,
             load_in(gnext, h4n, knn, knTn);
             // ---- forward recompute, layers 5..9 (rolling fragment prefetch)
             f32x4 h4[1] = {h4c}, h5[1], h6[1], h7[2], h8[4], e9[1];
-            f32x4 fr5[1 * 2]; frags_fwd<1, 2, CL::O4>(fr5, lw + P::A4, g, c);
-            f32x4 fr6[1 * 1]; frags_fwd<1, 1, CL::O5>(fr6, lw + P::A5, g, c); ST_FENCE();
+            f32x4 fr5[1 * 2]; frags_fwd<1, 2, CL::O4, BF>(fr5, lw + P::A4, g, c);
+            f32x4 fr6[1 * 1]; frags_fwd<1, 1, CL::O5, BF>(fr6, lw + P::A5, g, c); ST_FENCE();
             { const f32x4 hk[2] = {h4[0], kn}; fwdD_fr<1, 2, BF>(fr5, lw + P::B4, hk, h5, g); }
-            f32x4 fr7[2 * 1]; frags_fwd<2, 1, CL::O6>(fr7, lw + P::A6, g, c); ST_FENCE(); fwdD_fr<1, 1, BF>(fr6, lw + P::B5, h5, h6, g);
-            f32x4 fr8[4 * 2]; frags_fwd<4, 2, CL::O7>(fr8, lw + P::A7, g, c); ST_FENCE(); fwdD_fr<2, 1, BF>(fr7, lw + P::B6, h6, h7, g);
-            f32x4 fr9[1 * 4]; frags_fwd<1, 4, CL::O8>(fr9, lw + P::A8, g, c); ST_FENCE(); fwdD_fr<4, 2, BF>(fr8, lw + P::B7, h7, h8, g);
+            f32x4 fr7[2 * 1]; frags_fwd<2, 1, CL::O6, BF>(fr7, lw + P::A6, g, c); ST_FENCE(); fwdD_fr<1, 1, BF>(fr6, lw + P::B5, h5, h6, g);
+            f32x4 fr8[4 * 2]; frags_fwd<4, 2, CL::O7, BF>(fr8, lw + P::A7, g, c); ST_FENCE(); fwdD_fr<2, 1, BF>(fr7, lw + P::B6, h6, h7, g);
+            f32x4 fr9[1 * 4]; frags_fwd<1, 4, CL::O8, BF>(fr9, lw + P::A8, g, c); ST_FENCE(); fwdD_fr<4, 2, BF>(fr8, lw + P::B7, h7, h8, g);
             // ---- d out, part A under the layer-9 MFMAs (nn_proc.py:322-326 backward + the L1 term of loss_functions.py:36)
             f32x4 da9[1];
             float dxA[4], mtA[4];
@@ -233,16 +239,16 @@ ae_bwd_part_kernel(const float* __restrict__ mag, const float* __restrict__ phs,
             f32x4 hT8[4], da8[4], daT8[4], fd8[2 * 4];
             {
                 f32x4 daT9[1], fd9[4 * 1];
-                frags_dgrad<1, 4, CL::I8>(fd9, lw + P::G8, g, c);
+                frags_dgrad<1, 4, CL::I8, BF>(fd9, lw + P::G8, g, c);
                 daT9[0] = *reinterpret_cast<const f32x4*>(S0 + c * SP + 4 * g);
-                ST_BWD_STAGE2(1, 4, fd9, da9, daT9, h8, hT8, da8, daT8, rW9, rb9, (frags_dgrad<4, 2, CL::I7>(fd8, lw + P::G7, g, c)))
+                ST_BWD_STAGE2(1, 4, fd9, da9, daT9, h8, hT8, da8, daT8, rW9, rb9, (frags_dgrad<4, 2, CL::I7, BF>(fd8, lw + P::G7, g, c)))
             }
             f32x4 hT7[2], da7[2], daT7[2], fd7[1 * 2];
-            ST_BWD_STAGE2(4, 2, fd8, da8, daT8, h7, hT7, da7, daT7, rW8, rb8, (frags_dgrad<2, 1, CL::I6>(fd7, lw + P::G6, g, c)))
+            ST_BWD_STAGE2(4, 2, fd8, da8, daT8, h7, hT7, da7, daT7, rW8, rb8, (frags_dgrad<2, 1, CL::I6, BF>(fd7, lw + P::G6, g, c)))
             f32x4 hT6[1], da6[1], daT6[1], fd6[1];
-            ST_BWD_STAGE2(2, 1, fd7, da7, daT7, h6, hT6, da6, daT6, rW7, rb7, (frags_dgrad<1, 1, CL::I5>(fd6, lw + P::G5, g, c)))
+            ST_BWD_STAGE2(2, 1, fd7, da7, daT7, h6, hT6, da6, daT6, rW7, rb7, (frags_dgrad<1, 1, CL::I5, BF>(fd6, lw + P::G5, g, c)))
             f32x4 hT5[1], da5[1], daT5[1], fd5[1];
-            ST_BWD_STAGE2(1, 1, fd6, da6, daT6, h5, hT5, da5, daT5, rW6, rb6, (frags_dgrad<1, 1, CL::I4>(fd5, lw + P::G4, g, c)))
+            ST_BWD_STAGE2(1, 1, fd6, da6, daT6, h5, hT5, da5, daT5, rW6, rb6, (frags_dgrad<1, 1, CL::I4, BF>(fd5, lw + P::G4, g, c)))
             // layer 5 ([h4 ; knobs] -> 16): weight gradient over both input tiles, data gradient to h4 only -> d a4 leaves the kernel
             f32x4 hT4[1], hT4k[2], da4[1];
             {
@@ -328,26 +334,26 @@ ae_bwd_part_kernel(const float* __restrict__ mag, const float* __restrict__ phs,
             load_in(gnext, nxt);
             // ---- forward recompute, layers 1..3
             f32x4 h1[4], h2[2], h3[1];
-            f32x4 fr1[4 * 2]; frags_fwd<4, 2, CL::O0>(fr1, lw + P::A0, g, c);
-            f32x4 fr2[2 * 4]; frags_fwd<2, 4, CL::O1>(fr2, lw + P::A1, g, c);
+            f32x4 fr1[4 * 2]; frags_fwd<4, 2, CL::O0, BF>(fr1, lw + P::A0, g, c);
+            f32x4 fr2[2 * 4]; frags_fwd<2, 4, CL::O1, BF>(fr2, lw + P::A1, g, c);
 #pragma unroll
             for (int it = 0; it < 2; ++it)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) S0[(16 * it + 4 * g + r) * SP + c] = cur.v[it][r];   // [feature t][row c]: read back transposed for the layer-1 wgrad
             ST_FENCE();
             fwdD_fr<4, 2, BF>(fr1, lw + P::B0, cur.v, h1, g);
-            f32x4 fr3[1 * 2]; frags_fwd<1, 2, CL::O2>(fr3, lw + P::A2, g, c); ST_FENCE(); fwdD_fr<2, 4, BF>(fr2, lw + P::B1, h1, h2, g);
-            f32x4 fd4[1]; frags_dgrad<1, 1, CL::I3>(fd4, lw + P::G3, g, c);
+            f32x4 fr3[1 * 2]; frags_fwd<1, 2, CL::O2, BF>(fr3, lw + P::A2, g, c); ST_FENCE(); fwdD_fr<2, 4, BF>(fr2, lw + P::B1, h1, h2, g);
+            f32x4 fd4[1]; frags_dgrad<1, 1, CL::I3, BF>(fd4, lw + P::G3, g, c);
             f32x4 da4[1] = {cur.d4}, daT4[1];
             to_T<1>(XD, da4, daT4, g, c);
             ST_FENCE(); fwdD_fr<1, 2, BF>(fr3, lw + P::B2, h2, h3, g);
             // ---- backward 4..1
             f32x4 hT3[1], da3[1], daT3[1], fd3[2 * 1];
-            ST_BWD_STAGE2(1, 1, fd4, da4, daT4, h3, hT3, da3, daT3, rW4, rb4, (frags_dgrad<1, 2, CL::I2>(fd3, lw + P::G2, g, c)))
+            ST_BWD_STAGE2(1, 1, fd4, da4, daT4, h3, hT3, da3, daT3, rW4, rb4, (frags_dgrad<1, 2, CL::I2, BF>(fd3, lw + P::G2, g, c)))
             f32x4 hT2[2], da2[2], daT2[2], fd2[4 * 2];
-            ST_BWD_STAGE2(1, 2, fd3, da3, daT3, h2, hT2, da2, daT2, rW3, rb3, (frags_dgrad<2, 4, CL::I1>(fd2, lw + P::G1, g, c)))
+            ST_BWD_STAGE2(1, 2, fd3, da3, daT3, h2, hT2, da2, daT2, rW3, rb3, (frags_dgrad<2, 4, CL::I1, BF>(fd2, lw + P::G1, g, c)))
             f32x4 hT1[4], da1[4], daT1[4], fd1[2 * 4];
-            ST_BWD_STAGE2(2, 4, fd2, da2, daT2, h1, hT1, da1, daT1, rW2, rb2, (frags_dgrad<4, 2, CL::I0>(fd1, lw + P::G0, g, c)))
+            ST_BWD_STAGE2(2, 4, fd2, da2, daT2, h1, hT1, da1, daT1, rW2, rb2, (frags_dgrad<4, 2, CL::I0, BF>(fd1, lw + P::G0, g, c)))
             f32x4 vT[2], dv[2];
 #pragma unroll
             for (int it = 0; it < 2; ++it) vT[it] = *reinterpret_cast<const f32x4*>(S0 + (16 * it + c) * SP + 4 * g);
