@@ -52,18 +52,26 @@ class _AnalysisFn(torch.autograd.Function):
         x = wave.contiguous().float(); Wr_ = Wr.contiguous(); Wi_ = Wi.contiguous()
         _lib.check(lib.st_analysis_fwd(C.byref(_relax(d)), _lib.ptr(x), _lib.ptr(Wr_), _lib.ptr(Wi_), 1.0, _lib.ptr(re),
                                        _lib.ptr(im), None, None, _stream()), "st_analysis_fwd")
-        ctx.save_for_backward(x); ctx.geom = (B, L, N, H, T)
+        ctx.save_for_backward(x, Wr_, Wi_); ctx.geom = (B, L, N, H, T)
         return re, im
 
     @staticmethod
     @_lib.on_arg_device
     def backward(ctx, g_re, g_im):
         lib = _lib.load()
-        if ctx.needs_input_grad[0]:
-            raise NotImplementedError("signaltrain_amd.Analysis: the gradient w.r.t. the input waveform is not built (the model never "
-                                      "needs it: the waveform is data); detach the input, or use cls_fe_dct_bases.Analysis, whose backward returns it")
-        (x,) = ctx.saved_tensors
+        (x, Wr, Wi) = ctx.saved_tensors
         B, L, N, H, T = ctx.geom
+        gx = None
+        if ctx.needs_input_grad[0]:
+            # d/d(wave) of the Conv1d pair (cls_fe_dft.py:55-56) = conv-transpose of the output gradients with the same kernels, cropped by
+            # the padding: the generic front-end entry does it for C channels -- the F used rows of both bases stacked (padded to C % 16 == 0)
+            F = N // 2 + 1; Cp = -(-2 * F // 16) * 16
+            Wc = torch.zeros(Cp, N, device=x.device); Wc[:F] = Wr.reshape(N, N)[:F]; Wc[F:2 * F] = Wi.reshape(N, N)[:F]
+            gc = torch.zeros(B * T, Cp, device=x.device); gc[:, :F] = g_re.reshape(B * T, F); gc[:, F:2 * F] = g_im.reshape(B * T, F)
+            wsf = torch.empty(lib.st_fe_ws_floats(B, L, Cp, N, H, N), device=x.device)
+            gWc = torch.empty(Cp, N, device=x.device); gx = torch.empty(B, L, device=x.device)
+            _lib.check(lib.st_fe_analysis_bwd(_lib.ptr(x), B, L, _lib.ptr(Wc), Cp, N, H, N, _lib.ptr(gc), _lib.ptr(wsf), _lib.ptr(gWc), None,
+                                              _lib.ptr(gx), _stream()), "st_fe_analysis_bwd")
         d = _relax(_dims(B, L, N, H, T, 1))
         F = N // 2 + 1; KP = lib.st_kp(F)
         dG = torch.zeros(B * T, KP, device=x.device)
@@ -73,7 +81,7 @@ class _AnalysisFn(torch.autograd.Function):
         npart = torch.empty(lib.st_norm_partials(C.byref(d)), device=x.device)
         _lib.check(lib.st_analysis_wgrad(C.byref(d), _lib.ptr(dG), _lib.ptr(x), 1.0, _lib.ptr(ws), _lib.ptr(gWr), _lib.ptr(gWi),
                                          _lib.ptr(npart), _stream()), "st_analysis_wgrad")
-        return None, gWr, gWi, None, None
+        return gx, gWr, gWi, None, None
 
 
 def _relax(d):

@@ -199,6 +199,30 @@ def test_analysis_synthesis_modules_perfect_reconstruction():
     assert an.conv_analysis_real.weight.grad is not None and sy.conv_synthesis_imag.weight.grad.abs().max() > 0
 
 
+def test_analysis_module_input_gradient():
+    """The reference's Conv1d front end propagates d/d(wave) (cls_fe_dft.py:55-56 is plain autograd): Analysis.backward returns it too
+    (needed only when something trainable sits upstream of the model) -- against float64 torch autograd of the same convolution."""
+    import torch.nn.functional as Fn
+    from signaltrain_amd.cls_fe_dft import Analysis
+    an = Analysis().cuda()
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    with torch.no_grad():
+        for p in an.parameters(): p.add_(1e-3 * torch.randn(p.shape, device="cuda", generator=g))
+    x = (torch.randn(2, 8192, device="cuda", generator=g) * 0.3).requires_grad_(True)
+    re, im = an(x)
+    cr, ci = torch.randn(re.shape, device="cuda", generator=g), torch.randn(im.shape, device="cuda", generator=g)
+    ((re * cr).sum() + (im * ci).sum()).backward()
+    xd = x.detach().double().cpu().requires_grad_(True)
+    Wr, Wi = an.conv_analysis_real.weight.detach().double().cpu(), an.conv_analysis_imag.weight.detach().double().cpu()
+    rr = Fn.conv1d(xd.unsqueeze(1), Wr, stride=384, padding=1024).transpose(1, 2)[:, :, :513]
+    ii = Fn.conv1d(xd.unsqueeze(1), Wi, stride=384, padding=1024).transpose(1, 2)[:, :, :513]
+    ((rr * cr.double().cpu()).sum() + (ii * ci.double().cpu()).sum()).backward()
+    assert (re.detach().double().cpu() - rr.detach()).abs().max() < 1e-4 * rr.detach().abs().max()
+    e = (x.grad.double().cpu() - xd.grad).abs().max() / xd.grad.abs().max()
+    assert e < 1e-5, float(e)
+    assert an.conv_analysis_real.weight.grad is not None
+
+
 def test_train_driver_short_run(tmp_path):
     from signaltrain_amd import train, audio, nn_proc
     nn_proc._QUIET = True
