@@ -171,7 +171,8 @@ static int g_pl_bf16 = 0;    // ST_PREC_BF16*: analysis / frames GEMMs on the pl
                              // (analysis 53.8 vs 49.8 us + 12 us for the copies): three MFMAs per 16-deep k-tile and barrier; needs a 64-deep tile   (st_set_tuning(9400 + n))
 static int g_wg_split = 0;   // ST_PREC_F32X3: weight-gradient GEMMs on the in-kernel three-plane split instead of the fp32 MFMA kernel (see ST_GEMM_WG)   (st_set_tuning(9300 + n))
 static int g_pl_dgrad = 0;   // ST_PREC_F32X3: synthesis data gradient on the plane kernel (measured slower than the fp32 MFMA kernel at B = 256: 57 vs 45 us)   (st_set_tuning(9200 + n))
-static int g_pl_shape = 0;   // plane GEMM tile (ST_PREC_F32X3): 0 = 4 waves x (32 x 96), 1 = 2 waves x (64 x 96), 2 = 4 waves x (64 x 96)   (st_set_tuning(9100 + n))
+static int g_pl_shape = 3;   // analysis plane GEMM tile (ST_PREC_F32X3): 0 = 4 waves x (32 x 96) [91.9 us], 1 = 2 waves x (64 x 96) [117], 2 = 4 waves x (64 x 96) [112],
+                             // 3 = 8 waves x (32 x 96) = 256 x 96, one workgroup per CU: a quarter less L2 traffic at the same two waves per SIMD [88.1]   (st_set_tuning(9100 + n))
 static int g_frs_nt = 1;     // synthesis frames GEMM against the transposed fold (both operands K-contiguous); 0 = the k-major form (st_set_tuning(9000), diagnostics)
 static int g_xt = 0;       // 1: M/N-contiguous operands staged k-quad-major (st_gemm.h XT; st_set_tuning(7001), diagnostics).  MEASURED SLOWER at B=256 although
                            // conflict-free with a third fewer LDS cycles: analysis wgrad 173 vs 145 us, synthesis frames 63 vs 60 us (16 more prefetch
@@ -937,6 +938,7 @@ static int analysis_fwd_planes(const st_dims* d, WS& w, float* re, float* im, fl
     if (planes_of(d) == 1) ST_TRY((stg::launch_planes<4, 1>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream))));
     else if (g_pl_shape == 1) ST_TRY((stg::launch_planes<2, 3, 2>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream))));
     else if (g_pl_shape == 2) ST_TRY((stg::launch_planes<4, 3, 2>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream))));
+    else if (g_pl_shape == 3) ST_TRY((stg::launch_planes<8, 3, 1>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream))));
     else ST_TRY((stg::launch_planes<4, 3>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream))));
     ST_LAUNCHED("analysis_fwd");
     return ST_OK;
@@ -1455,6 +1457,7 @@ static int attr_prepare(const st_dims* d)
 #undef ST_PREP3
     if (use_planes(d)) {        // the 4-wave plane GEMM carries 67 KB of LDS (st_gemm_planes.h)
         ST_DYN_LDS((stg::gemm_planes_kernel<4, 3, 1, stg::FramedNT<true>, stg::ChunkP, stg::PolarStore>));
+        ST_DYN_LDS((stg::gemm_planes_kernel<8, 3, 1, stg::FramedNT<true>, stg::ChunkP, stg::PolarStore>));
         ST_DYN_LDS((stg::gemm_planes_kernel<4, 3, 1, stg::PlainNT, stg::ChunkP, stg::StoreC>));
         ST_DYN_LDS((stg::gemm_planes_kernel<4, 3, 1, stg::FramedNT<true>, stg::ChunkP, stg::StoreC>));
     }
