@@ -307,3 +307,45 @@ def test_engine_on_a_non_current_device_or_stream():
         e1.train_step(torch.from_numpy(X).to("cuda:1"), torch.from_numpy(KN).to("cuda:1"), torch.from_numpy(Y).to("cuda:1"), 1e-3)
         torch.cuda.synchronize("cuda:1")
         assert torch.equal(e1.params.cpu(), ref.params.cpu())
+
+
+@pytest.mark.parametrize("dtype,codes,restore", [
+    ("f32", (9000,), (9001,)),            # synthesis frames GEMM in the k-major form
+    ("f32", (8000,), (8001,)),            # single-kernel autoencoder backward
+    ("f32", (7001,), (7000,)),            # k-quad-major transposed staging of the weight-gradient GEMMs
+    ("f32", (102,), (100,)),              # weight-gradient tile mode 2
+    ("f32x3", (9201,), (9200,)),          # synthesis data gradient on the plane kernel
+    ("f32x3", (9100,), (9103,)),          # 4-wave analysis plane tile
+    ("f32x3", (9301,), (9300,)),          # weight gradients on the in-kernel three-plane split
+    ("bf16_all", (8002,), (8001,)),       # split autoencoder backward with 16-bit operands
+    ("bf16", (9401,), (9400,)),           # one-plane (pre-converted bf16) bases on the plane kernel
+])
+def test_alternative_code_paths_agree(dtype, codes, restore):
+    """The variants kept behind st_set_tuning (measured slower, or experiments) compute the same thing as the default path: loss and
+    all 40 gradient tensors of one batch (fp32-grade variants to 2e-5 of each tensor's largest element -- reassociation only --,
+    the 16-bit ones to the rounding noise of their arithmetic)."""
+    import numpy as np, torch
+    from tests import gpu_checks as G
+    from signaltrain_amd import _lib
+    from signaltrain_amd.engine import StepEngine
+    lib = _lib.load()
+    B, K = 4, 4
+    geo, X, Y, KN, P = G.make_case(B, 17, K=K)
+    x, kn, y = G.t(X), G.t(KN), G.t(Y)
+
+    def run():
+        d = G.dims_of(geo, B, K)
+        eng = StepEngine(d, G.DEV, compute_dtype=dtype); eng.load_state_dict(P)
+        eng.loss_backward(x, kn, y); torch.cuda.synchronize()
+        return {k: v.clone() for k, v in eng.layout.views(eng.grads).items()}, float(eng.scalars[0])
+    ref, l_ref = run()
+    try:
+        for c in codes: _lib.check(lib.st_set_tuning(c), "st_set_tuning")
+        alt, l_alt = run()
+    finally:
+        for c in restore: _lib.check(lib.st_set_tuning(c), "st_set_tuning")
+    tol = 2e-5 if dtype in ("f32", "f32x3") else 3e-2        # fp32-grade: reassociation only; 16-bit: a different summation order moves roundings
+    assert abs(l_alt - l_ref) <= tol * abs(l_ref), (l_ref, l_alt)
+    for k in ref:
+        sc = ref[k].abs().max().item()
+        assert (alt[k] - ref[k]).abs().max().item() <= tol * sc + 1e-12, (dtype, codes, k)
