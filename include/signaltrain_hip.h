@@ -288,6 +288,14 @@ int st_graph_destroy(st_graph* g);
  *   (Effect.knobs_wc, audio.py:455), y [B][ysz] = the last ysz samples of the processed window (datasets.py:327-330). */
 int st_compressor_4c(const float* x, const float* knobs_wc, float sr, int B, int L, int ysz, float* y, void* stream);
 
+/* Gradient of the loss w.r.t. the (halved) input waveform, for callers with something trainable upstream of the model (the reference's
+ * autograd provides it; nn_proc.py:307, cls_fe_dft.py:55-56).  Call right after st_model_bwd on the SAME workspace:
+ *   gxh[b][n] = conv-transpose of the analysis output gradient with both bases, cropped by the Conv1d padding   [B][L]
+ * The caller multiplies by 1/2 (nn_proc.py:307) and adds g_y_hat on the last y samples (the skip of nn_proc.py:340).
+ * scratch: st_model_input_grad_ws_floats(d) floats. */
+size_t st_model_input_grad_ws_floats(const st_dims* d);
+int st_model_input_grad(const st_dims* d, const float* params, void* ws, float* scratch, float* gxh, void* stream);
+
 /* ---- generic learned-basis front end: SURVEY.md row a15, signaltrain/cls_fe_dct_bases.py ------------------------------
  * Analysis.forward (:129-136)  = Conv1d(1 -> C, kernel KW, stride hop, padding pad, bias) transposed to [B][T][C];
  * Synthesis.forward (:174-179) = ConvTranspose1d(C -> 1, kernel KW, stride hop) with `crop` samples cut from both ends.

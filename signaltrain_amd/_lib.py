@@ -55,6 +55,8 @@ SIGNATURES = {
     "st_fe_ws_floats": (C.c_size_t, [C.c_int] * 6),
     "st_fe_analysis_fwd": (_i, [_p, C.c_int, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
     "st_fe_synthesis_fwd": (_i, [_p, C.c_int, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
+    "st_model_input_grad_ws_floats": (C.c_size_t, [_D]),
+    "st_model_input_grad": (_i, [_D, _p, _p, _p, _p, _p]),
     "st_fe_analysis_bwd": (_i, [_p, C.c_int, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p, _p]),
     "st_fe_synthesis_bwd": (_i, [_p, C.c_int, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p]),
     "st_ae_fwd_partials": (_i, [_D]),

@@ -1283,6 +1283,34 @@ extern "C" int st_fe_synthesis_fwd(const float* xft, int B, int T, const float* 
     ST_TRY(fe_frames_ola(xft, B, T, W, C, KW, hop, crop, len, ws, out, stream));
     ST_LAUNCHED("fe_synthesis_fwd"); return ST_OK;
 }
+// d loss / d (x/2) of the whole model, for callers with something trainable UPSTREAM of st_model (the reference's autograd gives it for
+// free; its own training never asks: x is data).  Must follow st_model_bwd on the same workspace: the analysis output gradient dG
+// [B*T][KP] is still there.  gxh[b][n] = sum_t sum_k dG[b,t,k] W[k][n - (H t - N)]  (conv-transpose of both Conv1d's, cropped by the
+// padding); the caller scales by the 1/2 of nn_proc.py:307 and adds the skip term of :340.  scratch: st_model_input_grad_ws_floats().
+__global__ void __launch_bounds__(256)
+wcat_kernel(const float* __restrict__ Wr, const float* __restrict__ Wi, float* __restrict__ out, const int F, const int N, const int KP)
+{
+    const int row = blockIdx.x, half = KP / 2;
+    const bool is_im = row >= half; const int k = is_im ? row - half : row;
+    for (int n = threadIdx.x; n < N; n += 256) out[(size_t)row * N + n] = k < F ? (is_im ? Wi : Wr)[(size_t)k * N + n] : 0.f;
+}
+extern "C" size_t st_model_input_grad_ws_floats(const st_dims* d)
+{
+    if (check_dims(d) != ST_OK) return 0;
+    return (size_t)st_kp_of(d->F) * d->N + (size_t)d->B * d->T * d->N + 64;
+}
+extern "C" int st_model_input_grad(const st_dims* d, const float* params, void* ws, float* scratch, float* gxh, void* stream)
+{
+    Layout L; ST_TRY(make_layout(d, &L));
+    ST_REQ(params && ws && scratch && gxh, "st_model_input_grad: null pointer");
+    ST_REQ(d->L % 4 == 0 && d->H % 4 == 0, "st_model_input_grad: L %% 4 and hop %% 4 required");
+    WS w; carve(d, ws, &w);
+    float* Wc = scratch; float* frs = scratch + (size_t)L.KP * d->N;
+    hipLaunchKernelGGL(wcat_kernel, dim3(L.KP), dim3(256), 0, st_stream(stream), params + L.offs[0], params + L.offs[1], Wc, d->F, d->N, L.KP);
+    ST_TRY(fe_frames_ola(w.dG, d->B, d->T, Wc, L.KP, d->N, d->H, d->N, d->L, frs, gxh, stream));
+    ST_LAUNCHED("model_input_grad");
+    return ST_OK;
+}
 // autograd of st_fe_analysis_fwd: gW [C][KW], gbias [C] (may be null), gx [B][L] (may be null)
 extern "C" int st_fe_analysis_bwd(const float* x, int B, int L, const float* W, int C, int KW, int hop, int pad, const float* g_out,
                                   float* ws, float* gW, float* gbias, float* gx, void* stream)

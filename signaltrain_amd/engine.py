@@ -201,6 +201,18 @@ class StepEngine:
                    _lib.ptr(knobs), _lib.ptr(g_y_hat), _lib.ptr(g_mag_hat), _lib.ptr(g_mag), _lib.ptr(self.ws), self._stream())
         return self.grads
 
+    def input_grad(self, x, g_y_hat):
+        """d loss / d x of the whole model (right after backward() on the same batch): half the conv-transpose of the analysis output
+        gradient (nn_proc.py:307 feeds x/2) plus the skip connection's share on the last y samples (nn_proc.py:340)."""
+        d = self._dims(x.shape[0])
+        scratch = torch.empty(self.lib.st_model_input_grad_ws_floats(C.byref(d)), dtype=torch.float32, device=self.device)
+        gx = torch.empty(d.B, d.L, dtype=torch.float32, device=self.device)
+        self._call("st_model_input_grad", C.byref(d), _lib.ptr(self.params), _lib.ptr(self.ws), _lib.ptr(scratch), _lib.ptr(gx), self._stream())
+        gx.mul_(0.5)
+        if g_y_hat is not None:
+            gx[:, d.L - d.y:] += g_y_hat.to(device=self.device, dtype=torch.float32)
+        return gx
+
     def loss_backward(self, x, knobs, y, want_outputs=False):
         """forward + calc_loss (loss_functions.py:26-36 with scale_by_freq) + backward; fills self.grads (times the loss
         scale, if one is set).  self.scalars[0..4] = loss, mean log-cosh, L1 term, L1 norm of the (unscaled) STFT grads, clip coefficient."""

@@ -130,14 +130,15 @@ class _STModelFn(torch.autograd.Function):
         if g_y is None:
             g_y = torch.zeros(x.shape[0], eng.dims.y, device=x.device)
         eng.backward(x, knobs, g_y, g_mh, g_mag)
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            raise NotImplementedError("signaltrain_amd.st_model: gradients w.r.t. the input waveform / knobs are not built "
-                                      "(the reference's training never needs them: x and knobs are data)")
+        if ctx.needs_input_grad[2]:
+            raise NotImplementedError("signaltrain_amd.st_model: the gradient w.r.t. the knob settings is not built "
+                                      "(the reference's training never needs it: knobs are data)")
+        gx = eng.input_grad(x, g_y) if ctx.needs_input_grad[1] else None     # something trainable upstream of the model
         # one flat clone, then per-parameter views of it: autograd accumulates into .grad, so the engine's gradient buffer
         # (overwritten by the next backward) must not be handed out itself
         flat = eng.grads.clone()
         grads = tuple(eng.layout.views(flat).values())
-        return (None, None, None) + grads
+        return (None, gx, None) + grads
 
 
 class AsymMPAEC(nn.Module):

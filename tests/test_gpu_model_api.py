@@ -621,3 +621,29 @@ def test_train_driver_file_dataset_three_knobs(tmp_path):
         assert len(vals) == 2 and all(np.isfinite(vals))
     finally:
         os.chdir(cwd)
+
+
+def test_model_input_gradient_matches_torch_autograd():
+    """Something trainable upstream of st_model gets its gradient: d loss / d x through the drop-in model (fused HIP backward +
+    st_model_input_grad: half the conv-transpose of the analysis output gradient + the skip connection) against float64 torch autograd
+    of the PyTorch-CPU restatement of the reference's op sequence (oracle/torch_cpu_step.py)."""
+    from oracle import torch_cpu_step as TC
+    from tests import gpu_checks as G
+    from signaltrain_amd import nn_proc
+    nn_proc._QUIET = True
+    B, K = 3, 4
+    geo, X, Y, KN, P = G.make_case(B, 13, K=K)
+    m = nn_proc.st_model(scale_factor=1, shrink_factor=4, num_knobs=K).cuda()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    x = torch.from_numpy(X).cuda().requires_grad_(True)
+    y_hat, mag, mag_hat = m(x, torch.from_numpy(KN).cuda())
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    cy, cm, ch = (torch.randn(t.shape, device="cuda", generator=g) for t in (y_hat, mag, mag_hat))
+    ((y_hat * cy).sum() + 1e-2 * (mag * cm).sum() + 1e-2 * (mag_hat * ch).sum()).backward()
+    P64 = {k: torch.from_numpy(v).double() for k, v in P.items()}
+    xd = torch.from_numpy(X).double().requires_grad_(True)
+    yr, mr, hr = TC.forward(P64, xd, torch.from_numpy(KN).double())
+    ((yr * cy.double().cpu()).sum() + 1e-2 * (mr * cm.double().cpu()).sum() + 1e-2 * (hr * ch.double().cpu()).sum()).backward()
+    assert (y_hat.detach().double().cpu() - yr.detach()).abs().max() < 1e-4 * yr.detach().abs().max()
+    e = (x.grad.double().cpu() - xd.grad).abs().max() / xd.grad.abs().max()
+    assert e < 2e-5, float(e)
