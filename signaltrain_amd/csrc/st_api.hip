@@ -333,7 +333,9 @@ static int ae_split_grid(const st_dims* d) { int g = (ae_fwd_groups(d) + AE_SPLI
 // The split form pays where the MFMAs are long (fp32: measured 181 vs 188 us at B = 256); with 16-bit operands the matrix time is a
 // few microseconds, the kernel is all instruction issue, and two kernels only add a second prologue (bf16_all: 128 vs 124 us): those
 // precisions keep the single kernel.
-static bool ae_use_split(const st_dims* d) { return g_ae_split && !ae_is_wide(d) && (ae_ht(d->prec) == 0 || g_ae_split == 2) && !(g_dbg & 256); }      // 2: also with 16-bit operands (st_set_tuning(8002); measured: halves 49 + 45 us vs 103 us, step unchanged at 0.362 ms -- the exchange buffers and the larger partial reduce take it back)
+// 16-bit operands in the split form were tried (decoder + encoder halves 49 + 45 us against 101 us for the single kernel, the step did not
+// move) and are NOT instantiated: the compiler emitted a cross-block MFMA-result hazard in the 16-bit encoder half (tools/check_mfma_hazards.py).
+static bool ae_use_split(const st_dims* d) { return g_ae_split && !ae_is_wide(d) && ae_ht(d->prec) == 0 && !(g_dbg & 256); }
 extern "C" size_t st_ae_fwd_ws_floats(const st_dims* d)
 {
     if (check_dims(d) != ST_OK) return 0;
@@ -722,12 +724,9 @@ static int ae_bwd_impl(const st_dims* d, const float* mag, const float* phs, con
                            mag, phs, knobs, ae_m, ae_p, L.go, L.PG, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, expfac, dmag, dphs, parts, \
                            (const float*)h4x, da4x, d->B, d->T, d->OT, d->F, d->K, L.KP, live.t_lo, live.t_lo + live.Tv - 1, st_synth_slabs(d), \
                            (size_t)d->B * d->OT * L.KP); } while (0)
-        const int sht = ae_ht(d->prec);
-        if (sht == 1) { if (g_mag_hat) ST_AE_PART(1, 1, true); else ST_AE_PART(1, 1, false); }
-        else if (sht == 2) { if (g_mag_hat) ST_AE_PART(1, 2, true); else ST_AE_PART(1, 2, false); }
-        else if (g_mag_hat) ST_AE_PART(1, 0, true); else ST_AE_PART(1, 0, false);
+        if (g_mag_hat) ST_AE_PART(1, 0, true); else ST_AE_PART(1, 0, false);
         ST_LAUNCHED("ae_bwd_dec");
-        if (sht == 1) ST_AE_PART(2, 1, false); else if (sht == 2) ST_AE_PART(2, 2, false); else ST_AE_PART(2, 0, false);
+        ST_AE_PART(2, 0, false);
         ST_LAUNCHED("ae_bwd_enc");
 #undef ST_AE_PART
         if (defer_reduce && *defer_reduce) return ST_OK;

@@ -317,7 +317,6 @@ def test_engine_on_a_non_current_device_or_stream():
     ("f32x3", (9201,), (9200,)),          # synthesis data gradient on the plane kernel
     ("f32x3", (9100,), (9103,)),          # 4-wave analysis plane tile
     ("f32x3", (9301,), (9300,)),          # weight gradients on the in-kernel three-plane split
-    ("bf16_all", (8002,), (8001,)),       # split autoencoder backward with 16-bit operands
     ("bf16", (9401,), (9400,)),           # one-plane (pre-converted bf16) bases on the plane kernel
 ])
 def test_alternative_code_paths_agree(dtype, codes, restore):
