@@ -1446,8 +1446,22 @@ extern "C" int st_dp_train_step(st_dp* p, const st_dims* d, float* params, float
         return st_train_step(d, params, grads, m, v, x, knobs, y_true, ws, scalars, lr, beta1, beta2, eps, step, stream);
     Layout L; ST_TRY(make_layout(d, &L));
     ST_REQ(stage, "st_dp_train_step: null staging buffer");
-    ST_TRY(st_loss_backward_p1(d, params, grads, x, knobs, y_true, ws, stream));
-    ST_TRY(st_dp_allreduce(p, grads + L.offs[2], L.total - L.offs[2], stream));
+    ST_REQ(params && grads && x && knobs && y_true && ws, "st_dp_train_step: null pointer");
+    // Three exchanges, each issued the moment its gradients are final (the communicator stream orders them):
+    //   synthesis bases (8.4 MB)  -- after their weight-gradient GEMM, BEFORE the autoencoder backward: hidden behind the longest
+    //                                kernels of the step (autoencoder backward + polar backward + analysis weight gradient);
+    //   autoencoders (67 KB)      -- after the autoencoder backward;
+    //   analysis bases            -- the 2F live rows, packed (4.2 MB), after the last GEMM of the step: the exposed one.
+    {
+        WS w; carve(d, ws, &w);
+        prof_mark("begin", stream);
+        ST_TRY(forward_impl(d, L, params, x, knobs, y_true, nullptr, nullptr, nullptr, w, true, stream));
+        const float reg_coef = loss_scale_of(d) * (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);
+        ST_TRY(backward_syn(d, L, grads, w, stream));                                  // slab reduce NOT deferred: the tensors are final here
+        ST_TRY(st_dp_allreduce(p, grads + L.offs[2], L.offs[4] - L.offs[2], stream));
+        ST_TRY(backward_ae(d, L, params, grads, knobs, nullptr, nullptr, reg_coef, w, stream));
+        ST_TRY(st_dp_allreduce(p, grads + L.offs[4], L.total - L.offs[4], stream));
+    }
     ST_TRY(st_loss_backward_p2_staged(d, grads, stage, x, ws, scalars, stream));
     ST_TRY(st_dp_allreduce(p, stage, (int64_t)2 * d->F * d->N, stream));
     ST_TRY(st_dp_sync(p, stream));
