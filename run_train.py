@@ -13,7 +13,7 @@ if __name__ == "__main__":
                    "fp32 accumulation, loss scaling, clip over all parameters (the library's f16_all arithmetic; there is no Apex on ROCm)",
                    default="O0", choices=["O0", "O1", "O2", "O3"])
     p.add_argument('--dtype', help="arithmetic of the accelerated step, overrides --apex: f32 | f32x3 (fp32-grade GEMMs on the bf16 matrix pipe) | bf16 | bf16_all | f16 | f16_all",
-                   default=None, choices=["f32", "bf16", "bf16_all", "f16", "f16_all"])
+                   default=None, choices=["f32", "f32x3", "bf16", "bf16_all", "f16", "f16_all"])
     p.add_argument('--gpus', type=int, default=None, help="data-parallel world size this job is meant to run on; launch with "
                    "`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 run_train.py --gpus N ...` "
                    "(one process per GPU); checked against WORLD_SIZE")
