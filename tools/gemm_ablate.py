@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Timing-only ablation of the analysis GEMM (results invalid under the debug switches)."""
+"""[needs a library built with -DST_GEMM_ABLATE: `make -C signaltrain_amd/csrc OUT=/path/libst_ablate.so EXTRA=-DST_GEMM_ABLATE`, then
+ST_LIB_PATH=/path/libst_ablate.so python this_tool; with the default build the switches are compiled out and every line shows the same time]
+Timing-only ablation of the analysis GEMM (results invalid under the debug switches)."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
