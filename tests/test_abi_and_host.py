@@ -177,3 +177,39 @@ def test_hazard_scanner_flags_the_known_bad_pattern():
 """.splitlines()
     assert len(chk.scan_kernel("bad", bad)) == 1
     assert chk.scan_kernel("good", good) == []
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/signaltrain_hip.h compiles as strict C99 (no C++, no torch types), and a C program
+    linked against libsignaltrain_hip.so can call the host-only entries (geometry, layout sizes, error reporting) without a GPU."""
+    import shutil, subprocess, sys
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "use_abi.c"
+    src.write_text('''
+#include <stdio.h>
+#include "signaltrain_hip.h"
+int main(void)
+{
+    st_dims d;
+    long long offs[40];
+    if (st_geometry(1.0f, 4.0f, 0, 4, 256, &d) != ST_OK) { printf("geometry failed: %s\\n", st_last_error()); return 1; }
+    d.prec = ST_PREC_F32X3; d.loss_scale = 0.0f; d.clip_all = 0;
+    printf("%d %d %d %d %d %lld %zu\\n", d.L, d.T, d.OT, d.F, d.y, (long long)st_param_offsets(&d, (int64_t*)offs), st_workspace_bytes(&d));
+    d.B = -1;
+    if (st_workspace_bytes(&d) != 0) return 2;                      /* bad dims are rejected on the host ... */
+    if (st_last_error()[0] == 0) return 3;                          /* ... with a message */
+    return 0;
+}
+''')
+    exe = tmp_path / "use_abi"
+    lib_dir = os.path.join(root, "signaltrain_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(src),
+                        "-o", str(exe), "-L", lib_dir, "-l:libsignaltrain_hip.so", "-Wl,-rpath," + lib_dir],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-500:])
+    L, T, OT, F, y, total, wsb = (int(v) for v in r.stdout.split())
+    assert (L, T, OT, F, y) == (8192, 25, 9, 513, 2048) and total == 4211096 and wsb > 100e6
