@@ -80,8 +80,11 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)       # defaults = the flags the round-end driver passes
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--prewarm-s", type=float, default=0.5, help="untimed, REPORTED pre-warm before the declared warm-up: steps are run until this many seconds "
+                                                                 "have passed (clocks / caches / allocator of a cold GPU settle; `prewarm_s`, `prewarm_steps` in the JSON line)")
+    ap.add_argument("--no-f32x3", action="store_true", help="N = 1, --dtype f32: skip the f32x3 measurement reported beside the exact-fp32 value (ms_per_step_f32x3)")
     ap.add_argument("--batch", type=int, default=256, help="windows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -178,18 +181,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64) if dist.get_backend() == "gloo" else torch.tensor([dt], device=dev, dtype=torch.float64)
+    def all_max(val):
+        if world == 1:
+            return val
+        tt = torch.tensor([val], dtype=torch.float64) if dist.get_backend() == "gloo" else torch.tensor([val], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        return float(tt.item())
+
+    def prewarm(fn):
+        """Untimed and reported: chunks of 10 steps until --prewarm-s seconds have passed on the slowest rank (every rank runs the same
+        number of steps -- the steps contain collectives).  A fresh box needs a few hundred ms of work before its step time is
+        stationary; the declared --warmup alone (5 steps = 4 ms) does not cover that."""
+        n, t_pw = 0, time.perf_counter()
+        fence()
+        while args.prewarm_s > 0 and n < 5000:
+            for _ in range(10):
+                fn(n); n += 1
+            fence()
+            if all_max(time.perf_counter() - t_pw) >= args.prewarm_s:
+                break
+        return n, time.perf_counter() - t_pw
+
+    def timed(fn):
+        for i in range(args.warmup):
+            fn(i)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            fn(args.warmup + i)
+        fence()
+        return time.perf_counter() - t0
+
+    prewarm_steps, prewarm_s = prewarm(step)
+    dt = timed(step)
+    dt = all_max(dt)
     loss = dp.mean_loss()
     ms = dt / args.steps * 1e3
     # the same step replayed from ONE captured HIP graph (st_graph_*: step counter and learning rate on the device): reported
@@ -199,28 +224,31 @@ def main():
     if world == 1 and not args.force_dp and not args.no_graph:
         eng.graph_capture(B, lrs)
         eng.gx.copy_(x); eng.gk.copy_(kn); eng.gy.copy_(y)
-        for i in range(args.warmup):
-            eng.graph_step()
-        fence()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            eng.graph_step()
-        fence()
-        ms_graph = (time.perf_counter() - t0) / args.steps * 1e3
+        ms_graph = timed(lambda i: eng.graph_step()) / args.steps * 1e3
         eng.graph_destroy()
+    # fp32-grade STFT GEMMs from the bf16 matrix pipe (compute_dtype "f32x3"), reported BESIDE the exact-fp32 headline, never as it
+    ms_x3 = None
+    if world == 1 and not args.force_dp and not args.no_f32x3 and args.dtype == "f32":
+        eng3 = StepEngine(d, dev, compute_dtype="f32x3")
+        eng3.load_state_dict(model.state_dict())
+        f3 = lambda i: eng3.train_step(x, kn, y, float(lrs[max(i - 1, 0)]))
+        for i in range(10):
+            f3(i)
+        ms_x3 = timed(f3) / args.steps * 1e3
+        del eng3
     windows_s = B * world / (ms * 1e-3)
 
     out = None
     if rank == 0:
         flops_k, flops_step = algorithmic_flops(d)
         out = {"metric": METRIC, "value": windows_s * d.T, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "warmup": args.warmup, "prewarm_s": prewarm_s, "prewarm_steps": prewarm_steps, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": workload_text(d, B, args.dtype, args.scale, args.scheme),
                           "window": d.L, "frames_per_window": d.T, "global_batch": B * world, "parallelism": f"dp{world}",
                           **({"dp_backend": dp_backend, "dp_schedule": args.dp_schedule} if (world > 1 or args.force_dp) else {}),
                           **({"dp_note": dp_note} if dp_note else {})},
-               "windows_per_s": windows_s, "samples_per_s": windows_s * d.L, "loss": loss, "ms_per_step_graph": ms_graph,
+               "windows_per_s": windows_s, "samples_per_s": windows_s * d.L, "loss": loss, "ms_per_step_graph": ms_graph, "ms_per_step_f32x3": ms_x3,
                "step_tflops": flops_step / (ms * 1e-3) / 1e12 * world,
                "step_frac_of_fp32_mfma_peak": flops_step / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TF}
         if args.dtype != "f32":
@@ -251,22 +279,33 @@ def main():
             dom = max((k for k in rows if k in flops_k and k not in ("ae_bwd_dec", "ae_bwd_enc")), key=lambda k: rows[k][0])
             ach = flops_k[dom] / (rows[dom][0] * 1e-3) / 1e12
             peak = kernel_peak(dom, args.dtype)
-            # HBM-side bytes per launch of that kernel: PMC counters cannot be collected from inside this process, so
-            # the value is quoted from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
-            # command (tools/profile_gpu.sh -> profiles/*_pmc_traffic.json); null when there is no such file.
+            # HBM-side bytes per launch of that kernel: PMC counters cannot be collected from inside this process, so the value
+            # comes from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS command on THIS build (tools/profile_gpu.sh ->
+            # profiles/*_pmc_traffic*.json, which records the hash of the library sources and the bench arguments it measured):
+            # a file measured on other sources or another workload is refused and traffic stays null.
             traffic, tsrc = None, None
             try:
                 import glob
-                cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-                if cand and args.scale == 1 and B == 256 and args.dtype == "f32":
-                    tj = json.load(open(cand[-1]))
-                    keys = {"ae_bwd": ("ae_bwd_kernel", "ae_bwd_part_kernel"), "ae_fwd": ("ae_fwd_kernel",)}.get(dom, ())
-                    hit = [v for k, v in tj.items() if any(q in k for q in keys)]
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from src_sha import src_sha
+                want = {"src_sha": src_sha(), "dtype": args.dtype, "scale": args.scale, "batch": B, "scheme": args.scheme}
+                keys = {"ae_bwd": ("ae_bwd_kernel", "ae_bwd_part_kernel"), "ae_fwd": ("ae_fwd_kernel",), "analysis_wgrad": ("gemm_tn_kernel", "PlainTN"),
+                        "analysis_fwd": ("AnalysisW",), "ae_wide_bwd": ("ae_bwd_kernel", "DgradStore", "DvStore"), "ae_wide_fwd": ("ae_inner_fwd_kernel", "ActStore", "OutStore")}.get(dom, ())
+                refused = []
+                for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic*.json")), reverse=True):
+                    tj = json.load(open(cand))
+                    meta = tj.get("meta", {})
+                    if any(meta.get(k) != v for k, v in want.items()):
+                        refused.append(os.path.basename(cand)); continue
+                    hit = [v for k, v in tj.get("kernels", {}).items() if any(q in k for q in keys)]
                     if hit and all("FETCH_SIZE_KB" in h and "WRITE_SIZE_KB" in h for h in hit):
-                        traffic = sum(h["FETCH_SIZE_KB"] + h["WRITE_SIZE_KB"] for h in hit) * 1024.0      # both halves of the split backward
-                        tsrc = os.path.basename(cand[-1]) + " (FETCH_SIZE + WRITE_SIZE, KB per dispatch, uncorrected: dword accesses)"
-            except Exception:
-                traffic, tsrc = None, None
+                        traffic = sum(h["FETCH_SIZE_KB"] + h["WRITE_SIZE_KB"] for h in hit) * 1024.0      # all launches of the logical kernel
+                        tsrc = os.path.basename(cand) + " (FETCH_SIZE + WRITE_SIZE per dispatch, rocprofv3 --pmc passes of this command on sources " + want["src_sha"] + "; uncorrected)"
+                        break
+                if traffic is None:
+                    tsrc = f"no PMC file for sources {want['src_sha']} / this workload (refused: {len(refused)} files of other builds or workloads)"
+            except Exception as e:
+                traffic, tsrc = None, f"traffic lookup failed: {e}"
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                "frac": ach / peak, "traffic": traffic, "traffic_source": tsrc,
                                "algorithmic_flops_per_launch": flops_k[dom], "avg_launch_us": rows[dom][0] * 1e3,
@@ -290,13 +329,25 @@ def main():
             if best is None or e < best:
                 best, cores = e, nt
         torch.set_num_threads(cores)
-        n, t1 = 0, time.perf_counter()
-        while n < 40 and (time.perf_counter() - t1) < 15.0:
-            port.step(xc, kc, yc, 1e-5); n += 1
-        tc = (time.perf_counter() - t1) / max(n, 1)
+        # BASELINE.md section 3's protocol: 5 warm-up + 20 timed steps, median (bounded: stops after 30 s of timed work)
+        for _ in range(5):
+            port.step(xc, kc, yc, 1e-5)
+        ts, t_all = [], time.perf_counter()
+        while len(ts) < 20 and (time.perf_counter() - t_all) < 30.0:
+            t1 = time.perf_counter(); port.step(xc, kc, yc, 1e-5); ts.append(time.perf_counter() - t1)
+        tc = float(np.median(ts))
+        cpu_model = "unknown"
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip(); break
+        except OSError:
+            pass
         out["cpu_baseline"] = {"value": Bc * d.T / tc, "unit": "frames/s", "cores": cores, "kind": "port",
-                               "sample": f"{n} train steps of batch {Bc} (BASELINE configs[0] shape), same comp_4c windows, fp32, "
-                                         f"PyTorch-CPU restatement of the reference op sequence, {torch.get_num_threads()} threads",
+                               "cpu_model": cpu_model, "cpu_count": ncpu,
+                               "sample": f"median of {len(ts)} train steps after 5 warm-up steps, batch {Bc} (BASELINE configs[0] shape), same comp_4c windows, fp32, "
+                                         f"PyTorch-CPU restatement of the reference op sequence, {torch.get_num_threads()} threads "
+                                         f"(thread count probed over 8/16/32/64)",
                                "ms_per_step": tc * 1e3, "windows_per_s": Bc / tc}
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

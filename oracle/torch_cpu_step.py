@@ -4,7 +4,7 @@ The reference's op sequence restated with the same PyTorch calls it makes (cls_f
 F.conv1d / F.conv_transpose1d; nn_proc.py:77-126: F.linear + F.elu; nn_proc.py:305-340; loss_functions.py:26-36;
 train.py:131-151: backward, L1 clip of the STFT grads, torch.optim.Adam), so that its CPU timing stands in for
 the reference's own CPU path on the GPU box, where /root/reference does not exist.  Validated against the
-numpy oracle in tests/test_cpu_port.py."""
+numpy oracle in tests/test_abi_and_host.py::test_cpu_port_matches_oracle."""
 import numpy as np
 import torch
 import torch.nn.functional as F

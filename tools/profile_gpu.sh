@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-graph ${BENCH_EXTRA:-}"
+CMD="python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-graph --no-f32x3 ${BENCH_EXTRA:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o st -- $CMD > $OUT/trace_stdout.txt 2>&1
 # counters in their own runs (no tracing domains besides kernel-trace)
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc1 -o st -- $CMD > $OUT/pmc1_stdout.txt 2>&1

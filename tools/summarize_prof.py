@@ -42,4 +42,12 @@ for sub, cname in (("pmc3", "FETCH_SIZE"), ("pmc4", "WRITE_SIZE")):
         for k in acc:
             traffic[k][cname + "_KB"] = acc[k] / cnt[k]
 if traffic:
-    json.dump(traffic, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
+    # meta: which sources and which bench arguments these counters were measured on (bench.py refuses anything else)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from src_sha import src_sha
+    extra = os.environ.get("BENCH_EXTRA", "").split()
+    def opt(name, default):
+        return extra[extra.index(name) + 1] if name in extra else default
+    meta = {"src_sha": src_sha(), "dtype": opt("--dtype", "f32"), "scale": int(opt("--scale", "1")), "batch": int(opt("--batch", "256")),
+            "scheme": opt("--scheme", "lean"), "bench_extra": " ".join(extra)}
+    json.dump({"meta": meta, "kernels": traffic}, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
