@@ -11,6 +11,7 @@
 #include "st_common.h"
 #include "st_gemm.h"
 #include "st_gemm_planes.h"
+#include "st_gemm_tn.h"
 #include "st_misc.h"
 #include "st_ae.h"
 #include "st_ae_wide.h"
@@ -173,6 +174,8 @@ static int g_wg_split = 0;   // ST_PREC_F32X3: weight-gradient GEMMs on the in-k
 static int g_pl_dgrad = 0;   // ST_PREC_F32X3: synthesis data gradient on the plane kernel (measured slower than the fp32 MFMA kernel at B = 256: 57 vs 45 us)   (st_set_tuning(9200 + n))
 static int g_pl_shape = 3;   // analysis plane GEMM tile (ST_PREC_F32X3): 0 = 4 waves x (32 x 96) [91.9 us], 1 = 2 waves x (64 x 96) [117], 2 = 4 waves x (64 x 96) [112],
                              // 3 = 8 waves x (32 x 96) = 256 x 96, one workgroup per CU: a quarter less L2 traffic at the same two waves per SIMD [88.1]   (st_set_tuning(9100 + n))
+static int g_tn128 = 1;      // weight-gradient GEMMs on the 128 x 128-tile kernel (st_gemm_tn.h) where it applies; 0 = gemm_kernel<3, ...> (st_set_tuning(9500), diagnostics)
+static int g_tn_bk = 32;     // its k-tile depth (st_set_tuning(9516 / 9532))
 static int g_frs_nt = 1;     // synthesis frames GEMM against the transposed fold (both operands K-contiguous); 0 = the k-major form (st_set_tuning(9000), diagnostics)
 static int g_xt = 0;       // 1: M/N-contiguous operands staged k-quad-major (st_gemm.h XT; st_set_tuning(7001), diagnostics).  MEASURED SLOWER at B=256 although
                            // conflict-free with a third fewer LDS cycles: analysis wgrad 173 vs 145 us, synthesis frames 63 vs 60 us (16 more prefetch
@@ -183,6 +186,7 @@ static int g_wg_mode_set(int v);
 static int g_wsplit_max = 16, g_wsplit_div = 200, g_an_waves = 4, g_syn_split = 3, g_frs_split = 3, g_wide_fused = 1, g_wsplit_half = 0;      // frames: 3, 4 measured equal, 6 slower (only 66 k-tiles to split)
 extern "C" int st_set_tuning(int bk)
 {
+    if (bk >= 9500) { const int v = bk - 9500; if (v == 16 || v == 32) g_tn_bk = v; else g_tn128 = v; return ST_OK; }
     if (bk >= 9400) { g_pl_bf16 = bk - 9400; return ST_OK; }
     if (bk >= 9300) { g_wg_split = bk - 9300; return ST_OK; }
     if (bk >= 9200) { g_pl_dgrad = bk - 9200; return ST_OK; }
@@ -275,11 +279,21 @@ static int synth_split(int R) { return R >= 4096 ? 1 : g_syn_split; }   // consu
 
 extern "C" int st_ae_fwd_partials(const st_dims* d) { return ae_fwd_grid(d) * ae_fwd_nw(d); }
 extern "C" int st_ola_loss_partials(const st_dims* d) { return d->B * ((d->y + 255) / 256); }
-extern "C" int st_norm_partials(const st_dims* d) { return 2 * d->F; }
+extern "C" int st_norm_partials(const st_dims* d) { return stm::norm_partial_count(d->F, d->N); }
+// k-slices of the 128 x 128-tile weight-gradient GEMM (st_gemm_tn.h): as many as fill the CUs with one workgroup each, never slices
+// shorter than 64 reduction rows
+static int tn_split(int R, int N)
+{
+    const int tiles = (N / 128) * (N / 128);
+    int s = num_cus() / (tiles > 0 ? tiles : 1); if (s > 16) s = 16;
+    const int cap = R / 64; if (s > cap) s = cap;
+    return s < 1 ? 1 : s;
+}
 extern "C" size_t st_wgrad_ws_floats(const st_dims* d)
 {
-    const int s = wgrad_split_tiles(d->B * d->T, st_kp_of(d->F), d->N);
-    return (size_t)s * st_kp_of(d->F) * d->N;
+    int s = wgrad_split_tiles(d->B * d->T, st_kp_of(d->F), d->N);
+    const int s2 = tn_split(d->B * d->T, d->N); if (s2 > s) s = s2;
+    return (size_t)s * st_kp_of(d->F) * d->N + (size_t)64 * 2 * d->N;       // + the Nyquist partials of the 128 x 128-tile form
 }
 extern "C" int st_synth_slabs(const st_dims* d) { return synth_split(synth_live_rows(d)); }
 // split-K slabs of the synthesis FRAMES GEMM (summed by ola_loss_kernel, which takes up to 6; the dgrad slabs are summed
@@ -505,21 +519,49 @@ extern "C" int st_synthesis_dgrad(const st_dims* d, const float* dsyn, const flo
     return synthesis_dgrad_impl(d, dsyn, false, Sfold, dAA, stream);
 }
 
+// The 128 x 128-tile form (st_gemm_tn.h): fp32 products (ST_PREC_F32, and ST_PREC_F32X3 whose weight gradients stay on the fp32 MFMA), operands
+// in the padded workspace layout, N a multiple of 256 (so that the F - 1 non-Nyquist bins of each basis are whole 128-row tiles)
+static bool use_tn128(const st_dims* d, bool padded)
+{
+    const int ht = gemm_ht(d->prec);
+    return g_tn128 && padded && (ht == 0 || (ht == 3 && !g_wg_split)) && d->N % 256 == 0 && g_wg_mode == 0;
+}
+static int wgrad_tn128(const st_dims* d, const stg::TNOperand& ta, const stg::TNOperand& tb, const float* zeros, const stg::RowMap& map, int R,
+                       float* ws, int ns, stm::NyqJob* nyq, void* stream)
+{
+    const int KP = st_kp_of(d->F);
+    const int mh = (d->N / 2) / 128;
+    // Nyquist partials [P][2][N] sit behind the ns slabs (st_wgrad_ws_floats reserves the room)
+    float* part = ws + (size_t)ns * KP * d->N;
+    int P = 0;
+    const unsigned c0 = (unsigned)(d->F - 1), c1 = (unsigned)(KP / 2 + d->F - 1);
+    if (g_tn_bk == 16) ST_TRY((stg::launch_tn128<16>(ta, tb, zeros, map, R, d->N, mh, (unsigned)(KP / 2), d->N, ws, d->N, (size_t)KP * d->N, ns, st_stream(stream), part, c0, c1, &P)));
+    else ST_TRY((stg::launch_tn128<32>(ta, tb, zeros, map, R, d->N, mh, (unsigned)(KP / 2), d->N, ws, d->N, (size_t)KP * d->N, ns, st_stream(stream), part, c0, c1, &P)));
+    nyq->part = part; nyq->P = P; nyq->on = 1;
+    return ST_OK;
+}
 static int synthesis_wgrad_impl(const st_dims* d, const float* AA, const float* dsyn, bool padded, float* ws,
-                                float* gSr, float* gSi, float* norm_partial, void* stream, int* defer_slabs = nullptr)
-{   // defer_slabs: the caller sums the slabs itself (post_ae_kernel); receives the slab count
+                                float* gSr, float* gSi, float* norm_partial, void* stream, int* defer_slabs = nullptr, stm::NyqJob* defer_nyq = nullptr)
+{   // defer_slabs: the caller sums the slabs itself (post_ae_kernel); receives the slab count (and the Nyquist job)
     const int KP = st_kp_of(d->F);
     const stg::RowMap ms = synth_live(d);
     const int R = ms.rows(d->B);
-    const int ns = wgrad_split_tiles(R, KP, d->N);
-    stg::PlainTN al{AA, R, KP, KP, ms};
-    stg::StoreC ep{ws, KP, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
-    if (padded) { stg::FramedTN<true> bl{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms}; ST_GEMM_WG(al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
-    else { stg::FramedTN<false> bl{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms}; ST_GEMM_WG(al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
+    int ns = wgrad_split_tiles(R, KP, d->N);
+    stm::NyqJob nyq{}; nyq.on = 0;
+    const stg::TNOperand ta{AA, (unsigned)(d->OT * KP), (unsigned)KP}, tb{dsyn, (unsigned)(d->y + 2 * d->N), (unsigned)d->H};
+    if (use_tn128(d, padded) && stg::tn128_fits(ta, tb, dsyn, ms, d->N, d->N, (size_t)d->B * d->OT * KP, (size_t)d->B * (d->y + 2 * d->N))) {
+        ns = tn_split(R, d->N);
+        ST_TRY(wgrad_tn128(d, ta, tb, dsyn, ms, R, ws, ns, &nyq, stream));
+    } else {
+        stg::PlainTN al{AA, R, KP, KP, ms};
+        stg::StoreC ep{ws, KP, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
+        if (padded) { stg::FramedTN<true> bl{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms}; ST_GEMM_WG(al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
+        else { stg::FramedTN<false> bl{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms}; ST_GEMM_WG(al, bl, ep, KP, d->N, R, ns, st_stream(stream)); }
+    }
     ST_LAUNCHED("synthesis_wgrad");
-    if (defer_slabs) { *defer_slabs = ns; return ST_OK; }
-    hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(2 * d->F), dim3(256), 0, st_stream(stream),
-                       ws, ns, gSr, gSi, norm_partial, d->N, d->F, KP, 1, 0, (float*)nullptr);
+    if (defer_slabs) { *defer_slabs = ns; if (defer_nyq) *defer_nyq = nyq; return ST_OK; }
+    hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(st_norm_partials(d)), dim3(256), 0, st_stream(stream),
+                       ws, ns, gSr, gSi, norm_partial, d->N, d->F, KP, 1, 0, 2 * d->F, (float*)nullptr, nyq);
     ST_LAUNCHED("synthesis_wgrad_reduce");
     return ST_OK;
 }
@@ -794,13 +836,22 @@ static int analysis_wgrad_impl(const st_dims* d, const float* dG, const float* s
         ns = (g_wsplit_half > 0 && g_wsplit_half < ns) ? g_wsplit_half : best;
     }
     const int M = half < 0 ? KP : KP / 2, m0 = half > 0 ? KP / 2 : 0;
-    stg::PlainTN al{dG + m0, R, KP, M, ma};
-    stg::StoreC ep{ws + (size_t)m0 * d->N, M, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
-    if (padded) { stg::FramedTN<true> bl{sig, d->L, d->H, d->N, R, d->N, 1.0f, ma}; ST_GEMM_WG(al, bl, ep, M, d->N, R, ns, st_stream(stream)); }
-    else { stg::FramedTN<false> bl{sig, d->L, d->H, d->N, R, d->N, in_scale, ma}; ST_GEMM_WG(al, bl, ep, M, d->N, R, ns, st_stream(stream)); }
+    stm::NyqJob nyq{}; nyq.on = 0;
+    const stg::TNOperand ta{dG, (unsigned)(d->T * KP), (unsigned)KP}, tb{sig, (unsigned)(d->L + 2 * d->N), (unsigned)d->H};
+    if (half < 0 && use_tn128(d, padded) && stg::tn128_fits(ta, tb, sig, ma, d->N, d->N, (size_t)d->B * d->T * KP, (size_t)d->B * (d->L + 2 * d->N))) {
+        ns = tn_split(R, d->N);
+        ST_TRY(wgrad_tn128(d, ta, tb, sig, ma, R, ws, ns, &nyq, stream));
+    } else {
+        stg::PlainTN al{dG + m0, R, KP, M, ma};
+        stg::StoreC ep{ws + (size_t)m0 * d->N, M, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
+        if (padded) { stg::FramedTN<true> bl{sig, d->L, d->H, d->N, R, d->N, 1.0f, ma}; ST_GEMM_WG(al, bl, ep, M, d->N, R, ns, st_stream(stream)); }
+        else { stg::FramedTN<false> bl{sig, d->L, d->H, d->N, R, d->N, in_scale, ma}; ST_GEMM_WG(al, bl, ep, M, d->N, R, ns, st_stream(stream)); }
+    }
     ST_LAUNCHED("analysis_wgrad");
-    hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(half < 0 ? 2 * d->F : d->F), dim3(256), 0, st_stream(stream),
-                       ws, ns, gWr, gWi, norm_partial, d->N, d->F, KP, 0, half > 0 ? d->F : 0, stage);
+    // grid: the gradient rows of this call, then (whole tensor / second half) the Nyquist blocks resp. the unused partial slots
+    const int nrows = half < 0 ? 2 * d->F : d->F, extra = half == 0 ? 0 : stm::nyq_blocks(d->N);
+    hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(nrows + extra), dim3(256), 0, st_stream(stream),
+                       ws, ns, gWr, gWi, norm_partial, d->N, d->F, KP, 0, half > 0 ? d->F : 0, nrows, stage, nyq);
     ST_LAUNCHED("analysis_wgrad_reduce");
     return ST_OK;
 }
@@ -1017,14 +1068,15 @@ static int forward_impl(const st_dims* d, const Layout& L, const float* params, 
 // backward of everything behind d syn (workspace holds the forward state): autograd of train.py:138.
 // phase 1 = synthesis dgrad/wgrad + autoencoders + polar backward (fills grads[n_stft/2 ..));
 // phase 2 = analysis weight gradient (fills rows [0,F) of the first two tensors).
-static int backward_syn(const st_dims* d, const Layout& L, float* grads, WS& w, void* stream, int* defer_slabs = nullptr)
+static int backward_syn(const st_dims* d, const Layout& L, float* grads, WS& w, void* stream, int* defer_slabs = nullptr, stm::NyqJob* defer_nyq = nullptr)
 {
     if (use_planes(d) && g_pl_dgrad) ST_TRY(synthesis_dgrad_planes(d, w, stream)); else
     ST_TRY(synthesis_dgrad_impl(d, w.dsyn, true, w.Sfold, w.dAA, stream));
-    return synthesis_wgrad_impl(d, w.AA, w.dsyn, true, w.wg, grads + L.offs[2], grads + L.offs[3], w.norm_s, stream, defer_slabs);
+    return synthesis_wgrad_impl(d, w.AA, w.dsyn, true, w.wg, grads + L.offs[2], grads + L.offs[3], w.norm_s, stream, defer_slabs, defer_nyq);
 }
 static int backward_ae(const st_dims* d, const Layout& L, const float* params, float* grads,
-                       const float* knobs, const float* g_mag_hat, const float* g_mag, float reg_coef, WS& w, void* stream, int syn_slabs = 0)
+                       const float* knobs, const float* g_mag_hat, const float* g_mag, float reg_coef, WS& w, void* stream, int syn_slabs = 0,
+                       const stm::NyqJob* syn_nyq = nullptr)
 {   // syn_slabs > 0: the synthesis weight-gradient slabs in w.wg are still to be summed (done by post_ae_kernel)
     const float* ae_m = params + L.offs[4]; const float* ae_p = params + L.offs[22];
     bool deferred = true;
@@ -1041,16 +1093,17 @@ static int backward_ae(const st_dims* d, const Layout& L, const float* params, f
     a.gx = (L.KP / 2 + 255) / 256; a.sat = gemm_ht(d->prec) == 2 ? 65504.0f : 0.0f;
     a.n_polar = a.gx * d->B * d->T;
     a.wg = w.wg; a.wg_nz = syn_slabs; a.gSr = grads + L.offs[2]; a.gSi = grads + L.offs[3]; a.norm_s = w.norm_s; a.N = d->N;
-    hipLaunchKernelGGL(stm::post_ae_kernel, dim3(a.n_red + a.n_polar + (syn_slabs > 0 ? 2 * d->F : 0)), dim3(256), 0, st_stream(stream), a);
+    a.nyq = stm::NyqJob{}; a.nyq.on = 0; if (syn_nyq) a.nyq = *syn_nyq;
+    hipLaunchKernelGGL(stm::post_ae_kernel, dim3(a.n_red + a.n_polar + (syn_slabs > 0 ? st_norm_partials(d) : 0)), dim3(256), 0, st_stream(stream), a);
     ST_LAUNCHED("post_ae");
     return ST_OK;
 }
 static int backward_p1(const st_dims* d, const Layout& L, const float* params, float* grads,
                        const float* knobs, const float* g_mag_hat, const float* g_mag, float reg_coef, WS& w, void* stream)
 {
-    int syn_slabs = 0;
-    ST_TRY(backward_syn(d, L, grads, w, stream, ae_is_wide(d) ? nullptr : &syn_slabs));      // fused geometries: post_ae_kernel also sums the synthesis slabs
-    return backward_ae(d, L, params, grads, knobs, g_mag_hat, g_mag, reg_coef, w, stream, syn_slabs);
+    int syn_slabs = 0; stm::NyqJob syn_nyq{}; syn_nyq.on = 0;
+    ST_TRY(backward_syn(d, L, grads, w, stream, ae_is_wide(d) ? nullptr : &syn_slabs, &syn_nyq));      // fused geometries: post_ae_kernel also sums the synthesis slabs
+    return backward_ae(d, L, params, grads, knobs, g_mag_hat, g_mag, reg_coef, w, stream, syn_slabs, &syn_nyq);
 }
 static int backward_p2(const st_dims* d, const Layout& L, float* grads, const float* x, WS& w, void* stream, float* stage = nullptr)
 {

@@ -232,11 +232,12 @@ struct AnalysisW {
 #ifndef ST_XCD_SWIZZLE
 #define ST_XCD_SWIZZLE 1
 #endif
-__device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz)
+// nz_: number of z-slices that take part (default: the whole grid; st_gemm_tn.h keeps its last slice out)
+__device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz, const int nz_ = 0)
 {
     bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
 #if ST_XCD_SWIZZLE
-    const int nx = gridDim.x, ny = gridDim.y, nz = gridDim.z;
+    const int nx = gridDim.x, ny = gridDim.y, nz = nz_ > 0 ? nz_ : (int)gridDim.z;
     const int T = nx * ny * nz;
     if (T < 16) return;
     const int L = bx + nx * (by + ny * bz);

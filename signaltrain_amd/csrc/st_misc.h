@@ -222,13 +222,60 @@ polar_bwd_kernel(const float* __restrict__ re, const float* __restrict__ im, con
 // ---------------------------------------------------------------- split-K slab reduce (+ unfold, + |g| sums)
 // ws[nz][KP][N] -> gradient tensors [N,N].  mode 0 (analysis): row k<F -> gRe[k], row half+k -> gIm[k].
 // mode 1 (synthesis): additionally mirror to row N-k with sign +1 (real) / -1 (imag)  (SURVEY.md 8a' "unfold").
+//
+// Round 3: the 128 x 128-tile weight-gradient GEMM (st_gemm_tn.h) covers the 2 (F - 1) = N rows that tile exactly and leaves the
+// two NYQUIST rows (bin F - 1 of the real and of the imaginary basis) to plain FMAs: g[n] = sum_k A[k][col] * B[k][n] is formed as P
+// partial sums over groups of windows by one extra z-slice of workgroups of the GEMM launch itself (st_gemm_tn.h nyq_partial: light
+// vector work beside the MFMA workgroups) and the P partials are added here, in a fixed order.  A ninth tile row for two rows of
+// output would cost the GEMM 11 % more MFMA work; a single-level dot product in this kernel measured 37 us (latency-bound).
+struct NyqJob {
+    const float* part; int P;        // partials [P][2][N] (real row, imaginary row) written by the GEMM launch's extra workgroups
+    int on;                          // 0: the Nyquist rows come from the slabs like every other row (gemm_kernel<3, ...> wrote them)
+};
+constexpr int NYQ_CW = 256;                              // output columns per Nyquist block (64 float4 lanes x 4 partial groups)
+__host__ __device__ static inline int nyq_blocks(int N) { return 2 * ((N + NYQ_CW - 1) / NYQ_CW); }
+__host__ __device__ static inline int norm_partial_count(int F, int N) { return 2 * F + nyq_blocks(N); }
+__device__ __forceinline__ void
+nyquist_chunk(const NyqJob& q, float* __restrict__ gRe, float* __restrict__ gIm, float* __restrict__ norm_partial,
+              const int N, const int F, const int blk, const int slot, float* __restrict__ stage)
+{
+    __shared__ float4 part[4][64];
+    __shared__ float red[4];
+    const int per = (N + NYQ_CW - 1) / NYQ_CW;
+    const bool is_im = blk >= per;
+    const int n4 = (is_im ? blk - per : blk) * (NYQ_CW / 4) + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (4 * n4 < N)
+        for (int p = grp; p < q.P; p += 4) {
+            const float4 u = *reinterpret_cast<const float4*>(q.part + ((size_t)p * 2 + (is_im ? 1 : 0)) * N + 4 * n4);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+    part[grp][threadIdx.x & 63] = v;
+    __syncthreads();
+    float na = 0.f;
+    if (threadIdx.x < 64 && 4 * n4 < N) {
+        const float4 a = part[0][threadIdx.x], b = part[1][threadIdx.x], c = part[2][threadIdx.x], d = part[3][threadIdx.x];
+        v = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+        *reinterpret_cast<float4*>((is_im ? gIm : gRe) + (size_t)(F - 1) * N + 4 * n4) = v;
+        if (stage) *reinterpret_cast<float4*>(stage + (size_t)((is_im ? F : 0) + F - 1) * N + 4 * n4) = v;
+        na = fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
+    }
+    const float tot = block_sum<4>(na, red);
+    if (threadIdx.x == 0) norm_partial[slot] = tot;
+}
 __device__ __forceinline__ void
 wgrad_reduce_block(const float* __restrict__ ws, int nz, float* __restrict__ gRe, float* __restrict__ gIm,
-                   float* __restrict__ norm_partial, int N, int F, int KP, int mode, const int row, float* __restrict__ stage)
+                   float* __restrict__ norm_partial, int N, int F, int KP, int mode, const int row, float* __restrict__ stage, const NyqJob& nyq)
 {
-    __shared__ float red[4];                          // row: 0 .. 2F-1 : [0,F) real rows, [F,2F) imag rows
+    __shared__ float red[4];                          // row: 0 .. 2F-1 : [0,F) real rows, [F,2F) imag rows; >= 2F: Nyquist blocks
+    if (row >= 2 * F) {
+        if (nyq.on) nyquist_chunk(nyq, gRe, gIm, norm_partial, N, F, row - 2 * F, row, stage);
+        else if (threadIdx.x == 0) norm_partial[row] = 0.f;      // the partial count is fixed (norm_partial_count): unused slots read as 0
+        return;
+    }
     const bool is_im = row >= F;
     const int k = is_im ? row - F : row;
+    if (nyq.on && k == F - 1) { if (threadIdx.x == 0) norm_partial[row] = 0.f; return; }
     const int src = is_im ? KP / 2 + k : k;
     float* g = is_im ? gIm : gRe;
     const bool mirror = mode == 1 && k >= 1 && k <= F - 2;
@@ -253,11 +300,15 @@ wgrad_reduce_block(const float* __restrict__ ws, int nz, float* __restrict__ gRe
     const float tot = block_sum<4>(na, red);
     if (threadIdx.x == 0) norm_partial[row] = tot;
 }
+// grid: norm_partial_count(F, N) blocks (row0 = 0), or F + nyq_blocks(N) for one half (row0 = 0 / F: the staged data-parallel schedule,
+// never with the Nyquist form)
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ ws, int nz, float* __restrict__ gRe, float* __restrict__ gIm,
-                    float* __restrict__ norm_partial, int N, int F, int KP, int mode, int row0, float* __restrict__ stage)
+                    float* __restrict__ norm_partial, int N, int F, int KP, int mode, int row0, int nrows, float* __restrict__ stage, const NyqJob nyq)
 {
-    wgrad_reduce_block(ws, nz, gRe, gIm, norm_partial, N, F, KP, mode, blockIdx.x + row0, stage);       // row0: imag half only
+    // blocks [0, nrows): gradient rows row0 ..; the rest: the Nyquist / unused partial slots 2F ..
+    const int row = (int)blockIdx.x < nrows ? (int)blockIdx.x + row0 : 2 * F + ((int)blockIdx.x - nrows);
+    wgrad_reduce_block(ws, nz, gRe, gIm, norm_partial, N, F, KP, mode, row, stage, nyq);
 }
 
 // L1 norm partials of an arbitrary flat range (data-parallel path: norm of the *reduced* gradient).
@@ -311,7 +362,7 @@ struct PostAeArgs {
     const float* re; const float* im; const float* dmag; const float* dphs; const float* g_mag; float* dG; int F, KP, gx; float sat;
     // third role (fused step): the split-K slabs of the synthesis weight gradient, written before the autoencoder backward, are summed,
     // un-folded and normed here instead of in a launch of their own
-    int n_polar; const float* wg; int wg_nz; float* gSr; float* gSi; float* norm_s; int N;
+    int n_polar; const float* wg; int wg_nz; float* gSr; float* gSi; float* norm_s; int N; NyqJob nyq;
 };
 __global__ void __launch_bounds__(256)
 post_ae_kernel(const PostAeArgs a)
@@ -319,7 +370,7 @@ post_ae_kernel(const PostAeArgs a)
     const int blk = blockIdx.x;
     if (blk < a.n_red) { const int ae = blk / a.n_red_x; ae_grad_reduce_block(a.ws, a.nparts, a.PG, a.g_m, a.g_p, blk - ae * a.n_red_x, ae); }
     else if (blk < a.n_red + a.n_polar) { const int q = blk - a.n_red, r = q / a.gx; polar_bwd_block(a.re, a.im, a.dmag, a.dphs, a.g_mag, a.dG, a.F, a.KP, a.sat, q - r * a.gx, r); }
-    else wgrad_reduce_block(a.wg, a.wg_nz, a.gSr, a.gSi, a.norm_s, a.N, a.F, a.KP, 1, blk - a.n_red - a.n_polar, nullptr);
+    else wgrad_reduce_block(a.wg, a.wg_nz, a.gSr, a.gSi, a.norm_s, a.N, a.F, a.KP, 1, blk - a.n_red - a.n_polar, nullptr, a.nyq);
 }
 
 // ---------------------------------------------------------------- scalars
