@@ -374,8 +374,10 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
               float* __restrict__ mag_hat, float* __restrict__ phs_hat, float* __restrict__ AA,
               float* __restrict__ reg_partial,
               const int B, const int T, const int OT, const int F, const int K, const int KP, const float expfac,
-              float* __restrict__ h4x = nullptr)      // optional: the 16-wide code h4 of both nets, [net][group][lane] float4 in D layout, for
+              float* __restrict__ h4x = nullptr,      // optional: the 16-wide code h4 of both nets, [net][group][lane] float4 in D layout, for
                                                       // the split backward (st_ae_split.h); mag_hat == NULL: h4 only (no other output is written)
+              unsigned short* __restrict__ AA16 = nullptr, const int aa_ht = 0)      // 16-bit GEMM configurations (st_gemm16.h): the spectra go out rounded to
+                                                      // the operand type (1 bf16 / 2 fp16) INSTEAD of fp32 -- their only consumers are the two synthesis GEMMs
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -440,8 +442,13 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
                     stg32(phs_hat, ST_MUL24(ro, F) + (unsigned)f, ph);
                     reg += fabsf(mh * wf);
                 }
-                stg32(AA, ST_MUL24(ro, KP) + (unsigned)f, mh * cs);           // f < FP always: pads get zeros
-                stg32(AA, ST_MUL24(ro, KP) + (unsigned)(FP + f), mh * sn);
+                if (AA16) {                                                   // wave-uniform
+                    AA16[ST_MUL24(ro, KP) + (unsigned)f] = st_to_h16(mh * cs, aa_ht);
+                    AA16[ST_MUL24(ro, KP) + (unsigned)(FP + f)] = st_to_h16(mh * sn, aa_ht);
+                } else {
+                    stg32(AA, ST_MUL24(ro, KP) + (unsigned)f, mh * cs);       // f < FP always: pads get zeros
+                    stg32(AA, ST_MUL24(ro, KP) + (unsigned)(FP + f), mh * sn);
+                }
             }
         }
         fwd_mask(nxt, K, fn < F, T, OT, g); cur = nxt;

@@ -154,7 +154,8 @@ wide_in_kernel(const float* __restrict__ mag, const float* __restrict__ phs, con
 // (loss_functions.py:33-36).  One partial per workgroup (st_ae_fwd_partials() of them), fixed summation order.
 __global__ void __launch_bounds__(256)
 wide_polar_out_kernel(const float* __restrict__ mag_hat, const float* __restrict__ phs_hat, float* __restrict__ AA,
-                      float* __restrict__ reg_partial, int B, int OT, int F, int FP, int KP, float expfac)
+                      float* __restrict__ reg_partial, int B, int OT, int F, int FP, int KP, float expfac,
+                      unsigned short* __restrict__ AA16 = nullptr, int aa_ht = 0)      // 16-bit GEMM configurations: see sta::ae_fwd_kernel
 {
     __shared__ float red[256];
     const size_t n = (size_t)B * OT * FP;
@@ -168,7 +169,8 @@ wide_polar_out_kernel(const float* __restrict__ mag_hat, const float* __restrict
             re = mh * cs; im = mh * sn;
             reg += fabsf(mh * expf(expfac * (float)f));
         }
-        AA[ro * KP + f] = re; AA[ro * KP + FP + f] = im;
+        if (AA16) { AA16[ro * KP + f] = st_to_h16(re, aa_ht); AA16[ro * KP + FP + f] = st_to_h16(im, aa_ht); }
+        else { AA[ro * KP + f] = re; AA[ro * KP + FP + f] = im; }
     }
     red[threadIdx.x] = reg; __syncthreads();
     for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }

@@ -12,6 +12,7 @@
 #include "st_gemm.h"
 #include "st_gemm_planes.h"
 #include "st_gemm_tn.h"
+#include "st_gemm16.h"
 #include "st_misc.h"
 #include "st_ae.h"
 #include "st_ae_wide.h"
@@ -174,6 +175,9 @@ static int g_wg_split = 0;   // ST_PREC_F32X3: weight-gradient GEMMs on the in-k
 static int g_pl_dgrad = 0;   // ST_PREC_F32X3: synthesis data gradient on the plane kernel (measured slower than the fp32 MFMA kernel at B = 256: 57 vs 45 us)   (st_set_tuning(9200 + n))
 static int g_pl_shape = 3;   // analysis plane GEMM tile (ST_PREC_F32X3): 0 = 4 waves x (32 x 96) [91.9 us], 1 = 2 waves x (64 x 96) [117], 2 = 4 waves x (64 x 96) [112],
                              // 3 = 8 waves x (32 x 96) = 256 x 96, one workgroup per CU: a quarter less L2 traffic at the same two waves per SIMD [88.1]   (st_set_tuning(9100 + n))
+static int g_g16 = 1;        // 16-bit configurations: the fused step's GEMMs on pre-rounded 16-bit operands (st_gemm16.h); 0 = gemm_half_kernel on fp32 operands (st_set_tuning(9600), diagnostics)
+static int g_g16_bk = 64;    // k-tile depth of its TN kernel (st_set_tuning(9632 / 9664))
+static int g_g16_split = 0;  // k-slices of its weight-gradient GEMMs (0: by residency; st_set_tuning(9700 + n))
 static int g_tn128 = 1;      // weight-gradient GEMMs on the 128 x 128-tile kernel (st_gemm_tn.h) where it applies; 0 = gemm_kernel<3, ...> (st_set_tuning(9500), diagnostics)
 static int g_tn_bk = 32;     // its k-tile depth (st_set_tuning(9516 / 9532))
 static int g_frs_nt = 1;     // synthesis frames GEMM against the transposed fold (both operands K-contiguous); 0 = the k-major form (st_set_tuning(9000), diagnostics)
@@ -186,6 +190,8 @@ static int g_wg_mode_set(int v);
 static int g_wsplit_max = 16, g_wsplit_div = 200, g_an_waves = 4, g_syn_split = 3, g_frs_split = 3, g_wide_fused = 1, g_wsplit_half = 0;      // frames: 3, 4 measured equal, 6 slower (only 66 k-tiles to split)
 extern "C" int st_set_tuning(int bk)
 {
+    if (bk >= 9700) { g_g16_split = bk - 9700; return ST_OK; }
+    if (bk >= 9600) { const int v = bk - 9600; if (v == 32 || v == 64) g_g16_bk = v; else g_g16 = v; return ST_OK; }
     if (bk >= 9500) { const int v = bk - 9500; if (v == 16 || v == 32) g_tn_bk = v; else g_tn128 = v; return ST_OK; }
     if (bk >= 9400) { g_pl_bf16 = bk - 9400; return ST_OK; }
     if (bk >= 9300) { g_wg_split = bk - 9300; return ST_OK; }
@@ -365,7 +371,7 @@ extern "C" size_t st_ae_bwd_ws_floats(const st_dims* d)
 }
 static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, const float* phs, const float* knobs,
                        const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA, float* reg_partial,
-                       WideWS& w, void* stream);
+                       WideWS& w, void* stream, unsigned short* AA16 = nullptr);
 
 // ------------------------------------------------------------------------------ per-op entry points
 // `padded`: sig is the workspace copy [B][N + L + N] (zero margins, input scale applied) written by pad_scale_kernel.
@@ -404,17 +410,28 @@ static int pad_scale(const float* in, float* out, int B, int Ls, int pad, float 
     return ST_OK;
 }
 
+// AA16 != NULL (fused step of the 16-bit GEMM configurations): the spectra are written rounded to the operand type, not as fp32
+static int ae_fwd_impl(const st_dims* d, const float* mag, const float* phs, const float* knobs,
+                       const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA,
+                       float* reg_partial, float* ws, void* stream, unsigned short* AA16 = nullptr);
 extern "C" int st_ae_fwd(const st_dims* d, const float* mag, const float* phs, const float* knobs,
                          const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA,
                          float* reg_partial, float* ws, void* stream)
 {
+    return ae_fwd_impl(d, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, AA, reg_partial, ws, stream);
+}
+static int ae_fwd_impl(const st_dims* d, const float* mag, const float* phs, const float* knobs,
+                       const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA,
+                       float* reg_partial, float* ws, void* stream, unsigned short* AA16)
+{
     Layout L; ST_TRY(make_layout(d, &L));
+    const int aa_ht = AA16 ? gemm_ht(d->prec) : 0;
     ST_REQ(mag && phs && knobs && ae_m && ae_p && ((mag_hat && phs_hat && AA) || (!mag_hat && !phs_hat && !AA && ws)), "st_ae_fwd: null pointer");
     if (ae_is_wide(d)) {
         ST_REQ(mag_hat, "st_ae_fwd: the code-only pass exists for the fused geometries only");
         ST_REQ(ws, "st_ae_fwd: this geometry (T=%d, OT=%d) needs st_ae_fwd_ws_floats() floats of workspace", d->T, d->OT);
         WideWS w; wide_carve(d, ws, &w);
-        return ae_wide_fwd(d, L, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, AA, reg_partial, w, stream);
+        return ae_wide_fwd(d, L, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, AA, reg_partial, w, stream, AA16);
     }
     ST_REQ((size_t)d->B * d->T * d->F < ((size_t)1 << 30) && (size_t)d->B * d->OT * L.KP < ((size_t)1 << 30),
            "st_ae_fwd: batch too large for the kernel's 32-bit element offsets (B=%d)", d->B);
@@ -423,7 +440,7 @@ extern "C" int st_ae_fwd(const st_dims* d, const float* mag, const float* phs, c
 #define ST_AE_FWD_LAUNCH(HT_) do { ST_DYN_LDS((sta::ae_fwd_kernel<AE_FWD_NW, HT_>)); \
         hipLaunchKernelGGL((sta::ae_fwd_kernel<AE_FWD_NW, HT_>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, st_stream(stream), \
                            mag, phs, knobs, ae_m, ae_p, L.go, mag_hat, phs_hat, AA, reg_partial, \
-                           d->B, d->T, d->OT, d->F, d->K, L.KP, expfac, ws); } while (0)
+                           d->B, d->T, d->OT, d->F, d->K, L.KP, expfac, ws, AA16, aa_ht); } while (0)
     switch (ae_ht(d->prec)) {
     case 1: ST_AE_FWD_LAUNCH(1); break;
     case 2: ST_AE_FWD_LAUNCH(2); break;
@@ -431,7 +448,7 @@ extern "C" int st_ae_fwd(const st_dims* d, const float* mag, const float* phs, c
         if (ae_fwd_nw(d) == 11) {
             ST_DYN_LDS((sta::ae_fwd_kernel<11, 0>));
             hipLaunchKernelGGL((sta::ae_fwd_kernel<11, 0>), dim3(ae_fwd_grid(d)), dim3(11 * 64), lds, st_stream(stream),
-                               mag, phs, knobs, ae_m, ae_p, L.go, mag_hat, phs_hat, AA, reg_partial, d->B, d->T, d->OT, d->F, d->K, L.KP, expfac, ws);
+                               mag, phs, knobs, ae_m, ae_p, L.go, mag_hat, phs_hat, AA, reg_partial, d->B, d->T, d->OT, d->F, d->K, L.KP, expfac, ws, AA16, aa_ht);
         } else ST_AE_FWD_LAUNCH(0);
     }
 #undef ST_AE_FWD_LAUNCH
@@ -476,12 +493,12 @@ static int synthesis_frames_impl(const st_dims* d, const float* AA, const float*
 }
 
 static int ola_loss_impl(const st_dims* d, const float* frs, const float* x, const float* y_true,
-                         float* y_hat, float* dsyn, int dsyn_pad, float* loss_partial, void* stream)
+                         float* y_hat, float* dsyn, int dsyn_pad, float* loss_partial, void* stream, unsigned short* dsyn16 = nullptr)
 {
     const float inv = loss_scale_of(d) / ((float)d->B * (float)d->y);     // d loss / d y_hat, times the loss scale (train.py:134-135)
     hipLaunchKernelGGL(stm::ola_loss_kernel, dim3((d->y + 255) / 256, d->B), dim3(256), 0, st_stream(stream),
                        frs, x, y_true, y_hat, dsyn, loss_partial, d->L, d->N, d->H, d->OT, d->y, inv,
-                       st_synth_frame_slabs(d), (size_t)d->B * d->OT * d->N, dsyn_pad);
+                       st_synth_frame_slabs(d), (size_t)d->B * d->OT * d->N, dsyn_pad, dsyn ? dsyn16 : nullptr, dsyn16 ? gemm_ht(d->prec) : 0);
     ST_LAUNCHED("ola_loss");
     return ST_OK;
 }
@@ -582,7 +599,7 @@ static inline int wide_half_type(const st_dims* d, int R) { return R % 32 == 0 ?
                            else stg::launch<2, 16>(__VA_ARGS__, g_dbg); } while (0)
 static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, const float* phs, const float* knobs,
                        const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA, float* reg_partial,
-                       WideWS& w, void* stream)
+                       WideWS& w, void* stream, unsigned short* AA16)
 {
     hipStream_t s = st_stream(stream);
     const int FP = L.KP / 2, F = d->F, T = d->T, OT = d->OT, R = (int)w.R, Tp = w.Tp;
@@ -630,7 +647,7 @@ static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, cons
     if (AA) {
         const float expfac = (float)(7.0 / d->F);
         hipLaunchKernelGGL(stw::wide_polar_out_kernel, dim3(st_ae_fwd_partials(d)), dim3(256), 0, s, mag_hat, phs_hat, AA, reg_partial,
-                           d->B, OT, F, FP, L.KP, expfac);
+                           d->B, OT, F, FP, L.KP, expfac, AA16, AA16 ? gemm_ht(d->prec) : 0);
         ST_LAUNCHED("ae_wide_polar_out");
     }
     return ST_OK;
@@ -928,6 +945,11 @@ struct WS {
     float *wg, *aews, *loss_p, *reg_p, *norm_a, *norm_s, *norm_e;
     // bfloat16 planes of the operands that are written once per step (st_gemm_planes.h): [3][same layout as the fp32 tensor]
     unsigned short *pl_W, *pl_Sfold, *pl_SfoldT;      // k-chunk-major: [K / 16][rows][3][16]
+    // 16-bit GEMM operands (st_gemm16.h), each written by its producer in the layout of its fp32 counterpart: padded x/2, the analysis
+    // bases as rows (bin, re | im) [2F][N], the folded synthesis bases [KP][N] and [N][KP], the spectra, the padded d syn, d G
+    unsigned short *xp16, *W16, *Sfold16, *SfoldT16, *AA16, *dsyn16, *dG16;
+    bool g16;          // this call runs the 16-bit operand pipeline (set by the entry point after carve(): use_g16(); the autograd entries and the
+                       // four-stage schedule keep fp32 operands + gemm_half_kernel)
     size_t bytes;
 };
 static void carve(const st_dims* d, void* base, WS* w)
@@ -948,6 +970,10 @@ static void carve(const st_dims* d, void* base, WS* w)
     w->norm_a = take(st_norm_partials(d)); w->norm_s = take(st_norm_partials(d)); w->norm_e = take(NORM_E_PARTIALS);
     auto take16 = [&](size_t n) { return reinterpret_cast<unsigned short*>(take((n + 1) / 2)); };      // always sized for three planes: 19 MB
     w->pl_W = take16((size_t)3 * 2 * F * N); w->pl_Sfold = take16((size_t)3 * KP * N); w->pl_SfoldT = take16((size_t)3 * KP * N);
+    // (+ 256: the 128-wide tiles of the TN kernel read up to 96 elements past the last row of an M/N-contiguous operand; masked outputs)
+    w->xp16 = take16((size_t)d->B * (d->L + 2 * d->N) + 256); w->W16 = take16((size_t)2 * F * N); w->Sfold16 = take16(KP * N); w->SfoldT16 = take16(KP * N);
+    w->AA16 = take16(RO * KP + 256); w->dsyn16 = take16((size_t)d->B * (d->y + 2 * d->N) + 256); w->dG16 = take16(RT * KP + 256);
+    w->g16 = false;
     w->bytes = off * sizeof(float);
 }
 extern "C" size_t st_workspace_bytes(const st_dims* d)
@@ -1027,6 +1053,79 @@ static int synthesis_dgrad_planes(const st_dims* d, WS& w, void* stream)
     ST_LAUNCHED("synthesis_dgrad"); return ST_OK;
 }
 
+// ------------------------------------------------------------------------------ the 16-bit operand pipeline (st_gemm16.h)
+static bool use_g16(const st_dims* d)
+{
+    const int ht = gemm_ht(d->prec);
+    return g_g16 && (ht == 1 || ht == 2) && !g_pl_bf16 && d->N % 128 == 0 && num_cus() > 0;
+}
+#define ST_G16(CALL_) do { if (gemm_ht(d->prec) == 2) ST_TRY((stg::CALL_<2>)); else ST_TRY((stg::CALL_<1>)); } while (0)
+static int analysis_fwd16(const st_dims* d, WS& w, float* re, float* im, float* mag, float* phs, void* stream)
+{
+    const stg::RowMap map = stg::live_frames(d->T, d->H, d->N, d->N, d->L);
+    const int R = map.rows(d->B);
+    const stg::Rows16 ra = stg::rows16(w.xp16, (unsigned)(d->L + 2 * d->N), (unsigned)d->H, map, R);
+    const stg::Rows16 rb = stg::rows16_plain(w.W16, (unsigned)d->N, 2 * d->F);
+    stg::PolarStore ep{re, im, mag, phs, R, d->F, map};
+    if (gemm_ht(d->prec) == 2) ST_TRY((stg::launch16_nt<2>(ra, rb, ep, R, 2 * d->F, d->N, 1, st_stream(stream))));
+    else ST_TRY((stg::launch16_nt<1>(ra, rb, ep, R, 2 * d->F, d->N, 1, st_stream(stream))));
+    ST_LAUNCHED("analysis_fwd"); return ST_OK;
+}
+static int synthesis_frames16(const st_dims* d, WS& w, void* stream)
+{
+    const int KP = st_kp_of(d->F);
+    const stg::RowMap ms = synth_live(d);
+    const int R = ms.rows(d->B);
+    const stg::Rows16 ra = stg::rows16(w.AA16, (unsigned)(d->OT * KP), (unsigned)KP, ms, R);
+    const stg::Rows16 rb = stg::rows16_plain(w.SfoldT16, (unsigned)KP, d->N);
+    stg::StoreC ep{w.frs, R, d->N, d->N, (size_t)d->B * d->OT * d->N, ms};
+    const int ns = frames_split(R);
+    if (gemm_ht(d->prec) == 2) ST_TRY((stg::launch16_nt<2>(ra, rb, ep, R, d->N, KP, ns, st_stream(stream))));
+    else ST_TRY((stg::launch16_nt<1>(ra, rb, ep, R, d->N, KP, ns, st_stream(stream))));
+    ST_LAUNCHED("synthesis_frames"); return ST_OK;
+}
+static int synthesis_dgrad16(const st_dims* d, WS& w, void* stream)
+{
+    const int KP = st_kp_of(d->F);
+    const stg::RowMap ms = synth_live(d);
+    const int R = ms.rows(d->B);
+    const stg::Rows16 ra = stg::rows16(w.dsyn16, (unsigned)(d->y + 2 * d->N), (unsigned)d->H, ms, R);
+    const stg::Rows16 rb = stg::rows16_plain(w.Sfold16, (unsigned)d->N, KP);
+    stg::StoreC ep{w.dAA, R, KP, KP, (size_t)d->B * d->OT * KP, ms};
+    const int ns = R >= 4096 ? 1 : synth_split(R);
+    if (gemm_ht(d->prec) == 2) ST_TRY((stg::launch16_nt<2>(ra, rb, ep, R, KP, d->N, ns, st_stream(stream))));
+    else ST_TRY((stg::launch16_nt<1>(ra, rb, ep, R, KP, d->N, ns, st_stream(stream))));
+    ST_LAUNCHED("synthesis_dgrad"); return ST_OK;
+}
+// k-slices of a 16-bit weight-gradient GEMM: about two workgroups per CU (their time is staging, not matrix work), never slices under
+// 128 reduction rows, never more slabs than the workspace holds
+static int g16_wsplit(const st_dims* d, int R)
+{
+    const int KP = st_kp_of(d->F), tiles = ((KP + 127) / 128) * (d->N / 128);
+    int s = g_g16_split > 0 ? g_g16_split : (2 * num_cus()) / (tiles > 0 ? tiles : 1);
+    const int cap = R / 128; if (s > cap) s = cap;
+    const int room = (int)(st_wgrad_ws_floats(d) / ((size_t)KP * d->N)); if (s > room) s = room;
+    return s < 1 ? 1 : s;
+}
+// A: [rows (b, t)][KP] 16-bit (d G or the spectra), B: frames of a padded 16-bit signal whose first N elements are zero (the block of zeros)
+static int wgrad16(const st_dims* d, const unsigned short* A, unsigned SA1, const unsigned short* Bsig, unsigned SB1, const stg::RowMap& map, int R,
+                   float* slabs, int ns, void* stream)
+{
+    const int KP = st_kp_of(d->F);
+    const unsigned short* lo = A < Bsig ? A : Bsig;
+    ST_REQ((size_t)(A - lo) + (size_t)R / map.Tv * SA1 + 256 < ((size_t)1 << 30) && (size_t)(Bsig - lo) + (size_t)R / map.Tv * SB1 + 256 < ((size_t)1 << 30) && map.Tv >= 2 &&
+           SA1 < (1u << 23) && SB1 < (1u << 23), "16-bit weight-gradient GEMM: operands out of the 32-bit / 24-bit addressing range (B=%d)", d->B);
+    stg::TN16Job j;
+    j.base = lo; j.a0 = (unsigned)(A - lo); j.b0 = (unsigned)(Bsig - lo); j.zero = j.b0;
+    j.SA1 = SA1; j.SA2 = (unsigned)KP; j.SB1 = SB1; j.SB2 = (unsigned)d->H;
+    j.magic = map.magic; j.Tv = map.Tv; j.t_lo = map.t_lo; j.K = R;
+    stg::StoreC ep{slabs, KP, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
+    const int ht = gemm_ht(d->prec);
+    if (g_g16_bk == 32) { if (ht == 2) ST_TRY((stg::launch16_tn<2, 32>(j, ep, KP, d->N, ns, st_stream(stream)))); else ST_TRY((stg::launch16_tn<1, 32>(j, ep, KP, d->N, ns, st_stream(stream)))); }
+    else { if (ht == 2) ST_TRY((stg::launch16_tn<2, 64>(j, ep, KP, d->N, ns, st_stream(stream)))); else ST_TRY((stg::launch16_tn<1, 64>(j, ep, KP, d->N, ns, st_stream(stream)))); }
+    return ST_OK;
+}
+
 // ------------------------------------------------------------------------------ fused entry points
 static int forward_impl(const st_dims* d, const Layout& L, const float* params, const float* x, const float* knobs,
                         const float* y_true, float* y_hat, float* mag, float* mag_hat, WS& w, bool save, void* stream)
@@ -1044,21 +1143,26 @@ static int forward_impl(const st_dims* d, const Layout& L, const float* params, 
         a.Sr = Sr; a.Si = Si; a.Sfold = w.Sfold; a.SfoldT = w.SfoldT; a.N = d->N; a.F = d->F; a.KP = L.KP; a.n_fold = (L.KP / 32) * (d->N / 32);
         a.re = save ? w.re : nullptr; a.im = save ? w.im : nullptr; a.mag = w.mag; a.phs = w.phs; a.T = d->T; a.t_lo = map.t_lo; a.Tv = map.Tv;
         const int n_dead = d->B * (d->T - map.Tv);
-        hipLaunchKernelGGL(stm::prep_kernel, dim3(a.n_pad + a.n_fold + n_dead), dim3(256), 0, st_stream(stream), a);
+        a.n_dead = n_dead; a.ht = w.g16 ? gemm_ht(d->prec) : 0; a.n_w16 = 0;
+        a.xp16 = w.xp16; a.Sfold16 = w.Sfold16; a.SfoldT16 = w.SfoldT16; a.W16 = w.W16; a.Wr = Wr; a.Wi = Wi;
+        if (a.ht) a.n_w16 = (int)(((size_t)2 * d->F * (d->N / 4) + 255) / 256);
+        hipLaunchKernelGGL(stm::prep_kernel, dim3(a.n_pad + a.n_fold + n_dead + a.n_w16), dim3(256), 0, st_stream(stream), a);
         ST_LAUNCHED("prep");
     }
-    const bool planes = use_planes(d);
-    if (planes) {
+    const bool planes = use_planes(d) && !w.g16;
+    if (w.g16) ST_TRY(analysis_fwd16(d, w, save ? w.re : nullptr, save ? w.im : nullptr, w.mag, w.phs, stream));
+    else if (planes) {
         ST_TRY(planes_prepare(d, Wr, Wi, w, stream));
         ST_TRY(analysis_fwd_planes(d, w, save ? w.re : nullptr, save ? w.im : nullptr, w.mag, w.phs, stream));
     } else
     ST_TRY(analysis_fwd_impl(d, w.xp, true, Wr, Wi, 1.0f, save ? w.re : nullptr, save ? w.im : nullptr, w.mag, w.phs, stream, true));
-    ST_TRY(st_ae_fwd(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.AA, w.reg_p,
-                     (ae_is_wide(d) || (save && ae_use_split(d))) ? w.aews : nullptr, stream));     // fused geometries: the code h4 is kept for the split backward
+    ST_TRY(ae_fwd_impl(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.AA, w.reg_p,
+                       (ae_is_wide(d) || (save && ae_use_split(d))) ? w.aews : nullptr, stream, w.g16 ? w.AA16 : nullptr));     // fused geometries: the code h4 is kept for the split backward
+    if (w.g16) ST_TRY(synthesis_frames16(d, w, stream)); else
     if (planes) ST_TRY(synthesis_frames_planes(d, w, stream)); else
     ST_TRY(synthesis_frames_impl(d, w.AA, w.Sfold, w.SfoldT, w.frs, stream));
     ST_TRY(ola_loss_impl(d, w.frs, x, y_true, y_hat ? y_hat : w.y_hat, (save && y_true) ? w.dsyn : nullptr, d->N,
-                         y_true ? w.loss_p : nullptr, stream));
+                         y_true ? w.loss_p : nullptr, stream, w.g16 ? w.dsyn16 : nullptr));
     const size_t nm = (size_t)d->B * d->T * d->F * sizeof(float), nh = (size_t)d->B * d->OT * d->F * sizeof(float);
     if (mag && hipMemcpyAsync(mag, w.mag, nm, hipMemcpyDeviceToDevice, st_stream(stream)) != hipSuccess) return st_fail(ST_ERR_LAUNCH, "copy mag");
     if (mag_hat && hipMemcpyAsync(mag_hat, w.mag_hat, nh, hipMemcpyDeviceToDevice, st_stream(stream)) != hipSuccess) return st_fail(ST_ERR_LAUNCH, "copy mag_hat");
@@ -1070,6 +1174,19 @@ static int forward_impl(const st_dims* d, const Layout& L, const float* params, 
 // phase 2 = analysis weight gradient (fills rows [0,F) of the first two tensors).
 static int backward_syn(const st_dims* d, const Layout& L, float* grads, WS& w, void* stream, int* defer_slabs = nullptr, stm::NyqJob* defer_nyq = nullptr)
 {
+    if (w.g16) {
+        ST_TRY(synthesis_dgrad16(d, w, stream));
+        const stg::RowMap ms = synth_live(d);
+        const int R = ms.rows(d->B), KP = st_kp_of(d->F), ns = g16_wsplit(d, R);
+        ST_TRY(wgrad16(d, w.AA16, (unsigned)(d->OT * KP), w.dsyn16, (unsigned)(d->y + 2 * d->N), ms, R, w.wg, ns, stream));
+        ST_LAUNCHED("synthesis_wgrad");
+        if (defer_slabs) { *defer_slabs = ns; if (defer_nyq) { *defer_nyq = stm::NyqJob{}; defer_nyq->on = 0; } return ST_OK; }
+        stm::NyqJob nq{}; nq.on = 0;
+        hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(st_norm_partials(d)), dim3(256), 0, st_stream(stream),
+                           w.wg, ns, grads + L.offs[2], grads + L.offs[3], w.norm_s, d->N, d->F, KP, 1, 0, 2 * d->F, (float*)nullptr, nq);
+        ST_LAUNCHED("synthesis_wgrad_reduce");
+        return ST_OK;
+    }
     if (use_planes(d) && g_pl_dgrad) ST_TRY(synthesis_dgrad_planes(d, w, stream)); else
     ST_TRY(synthesis_dgrad_impl(d, w.dsyn, true, w.Sfold, w.dAA, stream));
     return synthesis_wgrad_impl(d, w.AA, w.dsyn, true, w.wg, grads + L.offs[2], grads + L.offs[3], w.norm_s, stream, defer_slabs, defer_nyq);
@@ -1084,6 +1201,12 @@ static int backward_ae(const st_dims* d, const Layout& L, const float* params, f
                        w.aews, grads + L.offs[4], grads + L.offs[22], true, stream, &deferred));      // the forward left its AE state in w.aews
     if (!deferred) {
         ST_REQ(syn_slabs == 0, "internal: deferred synthesis slabs on a path without post_ae_kernel");
+        if (w.g16) {                       // wide geometries: the polar backward is its own launch; d G goes out in the GEMM operand type
+            const int R = d->B * d->T, KP = st_kp_of(d->F);
+            hipLaunchKernelGGL(stm::polar_bwd_kernel, dim3((KP / 2 + 255) / 256, R), dim3(256), 0, st_stream(stream),
+                               w.re, w.im, w.dmag, w.dphs, g_mag, (float*)nullptr, R, d->F, KP, gemm_ht(d->prec) == 2 ? 65504.0f : 0.0f, w.dG16, gemm_ht(d->prec));
+            ST_LAUNCHED("polar_bwd"); return ST_OK;
+        }
         return st_polar_bwd(d, w.re, w.im, w.dmag, w.dphs, g_mag, w.dG, stream);
     }
     stm::PostAeArgs a;
@@ -1094,6 +1217,8 @@ static int backward_ae(const st_dims* d, const Layout& L, const float* params, f
     a.n_polar = a.gx * d->B * d->T;
     a.wg = w.wg; a.wg_nz = syn_slabs; a.gSr = grads + L.offs[2]; a.gSi = grads + L.offs[3]; a.norm_s = w.norm_s; a.N = d->N;
     a.nyq = stm::NyqJob{}; a.nyq.on = 0; if (syn_nyq) a.nyq = *syn_nyq;
+    a.dG16 = nullptr; a.ht = 0;
+    if (w.g16) { a.dG16 = w.dG16; a.ht = gemm_ht(d->prec); a.dG = nullptr; }      // the analysis weight-gradient GEMM is the only consumer on this path
     hipLaunchKernelGGL(stm::post_ae_kernel, dim3(a.n_red + a.n_polar + (syn_slabs > 0 ? st_norm_partials(d) : 0)), dim3(256), 0, st_stream(stream), a);
     ST_LAUNCHED("post_ae");
     return ST_OK;
@@ -1108,6 +1233,17 @@ static int backward_p1(const st_dims* d, const Layout& L, const float* params, f
 static int backward_p2(const st_dims* d, const Layout& L, float* grads, const float* x, WS& w, void* stream, float* stage = nullptr)
 {
     (void)x;
+    if (w.g16) {
+        const stg::RowMap ma = stg::live_frames(d->T, d->H, d->N, d->N, d->L);
+        const int R = ma.rows(d->B), KP = st_kp_of(d->F), ns = g16_wsplit(d, R);
+        ST_TRY(wgrad16(d, w.dG16, (unsigned)(d->T * KP), w.xp16, (unsigned)(d->L + 2 * d->N), ma, R, w.wg, ns, stream));
+        ST_LAUNCHED("analysis_wgrad");
+        stm::NyqJob nq{}; nq.on = 0;
+        hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(st_norm_partials(d)), dim3(256), 0, st_stream(stream),
+                           w.wg, ns, grads + L.offs[0], grads + L.offs[1], w.norm_a, d->N, d->F, KP, 0, 0, 2 * d->F, stage, nq);
+        ST_LAUNCHED("analysis_wgrad_reduce");
+        return ST_OK;
+    }
     return analysis_wgrad_impl(d, w.dG, w.xp, true, 1.0f, w.wg, grads + L.offs[0], grads + L.offs[1], w.norm_a, stream, -1, stage);
 }
 static int backward_impl(const st_dims* d, const Layout& L, const float* params, float* grads, const float* x,
@@ -1143,6 +1279,7 @@ extern "C" int st_loss_backward(const st_dims* d, const float* params, float* gr
     Layout L; ST_TRY(make_layout(d, &L));
     ST_REQ(params && grads && x && knobs && y_true && ws && scalars, "st_loss_backward: null pointer");
     WS w; carve(d, ws, &w);
+    w.g16 = use_g16(d);
     prof_mark("begin", stream);
     ST_TRY(forward_impl(d, L, params, x, knobs, y_true, y_hat, mag, mag_hat, w, true, stream));
     const float reg_coef = loss_scale_of(d) * (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);   // loss_functions.py:36
@@ -1160,6 +1297,7 @@ extern "C" int st_loss_backward_p1(const st_dims* d, const float* params, float*
     Layout L; ST_TRY(make_layout(d, &L));
     ST_REQ(params && grads && x && knobs && y_true && ws, "st_loss_backward_p1: null pointer");
     WS w; carve(d, ws, &w);
+    w.g16 = use_g16(d);
     prof_mark("begin", stream);
     ST_TRY(forward_impl(d, L, params, x, knobs, y_true, nullptr, nullptr, nullptr, w, true, stream));
     const float reg_coef = loss_scale_of(d) * (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);
@@ -1170,6 +1308,7 @@ extern "C" int st_loss_backward_p2(const st_dims* d, float* grads, const float* 
     Layout L; ST_TRY(make_layout(d, &L));
     ST_REQ(grads && x && ws && scalars, "st_loss_backward_p2: null pointer");
     WS w; carve(d, ws, &w);
+    w.g16 = use_g16(d);
     ST_TRY(backward_p2(d, L, grads, x, w, stream));
     return st_finalize_scalars(d, w.loss_p, w.reg_p, w.norm_a, w.norm_s, 1.0f / loss_scale_of(d), scalars, stream);
 }
@@ -1182,6 +1321,7 @@ extern "C" int st_loss_backward_p2_staged(const st_dims* d, float* grads, float*
     Layout L; ST_TRY(make_layout(d, &L));
     ST_REQ(grads && stage && x && ws && scalars, "st_loss_backward_p2_staged: null pointer");
     WS w; carve(d, ws, &w);
+    w.g16 = use_g16(d);
     (void)scalars;      // the loss scalars are published by st_dp_clip_adam (no single-block finalize between this GEMM and the all-reduce)
     return backward_p2(d, L, grads, x, w, stream, stage);
 }
@@ -1241,6 +1381,7 @@ static int train_step_impl(const st_dims* d, float* params, float* grads, float*
     Layout L; ST_TRY(make_layout(d, &L));
     ST_REQ(params && grads && x && knobs && y_true && ws && scalars, "st_train_step: null pointer");
     WS w; carve(d, ws, &w);
+    w.g16 = use_g16(d);
     prof_mark("begin", stream);
     ST_TRY(forward_impl(d, L, params, x, knobs, y_true, nullptr, nullptr, nullptr, w, true, stream));
     const float reg_coef = loss_scale_of(d) * (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);   // loss_functions.py:36
@@ -1264,6 +1405,7 @@ extern "C" int st_dp_clip_adam(const st_dims* d, float* params, float* grads, fl
     Layout L; ST_TRY(make_layout(d, &L));
     ST_REQ(params && grads && m && v && ws && scalars, "st_dp_clip_adam: null pointer");
     WS w; carve(d, ws, &w);
+    w.g16 = use_g16(d);
     // L1 norm of the all-reduced, 1/world-scaled STFT gradient: identical on every rank, no second collective
     const int np = st_norm_partials(d);
     const int64_t n_clip = d->clip_all ? L.total : L.n_stft;
@@ -1507,6 +1649,7 @@ extern "C" int st_dp_train_step(st_dp* p, const st_dims* d, float* params, float
     //   analysis bases            -- the 2F live rows, packed (4.2 MB), after the last GEMM of the step: the exposed one.
     {
         WS w; carve(d, ws, &w);
+        w.g16 = use_g16(d);
         prof_mark("begin", stream);
         ST_TRY(forward_impl(d, L, params, x, knobs, y_true, nullptr, nullptr, nullptr, w, true, stream));
         const float reg_coef = loss_scale_of(d) * (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);
@@ -1549,6 +1692,13 @@ static int attr_prepare(const st_dims* d)
         else ST_PREP3((sta::ae_bwd_kernel<AE_BWD_NW, false, false, 0, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 1, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 2, 0>));
     }
 #undef ST_PREP3
+    if (use_g16(d)) {           // st_gemm16.h: 72 / 80 KB of LDS with 64-deep k-tiles
+        if (gemm_ht(d->prec) == 2) {
+            ST_DYN_LDS((stg::gemm16_nt_kernel<2, 64, stg::PolarStore>)); ST_DYN_LDS((stg::gemm16_nt_kernel<2, 64, stg::StoreC>)); ST_DYN_LDS((stg::gemm16_tn_kernel<2, 64>));
+        } else {
+            ST_DYN_LDS((stg::gemm16_nt_kernel<1, 64, stg::PolarStore>)); ST_DYN_LDS((stg::gemm16_nt_kernel<1, 64, stg::StoreC>)); ST_DYN_LDS((stg::gemm16_tn_kernel<1, 64>));
+        }
+    }
     if (use_planes(d)) {        // the 4-wave plane GEMM carries 67 KB of LDS (st_gemm_planes.h)
         ST_DYN_LDS((stg::gemm_planes_kernel<4, 3, 1, stg::FramedNT<true>, stg::ChunkP, stg::PolarStore>));
         ST_DYN_LDS((stg::gemm_planes_kernel<8, 3, 1, stg::FramedNT<true>, stg::ChunkP, stg::PolarStore>));

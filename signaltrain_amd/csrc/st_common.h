@@ -89,3 +89,18 @@ __device__ __forceinline__ f32x4 elu4(const f32x4 a)
 }
 // ELU'(a) through h = ELU(a):  1 if h > 0 else h + 1 (= exp(a)).
 __device__ __forceinline__ float elu_grad_from_out(float h) { return h > 0.f ? 1.0f : h + 1.0f; }
+
+// ---------------------------------------------------------------- 16-bit GEMM operands (st_gemm16.h)
+// Round an fp32 value to the 16-bit operand type of the call: ht = 1 bfloat16 (round to nearest even), 2 = IEEE float16 (round to
+// nearest even, overflow -> inf: the gradient norm then turns non-finite and the optimizer kernel skips the step).  The SAME
+// conversions gemm_half_kernel applied while staging fp32 operands (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32) -- and the oracle's
+// bf16_round / fp16_round -- so storing an operand pre-rounded changes no value.
+__device__ __forceinline__ unsigned short st_to_h16(const float x, const int ht)
+{
+    if (ht == 2) { const _Float16 h = (_Float16)x; return __builtin_bit_cast(unsigned short, h); }
+    const __bf16 b = (__bf16)x; return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ uint2 st_to_h16x4(const float4 v, const int ht)
+{
+    return make_uint2((unsigned)st_to_h16(v.x, ht) | ((unsigned)st_to_h16(v.y, ht) << 16), (unsigned)st_to_h16(v.z, ht) | ((unsigned)st_to_h16(v.w, ht) << 16));
+}

@@ -257,7 +257,8 @@ __device__ __forceinline__ int d_row(int i, int lane) { return (i & 3) + 8 * (i 
 
 struct StoreC {       // out[(z*slab) + full_row*ld + col]; z = blockIdx.z (split-K slab)
     float* out; int M, Nc, ld; size_t slab; RowMap map;
-    __device__ void operator()(int m0, int n0, const f32x16 (&acc)[NJ]) const {
+    template <int NJX>                                            // NJX = 32-column blocks per wave (3: the 32 x 96 strips; 2: st_gemm16.h)
+    __device__ void operator()(int m0, int n0, const f32x16 (&acc)[NJX]) const {
         const int lane = threadIdx.x & 63;
         int tbx, tby, tbz; xcd_tile(tbx, tby, tbz);               // the split-K slice this workgroup computed (see xcd_tile)
         float* o = out + (size_t)tbz * slab;
@@ -267,7 +268,7 @@ struct StoreC {       // out[(z*slab) + full_row*ld + col]; z = blockIdx.z (spli
             if (row < M) {
                 float* orow = o + (size_t)map.full(row) * ld;
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
+                for (int j = 0; j < NJX; ++j) {
                     const int col = n0 + 32 * j + (lane & 31);
                     if (col < Nc) orow[col] = acc[j][i];
                 }
@@ -302,7 +303,8 @@ struct BiasStore {    // out[row*ld + col] = acc + bias[col]   (Conv1d bias; bia
 // of row r and the odd lane that of row r+1, so every lane does ONE sqrt and ONE atan2 per register pair.
 struct PolarStore {
     float* re; float* im; float* mag; float* phs; int R, F; RowMap map;
-    __device__ void operator()(int m0, int n0, const f32x16 (&acc)[NJ]) const {
+    template <int NJX>
+    __device__ void operator()(int m0, int n0, const f32x16 (&acc)[NJX]) const {
         const int lane = threadIdx.x & 63;
         const bool odd = lane & 1;
 #pragma unroll
@@ -310,7 +312,7 @@ struct PolarStore {
             const int row = m0 + d_row(i + (odd ? 1 : 0), lane);
             const size_t rbase = (size_t)(row < R ? map.full(row) : 0) * F;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
+            for (int j = 0; j < NJX; ++j) {
                 const int bin = (n0 + 32 * j + (lane & 31)) >> 1;
                 const float v0 = acc[j][i], v1 = acc[j][i + 1];
                 const float got = __shfl_xor(odd ? v0 : v1, 1);      // even lane receives im(row r), odd lane re(row r+1)

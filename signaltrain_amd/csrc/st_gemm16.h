@@ -1,0 +1,271 @@
+// st_gemm16.h -- the STFT GEMMs of the 16-bit configurations on PRE-ROUNDED 16-bit operands (gfx950), round 3.
+//
+// BASELINE.json configs[2], [3] (bf16) and [4] (fp16): every GEMM operand is stored in 16 bits by the kernel that produces it
+// (prep_kernel: padded waveform, analysis bases, folded synthesis bases in both orientations; ae_fwd: the spectra AA; ola_loss: d syn;
+// post_ae: d G) -- the SAME values the rounding oracle uses (round each GEMM operand to bf16 / fp16, multiply exactly, accumulate in
+// fp32), so parity is that of gemm_half_kernel, which converted fp32 operands while staging them (SQ_INSTS_VALU / SQ_INSTS_MFMA = 13,
+// analysis forward 42 us = 13 % of the bf16 peak at B = 256).  Here no conversion and no fp32 byte is left in any k-loop:
+//   * workgroup tile 128 x 128, four waves as 2 x 2, wave tile 64 x 64 = 2 x 2 accumulators of v_mfma_f32_32x32x16_{bf16,f16}
+//     (one 16-byte LDS read per operand block per MFMA k-step: 4 reads per 4 MFMAs; the 32 x 96 strips needed 4 per 3 and, at two
+//     workgroups per CU, more LDS bandwidth than the CU has);
+//   * K-contiguous ("NT") operands: row-major LDS tiles [row][BK + 8] (pitch 144 / 80 bytes: the 16 lanes of a ds_read_b128 service
+//     group hit 16 distinct 16-byte slots), a global dwordx4 = 8 k is one ds_write_b128;
+//   * M/N-contiguous ("TN") operands of the weight-gradient GEMMs: k-major tiles [k][128 + 32], a global dwordx4 = 8 rows at one k is
+//     one ds_write_b128, and the MFMA fragments come out of ds_read_b64_tr_b16 -- the LDS transpose read of gfx950: a 16-lane group
+//     reads a [4 k][16 rows] block, lane i gets the four k of row i -- two reads per operand block per k-step, no register transposes
+//     (gemm_half_kernel transposed 4 x 4 fp32 micro-tiles with VALU moves);
+//   * row offsets of NT operands are per-thread constants, the k offset rides in the scalar base; TN operands split k -> (window, frame)
+//     once per load pass with 24-bit multiplies.
+#pragma once
+#include "st_gemm.h"
+
+namespace stg {
+
+typedef unsigned short h16_t;
+typedef short st_s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned st_u32x4 __attribute__((ext_vector_type(4)));      // native vector (HIP's uint4 struct in a captured array ends up in scratch)
+
+// NT-type operand: row r -> elements base[off(r) + k], k contiguous.  off = b * S1 + t * S2 with (b, t) = RowMap::split(min(r, R - 1))
+// (magic == 0: b = r, t = 0).  Rows past R are clamped: their products only reach outputs the epilogue masks.
+struct Rows16 { const h16_t* base; unsigned S1, S2, magic; int Tv, t_lo, R; };
+__device__ __forceinline__ unsigned rows16_off(const Rows16& o, const int r)
+{
+    const unsigned rc = (unsigned)(r < o.R ? r : o.R - 1);
+    const unsigned b = o.magic ? __umulhi(rc, o.magic) : rc;
+    const unsigned t = o.magic ? (unsigned)o.t_lo + (rc - b * (unsigned)o.Tv) : 0u;
+    return b * o.S1 + t * o.S2;
+}
+static inline Rows16 rows16(const h16_t* base, unsigned S1, unsigned S2, const RowMap& m, int R) { return Rows16{base, S1, S2, m.magic, m.Tv, m.t_lo, R}; }
+static inline Rows16 rows16_plain(const h16_t* base, unsigned ld, int R) { return Rows16{base, ld, 0u, 0u, 1, 0, R}; }
+
+template <int HT> struct frag16 { typedef st_bf16x8 type; };
+template <> struct frag16<2> { typedef st_f16x8 type; };
+template <int HT>
+__device__ __forceinline__ f32x16 mfma16x(const typename frag16<HT>::type a, const typename frag16<HT>::type b, const f32x16 c)
+{
+    if constexpr (HT == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------ NT x NT:  C[m][n] = sum_k A[m][k] * B[n][k]
+template <int HT, int BKH, class EPI>
+__global__ void __launch_bounds__(256)
+gemm16_nt_kernel(const Rows16 ra, const Rows16 rb, const EPI epi, const int K, const int ksplit)
+{
+    typedef typename frag16<HT>::type frag_t;
+    constexpr int LD = BKH + 8;                          // elements per LDS row
+    constexpr int TS = 128 * LD;                         // elements per operand tile
+    constexpr int TPR = BKH / 8, RP = 256 / TPR, NP = 128 / RP, KS = BKH / 16;
+    extern __shared__ __attribute__((aligned(16))) h16_t g16_lds[];      // As[2][128][LD] | Bs[2][128][LD]
+    h16_t* const As = g16_lds;
+    h16_t* const Bs = g16_lds + 2 * TS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    int tbx, tby, tbz; xcd_tile(tbx, tby, tbz);
+    const int m_blk = tby * 128, n_blk = tbx * 128;
+    const int k_begin = tbz * ksplit;
+    const int k_end = (k_begin + ksplit < K) ? k_begin + ksplit : K;
+
+    const int lr = tid / TPR, lk = (tid % TPR) * 8;
+    unsigned ao[NP], bo[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        ao[p] = 2u * (rows16_off(ra, m_blk + lr + RP * p) + (unsigned)lk);       // BYTE offsets
+        bo[p] = 2u * (rows16_off(rb, n_blk + lr + RP * p) + (unsigned)lk);
+    }
+    st_u32x4 va[NP], vb[NP];
+    auto gload = [&](const int kt) {
+        const char* pa = reinterpret_cast<const char*>(ra.base) + 2 * (size_t)kt;     // wave-uniform: the k offset rides in the scalar base
+        const char* pb = reinterpret_cast<const char*>(rb.base) + 2 * (size_t)kt;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            va[p] = *reinterpret_cast<const st_u32x4*>(pa + ao[p]);
+            vb[p] = *reinterpret_cast<const st_u32x4*>(pb + bo[p]);
+        }
+    };
+    auto lstore = [&](const int buf) {
+        h16_t* as = As + buf * TS + lr * LD + lk;
+        h16_t* bs = Bs + buf * TS + lr * LD + lk;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            *reinterpret_cast<st_u32x4*>(as + p * RP * LD) = va[p];
+            *reinterpret_cast<st_u32x4*>(bs + p * RP * LD) = vb[p];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mi][nj][i] = 0.f;
+
+    if (k_begin < k_end) {
+        gload(k_begin);
+        lstore(0);
+        __syncthreads();
+        int cur = 0;
+        const int g = lane >> 5, l31 = lane & 31;
+        const int a_off = (wm * 64 + l31) * LD + 8 * g;
+        const int b_off = (wn * 64 + l31) * LD + 8 * g;
+        for (int kt = k_begin; kt < k_end; kt += BKH) {
+            const bool more = kt + BKH < k_end;
+            gload(more ? kt + BKH : kt);                     // branch-free body (the last iteration re-loads its own tile)
+            __builtin_amdgcn_sched_barrier(0);
+            const h16_t* as = As + cur * TS + a_off;
+            const h16_t* bs = Bs + cur * TS + b_off;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const frag_t a0 = *reinterpret_cast<const frag_t*>(as + 16 * s), a1 = *reinterpret_cast<const frag_t*>(as + 32 * LD + 16 * s);
+                const frag_t b0 = *reinterpret_cast<const frag_t*>(bs + 16 * s), b1 = *reinterpret_cast<const frag_t*>(bs + 32 * LD + 16 * s);
+                acc[0][0] = mfma16x<HT>(a0, b0, acc[0][0]);
+                acc[0][1] = mfma16x<HT>(a0, b1, acc[0][1]);
+                acc[1][0] = mfma16x<HT>(a1, b0, acc[1][0]);
+                acc[1][1] = mfma16x<HT>(a1, b1, acc[1][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            lstore(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) epi(m_blk + wm * 64 + 32 * mi, n_blk + wn * 64, acc[mi]);
+}
+
+// ------------------------------------------------------------------------------ TN x TN:  C[m][n] = sum_k A[k][m] * B[k][n]
+// (the weight-gradient GEMMs: k = compact live frame row; A = d G / AA, B = frames of the padded waveform / of d syn, all 16-bit)
+struct TN16Job {
+    const h16_t* base;             // common base of both operands and the zero block (element offsets below, < 2^30)
+    unsigned a0, b0, zero;         // origins; >= 128 + 32 zero elements for A rows past K
+    unsigned SA1, SA2, SB1, SB2;   // element (k, c): a0 + b * SA1 + t * SA2 + c  /  b0 + b * SB1 + t * SB2 + c,  (b, t) = split(k)
+    unsigned magic; int Tv, t_lo, K;
+};
+template <int HT, int BKH>
+__global__ void __launch_bounds__(256)
+gemm16_tn_kernel(const TN16Job j, const StoreC epi, const int ksplit)
+{
+    typedef typename frag16<HT>::type frag_t;
+    constexpr int LD = 128 + 32;                          // elements per k row: 320 bytes -- the 4 k rows x 2 row-halves a 32-lane half reads
+                                                          // with ds_read_b64_tr_b16 land on 8 distinct 32-byte bank groups
+    constexpr int TS = BKH * LD;
+    constexpr int NP = BKH / 16, KS = BKH / 16;           // 16 threads x 8 elements per k row, 16 k rows per load pass
+    extern __shared__ __attribute__((aligned(16))) h16_t g16_lds[];      // As[2][BKH][LD] | Bs[2][BKH][LD]
+    h16_t* const As = g16_lds;
+    h16_t* const Bs = g16_lds + 2 * TS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    int tbx, tby, tbz; xcd_tile(tbx, tby, tbz);
+    const int m_blk = tby * 128, n_blk = tbx * 128;
+    const int k_begin = tbz * ksplit;
+    const int k_end = (k_begin + ksplit < j.K) ? k_begin + ksplit : j.K;
+
+    const int lk = tid >> 4, lc = (tid & 15) * 8;
+    const unsigned la = 2u * (j.a0 + (unsigned)m_blk + (unsigned)lc), lb = 2u * (j.b0 + (unsigned)n_blk + (unsigned)lc), lz = 2u * (j.zero + (unsigned)lc);
+    const unsigned sa1 = 2u * j.SA1, sa2 = 2u * j.SA2, sb1 = 2u * j.SB1, sb2 = 2u * j.SB2;
+    st_u32x4 va[NP], vb[NP];
+    auto ld = [&](const unsigned byte_off) { return *reinterpret_cast<const st_u32x4*>(reinterpret_cast<const char*>(j.base) + byte_off); };
+    auto gload = [&](const int kt) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int k = kt + lk + 16 * p;
+            const unsigned kc = (unsigned)(k < j.K ? k : j.K - 1);
+            const unsigned b = __umulhi(kc, j.magic);
+            const unsigned t = (unsigned)j.t_lo + kc - __umul24(b, (unsigned)j.Tv);
+            const unsigned oa = __umul24(b, sa1) + __umul24(t, sa2) + la;
+            const unsigned ob = __umul24(b, sb1) + __umul24(t, sb2) + lb;
+            const unsigned live = (unsigned)((k - j.K) >> 31);
+            va[p] = ld((oa & live) | (lz & ~live));
+            vb[p] = ld(ob);
+        }
+    };
+    auto lstore = [&](const int buf) {
+        h16_t* as = As + buf * TS + lk * LD + lc;
+        h16_t* bs = Bs + buf * TS + lk * LD + lc;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            *reinterpret_cast<st_u32x4*>(as + p * 16 * LD) = va[p];
+            *reinterpret_cast<st_u32x4*>(bs + p * 16 * LD) = vb[p];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mi][nj][i] = 0.f;
+
+    if (k_begin < k_end) {
+        gload(k_begin);
+        lstore(0);
+        __syncthreads();
+        int cur = 0;
+        // transpose read: lane l = 16 G + i supplies the address of 4 contiguous elements of k row (i >> 2), columns 4 (i & 3) .. + 3 of the
+        // [4 k][16 rows] block its 16-lane group reads, and receives the 4 k of column i.  MFMA lane l is row (l & 31) = 16 (G & 1) + i,
+        // k group (l >> 5) = G >> 1: block origin k = 16 s + 8 (G >> 1) + 4 q, row = 32 blk + 16 (G & 1).
+        const int G = lane >> 4, i16 = lane & 15;
+        const int t_off = (8 * (G >> 1) + (i16 >> 2)) * LD + 16 * (G & 1) + 4 * (i16 & 3);
+        const int a_off = t_off + wm * 64, b_off = t_off + wn * 64;
+        for (int kt = k_begin; kt < k_end; kt += BKH) {
+            const bool more = kt + BKH < k_end;
+            gload(more ? kt + BKH : kt);
+            __builtin_amdgcn_sched_barrier(0);
+            const h16_t* as = As + cur * TS + a_off;
+            const h16_t* bs = Bs + cur * TS + b_off;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                union { st_s16x4 h[2]; frag_t f; } a[2], b[2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        a[x].h[q] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((st_s16x4 __attribute__((address_space(3)))*)(as + (16 * s + 4 * q) * LD + 32 * x));
+                        b[x].h[q] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((st_s16x4 __attribute__((address_space(3)))*)(bs + (16 * s + 4 * q) * LD + 32 * x));
+                    }
+                acc[0][0] = mfma16x<HT>(a[0].f, b[0].f, acc[0][0]);
+                acc[0][1] = mfma16x<HT>(a[0].f, b[1].f, acc[0][1]);
+                acc[1][0] = mfma16x<HT>(a[1].f, b[0].f, acc[1][0]);
+                acc[1][1] = mfma16x<HT>(a[1].f, b[1].f, acc[1][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            lstore(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) epi(m_blk + wm * 64 + 32 * mi, n_blk + wn * 64, acc[mi]);
+}
+
+// ------------------------------------------------------------------------------ host side
+template <int HT, class EPI>
+static inline int launch16_nt(const Rows16& ra, const Rows16& rb, const EPI& epi, int M, int Nc, int K, int nsplit, hipStream_t s)
+{
+    dim3 grid((Nc + 127) / 128, (M + 127) / 128, nsplit > 1 ? nsplit : 1);
+    const bool k64 = K % 64 == 0 && (nsplit <= 1 || (K / 64) % nsplit == 0);
+    if (k64) {
+        int ksplit = K; if (nsplit > 1) ksplit = st_round_up((K + nsplit - 1) / nsplit, 64);
+        constexpr size_t lds = (size_t)4 * 128 * (64 + 8) * sizeof(h16_t);
+        const int rc = ::ensure_dyn_lds((const void*)gemm16_nt_kernel<HT, 64, EPI>, "gemm16_nt_kernel"); if (rc) return rc;
+        hipLaunchKernelGGL((gemm16_nt_kernel<HT, 64, EPI>), grid, dim3(256), lds, s, ra, rb, epi, K, ksplit);
+    } else {
+        int ksplit = K; if (nsplit > 1) ksplit = st_round_up((K + nsplit - 1) / nsplit, 32);
+        constexpr size_t lds = (size_t)4 * 128 * (32 + 8) * sizeof(h16_t);
+        hipLaunchKernelGGL((gemm16_nt_kernel<HT, 32, EPI>), grid, dim3(256), lds, s, ra, rb, epi, K, ksplit);
+    }
+    return 0;
+}
+template <int HT, int BKH>
+static inline int launch16_tn(const TN16Job& j, const StoreC& epi, int M, int Nc, int nsplit, hipStream_t s)
+{
+    int ksplit = j.K; if (nsplit > 1) ksplit = st_round_up((j.K + nsplit - 1) / nsplit, BKH);
+    constexpr size_t lds = (size_t)4 * BKH * (128 + 32) * sizeof(h16_t);
+    if (lds > 65536) { const int rc = ::ensure_dyn_lds((const void*)gemm16_tn_kernel<HT, BKH>, "gemm16_tn_kernel"); if (rc) return rc; }
+    hipLaunchKernelGGL((gemm16_tn_kernel<HT, BKH>), dim3((Nc + 127) / 128, (M + 127) / 128, nsplit > 1 ? nsplit : 1), dim3(256), lds, s, j, epi, ksplit);
+    return 0;
+}
+
+}  // namespace stg

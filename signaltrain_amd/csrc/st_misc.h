@@ -63,7 +63,8 @@ zero_dead_frames_kernel(float* __restrict__ a0, float* __restrict__ a1, float* _
 __global__ void __launch_bounds__(256)
 ola_loss_kernel(const float* __restrict__ frs, const float* __restrict__ x, const float* __restrict__ y_true,
                 float* __restrict__ y_hat, float* __restrict__ dsyn, float* __restrict__ loss_partial,
-                int L, int N, int H, int OT, int ysz, float inv_count, int nslab, size_t slab, int dsyn_pad)
+                int L, int N, int H, int OT, int ysz, float inv_count, int nslab, size_t slab, int dsyn_pad,
+                unsigned short* __restrict__ dsyn16 = nullptr, int ht = 0)      // 16-bit configurations: d syn goes out rounded to the GEMM operand type (same padded layout), INSTEAD of fp32
 {
     __shared__ float red[4];
     const int b = blockIdx.y;
@@ -92,13 +93,17 @@ ola_loss_kernel(const float* __restrict__ frs, const float* __restrict__ x, cons
             // a + log1p(e^-2a) - ln2 form loses ~1e-7 absolute per sample, i.e. 1e-3 of a 1e-4 mean); large |d|: overflow-free form
             if (a < 8.0f) { const float u = expm1f(0.5f * a); const float sh = 0.5f * (u + u / (u + 1.0f)); lc = log1pf(2.0f * sh * sh); }
             else lc = a + log1pf(__expf(-2.0f * a)) - 0.69314718056f;
-            if (dsyn) dsyn[(size_t)b * (ysz + 2 * dsyn_pad) + dsyn_pad + j] = -2.0f * tanhf(dlt) * inv_count;   // dsyn_pad > 0: padded layout for the framed loaders
+            const float ds = -2.0f * tanhf(dlt) * inv_count;
+            if (dsyn16) dsyn16[(size_t)b * (ysz + 2 * dsyn_pad) + dsyn_pad + j] = st_to_h16(ds, ht);
+            else if (dsyn) dsyn[(size_t)b * (ysz + 2 * dsyn_pad) + dsyn_pad + j] = ds;   // dsyn_pad > 0: padded layout for the framed loaders
         }
     }
-    if (dsyn && dsyn_pad > 0) {                  // zero margins of the padded gradient signal (2*pad floats per window)
-        float* row = dsyn + (size_t)b * (ysz + 2 * dsyn_pad);
-        for (int m = blockIdx.x * 256 + threadIdx.x; m < 2 * dsyn_pad; m += gridDim.x * 256)
-            row[m < dsyn_pad ? m : ysz + m] = 0.f;
+    if ((dsyn || dsyn16) && dsyn_pad > 0) {      // zero margins of the padded gradient signal (2*pad floats per window)
+        const size_t ro = (size_t)b * (ysz + 2 * dsyn_pad);
+        for (int m = blockIdx.x * 256 + threadIdx.x; m < 2 * dsyn_pad; m += gridDim.x * 256) {
+            if (dsyn16) dsyn16[ro + (m < dsyn_pad ? m : ysz + m)] = 0;
+            else dsyn[ro + (m < dsyn_pad ? m : ysz + m)] = 0.f;
+        }
     }
     if (loss_partial) {
         const float tot = block_sum<4>(lc, red);
@@ -109,16 +114,18 @@ ola_loss_kernel(const float* __restrict__ frs, const float* __restrict__ x, cons
 // out[b][pad + Ls + pad] = zero margins | s * in[b][Ls]: the padded, pre-scaled signal the framed GEMM loaders read
 // (x/2 of nn_proc.py:307 with the Conv1d padding of cls_fe_dft.py:28-31 materialised once per step, 10 MB at B=256).
 __device__ __forceinline__ void pad_scale_block(const float* __restrict__ in, float* __restrict__ out, const int Ls, const int pad, const float s,
-                                                const int bx, const int nbx, const int b)
+                                                const int bx, const int nbx, const int b, unsigned short* __restrict__ out16 = nullptr, const int ht = 0)
 {
     const int Lp4 = (Ls + 2 * pad) / 4;
     const float4* src = reinterpret_cast<const float4*>(in + (size_t)b * Ls);
     float4* dst = reinterpret_cast<float4*>(out + (size_t)b * (Ls + 2 * pad));
+    uint2* dst16 = reinterpret_cast<uint2*>(out16 + (size_t)b * (Ls + 2 * pad));
     for (int i = bx * 256 + threadIdx.x; i < Lp4; i += nbx * 256) {
         const int j = i - pad / 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (j >= 0 && j < Ls / 4) { v = src[j]; v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
-        dst[i] = v;
+        if (out16) dst16[i] = st_to_h16x4(v, ht);      // 16-bit configurations: the GEMM operand, rounded once here (x/2 is exact in either type's exponent range)
+        else dst[i] = v;
     }
 }
 __global__ void __launch_bounds__(256)
@@ -135,12 +142,16 @@ struct PrepArgs {
     const float* x; float* xp; int Ls, pad; float scale; int nbx, n_pad;
     const float* Sr; const float* Si; float* Sfold; float* SfoldT; int N, F, KP, n_fold;
     float *re, *im, *mag, *phs; int T, t_lo, Tv;
+    // 16-bit configurations (st_gemm16.h): ht = 1 bf16 / 2 fp16 -- the padded waveform and both folds go out in 16 bits INSTEAD of fp32,
+    // and n_w16 more blocks write the F used rows of the analysis bases as rows (bin, re | im) interleaved: W16[2 bin + part][N]
+    int ht; unsigned short *xp16, *Sfold16, *SfoldT16, *W16; const float* Wr; const float* Wi; int n_w16, n_dead;
 };
 // 32 x 32 tile of the folded synthesis bases, written twice: Sfold [KP][N] (rows k: the K-contiguous operand of the synthesis data-gradient
 // GEMM) and its transpose SfoldT [N][KP] (rows n: the K-contiguous operand of the synthesis FRAMES GEMM, which otherwise has to take
 // Sfold as an M/N-contiguous operand with scalar LDS fragment reads -- 52 % of the fp32 MFMA peak against 69 % for the NT x NT form).
 __device__ __forceinline__ void fold_tile(const float* __restrict__ Sr, const float* __restrict__ Si, float* __restrict__ Sfold,
-                                          float* __restrict__ SfoldT, const int N, const int F, const int KP, const int tile)
+                                          float* __restrict__ SfoldT, const int N, const int F, const int KP, const int tile,
+                                          unsigned short* __restrict__ Sfold16 = nullptr, unsigned short* __restrict__ SfoldT16 = nullptr, const int ht = 0)
 {
     __shared__ float tl[32][33];
     const int ntn = N / 32, tk = tile / ntn, tn = tile - tk * ntn;
@@ -157,23 +168,31 @@ __device__ __forceinline__ void fold_tile(const float* __restrict__ Sr, const fl
             v = S[(size_t)k * N + n];
             if (k >= 1 && k <= F - 2) { const float u = S[(size_t)(N - k) * N + n]; v += is_im ? -u : u; }
         }
-        Sfold[(size_t)row * N + n] = v;
+        if (Sfold16) Sfold16[(size_t)row * N + n] = st_to_h16(v, ht); else Sfold[(size_t)row * N + n] = v;
         tl[ry + 8 * j][cx] = v;
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = tn * 32 + ry + 8 * j, row = tk * 32 + cx;
-        SfoldT[(size_t)n * KP + row] = tl[cx][ry + 8 * j];
+        if (SfoldT16) SfoldT16[(size_t)n * KP + row] = st_to_h16(tl[cx][ry + 8 * j], ht); else SfoldT[(size_t)n * KP + row] = tl[cx][ry + 8 * j];
     }
 }
 __global__ void __launch_bounds__(256)
 prep_kernel(const PrepArgs a)
 {
     const int blk = blockIdx.x;
-    if (blk < a.n_pad) { const int b = blk / a.nbx; pad_scale_block(a.x, a.xp, a.Ls, a.pad, a.scale, blk - b * a.nbx, a.nbx, b); }
-    else if (blk < a.n_pad + a.n_fold) fold_tile(a.Sr, a.Si, a.Sfold, a.SfoldT, a.N, a.F, a.KP, blk - a.n_pad);
-    else zero_dead_frame(a.re, a.im, a.mag, a.phs, a.T, a.F, a.t_lo, a.Tv, blk - a.n_pad - a.n_fold);
+    if (blk < a.n_pad) { const int b = blk / a.nbx; pad_scale_block(a.x, a.xp, a.Ls, a.pad, a.scale, blk - b * a.nbx, a.nbx, b, a.ht ? a.xp16 : nullptr, a.ht); }
+    else if (blk < a.n_pad + a.n_fold) fold_tile(a.Sr, a.Si, a.Sfold, a.SfoldT, a.N, a.F, a.KP, blk - a.n_pad, a.ht ? a.Sfold16 : nullptr, a.ht ? a.SfoldT16 : nullptr, a.ht);
+    else if (blk < a.n_pad + a.n_fold + a.n_dead) zero_dead_frame(a.re, a.im, a.mag, a.phs, a.T, a.F, a.t_lo, a.Tv, blk - a.n_pad - a.n_fold);
+    else {                                           // analysis bases, 4 taps per thread
+        const size_t i4 = (size_t)(blk - a.n_pad - a.n_fold - a.n_dead) * 256 + threadIdx.x, n4 = a.N / 4;
+        if (i4 < (size_t)2 * a.F * n4) {
+            const int jrow = (int)(i4 / n4), c = (int)(i4 - (size_t)jrow * n4);
+            const float4 v = reinterpret_cast<const float4*>(((jrow & 1) ? a.Wi : a.Wr) + (size_t)(jrow >> 1) * a.N)[c];
+            reinterpret_cast<uint2*>(a.W16 + (size_t)jrow * a.N)[c] = st_to_h16x4(v, a.ht);
+        }
+    }
 }
 
 // dsyn = 2 * g_y_hat  (y_hat = 2*(syn + x/2), nn_proc.py:332,340) -- generic autograd entry
@@ -189,7 +208,7 @@ scale_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, f
 __device__ __forceinline__ void polar_bwd_block(const float* __restrict__ re, const float* __restrict__ im, const float* __restrict__ dmag,
                  const float* __restrict__ dphs, const float* __restrict__ g_mag, float* __restrict__ dG, const int F, const int KP,
                  const float sat,      // > 0: saturate the result to +-sat (the consumer GEMM narrows it to fp16, see below)
-                 const int bx, const int r)
+                 const int bx, const int r, unsigned short* __restrict__ dG16 = nullptr, const int ht = 0)
 {
     const int half = KP / 2;
     const int c = bx * 256 + threadIdx.x;     // column in [0, half)
@@ -209,14 +228,15 @@ __device__ __forceinline__ void polar_bwd_block(const float* __restrict__ re, co
         // The sub-gradient is computed in fp32 as always and saturated HERE, before the consumer narrows it.
         if (sat > 0.f) { gre = __builtin_amdgcn_fmed3f(gre, -sat, sat); gim = __builtin_amdgcn_fmed3f(gim, -sat, sat); }
     }
-    dG[(size_t)r * KP + c] = gre;
-    dG[(size_t)r * KP + half + c] = gim;
+    if (dG16) { dG16[(size_t)r * KP + c] = st_to_h16(gre, ht); dG16[(size_t)r * KP + half + c] = st_to_h16(gim, ht); }      // the operand of the analysis weight-gradient GEMM (st_gemm16.h)
+    if (dG) { dG[(size_t)r * KP + c] = gre; dG[(size_t)r * KP + half + c] = gim; }
 }
 __global__ void __launch_bounds__(256)
 polar_bwd_kernel(const float* __restrict__ re, const float* __restrict__ im, const float* __restrict__ dmag,
-                 const float* __restrict__ dphs, const float* __restrict__ g_mag, float* __restrict__ dG, int R, int F, int KP, const float sat)
+                 const float* __restrict__ dphs, const float* __restrict__ g_mag, float* __restrict__ dG, int R, int F, int KP, const float sat,
+                 unsigned short* __restrict__ dG16 = nullptr, const int ht = 0)
 {
-    polar_bwd_block(re, im, dmag, dphs, g_mag, dG, F, KP, sat, blockIdx.x, blockIdx.y);
+    polar_bwd_block(re, im, dmag, dphs, g_mag, dG, F, KP, sat, blockIdx.x, blockIdx.y, dG16, ht);
 }
 
 // ---------------------------------------------------------------- split-K slab reduce (+ unfold, + |g| sums)
@@ -363,13 +383,14 @@ struct PostAeArgs {
     // third role (fused step): the split-K slabs of the synthesis weight gradient, written before the autoencoder backward, are summed,
     // un-folded and normed here instead of in a launch of their own
     int n_polar; const float* wg; int wg_nz; float* gSr; float* gSi; float* norm_s; int N; NyqJob nyq;
+    unsigned short* dG16; int ht;          // 16-bit configurations: d G rounded to the GEMM operand type (dG itself may then be NULL)
 };
 __global__ void __launch_bounds__(256)
 post_ae_kernel(const PostAeArgs a)
 {
     const int blk = blockIdx.x;
     if (blk < a.n_red) { const int ae = blk / a.n_red_x; ae_grad_reduce_block(a.ws, a.nparts, a.PG, a.g_m, a.g_p, blk - ae * a.n_red_x, ae); }
-    else if (blk < a.n_red + a.n_polar) { const int q = blk - a.n_red, r = q / a.gx; polar_bwd_block(a.re, a.im, a.dmag, a.dphs, a.g_mag, a.dG, a.F, a.KP, a.sat, q - r * a.gx, r); }
+    else if (blk < a.n_red + a.n_polar) { const int q = blk - a.n_red, r = q / a.gx; polar_bwd_block(a.re, a.im, a.dmag, a.dphs, a.g_mag, a.dG, a.F, a.KP, a.sat, q - r * a.gx, r, a.dG16, a.ht); }
     else wgrad_reduce_block(a.wg, a.wg_nz, a.gSr, a.gSi, a.norm_s, a.N, a.F, a.KP, 1, blk - a.n_red - a.n_polar, nullptr, a.nyq);
 }
 
