@@ -17,7 +17,7 @@ if __name__ == "__main__":
     p.add_argument('--gpus', type=int, default=None, help="data-parallel world size this job is meant to run on; launch with "
                    "`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 run_train.py --gpus N ...` "
                    "(one process per GPU); checked against WORLD_SIZE")
-    p.add_argument('--device-feed', action='store_true', help="keep a recycled synthetic dataset in HBM instead of the 10-worker CPU DataLoader")
+    p.add_argument('--device-feed', action='store_true', help="generate every training minibatch on the GPU (signal generators + compressor kernels) and keep the validation set in HBM, instead of the 10-worker CPU DataLoader")
     p.add_argument('-b', '--batch', type=int, help="batch size (per GPU)", default=200)
     p.add_argument('--checkpoint', help='name of checkpoint .tar file to start from', default='modelcheckpoint.tar')
     p.add_argument('-c', '--compand', help='accepted for compatibility', action='store_true')

@@ -11,6 +11,7 @@
 // carries one (PyTorch-ROCm does) shares that copy instead of loading a second RCCL.
 #pragma once
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <rccl/rccl.h>
 #include "st_common.h"
 
@@ -33,6 +34,10 @@ namespace stdp {
 
 static void* open_rccl()
 {
+    // ST_RCCL_LIB: bind THIS library instead (same six entry points).  tests/fake_rccl.cpp uses it to run the world > 1 C path with two
+    // processes on one GPU; a site could point it at a differently built RCCL.
+    const char* ov = getenv("ST_RCCL_LIB");
+    if (ov && *ov) return dlopen(ov, RTLD_NOW | RTLD_LOCAL);
     // already in the process (PyTorch-ROCm links it)?  else the system copy
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) { void* h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (h) return h; }

@@ -217,6 +217,7 @@ class StepEngine:
         """forward + calc_loss (loss_functions.py:26-36 with scale_by_freq) + backward; fills self.grads (times the loss
         scale, if one is set).  self.scalars[0..4] = loss, mean log-cosh, L1 term, L1 norm of the (unscaled) STFT grads, clip coefficient."""
         d, x, knobs, y = self._prep(x, knobs, y)
+        self._pending = (d, x, knobs, y)   # the dims clip_adam() carves the workspace with are those of the LAST backward
         outs = (None, None, None)
         if want_outputs:
             outs = (torch.empty(d.B, d.y, dtype=torch.float32, device=self.device),
@@ -281,6 +282,7 @@ class StepEngine:
         """One optimisation step (train.py:112-151).  `lr` is the value sitting in param_groups at step
         time, i.e. lr_sched[max(i-1,0)] in the reference loop (train.py:150).  No host sync."""
         d, x, knobs, y = self._prep(x, knobs, y)
+        self._pending = None               # a later clip_adam() must not carve the workspace with an older backward's dims
         self.step_count += 1; self.generation += 1; self.lr = float(lr)
         self._call("st_train_step", C.byref(d), _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.m),
                    _lib.ptr(self.v), _lib.ptr(x), _lib.ptr(knobs), _lib.ptr(y), _lib.ptr(self.ws),

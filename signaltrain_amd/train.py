@@ -55,6 +55,25 @@ def train_loop(model, engine, effect, device, epochs, batch_size, lr_sched, mom_
     step count = position in the 1-cycle table, the learning rate that sat in the optimizer) -- the reference restarts all
     three at zero on resume (train.py:229 TODO)."""
     dp = DataParallel(engine)
+    try:
+        return _train_loop(dp, model, engine, effect, device, epochs, batch_size, lr_sched, mom_sched, dataloader, dataloader_val,
+                           y_size, logfilename, out_checkpointname, plot_every, cp_every, sr, lr_max, start_epoch, start_iter, lr_resume)
+    finally:
+        dp.close()          # the library-owned RCCL communicator, its stream and events (before the caller destroys the process group)
+
+
+def seed_data_streams(rank):
+    """Fold the rank into the DATA random streams (numpy's global state, torch's global generator) -- after the model has been
+    initialised from the common seed (run_train.py:20-21 seeds 218 on every rank): each rank must draw different minibatches, or the
+    all-reduced gradient is just the single-GPU gradient N times over.  (The reference's CPU workers re-seed from OS entropy,
+    datasets.py:54-61; the device feeds draw from these two streams.)  Rank 0 keeps its streams."""
+    if rank:
+        np.random.seed((int(np.random.randint(0, 2 ** 31 - 1)) + 7919 * int(rank)) % (2 ** 31 - 1))
+        torch.manual_seed(int(torch.initial_seed()) + 7919 * int(rank))
+
+
+def _train_loop(dp, model, engine, effect, device, epochs, batch_size, lr_sched, mom_sched, dataloader, dataloader_val,
+                y_size, logfilename, out_checkpointname, plot_every, cp_every, sr, lr_max, start_epoch, start_iter, lr_resume):
     dp.broadcast_parameters()
     is_main = (not dist.is_initialized()) or dist.get_rank() == 0
     iter_count, batch_num, status_every = int(start_iter), 0, 10
@@ -83,9 +102,10 @@ def train_loop(model, engine, effect, device, epochs, batch_size, lr_sched, mom_
             if 0 == batch_num % status_every:                        # train.py:124-129 (the only device->host sync)
                 avg_loss = beta * avg_loss + (1 - beta) * dp.mean_loss()
                 smoothed_loss = avg_loss / (1 - beta ** batch_num)
-                if engine.loss_scale != 1.0:
+                if engine.compute_dtype.startswith("f16"):
                     # loss-scale policy of Apex's dynamic scaler at this loop's only sync point: halve on overflow (the kernel
-                    # already skipped those steps), double after 2000 clean steps
+                    # already skipped those steps), double after 2000 clean steps.  Gated on the arithmetic, not on the current
+                    # scale: a scale that overflows halved its way down to 1 must be able to grow back
                     if engine.overflow_steps():
                         engine.loss_scale = max(engine.loss_scale / 2.0, 1.0); clean_steps = 0
                     else:
@@ -114,7 +134,7 @@ def train_loop(model, engine, effect, device, epochs, batch_size, lr_sched, mom_
 def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=None, plot_every=10, cp_every=25, sr=44100,
           datapath=None, scale_factor=1, shrink_factor=4, apex_opt="O0", target_type="stream", lr_max=1e-4,
           in_checkpointname='modelcheckpoint.tar', compand=False, num_workers=10, device_feed=False, compute_dtype=None,
-          resume_optimizer=True):
+          resume_optimizer=False):
     """train.py:167-278.  datapath: directory with Train/ and Val/ wav pairs (datasets.AudioFileDataSet, the reference's
     file feed, e.g. the LA2A set of BASELINE configs[3]; pass effect=audio.FileEffect(datapath)); compand is refused by that dataset.
     apex_opt: "O0" = fp32 (the parity path); "O1" / "O2" / "O3" = the reference's Apex mixed precision (train.py:254-255),
@@ -123,8 +143,10 @@ def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=N
     "bf16_all", "f16", "f16_all"; bf16 is the MI355X-native choice and needs no loss scale); device_feed=True generates every
     training minibatch on the GPU (signals: audio_device.py, effect: st_compressor_4c) and keeps the validation set in HBM
     instead of the 10-worker CPU DataLoader, which otherwise caps training far below the GPU step rate ("recycle": one
-    device-resident training set re-sampled each epoch); resume_optimizer=True restores Adam's moments, the step count (= position in the
-    1-cycle table) and the epoch counter from the checkpoint, which the reference saves but never reads back (train.py:229)."""
+    device-resident training set re-sampled each epoch); resume_optimizer: False (default, the reference's behaviour: train `epochs`
+    more epochs from the loaded weights with a fresh optimizer and schedule -- its fine-tune workflow); True restores Adam's moments
+    from the checkpoint (which the reference saves but never reads back, train.py:229) and, if the checkpoint belongs to THIS schedule
+    (its epoch counter is below `epochs` and its step count lies inside the 1-cycle table), also the position in the run."""
     if compute_dtype is None:
         compute_dtype = "f32" if str(apex_opt).upper() in ("O0", "NONE", "") else "f16_all"
     effect = audio.Compressor_4c() if effect is None else effect
@@ -145,13 +167,22 @@ def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=N
     model.to(device)
     model.set_compute_dtype(compute_dtype)
     engine = model.engine(torch.zeros(batch_size, chunk_size, device=device))     # parameters become views of the engine's flat buffer
+    seed_data_streams(dist.get_rank() if dist.is_initialized() else 0)            # identical weights above, distinct minibatches below
     start_epoch, start_iter, lr_resume = 0, 0, None
+    lr_sched, mom_sched = learningrate.get_1cycle_schedule(lr_max=lr_max, n_data_points=n_data_points, epochs=epochs, batch_size=batch_size)
     if state_dict != {} and resume_optimizer and rv.get('optimizer'):
         lr_resume = engine.load_optimizer_state_dict(rv['optimizer'])
         if lr_resume is not None:
-            start_epoch, start_iter = int(rv.get('epoch', 0)), engine.step_count
-            print(f"Optimizer state restored: {start_iter} steps done, resuming at epoch {start_epoch + 1} with lr = {lr_resume:.3e}")
-    lr_sched, mom_sched = learningrate.get_1cycle_schedule(lr_max=lr_max, n_data_points=n_data_points, epochs=epochs, batch_size=batch_size)
+            ck_epoch, ck_iter = int(rv.get('epoch', 0)), engine.step_count
+            per_epoch = max(n_data_points // batch_size, 1)
+            if ck_epoch < epochs and ck_iter < len(lr_sched) and ck_iter == ck_epoch * per_epoch:
+                start_epoch, start_iter = ck_epoch, ck_iter
+                print(f"Optimizer state restored: {start_iter} steps done, resuming at epoch {start_epoch + 1} with lr = {lr_resume:.3e}")
+            else:
+                # a finished run, or a checkpoint of another n_data_points / batch_size / epochs: its position means nothing in this schedule
+                print(f"WARNING: the checkpoint's position (epoch {ck_epoch}, step {ck_iter}) does not belong to this schedule ({epochs} epochs of "
+                      f"{per_epoch} steps): Adam's moments are kept, epoch / step / learning rate restart at the beginning")
+                lr_resume = None
     if datapath is not None:
         # pre-recorded input / target pairs (train.py:241-246; BASELINE configs[3]): windows gathered on the device from the preloaded audio
         dataset = datasets.AudioFileDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points, path=datapath + "/Train/", y_size=out_chunk_size,

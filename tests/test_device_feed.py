@@ -122,3 +122,22 @@ def test_audio_file_dataset_contract(tmp_path):
         src_x, src_y = ds.x[hit[0]], ds.y[hit[0]]
         pos = [p for p in range(0, len(src_x) - 8192) if src_x[p] == x[0] and np.array_equal(src_x[p:p + 8192], x)]
         assert pos and np.array_equal(src_y[pos[0] + 8192 - 2048:pos[0] + 8192], y)      # target = the LAST y_size samples of the same window
+
+
+def test_ranks_draw_different_minibatches():
+    """Data parallel: every rank initialises the model from the common seed (run_train.py:20-21) and must then draw DIFFERENT minibatches --
+    train.seed_data_streams folds the rank into numpy's and torch's global streams (which the device feeds draw from); rank 0 keeps
+    its streams, so a single-GPU run is unchanged."""
+    import torch
+    from signaltrain_amd import train as T
+    draws = {}
+    for rank in (0, 1, 2):
+        np.random.seed(218); torch.manual_seed(218)
+        w = torch.randn(4)                       # "model init": identical on every rank
+        T.seed_data_streams(rank)
+        draws[rank] = (w, np.random.rand(4), torch.rand(4))
+    assert torch.equal(draws[0][0], draws[1][0]) and torch.equal(draws[0][0], draws[2][0])
+    np.random.seed(218); torch.manual_seed(218); torch.randn(4)
+    assert np.array_equal(draws[0][1], np.random.rand(4)) and torch.equal(draws[0][2], torch.rand(4))      # rank 0 untouched
+    for a, b in ((0, 1), (0, 2), (1, 2)):
+        assert not np.array_equal(draws[a][1], draws[b][1]) and not torch.equal(draws[a][2], draws[b][2])

@@ -1,0 +1,117 @@
+"""World 2 through the LIBRARY's exchange path (st_dp_init / st_dp_broadcast / st_dp_train_step), on one GPU.
+
+Two rank processes share cuda:0; libsignaltrain_hip.so binds tests/libfake_rccl.so (ST_RCCL_LIB) instead of librccl: a test
+double whose all-reduce / broadcast are stream-ordered like RCCL's, move the data through a shared-memory segment (slow: PCIe both
+ways) and can hold one rank back (ST_FAKE_RCCL_DELAY_*).  Checked, SURVEY.md 8(e): three data-parallel steps on the two shards of
+a global batch give the parameters of ONE process on the global batch (<= 1e-5 of the parameter scale + the Adam ulp floor), both
+ranks end bit-identical, and the averaged loss is the global-batch loss.  A wrong range (offs[2]..offs[4], offs[4]..total, the
+staging rows), a collective issued before its producer kernels, or a consumer that does not wait for the collective is invisible
+with one rank (test_dp_collective_path_single_rank: the all-reduce over one rank is the identity) and fails here.
+
+Reference: signaltrain/train.py:259-263 (the reference's disabled nn.DataParallel stub and its 2-GPU remark).
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE = os.path.join(ROOT, "tests", "libfake_rccl.so")
+B_GLOBAL, K, STEPS, LR = 4, 4, 3, 1e-3
+
+
+def _build_fake():
+    src = os.path.join(ROOT, "tests", "fake_rccl.cpp")
+    if not os.path.exists(FAKE) or os.path.getmtime(FAKE) < os.path.getmtime(src):
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-fPIC", "-shared", src, "-o", FAKE, "-lrt"], check=True)
+
+
+def worker():
+    """One rank: python tests/test_dp_world2.py <rank> <world> <port> <outdir> <dtype>"""
+    rank, world, port, outdir, dtype = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+    import torch
+    import torch.distributed as dist
+    from tests import gpu_checks as G
+    from signaltrain_amd.engine import StepEngine
+    from signaltrain_amd.dp import DataParallel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    geo, X, Y, KN, P = G.make_case(B_GLOBAL, 21, K=K)
+    bl = B_GLOBAL // world
+    d = G.dims_of(geo, bl, K)
+    eng = StepEngine(d, G.DEV, compute_dtype=dtype)
+    if rank == 0:
+        eng.load_state_dict(P)              # the other ranks start from zeros: broadcast_parameters must deliver the weights
+    dp = DataParallel(eng, backend="lib")
+    assert dp.backend == "lib" and dp.world == world
+    dp.broadcast_parameters()
+    sl = slice(rank * bl, (rank + 1) * bl)
+    x, kn, y = G.t(X[sl]), G.t(KN[sl]), G.t(Y[sl])
+    losses = []
+    for it in range(STEPS):
+        dp.train_step(x, kn, y, LR)
+        losses.append(dp.mean_loss())
+    torch.cuda.synchronize()
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), params=eng.params.cpu().numpy(), losses=np.array(losses), grads=eng.grads.cpu().numpy())
+    dp.close()
+    dist.destroy_process_group()
+
+
+def _run_world2(tmp_path, dtype, delay_rank=None):
+    _build_fake()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, ST_RCCL_LIB=FAKE, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if delay_rank is not None:
+        env.update(ST_FAKE_RCCL_DELAY_RANK=str(delay_rank), ST_FAKE_RCCL_DELAY_US="20000")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(r), "2", str(port), str(tmp_path), dtype], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
+    return [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(2)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,delay_rank", [("f32", None), ("f32", 1), ("f32", 0), ("bf16_all", 1)])
+def test_world2_library_exchange_equals_single_process(tmp_path, dtype, delay_rank):
+    import torch
+    from tests import gpu_checks as G
+    from signaltrain_amd.engine import StepEngine
+    r0, r1 = _run_world2(tmp_path, dtype, delay_rank)
+    # both replicas identical: same reduced gradient (the double sums in rank order), same clip, same Adam
+    assert np.array_equal(r0["params"], r1["params"]), float(np.abs(r0["params"] - r1["params"]).max())
+    assert np.array_equal(r0["grads"], r1["grads"])
+    # one process, the global batch
+    geo, X, Y, KN, P = G.make_case(B_GLOBAL, 21, K=K)
+    ref = StepEngine(G.dims_of(geo, B_GLOBAL, K), G.DEV, compute_dtype=dtype); ref.load_state_dict(P)
+    x, kn, y = G.t(X), G.t(KN), G.t(Y)
+    ref_losses = []
+    for it in range(STEPS):
+        ref.train_step(x, kn, y, LR)
+        ref_losses.append(float(ref.scalars[0]))
+    torch.cuda.synchronize()
+    pr = ref.params.cpu().numpy()
+    err = float(np.abs(pr - r0["params"]).max())
+    # fp32: reassociation of the batch sum only (<= 1e-5 rel on the parameters; Adam turns ulp noise on noise-level gradient
+    # elements into a fraction of lr, hence the absolute floor the fused-vs-oracle checks use).  16-bit: each rank rounds its own
+    # operands -- the shards' partial products are the same numbers, their fp32 sums re-associate.
+    tol = 2e-5 if dtype == "f32" else 2e-3
+    assert err <= tol, (dtype, err)
+    for a, b in zip(ref_losses, r0["losses"]):
+        assert abs(a - b) <= (1e-5 if dtype == "f32" else 2e-3) * abs(a), (ref_losses, r0["losses"])
+
+
+if __name__ == "__main__":
+    worker()

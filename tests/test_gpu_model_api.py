@@ -244,11 +244,23 @@ def test_train_driver_short_run(tmp_path):
         m_before = eng.m.clone()
         assert float(m_before.abs().max()) > 0
         model2 = train.train(effect=audio.Compressor_4c(), epochs=2, n_data_points=256, batch_size=32,
-                             device=torch.device("cuda:0"), num_workers=2)        # resumes from modelcheckpoint.tar
+                             device=torch.device("cuda:0"), num_workers=2, resume_optimizer=True)        # resumes from modelcheckpoint.tar
         eng2 = model2.engine(torch.zeros(32, 8192, device="cuda"))
         assert eng2.step_count == 2 * steps0                          # epoch 2 only: optimizer step count and epoch counter continued
         sd2, rv2 = misc.load_checkpoint("modelcheckpoint.tar", device="cpu")
         assert rv2["epoch"] == 2 and int(float(rv2["optimizer"]["state"][0]["step"])) == 2 * steps0
+        # the reference's behaviour (and the default): train `epochs` MORE from the loaded weights -- a finished run's checkpoint must not
+        # turn the next train() call into a silent no-op
+        w_before = {k: v.clone() for k, v in sd2.items()}
+        model3 = train.train(effect=audio.Compressor_4c(), epochs=1, n_data_points=256, batch_size=32, device=torch.device("cuda:0"), num_workers=2)
+        eng3 = model3.engine(torch.zeros(32, 8192, device="cuda"))
+        assert eng3.step_count == steps0                              # fresh optimizer, one epoch of steps
+        sd3, rv3 = misc.load_checkpoint("modelcheckpoint.tar", device="cpu")
+        assert any(not torch.equal(sd3[k], w_before[k]) for k in sd3), "train() from a finished checkpoint trained nothing"
+        # ... and with resume_optimizer=True a checkpoint whose position lies outside the new schedule keeps the moments but restarts the position
+        model4 = train.train(effect=audio.Compressor_4c(), epochs=1, n_data_points=256, batch_size=32, device=torch.device("cuda:0"), num_workers=2,
+                             resume_optimizer=True)
+        assert model4.engine(torch.zeros(32, 8192, device="cuda")).step_count == 2 * steps0     # moments + their step counter kept, 8 more steps
     finally:
         os.chdir(cwd)
 
