@@ -168,8 +168,8 @@ def main():
     dp.broadcast_parameters()
     np.random.seed(218 + 1000 * (rank + 1))
     ds = datasets.SynthAudioDataSet(d.L, audio.Compressor_4c(), y_size=d.y, augment=True)
-    X, Y, KN = ds.batch(B)
-    x, y, kn = (torch.from_numpy(a).to(dev) for a in (X, Y, KN))
+    x, y, kn = ds.batch_device(B, dev)          # comp_4c windows from the device feed (csrc/st_feed.h): signals, knobs, compressor targets
+    X, Y, KN = (a.cpu().numpy() for a in (x, y, kn))
     lrs, _ = learningrate.get_1cycle_schedule(lr_max=1e-4, n_data_points=200000, epochs=100, batch_size=B * world)
 
     def step(i):

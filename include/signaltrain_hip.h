@@ -287,6 +287,18 @@ int st_graph_destroy(st_graph* g);
  *   x [B][L] fp32, knobs_wc [B][4] = (threshold dB, ratio, attack s, release s) in WORLD coordinates
  *   (Effect.knobs_wc, audio.py:455), y [B][ysz] = the last ysz samples of the processed window (datasets.py:327-330). */
 int st_compressor_4c(const float* x, const float* knobs_wc, float sr, int B, int L, int ysz, float* y, void* stream);
+/* One training minibatch of the synthetic comp_4c task made on the device in ONE launch (st_feed.h; replaces
+ * SynthAudioDataSet.gen_single_chunk, datasets.py:312-334, over audio.synth_input_sample, audio.py:296-334, chooser set
+ * {0,1,2,4,6,7}, and compressor_4controls): per window the test signal, knobs = Beta(0.8, 0.8) - 0.5 (audio.py:20-21,
+ * datasets.py:325), the target (last ysz samples of the compressed window) and, if `augment`, the random polarity flip of
+ * the pair (datasets.py:27-29).  Counter-based generator: window i of the stream `seed` is the same whatever the batching;
+ * `first_window` = index of window 0 of this call.  K must be 4; knob_lo / knob_hi = Effect.knob_ranges (host arrays of 4).
+ * chooser: -1 = drawn per window (the training feed); 0,1,2,4,6,7 force one signal family (tests).
+ * pink_in: [B][L] unit-peak 1/f noise for windows longer than 8192 samples (the in-kernel FFT's limit), else NULL.
+ * Outputs x [B][L], y [B][ysz], knobs [B][4] (fp32, normalised to [-0.5, 0.5]). */
+int st_synth_comp4c(unsigned seed, unsigned long long first_window, int B, int L, int ysz, int K, float sr,
+                    const float* knob_lo, const float* knob_hi, int augment, int chooser, const float* pink_in,
+                    float* x, float* y, float* knobs, void* stream);
 
 /* Gradient of the loss w.r.t. the (halved) input waveform, for callers with something trainable upstream of the model (the reference's
  * autograd provides it; nn_proc.py:307, cls_fe_dft.py:55-56).  Call right after st_model_bwd on the SAME workspace:

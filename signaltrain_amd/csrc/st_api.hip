@@ -18,6 +18,7 @@
 #include "st_ae_wide.h"
 #include "st_ae_split.h"
 #include "st_dp.h"
+#include "st_feed.h"
 
 // ------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -1425,6 +1426,24 @@ extern "C" int st_compressor_4c(const float* x, const float* knobs_wc, float sr,
     ST_REQ(B > 0 && L > 0 && ysz > 0 && ysz <= L && sr > 0.f, "st_compressor_4c: bad sizes (B=%d L=%d ysz=%d)", B, L, ysz);
     hipLaunchKernelGGL(stm::compressor_4c_kernel, dim3(B), dim3(256), 0, st_stream(stream), x, knobs_wc, sr, L, ysz, y);
     ST_LAUNCHED("compressor_4c"); return ST_OK;
+}
+
+extern "C" int st_synth_comp4c(unsigned seed, unsigned long long first_window, int B, int L, int ysz, int K, float sr,
+                               const float* knob_lo, const float* knob_hi, int augment, int chooser, const float* pink_in,
+                               float* x, float* y, float* knobs, void* stream)
+{
+    ST_REQ(x && y && knobs && knob_lo && knob_hi, "st_synth_comp4c: null pointer");
+    ST_REQ(B > 0 && L > 0 && ysz > 0 && ysz <= L && sr > 0.f && K == 4, "st_synth_comp4c: bad sizes (B=%d L=%d ysz=%d K=%d)", B, L, ysz, K);
+    ST_REQ(chooser == -1 || chooser == 0 || chooser == 1 || chooser == 2 || chooser == 4 || chooser == 6 || chooser == 7 || chooser == 100, "st_synth_comp4c: signal family %d is not built (the compressor's set is 0,1,2,4,6,7)", chooser);
+    const bool fft_ok = L <= stf::FFT_MAX && (L & (L - 1)) == 0;
+    ST_REQ(fft_ok || pink_in, "st_synth_comp4c: a %d-sample window needs the 1/f noise from the caller (pink_in): the in-kernel FFT handles powers of two up to %d", L, stf::FFT_MAX);
+    stf::FeedArgs a;
+    a.x = x; a.y = y; a.knobs = knobs; a.pink_in = pink_in; a.seed = seed; a.first = first_window;
+    a.L = L; a.ysz = ysz; a.K = K; a.sr = sr; a.augment = augment; a.chooser = chooser;
+    for (int k = 0; k < 4; ++k) { a.lo[k] = knob_lo[k]; a.hi[k] = knob_hi[k]; }
+    const size_t lds = pink_in ? (size_t)stm::COMP_CH * sizeof(float) : (size_t)stf::FFT_MAX * sizeof(float2);
+    hipLaunchKernelGGL(stf::synth_comp4c_kernel, dim3(B), dim3(256), lds, st_stream(stream), a);
+    ST_LAUNCHED("synth_comp4c"); return ST_OK;
 }
 
 // ------------------------------------------------------------------------------ generic learned-basis front end (a15)

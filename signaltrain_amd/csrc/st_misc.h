@@ -527,18 +527,12 @@ __global__ void step_tick_kernel(float* __restrict__ scalars, const float* __res
 // exactly like the reference's float32 lin_A array; the step arithmetic is float64 (numpy float64 scalars alphaA/R).
 // y receives the LAST ysz samples of each processed window (the training target, datasets.py:327-330).
 constexpr int COMP_CH = 8192;
-__global__ void __launch_bounds__(256)
-compressor_4c_kernel(const float* __restrict__ x, const float* __restrict__ knobs_wc, float sr, int L, int ysz, float* __restrict__ y)
+// one window; g: LDS float[COMP_CH], carry: LDS float.  Called by every thread of a 256-thread workgroup.
+__device__ __forceinline__ void
+compressor_window(const float* __restrict__ xb, float* __restrict__ yb, const double thresh, const double ratio, const double alphaA, const double alphaR,
+                  const int L, const int ysz, float* __restrict__ g, float* __restrict__ carry_p)
 {
-    __shared__ __attribute__((aligned(16))) float g[COMP_CH];
-    __shared__ float carry;
-    const int b = blockIdx.x;
-    const float* xb = x + (size_t)b * L;
-    float* yb = y + (size_t)b * ysz;
-    const double thresh = knobs_wc[4 * b + 0], ratio = knobs_wc[4 * b + 1];
-    const double alphaA = exp(-log(9.0) / ((double)sr * (double)knobs_wc[4 * b + 2]));
-    const double alphaR = exp(-log(9.0) / ((double)sr * (double)knobs_wc[4 * b + 3]));
-    if (threadIdx.x == 0) carry = 0.f;
+    if (threadIdx.x == 0) *carry_p = 0.f;
     for (int c0 = 0; c0 < L; c0 += COMP_CH) {
         const int n = L - c0 < COMP_CH ? L - c0 : COMP_CH;
         for (int i = threadIdx.x; i < n; i += 256) {
@@ -550,7 +544,7 @@ compressor_4c_kernel(const float* __restrict__ x, const float* __restrict__ knob
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            float prev = carry;
+            float prev = *carry_p;
             if (c0 == 0) g[0] = 0.f;                      // lin_A[0] = 0: the loop of the reference starts at n = 1
             // one step: lin_A[n] = float32( (1-a) g + a prev ), a = attack coefficient while the gain is falling.
             // Evaluated as g + a (prev - g) in float64 (differs from the reference's expression by < 1e-16 relative
@@ -574,7 +568,7 @@ compressor_4c_kernel(const float* __restrict__ x, const float* __restrict__ knob
                 *reinterpret_cast<float4*>(g + i) = u; *reinterpret_cast<float4*>(g + i + 4) = v;
             }
             for (; i < n; ++i) g[i] = step(g[i]);
-            carry = prev;
+            *carry_p = prev;
         }
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += 256) {
@@ -583,6 +577,17 @@ compressor_4c_kernel(const float* __restrict__ x, const float* __restrict__ knob
         }
         __syncthreads();
     }
+}
+__global__ void __launch_bounds__(256)
+compressor_4c_kernel(const float* __restrict__ x, const float* __restrict__ knobs_wc, float sr, int L, int ysz, float* __restrict__ y)
+{
+    __shared__ __attribute__((aligned(16))) float g[COMP_CH];
+    __shared__ float carry;
+    const int b = blockIdx.x;
+    const double thresh = knobs_wc[4 * b + 0], ratio = knobs_wc[4 * b + 1];
+    const double alphaA = exp(-log(9.0) / ((double)sr * (double)knobs_wc[4 * b + 2]));
+    const double alphaR = exp(-log(9.0) / ((double)sr * (double)knobs_wc[4 * b + 3]));
+    compressor_window(x + (size_t)b * L, y + (size_t)b * ysz, thresh, ratio, alphaA, alphaR, L, ysz, g, &carry);
 }
 
 

@@ -1,5 +1,5 @@
-"""SynthAudioDataSet -- mirror of signaltrain/datasets.py:263-334 (on-the-fly synthetic windows) and
-do_augment (:21-29).  Items: (x f32[chunk], y[y_size], knobs f32[K])."""
+"""Data sets of the training driver: SynthAudioDataSet (signaltrain/datasets.py:263-334, synthetic windows of an effect -- generated on the GPU),
+AudioFileDataSet (:64-259, pre-recorded input / target pairs) and their device-resident loaders.  Items: (x f32[chunk], y[y_size], knobs f32[K])."""
 import numpy as np
 from torch.utils.data import Dataset
 
@@ -18,66 +18,67 @@ def worker_init(worker_id):
 
 
 class SynthAudioDataSet(Dataset):
+    """signaltrain/datasets.py:263-334: on-the-fly synthetic (x, y, knobs) items of an Effect.  Here the items are made ON THE GPU, a whole
+    minibatch per call (batch_device; DeviceSynthLoader / DeviceRecycledDataSet iterate it for train.train); there is no per-item host
+    generator behind __getitem__ -- the reference's CPU workers top out at ~100 windows/s per core, three to four orders of magnitude
+    below the train step."""
+
     def __init__(self, chunk_size, effect, sr=44100, datapoints=8000, dtype=np.float32, recycle=False, y_size=None, augment=True):
         super().__init__()
         self.chunk_size, self.effect, self.sr, self.datapoints, self.dtype = chunk_size, effect, sr, datapoints, dtype
         self.recycle, self.num_knobs, self.augment = recycle, len(effect.knob_names), augment
         self.y_size = chunk_size if y_size is None else y_size
-        self.t = np.arange(chunk_size, dtype=np.float32) / sr
-        if recycle:
-            self.x = np.zeros((datapoints, chunk_size), dtype=dtype); self.y = np.zeros((datapoints, self.y_size), dtype=dtype)
-            self.knobs = np.zeros((datapoints, self.num_knobs), dtype=dtype)
-            for i in range(datapoints):
-                self.x[i], self.y[i], self.knobs[i] = self.gen_single_chunk()
 
     def __len__(self):
         return self.datapoints
 
     def __getitem__(self, idx):
-        if self.recycle:
-            return self.x[idx], self.y[idx], self.knobs[idx]
-        x, y, knobs = self.gen_single_chunk()
-        return x.astype(self.dtype, copy=False)[-self.chunk_size:], y[-self.y_size:].astype(self.dtype, copy=False), \
-            knobs.astype(self.dtype, copy=False)
+        raise NotImplementedError("signaltrain_amd.SynthAudioDataSet generates minibatches on the GPU: use batch_device(), "
+                                  "DeviceSynthLoader or DeviceRecycledDataSet (train.train does)")
 
-    def gen_single_chunk(self, chooser=None, knobs=None):
-        if chooser is None:
-            chooser = np.random.choice([0, 1, 2, 4, 6, 7])            # datasets.py:317
-        x = audio.synth_input_sample(self.t, chooser)
-        if knobs is None:
-            knobs = audio.random_ends(len(self.effect.knob_ranges)) - 0.5
-        y, x = self.effect.go(x, knobs)
-        y = y[-self.y_size:]
-        if self.augment:
-            x, y = do_augment(x, y)
-        return x, y, knobs
-
-    def batch(self, B):
-        """B stacked items as float32 arrays (used by bench.py / tests for device-resident synthetic data)."""
-        xs, ys, ks = zip(*(self.gen_single_chunk() for _ in range(B)))
-        return (np.stack(xs).astype(np.float32), np.stack(ys).astype(np.float32), np.stack(ks).astype(np.float32))
-
-    def batch_device(self, B, device="cuda:0", generator=None, host_signals=False):
+    def batch_device(self, B, device="cuda:0", generator=None, chooser=-1):
         """Device-resident minibatch generated ON the GPU: input signals and knob settings by the batched
         device generators of audio_device.py (counter-free device RNG, no host loop), the sequential compressor as one HIP launch
-        for the whole batch (st_compressor_4c).  host_signals=True keeps the numpy signal generators of batch() and only runs
-        the effect on the GPU (round-1 behaviour; ~10 ms per window on the host).  Returns (x, y, knobs) torch tensors."""
+        for the whole batch (st_compressor_4c) -- or, for the comp_4c effects on a ROCm device, everything in ONE launch (st_synth_comp4c).
+        chooser: force one signal family (tests).  Returns (x, y, knobs) torch tensors."""
         import torch
         from . import audio_device
         device = torch.device(device)
-        if host_signals:
-            xs = np.stack([audio.synth_input_sample(self.t, np.random.choice([0, 1, 2, 4, 6, 7])) for _ in range(B)]).astype(np.float32)
-            ks = np.stack([audio.random_ends(len(self.effect.knob_ranges)) - 0.5 for _ in range(B)]).astype(np.float32)
-            x = torch.from_numpy(xs).to(device); kn = torch.from_numpy(ks).to(device)
-            gen = None
-        else:
+        fused = generator is None and device.type == "cuda" and len(self.effect.knob_ranges) == 4 \
+            and type(self.effect).__name__.startswith("Compressor_4c")
+        if fused:
+            # ONE launch per minibatch (st_synth_comp4c, csrc/st_feed.h): signals, knobs, compressor and the polarity flip of the pair.
+            # Counter-based generator: the stream is (seed, global window index) -- the seed follows np.random.seed(...) of the run
+            # (and so the rank, train.seed_data_streams), the index counts the windows this dataset has produced.
+            import ctypes as C
+            from . import _lib
+            if getattr(self, "_feed_seed", None) is None:
+                self._feed_seed, self._feed_count = int(np.random.randint(0, 2 ** 31 - 1)), 0
+            x = torch.empty(B, self.chunk_size, dtype=torch.float32, device=device)
+            y = torch.empty(B, self.y_size, dtype=torch.float32, device=device)
+            kn = torch.empty(B, 4, dtype=torch.float32, device=device)
+            pink = None
+            if self.chunk_size > 8192 or (self.chunk_size & (self.chunk_size - 1)):      # beyond the in-kernel FFT: rocFFT makes the 1/f noise
+                g = getattr(self, "_dev_gen", None)
+                if g is None or g.device != device:
+                    g = torch.Generator(device=device); g.manual_seed(self._feed_seed); self._dev_gen = g
+                pink = audio_device.pinknoise(B, self.chunk_size, g, device).contiguous()
+            lo = (C.c_float * 4)(*[float(v) for v in self.effect.knob_ranges[:, 0]])
+            hi = (C.c_float * 4)(*[float(v) for v in self.effect.knob_ranges[:, 1]])
+            with torch.cuda.device(device):
+                _lib.check(_lib.load().st_synth_comp4c(self._feed_seed, self._feed_count, B, self.chunk_size, self.y_size, 4, float(self.sr), lo, hi,
+                                                       1 if self.augment else 0, int(chooser), _lib.ptr(pink), _lib.ptr(x), _lib.ptr(y), _lib.ptr(kn),
+                                                       C.c_void_p(torch.cuda.current_stream(device).cuda_stream)), "st_synth_comp4c")
+            self._feed_count += B
+            return x, y, kn
+        if True:
             gen = generator
             if gen is None:
                 gen = getattr(self, "_dev_gen", None)
                 if gen is None or gen.device != device:
                     gen = torch.Generator(device=device); gen.manual_seed(int(np.random.randint(0, 2 ** 31 - 1)))    # follows np.random.seed(...) of the run
                     self._dev_gen = gen
-            x, _ = audio_device.synth_input_batch(B, self.chunk_size, self.sr, gen, device)
+            x, _ = audio_device.synth_input_batch(B, self.chunk_size, self.sr, gen, device, chooser=(None if chooser < 0 else chooser))
             kn = audio_device.random_ends(B, len(self.effect.knob_ranges), gen, device) - 0.5
         y = self.effect.go_device(x, kn, self.y_size)
         if self.augment:                                   # do_augment: random polarity flip of the pair (datasets.py:27-29)
@@ -89,8 +90,8 @@ class SynthAudioDataSet(Dataset):
 class DeviceSynthLoader:
     """The reference's TRAINING feed (SynthAudioDataSet without recycling behind a shuffling DataLoader, train.py:233-248:
     every item is generated on the fly) moved onto the GPU: each iteration yields a freshly generated (x, y, knobs) minibatch,
-    `datapoints // batch_size` batches per epoch.  Nothing is stored; generation runs at a few hundred thousand windows per
-    second, i.e. at the step rate of the fp32 train step instead of the ~100 windows/s/core of the CPU workers."""
+    `datapoints // batch_size` batches per epoch.  Nothing is stored.  For the comp_4c effects a minibatch is ONE kernel launch
+    (st_synth_comp4c); measured rates: profiles/r03_train_loop_throughput.txt."""
 
     def __init__(self, dataset, batch_size, device="cuda:0", gen_windows=2048):
         """gen_windows: windows generated per call of the device generators (a few dozen small launches whatever the count:

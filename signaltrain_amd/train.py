@@ -140,10 +140,9 @@ def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=N
     apex_opt: "O0" = fp32 (the parity path); "O1" / "O2" / "O3" = the reference's Apex mixed precision (train.py:254-255),
     here float16 operands with fp32 accumulation, a loss scale and the L1 clip over all parameters (train.py:133-136) --
     compute_dtype "f16_all".  Extra keywords (not in the reference): compute_dtype overrides the arithmetic ("f32", "bf16",
-    "bf16_all", "f16", "f16_all"; bf16 is the MI355X-native choice and needs no loss scale); device_feed=True generates every
-    training minibatch on the GPU (signals: audio_device.py, effect: st_compressor_4c) and keeps the validation set in HBM
-    instead of the 10-worker CPU DataLoader, which otherwise caps training far below the GPU step rate ("recycle": one
-    device-resident training set re-sampled each epoch); resume_optimizer: False (default, the reference's behaviour: train `epochs`
+    "bf16_all", "f16", "f16_all"; bf16 is the MI355X-native choice and needs no loss scale); device_feed: the synthetic task's minibatches are
+    always generated on the GPU (csrc/st_feed.h; "recycle": one device-resident training set re-sampled each epoch), for file datasets
+    device_feed=True gathers the windows on the device instead of the CPU DataLoader; resume_optimizer: False (default, the reference's behaviour: train `epochs`
     more epochs from the loaded weights with a fresh optimizer and schedule -- its fine-tune workflow); True restores Adam's moments
     from the checkpoint (which the reference saves but never reads back, train.py:229) and, if the checkpoint belongs to THIS schedule
     (its epoch counter is below `epochs` and its step count lies inside the 1-cycle table), also the position in the run."""
@@ -197,11 +196,13 @@ def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=N
         else:
             dataloader = DataLoader(dataset, batch_size=batch_size, num_workers=num_workers, shuffle=True, worker_init_fn=datasets.worker_init, drop_last=True)
             dataloader_val = DataLoader(dataset_val, batch_size=batch_size, num_workers=num_workers, shuffle=False, drop_last=True)
-    elif device_feed:
+    else:
+        # synthetic effect: every training minibatch is generated ON the GPU (one st_synth_comp4c launch per minibatch for the comp_4c
+        # effects), as the reference's non-recycled dataset does on its CPU workers (train.py:233-248); device_feed="recycle": one dataset
+        # generated up front and re-sampled by index each epoch (the reference's recycle=True mode).  There is no CPU-worker path for the
+        # synthetic task (device_feed=False is accepted for compatibility): ~100 windows/s per core against 3-8 x 10^5 per second for the step.
+        # Validation: the reference's recycled set (train.py:237-238), resident in HBM.
         dataset = datasets.SynthAudioDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points, y_size=out_chunk_size, augment=True)
-        # training: every minibatch generated on the fly ON the GPU, as the reference's non-recycled dataset does on its CPU workers
-        # (device_feed="recycle": one dataset generated up front and re-sampled by index each epoch, the reference's recycle=True mode);
-        # validation: the reference's recycled set (train.py:237-238), resident in HBM
         t0 = time.time()
         if device_feed == "recycle":
             dev_ds = datasets.DeviceRecycledDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points, y_size=out_chunk_size, augment=True, device=device)
@@ -219,13 +220,6 @@ def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=N
                 return val_ds.batches(batch_size, shuffle=False)
         dataloader_val = _ValLoader()
         print(f"device-side data feed ready in {time.time() - t0:.1f} s ({n_data_points // 4} validation windows resident in HBM)")
-    else:
-        dataset = datasets.SynthAudioDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points, y_size=out_chunk_size, augment=True)
-        dataset_val = datasets.SynthAudioDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points // 4, recycle=True,
-                                                 y_size=out_chunk_size, augment=False)
-        dataloader = DataLoader(dataset, batch_size=batch_size, num_workers=num_workers, shuffle=True, worker_init_fn=datasets.worker_init,
-                                drop_last=True)
-        dataloader_val = DataLoader(dataset_val, batch_size=batch_size, num_workers=num_workers, shuffle=False, drop_last=True)
     logfilename = "vl_avg_out.dat"
     open(logfilename, "a").close()
     train_loop(model, engine, effect, device, epochs, batch_size, lr_sched, mom_sched, dataloader, dataloader_val,

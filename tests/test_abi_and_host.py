@@ -110,16 +110,22 @@ def test_learningrate_and_loss_mirrors(golden_dir):
 
 
 def test_audio_and_dataset_contract(golden_dir):
+    from oracle import host_audio
     from signaltrain_amd import audio, datasets
     g = np.load(os.path.join(golden_dir, "g9_compressor.npz"))
     y = audio.compressor_4controls(g["x"], *g["knobs"][:4], sr=g["knobs"][4])
     assert np.abs(y - g["y"]).max() < 1e-6
-    np.testing.assert_array_equal(audio.sliding_window(np.arange(10), 5, overlap=2), [[0, 1, 2, 3, 4], [3, 4, 5, 6, 7], [6, 7, 8, 9, 0]])
+    np.testing.assert_array_equal(host_audio.sliding_window(np.arange(10), 5, overlap=2), [[0, 1, 2, 3, 4], [3, 4, 5, 6, 7], [6, 7, 8, 9, 0]])
+    # the checker-side item assembly (datasets.py:312-334) over the product's host effect: shapes, dtypes, knob range
     np.random.seed(1)
-    ds = datasets.SynthAudioDataSet(8192, audio.Compressor_4c(), y_size=2048)
-    x, yy, k = ds[0]
-    assert x.shape == (8192,) and yy.shape == (2048,) and k.shape == (4,) and x.dtype == np.float32 and k.dtype == np.float32
+    x, yy, k = host_audio.batch(2, 8192, audio.Compressor_4c(), 2048)
+    assert x.shape == (2, 8192) and yy.shape == (2, 2048) and k.shape == (2, 4) and x.dtype == np.float32 and k.dtype == np.float32
     assert np.all(np.abs(k) <= 0.5) and np.abs(x).max() < 1.5
+    # the product's dataset has no per-item host generator: minibatches are made on the GPU (batch_device)
+    ds = datasets.SynthAudioDataSet(8192, audio.Compressor_4c(), y_size=2048)
+    assert len(ds) == 8000
+    with pytest.raises(NotImplementedError):
+        ds[0]
 
 
 def test_cpu_port_matches_oracle():

@@ -5,6 +5,7 @@ Beta(0.8, 0.8) knob law.  The same code runs on the GPU in the -m gpu suite (tes
 import numpy as np
 import torch
 
+from oracle import host_audio as H
 from signaltrain_amd import audio, audio_device as AD
 
 L, SR = 8192, 44100
@@ -21,7 +22,7 @@ def test_families_match_host_generators():
     for c in AD.COMPRESSOR_CHOOSERS:
         x, pick = AD.synth_input_batch(192, L, SR, g, "cpu", chooser=c)
         assert x.shape == (192, L) and x.dtype == torch.float32 and bool((pick == c).all()) and bool(torch.isfinite(x).all())
-        host = np.stack([audio.synth_input_sample(tt, c) for _ in range(96)])
+        host = np.stack([H.synth_input_sample(tt, c) for _ in range(96)])
         peak_d, peak_h = x.abs().amax(1).numpy(), np.abs(host).max(1)
         # normish / box heights bound the peaks: same support (5 % / 95 % quantiles of the per-window peak), same centre
         for q in (0.05, 0.95):
@@ -53,7 +54,7 @@ def test_pinknoise_is_the_reference_construction():
     slope = np.polyfit(np.log(k + 1.0), np.log(spec[k]), 1)[0]
     assert -0.6 < slope < -0.4, slope
     np.random.seed(1)
-    hs = np.abs(np.fft.rfft(np.stack([audio.pinknoise(L) for _ in range(32)]), axis=1)).mean(0)
+    hs = np.abs(np.fft.rfft(np.stack([H.pinknoise(L) for _ in range(32)]), axis=1)).mean(0)
     assert abs(np.polyfit(np.log(k + 1.0), np.log(hs[k]), 1)[0] - slope) < 0.05
 
 

@@ -1,0 +1,98 @@
+"""GPU: the fused comp_4c feed kernel (csrc/st_feed.h, st_synth_comp4c) -- SURVEY.md 8(f)-1.  One launch makes signals, knobs, targets and the
+polarity flip for a whole minibatch; its draws come from a counter-based device generator, so parity with the reference's numpy generators
+(signaltrain/audio.py:85-196, :296-334; restated on the checker side in oracle/host_audio.py) is DISTRIBUTIONAL, like tests/test_device_feed.py for
+the torch generators.  What is exact: y == compressor(x, knobs) (the same device function as st_compressor_4c, itself pinned by golden G9), the
+knob range, and reproducibility per global window index whatever the batching."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+L, Y, SR = 8192, 2048, 44100
+
+
+def _ds(augment=False, seed=11):
+    from signaltrain_amd import audio, datasets
+    np.random.seed(seed)
+    return datasets.SynthAudioDataSet(L, audio.Compressor_4c(), y_size=Y, augment=augment)
+
+
+def test_target_is_the_compressor_of_the_generated_window():
+    from signaltrain_amd import audio
+    ds = _ds()
+    x, y, kn = ds.batch_device(96)
+    assert x.shape == (96, L) and y.shape == (96, Y) and kn.shape == (96, 4) and x.dtype == y.dtype == kn.dtype == torch.float32
+    assert bool(torch.isfinite(x).all()) and bool(torch.isfinite(y).all())
+    assert float(kn.min()) >= -0.5 and float(kn.max()) <= 0.5
+    y2 = audio.Compressor_4c().go_device(x, kn, Y)                  # the stand-alone effect kernel on the same windows
+    assert float((y - y2).abs().max()) <= 1e-6 * float(y2.abs().max())
+    assert float(x.abs().amax(1).min()) > 0.05                      # no silent windows
+
+
+def test_windows_are_a_function_of_seed_and_index_only():
+    a, b = _ds(seed=5), _ds(seed=5)
+    xa, ya, ka = a.batch_device(8)
+    parts = [b.batch_device(3), b.batch_device(5)]
+    xb = torch.cat([p[0] for p in parts]); yb = torch.cat([p[1] for p in parts]); kb = torch.cat([p[2] for p in parts])
+    assert torch.equal(xa, xb) and torch.equal(ya, yb) and torch.equal(ka, kb)
+    xc, _, _ = _ds(seed=6).batch_device(8)
+    assert not torch.equal(xa, xc)
+    xd, _, _ = a.batch_device(8)                                    # the stream moves on
+    assert not torch.equal(xa, xd)
+
+
+def test_families_match_host_generators():
+    from oracle import host_audio as H
+    tt = np.arange(L, dtype=np.float32) / SR
+    np.random.seed(5)
+    ds = _ds()
+    for c in (0, 1, 2, 4, 6, 7):
+        x, _, _ = ds.batch_device(256, chooser=c)
+        x = x.cpu()
+        host = np.stack([H.synth_input_sample(tt, c) for _ in range(96)])
+        peak_d, peak_h = x.abs().amax(1).numpy(), np.abs(host).max(1)
+        for q in (0.05, 0.95):
+            assert abs(np.quantile(peak_d, q) - np.quantile(peak_h, q)) <= 0.06, (c, q, np.quantile(peak_d, q), np.quantile(peak_h, q))
+        assert peak_d.min() >= 0.55 and peak_d.max() <= 1.35
+        assert abs(peak_d.mean() - peak_h.mean()) <= 0.05, (c, peak_d.mean(), peak_h.mean())
+        assert abs(float(x.abs().mean()) - np.abs(host).mean()) <= 0.12 * np.abs(host).mean() + 0.01, (c, float(x.abs().mean()), np.abs(host).mean())
+
+
+def test_all_families_drawn_polarity_and_knob_law():
+    ds = _ds()
+    x, y, kn = ds.batch_device(3000)
+    k = (kn.cpu().numpy() + 0.5).ravel()
+    assert abs(k.mean() - 0.5) < 0.01 and abs(k.var() - 0.25 / 2.6) < 0.006            # Beta(a, a): var = 1 / (4 (2a + 1))
+    np.random.seed(2)
+    ref = np.random.beta(0.8, 0.8, size=k.shape)
+    for q in (0.05, 0.25, 0.5, 0.75, 0.95):
+        assert abs(np.quantile(k, q) - np.quantile(ref, q)) < 0.02, q
+    # the box families (4, 6) are the only ones with exactly-constant stretches: roughly a third of the windows; their mean sign is the polarity
+    xc = x.cpu()
+    flat = ((xc[:, 1:] - xc[:, :-1]).abs() < 1e-7).float().mean(1) > 0.5           # plain box
+    frac = float(flat.float().mean())
+    assert 0.10 < frac < 0.24, frac                                                  # 1 of 6 families
+    neg = float((xc[flat].mean(1) < 0).float().mean())
+    assert 0.3 < neg < 0.7, neg
+
+
+def test_pink_noise_is_the_reference_construction():
+    ds = _ds()
+    y, _, _ = ds.batch_device(64, chooser=100)                       # test hook: x = the bare 1/f noise
+    y = y.cpu()
+    assert float(y.abs().amax(1).min()) > 0.999 and float(y.abs().amax(1).max()) < 1.001        # unit peak
+    assert float((y[:, 1:L // 2] - y[:, L // 2 + 1:].flip(1)).abs().max()) < 2e-4               # real spectrum -> even sequence
+    spec = torch.fft.rfft(y, dim=1).abs().mean(0).numpy()
+    k = np.arange(8, 2000)
+    slope = np.polyfit(np.log(k + 1.0), np.log(spec[k]), 1)[0]
+    assert -0.6 < slope < -0.4, slope
+
+
+def test_long_window_takes_the_noise_from_rocfft():
+    from signaltrain_amd import audio, datasets
+    np.random.seed(3)
+    ds = datasets.SynthAudioDataSet(65536, audio.Compressor_4c(), y_size=16256, augment=True)
+    x, y, kn = ds.batch_device(16)
+    assert x.shape == (16, 65536) and y.shape == (16, 16256) and bool(torch.isfinite(x).all()) and bool(torch.isfinite(y).all())
+    y2 = audio.Compressor_4c().go_device(x, kn, 16256)
+    assert float((y - y2).abs().max()) <= 1e-6 * float(y2.abs().max())

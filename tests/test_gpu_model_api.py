@@ -396,7 +396,8 @@ def test_predict_long_matches_windowed_oracle(golden_dir):
     y = predict_long(sig, kn, m, geo["L"], geo["y"], batch_size=3)
     # like the reference, the prediction starts after the first window's lookback: n - (chunk - out_chunk) samples
     assert y.shape == (n - (geo["L"] - geo["y"]),) and y.dtype == np.float32
-    xw = audio.sliding_window(sig, geo["L"], overlap=geo["L"] - geo["y"])
+    from oracle import host_audio
+    xw = host_audio.sliding_window(sig, geo["L"], overlap=geo["L"] - geo["y"])
     ref = O.model_fwd(np.ascontiguousarray(xw), np.tile(kn, (xw.shape[0], 1)), P, geo)[0].reshape(-1)[:y.size]
     assert np.abs(y - ref).max() <= 1e-4 * np.abs(ref).max()
 
