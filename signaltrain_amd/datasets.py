@@ -28,6 +28,9 @@ class SynthAudioDataSet(Dataset):
         self.chunk_size, self.effect, self.sr, self.datapoints, self.dtype = chunk_size, effect, sr, datapoints, dtype
         self.recycle, self.num_knobs, self.augment = recycle, len(effect.knob_names), augment
         self.y_size = chunk_size if y_size is None else y_size
+        # stream of the fused device feed: (seed, global window index).  The seed is drawn HERE from numpy's global generator, so it follows
+        # np.random.seed(...) of the run (and the rank, train.seed_data_streams); the index counts the windows this dataset has produced
+        self._feed_seed, self._feed_count = int(np.random.randint(0, 2 ** 31 - 1)), 0
 
     def __len__(self):
         return self.datapoints
@@ -52,8 +55,6 @@ class SynthAudioDataSet(Dataset):
             # (and so the rank, train.seed_data_streams), the index counts the windows this dataset has produced.
             import ctypes as C
             from . import _lib
-            if getattr(self, "_feed_seed", None) is None:
-                self._feed_seed, self._feed_count = int(np.random.randint(0, 2 ** 31 - 1)), 0
             x = torch.empty(B, self.chunk_size, dtype=torch.float32, device=device)
             y = torch.empty(B, self.y_size, dtype=torch.float32, device=device)
             kn = torch.empty(B, 4, dtype=torch.float32, device=device)
@@ -103,14 +104,43 @@ class DeviceSynthLoader:
         return self.ds.datapoints // self.batch_size
 
     def __iter__(self):
+        """Chunks of `per_call` minibatches are generated on a SIDE stream one chunk ahead: the generator kernel (one lane per window in
+        its sequential compressor stage) then runs beside the training steps of the previous chunk instead of in front of them."""
+        import torch
+        dev = torch.device(self.device)
+        if dev.type != "cuda":
+            left = len(self)
+            while left > 0:
+                k = min(self.per_call, left)
+                x, y, kn = self.ds.batch_device(k * self.batch_size, self.device)
+                for i in range(k):
+                    sl = slice(i * self.batch_size, (i + 1) * self.batch_size)
+                    yield x[sl], y[sl], kn[sl]
+                left -= k
+            return
+        main = torch.cuda.current_stream(dev)
+        side = getattr(self, "_side", None)
+        if side is None:
+            side = self._side = torch.cuda.Stream(device=dev)
+
+        def produce(k):
+            side.wait_stream(main)                       # buffers the caching allocator hands out may still be read by earlier steps
+            with torch.cuda.stream(side):
+                out = self.ds.batch_device(k * self.batch_size, dev)
+                ev = torch.cuda.Event(); ev.record(side)
+            return out, ev, k
         left = len(self)
-        while left > 0:
-            k = min(self.per_call, left)
-            x, y, kn = self.ds.batch_device(k * self.batch_size, self.device)
+        nxt = produce(min(self.per_call, left)) if left > 0 else None
+        while nxt is not None:
+            (x, y, kn), ev, k = nxt
+            left -= k
+            main.wait_event(ev)
+            for t in (x, y, kn):
+                t.record_stream(main)
+            nxt = produce(min(self.per_call, left)) if left > 0 else None
             for i in range(k):
                 sl = slice(i * self.batch_size, (i + 1) * self.batch_size)
                 yield x[sl], y[sl], kn[sl]
-            left -= k
 
 
 class DeviceRecycledDataSet:

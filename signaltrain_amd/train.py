@@ -84,7 +84,7 @@ def _train_loop(dp, model, engine, effect, device, epochs, batch_size, lr_sched,
     engine.lr = float(lr_in_optimizer)
     opt = engine.optimizer_view()         # state_dict() in torch.optim.Adam's layout for misc.save_checkpoint
     windows, t_train = 0, 0.0
-    clean_steps = 0
+    clean_steps, n_loss = 0, 0
     for epoch in range(int(start_epoch), epochs):
         if is_main:
             print("")
@@ -100,8 +100,13 @@ def _train_loop(dp, model, engine, effect, device, epochs, batch_size, lr_sched,
             dp.train_step(x_c, k_c, y_c, lr_in_optimizer)          # forward, loss, backward, clip, Adam (train.py:112-147)
             batch_num += 1
             if 0 == batch_num % status_every:                        # train.py:124-129 (the only device->host sync)
-                avg_loss = beta * avg_loss + (1 - beta) * dp.mean_loss()
-                smoothed_loss = avg_loss / (1 - beta ** batch_num)
+                # the progress line shows the loss of the PREVIOUS reporting point (no queue drain, dp.mean_loss_lagged); f16 needs the
+                # overflow counter now anyway, and data parallel its collective
+                lval = dp.mean_loss() if (engine.compute_dtype.startswith("f16") or dp.world > 1) else dp.mean_loss_lagged()
+                if lval == lval:
+                    n_loss += 1
+                    avg_loss = beta * avg_loss + (1 - beta) * lval
+                    smoothed_loss = avg_loss / (1 - beta ** (status_every * n_loss))
                 if engine.compute_dtype.startswith("f16"):
                     # loss-scale policy of Apex's dynamic scaler at this loop's only sync point: halve on overflow (the kernel
                     # already skipped those steps), double after 2000 clean steps.  Gated on the arithmetic, not on the current
