@@ -295,10 +295,12 @@ int st_compressor_4c(const float* x, const float* knobs_wc, float sr, int B, int
  * `first_window` = index of window 0 of this call.  K must be 4; knob_lo / knob_hi = Effect.knob_ranges (host arrays of 4).
  * chooser: -1 = drawn per window (the training feed); 0,1,2,4,6,7 force one signal family (tests).
  * pink_in: [B][L] unit-peak 1/f noise for windows longer than 8192 samples (the in-kernel FFT's limit), else NULL.
+ * scratch: B * (L + 4) floats (may be NULL): with it (and L % 64 == 0) the effect's sequential attack / release stage runs one LANE per window
+ * in a second, tiny launch (64 windows per wave) instead of one workgroup per window -- the form that runs beside the training step.
  * Outputs x [B][L], y [B][ysz], knobs [B][4] (fp32, normalised to [-0.5, 0.5]). */
 int st_synth_comp4c(unsigned seed, unsigned long long first_window, int B, int L, int ysz, int K, float sr,
                     const float* knob_lo, const float* knob_hi, int augment, int chooser, const float* pink_in,
-                    float* x, float* y, float* knobs, void* stream);
+                    float* x, float* y, float* knobs, float* scratch, void* stream);
 
 /* Gradient of the loss w.r.t. the (halved) input waveform, for callers with something trainable upstream of the model (the reference's
  * autograd provides it; nn_proc.py:307, cls_fe_dft.py:55-56).  Call right after st_model_bwd on the SAME workspace:

@@ -52,7 +52,7 @@ SIGNATURES = {
     "st_ae_fwd_ws_floats": (C.c_size_t, [_D]),
     "st_compressor_4c": (_i, [_p, _p, C.c_float, C.c_int, C.c_int, C.c_int, _p, _p]),
     "st_synth_comp4c": (_i, [C.c_uint, C.c_ulonglong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float),
-                             C.c_int, C.c_int, _p, _p, _p, _p, _p]),
+                             C.c_int, C.c_int, _p, _p, _p, _p, _p, _p]),
     "st_fe_frames": (_i, [C.c_int] * 4),
     "st_fe_ws_floats": (C.c_size_t, [C.c_int] * 6),
     "st_fe_analysis_fwd": (_i, [_p, C.c_int, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),

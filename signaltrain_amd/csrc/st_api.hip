@@ -1430,7 +1430,7 @@ extern "C" int st_compressor_4c(const float* x, const float* knobs_wc, float sr,
 
 extern "C" int st_synth_comp4c(unsigned seed, unsigned long long first_window, int B, int L, int ysz, int K, float sr,
                                const float* knob_lo, const float* knob_hi, int augment, int chooser, const float* pink_in,
-                               float* x, float* y, float* knobs, void* stream)
+                               float* x, float* y, float* knobs, float* scratch, void* stream)
 {
     ST_REQ(x && y && knobs && knob_lo && knob_hi, "st_synth_comp4c: null pointer");
     ST_REQ(B > 0 && L > 0 && ysz > 0 && ysz <= L && sr > 0.f && K == 4, "st_synth_comp4c: bad sizes (B=%d L=%d ysz=%d K=%d)", B, L, ysz, K);
@@ -1441,9 +1441,16 @@ extern "C" int st_synth_comp4c(unsigned seed, unsigned long long first_window, i
     a.x = x; a.y = y; a.knobs = knobs; a.pink_in = pink_in; a.seed = seed; a.first = first_window;
     a.L = L; a.ysz = ysz; a.K = K; a.sr = sr; a.augment = augment; a.chooser = chooser;
     for (int k = 0; k < 4; ++k) { a.lo[k] = knob_lo[k]; a.hi[k] = knob_hi[k]; }
-    const size_t lds = pink_in ? (size_t)stm::COMP_CH * sizeof(float) : (size_t)stf::FFT_MAX * sizeof(float2);
+    const bool split = scratch && L % 64 == 0;
+    a.gc = split ? scratch : nullptr; a.kw = split ? scratch + (size_t)B * L : nullptr;
+    const size_t lds = pink_in ? (split ? 0 : (size_t)stm::COMP_CH * sizeof(float)) : (size_t)stf::FFT_MAX * sizeof(float2);
     hipLaunchKernelGGL(stf::synth_comp4c_kernel, dim3(B), dim3(256), lds, st_stream(stream), a);
-    ST_LAUNCHED("synth_comp4c"); return ST_OK;
+    ST_LAUNCHED("synth_comp4c");
+    if (split) {
+        hipLaunchKernelGGL(stm::comp_smooth_apply_kernel, dim3((B + 63) / 64), dim3(64), 0, st_stream(stream), x, a.gc, a.kw, sr, B, L, ysz, y);
+        ST_LAUNCHED("comp_smooth_apply");
+    }
+    return ST_OK;
 }
 
 // ------------------------------------------------------------------------------ generic learned-basis front end (a15)

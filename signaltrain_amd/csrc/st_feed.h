@@ -51,6 +51,8 @@ struct FeedArgs {
     int L, ysz, K; float sr;
     float lo[4], hi[4];                     // knob ranges (Effect.knob_ranges, audio.py:493-510)
     int augment;
+    float* gc; float* kw;                   // optional scratch [B][L] + [B][4]: the generator leaves the gain curve and the world-coordinate knobs there and
+                                            // stm::comp_smooth_apply_kernel finishes the effect (lane per window); NULL: the effect runs inside this kernel
     int chooser;                            // -1: drawn per window from {0, 1, 2, 4, 6, 7}; else forced (tests); 100 = the bare 1/f noise (tests)
 };
 constexpr int FFT_MAX = 8192;
@@ -168,6 +170,12 @@ synth_comp4c_kernel(const FeedArgs a)
     __threadfence_block();
     __syncthreads();                                                 // the window is complete (and the FFT buffer is dead)
     // ---- the effect (audio.py:380-426) on the finished window
+    if (a.gc) {                                                      // workgroup-uniform: gain curve in parallel here, recurrence + apply lane-per-window
+        float* gcb = a.gc + (size_t)b * L;
+        for (int n = threadIdx.x; n < L; n += 256) gcb[n] = stm::comp_gain_curve(xb[n], (double)kw[0], (double)kw[1]);
+        if (threadIdx.x == 0) { for (int k = 0; k < 4; ++k) a.kw[(size_t)b * 4 + k] = kw[k]; }
+        return;
+    }
     const double alphaA = exp(-log(9.0) / ((double)a.sr * (double)kw[2])), alphaR = exp(-log(9.0) / ((double)a.sr * (double)kw[3]));
     stm::compressor_window(xb, a.y + (size_t)b * a.ysz, (double)kw[0], (double)kw[1], alphaA, alphaR, L, a.ysz, feed_lds, &carry);
 }

@@ -578,6 +578,70 @@ compressor_window(const float* __restrict__ xb, float* __restrict__ yb, const do
         __syncthreads();
     }
 }
+// The same effect with the sequential stage turned sideways: ONE LANE PER WINDOW, 64 windows per wave.  In compressor_window the attack /
+// release recurrence runs in one lane while the other 255 threads of the workgroup (and its LDS) wait -- 8192 dependent float64 steps, ~240 us
+// per window; as part of the training feed that held every CU for a millisecond per 2048 windows.  Here the gain curve arrives precomputed
+// (gc [B][L], written by the parallel generator kernel), a wave stages [64 windows][64 samples] tiles through LDS (coalesced float4 rows in,
+// one row per lane out), every lane advances ITS window by 64 steps, and the write-back pass applies the smoothed gain to the last ysz
+// samples.  Same step arithmetic as compressor_window (bit-identical results); 32 waves for 2048 windows, so the kernel runs beside the
+// training step on a side stream instead of in front of it.  Requires L % 64 == 0.
+__global__ void __launch_bounds__(64)
+comp_smooth_apply_kernel(const float* __restrict__ x, const float* __restrict__ gc, const float* __restrict__ kw, const float sr,
+                         const int B, const int L, const int ysz, float* __restrict__ y)
+{
+    __shared__ float tile[64][65];
+    const int lane = threadIdx.x, b0 = blockIdx.x * 64, b = b0 + lane;
+    const int bc = b < B ? b : B - 1;
+    const double alphaA = exp(-log(9.0) / ((double)sr * (double)kw[4 * bc + 2]));
+    const double alphaR = exp(-log(9.0) / ((double)sr * (double)kw[4 * bc + 3]));
+    const int q = lane >> 4, c4 = 4 * (lane & 15);
+    float prev = 0.f;
+    for (int c0 = 0; c0 < L; c0 += 64) {
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int r = 4 * i + q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b0 + r < B) v = *reinterpret_cast<const float4*>(gc + (size_t)(b0 + r) * L + c0 + c4);
+            tile[r][c4] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
+        }
+        __syncthreads();
+        int k = 0;
+        if (c0 == 0) { tile[lane][0] = 0.f; k = 1; }        // lin_A[0] = 0: the loop of the reference starts at n = 1
+        for (; k < 64; ++k) {
+            const float gi_f = tile[lane][k];
+            const double a = gi_f < prev ? alphaA : alphaR;
+            const double gi = gi_f;
+            prev = (float)__builtin_fma(a, (double)prev - gi, gi);
+            tile[lane][k] = prev;
+        }
+        __syncthreads();
+        if (c0 + 64 > L - ysz) {
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                const int r = 4 * i + q;
+                if (b0 + r < B) {
+                    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)(b0 + r) * L + c0 + c4);
+                    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int j = c0 + c4 + e - (L - ysz);
+                        if (j >= 0) y[(size_t)(b0 + r) * ysz + j] = (float)pow(10.0, (double)tile[r][c4 + e] / 20.0) * xs[e];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+// the static gain curve of one sample (audio.py:392-399), shared by the kernels above and the feed generator
+__device__ __forceinline__ float comp_gain_curve(const float xv, const double thresh, const double ratio)
+{
+    float xdb = (float)(20.0 * log10((double)fabsf(xv) + 1e-8));
+    if (xdb < -96.0f) xdb = -96.0f;
+    float gc = 0.0f;
+    if ((double)xdb > thresh) gc = (float)(thresh + ((double)xdb - thresh) / ratio - (double)xdb);
+    return gc;
+}
 __global__ void __launch_bounds__(256)
 compressor_4c_kernel(const float* __restrict__ x, const float* __restrict__ knobs_wc, float sr, int L, int ysz, float* __restrict__ y)
 {

@@ -69,6 +69,7 @@ class SynthAudioDataSet(Dataset):
             with torch.cuda.device(device):
                 _lib.check(_lib.load().st_synth_comp4c(self._feed_seed, self._feed_count, B, self.chunk_size, self.y_size, 4, float(self.sr), lo, hi,
                                                        1 if self.augment else 0, int(chooser), _lib.ptr(pink), _lib.ptr(x), _lib.ptr(y), _lib.ptr(kn),
+                                                       _lib.ptr(torch.empty(B * (self.chunk_size + 4), dtype=torch.float32, device=device)),
                                                        C.c_void_p(torch.cuda.current_stream(device).cuda_stream)), "st_synth_comp4c")
             self._feed_count += B
             return x, y, kn

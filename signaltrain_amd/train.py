@@ -83,7 +83,7 @@ def _train_loop(dp, model, engine, effect, device, epochs, batch_size, lr_sched,
     lr_in_optimizer = lr_sched[0] if lr_resume is None else lr_resume      # torch.optim.Adam(lr=lr_sched[0]), train.py:228
     engine.lr = float(lr_in_optimizer)
     opt = engine.optimizer_view()         # state_dict() in torch.optim.Adam's layout for misc.save_checkpoint
-    windows, t_train = 0, 0.0
+    windows, t_train, t_last = 0, 0.0, 0.0
     clean_steps, n_loss = 0, 0
     for epoch in range(int(start_epoch), epochs):
         if is_main:
@@ -125,14 +125,16 @@ def _train_loop(dp, model, engine, effect, device, epochs, batch_size, lr_sched,
             iter_count += 1
             windows += batch_size
         torch.cuda.synchronize()
-        t_train += time.time() - t_ep
+        t_last = time.time() - t_ep
+        t_train += t_last
         vl_avg = eval_status_save(model, engine, effect, epoch, epochs, lr_in_optimizer, 0.0, device, dataloader_val, logfilename,
                                   first_time, beta, vl_avg, out_checkpointname, False, opt, data_point, smoothed_loss, y_size, sr,
                                   status_every, is_main=is_main)
     if is_main:
         world = dist.get_world_size() if dist.is_initialized() else 1
+        per_epoch = windows // max(epochs - int(start_epoch), 1)
         print(f"\nTotal elapsed time for training loop = {time.time() - first_time:.2f}  "
-              f"({windows * world / max(t_train, 1e-9):.0f} train windows/s incl. the data feed)")
+              f"({windows * world / max(t_train, 1e-9):.0f} train windows/s incl. the data feed; last epoch {per_epoch * world / max(t_last, 1e-9):.0f})")
     return None
 
 

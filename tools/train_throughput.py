@@ -9,11 +9,11 @@ nn_proc._QUIET = True
 os.chdir(tempfile.mkdtemp())
 B = 256
 DT = sys.argv[1] if len(sys.argv) > 1 else "f32"
-for feed, npts, workers in (("device", 256 * 400, 2), ("recycle", 256 * 400, 2)):
+for feed, npts, workers in (("device", 256 * 1500, 2), ("recycle", 256 * 1500, 2)):
     torch.manual_seed(0); np.random.seed(0)
     t0 = time.time()
-    train.train(effect=audio.Compressor_4c(), epochs=2, n_data_points=npts, batch_size=B, device=torch.device("cuda:0"),
+    train.train(effect=audio.Compressor_4c(), epochs=3, n_data_points=npts, batch_size=B, device=torch.device("cuda:0"),
                 num_workers=workers, device_feed={"device": True, "recycle": "recycle"}[feed], compute_dtype=DT)
-    print(f"==> dtype={DT} feed={feed}: total wall {time.time() - t0:.1f} s for {2 * npts} training windows (see the loop's own windows/s line above)")
+    print(f"==> dtype={DT} feed={feed}: total wall {time.time() - t0:.1f} s for {3 * npts} training windows (see the loop's own windows/s line above)")
     for f in ("modelcheckpoint.tar", "vl_avg_out.dat", "val_err_mae.dat"):
         if os.path.exists(f): os.remove(f)
