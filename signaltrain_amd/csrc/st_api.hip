@@ -1447,8 +1447,10 @@ extern "C" int st_synth_comp4c(unsigned seed, unsigned long long first_window, i
     hipLaunchKernelGGL(stf::synth_comp4c_kernel, dim3(B), dim3(256), lds, st_stream(stream), a);
     ST_LAUNCHED("synth_comp4c");
     if (split) {
-        hipLaunchKernelGGL(stm::comp_smooth_apply_kernel, dim3((B + 63) / 64), dim3(64), 0, st_stream(stream), x, a.gc, a.kw, sr, B, L, ysz, y);
-        ST_LAUNCHED("comp_smooth_apply");
+        hipLaunchKernelGGL(stm::comp_smooth_kernel, dim3((B + 63) / 64), dim3(64), 0, st_stream(stream), a.gc, a.kw, sr, B, L);
+        ST_LAUNCHED("comp_smooth");
+        hipLaunchKernelGGL(stm::comp_apply_kernel, dim3((ysz + 255) / 256, B), dim3(256), 0, st_stream(stream), x, a.gc, L, ysz, y);
+        ST_LAUNCHED("comp_apply");
     }
     return ST_OK;
 }

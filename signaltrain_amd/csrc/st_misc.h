@@ -582,12 +582,11 @@ compressor_window(const float* __restrict__ xb, float* __restrict__ yb, const do
 // release recurrence runs in one lane while the other 255 threads of the workgroup (and its LDS) wait -- 8192 dependent float64 steps, ~240 us
 // per window; as part of the training feed that held every CU for a millisecond per 2048 windows.  Here the gain curve arrives precomputed
 // (gc [B][L], written by the parallel generator kernel), a wave stages [64 windows][64 samples] tiles through LDS (coalesced float4 rows in,
-// one row per lane out), every lane advances ITS window by 64 steps, and the write-back pass applies the smoothed gain to the last ysz
-// samples.  Same step arithmetic as compressor_window (bit-identical results); 32 waves for 2048 windows, so the kernel runs beside the
+// one row per lane out), every lane advances ITS window by 64 steps and the smoothed gain goes back in place; comp_apply_kernel then applies it to
+// the last ysz samples.  Same step arithmetic as compressor_window (bit-identical results); 32 waves for 2048 windows, so the kernel runs beside the
 // training step on a side stream instead of in front of it.  Requires L % 64 == 0.
 __global__ void __launch_bounds__(64)
-comp_smooth_apply_kernel(const float* __restrict__ x, const float* __restrict__ gc, const float* __restrict__ kw, const float sr,
-                         const int B, const int L, const int ysz, float* __restrict__ y)
+comp_smooth_kernel(float* __restrict__ gc, const float* __restrict__ kw, const float sr, const int B, const int L)
 {
     __shared__ float tile[64][65];
     const int lane = threadIdx.x, b0 = blockIdx.x * 64, b = b0 + lane;
@@ -596,42 +595,57 @@ comp_smooth_apply_kernel(const float* __restrict__ x, const float* __restrict__ 
     const double alphaR = exp(-log(9.0) / ((double)sr * (double)kw[4 * bc + 3]));
     const int q = lane >> 4, c4 = 4 * (lane & 15);
     float prev = 0.f;
-    for (int c0 = 0; c0 < L; c0 += 64) {
-#pragma unroll 4
+    float4 nx[16];                                         // the next tile, loaded while this one's chain runs
+    auto load = [&](const int c0) {
+#pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int r = 4 * i + q;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b0 + r < B) v = *reinterpret_cast<const float4*>(gc + (size_t)(b0 + r) * L + c0 + c4);
-            tile[r][c4] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
+            nx[i] = *reinterpret_cast<const float4*>(gc + (size_t)(b0 + r < B ? b0 + r : B - 1) * L + c0 + c4);
+        }
+    };
+    load(0);
+    for (int c0 = 0; c0 < L; c0 += 64) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = 4 * i + q;
+            tile[r][c4] = nx[i].x; tile[r][c4 + 1] = nx[i].y; tile[r][c4 + 2] = nx[i].z; tile[r][c4 + 3] = nx[i].w;
         }
         __syncthreads();
-        int k = 0;
-        if (c0 == 0) { tile[lane][0] = 0.f; k = 1; }        // lin_A[0] = 0: the loop of the reference starts at n = 1
-        for (; k < 64; ++k) {
-            const float gi_f = tile[lane][k];
+        load(c0 + 64 < L ? c0 + 64 : c0);
+        // the lane's 64 samples through REGISTERS: reading tile[lane][k + 1] behind the store of tile[lane][k] serialises an LDS round trip
+        // into every step of the dependent chain
+        float gv[64];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) gv[k] = tile[lane][k];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            if (k == 0 && c0 == 0) { gv[0] = 0.f; continue; }        // lin_A[0] = 0: the loop of the reference starts at n = 1
+            const float gi_f = gv[k];
             const double a = gi_f < prev ? alphaA : alphaR;
             const double gi = gi_f;
             prev = (float)__builtin_fma(a, (double)prev - gi, gi);
-            tile[lane][k] = prev;
+            gv[k] = prev;
         }
-        __syncthreads();
-        if (c0 + 64 > L - ysz) {
-#pragma unroll 4
-            for (int i = 0; i < 16; ++i) {
-                const int r = 4 * i + q;
-                if (b0 + r < B) {
-                    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)(b0 + r) * L + c0 + c4);
-                    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int j = c0 + c4 + e - (L - ysz);
-                        if (j >= 0) y[(size_t)(b0 + r) * ysz + j] = (float)pow(10.0, (double)tile[r][c4 + e] / 20.0) * xs[e];
-                    }
-                }
-            }
+        for (int k = 0; k < 64; ++k) tile[lane][k] = gv[k];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {                      // smoothed gain back in place, coalesced rows
+            const int r = 4 * i + q;
+            if (b0 + r < B) *reinterpret_cast<float4*>(gc + (size_t)(b0 + r) * L + c0 + c4) = make_float4(tile[r][c4], tile[r][c4 + 1], tile[r][c4 + 2], tile[r][c4 + 3]);
         }
         __syncthreads();
     }
+}
+// dB -> linear and apply (audio.py:421-425) on the last ysz samples: fully parallel (the float64 pow is ~300 instructions; inside the
+// lane-per-window kernel it was 2/3 of its 1.8 ms)
+__global__ void __launch_bounds__(256)
+comp_apply_kernel(const float* __restrict__ x, const float* __restrict__ g, const int L, const int ysz, float* __restrict__ y)
+{
+    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= ysz) return;
+    const size_t i = (size_t)b * L + (L - ysz) + j;
+    y[(size_t)b * ysz + j] = (float)pow(10.0, (double)g[i] / 20.0) * x[i];
 }
 // the static gain curve of one sample (audio.py:392-399), shared by the kernels above and the feed generator
 __device__ __forceinline__ float comp_gain_curve(const float xv, const double thresh, const double ratio)
