@@ -185,12 +185,14 @@ static int g_frs_nt = 1;     // synthesis frames GEMM against the transposed fol
 static int g_xt = 0;       // 1: M/N-contiguous operands staged k-quad-major (st_gemm.h XT; st_set_tuning(7001), diagnostics).  MEASURED SLOWER at B=256 although
                            // conflict-free with a third fewer LDS cycles: analysis wgrad 173 vs 145 us, synthesis frames 63 vs 60 us (16 more prefetch
                            // registers -> 4 instead of 4.5 waves per SIMD, and 16 v_mov per micro-tile): the k-major staging stays the default
+static int g_nt_mi = 0;     // fp32 NT x NT GEMMs with 64 x 96 wave tiles (MI = 2): 0 off; bit 0 analysis forward <4,16,2>, bit 1 <2,32,2>, bit 2 frames / dgrad <2,16,2>  (st_set_tuning(9800 + n), experiments)
 static int g_an_bk = 32;   // k-tile depth of the analysis forward GEMM (see ST_GEMM_AN)
 static int g_bk = 16;   // k-tile depth of the GEMM family (16: 36 KB LDS/WG -> 4 WGs/CU; 32: 64 KB -> 2 WGs/CU)
 static int g_wg_mode_set(int v);
 static int g_wsplit_max = 16, g_wsplit_div = 200, g_an_waves = 4, g_syn_split = 3, g_frs_split = 3, g_wide_fused = 1, g_wsplit_half = 0;      // frames: 3, 4 measured equal, 6 slower (only 66 k-tiles to split)
 extern "C" int st_set_tuning(int bk)
 {
+    if (bk >= 9800) { g_nt_mi = bk - 9800; return ST_OK; }
     if (bk >= 9700) { g_g16_split = bk - 9700; return ST_OK; }
     if (bk >= 9600) { const int v = bk - 9600; if (v == 32 || v == 64) g_g16_bk = v; else g_g16 = v; return ST_OK; }
     if (bk >= 9500) { const int v = bk - 9500; if (v == 16 || v == 32) g_tn_bk = v; else g_tn128 = v; return ST_OK; }
@@ -385,7 +387,9 @@ static int analysis_fwd_impl(const st_dims* d, const float* sig, bool padded, co
     stg::PolarStore ep{re, im, mag, phs, R, d->F, map};
     if (padded) {
         stg::FramedNT<true> al{sig, d->L, d->H, d->N, R, d->N, 1.0f, map};
-        if (g_an_waves == 2) ST_GEMM_AN(2, al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream));
+        if (gemm_ht(d->prec) == 0 && (g_nt_mi & 1)) stg::launch<4, 16, 2>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream), g_dbg);
+        else if (gemm_ht(d->prec) == 0 && (g_nt_mi & 2)) stg::launch<2, 32, 2>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream), g_dbg);
+        else if (g_an_waves == 2) ST_GEMM_AN(2, al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream));
         else if (g_an_waves == 3) ST_GEMM_AN(3, al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream));
         else ST_GEMM_AN(4, al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream));
     }
@@ -486,6 +490,7 @@ static int synthesis_frames_impl(const st_dims* d, const float* AA, const float*
     if (SfoldT && g_frs_nt) {
         stg::PlainNT bt{SfoldT, d->N, KP, KP, stg::all_frames(1)};
         if (R >= 4096) ST_GEMM(4, al, bt, ep, R, d->N, KP, 1, st_stream(stream));
+        else if (gemm_ht(d->prec) == 0 && (g_nt_mi & 4)) stg::launch<2, 16, 2>(al, bt, ep, R, d->N, KP, frames_split(R), st_stream(stream), g_dbg);
         else ST_GEMM(2, al, bt, ep, R, d->N, KP, frames_split(R), st_stream(stream));
     }
     else if (R >= 4096) ST_GEMM(4, al, bl, ep, R, d->N, KP, 1, st_stream(stream));
@@ -523,7 +528,9 @@ static int synthesis_dgrad_impl(const st_dims* d, const float* dsyn, bool padded
     const int ns = R >= 4096 ? 1 : synth_split(R);
     if (padded) {
         stg::FramedNT<true> al{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms};
-        if (R >= 4096) ST_GEMM(4, al, bl, ep, R, KP, d->N, ns, st_stream(stream)); else ST_GEMM(2, al, bl, ep, R, KP, d->N, ns, st_stream(stream));
+        if (R >= 4096) ST_GEMM(4, al, bl, ep, R, KP, d->N, ns, st_stream(stream));
+        else if (gemm_ht(d->prec) == 0 && (g_nt_mi & 4)) stg::launch<2, 16, 2>(al, bl, ep, R, KP, d->N, ns, st_stream(stream), g_dbg);
+        else ST_GEMM(2, al, bl, ep, R, KP, d->N, ns, st_stream(stream));
     } else {
         stg::FramedNT<false> al{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms};
         if (R >= 4096) ST_GEMM(4, al, bl, ep, R, KP, d->N, ns, st_stream(stream)); else ST_GEMM(2, al, bl, ep, R, KP, d->N, ns, st_stream(stream));

@@ -265,6 +265,43 @@ def test_train_driver_short_run(tmp_path):
         os.chdir(cwd)
 
 
+def test_scale8_golden_backward(golden_dir):
+    """Golden G8b (the reference's autograd at the 65536-sample window, B = 1): loss and gradients of the HIP path -- the wide autoencoder
+    kernels of st_ae_wide.h, the 174-frame GEMMs -- through the drop-in st_model + autograd AND through the fused loss_backward entry."""
+    from oracle import st_oracle as O
+    from tests.test_oracle_golden import golden_params
+    from tests.golden_util import ae_keys, projections, SAMPLE_ROWS, STFT_KEYS
+    from signaltrain_amd import nn_proc, loss_functions
+    nn_proc._QUIET = True
+    g8 = np.load(os.path.join(golden_dir, "g8_scale8.npz")); g = np.load(os.path.join(golden_dir, "g8b_scale8_backward.npz"))
+    geo = O.geometry(8, 4)
+    P = golden_params(golden_dir, geo, "g8_scale8.npz", "ae_", seed=9)
+    m = nn_proc.st_model(scale_factor=8, shrink_factor=4, num_knobs=4)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in P.items()})
+    m = m.to("cuda:0")
+    x, kn, yt = torch.from_numpy(g8["x"]).cuda(), torch.from_numpy(g8["knobs"]).cuda(), torch.from_numpy(g["y"]).cuda()
+    PROJ = projections(seed=13)
+
+    def check(loss, grads, what):
+        assert abs(loss - float(g["loss"])) <= 1e-4 * abs(float(g["loss"])), (what, loss, float(g["loss"]))
+        for k in ae_keys():
+            ref = g["g_" + k]
+            assert np.abs(grads[k] - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-12, (what, k)
+        for k in STFT_KEYS:
+            gk = grads[k].reshape(1024, 1024)
+            assert np.abs(gk[SAMPLE_ROWS] - g["rows_" + k]).max() <= 2e-4 * np.abs(g["rows_" + k]).max(), (what, k)
+            assert np.abs(PROJ @ gk - g["proj_" + k]).max() <= 2e-4 * np.abs(g["proj_" + k]).max(), (what, k)
+            assert abs(np.abs(gk).sum() - float(g["l1_" + k])) <= 1e-3 * float(g["l1_" + k]), (what, k)
+    y, mag, mag_hat = m.forward(x, kn)
+    sbf = torch.exp((7. / 513) * torch.arange(0., 513, device="cuda")).expand_as(mag_hat).float()
+    loss = loss_functions.calc_loss(y, yt, mag_hat, scale_by_freq=sbf)
+    loss.backward()
+    check(loss.item(), {k: p.grad.detach().cpu().numpy().astype(np.float64) for k, p in m.named_parameters()}, "autograd")
+    eng = m.engine(x)
+    eng.loss_backward(x, kn, yt); torch.cuda.synchronize()
+    check(float(eng.scalars[0]), {k: v.detach().cpu().numpy().astype(np.float64) for k, v in eng.layout.views(eng.grads).items()}, "fused")
+
+
 def test_scale8_golden_forward(golden_dir):
     """BASELINE configs[4] geometry (65536-sample window: T=174, OT=46, y=16256): the reference's forward
     outputs (golden G8, mag_hat sampled every 4th bin) reproduced by the HIP path through st_model."""

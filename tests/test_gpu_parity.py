@@ -96,32 +96,40 @@ def test_ae_bwd_repeatable():
     assert not names, names
 
 
-def test_full_size_batch_properties():
-    """BASELINE configs[1] size (B = 256 windows of 8192 samples): properties that do not need the (slow) oracle.
-    Windows are independent, the loss is a mean over the batch and the L1 term a mean over B*OT*F, so
+@pytest.mark.parametrize("dtype", ["f32", "bf16_all", "f16_all"])
+@pytest.mark.parametrize("scale,B", [(1, 256), (8, 64)])
+def test_full_size_batch_properties(dtype, scale, B):
+    """The per-GPU workloads of BASELINE configs[1..4] at FULL size -- 256 windows of 8192 samples, 64 windows of 65536 -- in the three
+    arithmetic modes the configs name: properties that do not need the (slow) oracle.  Windows are independent, the loss is a mean over
+    the batch and the L1 term a mean over B*OT*F, so
       forward(B) == concat(forward(halves)),   grads(B) == (grads(half 1) + grads(half 2)) / 2,
-    and two runs give identical bits.  Exercises the full-size tiling / split-K / reduction paths."""
+    and two runs give identical bits.  Exercises the full-size tiling / split-K / reduction paths (128 x 128 weight-gradient tiles + Nyquist
+    partials, the 16-bit operand pipeline, the wide autoencoder path).  16-bit modes: every product is exact in fp32 on both sides, only
+    fp32 sums re-associate -- and d loss / d y_hat carries 1 / (B y), a power of two between full and half batch, which commutes with the
+    rounding except for fp16 subnormals: tolerance 2e-3 there."""
     import numpy as np, torch
     from tests import gpu_checks as G
     from signaltrain_amd.engine import StepEngine
-    B, K = 256, 4
-    geo, X, Y, KN, P = G.make_case(8, 31, K=K)
+    K = 4
+    geo, X, Y, KN, P = G.make_case(8, 31, K=K, scale=scale)
     rng = np.random.default_rng(1)
     reps = B // 8
     X = (np.tile(X, (reps, 1)) * rng.uniform(0.4, 1.0, (B, 1))).astype(np.float32)
     Y = (np.tile(Y, (reps, 1)) * rng.uniform(0.4, 1.0, (B, 1))).astype(np.float32)
     KN = (rng.random((B, K)) - 0.5).astype(np.float32)
     x, y, kn = G.t(X), G.t(Y), G.t(KN)
-    full = StepEngine(G.dims_of(geo, B, K), G.DEV); full.load_state_dict(P)
-    half = StepEngine(G.dims_of(geo, B // 2, K), G.DEV); half.load_state_dict(P)
+    tf, tg = (1e-6, 2e-5) if dtype == "f32" else (1e-6, 2e-3)
+    full = StepEngine(G.dims_of(geo, B, K), G.DEV, compute_dtype=dtype); full.load_state_dict(P)
+    half = StepEngine(G.dims_of(geo, B // 2, K), G.DEV, compute_dtype=dtype); half.load_state_dict(P)
     yf, mf, hf = full.forward(x, kn)
     parts = [half.forward(x[i:i + B // 2], kn[i:i + B // 2]) for i in (0, B // 2)]
     for a, name, j in ((yf, "y_hat", 0), (mf, "mag", 1), (hf, "mag_hat", 2)):
         ref = torch.cat([p[j] for p in parts])
-        assert (a - ref).abs().max().item() <= 1e-6 * ref.abs().max().item(), name
+        assert (a - ref).abs().max().item() <= tf * ref.abs().max().item(), name
     full.loss_backward(x, kn, y); torch.cuda.synchronize(); g_full = full.grads.clone(); l_full = float(full.scalars[0])
     full.loss_backward(x, kn, y); torch.cuda.synchronize()
     assert torch.equal(g_full, full.grads)                          # bit-repeatable at full size
+    assert bool(torch.isfinite(g_full).all())
     gs, ls = [], []
     for i in (0, B // 2):
         half.loss_backward(x[i:i + B // 2], kn[i:i + B // 2], y[i:i + B // 2]); torch.cuda.synchronize()
@@ -130,7 +138,7 @@ def test_full_size_batch_properties():
     assert abs(l_full - 0.5 * (ls[0] + ls[1])) <= 1e-5 * abs(l_full)
     for name, v in full.layout.views(g_full).items():
         r = full.layout.views(g_ref)[name]
-        assert (v - r).abs().max().item() <= 2e-5 * max(r.abs().max().item(), 1e-12), name
+        assert (v - r).abs().max().item() <= tg * max(r.abs().max().item(), 1e-12), (name, (v - r).abs().max().item(), r.abs().max().item())
 
 
 @pytest.mark.parametrize("B,seed,K", [(3, 0, 4), (5, 2, 3)])

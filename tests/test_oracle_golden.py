@@ -187,6 +187,24 @@ def test_g8_scale8(golden_dir):
     close(y, g["y_hat"], 5e-6, "y"); close(mag_hat[:, :, ::4], g["mag_hat"], 5e-6, "mag_hat")
 
 
+def test_g8b_scale8_backward(golden_dir):
+    """BASELINE configs[4] geometry (T = 174, OT = 46): the reference's autograd at the 65536-sample window (golden G8b, round 3) --
+    loss, all 36 autoencoder gradients, the STFT gradients by sampled rows / projections / L1 norms -- against the oracle's hand-derived
+    backward, which rounds 1-2 had pinned at scale 1 only."""
+    g8, g = load(golden_dir, "g8_scale8.npz"), load(golden_dir, "g8b_scale8_backward.npz")
+    geo = O.geometry(8, 4)
+    P = golden_params(golden_dir, geo, "g8_scale8.npz", "ae_", seed=9)
+    loss, G, _ = O.model_loss_bwd(g8["x"].astype(np.float64), g8["knobs"].astype(np.float64), g["y"].astype(np.float64), P, geo)
+    close(loss, g["loss"], 3e-5, "loss")
+    for k in ae_keys():
+        close(G[k], g["g_" + k], 3e-5, k)
+    PROJ = projections(seed=13)
+    for k in STFT_KEYS:
+        close(G[k][SAMPLE_ROWS, 0, :], g["rows_" + k], 3e-5, "rows " + k)
+        close(PROJ @ G[k][:, 0, :], g["proj_" + k], 3e-5, "proj " + k)
+        close(np.abs(G[k]).sum(), g["l1_" + k], 1e-4, "l1 " + k)
+
+
 def test_g9_compressor(golden_dir):
     g = load(golden_dir, "g9_compressor.npz")
     y = O.compressor_4controls(g["x"].copy(), *g["knobs"][:4], sr=g["knobs"][4])

@@ -13,8 +13,12 @@ nn_proc._QUIET = True
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 dev = torch.device("cuda:0")
-MODES = ("f32", "f32+1e-6", "f32+seed", "f32x3", "bf16", "bf16_all", "f16", "f16_all")     # f32+1e-6: fp32 from initial weights perturbed by 1e-6 relative;
-                                                                                               # f32+seed: fp32 with the minibatch order reversed -- the spread of the loss itself
+MODES = ("f32", "f32+1e-6", "f32+seed", "f32x3", "bf16", "bf16_all", "f16", "f16_all",
+         "f32/ca1", "bf16_all/ca1", "f16_all/ca0")     # f32+1e-6: fp32 from initial weights perturbed by 1e-6 relative; f32+seed: fp32 with the minibatch order reversed -- the
+                                                        # spread of the loss itself; /ca1, /ca0: the L1 clip over ALL parameters (train.py:136, the f16 modes' default) switched on / off:
+                                                        # separates the clip SCOPE from the operand ROUNDING as the cause of the 16-bit modes' lower final loss
+if len(sys.argv) > 3:
+    MODES = tuple(sys.argv[3].split(","))
 
 torch.manual_seed(218); np.random.seed(218)
 model = nn_proc.st_model(scale_factor=1, shrink_factor=4, num_knobs=4)
@@ -37,7 +41,9 @@ def val_loss(eng_params):
 
 rows = {}
 for mode in MODES:
-    eng = StepEngine(d, dev, compute_dtype=mode.split("+")[0]); eng.load_state_dict(sd)
+    base = mode.split("+")[0].split("/")[0]
+    ca = {"ca1": True, "ca0": False}.get(mode.split("/")[1]) if "/" in mode else None
+    eng = StepEngine(d, dev, compute_dtype=base, clip_all=ca); eng.load_state_dict(sd)
     if mode == "f32+1e-6":
         g = torch.Generator(device=dev); g.manual_seed(1)
         eng.params.mul_(1.0 + 1e-6 * torch.randn(eng.params.shape, device=dev, generator=g))
@@ -54,6 +60,6 @@ for mode in MODES:
                       val=val_loss(eng.params), skipped=int(eng.scalars[5]))
 ref = rows["f32"]
 print(f"{STEPS} steps of batch {B} (comp_4c windows generated on the device, 1-cycle lr to 1e-3), training loss = mean over the steps of each quarter; validation: 256 fixed windows, fp32 forward")
-print(f"{'mode':9s} {'first 10':>10s} {'Q1':>10s} {'Q2':>10s} {'Q3':>10s} {'Q4':>10s} {'last 50':>10s} {'validation':>11s} {'val vs f32':>10s} {'skipped steps':>14s}")
+print(f"{'mode':12s} {'first 10':>10s} {'Q1':>10s} {'Q2':>10s} {'Q3':>10s} {'Q4':>10s} {'last 50':>10s} {'validation':>11s} {'val vs f32':>10s} {'skipped steps':>14s}")
 for mode, r in rows.items():
-    print(f"{mode:9s} {r['first']:10.3e} " + " ".join(f"{v:10.3e}" for v in r["quarters"]) + f" {r['last50']:10.3e} {r['val']:11.3e} {r['val'] / ref['val'] - 1:+10.1%} {r['skipped']:14d}")
+    print(f"{mode:12s} {r['first']:10.3e} " + " ".join(f"{v:10.3e}" for v in r["quarters"]) + f" {r['last50']:10.3e} {r['val']:11.3e} {r['val'] / ref['val'] - 1:+10.1%} {r['skipped']:14d}")
