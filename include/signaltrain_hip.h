@@ -281,6 +281,16 @@ int st_graph_create(const st_dims* d, float* params, float* grads, float* m, flo
 int st_graph_launch(st_graph* g, void* stream);
 int st_graph_destroy(st_graph* g);
 
+/* ---- diagnostics: the activations st_model.forward(return_acts=True) returns (nn_proc.py:311-338, plotted by utils/viz.py:135) ----
+ * st_workspace_offsets: float offsets, inside a workspace carved for d, of the forward state st_model_fwd(save_for_backward = 1) left:
+ *   offs8 = { re, im, mag, phs [B][T][F], mag_hat, phs_hat [B][OT][F], AA [B*OT][KP] (an_real | an_imag halves), y_hat [B][y] }.
+ * st_ae_acts: the ten activation tensors of ONE autoencoder (nn_proc.py:77-126 with return_acts), [B][F][width] each, concatenated
+ *   (widths 64, 32, 16, 16, 16 + K, 16, 16, 32, 64, OT = st_ae_acts_floats(d) floats); v = its [B][T][F] input, ae = its packed parameters,
+ *   sf != 0 for the magnitude net's skip-filter output (nn_proc.py:115), 0 for the phase net's bare output (nn_proc.py:117). */
+int st_workspace_offsets(const st_dims* d, int64_t* offs8);
+size_t st_ae_acts_floats(const st_dims* d);
+int st_ae_acts(const st_dims* d, const float* v, const float* knobs, const float* ae, int sf, float* acts, void* stream);
+
 /* ---- device-side data feed -------------------------------------------------------------------
  * audio.compressor_4controls (signaltrain/audio.py:380-426), the effect of the synthetic comp_4c task
  * (SynthAudioDataSet, datasets.py:312-334), for a batch of device-resident windows:

@@ -50,6 +50,9 @@ SIGNATURES = {
     "st_analysis_fwd": (_i, [_D, _p, _p, _p, _f, _p, _p, _p, _p, _p]),
     "st_ae_fwd": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "st_ae_fwd_ws_floats": (C.c_size_t, [_D]),
+    "st_workspace_offsets": (_i, [_D, C.POINTER(C.c_int64)]),
+    "st_ae_acts_floats": (C.c_size_t, [_D]),
+    "st_ae_acts": (_i, [_D, _p, _p, _p, _i, _p, _p]),
     "st_compressor_4c": (_i, [_p, _p, C.c_float, C.c_int, C.c_int, C.c_int, _p, _p]),
     "st_synth_comp4c": (_i, [C.c_uint, C.c_ulonglong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float),
                              C.c_int, C.c_int, _p, _p, _p, _p, _p, _p]),

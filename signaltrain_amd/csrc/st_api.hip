@@ -984,6 +984,35 @@ static void carve(const st_dims* d, void* base, WS* w)
     w->g16 = false;
     w->bytes = off * sizeof(float);
 }
+// float offsets of the forward state inside a workspace carved for `d` (after st_model_fwd with save_for_backward):
+// re, im, mag, phs [B][T][F]; mag_hat, phs_hat [B][OT][F]; AA [B*OT][KP] (an_real at columns [0, F), an_imag at [KP/2, KP/2 + F)); y_hat [B][y].
+// For diagnostics (st_model.forward(return_acts=True), nn_proc.py:311-338): the caller views its own buffer, nothing is copied.
+extern "C" int st_workspace_offsets(const st_dims* d, int64_t* offs8)
+{
+    ST_TRY(check_dims(d)); ST_REQ(offs8, "st_workspace_offsets: null pointer");
+    WS w; carve(d, reinterpret_cast<void*>(sizeof(float)), &w);       // a non-null dummy base: pointer differences are the offsets
+    float* base = reinterpret_cast<float*>(sizeof(float));
+    float* p[8] = {w.re, w.im, w.mag, w.phs, w.mag_hat, w.phs_hat, w.AA, w.y_hat};
+    for (int i = 0; i < 8; ++i) offs8[i] = (int64_t)(p[i] - base);
+    return ST_OK;
+}
+// The ten return_acts tensors of ONE autoencoder (nn_proc.py:77-126), [B][F][width] each, concatenated in `acts`
+// (widths 64, 32, 16, 16, 16 + K, 16, 16, 32, 64, OT; st_ae_acts_floats() floats).  v: [B][T][F] (mag or phs); ae: that autoencoder's
+// packed parameters (st_param_offsets order); sf != 0: the skip-filter output (magnitude net), else the bare ELU output (phase net).
+extern "C" size_t st_ae_acts_floats(const st_dims* d) { return (size_t)d->B * d->F * (64 + 32 + 16 + 16 + 16 + d->K + 16 + 16 + 32 + 64 + d->OT); }
+extern "C" int st_ae_acts(const st_dims* d, const float* v, const float* knobs, const float* ae, int sf, float* acts, void* stream)
+{
+    Layout L; ST_TRY(make_layout(d, &L));
+    ST_REQ(v && knobs && ae && acts, "st_ae_acts: null pointer");
+    stm::AeActsArgs a;
+    a.v = v; a.knobs = knobs; a.ae = ae; a.B = d->B; a.T = d->T; a.OT = d->OT; a.F = d->F; a.K = d->K; a.sf = sf;
+    for (int l = 0; l < 9; ++l) { a.w_off[l] = L.go.w[l]; a.b_off[l] = L.go.b[l]; }
+    const int widths[10] = {64, 32, 16, 16, 16 + d->K, 16, 16, 32, 64, d->OT};
+    size_t off = 0;
+    for (int i = 0; i < 10; ++i) { a.out[i] = acts + off; off += (size_t)d->B * d->F * widths[i]; }
+    hipLaunchKernelGGL(stm::ae_acts_kernel, dim3((d->B * d->F + 63) / 64), dim3(64), 0, st_stream(stream), a);
+    ST_LAUNCHED("ae_acts"); return ST_OK;
+}
 extern "C" size_t st_workspace_bytes(const st_dims* d)
 {
     if (check_dims(d) != ST_OK) return 0;

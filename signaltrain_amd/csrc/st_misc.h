@@ -669,6 +669,42 @@ compressor_4c_kernel(const float* __restrict__ x, const float* __restrict__ knob
 }
 
 
+// ------------------------------------------------------------------------------ layer activations of one autoencoder (diagnostics)
+// nn_proc.py:77-126 with return_acts=True (what utils/viz.py:135 plots): the ten tensors the reference appends -- ELU outputs of the four
+// encoder layers, the [z ; knobs] concatenation, ELU outputs of fnn_addknobs / fnn_dec4 / fnn_dec3 / fnn_dec2 and the final output (ELU of
+// fnn_dec, times the last OT input frames in 'sf' mode) -- each in the reference's [B][F][width] layout.  One thread per (window, bin) row
+// walks the nine layers with plain fp32 FMAs: a diagnostic kernel (the training kernels keep these activations in registers), also an
+// MFMA-free cross-check of ae_fwd_kernel.  ae: the packed parameter block of ONE autoencoder (weights row-major [out][in], then bias).
+struct AeActsArgs { const float* v; const float* knobs; const float* ae; int w_off[9], b_off[9]; float* out[10]; int B, T, OT, F, K, sf; };
+__global__ void __launch_bounds__(64)
+ae_acts_kernel(const AeActsArgs a)
+{
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= a.B * a.F) return;
+    const int b = row / a.F, f = row - b * a.F;
+    float h[64 + 16], z[64 + 16];                      // widths <= 64 (+ K <= 16 knobs)
+    const int outw[9] = {64, 32, 16, 16, 16, 16, 32, 64, a.OT};
+    int inw = a.T;
+    // layer 1 reads the T input frames of this row straight from [B][T][F]
+    for (int l = 0; l < 9; ++l) {
+        const float* W = a.ae + a.w_off[l]; const float* bias = a.ae + a.b_off[l];
+        if (l == 4) {                                  // fnn_addknobs: input = [z ; knobs] (nn_proc.py:92-93), itself an activation entry
+            for (int k = 0; k < a.K; ++k) h[16 + k] = a.knobs[b * a.K + k];
+            for (int j = 0; j < 16 + a.K; ++j) a.out[4][(size_t)row * (16 + a.K) + j] = h[j];
+            inw = 16 + a.K;
+        }
+        for (int o = 0; o < outw[l]; ++o) {
+            float s = bias[o];
+            for (int i = 0; i < inw; ++i) s = __builtin_fmaf(W[o * inw + i], l == 0 ? a.v[((size_t)b * a.T + i) * a.F + f] : h[i], s);
+            z[o] = s > 0.f ? s : expm1f(s);            // ELU, alpha = 1
+        }
+        if (l == 8 && a.sf) for (int o = 0; o < a.OT; ++o) z[o] *= a.v[((size_t)b * a.T + (a.T - a.OT + o)) * a.F + f];      // skip-filter (nn_proc.py:115)
+        const int slot = l < 4 ? l : l + 1;
+        for (int o = 0; o < outw[l]; ++o) { h[o] = z[o]; a.out[slot][(size_t)row * outw[l] + o] = z[o]; }
+        inw = outw[l];
+    }
+}
+
 // ------------------------------------------------------------------------------ generic learned-basis front end (cls_fe_dct_bases.py)
 // ConvTranspose1d(C -> 1, k = KW, stride = hop) after its GEMM: overlap-add of the frames [B*T][KW] and crop
 // (cls_fe_dct_bases.py:174-179); also the input gradient of Conv1d(1 -> C) (crop = its padding).

@@ -58,22 +58,27 @@ class AsymAutoEncoder(nn.Module):
             torch.nn.init.xavier_normal_(x.weight)
             x.bias.data.zero_()
 
-    def acts_reference(self, x_input, knobs, skip_connections):
-        """Diagnostic only (return_acts for utils/viz.py): the layer activations via torch ops."""
-        F_ = torch.nn.functional
-        acts = []
-        xi = x_input.transpose(2, 1)
-        z = xi
-        for l in self.layer_list[:4]:
-            z = F_.elu(F_.linear(z, l.weight, l.bias)); acts.append(z)
-        catted = torch.cat((z, knobs.unsqueeze(1).repeat(1, z.size(1), 1)), 2); acts.append(catted)
-        z = catted
-        for l in self.layer_list[4:8]:
-            z = F_.elu(F_.linear(z, l.weight, l.bias)); acts.append(z)
-        out = F_.elu(F_.linear(z, self.fnn_dec.weight, self.fnn_dec.bias))
-        if skip_connections == 'sf':
-            out = out * xi[:, :, -self._OT:]
-        acts.append(out)
+    def acts_device(self, x_input, knobs, skip_connections):
+        """The ten return_acts tensors of nn_proc.py:77-126 ([B, F, width] each) from the library's diagnostic kernel (st_ae_acts): plain
+        fp32 FMAs per (window, bin) row -- the training kernels keep these activations in registers."""
+        lib = _lib.load()
+        x = x_input.contiguous().float(); kn = knobs.contiguous().float()
+        B, T, F = x.shape
+        d = _lib.st_dims(); d.B, d.N, d.F, d.T, d.OT, d.K, d.H = B, 2 * (F - 1), F, T, self._OT, self._K, 384
+        d.y = (d.OT - 1) * d.H - d.N; d.L = max(4 * d.y, 4)
+        offs, total = _lib.param_offsets(d)
+        packed = torch.zeros(offs[22] - offs[4], device=x.device)
+        k = 0
+        for l in self.layer_list:
+            for t in (l.weight, l.bias):
+                o = offs[4 + k] - offs[4]; packed[o:o + t.numel()] = t.detach().reshape(-1); k += 1
+        flat = torch.empty(int(lib.st_ae_acts_floats(C.byref(d))), device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.st_ae_acts(C.byref(d), _lib.ptr(x), _lib.ptr(kn), _lib.ptr(packed), 1 if skip_connections == 'sf' else 0, _lib.ptr(flat),
+                                      C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "st_ae_acts")
+        acts, o = [], 0
+        for w in (64, 32, 16, 16, 16 + self._K, 16, 16, 32, 64, self._OT):
+            acts.append(flat[o:o + B * F * w].view(B, F, w)); o += B * F * w
         return acts
 
     def forward(self, x_input, knobs, skip_connections='res', return_acts=False):
@@ -102,7 +107,7 @@ class AsymAutoEncoder(nn.Module):
             _lib.check(lib.st_ae_fwd(C.byref(d), _lib.ptr(x), _lib.ptr(x), _lib.ptr(kn), _lib.ptr(packed), _lib.ptr(packed),
                                      _lib.ptr(mh), _lib.ptr(ph), _lib.ptr(AA), None, _lib.ptr(ws), st), "st_ae_fwd")
         out = mh if skip_connections == 'sf' else ph - x[:, T - self._OT:, :]
-        return out, (self.acts_reference(x_input, knobs, skip_connections) if return_acts else [])
+        return out, (self.acts_device(x_input, knobs, skip_connections) if return_acts else [])
 
 
 class _STModelFn(torch.autograd.Function):
@@ -212,17 +217,25 @@ class AsymMPAEC(nn.Module):
         return y_hat, mag, mag_hat, self._acts(x, kn, y_hat, mag, mag_hat)
 
     def _acts(self, x, kn, y_hat, mag, mag_hat):
-        """The 30-entry activation list of nn_proc.py:311-338 (diagnostics for utils/viz.py)."""
+        """The 30-entry activation list of nn_proc.py:311-338 (diagnostics for utils/viz.py), from the HIP path's own buffers: re, im, phs,
+        phs_hat, an_real, an_imag are views of the forward state the fused forward left in the engine's workspace (st_workspace_offsets),
+        the 2 x 10 layer activations come from the library's diagnostic kernel (st_ae_acts)."""
+        eng = self._engine
         with torch.no_grad():
-            re, im = self.dft_analysis(x / 2)
-            phs = torch.atan2(im, re + 1e-7)
+            d = eng._dims(x.shape[0])
+            offs = (C.c_int64 * 8)()
+            _lib.check(eng.lib.st_workspace_offsets(C.byref(d), offs), "st_workspace_offsets")
+            wsf = eng.ws.view(torch.float32)
+            KP = int(eng.lib.st_kp(d.F))
+            view = lambda i, *shape: wsf[offs[i]:offs[i] + int(np.prod(shape))].view(*shape).clone()
+            re, im, phs = view(0, d.B, d.T, d.F), view(1, d.B, d.T, d.F), view(3, d.B, d.T, d.F)
+            phs_hat = view(5, d.B, d.OT, d.F)
+            AA = wsf[offs[6]:offs[6] + d.B * d.OT * KP].view(d.B, d.OT, KP)
+            an_real, an_imag = AA[:, :, :d.F].clone(), AA[:, :, KP // 2:KP // 2 + d.F].clone()
             acts = [re, im, mag, phs]
-            acts += self.aenc.acts_reference(mag, kn, 'sf')
-            p_acts = self.phs_aenc.acts_reference(phs, kn, '')
-            acts += p_acts
-            phs_hat = p_acts[-1].transpose(2, 1) + phs[:, -self.output_tf:, :]
-            an_real, an_imag = mag_hat * torch.cos(phs_hat), mag_hat * torch.sin(phs_hat)
-            x_fwdsyn = y_hat / 2 - x[:, -y_hat.shape[1]:] / 2
+            acts += self.aenc.acts_device(mag, kn, 'sf')
+            acts += self.phs_aenc.acts_device(phs, kn, '')
+            x_fwdsyn = y_hat / 2 - x[:, -y_hat.shape[1]:] / 2         # nn_proc.py:332,340 inverted: y_hat = 2 (x_fwdsyn + x_tail / 2)
             acts += [mag_hat, phs_hat, an_real, an_imag, x_fwdsyn, y_hat / 2]
         return acts
 
