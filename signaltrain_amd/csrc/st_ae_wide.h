@@ -228,23 +228,47 @@ struct GradTab { int so[10]; int out[9]; int in[9]; int gw[9]; int gb[9]; };
 __global__ void __launch_bounds__(256)
 wide_grad_finish_kernel(const float* __restrict__ slabs, int nslab, size_t SL, const GradTab tab, float* __restrict__ g)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= tab.so[9]) return;
+    // block = 64 slab elements x 4 slab lanes, 8 loads in flight per thread (one thread walking 256 slabs four at a time was 30 us of pure
+    // latency per net at the 65536-sample window); the four lanes are added in a fixed order
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + col;
     int l = 0;
 #pragma unroll
     for (int q = 1; q < 9; ++q) l += idx >= tab.so[q];
     const int e = idx - tab.so[l], n1 = tab.in[l] + 1;
-    if (e >= tab.out[l] * n1) return;                      // alignment pad between layers
-    const int o = e / n1, i = e - o * n1;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // 4 independent chains: slabs are L2-resident, latency-bound otherwise
-    int z = 0;
-    for (; z + 4 <= nslab; z += 4) {
-        s0 += slabs[(size_t)z * SL + idx]; s1 += slabs[(size_t)(z + 1) * SL + idx];
-        s2 += slabs[(size_t)(z + 2) * SL + idx]; s3 += slabs[(size_t)(z + 3) * SL + idx];
+    const bool live = idx < tab.so[9] && e < tab.out[l] * n1;      // not an alignment pad between layers, not a layer the fused inner kernel owns (out = 0)
+    float s = 0.f;
+    if (live) {
+        const float* base = slabs + idx;
+        for (int z0 = pl; z0 < nslab; z0 += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int z = z0 + 4 * u; v[u] = z < nslab ? base[(size_t)z * SL] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
     }
-    for (; z < nslab; ++z) s0 += slabs[(size_t)z * SL + idx];
-    const float s = (s0 + s1) + (s2 + s3);
+    red[pl][col] = s;
+    __syncthreads();
+    if (pl != 0 || !live) return;
+    s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    const int o = e / n1, i = e - o * n1;
     if (i < tab.in[l]) g[tab.gw[l] + o * tab.in[l] + i] = s; else g[tab.gb[l] + o] = s;
+}
+
+// The zero-padded copies of W_1 ([64][Tp]) and W_5 ([16][32]) of both autoencoders in ONE launch (was four pad_rows launches, 5 us each)
+struct PadJobs { const float* src[4]; float* dst[4]; int rows[4], cols[4], pitch[4], blk0[5]; };
+__global__ void __launch_bounds__(256)
+pad_rows4_kernel(const PadJobs j)
+{
+    int q = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) q += (int)blockIdx.x >= j.blk0[k];
+    const int i = ((int)blockIdx.x - j.blk0[q]) * 256 + threadIdx.x;
+    if (i >= j.rows[q] * j.pitch[q]) return;
+    const int r = i / j.pitch[q], c = i - r * j.pitch[q];
+    j.dst[q][i] = c < j.cols[q] ? j.src[q][r * j.cols[q] + c] : 0.f;
 }
 
 }  // namespace stw

@@ -615,10 +615,17 @@ static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, cons
     ST_REQ(w.R * (size_t)(T > 64 ? T : 64) < ((size_t)1 << 30), "wide autoencoder path: batch too large (B=%d)", d->B);
     const stg::RowMap id = stg::all_frames(1);
     int out[9], in[9]; ae_shapes(d, out, in);
-    for (int a = 0; a < 2; ++a) {
-        const float* ae = a ? ae_p : ae_m;
-        hipLaunchKernelGGL(stw::pad_rows_kernel, dim3((64 * Tp + 255) / 256), dim3(256), 0, s, ae + L.go.w[0], 64, T, w.W1p[a], Tp);
-        hipLaunchKernelGGL(stw::pad_rows_kernel, dim3(2), dim3(256), 0, s, ae + L.go.w[4], 16, 16 + d->K, w.W5p[a], 32);
+    {
+        stw::PadJobs pj; int blk = 0;
+        for (int a = 0; a < 2; ++a) {
+            const float* ae = a ? ae_p : ae_m;
+            pj.src[2 * a] = ae + L.go.w[0]; pj.dst[2 * a] = w.W1p[a]; pj.rows[2 * a] = 64; pj.cols[2 * a] = T; pj.pitch[2 * a] = Tp;
+            pj.blk0[2 * a] = blk; blk += (64 * Tp + 255) / 256;
+            pj.src[2 * a + 1] = ae + L.go.w[4]; pj.dst[2 * a + 1] = w.W5p[a]; pj.rows[2 * a + 1] = 16; pj.cols[2 * a + 1] = 16 + d->K; pj.pitch[2 * a + 1] = 32;
+            pj.blk0[2 * a + 1] = blk; blk += 2;
+        }
+        pj.blk0[4] = blk;
+        hipLaunchKernelGGL(stw::pad_rows4_kernel, dim3(blk), dim3(256), 0, s, pj);
     }
     hipLaunchKernelGGL(stw::wide_in_kernel, dim3(T + d->K, d->B), dim3(256), 0, s, mag, phs, knobs, w.V[0], w.V[1], w.H[0][3], w.H[1][3],
                        d->B, T, F, FP, d->K);
@@ -737,13 +744,13 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
         for (int l = 1; l < 8; ++l) tab.out[l] = 0;                 // the finish kernel only scatters layers 1 and 9
         for (int a = 0; a < 2; ++a) {
             wide_wgrad(d, w, a, 0, out, in, s, wide_ht); dgrad(a, 0, false);
-            hipLaunchKernelGGL(stw::wide_grad_finish_kernel, dim3((w.so[9] + 255) / 256), dim3(256), 0, s,
+            hipLaunchKernelGGL(stw::wide_grad_finish_kernel, dim3((w.so[9] + 63) / 64), dim3(256), 0, s,
                                w.slabs + (size_t)a * w.nsplit * w.SL, w.nsplit, w.SL, tab, a ? g_p : g_m);
         }
     } else {
         for (int a = 0; a < 2; ++a) {
             for (int l = 8; l >= 0; --l) { wide_wgrad(d, w, a, l, out, in, s, wide_ht); dgrad(a, l, false); }
-            hipLaunchKernelGGL(stw::wide_grad_finish_kernel, dim3((w.so[9] + 255) / 256), dim3(256), 0, s,
+            hipLaunchKernelGGL(stw::wide_grad_finish_kernel, dim3((w.so[9] + 63) / 64), dim3(256), 0, s,
                                w.slabs + (size_t)a * w.nsplit * w.SL, w.nsplit, w.SL, tab, a ? g_p : g_m);
         }
     }
