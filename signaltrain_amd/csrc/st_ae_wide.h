@@ -14,6 +14,8 @@
 #pragma once
 #include "st_common.h"
 #include "st_gemm.h"
+#include <type_traits>
+#include "st_ae.h"
 
 namespace stw {
 using stg::NJ;
@@ -116,6 +118,149 @@ struct DvStore {           // gradient w.r.t. the AE input rows, written in the 
         }
     }
 };
+
+// ------------------------------------------------------------------------------------------------ layer-1 data gradient + polar backward
+// Round 3.  At the 65536-sample window the gradient w.r.t. the autoencoder inputs was two generic GEMMs with a scatter epilogue (DvStore:
+// 36 us each for 0.75 GFLOP) followed by the polar backward (29 us): dmag / dphs went out to HBM (46 MB) only to be read back.  One kernel now
+// walks 16-row groups like the fused autoencoder kernels: d a1 of both nets in D layout (16 + 16 dwords per lane from the feature-major
+// buffers), W1^T fragments from an LDS dgrad image, one 16-frame output tile at a time
+//     dv[t][row] = sum_o W1[o][t] * d a1[o][row]  (+ the skip / residual tail for the last OT frames)
+// and -- fused step -- straight through nn_proc.py:309-310's backward into d G in the weight-gradient GEMM's operand type.
+// re == NULL (per-op st_ae_bwd): dmag / dphs only.  BF: 16-bit operands (both rounded, as gemm_half_kernel did).
+struct DvPolarArgs {
+    const float *DA1m, *DA1p, *TLm, *TLp, *W1m, *W1p;       // d a1 [64][R], tails [OT][R], layer-1 weights [64][T] of the two nets
+    const float *re, *im, *g_mag;                           // forward state [B][T][F] (NULL: no polar stage); optional upstream d mag
+    float *dmag, *dphs, *dG; unsigned short* dG16;          // any of them may be NULL
+    int ht; float sat; int B, T, OT, F, FP, KP;
+};
+template <int BF>
+__global__ void __launch_bounds__(512)
+wide_dv_polar_kernel(const DvPolarArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float dvp_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int T = a.T, TP = (T + 15) / 16 * 16, NIT = TP / 16;
+    constexpr int RW = BF ? 32 : 64;                        // floats per image row block: 16-bit images take half the room
+    float* const img[2] = {dvp_lds, dvp_lds + RW * TP};      // G[(o >> 2)][i][o & 3] per net
+    for (int e = tid; e < 2 * RW * TP; e += 512) dvp_lds[e] = 0.f;
+    __syncthreads();
+    // thread i < T owns input column i of W1 [64][T] (coalesced across threads, NO integer division: e / T for 22 k elements was 6 k of this
+    // kernel's 9 k vector instructions per wave), sixteen loads in flight
+    if (tid < T) {
+        for (int n = 0; n < 2; ++n) {
+            const float* W = n ? a.W1p : a.W1m;
+#pragma unroll
+            for (int o0 = 0; o0 < 64; o0 += 16) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = W[(o0 + u) * T + tid];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int o = o0 + u;
+                    const int idx = (((o >> 2) * TP + tid) << 2) + (o & 3);
+                    if constexpr (BF) reinterpret_cast<unsigned short*>(img[n])[idx] = sta::st_half_bits<BF>(v[u]);
+                    else img[n][idx] = v[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int gpw = a.FP / 16, ngroups = a.B * gpw;
+    const unsigned R = (unsigned)a.B * a.FP;
+    // The NWV waves of a workgroup take ADJACENT 16-bin groups and walk the frame tiles together: a group touches only 64 bytes of every
+    // [B][T][F] row, eight neighbours touch 512 contiguous bytes at about the same time (DRAM page / L2 line locality: with the waves on
+    // different frames of ONE group the kernel ran at 1.3 TB/s).  One tile of look-ahead for the inputs of the next frame tile.
+    constexpr int NWV = 8;
+    const int per = (ngroups + (int)gridDim.x * NWV - 1) / ((int)gridDim.x * NWV) * NWV;       // groups per workgroup, a multiple of NWV
+    for (int g0 = (int)blockIdx.x * per; g0 < ((int)blockIdx.x + 1) * per && g0 < ngroups; g0 += NWV) {
+        const int grp = g0 + wave < ngroups ? g0 + wave : ngroups - 1;
+        const bool gv = g0 + wave < ngroups;
+        const int b = grp / gpw, f = (grp - b * gpw) * 16 + c;
+        const bool fv = gv && f < a.F;
+        const unsigned col = (unsigned)b * a.FP + (unsigned)f;
+        f32x4 da[2][4];
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                da[0][ot][r] = sta::ldg32(a.DA1m, (unsigned)(16 * ot + 4 * g + r) * R + col);
+                da[1][ot][r] = sta::ldg32(a.DA1p, (unsigned)(16 * ot + 4 * g + r) * R + col);
+            }
+        float xr[2][4], yr[2][4], tm[2][4], tp[2][4], gm[2][4];
+        auto load_tile = [&](const int it, const int s_) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = 16 * it + 4 * g + r;
+                const bool ok = fv && t < T;
+                const unsigned o = ((unsigned)b * T + (unsigned)(ok ? t : 0)) * (unsigned)a.F + (unsigned)(fv ? f : 0);
+                const bool tl = ok && t >= T - a.OT;
+                const unsigned q = (unsigned)(tl ? t - (T - a.OT) : 0) * R + col;
+                xr[s_][r] = a.re ? sta::ldg32(a.re, o) : 0.f; yr[s_][r] = a.re ? sta::ldg32(a.im, o) : 0.f;
+                gm[s_][r] = a.g_mag ? sta::ldg32(a.g_mag, o) : 0.f;
+                const float u = sta::ldg32(a.TLm, q), v = sta::ldg32(a.TLp, q);
+                tm[s_][r] = tl ? u : 0.f; tp[s_][r] = tl ? v : 0.f;
+            }
+        };
+        load_tile(0, 0);
+        sta::s16x4 pd[2][4];
+        if constexpr (BF) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int ot = 0; ot < 4; ++ot) pd[n][ot] = sta::pack_h4<BF>(da[n][ot]);
+        }
+        // two frame tiles per trip so that the look-ahead buffers are indexed statically (a run-time buffer index put them in scratch)
+        auto tile = [&](const int it, auto sb) {
+            constexpr int SB = decltype(sb)::value;
+            f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const f32x4 w = sta::frag_read<BF>(img[n], ((4 * ot + g) * TP + 16 * it + c) << 2);
+                    if constexpr (BF) acc[n] = sta::mfma16h<BF>(sta::frag_bits(w), pd[n][ot], acc[n]);
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[n] = ST_MFMA16(w[r], da[n][ot][r], acc[n]);
+                    }
+                }
+            // tile `it` of dv in D layout: lane (g, c), register r <-> frame t = 16 it + 4 g + r, row c
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = 16 * it + 4 * g + r;
+                if (t >= T) continue;
+                const unsigned o = ((unsigned)b * T + (unsigned)t) * (unsigned)a.F + (unsigned)(fv ? f : 0);
+                const float dm = fv ? acc[0][r] + tm[SB][r] : 0.f, dp = fv ? acc[1][r] + tp[SB][r] : 0.f;
+                if (a.dmag && fv) { sta::stg32(a.dmag, o, dm); sta::stg32(a.dphs, o, dp); }
+                if (a.re) {
+                    float gre = 0.f, gim = 0.f;
+                    if (fv) {                      // stm::polar_bwd_block's formulas (v_rcp_f32 / v_sqrt_f32: 1 ulp, against a 1e-4 tolerance)
+                        const float x = xr[SB][r], y = yr[SB][r];
+                        const float dmt = dm + gm[SB][r];
+                        const float m2 = x * x + y * y;
+                        const float inv = m2 > 0.f ? __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(m2)) : 0.f;
+                        const float rp = x + 1e-7f;
+                        const float rden = __builtin_amdgcn_rcpf(rp * rp + y * y);
+                        gre = dmt * x * inv - dp * y * rden;
+                        gim = dmt * y * inv + dp * rp * rden;
+                        if (a.sat > 0.f) { gre = __builtin_amdgcn_fmed3f(gre, -a.sat, a.sat); gim = __builtin_amdgcn_fmed3f(gim, -a.sat, a.sat); }
+                    }
+                    const size_t go = ((size_t)b * T + t) * a.KP + f;          // f < FP = KP / 2: pad columns get zeros
+                    if (gv && a.dG16) { a.dG16[go] = st_to_h16(gre, a.ht); a.dG16[go + a.FP] = st_to_h16(gim, a.ht); }
+                    if (gv && a.dG) { a.dG[go] = gre; a.dG[go + a.FP] = gim; }
+                }
+            }
+        };
+        for (int it = 0; it < NIT; it += 2) {
+            load_tile(it + 1 < NIT ? it + 1 : it, 1);
+            tile(it, std::integral_constant<int, 0>{});
+            if (it + 1 < NIT) {                             // wave-uniform
+                load_tile(it + 2 < NIT ? it + 2 : it + 1, 0);
+                tile(it + 1, std::integral_constant<int, 1>{});
+            }
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------------ small kernels
 __global__ void pad_rows_kernel(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst, int pitch)

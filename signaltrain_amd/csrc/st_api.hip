@@ -185,6 +185,7 @@ static int g_frs_nt = 1;     // synthesis frames GEMM against the transposed fol
 static int g_xt = 0;       // 1: M/N-contiguous operands staged k-quad-major (st_gemm.h XT; st_set_tuning(7001), diagnostics).  MEASURED SLOWER at B=256 although
                            // conflict-free with a third fewer LDS cycles: analysis wgrad 173 vs 145 us, synthesis frames 63 vs 60 us (16 more prefetch
                            // registers -> 4 instead of 4.5 waves per SIMD, and 16 v_mov per micro-tile): the k-major staging stays the default
+static int g_wide_dvp = 1;   // wide geometries: layer-1 data gradient (+ polar backward) as one fused kernel; 0 = two GEMMs + polar_bwd (st_set_tuning(9900), diagnostics)
 static int g_nt_mi = 0;     // fp32 NT x NT GEMMs with 64 x 96 wave tiles (MI = 2): 0 off; bit 0 analysis forward <4,16,2>, bit 1 <2,32,2>, bit 2 frames / dgrad <2,16,2>  (st_set_tuning(9800 + n), experiments)
 static int g_an_bk = 32;   // k-tile depth of the analysis forward GEMM (see ST_GEMM_AN)
 static int g_bk = 16;   // k-tile depth of the GEMM family (16: 36 KB LDS/WG -> 4 WGs/CU; 32: 64 KB -> 2 WGs/CU)
@@ -192,6 +193,7 @@ static int g_wg_mode_set(int v);
 static int g_wsplit_max = 16, g_wsplit_div = 200, g_an_waves = 4, g_syn_split = 3, g_frs_split = 3, g_wide_fused = 1, g_wsplit_half = 0;      // frames: 3, 4 measured equal, 6 slower (only 66 k-tiles to split)
 extern "C" int st_set_tuning(int bk)
 {
+    if (bk >= 9900) { g_wide_dvp = bk - 9900; return ST_OK; }
     if (bk >= 9800) { g_nt_mi = bk - 9800; return ST_OK; }
     if (bk >= 9700) { g_g16_split = bk - 9700; return ST_OK; }
     if (bk >= 9600) { const int v = bk - 9600; if (v == 32 || v == 64) g_g16_bk = v; else g_g16 = v; return ST_OK; }
@@ -680,10 +682,12 @@ static void wide_wgrad(const st_dims* d, WideWS& w, int a, int l, const int* out
     ST_WGEMM(al, bl, ep, out[l], in[l] + 1, R, w.nsplit, s);
 }
 
+// Where the gradient w.r.t. the autoencoder inputs goes on the fused path: straight through the polar backward into d G (wide_dv_polar_kernel)
+struct PolarSink { const float* re; const float* im; const float* g_mag; float* dG; unsigned short* dG16; };
 static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, const float* phs, const float* knobs,
                        const float* ae_m, const float* ae_p, const float* mag_hat, const float* phs_hat, const float* dAA,
                        const float* g_mag_hat, float reg_coef, float* dmag, float* dphs, WideWS& w, float* g_m, float* g_p,
-                       bool have_fwd, void* stream)
+                       bool have_fwd, void* stream, const PolarSink* sink = nullptr, bool* sink_used = nullptr)
 {
     hipStream_t s = st_stream(stream);
     const int FP = L.KP / 2, F = d->F, T = d->T, OT = d->OT, R = (int)w.R, Tp = w.Tp;
@@ -743,9 +747,27 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
         }
         for (int l = 1; l < 8; ++l) tab.out[l] = 0;                 // the finish kernel only scatters layers 1 and 9
         for (int a = 0; a < 2; ++a) {
-            wide_wgrad(d, w, a, 0, out, in, s, wide_ht); dgrad(a, 0, false);
+            wide_wgrad(d, w, a, 0, out, in, s, wide_ht);
+            if (!g_wide_dvp) dgrad(a, 0, false);
             hipLaunchKernelGGL(stw::wide_grad_finish_kernel, dim3((w.so[9] + 63) / 64), dim3(256), 0, s,
                                w.slabs + (size_t)a * w.nsplit * w.SL, w.nsplit, w.SL, tab, a ? g_p : g_m);
+        }
+        if (g_wide_dvp) {
+            stw::DvPolarArgs q;
+            q.DA1m = w.DA[0][0]; q.DA1p = w.DA[1][0]; q.TLm = w.TL[0]; q.TLp = w.TL[1]; q.W1m = ae_m + L.go.w[0]; q.W1p = ae_p + L.go.w[0];
+            q.re = sink ? sink->re : nullptr; q.im = sink ? sink->im : nullptr; q.g_mag = sink ? sink->g_mag : nullptr;
+            q.dG = sink ? sink->dG : nullptr; q.dG16 = sink ? sink->dG16 : nullptr;
+            q.dmag = sink ? nullptr : dmag; q.dphs = sink ? nullptr : dphs;          // fused step: d mag / d phs never leave the kernel
+            q.ht = gemm_ht(d->prec) <= 2 ? gemm_ht(d->prec) : 0; q.sat = gemm_ht(d->prec) == 2 ? 65504.0f : 0.0f;
+            q.B = d->B; q.T = T; q.OT = OT; q.F = F; q.FP = FP; q.KP = L.KP;
+            const int TP16 = (T + 15) / 16 * 16, groups = d->B * (FP / 16);
+            ST_REQ(TP16 <= 192, "wide autoencoder path: T = %d frames exceeds the layer-1 data-gradient kernel's 192", T);
+            const size_t lds = (size_t)2 * (wide_ht ? 32 : 64) * TP16 * sizeof(float);          // 16-bit images take half the room
+            int grid = (groups + 7) / 8; if (grid > num_cus()) grid = num_cus();      // 8 adjacent groups per workgroup pass, one workgroup per CU
+#define ST_DVP(HT_) do { ST_DYN_LDS((stw::wide_dv_polar_kernel<HT_>)); hipLaunchKernelGGL((stw::wide_dv_polar_kernel<HT_>), dim3(grid), dim3(512), lds, s, q); } while (0)
+            switch (wide_ht) { case 1: ST_DVP(1); break; case 2: ST_DVP(2); break; default: ST_DVP(0); }
+#undef ST_DVP
+            if (sink_used) *sink_used = sink != nullptr;
         }
     } else {
         for (int a = 0; a < 2; ++a) {
@@ -762,7 +784,8 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
 static int ae_bwd_impl(const st_dims* d, const float* mag, const float* phs, const float* knobs,
                        const float* ae_m, const float* ae_p, const float* mag_hat, const float* phs_hat,
                        const float* dAA, const float* g_mag_hat, float reg_coef, float* dmag, float* dphs, float* ws,
-                       float* g_m, float* g_p, bool have_fwd, void* stream, bool* defer_reduce = nullptr)
+                       float* g_m, float* g_p, bool have_fwd, void* stream, bool* defer_reduce = nullptr,
+                       const PolarSink* sink = nullptr, bool* sink_used = nullptr)
 {
     // defer_reduce: in -> the caller will sum the workgroup partials itself (post_ae_kernel, together with the polar backward);
     // out -> false if this geometry's path already reduced them (wide geometries)
@@ -771,7 +794,7 @@ static int ae_bwd_impl(const st_dims* d, const float* mag, const float* phs, con
     if (ae_is_wide(d)) {
         if (defer_reduce) *defer_reduce = false;
         WideWS w; wide_carve(d, ws, &w);
-        return ae_wide_bwd(d, L, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, dmag, dphs, w, g_m, g_p, have_fwd, stream);
+        return ae_wide_bwd(d, L, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, dmag, dphs, w, g_m, g_p, have_fwd, stream, sink, sink_used);
     }
     const size_t lds = (size_t)sta::ae_bwd_lds_floats(AE_BWD_NW) * sizeof(float);
     static_assert((size_t)sta::ae_bwd_lds_floats(AE_BWD_NW) * sizeof(float) <= 160 * 1024, "ae_bwd LDS budget");
@@ -1240,9 +1263,11 @@ static int backward_ae(const st_dims* d, const Layout& L, const float* params, f
                        const stm::NyqJob* syn_nyq = nullptr)
 {   // syn_slabs > 0: the synthesis weight-gradient slabs in w.wg are still to be summed (done by post_ae_kernel)
     const float* ae_m = params + L.offs[4]; const float* ae_p = params + L.offs[22];
-    bool deferred = true;
+    bool deferred = true, sink_used = false;
+    const PolarSink sink{w.re, w.im, g_mag, w.g16 ? nullptr : w.dG, w.g16 ? w.dG16 : nullptr};
     ST_TRY(ae_bwd_impl(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.dAA, g_mag_hat, reg_coef, w.dmag, w.dphs,
-                       w.aews, grads + L.offs[4], grads + L.offs[22], true, stream, &deferred));      // the forward left its AE state in w.aews
+                       w.aews, grads + L.offs[4], grads + L.offs[22], true, stream, &deferred, &sink, &sink_used));      // the forward left its AE state in w.aews
+    if (sink_used) return ST_OK;                       // wide geometries: the polar backward ran inside wide_dv_polar_kernel
     if (!deferred) {
         ST_REQ(syn_slabs == 0, "internal: deferred synthesis slabs on a path without post_ae_kernel");
         if (w.g16) {                       // wide geometries: the polar backward is its own launch; d G goes out in the GEMM operand type
@@ -1755,6 +1780,7 @@ static int attr_prepare(const st_dims* d)
     if (ae_is_wide(d)) {
         ST_PREP3((sta::ae_inner_fwd_kernel<AE_FWD_NW, 0>), (sta::ae_inner_fwd_kernel<AE_FWD_NW, 1>), (sta::ae_inner_fwd_kernel<AE_FWD_NW, 2>));
         ST_PREP3((sta::ae_bwd_kernel<AE_BWD_NW, false, true, 0, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, true, 1, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, true, 2, 0>));
+        ST_PREP3((stw::wide_dv_polar_kernel<0>), (stw::wide_dv_polar_kernel<1>), (stw::wide_dv_polar_kernel<2>));
     } else {
         ST_PREP3((sta::ae_fwd_kernel<AE_FWD_NW, 0>), (sta::ae_fwd_kernel<AE_FWD_NW, 1>), (sta::ae_fwd_kernel<AE_FWD_NW, 2>));
         if (ht == 0) ST_DYN_LDS((sta::ae_fwd_kernel<11, 0>));
