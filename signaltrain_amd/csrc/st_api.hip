@@ -1134,8 +1134,8 @@ static int analysis_fwd16(const st_dims* d, WS& w, float* re, float* im, float* 
     const stg::Rows16 ra = stg::rows16(w.xp16, (unsigned)(d->L + 2 * d->N), (unsigned)d->H, map, R);
     const stg::Rows16 rb = stg::rows16_plain(w.W16, (unsigned)d->N, 2 * d->F);
     stg::PolarStore ep{re, im, mag, phs, R, d->F, map};
-    if (gemm_ht(d->prec) == 2) ST_TRY((stg::launch16_nt<2>(ra, rb, ep, R, 2 * d->F, d->N, 1, st_stream(stream))));
-    else ST_TRY((stg::launch16_nt<1>(ra, rb, ep, R, 2 * d->F, d->N, 1, st_stream(stream))));
+    if (gemm_ht(d->prec) == 2) ST_TRY((stg::launch16_nt<2>(ra, rb, ep, R, 2 * d->F, d->N, 1, st_stream(stream), g_g16_bk != 32)));
+    else ST_TRY((stg::launch16_nt<1>(ra, rb, ep, R, 2 * d->F, d->N, 1, st_stream(stream), g_g16_bk != 32)));
     ST_LAUNCHED("analysis_fwd"); return ST_OK;
 }
 static int synthesis_frames16(const st_dims* d, WS& w, void* stream)

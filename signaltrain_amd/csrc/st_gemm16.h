@@ -14,6 +14,9 @@
 //     one ds_write_b128, and the MFMA fragments come out of ds_read_b64_tr_b16 -- the LDS transpose read of gfx950: a 16-lane group
 //     reads a [4 k][16 rows] block, lane i gets the four k of row i -- two reads per operand block per k-step, no register transposes
 //     (gemm_half_kernel transposed 4 x 4 fp32 micro-tiles with VALU moves);
+//   * MEASURED and dropped (round 3): a second register set so that the loads of tile t + 2 are in flight during tile t (analysis forward 32.1 ->
+//     35.6 us): these kernels are not waiting for their loads -- the analysis forward WRITES 48 MB of fp32 re / im / mag / phs (12 us at HBM speed)
+//     through 4-byte scattered stores, the synthesis GEMMs write 22 MB of split-K slabs each;
 //   * row offsets of NT operands are per-thread constants, the k offset rides in the scalar base; TN operands split k -> (window, frame)
 //     once per load pass with 24-bit multiplies.
 #pragma once
@@ -242,10 +245,10 @@ gemm16_tn_kernel(const TN16Job j, const StoreC epi, const int ksplit)
 
 // ------------------------------------------------------------------------------ host side
 template <int HT, class EPI>
-static inline int launch16_nt(const Rows16& ra, const Rows16& rb, const EPI& epi, int M, int Nc, int K, int nsplit, hipStream_t s)
+static inline int launch16_nt(const Rows16& ra, const Rows16& rb, const EPI& epi, int M, int Nc, int K, int nsplit, hipStream_t s, bool allow64 = true)
 {
     dim3 grid((Nc + 127) / 128, (M + 127) / 128, nsplit > 1 ? nsplit : 1);
-    const bool k64 = K % 64 == 0 && (nsplit <= 1 || (K / 64) % nsplit == 0);
+    const bool k64 = allow64 && K % 64 == 0 && (nsplit <= 1 || (K / 64) % nsplit == 0);
     if (k64) {
         int ksplit = K; if (nsplit > 1) ksplit = st_round_up((K + nsplit - 1) / nsplit, 64);
         constexpr size_t lds = (size_t)4 * 128 * (64 + 8) * sizeof(h16_t);
