@@ -169,7 +169,8 @@ extern "C" int st_set_debug(int v) { g_dbg = v; return ST_OK; }
 namespace sta { extern __device__ unsigned long long g_ae_stage_cycles[32]; }
 // Diagnostics: read (and clear) the per-stage s_memtime accumulators of ae_bwd_kernel (st_set_debug(256)).
 extern "C" int st_debug_read_stage_cycles(unsigned long long* out32);
-static int g_ae_split = 1;   // autoencoder backward of the fused geometries: 1 = two kernels at two waves per SIMD (st_ae_split.h), 0 = the single kernel
+static int g_ae_split = 0;   // autoencoder backward of the fused geometries: 0 = the single kernel (default since round 3: 179.5 us against 87.0 + 92.4 us for the
+                             // two-kernel form at B = 256 -- equal -- and the split moves 66 MB more per step: h4 / d a4 / tails hand-over), 1 = st_ae_split.h (st_set_tuning(8001))
 static int g_pl_bf16 = 0;    // ST_PREC_BF16*: analysis / frames GEMMs on the plane kernel with ONE plane (bf16 copies of the bases, k-chunk-major).  MEASURED SLOWER at B = 256
                              // (analysis 53.8 vs 49.8 us + 12 us for the copies): three MFMAs per 16-deep k-tile and barrier; needs a 64-deep tile   (st_set_tuning(9400 + n))
 static int g_wg_split = 0;   // ST_PREC_F32X3: weight-gradient GEMMs on the in-kernel three-plane split instead of the fp32 MFMA kernel (see ST_GEMM_WG)   (st_set_tuning(9300 + n))
