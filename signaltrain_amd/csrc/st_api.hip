@@ -180,6 +180,7 @@ static int g_pl_shape = 3;   // analysis plane GEMM tile (ST_PREC_F32X3): 0 = 4 
 static int g_g16 = 1;        // 16-bit configurations: the fused step's GEMMs on pre-rounded 16-bit operands (st_gemm16.h); 0 = gemm_half_kernel on fp32 operands (st_set_tuning(9600), diagnostics)
 static int g_g16_bk = 64;    // k-tile depth of its TN kernel (st_set_tuning(9632 / 9664))
 static int g_g16_split = 0;  // k-slices of its weight-gradient GEMMs (0: by residency; st_set_tuning(9700 + n))
+static int g_nt128 = 1;      // fp32 synthesis frames / data-gradient GEMMs on the 128 x 128-tile NT kernel (st_gemm_tn.h); 0 = gemm_kernel<2, ...> (st_set_tuning(9950), diagnostics)
 static int g_tn128 = 1;      // weight-gradient GEMMs on the 128 x 128-tile kernel (st_gemm_tn.h) where it applies; 0 = gemm_kernel<3, ...> (st_set_tuning(9500), diagnostics)
 static int g_tn_bk = 32;     // its k-tile depth (st_set_tuning(9516 / 9532))
 static int g_frs_nt = 1;     // synthesis frames GEMM against the transposed fold (both operands K-contiguous); 0 = the k-major form (st_set_tuning(9000), diagnostics)
@@ -194,6 +195,7 @@ static int g_wg_mode_set(int v);
 static int g_wsplit_max = 16, g_wsplit_div = 200, g_an_waves = 4, g_syn_split = 3, g_frs_split = 3, g_wide_fused = 1, g_wsplit_half = 0;      // frames: 3, 4 measured equal, 6 slower (only 66 k-tiles to split)
 extern "C" int st_set_tuning(int bk)
 {
+    if (bk >= 9950) { g_nt128 = bk - 9950; return ST_OK; }
     if (bk >= 9900) { g_wide_dvp = bk - 9900; return ST_OK; }
     if (bk >= 9800) { g_nt_mi = bk - 9800; return ST_OK; }
     if (bk >= 9700) { g_g16_split = bk - 9700; return ST_OK; }
@@ -481,6 +483,17 @@ extern "C" int st_synthesis_frames(const st_dims* d, const float* AA, const floa
     ST_TRY(check_dims(d)); ST_REQ(AA && Sfold && frs, "st_synthesis_frames: null pointer");
     return synthesis_frames_impl(d, AA, Sfold, nullptr, frs, stream);
 }
+// k-slices that carry work on the 128 x 128 NT kernel: as many as fill the CUs with one workgroup each, at most the consumer's slab count
+static int nt128_active(int M, int Nc, int nslabs)
+{
+    const int tiles = ((M + 127) / 128) * ((Nc + 127) / 128);
+    int a = num_cus() / (tiles > 0 ? tiles : 1);
+    if (a < 1) a = 1;
+    return a < nslabs ? a : nslabs;
+}
+// only where one workgroup per CU covers the whole GEMM (the B = 256 headline geometry: 112 / 126 tiles x 2 k-slices); larger problems stay on
+// gemm_kernel<4, ...> / <2, ...>, whose smaller tiles balance better over several rounds
+static bool use_nt128(const st_dims* d, int M, int Nc) { return g_nt128 && gemm_ht(d->prec) == 0 && d->N % 32 == 0 && ((M + 127) / 128) * ((Nc + 127) / 128) * 2 <= num_cus(); }
 static int synthesis_frames_impl(const st_dims* d, const float* AA, const float* Sfold, const float* SfoldT, float* frs, void* stream)
 {
     const int KP = st_kp_of(d->F);
@@ -492,7 +505,12 @@ static int synthesis_frames_impl(const st_dims* d, const float* AA, const float*
     stg::StoreC ep{frs, R, d->N, d->N, (size_t)d->B * d->OT * d->N, ms};
     if (SfoldT && g_frs_nt) {
         stg::PlainNT bt{SfoldT, d->N, KP, KP, stg::all_frames(1)};
-        if (R >= 4096) ST_GEMM(4, al, bt, ep, R, d->N, KP, 1, st_stream(stream));
+        if (use_nt128(d, R, d->N)) {
+            const stg::NTRows ra{AA, (unsigned)(d->OT * KP), (unsigned)KP, ms.magic, ms.Tv, ms.t_lo, R}, rb{SfoldT, (unsigned)KP, 0u, 0u, 1, 0, d->N};
+            const int nsl = frames_split(R);
+            ST_TRY(stg::launch_nt128(ra, rb, ep, R, d->N, KP, nsl, nt128_active(R, d->N, nsl), st_stream(stream)));
+        }
+        else if (R >= 4096) ST_GEMM(4, al, bt, ep, R, d->N, KP, 1, st_stream(stream));
         else if (gemm_ht(d->prec) == 0 && (g_nt_mi & 4)) stg::launch<2, 16, 2>(al, bt, ep, R, d->N, KP, frames_split(R), st_stream(stream), g_dbg);
         else ST_GEMM(2, al, bt, ep, R, d->N, KP, frames_split(R), st_stream(stream));
     }
@@ -531,7 +549,11 @@ static int synthesis_dgrad_impl(const st_dims* d, const float* dsyn, bool padded
     const int ns = R >= 4096 ? 1 : synth_split(R);
     if (padded) {
         stg::FramedNT<true> al{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms};
-        if (R >= 4096) ST_GEMM(4, al, bl, ep, R, KP, d->N, ns, st_stream(stream));
+        if (use_nt128(d, R, KP)) {
+            const stg::NTRows ra{dsyn, (unsigned)(d->y + 2 * d->N), (unsigned)d->H, ms.magic, ms.Tv, ms.t_lo, R}, rb{Sfold, (unsigned)d->N, 0u, 0u, 1, 0, KP};
+            ST_TRY(stg::launch_nt128(ra, rb, ep, R, KP, d->N, ns, nt128_active(R, KP, ns), st_stream(stream)));
+        }
+        else if (R >= 4096) ST_GEMM(4, al, bl, ep, R, KP, d->N, ns, st_stream(stream));
         else if (gemm_ht(d->prec) == 0 && (g_nt_mi & 4)) stg::launch<2, 16, 2>(al, bl, ep, R, KP, d->N, ns, st_stream(stream), g_dbg);
         else ST_GEMM(2, al, bl, ep, R, KP, d->N, ns, st_stream(stream));
     } else {
@@ -1790,6 +1812,7 @@ static int attr_prepare(const st_dims* d)
         else ST_PREP3((sta::ae_bwd_kernel<AE_BWD_NW, false, false, 0, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 1, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 2, 0>));
     }
 #undef ST_PREP3
+    if (g_nt128 && gemm_ht(d->prec) == 0) ST_DYN_LDS((stg::gemm_nt128_kernel<stg::StoreC>));
     if (use_g16(d)) {           // st_gemm16.h: 72 / 80 KB of LDS with 64-deep k-tiles
         if (gemm_ht(d->prec) == 2) {
             ST_DYN_LDS((stg::gemm16_nt_kernel<2, 64, stg::PolarStore>)); ST_DYN_LDS((stg::gemm16_nt_kernel<2, 64, stg::StoreC>)); ST_DYN_LDS((stg::gemm16_tn_kernel<2, 64>));

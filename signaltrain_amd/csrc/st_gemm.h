@@ -257,6 +257,7 @@ __device__ __forceinline__ int d_row(int i, int lane) { return (i & 3) + 8 * (i 
 
 struct StoreC {       // out[(z*slab) + full_row*ld + col]; z = blockIdx.z (split-K slab)
     float* out; int M, Nc, ld; size_t slab; RowMap map;
+    __device__ StoreC slab_shifted(int dz) const { StoreC e = *this; e.out += (size_t)dz * slab; return e; }
     template <int NJX>                                            // NJX = 32-column blocks per wave (3: the 32 x 96 strips; 2: st_gemm16.h)
     __device__ void operator()(int m0, int n0, const f32x16 (&acc)[NJX]) const {
         const int lane = threadIdx.x & 63;

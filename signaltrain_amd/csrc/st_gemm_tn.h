@@ -226,3 +226,150 @@ static inline int launch_tn128(const TNOperand& A, const TNOperand& B, const flo
 }
 
 }  // namespace stg
+
+// ================================================================================================ NT x NT on the same 128 x 128 tiles (round 3)
+//   C[m][n] = sum_k A[m][k] * B[n][k],  both operands K-contiguous:  the synthesis FRAMES GEMM (cls_fe_dft.py:112 as a GEMM: A = spectra AA
+//   [live frames][KP], B = transposed fold [N][KP]) -- 58 us = 53 % of the fp32 peak on the 64 x 96 workgroup tiles of gemm_kernel<2, ...>
+//   (M = 1792 live frames only: 19 x 11 small tiles x 3 k-slices).  Here: 14 x 8 tiles of 128 x 128 x 2 k-slices = 224 workgroups, one per CU;
+//   row-major LDS tiles [row][BK + 4] (a global float4 along k = one ds_write_b128; a lane's 16 k of its row = four ds_read_b128, conflict-free at
+//   pitch 36), lane half h takes k in [16 h, 16 h + 16) of the 32-deep tile as in gemm_kernel; row offsets are per-thread constants and the k
+//   offset rides in the scalar base: NO address arithmetic in the loop.
+namespace stg {
+
+struct NTRows { const float* base; unsigned S1, S2, magic; int Tv, t_lo, R; };      // row r -> base[off(r) + k]; off = b * S1 + t * S2, (b, t) = split(min(r, R - 1)); magic == 0: b = r, t = 0
+__device__ __forceinline__ unsigned ntrows_off(const NTRows& o, const int r)
+{
+    const unsigned rc = (unsigned)(r < o.R ? r : o.R - 1);
+    const unsigned b = o.magic ? __umulhi(rc, o.magic) : rc;
+    const unsigned t = o.magic ? (unsigned)o.t_lo + (rc - b * (unsigned)o.Tv) : 0u;
+    return b * o.S1 + t * o.S2;
+}
+
+template <class EPI>
+__global__ void __launch_bounds__(256)
+gemm_nt128_kernel(const NTRows ra, const NTRows rb, const EPI epi, const int K, const int ksplit, const int nzero)
+{
+    constexpr int BKT = 32, LD = BKT + 4, TS = 128 * LD;
+    constexpr int NP = 4;                                  // 256 threads = 32 rows x 8 float4 per pass
+    extern __shared__ __attribute__((aligned(16))) float nt_lds[];       // As[2][128][LD] | Bs[2][128][LD]
+    float* const As = nt_lds;
+    float* const Bs = nt_lds + 2 * TS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    int tbx, tby, tbz; xcd_tile(tbx, tby, tbz);
+    const int m_blk = tby * 128, n_blk = tbx * 128;
+    const int k_begin = tbz * ksplit;
+    const int k_end = (k_begin + ksplit < K) ? k_begin + ksplit : K;
+
+    const int lr = tid >> 3, lk = (tid & 7) * 4;
+    unsigned ao[NP], bo[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        ao[p] = 4u * (ntrows_off(ra, m_blk + lr + 32 * p) + (unsigned)lk);       // BYTE offsets
+        bo[p] = 4u * (ntrows_off(rb, n_blk + lr + 32 * p) + (unsigned)lk);
+    }
+    f32x4 va[NP], vb[NP];
+    auto gload = [&](const int kt) {
+        const char* pa = reinterpret_cast<const char*>(ra.base) + 4 * (size_t)kt;
+        const char* pb = reinterpret_cast<const char*>(rb.base) + 4 * (size_t)kt;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            va[p] = *reinterpret_cast<const f32x4*>(pa + ao[p]);
+            vb[p] = *reinterpret_cast<const f32x4*>(pb + bo[p]);
+        }
+    };
+    auto lstore = [&](const int buf) {
+        float* as = As + buf * TS + lr * LD + lk;
+        float* bs = Bs + buf * TS + lr * LD + lk;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            *reinterpret_cast<f32x4*>(as + p * 32 * LD) = va[p];
+            *reinterpret_cast<f32x4*>(bs + p * 32 * LD) = vb[p];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mi][nj][i] = 0.f;
+
+    if (k_begin < k_end) {
+        gload(k_begin);
+        lstore(0);
+        __syncthreads();
+        int cur = 0;
+        const int h = lane >> 5, l31 = lane & 31;
+        const int a_off = (wm * 64 + l31) * LD + 16 * h, b_off = (wn * 64 + l31) * LD + 16 * h;
+        for (int kt = k_begin; kt < k_end; kt += BKT) {
+            const bool more = kt + BKT < k_end;
+            gload(more ? kt + BKT : kt);
+            __builtin_amdgcn_sched_barrier(0);
+            const float* as = As + cur * TS + a_off;
+            const float* bs = Bs + cur * TS + b_off;
+            // fragments in two halves of 8 k each: the second half is read while the first half's 32 MFMAs run
+            f32x4 fa[2][2][2], fb[2][2][2];                // [half][block][quad] (native vectors: HIP's float4 struct indexed through a pointer went to scratch)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        fa[hf][x][q] = *reinterpret_cast<const f32x4*>(as + x * 32 * LD + 8 * hf + 4 * q);
+                        fb[hf][x][q] = *reinterpret_cast<const f32x4*>(bs + x * 32 * LD + 8 * hf + 4 * q);
+                    }
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a0 = fa[hf][0][q][e], a1 = fa[hf][1][q][e];
+                        const float b0 = fb[hf][0][q][e], b1 = fb[hf][1][q][e];
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                    }
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // first half's fragments
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // second half's reads issued before the first MFMA
+            __builtin_amdgcn_sched_group_barrier(0x008, 64, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            lstore(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) epi(m_blk + wm * 64 + 32 * mi, n_blk + wn * 64, acc[mi]);
+    if (nzero > 0 && tbz == 0) {                           // the slabs no k-slice computes: this tile of each, zeros
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mi][nj][i] = 0.f;
+        for (int z = 0; z < nzero; ++z) {
+            const EPI ez = epi.slab_shifted((int)gridDim.z + z);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) ez(m_blk + wm * 64 + 32 * mi, n_blk + wn * 64, acc[mi]);
+        }
+    }
+}
+
+// nslabs: slabs the consumer sums (grid z); nactive <= nslabs: k-slices that carry work -- the others start past K and store zeros
+// (the consumers' slab counts are a function of the geometry alone; this kernel fills the chip with fewer, longer slices).
+// Launched with MORE than half the LDS of a CU so that no two workgroups share one: with tiles x nactive <= #CUs every workgroup then has a CU
+// to itself -- measured without this, 224 + 112 workgroups at 2 per CU: the dispatcher doubled up heavy ones and the GEMM took 79 us (61 TFLOP/s).
+template <class EPI>
+static inline int launch_nt128(const NTRows& ra, const NTRows& rb, const EPI& epi, int M, int Nc, int K, int nslabs, int nactive, hipStream_t s)
+{
+    int ksplit = K;
+    if (nactive > 1) ksplit = st_round_up((K + nactive - 1) / nactive, 32);
+    constexpr size_t lds = (size_t)84 * 1024;              // tiles: 4 * 128 * 36 * 4 = 72 KB; 84 KB > 160 / 2 keeps a CU to one workgroup
+    const int rc = ::ensure_dyn_lds((const void*)gemm_nt128_kernel<EPI>, "gemm_nt128_kernel"); if (rc) return rc;
+    hipLaunchKernelGGL((gemm_nt128_kernel<EPI>), dim3((Nc + 127) / 128, (M + 127) / 128, nactive > 1 ? nactive : 1), dim3(256), lds, s, ra, rb, epi, K, ksplit, nslabs - (nactive > 1 ? nactive : 1));
+    return 0;
+}
+
+}  // namespace stg
