@@ -331,11 +331,17 @@ gemm_nt128_kernel(const NTRows ra, const NTRows rb, const EPI epi, const int K, 
                         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
                         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
                     }
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // first half's fragments
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // second half's reads issued before the first MFMA
-            __builtin_amdgcn_sched_group_barrier(0x008, 64, 0);
-            __builtin_amdgcn_sched_barrier(0);
             lstore(cur ^ 1);
+            // one wave per SIMD (see launch_nt128): nothing else hides LDS traffic, so it is placed by hand --
+            // 8 reads | 32 MFMAs with the second half's 8 reads between them | 16 MFMAs | 16 MFMAs with the next tile's 8 ds_write_b128 between them
+            // (the global loads behind those writes were issued ~48 MFMAs = 3000 cycles earlier)
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             cur ^= 1;
         }
