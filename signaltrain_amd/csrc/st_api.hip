@@ -169,8 +169,11 @@ extern "C" int st_set_debug(int v) { g_dbg = v; return ST_OK; }
 namespace sta { extern __device__ unsigned long long g_ae_stage_cycles[32]; }
 // Diagnostics: read (and clear) the per-stage s_memtime accumulators of ae_bwd_kernel (st_set_debug(256)).
 extern "C" int st_debug_read_stage_cycles(unsigned long long* out32);
-static int g_ae_split = 0;   // autoencoder backward of the fused geometries: 0 = the single kernel (default since round 3: 179.5 us against 87.0 + 92.4 us for the
-                             // two-kernel form at B = 256 -- equal -- and the split moves 66 MB more per step: h4 / d a4 / tails hand-over), 1 = st_ae_split.h (st_set_tuning(8001))
+static int g_ae_split = -1;  // autoencoder backward of the fused geometries: 0 = the single kernel (st_set_tuning(8000)), 1 = the two kernels of st_ae_split.h (8001),
+                             // -1 = by precision (8002, default): fp32 -> single (179.5 us against 87.0 + 92.4 us at B = 256 -- equal: the fp32 MFMA holds the vector ALUs, a partner
+                             // wave has nothing to overlap with -- and the split moves 66 MB more per step: h4 / d a4 / tails hand-over); 16-bit Linear layers -> split (the
+                             // matrix pipe is then a separate unit and two waves per SIMD overlap it with the ELU / conversion / transpose work: 102 -> 48 + 44 us at
+                             // B = 256, 354 -> 152 + 138 us at B = 1024, bf16_all)
 static int g_pl_bf16 = 0;    // ST_PREC_BF16*: analysis / frames GEMMs on the plane kernel with ONE plane (bf16 copies of the bases, k-chunk-major).  MEASURED SLOWER at B = 256
                              // (analysis 53.8 vs 49.8 us + 12 us for the copies): three MFMAs per 16-deep k-tile and barrier; needs a 64-deep tile   (st_set_tuning(9400 + n))
 static int g_wg_split = 0;   // ST_PREC_F32X3: weight-gradient GEMMs on the in-kernel three-plane split instead of the fp32 MFMA kernel (see ST_GEMM_WG)   (st_set_tuning(9300 + n))
@@ -179,6 +182,7 @@ static int g_pl_shape = 3;   // analysis plane GEMM tile (ST_PREC_F32X3): 0 = 4 
                              // 3 = 8 waves x (32 x 96) = 256 x 96, one workgroup per CU: a quarter less L2 traffic at the same two waves per SIMD [88.1]   (st_set_tuning(9100 + n))
 static int g_g16 = 1;        // 16-bit configurations: the fused step's GEMMs on pre-rounded 16-bit operands (st_gemm16.h); 0 = gemm_half_kernel on fp32 operands (st_set_tuning(9600), diagnostics)
 static int g_g16_bk = 64;    // k-tile depth of its TN kernel (st_set_tuning(9632 / 9664))
+static int g_g16_abl = 0;    // TIMING ONLY (results invalid): analysis forward epilogue ablation, bit0 no mag/phs, bit1 no re/im (st_set_tuning(9680 + bits))
 static int g_g16_split = 0;  // k-slices of its weight-gradient GEMMs (0: by residency; st_set_tuning(9700 + n))
 static int g_nt128 = 1;      // fp32 synthesis frames / data-gradient GEMMs on the 128 x 128-tile NT kernel (st_gemm_tn.h); 0 = gemm_kernel<2, ...> (st_set_tuning(9950), diagnostics)
 static int g_tn128 = 1;      // weight-gradient GEMMs on the 128 x 128-tile kernel (st_gemm_tn.h) where it applies; 0 = gemm_kernel<3, ...> (st_set_tuning(9500), diagnostics)
@@ -199,6 +203,7 @@ extern "C" int st_set_tuning(int bk)
     if (bk >= 9900) { g_wide_dvp = bk - 9900; return ST_OK; }
     if (bk >= 9800) { g_nt_mi = bk - 9800; return ST_OK; }
     if (bk >= 9700) { g_g16_split = bk - 9700; return ST_OK; }
+    if (bk >= 9680 && bk < 9684) { g_g16_abl = bk - 9680; return ST_OK; }
     if (bk >= 9600) { const int v = bk - 9600; if (v == 32 || v == 64) g_g16_bk = v; else g_g16 = v; return ST_OK; }
     if (bk >= 9500) { const int v = bk - 9500; if (v == 16 || v == 32) g_tn_bk = v; else g_tn128 = v; return ST_OK; }
     if (bk >= 9400) { g_pl_bf16 = bk - 9400; return ST_OK; }
@@ -206,7 +211,7 @@ extern "C" int st_set_tuning(int bk)
     if (bk >= 9200) { g_pl_dgrad = bk - 9200; return ST_OK; }
     if (bk >= 9100) { g_pl_shape = bk - 9100; return ST_OK; }
     if (bk >= 9000) { g_frs_nt = bk - 9000; return ST_OK; }
-    if (bk >= 8000) { g_ae_split = bk - 8000; return ST_OK; }     // 8000 / 8001: single-kernel / split autoencoder backward
+    if (bk >= 8000) { g_ae_split = bk == 8002 ? -1 : bk - 8000; return ST_OK; }     // 8000 / 8001 / 8002: single-kernel / split autoencoder backward / by precision
     if (bk >= 7000) { g_xt = bk - 7000; return ST_OK; }
     if (bk >= 6000) { g_wsplit_half = bk - 6000; return ST_OK; }  // 6000 + n: split-K of the half (one-basis) analysis weight-gradient GEMMs of st_loss_backward_stage (0: as the full GEMM)
     if (bk >= 5000) { g_wide_fused = bk - 5000; return ST_OK; }   // 5000 / 5001: wide AE path all-GEMM / fused inner layers
@@ -363,7 +368,7 @@ static int ae_split_grid(const st_dims* d) { int g = (ae_fwd_groups(d) + AE_SPLI
 // precisions keep the single kernel.
 // 16-bit operands in the split form were tried (decoder + encoder halves 49 + 45 us against 101 us for the single kernel, the step did not
 // move) and are NOT instantiated: the compiler emitted a cross-block MFMA-result hazard in the 16-bit encoder half (tools/check_mfma_hazards.py).
-static bool ae_use_split(const st_dims* d) { return g_ae_split && !ae_is_wide(d) && ae_ht(d->prec) == 0 && !(g_dbg & 256); }
+static bool ae_use_split(const st_dims* d) { return (g_ae_split < 0 ? ae_ht(d->prec) != 0 : g_ae_split != 0) && !ae_is_wide(d) && !(g_dbg & 256); }
 extern "C" size_t st_ae_fwd_ws_floats(const st_dims* d)
 {
     if (check_dims(d) != ST_OK) return 0;
@@ -844,10 +849,9 @@ static int ae_bwd_impl(const st_dims* d, const float* mag, const float* phs, con
                            mag, phs, knobs, ae_m, ae_p, L.go, L.PG, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, expfac, dmag, dphs, parts, \
                            (const float*)h4x, da4x, d->B, d->T, d->OT, d->F, d->K, L.KP, live.t_lo, live.t_lo + live.Tv - 1, st_synth_slabs(d), \
                            (size_t)d->B * d->OT * L.KP); } while (0)
-        if (g_mag_hat) ST_AE_PART(1, 0, true); else ST_AE_PART(1, 0, false);
-        ST_LAUNCHED("ae_bwd_dec");
-        ST_AE_PART(2, 0, false);
-        ST_LAUNCHED("ae_bwd_enc");
+#define ST_AE_PARTS(HT_) do { if (g_mag_hat) ST_AE_PART(1, HT_, true); else ST_AE_PART(1, HT_, false); ST_LAUNCHED("ae_bwd_dec"); ST_AE_PART(2, HT_, false); ST_LAUNCHED("ae_bwd_enc"); } while (0)
+        switch (ae_ht(d->prec)) { case 1: ST_AE_PARTS(1); break; case 2: ST_AE_PARTS(2); break; default: ST_AE_PARTS(0); }
+#undef ST_AE_PARTS
 #undef ST_AE_PART
         if (defer_reduce && *defer_reduce) return ST_OK;
         hipLaunchKernelGGL(stm::ae_grad_reduce_kernel, dim3((L.PG + 63) / 64, 2), dim3(256), 0, st_stream(stream), parts, grid, L.PG, g_m, g_p);
@@ -1157,6 +1161,8 @@ static int analysis_fwd16(const st_dims* d, WS& w, float* re, float* im, float* 
     const stg::Rows16 ra = stg::rows16(w.xp16, (unsigned)(d->L + 2 * d->N), (unsigned)d->H, map, R);
     const stg::Rows16 rb = stg::rows16_plain(w.W16, (unsigned)d->N, 2 * d->F);
     stg::PolarStore ep{re, im, mag, phs, R, d->F, map};
+    if (g_g16_abl & 1) ep.mag = ep.phs = nullptr;
+    if (g_g16_abl & 2) ep.re = ep.im = nullptr;
     if (gemm_ht(d->prec) == 2) ST_TRY((stg::launch16_nt<2>(ra, rb, ep, R, 2 * d->F, d->N, 1, st_stream(stream), g_g16_bk != 32)));
     else ST_TRY((stg::launch16_nt<1>(ra, rb, ep, R, 2 * d->F, d->N, 1, st_stream(stream), g_g16_bk != 32)));
     ST_LAUNCHED("analysis_fwd"); return ST_OK;
@@ -1807,7 +1813,8 @@ static int attr_prepare(const st_dims* d)
     } else {
         ST_PREP3((sta::ae_fwd_kernel<AE_FWD_NW, 0>), (sta::ae_fwd_kernel<AE_FWD_NW, 1>), (sta::ae_fwd_kernel<AE_FWD_NW, 2>));
         if (ht == 0) ST_DYN_LDS((sta::ae_fwd_kernel<11, 0>));
-        if (ht == 0) { ST_DYN_LDS((sta::ae_bwd_part_kernel<AE_SPLIT_NW, 1, 0, false>)); ST_DYN_LDS((sta::ae_bwd_part_kernel<AE_SPLIT_NW, 2, 0, false>)); }
+        ST_PREP3((sta::ae_bwd_part_kernel<AE_SPLIT_NW, 1, 0, false>), (sta::ae_bwd_part_kernel<AE_SPLIT_NW, 1, 1, false>), (sta::ae_bwd_part_kernel<AE_SPLIT_NW, 1, 2, false>));
+        ST_PREP3((sta::ae_bwd_part_kernel<AE_SPLIT_NW, 2, 0, false>), (sta::ae_bwd_part_kernel<AE_SPLIT_NW, 2, 1, false>), (sta::ae_bwd_part_kernel<AE_SPLIT_NW, 2, 2, false>));
         if (d->T - d->OT == 16) ST_PREP3((sta::ae_bwd_kernel<AE_BWD_NW, false, false, 0, 2>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 1, 2>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 2, 2>));
         else ST_PREP3((sta::ae_bwd_kernel<AE_BWD_NW, false, false, 0, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 1, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 2, 0>));
     }

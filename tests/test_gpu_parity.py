@@ -325,7 +325,9 @@ def test_engine_on_a_non_current_device_or_stream():
 
 @pytest.mark.parametrize("dtype,codes,restore", [
     ("f32", (9000,), (9001,)),            # synthesis frames GEMM in the k-major form
-    ("f32", (8000,), (8001,)),            # single-kernel autoencoder backward
+    ("f32", (8001,), (8002,)),            # two-kernel autoencoder backward in fp32
+    ("bf16_all", (8000,), (8002,)),       # single-kernel autoencoder backward with 16-bit Linear layers
+    ("f16_all", (8000,), (8002,)),
     ("f32", (7001,), (7000,)),            # k-quad-major transposed staging of the weight-gradient GEMMs
     ("f32", (102,), (100,)),              # weight-gradient tile mode 2
     ("f32x3", (9201,), (9200,)),          # synthesis data gradient on the plane kernel
