@@ -182,7 +182,8 @@ static int g_pl_shape = 3;   // analysis plane GEMM tile (ST_PREC_F32X3): 0 = 4 
                              // 3 = 8 waves x (32 x 96) = 256 x 96, one workgroup per CU: a quarter less L2 traffic at the same two waves per SIMD [88.1]   (st_set_tuning(9100 + n))
 static int g_g16 = 1;        // 16-bit configurations: the fused step's GEMMs on pre-rounded 16-bit operands (st_gemm16.h); 0 = gemm_half_kernel on fp32 operands (st_set_tuning(9600), diagnostics)
 static int g_g16_bk = 64;    // k-tile depth of its TN kernel (st_set_tuning(9632 / 9664))
-static int g_g16_abl = 0;    // TIMING ONLY (results invalid): analysis forward epilogue ablation, bit0 no mag/phs, bit1 no re/im (st_set_tuning(9680 + bits))
+static int g_g16_dma = 1;    // its K-contiguous GEMMs with K % 64 == 0 (analysis forward, synthesis data gradient) on the LDS-DMA kernel gemm16_nt256_kernel; 0 = gemm16_nt_kernel (st_set_tuning(9690 + n))
+static int g_g16_abl = 0;    // TIMING ONLY (results invalid): analysis forward epilogue ablation, bit0 no mag/phs, bit1 no re/im, bit2 frame rows at 16-byte aligned (wrong) offsets (st_set_tuning(9680 + bits))
 static int g_g16_split = 0;  // k-slices of its weight-gradient GEMMs (0: by residency; st_set_tuning(9700 + n))
 static int g_nt128 = 1;      // fp32 synthesis frames / data-gradient GEMMs on the 128 x 128-tile NT kernel (st_gemm_tn.h); 0 = gemm_kernel<2, ...> (st_set_tuning(9950), diagnostics)
 static int g_tn128 = 1;      // weight-gradient GEMMs on the 128 x 128-tile kernel (st_gemm_tn.h) where it applies; 0 = gemm_kernel<3, ...> (st_set_tuning(9500), diagnostics)
@@ -199,11 +200,13 @@ static int g_wg_mode_set(int v);
 static int g_wsplit_max = 16, g_wsplit_div = 200, g_an_waves = 4, g_syn_split = 3, g_frs_split = 3, g_wide_fused = 1, g_wsplit_half = 0;      // frames: 3, 4 measured equal, 6 slower (only 66 k-tiles to split)
 extern "C" int st_set_tuning(int bk)
 {
+    if (bk >= 96800 && bk < 96928) { g_g16_abl = bk - 96800; return ST_OK; }      // timing-only ablations of the 16-bit analysis GEMM (bits 3..5: its k-loop)
     if (bk >= 9950) { g_nt128 = bk - 9950; return ST_OK; }
     if (bk >= 9900) { g_wide_dvp = bk - 9900; return ST_OK; }
     if (bk >= 9800) { g_nt_mi = bk - 9800; return ST_OK; }
     if (bk >= 9700) { g_g16_split = bk - 9700; return ST_OK; }
-    if (bk >= 9680 && bk < 9684) { g_g16_abl = bk - 9680; return ST_OK; }
+    if (bk >= 9690 && bk < 9700) { g_g16_dma = bk - 9690; return ST_OK; }
+    if (bk >= 9680 && bk < 9690) { g_g16_abl = bk - 9680; return ST_OK; }
     if (bk >= 9600) { const int v = bk - 9600; if (v == 32 || v == 64) g_g16_bk = v; else g_g16 = v; return ST_OK; }
     if (bk >= 9500) { const int v = bk - 9500; if (v == 16 || v == 32) g_tn_bk = v; else g_tn128 = v; return ST_OK; }
     if (bk >= 9400) { g_pl_bf16 = bk - 9400; return ST_OK; }
@@ -1158,12 +1161,17 @@ static int analysis_fwd16(const st_dims* d, WS& w, float* re, float* im, float* 
 {
     const stg::RowMap map = stg::live_frames(d->T, d->H, d->N, d->N, d->L);
     const int R = map.rows(d->B);
-    const stg::Rows16 ra = stg::rows16(w.xp16, (unsigned)(d->L + 2 * d->N), (unsigned)d->H, map, R);
+    stg::Rows16 ra = stg::rows16(w.xp16, (unsigned)(d->L + 2 * d->N), (unsigned)d->H, map, R);
+    if (g_g16_abl & 4) ra.S2 &= ~7u;              // timing only: 16-byte aligned frame rows
     const stg::Rows16 rb = stg::rows16_plain(w.W16, (unsigned)d->N, 2 * d->F);
     stg::PolarStore ep{re, im, mag, phs, R, d->F, map};
     if (g_g16_abl & 1) ep.mag = ep.phs = nullptr;
     if (g_g16_abl & 2) ep.re = ep.im = nullptr;
-    if (gemm_ht(d->prec) == 2) ST_TRY((stg::launch16_nt<2>(ra, rb, ep, R, 2 * d->F, d->N, 1, st_stream(stream), g_g16_bk != 32)));
+    if ((g_g16_dma & 1) && d->N % 64 == 0) {
+        if (gemm_ht(d->prec) == 2) ST_TRY((stg::launch16_nt256<2>(ra, rb, ep, R, 2 * d->F, d->N, 1, st_stream(stream), g_g16_abl >> 3)));
+        else ST_TRY((stg::launch16_nt256<1>(ra, rb, ep, R, 2 * d->F, d->N, 1, st_stream(stream), g_g16_abl >> 3)));
+    }
+    else if (gemm_ht(d->prec) == 2) ST_TRY((stg::launch16_nt<2>(ra, rb, ep, R, 2 * d->F, d->N, 1, st_stream(stream), g_g16_bk != 32)));
     else ST_TRY((stg::launch16_nt<1>(ra, rb, ep, R, 2 * d->F, d->N, 1, st_stream(stream), g_g16_bk != 32)));
     ST_LAUNCHED("analysis_fwd"); return ST_OK;
 }
@@ -1189,7 +1197,11 @@ static int synthesis_dgrad16(const st_dims* d, WS& w, void* stream)
     const stg::Rows16 rb = stg::rows16_plain(w.Sfold16, (unsigned)d->N, KP);
     stg::StoreC ep{w.dAA, R, KP, KP, (size_t)d->B * d->OT * KP, ms};
     const int ns = R >= 4096 ? 1 : synth_split(R);
-    if (gemm_ht(d->prec) == 2) ST_TRY((stg::launch16_nt<2>(ra, rb, ep, R, KP, d->N, ns, st_stream(stream))));
+    if ((g_g16_dma & 2) && d->N % 64 == 0 && d->N / 64 >= ns) {
+        if (gemm_ht(d->prec) == 2) ST_TRY((stg::launch16_nt256<2>(ra, rb, ep, R, KP, d->N, ns, st_stream(stream))));
+        else ST_TRY((stg::launch16_nt256<1>(ra, rb, ep, R, KP, d->N, ns, st_stream(stream))));
+    }
+    else if (gemm_ht(d->prec) == 2) ST_TRY((stg::launch16_nt<2>(ra, rb, ep, R, KP, d->N, ns, st_stream(stream))));
     else ST_TRY((stg::launch16_nt<1>(ra, rb, ep, R, KP, d->N, ns, st_stream(stream))));
     ST_LAUNCHED("synthesis_dgrad"); return ST_OK;
 }
@@ -1822,8 +1834,10 @@ static int attr_prepare(const st_dims* d)
     if (g_nt128 && gemm_ht(d->prec) == 0) ST_DYN_LDS((stg::gemm_nt128_kernel<stg::StoreC>));
     if (use_g16(d)) {           // st_gemm16.h: 72 / 80 KB of LDS with 64-deep k-tiles
         if (gemm_ht(d->prec) == 2) {
+            ST_DYN_LDS((stg::gemm16_nt256_kernel<2, stg::PolarStore>)); ST_DYN_LDS((stg::gemm16_nt256_kernel<2, stg::StoreC>));
             ST_DYN_LDS((stg::gemm16_nt_kernel<2, 64, stg::PolarStore>)); ST_DYN_LDS((stg::gemm16_nt_kernel<2, 64, stg::StoreC>)); ST_DYN_LDS((stg::gemm16_tn_kernel<2, 64>));
         } else {
+            ST_DYN_LDS((stg::gemm16_nt256_kernel<1, stg::PolarStore>)); ST_DYN_LDS((stg::gemm16_nt256_kernel<1, stg::StoreC>));
             ST_DYN_LDS((stg::gemm16_nt_kernel<1, 64, stg::PolarStore>)); ST_DYN_LDS((stg::gemm16_nt_kernel<1, 64, stg::StoreC>)); ST_DYN_LDS((stg::gemm16_tn_kernel<1, 64>));
         }
     }

@@ -137,6 +137,123 @@ gemm16_nt_kernel(const Rows16 ra, const Rows16 rb, const EPI epi, const int K, c
     for (int mi = 0; mi < 2; ++mi) epi(m_blk + wm * 64 + 32 * mi, n_blk + wn * 64, acc[mi]);
 }
 
+// ------------------------------------------------------------------------------ NT x NT through LDS-DMA (round 3)
+// gemm16_nt_kernel above re-fetches (128 + 128) x 64 operand elements per 128 x 128 x 64 of work through registers, one tile ahead: measured
+// (bf16, B = 1024 analysis forward, epilogue ablated) 94 us = 590 TFLOP/s -- each k-tile costs a workgroup ~4100 cycles against 512 of MFMA.
+// Here:  * workgroup tile 256 x 128, eight waves as 4 x 2 (wave tile 64 x 64 as before: two waves per SIMD, the partner fills the stalls), one
+//          workgroup per CU: 25 % less L2 -> LDS traffic per unit of work;
+//        * operands go global -> LDS by global_load_lds_dwordx4 (no staging registers, no ds_write pass), THREE 48 KB stages, the loads of tile
+//          t + 2 issued while tile t is multiplied: the wait before tile t is vmcnt(6) (this thread's six loads of tile t + 1 may still fly),
+//          never 0, and there is ONE barrier per tile (it both publishes tile t and retires the readers of the stage tile t + 2 overwrites);
+//        * an LDS-DMA instruction writes its 64 x 16 bytes lane-linear, so the bank swizzle is applied to the SOURCE address: LDS row r
+//          (128 bytes = 8 chunks of 8 k) holds chunk c at position c ^ ((r >> 1) & 7); the 16 rows x one chunk a ds_read_b128 service group
+//          fetches then cover all 64 banks (same involution on the read side).
+// K % 64 == 0 only (analysis forward: K = N; synthesis data gradient: K = N).
+template <int HT, class EPI>
+__global__ void __launch_bounds__(512, 2)
+gemm16_nt256_kernel(const Rows16 ra, const Rows16 rb, const EPI epi, const int K, const int ksplit, const int dbg)
+{
+    typedef typename frag16<HT>::type frag_t;
+    constexpr int A_BYTES = 256 * 128, B_BYTES = 128 * 128, STAGE = A_BYTES + B_BYTES, NST = 3;
+    extern __shared__ __attribute__((aligned(16))) h16_t g16_lds[];      // NST x [A 256 rows x 128 B | B 128 rows x 128 B]
+    char* const lds = reinterpret_cast<char*>(g16_lds);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    int tbx, tby, tbz; xcd_tile(tbx, tby, tbz);
+    const int m_blk = tby * 256, n_blk = tbx * 128;
+    const int k_begin = tbz * ksplit;
+    const int k_end = (k_begin + ksplit < K) ? k_begin + ksplit : K;
+    const int nt = (dbg & 8) ? 1 : (k_end - k_begin) / 64;
+
+    // DMA roles: instruction i of wave w covers LDS rows 8 (4 w + i) .. + 7 of A (i < 4) / 8 (2 w + i) .. + 7 of B (i < 2); lane l fills position
+    // l & 7 of row l >> 3 with source chunk (l & 7) ^ ((row >> 1) & 7)
+    const int dr = lane >> 3, dp = lane & 7;
+    unsigned ao[4], bo[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int r = 8 * (4 * wave + i) + dr; ao[i] = 2u * (rows16_off(ra, m_blk + r) + 8u * (unsigned)(dp ^ ((r >> 1) & 7))); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int r = 8 * (2 * wave + i) + dr; bo[i] = 2u * (rows16_off(rb, n_blk + r) + 8u * (unsigned)(dp ^ ((r >> 1) & 7))); }
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    auto issue = [&](const int tile, const int stage) {
+        const int tc = tile < nt ? tile : nt - 1;                          // past the end: reload the last tile into a free stage (uniform wait counts)
+        const char* pa = reinterpret_cast<const char*>(ra.base) + 2 * (size_t)(k_begin + 64 * tc);
+        const char* pb = reinterpret_cast<const char*>(rb.base) + 2 * (size_t)(k_begin + 64 * tc);
+        char* la = lds + stage * STAGE + 1024 * (4 * wave);
+        char* lb = lds + stage * STAGE + A_BYTES + 1024 * (2 * wave);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa + ao[i]), (lds_ptr_t)(la + 1024 * i), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) __builtin_amdgcn_global_load_lds((glb_ptr_t)(pb + bo[i]), (lds_ptr_t)(lb + 1024 * i), 16, 0, 0);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mi][nj][i] = 0.f;
+
+    if (nt > 0) {
+        issue(0, 0);
+        issue(1, 1);
+        const int g = lane >> 5, l31 = lane & 31;
+        const int p0 = (g ^ (l31 >> 1)) & 7;                               // chunk position of k-step 0 (chunk g of row l31); k-step s (chunk 2 s + g): p0 ^ 2 s
+        int a_off[4], b_off[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            a_off[s] = (wm * 64 + l31) * 128 + 16 * (p0 ^ (2 * s));
+            b_off[s] = A_BYTES + (wn * 64 + l31) * 128 + 16 * (p0 ^ (2 * s));
+        }
+        // PING-PONG: waves w and w + 4 share a SIMD; group A = waves 0..3, group B = waves 4..7 runs ONE PHASE behind.  Every wave alternates a
+        // READ phase (issue the DMA of tile t + 2, fetch the 16 fragments of tile t into registers) and a MULTIPLY phase (16 MFMAs), a barrier after
+        // each: while one wave of a SIMD multiplies, the other one reads -- measured before this, with all eight waves in step, a k-tile cost
+        // LDS time + MFMA time + DMA issue (2700 .. 3400 cycles against 1024 of MFMA per SIMD).
+        //   publication of tile t + 1: every wave waits for ITS loads of tile t + 1 (vmcnt(6): only tile t + 2's six may still fly) before the barrier that
+        //   ends its READ phase of tile t; group A then reads t + 1 two phases later, group B three.
+        //   reuse of stage (t + 2) % 3 == (t - 1) % 3: a wave issues into it at the start of its READ phase of tile t; by then both groups have passed the
+        //   barrier that followed their READ phase of tile t - 1 (whose lgkmcnt(0) retired those ds_reads).
+        const bool grp_b = wave >= 4;
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                   // tile 0 (this thread's part) has landed ...
+        __builtin_amdgcn_s_barrier();                                       // ... and everyone's
+        if (grp_b) __builtin_amdgcn_s_barrier();
+        int stage = 0;
+        for (int t = 0; t < nt; ++t) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(dbg & 1)) issue(t + 2, stage >= 1 ? stage - 1 : NST - 1);
+            const char* st = lds + stage * STAGE;
+            frag_t fa[4][2], fb[4][2];                                      // [k-step][32-row block]
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                fa[s][0] = *reinterpret_cast<const frag_t*>(st + a_off[s]); fb[s][0] = *reinterpret_cast<const frag_t*>(st + b_off[s]);
+                fa[s][1] = *reinterpret_cast<const frag_t*>(st + a_off[s] + 32 * 128); fb[s][1] = *reinterpret_cast<const frag_t*>(st + b_off[s] + 32 * 128);
+            }
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[0][0] = mfma16x<HT>(fa[s][0], fb[s][0], acc[0][0]);
+                acc[0][1] = mfma16x<HT>(fa[s][0], fb[s][1], acc[0][1]);
+                acc[1][0] = mfma16x<HT>(fa[s][1], fb[s][0], acc[1][0]);
+                acc[1][1] = mfma16x<HT>(fa[s][1], fb[s][1], acc[1][1]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            stage = stage == NST - 1 ? 0 : stage + 1;
+        }
+        if (!grp_b) __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the tail reloads: nothing may still be writing LDS when the workgroup retires
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) epi(m_blk + wm * 64 + 32 * mi, n_blk + wn * 64, acc[mi]);
+}
+
 // ------------------------------------------------------------------------------ TN x TN:  C[m][n] = sum_k A[k][m] * B[k][n]
 // (the weight-gradient GEMMs: k = compact live frame row; A = d G / AA, B = frames of the padded waveform / of d syn, all 16-bit)
 struct TN16Job {
@@ -259,6 +376,17 @@ static inline int launch16_nt(const Rows16& ra, const Rows16& rb, const EPI& epi
         constexpr size_t lds = (size_t)4 * 128 * (32 + 8) * sizeof(h16_t);
         hipLaunchKernelGGL((gemm16_nt_kernel<HT, 32, EPI>), grid, dim3(256), lds, s, ra, rb, epi, K, ksplit);
     }
+    return 0;
+}
+template <int HT, class EPI>
+static inline bool nt256_fits(int K, int nsplit) { return K % 64 == 0 && K / 64 >= (nsplit > 1 ? nsplit : 1); }
+template <int HT, class EPI>
+static inline int launch16_nt256(const Rows16& ra, const Rows16& rb, const EPI& epi, int M, int Nc, int K, int nsplit, hipStream_t s, int dbg = 0)
+{
+    int ksplit = K; if (nsplit > 1) ksplit = st_round_up((K + nsplit - 1) / nsplit, 64);
+    constexpr size_t lds = (size_t)3 * (256 + 128) * 128;
+    const int rc = ::ensure_dyn_lds((const void*)gemm16_nt256_kernel<HT, EPI>, "gemm16_nt256_kernel"); if (rc) return rc;
+    hipLaunchKernelGGL((gemm16_nt256_kernel<HT, EPI>), dim3((Nc + 127) / 128, (M + 255) / 256, nsplit > 1 ? nsplit : 1), dim3(512), lds, s, ra, rb, epi, K, ksplit, dbg);
     return 0;
 }
 template <int HT, int BKH>
