@@ -182,7 +182,8 @@ static int g_pl_shape = 3;   // analysis plane GEMM tile (ST_PREC_F32X3): 0 = 4 
                              // 3 = 8 waves x (32 x 96) = 256 x 96, one workgroup per CU: a quarter less L2 traffic at the same two waves per SIMD [88.1]   (st_set_tuning(9100 + n))
 static int g_g16 = 1;        // 16-bit configurations: the fused step's GEMMs on pre-rounded 16-bit operands (st_gemm16.h); 0 = gemm_half_kernel on fp32 operands (st_set_tuning(9600), diagnostics)
 static int g_g16_bk = 64;    // k-tile depth of its TN kernel (st_set_tuning(9632 / 9664))
-static int g_g16_dma = 1;    // its K-contiguous GEMMs with K % 64 == 0 (analysis forward, synthesis data gradient) on the LDS-DMA kernel gemm16_nt256_kernel; 0 = gemm16_nt_kernel (st_set_tuning(9690 + n))
+static int g_g16_dma = 0;    // bit 0 / bit 1: its analysis forward / synthesis data-gradient GEMM on the LDS-DMA kernel gemm16_nt256_kernel (st_set_tuning(9690 + bits)).  MEASURED EQUAL to
+                             // gemm16_nt_kernel (analysis forward, bf16, B = 256 / 1024: 34.2 / 138.6 us against 35.5 / 137.2): both deliver ~20 B/clk/CU from L2 to LDS, see st_gemm16.h
 static int g_g16_abl = 0;    // TIMING ONLY (results invalid): analysis forward epilogue ablation, bit0 no mag/phs, bit1 no re/im, bit2 frame rows at 16-byte aligned (wrong) offsets (st_set_tuning(9680 + bits))
 static int g_g16_split = 0;  // k-slices of its weight-gradient GEMMs (0: by residency; st_set_tuning(9700 + n))
 static int g_nt128 = 1;      // fp32 synthesis frames / data-gradient GEMMs on the 128 x 128-tile NT kernel (st_gemm_tn.h); 0 = gemm_kernel<2, ...> (st_set_tuning(9950), diagnostics)
@@ -1325,6 +1326,11 @@ static int backward_ae(const st_dims* d, const Layout& L, const float* params, f
     a.re = w.re; a.im = w.im; a.dmag = w.dmag; a.dphs = w.dphs; a.g_mag = g_mag; a.dG = w.dG; a.F = d->F; a.KP = L.KP;
     a.gx = (L.KP / 2 + 255) / 256; a.sat = gemm_ht(d->prec) == 2 ? 65504.0f : 0.0f;
     a.n_polar = a.gx * d->B * d->T;
+    a.polar_total = 0; a.polar_magic = 0;
+    if (stm::polar_flat_ok((long long)d->B * d->T, L.KP / 2)) {
+        a.polar_total = (unsigned)((long long)d->B * d->T * (L.KP / 2)); a.polar_magic = stm::polar_magic(L.KP / 2);
+        a.n_polar = (int)((a.polar_total + 256 * stm::POLAR_EPT - 1) / (256 * stm::POLAR_EPT));
+    }
     a.wg = w.wg; a.wg_nz = syn_slabs; a.gSr = grads + L.offs[2]; a.gSi = grads + L.offs[3]; a.norm_s = w.norm_s; a.N = d->N;
     a.nyq = stm::NyqJob{}; a.nyq.on = 0; if (syn_nyq) a.nyq = *syn_nyq;
     a.dG16 = nullptr; a.ht = 0;

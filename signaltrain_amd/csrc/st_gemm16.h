@@ -150,7 +150,7 @@ gemm16_nt_kernel(const Rows16 ra, const Rows16 rb, const EPI epi, const int K, c
 //          fetches then cover all 64 banks (same involution on the read side).
 // K % 64 == 0 only (analysis forward: K = N; synthesis data gradient: K = N).
 template <int HT, class EPI>
-__global__ void __launch_bounds__(512, 2)
+__global__ void __launch_bounds__(768)
 gemm16_nt256_kernel(const Rows16 ra, const Rows16 rb, const EPI epi, const int K, const int ksplit, const int dbg)
 {
     typedef typename frag16<HT>::type frag_t;
@@ -159,35 +159,73 @@ gemm16_nt256_kernel(const Rows16 ra, const Rows16 rb, const EPI epi, const int K
     char* const lds = reinterpret_cast<char*>(g16_lds);
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tbx, tby, tbz; xcd_tile(tbx, tby, tbz);
     const int m_blk = tby * 256, n_blk = tbx * 128;
     const int k_begin = tbz * ksplit;
     const int k_end = (k_begin + ksplit < K) ? k_begin + ksplit : K;
     const int nt = (dbg & 8) ? 1 : (k_end - k_begin) / 64;
+    if (nt <= 0) {                                                          // a k-slice past K: zeros (consumers only)
+        if (wave < 8) {
+            f32x16 z[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) z[j][i] = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) epi(m_blk + (wave >> 1) * 64 + 32 * mi, n_blk + (wave & 1) * 64, z);
+        }
+        return;
+    }
 
-    // DMA roles: instruction i of wave w covers LDS rows 8 (4 w + i) .. + 7 of A (i < 4) / 8 (2 w + i) .. + 7 of B (i < 2); lane l fills position
-    // l & 7 of row l >> 3 with source chunk (l & 7) ^ ((row >> 1) & 7)
-    const int dr = lane >> 3, dp = lane & 7;
-    unsigned ao[4], bo[2];
+    // ---------------------------------------------------------------- PRODUCERS: waves 8..11 (one per SIMD) only move data
+    // An LDS-DMA instruction holds its wave until the CU's one address path has taken it -- measured 100 .. 190 cycles each beside ds_reads: issued
+    // by the multiplying waves themselves (6 per wave per tile) they made the READ phase 1150 cycles long against 512 of MFMAs.  A producer has
+    // nothing else to do.  Producer p issues 8 instructions of A (LDS rows 64 p .. 64 p + 63) and 4 of B (rows 32 p ..) per tile; lane l fills
+    // position l & 7 of row l >> 3 of its 8-row piece with source chunk (l & 7) ^ ((row >> 1) & 7).
+    if (wave >= 8) {
+        const int p = wave - 8, dr = lane >> 3, dp = lane & 7;
+        unsigned ao[8], bo[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int r = 8 * (4 * wave + i) + dr; ao[i] = 2u * (rows16_off(ra, m_blk + r) + 8u * (unsigned)(dp ^ ((r >> 1) & 7))); }
+        for (int i = 0; i < 8; ++i) { const int r = 8 * (8 * p + i) + dr; ao[i] = 2u * (rows16_off(ra, m_blk + r) + 8u * (unsigned)(dp ^ ((r >> 1) & 7))); }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { const int r = 8 * (2 * wave + i) + dr; bo[i] = 2u * (rows16_off(rb, n_blk + r) + 8u * (unsigned)(dp ^ ((r >> 1) & 7))); }
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-    auto issue = [&](const int tile, const int stage) {
-        const int tc = tile < nt ? tile : nt - 1;                          // past the end: reload the last tile into a free stage (uniform wait counts)
-        const char* pa = reinterpret_cast<const char*>(ra.base) + 2 * (size_t)(k_begin + 64 * tc);
-        const char* pb = reinterpret_cast<const char*>(rb.base) + 2 * (size_t)(k_begin + 64 * tc);
-        char* la = lds + stage * STAGE + 1024 * (4 * wave);
-        char* lb = lds + stage * STAGE + A_BYTES + 1024 * (2 * wave);
+        for (int i = 0; i < 4; ++i) { const int r = 8 * (4 * p + i) + dr; bo[i] = 2u * (rows16_off(rb, n_blk + r) + 8u * (unsigned)(dp ^ ((r >> 1) & 7))); }
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+        typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+        auto issue = [&](const int tile, const int stage) {
+            const int tc = tile < nt ? tile : nt - 1;                      // past the end: reload the last tile into a free stage (uniform wait counts)
+            const char* pa = reinterpret_cast<const char*>(ra.base) + 2 * (size_t)(k_begin + 64 * tc);
+            const char* pb = reinterpret_cast<const char*>(rb.base) + 2 * (size_t)(k_begin + 64 * tc);
+            char* la = lds + stage * STAGE + 1024 * (8 * p);
+            char* lb = lds + stage * STAGE + A_BYTES + 1024 * (4 * p);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa + ao[i]), (lds_ptr_t)(la + 1024 * i), 16, 0, 0);
+            for (int i = 0; i < 8; ++i) __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa + ao[i]), (lds_ptr_t)(la + 1024 * i), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) __builtin_amdgcn_global_load_lds((glb_ptr_t)(pb + bo[i]), (lds_ptr_t)(lb + 1024 * i), 16, 0, 0);
-    };
+            for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((glb_ptr_t)(pb + bo[i]), (lds_ptr_t)(lb + 1024 * i), 16, 0, 0);
+        };
+        issue(0, 0);
+        issue(1, 1);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                  // tile 0 has landed
+        __builtin_amdgcn_s_barrier();                                       // P0
+        int stage = 0;
+        for (int t = 0; t < nt; ++t) {
+            // start of phase 2 t: group B fetched tile t - 1 during phase 2 t - 1 -> stage (t - 1) % 3 == (t + 2) % 3 is free
+            if (!(dbg & 1)) issue(t + 2, stage >= 1 ? stage - 1 : NST - 1);
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");              // tile t + 1 (issued a whole tile ago) has landed: group A reads it in phase 2 t + 2
+            __builtin_amdgcn_s_barrier();                                   // end of phase 2 t
+            __builtin_amdgcn_s_barrier();                                   // end of phase 2 t + 1
+            stage = stage == NST - 1 ? 0 : stage + 1;
+        }
+        __builtin_amdgcn_s_barrier();                                       // end of phase 2 nt (group B's last MULTIPLY phase)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the tail reloads: nothing may still be writing LDS when the workgroup retires
+        return;
+    }
 
+    // ---------------------------------------------------------------- CONSUMERS: waves 0..7 as 4 x 2, wave tile 64 x 64
+    // PING-PONG: waves w and w + 4 share a SIMD; group A = waves 0..3, group B = waves 4..7 runs ONE PHASE behind.  A consumer alternates a READ phase
+    // (the 16 fragments of tile t into registers) and a MULTIPLY phase (16 MFMAs), a barrier after each: while one wave of a SIMD multiplies, the
+    // other one reads (all eight in step, a k-tile cost LDS time + MFMA time: 2700 .. 3400 cycles against 1024 of MFMAs per SIMD).
+    const int wm = wave >> 1, wn = wave & 1;
     f32x16 acc[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -195,10 +233,7 @@ gemm16_nt256_kernel(const Rows16 ra, const Rows16 rb, const EPI epi, const int K
         for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mi][nj][i] = 0.f;
-
-    if (nt > 0) {
-        issue(0, 0);
-        issue(1, 1);
+    {
         const int g = lane >> 5, l31 = lane & 31;
         const int p0 = (g ^ (l31 >> 1)) & 7;                               // chunk position of k-step 0 (chunk g of row l31); k-step s (chunk 2 s + g): p0 ^ 2 s
         int a_off[4], b_off[4];
@@ -207,22 +242,12 @@ gemm16_nt256_kernel(const Rows16 ra, const Rows16 rb, const EPI epi, const int K
             a_off[s] = (wm * 64 + l31) * 128 + 16 * (p0 ^ (2 * s));
             b_off[s] = A_BYTES + (wn * 64 + l31) * 128 + 16 * (p0 ^ (2 * s));
         }
-        // PING-PONG: waves w and w + 4 share a SIMD; group A = waves 0..3, group B = waves 4..7 runs ONE PHASE behind.  Every wave alternates a
-        // READ phase (issue the DMA of tile t + 2, fetch the 16 fragments of tile t into registers) and a MULTIPLY phase (16 MFMAs), a barrier after
-        // each: while one wave of a SIMD multiplies, the other one reads -- measured before this, with all eight waves in step, a k-tile cost
-        // LDS time + MFMA time + DMA issue (2700 .. 3400 cycles against 1024 of MFMA per SIMD).
-        //   publication of tile t + 1: every wave waits for ITS loads of tile t + 1 (vmcnt(6): only tile t + 2's six may still fly) before the barrier that
-        //   ends its READ phase of tile t; group A then reads t + 1 two phases later, group B three.
-        //   reuse of stage (t + 2) % 3 == (t - 1) % 3: a wave issues into it at the start of its READ phase of tile t; by then both groups have passed the
-        //   barrier that followed their READ phase of tile t - 1 (whose lgkmcnt(0) retired those ds_reads).
         const bool grp_b = wave >= 4;
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                   // tile 0 (this thread's part) has landed ...
-        __builtin_amdgcn_s_barrier();                                       // ... and everyone's
+        __builtin_amdgcn_s_barrier();                                       // P0: tile 0 is in LDS
         if (grp_b) __builtin_amdgcn_s_barrier();
         int stage = 0;
         for (int t = 0; t < nt; ++t) {
             __builtin_amdgcn_sched_barrier(0);
-            if (!(dbg & 1)) issue(t + 2, stage >= 1 ? stage - 1 : NST - 1);
             const char* st = lds + stage * STAGE;
             frag_t fa[4][2], fb[4][2];                                      // [k-step][32-row block]
 #pragma unroll
@@ -230,7 +255,7 @@ gemm16_nt256_kernel(const Rows16 ra, const Rows16 rb, const EPI epi, const int K
                 fa[s][0] = *reinterpret_cast<const frag_t*>(st + a_off[s]); fb[s][0] = *reinterpret_cast<const frag_t*>(st + b_off[s]);
                 fa[s][1] = *reinterpret_cast<const frag_t*>(st + a_off[s] + 32 * 128); fb[s][1] = *reinterpret_cast<const frag_t*>(st + b_off[s] + 32 * 128);
             }
-            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the stage may be overwritten once everyone is past the next barrier
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -248,7 +273,6 @@ gemm16_nt256_kernel(const Rows16 ra, const Rows16 rb, const EPI epi, const int K
             stage = stage == NST - 1 ? 0 : stage + 1;
         }
         if (!grp_b) __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the tail reloads: nothing may still be writing LDS when the workgroup retires
     }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) epi(m_blk + wm * 64 + 32 * mi, n_blk + wn * 64, acc[mi]);
@@ -386,7 +410,7 @@ static inline int launch16_nt256(const Rows16& ra, const Rows16& rb, const EPI& 
     int ksplit = K; if (nsplit > 1) ksplit = st_round_up((K + nsplit - 1) / nsplit, 64);
     constexpr size_t lds = (size_t)3 * (256 + 128) * 128;
     const int rc = ::ensure_dyn_lds((const void*)gemm16_nt256_kernel<HT, EPI>, "gemm16_nt256_kernel"); if (rc) return rc;
-    hipLaunchKernelGGL((gemm16_nt256_kernel<HT, EPI>), dim3((Nc + 127) / 128, (M + 255) / 256, nsplit > 1 ? nsplit : 1), dim3(512), lds, s, ra, rb, epi, K, ksplit, dbg);
+    hipLaunchKernelGGL((gemm16_nt256_kernel<HT, EPI>), dim3((Nc + 127) / 128, (M + 255) / 256, nsplit > 1 ? nsplit : 1), dim3(768), lds, s, ra, rb, epi, K, ksplit, dbg);
     return 0;
 }
 template <int HT, int BKH>

@@ -231,6 +231,52 @@ __device__ __forceinline__ void polar_bwd_block(const float* __restrict__ re, co
     if (dG16) { dG16[(size_t)r * KP + c] = st_to_h16(gre, ht); dG16[(size_t)r * KP + half + c] = st_to_h16(gim, ht); }      // the operand of the analysis weight-gradient GEMM (st_gemm16.h)
     if (dG) { dG[(size_t)r * KP + c] = gre; dG[(size_t)r * KP + half + c] = gim; }
 }
+// The same over the flattened (row, column) space, FOUR elements per thread with all sixteen loads issued before the first use (post_ae_kernel):
+// one element per thread -- three blocks per 528-column row, the third with 16 live lanes -- ran at half the HBM rate (71 us for 264 MB at B = 1024).
+// e = r * half + c;  r = umulhi(e, magic) with magic = ceil(2^32 / half), exact for the e the host admits (polar_flat_ok).
+constexpr int POLAR_EPT = 4;
+__host__ __device__ static inline unsigned polar_magic(int half) { return (unsigned)((0x100000000ull + (unsigned)half - 1) / (unsigned)half); }
+__host__ static inline bool polar_flat_ok(long long R, int half)
+{
+    const unsigned long long M = polar_magic(half), slack = M * (unsigned)half - 0x100000000ull;      // q is exact while e * slack < 2^32
+    const unsigned long long total = (unsigned long long)R * (unsigned)half;
+    return total < 0x7fffffffull && (slack == 0 || total < 0x100000000ull / slack);
+}
+__device__ __forceinline__ void polar_bwd_flat(const float* __restrict__ re, const float* __restrict__ im, const float* __restrict__ dmag,
+                 const float* __restrict__ dphs, const float* __restrict__ g_mag, float* __restrict__ dG, const int F, const int KP, const float sat,
+                 const unsigned bx, const unsigned total, const unsigned magic, unsigned short* __restrict__ dG16, const int ht)
+{
+    const unsigned half = (unsigned)KP / 2;
+    unsigned r[POLAR_EPT], c[POLAR_EPT]; bool on[POLAR_EPT], live[POLAR_EPT];
+    float a[POLAR_EPT], bb[POLAR_EPT], dm[POLAR_EPT], dp[POLAR_EPT];
+#pragma unroll
+    for (int u = 0; u < POLAR_EPT; ++u) {
+        const unsigned e = (bx * POLAR_EPT + u) * 256 + threadIdx.x;
+        on[u] = e < total;
+        r[u] = __umulhi(on[u] ? e : 0u, magic); c[u] = (on[u] ? e : 0u) - r[u] * half;
+        live[u] = on[u] && c[u] < (unsigned)F;
+        const size_t i = live[u] ? (size_t)r[u] * F + c[u] : 0;
+        a[u] = re[i]; bb[u] = im[i]; dm[u] = dmag[i] + (g_mag ? g_mag[i] : 0.f); dp[u] = dphs[i];
+    }
+#pragma unroll
+    for (int u = 0; u < POLAR_EPT; ++u) {
+        float gre = 0.f, gim = 0.f;
+        if (live[u]) {
+            const float mg = sqrtf(a[u] * a[u] + bb[u] * bb[u]);
+            const float inv = mg > 0.f ? 1.0f / mg : 0.f;
+            const float rp = a[u] + 1e-7f;
+            const float den = rp * rp + bb[u] * bb[u];
+            gre = dm[u] * a[u] * inv - dp[u] * bb[u] / den;
+            gim = dm[u] * bb[u] * inv + dp[u] * rp / den;
+            if (sat > 0.f) { gre = __builtin_amdgcn_fmed3f(gre, -sat, sat); gim = __builtin_amdgcn_fmed3f(gim, -sat, sat); }
+        }
+        if (on[u]) {
+            const size_t o = (size_t)r[u] * KP + c[u];
+            if (dG16) { dG16[o] = st_to_h16(gre, ht); dG16[o + half] = st_to_h16(gim, ht); }
+            if (dG) { dG[o] = gre; dG[o + half] = gim; }
+        }
+    }
+}
 __global__ void __launch_bounds__(256)
 polar_bwd_kernel(const float* __restrict__ re, const float* __restrict__ im, const float* __restrict__ dmag,
                  const float* __restrict__ dphs, const float* __restrict__ g_mag, float* __restrict__ dG, int R, int F, int KP, const float sat,
@@ -384,12 +430,14 @@ struct PostAeArgs {
     // un-folded and normed here instead of in a launch of their own
     int n_polar; const float* wg; int wg_nz; float* gSr; float* gSi; float* norm_s; int N; NyqJob nyq;
     unsigned short* dG16; int ht;          // 16-bit configurations: d G rounded to the GEMM operand type (dG itself may then be NULL)
+    unsigned polar_total, polar_magic;     // polar_total > 0: the polar blocks walk the flattened element space (polar_bwd_flat)
 };
 __global__ void __launch_bounds__(256)
 post_ae_kernel(const PostAeArgs a)
 {
     const int blk = blockIdx.x;
     if (blk < a.n_red) { const int ae = blk / a.n_red_x; ae_grad_reduce_block(a.ws, a.nparts, a.PG, a.g_m, a.g_p, blk - ae * a.n_red_x, ae); }
+    else if (blk < a.n_red + a.n_polar && a.polar_total) polar_bwd_flat(a.re, a.im, a.dmag, a.dphs, a.g_mag, a.dG, a.F, a.KP, a.sat, (unsigned)(blk - a.n_red), a.polar_total, a.polar_magic, a.dG16, a.ht);
     else if (blk < a.n_red + a.n_polar) { const int q = blk - a.n_red, r = q / a.gx; polar_bwd_block(a.re, a.im, a.dmag, a.dphs, a.g_mag, a.dG, a.F, a.KP, a.sat, q - r * a.gx, r, a.dG16, a.ht); }
     else wgrad_reduce_block(a.wg, a.wg_nz, a.gSr, a.gSi, a.norm_s, a.N, a.F, a.KP, 1, blk - a.n_red - a.n_polar, nullptr, a.nyq);
 }
@@ -407,12 +455,31 @@ struct FinArgs {
 // coefficient, thread 0 also gets the loss terms.  One summation order, so any block that evaluates this gets the same bits.
 __device__ __forceinline__ float finalize_block(const FinArgs& f, const bool want_loss, float* red, float& lc, float& rg, float& nrm)
 {
+    // a thread's share of a partial array: float4 loads, four of them in flight per trip (the arrays grow with the batch -- 8 partials per window
+    // from ola_loss: as one dependent 4-byte load per trip, block 0 of the optimizer kernel spent 32 round trips = 20 us here at B = 1024 while
+    // every other block waited for nothing)
+    auto psum = [](const float* __restrict__ p, const int n) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+            const int n4 = n >> 2;
+            const float4* p4 = reinterpret_cast<const float4*>(p);
+            int i = threadIdx.x;
+            for (; i + 768 < n4; i += 1024) {
+                const float4 u0 = p4[i], u1 = p4[i + 256], u2 = p4[i + 512], u3 = p4[i + 768];
+                s0 += (u0.x + u0.y) + (u0.z + u0.w); s1 += (u1.x + u1.y) + (u1.z + u1.w);
+                s2 += (u2.x + u2.y) + (u2.z + u2.w); s3 += (u3.x + u3.y) + (u3.z + u3.w);
+            }
+            for (; i < n4; i += 256) { const float4 u = p4[i]; s0 += (u.x + u.y) + (u.z + u.w); }
+            for (int j = 4 * n4 + threadIdx.x; j < n; j += 256) s1 += p[j];
+        } else for (int j = threadIdx.x; j < n; j += 256) s0 += p[j];
+        return (s0 + s1) + (s2 + s3);
+    };
     float a = 0.f, b = 0.f, c = 0.f;
-    if (want_loss && f.loss_partial) for (int i = threadIdx.x; i < f.n_loss; i += 256) a += f.loss_partial[i];
-    if (want_loss && f.reg_partial) for (int i = threadIdx.x; i < f.n_reg; i += 256) b += f.reg_partial[i];
-    if (f.norm_a) for (int i = threadIdx.x; i < f.n_na; i += 256) c += f.norm_a[i];
-    if (f.norm_s) for (int i = threadIdx.x; i < f.n_ns; i += 256) c += f.norm_s[i];
-    if (f.norm_e) for (int i = threadIdx.x; i < f.n_ne; i += 256) c += f.norm_e[i];
+    if (want_loss && f.loss_partial) a = psum(f.loss_partial, f.n_loss);
+    if (want_loss && f.reg_partial) b = psum(f.reg_partial, f.n_reg);
+    if (f.norm_a) c += psum(f.norm_a, f.n_na);
+    if (f.norm_s) c += psum(f.norm_s, f.n_ns);
+    if (f.norm_e) c += psum(f.norm_e, f.n_ne);
     if (want_loss) { a = block_sum<4>(a, red); b = block_sum<4>(b, red); }
     c = block_sum<4>(c, red);
     __shared__ float bc;
