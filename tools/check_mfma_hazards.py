@@ -19,7 +19,9 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "signaltrain_amd", "csrc", "st_api.hip")
 # wait states an independent VALU read needs after the MFMA issues (passes + 3, rounded up generously)
-NEED = {"16x16x4": 10, "32x32x2": 18, "4x4": 4}     # = what the compiler pads to inside one block (s_nop 9 / s_nop 15 + 2)
+NEED = {"16x16x4_": 10, "32x32x2_": 18, "4x4": 4,     # = what the compiler pads to inside one block (s_nop 9 / s_nop 15 + 2)
+        "16x16x16": 8}                               # v_mfma_f32_16x16x16_{bf16,f16}: the smallest in-block MFMA -> VALU distance the compiler emits anywhere in the
+                                                     # library is 8 (measured over all 219 kernels, round 3); other types: 11, generously
 
 
 def regs(tok):
