@@ -334,6 +334,11 @@ def test_engine_on_a_non_current_device_or_stream():
     ("f32x3", (9100,), (9103,)),          # 4-wave analysis plane tile
     ("f32x3", (9301,), (9300,)),          # weight gradients on the in-kernel three-plane split
     ("bf16", (9401,), (9400,)),           # one-plane (pre-converted bf16) bases on the plane kernel
+    ("f32", (9950,), (9951,)),            # synthesis frames / data gradient on gemm_kernel<2, ...> instead of the 128 x 128 NT tiles
+    ("f32", (9500,), (9501,)),            # weight gradients on gemm_kernel<3, ...> instead of the 128 x 128 TN tiles
+    ("bf16_all", (9693,), (9690,)),       # 16-bit analysis forward + data gradient on the LDS-DMA kernel (producer / consumer waves)
+    ("f16_all", (9693,), (9690,)),
+    ("bf16_all", (9600,), (9601,)),       # converting GEMM (gemm_half_kernel) instead of the pre-rounded 16-bit operand pipeline
 ])
 def test_alternative_code_paths_agree(dtype, codes, restore):
     """The variants kept behind st_set_tuning (measured slower, or experiments) compute the same thing as the default path: loss and
