@@ -1785,6 +1785,7 @@ extern "C" int st_dp_train_step(st_dp* p, const st_dims* d, float* params, float
     Layout L; ST_TRY(make_layout(d, &L));
     ST_REQ(stage, "st_dp_train_step: null staging buffer");
     ST_REQ(params && grads && x && knobs && y_true && ws, "st_dp_train_step: null pointer");
+    const float gs = (1.0f / (float)p->world) / loss_scale_of(d);          // 1/world and the loss scale leave the gradient together
     // Three exchanges, each issued the moment its gradients are final (the communicator stream orders them):
     //   synthesis bases (8.4 MB)  -- after their weight-gradient GEMM, BEFORE the autoencoder backward: hidden behind the longest
     //                                kernels of the step (autoencoder backward + polar backward + analysis weight gradient);
@@ -1798,14 +1799,26 @@ extern "C" int st_dp_train_step(st_dp* p, const st_dims* d, float* params, float
         const float reg_coef = loss_scale_of(d) * (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);
         ST_TRY(backward_syn(d, L, grads, w, stream));                                  // slab reduce NOT deferred: the tensors are final here
         ST_TRY(st_dp_allreduce(p, grads + L.offs[2], L.offs[4] - L.offs[2], stream));
+        // The clip norm is that of the REDUCED, 1/world-scaled gradient.  The two ranges whose exchange is hidden get their |g| partials on the communicator
+        // stream right behind their collective (hidden as well); only the analysis rows' share is formed after the exposed collective, in the pass that
+        // copies them back (unstage_l1_kernel).  Same kernels, same order, same data on every rank: the norm is bit-identical across ranks.
+        hipLaunchKernelGGL(stm::l1_partial_kernel, dim3(st_norm_partials(d)), dim3(256), 0, p->cs, grads + L.offs[2], L.offs[4] - L.offs[2], gs, w.norm_s);
         ST_TRY(backward_ae(d, L, params, grads, knobs, nullptr, nullptr, reg_coef, w, stream));
         ST_TRY(st_dp_allreduce(p, grads + L.offs[4], L.total - L.offs[4], stream));
+        if (d->clip_all) hipLaunchKernelGGL(stm::l1_partial_kernel, dim3(NORM_E_PARTIALS), dim3(256), 0, p->cs, grads + L.n_stft, L.total - L.n_stft, gs, w.norm_e);
     }
     ST_TRY(st_loss_backward_p2_staged(d, grads, stage, x, ws, scalars, stream));
     ST_TRY(st_dp_allreduce(p, stage, (int64_t)2 * d->F * d->N, stream));
     ST_TRY(st_dp_sync(p, stream));
-    ST_TRY(st_unstage_analysis(d, grads, stage, stream));
-    return st_dp_clip_adam(d, params, grads, m, v, ws, scalars, 1.0f / (float)p->world, lr, beta1, beta2, eps, step, stream);
+    {
+        WS w; carve(d, ws, &w);
+        const int np = st_norm_partials(d);
+        hipLaunchKernelGGL(stm::unstage_l1_kernel, dim3(2 * d->F), dim3(256), 0, st_stream(stream), stage, grads + L.offs[0], grads + L.offs[1], d->F, d->N, gs, w.norm_a, np);
+        ST_LAUNCHED("unstage_l1");
+        stm::FinArgs f = fin_args(d, w.loss_p, w.reg_p, w.norm_a, w.norm_s, 1.0f);
+        if (d->clip_all) { f.norm_e = w.norm_e; f.n_ne = NORM_E_PARTIALS; }
+        return clip_adam_impl(params, grads, m, v, L.total, d->clip_all ? L.total : L.n_stft, scalars, gs, lr, beta1, beta2, eps, step, &f, stream);
+    }
 }
 
 

@@ -392,6 +392,29 @@ l1_partial_kernel(const float* __restrict__ g, int64_t n, float scale, float* __
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
+// Data-parallel tail: the all-reduced live analysis rows [2F][N] go back into the two gradient tensors AND their scaled |g| sums are formed in the
+// same pass (one partial per row; slots >= 2F of the fixed-count partial array are zeroed by the last block) -- was two device copies + a norm
+// pass over the whole STFT range, all of it exposed behind the last collective.
+__global__ void __launch_bounds__(256)
+unstage_l1_kernel(const float* __restrict__ stage, float* __restrict__ gRe, float* __restrict__ gIm, const int F, const int N, const float scale,
+                  float* __restrict__ partial, const int n_partial)
+{
+    __shared__ float red[4];
+    const int row = blockIdx.x;                       // 0 .. 2F-1
+    const bool is_im = row >= F;
+    float* dst = (is_im ? gIm : gRe) + (size_t)(is_im ? row - F : row) * N;
+    const float* src = stage + (size_t)row * N;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < N / 4; i += 256) {
+        const float4 v = reinterpret_cast<const float4*>(src)[i];
+        reinterpret_cast<float4*>(dst)[i] = v;
+        a += fabsf(v.x * scale) + fabsf(v.y * scale) + fabsf(v.z * scale) + fabsf(v.w * scale);
+    }
+    const float tot = block_sum<4>(a, red);
+    if (threadIdx.x == 0) partial[row] = tot;
+    if (row == 2 * F - 1) for (int j = 2 * F + threadIdx.x; j < n_partial; j += 256) partial[j] = 0.f;
+}
+
 // ---------------------------------------------------------------- per-wave AE gradient partial reduce
 // ws[nparts][2][PG] -> g_m[PG], g_p[PG].  Block = 64 columns x 4 partial-lanes; 8 loads in flight per thread.
 __device__ __forceinline__ void ae_grad_reduce_block(const float* __restrict__ ws, const int nparts, const int PG,
