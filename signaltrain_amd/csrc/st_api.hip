@@ -193,6 +193,7 @@ static int g_frs_nt = 1;     // synthesis frames GEMM against the transposed fol
 static int g_xt = 0;       // 1: M/N-contiguous operands staged k-quad-major (st_gemm.h XT; st_set_tuning(7001), diagnostics).  MEASURED SLOWER at B=256 although
                            // conflict-free with a third fewer LDS cycles: analysis wgrad 173 vs 145 us, synthesis frames 63 vs 60 us (16 more prefetch
                            // registers -> 4 instead of 4.5 waves per SIMD, and 16 v_mov per micro-tile): the k-major staging stays the default
+static int g_wide_pair = 1;  // wide geometries, 16-bit: the layer-1 / layer-9 GEMMs of the two autoencoders as ONE launch each (gemm_half_pair_kernel); 0 = two launches (st_set_tuning(9960 + n), diagnostics)
 static int g_wide_dvp = 1;   // wide geometries: layer-1 data gradient (+ polar backward) as one fused kernel; 0 = two GEMMs + polar_bwd (st_set_tuning(9900), diagnostics)
 static int g_nt_mi = 0;     // fp32 NT x NT GEMMs with 64 x 96 wave tiles (MI = 2): 0 off; bit 0 analysis forward <4,16,2>, bit 1 <2,32,2>, bit 2 frames / dgrad <2,16,2>  (st_set_tuning(9800 + n), experiments)
 static int g_an_bk = 32;   // k-tile depth of the analysis forward GEMM (see ST_GEMM_AN)
@@ -202,7 +203,8 @@ static int g_wsplit_max = 16, g_wsplit_div = 200, g_an_waves = 4, g_syn_split = 
 extern "C" int st_set_tuning(int bk)
 {
     if (bk >= 96800 && bk < 96928) { g_g16_abl = bk - 96800; return ST_OK; }      // timing-only ablations of the 16-bit analysis GEMM (bits 3..5: its k-loop)
-    if (bk >= 9950) { g_nt128 = bk - 9950; return ST_OK; }
+    if (bk >= 9960) { g_wide_pair = bk - 9960; return ST_OK; }
+    if (bk >= 9950 && bk < 9960) { g_nt128 = bk - 9950; return ST_OK; }
     if (bk >= 9900) { g_wide_dvp = bk - 9900; return ST_OK; }
     if (bk >= 9800) { g_nt_mi = bk - 9800; return ST_OK; }
     if (bk >= 9700) { g_g16_split = bk - 9700; return ST_OK; }
@@ -639,6 +641,11 @@ extern "C" int st_synthesis_wgrad(const st_dims* d, const float* AA, const float
 static inline int wide_half_type(const st_dims* d, int R) { return R % 32 == 0 ? ae_ht(d->prec) : 0; }
 #define ST_WGEMM(...) do { if (wide_ht == 1) stg::launch_half<2, 1>(__VA_ARGS__); else if (wide_ht == 2) stg::launch_half<2, 2>(__VA_ARGS__); \
                            else stg::launch<2, 16>(__VA_ARGS__, g_dbg); } while (0)
+// the same GEMM for both autoencoders: ONE launch in the 16-bit configurations (gemm_half_pair_kernel), two on the fp32 kernel
+#define ST_WGEMM_PAIR(A0_, B0_, E0_, A1_, B1_, E1_, M_, N_, K_, NS_, S_) do { \
+        if (wide_ht == 1 && g_wide_pair) stg::launch_half_pair<2, 1>(A0_, B0_, E0_, A1_, B1_, E1_, M_, N_, K_, NS_, S_); \
+        else if (wide_ht == 2 && g_wide_pair) stg::launch_half_pair<2, 2>(A0_, B0_, E0_, A1_, B1_, E1_, M_, N_, K_, NS_, S_); \
+        else { ST_WGEMM(A0_, B0_, E0_, M_, N_, K_, NS_, S_); ST_WGEMM(A1_, B1_, E1_, M_, N_, K_, NS_, S_); } } while (0)
 static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, const float* phs, const float* knobs,
                        const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA, float* reg_partial,
                        WideWS& w, void* stream, unsigned short* AA16)
@@ -665,9 +672,15 @@ static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, cons
                        d->B, T, F, FP, d->K);
     ST_LAUNCHED("ae_wide_in");
     // layers 1..8: GEMM for layer 1 (K = T); layers 2..8 either one fused kernel for both nets (default) or seven more GEMMs
-    for (int a = 0; a < 2; ++a) {
+    if (g_wide_fused) {
+        stg::PlainNT al0{w.W1p[0], out[0], Tp, Tp, id}, al1{w.W1p[1], out[0], Tp, Tp, id};
+        stg::PlainTN bl0{w.V[0], in[0], R, R, id}, bl1{w.V[1], in[0], R, R, id};
+        stw::ActStore ep0{w.H[0][0], ae_m + L.go.b[0], out[0], R, FP, F}, ep1{w.H[1][0], ae_p + L.go.b[0], out[0], R, FP, F};
+        ST_WGEMM_PAIR(al0, bl0, ep0, al1, bl1, ep1, out[0], R, Tp, 1, s);
+    }
+    else for (int a = 0; a < 2; ++a) {
         const float* ae = a ? ae_p : ae_m;
-        for (int l = 0; l < (g_wide_fused ? 1 : 8); ++l) {
+        for (int l = 0; l < 8; ++l) {
             const float* Wl = l == 0 ? w.W1p[a] : (l == 4 ? w.W5p[a] : ae + L.go.w[l]);
             const int kp = l == 0 ? Tp : (l == 4 ? 32 : in[l]);                       // padded reduction length = row pitch of Wl
             const float* Hin = l == 0 ? w.V[a] : w.H[a][l - 1];
@@ -685,12 +698,12 @@ static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, cons
         switch (wide_ht) { case 1: ST_AE_INNER_FWD(1); break; case 2: ST_AE_INNER_FWD(2); break; default: ST_AE_INNER_FWD(0); }
 #undef ST_AE_INNER_FWD
     }
-    for (int a = 0; a < 2; ++a) {
-        const float* ae = a ? ae_p : ae_m;
-        stg::PlainNT al{ae + L.go.w[8], OT, 64, 64, id};
-        stg::PlainTN bl{w.H[a][7], 64, R, R, id};
-        stw::OutStore ep{w.E9[a], a ? phs_hat : mag_hat, w.V[a] + (size_t)(T - OT) * R, ae + L.go.b[8], OT, R, FP, F, a};
-        ST_WGEMM(al, bl, ep, OT, R, 64, 1, s);
+    {
+        stg::PlainNT al0{ae_m + L.go.w[8], OT, 64, 64, id}, al1{ae_p + L.go.w[8], OT, 64, 64, id};
+        stg::PlainTN bl0{w.H[0][7], 64, R, R, id}, bl1{w.H[1][7], 64, R, R, id};
+        stw::OutStore ep0{w.E9[0], mag_hat, w.V[0] + (size_t)(T - OT) * R, ae_m + L.go.b[8], OT, R, FP, F, 0};
+        stw::OutStore ep1{w.E9[1], phs_hat, w.V[1] + (size_t)(T - OT) * R, ae_p + L.go.b[8], OT, R, FP, F, 1};
+        ST_WGEMM_PAIR(al0, bl0, ep0, al1, bl1, ep1, OT, R, 64, 1, s);
     }
     ST_LAUNCHED("ae_wide_fwd");
     if (AA) {
@@ -712,6 +725,19 @@ static void wide_wgrad(const st_dims* d, WideWS& w, int a, int l, const int* out
     stg::PlainNT bl{Hin, in[l] + 1, R, R, id};
     stg::StoreC ep{w.slabs + (size_t)a * w.nsplit * w.SL + w.so[l], out[l], in[l] + 1, in[l] + 1, w.SL, id};
     ST_WGEMM(al, bl, ep, out[l], in[l] + 1, R, w.nsplit, s);
+}
+
+// ... of both nets in one launch: net 1's slabs follow net 0's (slab z of the pair launch = net * nsplit + slice), so both epilogues share one origin
+static void wide_wgrad_pair(const st_dims* d, WideWS& w, int l, const int* out, const int* in, hipStream_t s, const int wide_ht)
+{
+    const int R = (int)w.R;
+    const stg::RowMap id = stg::all_frames(1);
+    stg::PlainNT al0{w.DA[0][l], out[l], R, R, id}, al1{w.DA[1][l], out[l], R, R, id};
+    stg::PlainNT bl0{l == 0 ? w.V[0] : w.H[0][l - 1], in[l] + 1, R, R, id}, bl1{l == 0 ? w.V[1] : w.H[1][l - 1], in[l] + 1, R, R, id};
+    stg::StoreC ep0{w.slabs + w.so[l], out[l], in[l] + 1, in[l] + 1, w.SL, id};
+    stg::StoreC ep1 = ep0;
+    if (!(g_wide_pair && wide_ht)) ep1.out = w.slabs + (size_t)w.nsplit * w.SL + w.so[l];      // two launches: each with its own z = 0 .. nsplit - 1
+    ST_WGEMM_PAIR(al0, bl0, ep0, al1, bl1, ep1, out[l], in[l] + 1, R, w.nsplit, s);
 }
 
 // Where the gradient w.r.t. the autoencoder inputs goes on the fused path: straight through the polar backward into d G (wide_dv_polar_kernel)
@@ -764,7 +790,13 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
     tab.so[9] = w.so[9];
     if (g_wide_fused) {
         // layer 9 as GEMMs, layers 8..2 in one fused kernel (both nets), layer 1 as GEMMs
-        for (int a = 0; a < 2; ++a) { wide_wgrad(d, w, a, 8, out, in, s, wide_ht); dgrad(a, 8, true); }
+        wide_wgrad_pair(d, w, 8, out, in, s, wide_ht);
+        {   // d H8 = W9^T d A9 of both nets (the fused kernel applies ELU')
+            stg::PlainTN al0{ae_m + L.go.w[8], out[8], in[8], in[8], id}, al1{ae_p + L.go.w[8], out[8], in[8], in[8], id};
+            stg::PlainTN bl0{w.DA[0][8], out[8], R, R, id}, bl1{w.DA[1][8], out[8], R, R, id};
+            stg::StoreC ep0{w.DA[0][7], in[8], R, R, 0, id}, ep1{w.DA[1][7], in[8], R, R, 0, id};
+            ST_WGEMM_PAIR(al0, bl0, ep0, al1, bl1, ep1, in[8], R, out[8], 1, s);
+        }
         {
             const size_t lds = (size_t)sta::ae_bwd_lds_floats(AE_BWD_NW) * sizeof(float);
             const int grid = ae_bwd_grid(d);
@@ -778,8 +810,8 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
             hipLaunchKernelGGL(stm::ae_grad_reduce_kernel, dim3((L.PG + 63) / 64, 2), dim3(256), 0, s, w.inner_ws, grid, L.PG, g_m, g_p);
         }
         for (int l = 1; l < 8; ++l) tab.out[l] = 0;                 // the finish kernel only scatters layers 1 and 9
+        wide_wgrad_pair(d, w, 0, out, in, s, wide_ht);
         for (int a = 0; a < 2; ++a) {
-            wide_wgrad(d, w, a, 0, out, in, s, wide_ht);
             if (!g_wide_dvp) dgrad(a, 0, false);
             hipLaunchKernelGGL(stw::wide_grad_finish_kernel, dim3((w.so[9] + 63) / 64), dim3(256), 0, s,
                                w.slabs + (size_t)a * w.nsplit * w.SL, w.nsplit, w.SL, tab, a ? g_p : g_m);

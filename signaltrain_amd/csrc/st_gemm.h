@@ -680,9 +680,12 @@ __device__ __forceinline__ void st_split3(const float x, const float y, const fl
 #ifndef ST_SPLIT_VALU_PER_MFMA
 #define ST_SPLIT_VALU_PER_MFMA 5
 #endif
+// The kernel proper is gemm_half_body (tile coordinates passed in): gemm_half_kernel runs it for one operand set, gemm_half_pair_kernel for TWO
+// independent GEMMs of the same shape in one launch (round 3: the layer-1 / layer-9 GEMMs of the two autoencoders on the wide path are 64 x 33.8 k-output
+// launches that fill a third of the chip and cost 10-28 us each mostly in launch, ramp and drain: ten launches -> five).
 template <int WAVES_M, int HT, int PL, int BKH, class AL, class BL, class EPI>
-__global__ void __launch_bounds__(WAVES_M * 64)
-gemm_half_kernel(const AL al, const BL bl, const EPI epi, const int K, const int ksplit)
+__device__ __forceinline__ void
+gemm_half_body(const AL& al, const BL& bl, const EPI& epi, const int K, const int ksplit, const int tbx, const int tby, const int tbz)
 {
     static_assert(PL == 1 || (PL == 3 && HT == 1), "the split needs the fp32 exponent range: bfloat16 planes only");
     constexpr int BM = 32 * WAVES_M, NT = 64 * WAVES_M;
@@ -699,7 +702,6 @@ gemm_half_kernel(const AL al, const BL bl, const EPI epi, const int K, const int
     unsigned short* const dump = half_lds + 2 * PL * (A_SZ + B_SZ) + 4 * threadIdx.x;   // threads without an item store there: no branch in the loop body
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int tbx, tby, tbz; xcd_tile(tbx, tby, tbz);
     const int m_blk = tby * BM, n_blk = tbx * BN;
     const int k_begin = tbz * ksplit;
     const int k_end = (k_begin + ksplit < K) ? k_begin + ksplit : K;
@@ -968,6 +970,38 @@ gemm_half_kernel(const AL al, const BL bl, const EPI epi, const int K, const int
         }
     }
     epi(m_blk + wave * 32, n_blk, acc);
+}
+template <int WAVES_M, int HT, int PL, int BKH, class AL, class BL, class EPI>
+__global__ void __launch_bounds__(WAVES_M * 64)
+gemm_half_kernel(const AL al, const BL bl, const EPI epi, const int K, const int ksplit)
+{
+    int tbx, tby, tbz; xcd_tile(tbx, tby, tbz);
+    gemm_half_body<WAVES_M, HT, PL, BKH>(al, bl, epi, K, ksplit, tbx, tby, tbz);
+}
+// z-slices [0, nzh) belong to the first GEMM, [nzh, 2 nzh) to the second.  An epilogue that derives its split-K slab from the launch's z index (StoreC,
+// through xcd_tile) sees z = nzh + slice for the second GEMM: the launcher hands that epilogue an output pointer moved back by nzh slabs.
+template <int WAVES_M, int HT, int PL, int BKH, class AL, class BL, class EPI>
+__global__ void __launch_bounds__(WAVES_M * 64)
+gemm_half_pair_kernel(const AL al0, const BL bl0, const EPI epi0, const AL al1, const BL bl1, const EPI epi1, const int K, const int ksplit, const int nzh)
+{
+    int tbx, tby, tbz; xcd_tile(tbx, tby, tbz);
+    if (tbz < nzh) gemm_half_body<WAVES_M, HT, PL, BKH>(al0, bl0, epi0, K, ksplit, tbx, tby, tbz);
+    else gemm_half_body<WAVES_M, HT, PL, BKH>(al1, bl1, epi1, K, ksplit, tbx, tby, tbz - nzh);
+}
+
+template <int WAVES_M, int HT = 1, int PL = 1, int BKH = (PL == 3 ? 16 : 32), class AL, class BL, class EPI>
+static inline int launch_half_pair(const AL& al0, const BL& bl0, const EPI& epi0, const AL& al1, const BL& bl1, const EPI& epi1,
+                                   int M, int Nc, int K, int nsplit, hipStream_t s)
+{
+    constexpr int BM = 32 * WAVES_M;
+    constexpr size_t lds = ((size_t)2 * PL * (BM + BN) * (BKH + 8) + (PL == 3 ? 4 * 64 * WAVES_M : 0)) * sizeof(unsigned short);
+    int ksplit = K;
+    if (nsplit > 1) ksplit = st_round_up((K + nsplit - 1) / nsplit, 32);
+    const int nzh = nsplit > 1 ? nsplit : 1;
+    dim3 grid((Nc + BN - 1) / BN, (M + BM - 1) / BM, 2 * nzh);
+    if (lds > 65536) { const int rc = ::ensure_dyn_lds((const void*)gemm_half_pair_kernel<WAVES_M, HT, PL, BKH, AL, BL, EPI>, "gemm_half_pair_kernel"); if (rc) return rc; }
+    hipLaunchKernelGGL((gemm_half_pair_kernel<WAVES_M, HT, PL, BKH, AL, BL, EPI>), grid, dim3(WAVES_M * 64), lds, s, al0, bl0, epi0, al1, bl1, epi1, K, ksplit, nzh);
+    return 0;
 }
 
 template <int WAVES_M, int HT = 1, int PL = 1, int BKH = (PL == 3 ? 16 : 32), class AL, class BL, class EPI>
