@@ -271,28 +271,50 @@ __global__ void pad_rows_kernel(const float* __restrict__ src, int rows, int col
     dst[i] = c < cols ? src[r * cols + c] : 0.f;
 }
 
+// The zero-padded copies of W_1 ([64][Tp]) and W_5 ([16][32]) of both autoencoders (was four pad_rows launches, then one of its own, now extra
+// blocks of wide_in_kernel)
+struct PadJobs { const float* src[4]; float* dst[4]; int rows[4], cols[4], pitch[4], blk0[5]; };
+__device__ __forceinline__ void pad_rows4_block(const PadJobs& j, const int blk)
+{
+    int q = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) q += blk >= j.blk0[k];
+    const int i = (blk - j.blk0[q]) * 256 + threadIdx.x;
+    if (i >= j.rows[q] * j.pitch[q]) return;
+    const int r = i / j.pitch[q], c = i - r * j.pitch[q];
+    j.dst[q][i] = c < j.cols[q] ? j.src[q][r * j.cols[q] + c] : 0.f;
+}
 // Inputs in the feature-major layout: V[a][t][b*FP + f] = (mag | phs)[b][t][f]; knob rows 16.. of the layer-5 input.
-// grid (T + K, B)
+// Flattened over (row, window, quad of bins): one thread = four bins of both nets = eight 4-byte loads (the [B][T][F] rows are 4-byte aligned
+// only) and two 16-byte stores (FP % 4 == 0).  Round 3: as one block per (row, window) with a 256-stride loop over 528 bins -- the third
+// trip 16 lanes wide -- this copy took 23 us for 91 MB.  Blocks [n_copy, n_copy + n_pad): the weight padding jobs.
 __global__ void __launch_bounds__(256)
 wide_in_kernel(const float* __restrict__ mag, const float* __restrict__ phs, const float* __restrict__ knobs,
                float* __restrict__ Vm, float* __restrict__ Vp, float* __restrict__ H4Km, float* __restrict__ H4Kp,
-               int B, int T, int F, int FP, int K)
+               int B, int T, int F, int FP, int K, int n_copy, const PadJobs pj)
 {
-    const int row = blockIdx.x, b = blockIdx.y;
+    if ((int)blockIdx.x >= n_copy) { pad_rows4_block(pj, (int)blockIdx.x - n_copy); return; }
+    const unsigned Q = (unsigned)FP / 4, idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (unsigned)(T + K) * (unsigned)B * Q) return;
+    const unsigned rb = idx / Q, j = idx - rb * Q, row = rb / (unsigned)B, b = rb - row * (unsigned)B;
     const size_t R = (size_t)B * FP;
-    if (row < T) {
+    const int f0 = 4 * (int)j;
+    float4 vm, vp;
+    float* dm; float* dp;
+    if ((int)row < T) {
         const float* sm = mag + ((size_t)b * T + row) * F;
         const float* sp = phs + ((size_t)b * T + row) * F;
-        float* dm = Vm + (size_t)row * R + (size_t)b * FP;
-        float* dp = Vp + (size_t)row * R + (size_t)b * FP;
-        for (int f = threadIdx.x; f < FP; f += 256) { const bool ok = f < F; dm[f] = ok ? sm[f] : 0.f; dp[f] = ok ? sp[f] : 0.f; }
+        vm = make_float4(f0 < F ? sm[f0] : 0.f, f0 + 1 < F ? sm[f0 + 1] : 0.f, f0 + 2 < F ? sm[f0 + 2] : 0.f, f0 + 3 < F ? sm[f0 + 3] : 0.f);
+        vp = make_float4(f0 < F ? sp[f0] : 0.f, f0 + 1 < F ? sp[f0 + 1] : 0.f, f0 + 2 < F ? sp[f0 + 2] : 0.f, f0 + 3 < F ? sp[f0 + 3] : 0.f);
+        dm = Vm + (size_t)row * R + (size_t)b * FP; dp = Vp + (size_t)row * R + (size_t)b * FP;
     } else {
-        const int k = row - T;
+        const int k = (int)row - T;
         const float v = knobs[b * K + k];
-        float* dm = H4Km + (size_t)(16 + k) * R + (size_t)b * FP;
-        float* dp = H4Kp + (size_t)(16 + k) * R + (size_t)b * FP;
-        for (int f = threadIdx.x; f < FP; f += 256) { const float x = f < F ? v : 0.f; dm[f] = x; dp[f] = x; }
+        vm = make_float4(f0 < F ? v : 0.f, f0 + 1 < F ? v : 0.f, f0 + 2 < F ? v : 0.f, f0 + 3 < F ? v : 0.f); vp = vm;
+        dm = H4Km + (size_t)(16 + k) * R + (size_t)b * FP; dp = H4Kp + (size_t)(16 + k) * R + (size_t)b * FP;
     }
+    reinterpret_cast<float4*>(dm)[j] = vm;
+    reinterpret_cast<float4*>(dp)[j] = vp;
 }
 
 // nn_proc.py:325-326 (polar -> rectangular) into the KP-pitched synthesis operand + partial sums of the L1 term
@@ -303,25 +325,26 @@ wide_polar_out_kernel(const float* __restrict__ mag_hat, const float* __restrict
                       unsigned short* __restrict__ AA16 = nullptr, int aa_ht = 0)      // 16-bit GEMM configurations: see sta::ae_fwd_kernel
 {
     __shared__ float red[256];
-    const size_t n = (size_t)B * OT * FP;
+    const unsigned n = (unsigned)B * (unsigned)OT * (unsigned)FP;          // < 2^30 (host check): 32-bit index arithmetic (the size_t divisions were most of this kernel)
     float reg = 0.f;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
-        const size_t ro = idx / FP; const int f = (int)(idx - ro * FP);
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < n; idx += gridDim.x * 256u) {
+        const unsigned ro = idx / (unsigned)FP; const int f = (int)(idx - ro * (unsigned)FP);
         float re = 0.f, im = 0.f;
         if (f < F) {
-            const float mh = mag_hat[ro * F + f], ph = phs_hat[ro * F + f];
-            float sn, cs; sincosf(ph, &sn, &cs);
+            const float mh = mag_hat[(size_t)ro * F + f], ph = phs_hat[(size_t)ro * F + f];
+            float sn, cs; st_sincos(ph, sn, cs);                             // as sta::ae_fwd_kernel
             re = mh * cs; im = mh * sn;
             reg += fabsf(mh * expf(expfac * (float)f));
         }
-        if (AA16) { AA16[ro * KP + f] = st_to_h16(re, aa_ht); AA16[ro * KP + FP + f] = st_to_h16(im, aa_ht); }
-        else { AA[ro * KP + f] = re; AA[ro * KP + FP + f] = im; }
+        if (AA16) { AA16[(size_t)ro * KP + f] = st_to_h16(re, aa_ht); AA16[(size_t)ro * KP + FP + f] = st_to_h16(im, aa_ht); }
+        else { AA[(size_t)ro * KP + f] = re; AA[(size_t)ro * KP + FP + f] = im; }
     }
     red[threadIdx.x] = reg; __syncthreads();
     for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
     if (reg_partial && threadIdx.x == 0) reg_partial[blockIdx.x] = red[0];
 }
 
+struct OnesRows { float* p[18]; };
 // Gradient entering the two output layers (same algebra as the d-out stage of sta::ae_bwd_kernel): from d(AA) (split-K
 // slabs of the synthesis dgrad, dead frames = 0), the L1 term and an optional upstream d(mag_hat).
 __global__ void __launch_bounds__(256)
@@ -329,23 +352,30 @@ wide_dout_kernel(const float* __restrict__ dAA, int nslab, size_t slab, const fl
                  const float* __restrict__ E9m, const float* __restrict__ E9p, const float* __restrict__ mag_tail,
                  const float* __restrict__ g_mag_hat, float reg_coef, float expfac,
                  float* __restrict__ DA9m, float* __restrict__ DA9p, float* __restrict__ TLm, float* __restrict__ TLp,
-                 int B, int OT, int F, int FP, int KP, int to_lo, int to_hi)
+                 int B, int OT, int F, int FP, int KP, int to_lo, int to_hi, int n_main, const OnesRows ones)
 {
-    const size_t n = (size_t)B * OT * FP, R = (size_t)B * FP;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
-        const size_t ro = idx / FP; const int f = (int)(idx - ro * FP);
-        const int b = (int)(ro / OT), to = (int)(ro - (size_t)b * OT);
+    if ((int)blockIdx.x >= n_main) {             // the rows of ones the bias gradients ride on (was a launch of its own): block = (buffer, window)
+        const int q = (int)blockIdx.x - n_main, buf = q / B, b = q - buf * B;
+        float* d = ones.p[buf] + (size_t)b * FP;
+        for (int f = threadIdx.x; f < FP; f += 256) d[f] = f < F ? 1.f : 0.f;
+        return;
+    }
+    const unsigned n = (unsigned)B * (unsigned)OT * (unsigned)FP;          // < 2^30 (host check)
+    const size_t R = (size_t)B * FP;
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < n; idx += (unsigned)n_main * 256u) {
+        const unsigned ro = idx / (unsigned)FP; const int f = (int)(idx - ro * (unsigned)FP);
+        const int b = (int)(ro / (unsigned)OT), to = (int)(ro - (unsigned)b * (unsigned)OT);
         const size_t ix = (size_t)to * R + (size_t)b * FP + f;
         float d9m = 0.f, d9p = 0.f, tm = 0.f, tp = 0.f;
         if (f < F) {
             float gre = 0.f, gim = 0.f;
             if (to >= to_lo && to <= to_hi)
-                for (int z = 0; z < nslab; ++z) { gre += dAA[z * slab + ro * KP + f]; gim += dAA[z * slab + ro * KP + FP + f]; }
-            const float mh = mag_hat[ro * F + f], ph = phs_hat[ro * F + f];
-            float sn, cs; sincosf(ph, &sn, &cs);
+                for (int z = 0; z < nslab; ++z) { gre += dAA[z * slab + (size_t)ro * KP + f]; gim += dAA[z * slab + (size_t)ro * KP + FP + f]; }
+            const float mh = mag_hat[(size_t)ro * F + f], ph = phs_hat[(size_t)ro * F + f];
+            float sn, cs; st_sincos(ph, sn, cs);                             // as the d-out stage of sta::ae_bwd_kernel
             const float wf = expf(expfac * (float)f);
             const float sg = mh > 0.f ? 1.f : (mh < 0.f ? -1.f : 0.f);
-            const float dmh = gre * cs + gim * sn + reg_coef * sg * wf + (g_mag_hat ? g_mag_hat[ro * F + f] : 0.f);
+            const float dmh = gre * cs + gim * sn + reg_coef * sg * wf + (g_mag_hat ? g_mag_hat[(size_t)ro * F + f] : 0.f);
             const float em = E9m[ix], ep = E9p[ix];
             d9m = dmh * mag_tail[ix] * elu_grad_from_out(em);
             tm = dmh * em;
@@ -359,20 +389,15 @@ wide_dout_kernel(const float* __restrict__ dAA, int nslab, size_t slab, const fl
 
 // The bias gradient rides in the weight-gradient GEMM: every layer input buffer carries one extra row of ones (on real
 // bins), so column IN of the [OUT][IN + 1] product is the row sum of dA.  grid (18, B): the 9 input buffers of both nets.
-struct OnesRows { float* p[18]; };
-__global__ void __launch_bounds__(256)
-wide_ones_kernel(const OnesRows rows, int FP, int F)
-{
-    float* d = rows.p[blockIdx.x] + (size_t)blockIdx.y * FP;
-    for (int f = threadIdx.x; f < FP; f += 256) d[f] = f < F ? 1.f : 0.f;
-}
 
 // Sum of the split-K slabs of all nine weight-gradient GEMMs of one autoencoder (fixed slab order) scattered into the
 // packed gradient block: slab layout per layer [OUT][IN + 1] at so[l]; column IN is the bias gradient.
 struct GradTab { int so[10]; int out[9]; int in[9]; int gw[9]; int gb[9]; };
 __global__ void __launch_bounds__(256)
-wide_grad_finish_kernel(const float* __restrict__ slabs, int nslab, size_t SL, const GradTab tab, float* __restrict__ g)
+wide_grad_finish_kernel(const float* __restrict__ slabs0, int nslab, size_t SL, const GradTab tab, float* __restrict__ g0, float* __restrict__ g1)
 {
+    const float* slabs = slabs0 + (size_t)blockIdx.y * nslab * SL;      // net y: its slabs follow net 0's
+    float* g = blockIdx.y ? g1 : g0;
     // block = 64 slab elements x 4 slab lanes, 8 loads in flight per thread (one thread walking 256 slabs four at a time was 30 us of pure
     // latency per net at the 65536-sample window); the four lanes are added in a fixed order
     __shared__ float red[4][64];
@@ -400,20 +425,6 @@ wide_grad_finish_kernel(const float* __restrict__ slabs, int nslab, size_t SL, c
     s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
     const int o = e / n1, i = e - o * n1;
     if (i < tab.in[l]) g[tab.gw[l] + o * tab.in[l] + i] = s; else g[tab.gb[l] + o] = s;
-}
-
-// The zero-padded copies of W_1 ([64][Tp]) and W_5 ([16][32]) of both autoencoders in ONE launch (was four pad_rows launches, 5 us each)
-struct PadJobs { const float* src[4]; float* dst[4]; int rows[4], cols[4], pitch[4], blk0[5]; };
-__global__ void __launch_bounds__(256)
-pad_rows4_kernel(const PadJobs j)
-{
-    int q = 0;
-#pragma unroll
-    for (int k = 1; k < 4; ++k) q += (int)blockIdx.x >= j.blk0[k];
-    const int i = ((int)blockIdx.x - j.blk0[q]) * 256 + threadIdx.x;
-    if (i >= j.rows[q] * j.pitch[q]) return;
-    const int r = i / j.pitch[q], c = i - r * j.pitch[q];
-    j.dst[q][i] = c < j.cols[q] ? j.src[q][r * j.cols[q] + c] : 0.f;
 }
 
 }  // namespace stw

@@ -666,10 +666,11 @@ static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, cons
             pj.blk0[2 * a + 1] = blk; blk += 2;
         }
         pj.blk0[4] = blk;
-        hipLaunchKernelGGL(stw::pad_rows4_kernel, dim3(blk), dim3(256), 0, s, pj);
+        ST_REQ(FP % 4 == 0 && (size_t)(T + d->K) * d->B * (FP / 4) < ((size_t)1 << 31), "wide autoencoder path: batch too large (B=%d)", d->B);
+        const int n_copy = (int)(((size_t)(T + d->K) * d->B * (FP / 4) + 255) / 256);
+        hipLaunchKernelGGL(stw::wide_in_kernel, dim3(n_copy + blk), dim3(256), 0, s, mag, phs, knobs, w.V[0], w.V[1], w.H[0][3], w.H[1][3],
+                           d->B, T, F, FP, d->K, n_copy, pj);
     }
-    hipLaunchKernelGGL(stw::wide_in_kernel, dim3(T + d->K, d->B), dim3(256), 0, s, mag, phs, knobs, w.V[0], w.V[1], w.H[0][3], w.H[1][3],
-                       d->B, T, F, FP, d->K);
     ST_LAUNCHED("ae_wide_in");
     // layers 1..8: GEMM for layer 1 (K = T); layers 2..8 either one fused kernel for both nets (default) or seven more GEMMs
     if (g_wide_fused) {
@@ -755,22 +756,20 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
     // forward state (activations + ELU outputs of layer 9): recomputed into the workspace unless the fused step's own
     // forward just left it there (same workspace, same layout); no user-visible outputs
     if (!have_fwd) ST_TRY(ae_wide_fwd(d, L, mag, phs, knobs, ae_m, ae_p, nullptr, nullptr, nullptr, nullptr, w, stream));
-    {
-        stw::OnesRows rows;
-        for (int a = 0; a < 2; ++a) {
-            rows.p[9 * a] = w.V[a] + (size_t)in[0] * R;
-            for (int j = 0; j < 8; ++j) rows.p[9 * a + 1 + j] = w.H[a][j] + (size_t)in[j + 1] * R;
-        }
-        hipLaunchKernelGGL(stw::wide_ones_kernel, dim3(18, d->B), dim3(256), 0, s, rows, FP, F);
+    stw::OnesRows rows;
+    for (int a = 0; a < 2; ++a) {
+        rows.p[9 * a] = w.V[a] + (size_t)in[0] * R;
+        for (int j = 0; j < 8; ++j) rows.p[9 * a + 1 + j] = w.H[a][j] + (size_t)in[j + 1] * R;
     }
     const float expfac = (float)(7.0 / d->F);
     const stg::RowMap ms = synth_live(d);
     {
         const size_t n = (size_t)d->B * OT * FP;
-        int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096;
-        hipLaunchKernelGGL(stw::wide_dout_kernel, dim3(grid), dim3(256), 0, s, dAA, st_synth_slabs(d), (size_t)d->B * OT * L.KP,
+        ST_REQ(n < ((size_t)1 << 30), "wide autoencoder path: batch too large (B=%d)", d->B);
+        int grid = (int)((n + 255) / 256); if (grid > 8192) grid = 8192;
+        hipLaunchKernelGGL(stw::wide_dout_kernel, dim3(grid + 18 * d->B), dim3(256), 0, s, dAA, st_synth_slabs(d), (size_t)d->B * OT * L.KP,
                            mag_hat, phs_hat, w.E9[0], w.E9[1], w.V[0] + (size_t)(T - OT) * R, g_mag_hat, reg_coef, expfac,
-                           w.DA[0][8], w.DA[1][8], w.TL[0], w.TL[1], d->B, OT, F, FP, L.KP, ms.t_lo, ms.t_lo + ms.Tv - 1);
+                           w.DA[0][8], w.DA[1][8], w.TL[0], w.TL[1], d->B, OT, F, FP, L.KP, ms.t_lo, ms.t_lo + ms.Tv - 1, grid, rows);
         ST_LAUNCHED("ae_wide_dout");
     }
     // data gradient through W_l into dA_{l-1} (layer 5: only the 16 code columns; the knobs take no gradient)
@@ -811,11 +810,8 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
         }
         for (int l = 1; l < 8; ++l) tab.out[l] = 0;                 // the finish kernel only scatters layers 1 and 9
         wide_wgrad_pair(d, w, 0, out, in, s, wide_ht);
-        for (int a = 0; a < 2; ++a) {
-            if (!g_wide_dvp) dgrad(a, 0, false);
-            hipLaunchKernelGGL(stw::wide_grad_finish_kernel, dim3((w.so[9] + 63) / 64), dim3(256), 0, s,
-                               w.slabs + (size_t)a * w.nsplit * w.SL, w.nsplit, w.SL, tab, a ? g_p : g_m);
-        }
+        if (!g_wide_dvp) for (int a = 0; a < 2; ++a) dgrad(a, 0, false);
+        hipLaunchKernelGGL(stw::wide_grad_finish_kernel, dim3((w.so[9] + 63) / 64, 2), dim3(256), 0, s, w.slabs, w.nsplit, w.SL, tab, g_m, g_p);
         if (g_wide_dvp) {
             stw::DvPolarArgs q;
             q.DA1m = w.DA[0][0]; q.DA1p = w.DA[1][0]; q.TLm = w.TL[0]; q.TLp = w.TL[1]; q.W1m = ae_m + L.go.w[0]; q.W1p = ae_p + L.go.w[0];
@@ -836,8 +832,8 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
     } else {
         for (int a = 0; a < 2; ++a) {
             for (int l = 8; l >= 0; --l) { wide_wgrad(d, w, a, l, out, in, s, wide_ht); dgrad(a, l, false); }
-            hipLaunchKernelGGL(stw::wide_grad_finish_kernel, dim3((w.so[9] + 63) / 64), dim3(256), 0, s,
-                               w.slabs + (size_t)a * w.nsplit * w.SL, w.nsplit, w.SL, tab, a ? g_p : g_m);
+            hipLaunchKernelGGL(stw::wide_grad_finish_kernel, dim3((w.so[9] + 63) / 64, 1), dim3(256), 0, s,
+                               w.slabs + (size_t)a * w.nsplit * w.SL, w.nsplit, w.SL, tab, a ? g_p : g_m, a ? g_p : g_m);
         }
     }
     ST_LAUNCHED("ae_wide_bwd");
