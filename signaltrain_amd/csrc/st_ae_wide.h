@@ -394,10 +394,37 @@ wide_dout_kernel(const float* __restrict__ dAA, int nslab, size_t slab, const fl
 // packed gradient block: slab layout per layer [OUT][IN + 1] at so[l]; column IN is the bias gradient.
 struct GradTab { int so[10]; int out[9]; int in[9]; int gw[9]; int gb[9]; };
 __global__ void __launch_bounds__(256)
-wide_grad_finish_kernel(const float* __restrict__ slabs0, int nslab, size_t SL, const GradTab tab, float* __restrict__ g0, float* __restrict__ g1)
+wide_grad_finish_kernel(const float* __restrict__ slabs0, int nslab, size_t SL, const GradTab tab, float* __restrict__ g0, float* __restrict__ g1,
+                        const int n_fin = 1 << 30, const float* __restrict__ red_ws = nullptr, const int red_parts = 0, const int PG = 0)
 {
-    const float* slabs = slabs0 + (size_t)blockIdx.y * nslab * SL;      // net y: its slabs follow net 0's
     float* g = blockIdx.y ? g1 : g0;
+    if ((int)blockIdx.x >= n_fin) {
+        // second role (fused wide path): the workgroup partials of the inner-layer kernel ws[nparts][2][PG] -> g, as stm::ae_grad_reduce_block, but ONLY
+        // the parameters of layers 2..8: the layer-1 / layer-9 entries of those partials are zeros and their gradients come from the slabs (first role)
+        __shared__ float rr[4][64];
+        const int col = threadIdx.x & 63, pl = threadIdx.x >> 6;
+        const int i = ((int)blockIdx.x - n_fin) * 64 + col;
+        auto in_range = [&](int lo, int n) { return i >= lo && i < lo + n; };
+        const bool mine = i < PG && !in_range(tab.gw[0], tab.out[0] * tab.in[0]) && !in_range(tab.gb[0], tab.out[0]) &&
+                          !in_range(tab.gw[8], tab.out[8] * tab.in[8]) && !in_range(tab.gb[8], tab.out[8]);
+        float s = 0.f;
+        if (mine) {
+            const float* base = red_ws + (size_t)blockIdx.y * PG + i;
+            const size_t stride = (size_t)2 * PG;
+            for (int p0 = pl; p0 < red_parts; p0 += 32) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int p = p0 + 4 * u; v[u] = p < red_parts ? base[(size_t)p * stride] : 0.f; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+        }
+        rr[pl][col] = s;
+        __syncthreads();
+        if (pl == 0 && mine) g[i] = (rr[0][col] + rr[1][col]) + (rr[2][col] + rr[3][col]);
+        return;
+    }
+    const float* slabs = slabs0 + (size_t)blockIdx.y * nslab * SL;      // net y: its slabs follow net 0's
     // block = 64 slab elements x 4 slab lanes, 8 loads in flight per thread (one thread walking 256 slabs four at a time was 30 us of pure
     // latency per net at the 65536-sample window); the four lanes are added in a fixed order
     __shared__ float red[4][64];

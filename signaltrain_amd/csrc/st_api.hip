@@ -787,6 +787,7 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
     stw::GradTab tab;
     for (int l = 0; l < 9; ++l) { tab.so[l] = w.so[l]; tab.out[l] = out[l]; tab.in[l] = in[l]; tab.gw[l] = L.go.w[l]; tab.gb[l] = L.go.b[l]; }
     tab.so[9] = w.so[9];
+    int inner_parts = 0;
     if (g_wide_fused) {
         // layer 9 as GEMMs, layers 8..2 in one fused kernel (both nets), layer 1 as GEMMs
         wide_wgrad_pair(d, w, 8, out, in, s, wide_ht);
@@ -806,12 +807,13 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
                                    w.DA[0][0], w.DA[1][0], w.inner_ws, d->B, T, OT, F, d->K, L.KP, 0, 0, 1, (size_t)0, 0); } while (0)
             switch (wide_ht) { case 1: ST_AE_INNER_BWD(1); break; case 2: ST_AE_INNER_BWD(2); break; default: ST_AE_INNER_BWD(0); }
 #undef ST_AE_INNER_BWD
-            hipLaunchKernelGGL(stm::ae_grad_reduce_kernel, dim3((L.PG + 63) / 64, 2), dim3(256), 0, s, w.inner_ws, grid, L.PG, g_m, g_p);
+            inner_parts = grid;                          // summed by the second role of wide_grad_finish_kernel below (was a launch of its own)
         }
         for (int l = 1; l < 8; ++l) tab.out[l] = 0;                 // the finish kernel only scatters layers 1 and 9
         wide_wgrad_pair(d, w, 0, out, in, s, wide_ht);
         if (!g_wide_dvp) for (int a = 0; a < 2; ++a) dgrad(a, 0, false);
-        hipLaunchKernelGGL(stw::wide_grad_finish_kernel, dim3((w.so[9] + 63) / 64, 2), dim3(256), 0, s, w.slabs, w.nsplit, w.SL, tab, g_m, g_p);
+        hipLaunchKernelGGL(stw::wide_grad_finish_kernel, dim3((w.so[9] + 63) / 64 + (L.PG + 63) / 64, 2), dim3(256), 0, s, w.slabs, w.nsplit, w.SL, tab, g_m, g_p,
+                           (w.so[9] + 63) / 64, (const float*)w.inner_ws, inner_parts, L.PG);
         if (g_wide_dvp) {
             stw::DvPolarArgs q;
             q.DA1m = w.DA[0][0]; q.DA1p = w.DA[1][0]; q.TLm = w.TL[0]; q.TLp = w.TL[1]; q.W1m = ae_m + L.go.w[0]; q.W1p = ae_p + L.go.w[0];
