@@ -16,6 +16,7 @@
 #include "st_gemm.h"
 #include <type_traits>
 #include "st_ae.h"
+#include "st_misc.h"
 
 namespace stw {
 using stg::NJ;
@@ -393,11 +394,20 @@ wide_dout_kernel(const float* __restrict__ dAA, int nslab, size_t slab, const fl
 // Sum of the split-K slabs of all nine weight-gradient GEMMs of one autoencoder (fixed slab order) scattered into the
 // packed gradient block: slab layout per layer [OUT][IN + 1] at so[l]; column IN is the bias gradient.
 struct GradTab { int so[10]; int out[9]; int in[9]; int gw[9]; int gb[9]; };
+struct SynReduce { const float* wg; int nz; float* gSr; float* gSi; float* norm_s; int N, F, KP; stm::NyqJob nyq; };      // wg == NULL: none
 __global__ void __launch_bounds__(256)
 wide_grad_finish_kernel(const float* __restrict__ slabs0, int nslab, size_t SL, const GradTab tab, float* __restrict__ g0, float* __restrict__ g1,
-                        const int n_fin = 1 << 30, const float* __restrict__ red_ws = nullptr, const int red_parts = 0, const int PG = 0)
+                        const int n_fin = 1 << 30, const float* __restrict__ red_ws = nullptr, const int red_parts = 0, const int PG = 0,
+                        const SynReduce syn = SynReduce{})
 {
     float* g = blockIdx.y ? g1 : g0;
+    const int n_red = red_ws ? (PG + 63) / 64 : 0;
+    if ((int)blockIdx.x >= n_fin + n_red) {
+        // third role (fused step): the split-K slabs of the SYNTHESIS weight gradient -> the two synthesis gradient tensors (un-folded) + their |g|
+        // partials, exactly stm::wgrad_reduce_kernel (which this replaces as a launch); the slabs were written before the autoencoder backward
+        if (blockIdx.y == 0 && syn.wg) stm::wgrad_reduce_block(syn.wg, syn.nz, syn.gSr, syn.gSi, syn.norm_s, syn.N, syn.F, syn.KP, 1, (int)blockIdx.x - n_fin - n_red, nullptr, syn.nyq);
+        return;
+    }
     if ((int)blockIdx.x >= n_fin) {
         // second role (fused wide path): the workgroup partials of the inner-layer kernel ws[nparts][2][PG] -> g, as stm::ae_grad_reduce_block, but ONLY
         // the parameters of layers 2..8: the layer-1 / layer-9 entries of those partials are zeros and their gradients come from the slabs (first role)

@@ -746,7 +746,8 @@ struct PolarSink { const float* re; const float* im; const float* g_mag; float* 
 static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, const float* phs, const float* knobs,
                        const float* ae_m, const float* ae_p, const float* mag_hat, const float* phs_hat, const float* dAA,
                        const float* g_mag_hat, float reg_coef, float* dmag, float* dphs, WideWS& w, float* g_m, float* g_p,
-                       bool have_fwd, void* stream, const PolarSink* sink = nullptr, bool* sink_used = nullptr)
+                       bool have_fwd, void* stream, const PolarSink* sink = nullptr, bool* sink_used = nullptr,
+                       const stw::SynReduce* syn = nullptr, bool* syn_done = nullptr)
 {
     hipStream_t s = st_stream(stream);
     const int FP = L.KP / 2, F = d->F, T = d->T, OT = d->OT, R = (int)w.R, Tp = w.Tp;
@@ -812,8 +813,9 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
         for (int l = 1; l < 8; ++l) tab.out[l] = 0;                 // the finish kernel only scatters layers 1 and 9
         wide_wgrad_pair(d, w, 0, out, in, s, wide_ht);
         if (!g_wide_dvp) for (int a = 0; a < 2; ++a) dgrad(a, 0, false);
-        hipLaunchKernelGGL(stw::wide_grad_finish_kernel, dim3((w.so[9] + 63) / 64 + (L.PG + 63) / 64, 2), dim3(256), 0, s, w.slabs, w.nsplit, w.SL, tab, g_m, g_p,
-                           (w.so[9] + 63) / 64, (const float*)w.inner_ws, inner_parts, L.PG);
+        hipLaunchKernelGGL(stw::wide_grad_finish_kernel, dim3((w.so[9] + 63) / 64 + (L.PG + 63) / 64 + (syn ? st_norm_partials(d) : 0), 2), dim3(256), 0, s, w.slabs, w.nsplit, w.SL, tab, g_m, g_p,
+                           (w.so[9] + 63) / 64, (const float*)w.inner_ws, inner_parts, L.PG, syn ? *syn : stw::SynReduce{});
+        if (syn && syn_done) *syn_done = true;
         if (g_wide_dvp) {
             stw::DvPolarArgs q;
             q.DA1m = w.DA[0][0]; q.DA1p = w.DA[1][0]; q.TLm = w.TL[0]; q.TLp = w.TL[1]; q.W1m = ae_m + L.go.w[0]; q.W1p = ae_p + L.go.w[0];
@@ -847,7 +849,7 @@ static int ae_bwd_impl(const st_dims* d, const float* mag, const float* phs, con
                        const float* ae_m, const float* ae_p, const float* mag_hat, const float* phs_hat,
                        const float* dAA, const float* g_mag_hat, float reg_coef, float* dmag, float* dphs, float* ws,
                        float* g_m, float* g_p, bool have_fwd, void* stream, bool* defer_reduce = nullptr,
-                       const PolarSink* sink = nullptr, bool* sink_used = nullptr)
+                       const PolarSink* sink = nullptr, bool* sink_used = nullptr, const stw::SynReduce* syn = nullptr, bool* syn_done = nullptr)
 {
     // defer_reduce: in -> the caller will sum the workgroup partials itself (post_ae_kernel, together with the polar backward);
     // out -> false if this geometry's path already reduced them (wide geometries)
@@ -856,7 +858,7 @@ static int ae_bwd_impl(const st_dims* d, const float* mag, const float* phs, con
     if (ae_is_wide(d)) {
         if (defer_reduce) *defer_reduce = false;
         WideWS w; wide_carve(d, ws, &w);
-        return ae_wide_bwd(d, L, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, dmag, dphs, w, g_m, g_p, have_fwd, stream, sink, sink_used);
+        return ae_wide_bwd(d, L, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, dmag, dphs, w, g_m, g_p, have_fwd, stream, sink, sink_used, syn, syn_done);
     }
     const size_t lds = (size_t)sta::ae_bwd_lds_floats(AE_BWD_NW) * sizeof(float);
     static_assert((size_t)sta::ae_bwd_lds_floats(AE_BWD_NW) * sizeof(float) <= 160 * 1024, "ae_bwd LDS budget");
@@ -1335,10 +1337,21 @@ static int backward_ae(const st_dims* d, const Layout& L, const float* params, f
                        const stm::NyqJob* syn_nyq = nullptr)
 {   // syn_slabs > 0: the synthesis weight-gradient slabs in w.wg are still to be summed (done by post_ae_kernel)
     const float* ae_m = params + L.offs[4]; const float* ae_p = params + L.offs[22];
-    bool deferred = true, sink_used = false;
+    bool deferred = true, sink_used = false, syn_done = false;
     const PolarSink sink{w.re, w.im, g_mag, w.g16 ? nullptr : w.dG, w.g16 ? w.dG16 : nullptr};
+    stw::SynReduce syn{};
+    if (syn_slabs > 0 && ae_is_wide(d)) {              // wide geometries: the synthesis slab sum rides in the gradient-finish launch of the autoencoder backward
+        syn.wg = w.wg; syn.nz = syn_slabs; syn.gSr = grads + L.offs[2]; syn.gSi = grads + L.offs[3]; syn.norm_s = w.norm_s; syn.N = d->N; syn.F = d->F; syn.KP = L.KP;
+        syn.nyq = stm::NyqJob{}; syn.nyq.on = 0; if (syn_nyq) syn.nyq = *syn_nyq;
+    }
     ST_TRY(ae_bwd_impl(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.dAA, g_mag_hat, reg_coef, w.dmag, w.dphs,
-                       w.aews, grads + L.offs[4], grads + L.offs[22], true, stream, &deferred, &sink, &sink_used));      // the forward left its AE state in w.aews
+                       w.aews, grads + L.offs[4], grads + L.offs[22], true, stream, &deferred, &sink, &sink_used, syn.wg ? &syn : nullptr, &syn_done));      // the forward left its AE state in w.aews
+    if (syn.wg && !syn_done) {                         // the path taken had no launch to ride in (all-GEMM variant): the reduce as a launch of its own
+        hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(st_norm_partials(d)), dim3(256), 0, st_stream(stream),
+                           syn.wg, syn.nz, syn.gSr, syn.gSi, syn.norm_s, d->N, d->F, L.KP, 1, 0, 2 * d->F, (float*)nullptr, syn.nyq);
+        ST_LAUNCHED("synthesis_wgrad_reduce");
+    }
+    if (syn.wg) syn_slabs = 0;
     if (sink_used) return ST_OK;                       // wide geometries: the polar backward ran inside wide_dv_polar_kernel
     if (!deferred) {
         ST_REQ(syn_slabs == 0, "internal: deferred synthesis slabs on a path without post_ae_kernel");
@@ -1373,7 +1386,7 @@ static int backward_p1(const st_dims* d, const Layout& L, const float* params, f
                        const float* knobs, const float* g_mag_hat, const float* g_mag, float reg_coef, WS& w, void* stream)
 {
     int syn_slabs = 0; stm::NyqJob syn_nyq{}; syn_nyq.on = 0;
-    ST_TRY(backward_syn(d, L, grads, w, stream, ae_is_wide(d) ? nullptr : &syn_slabs, &syn_nyq));      // fused geometries: post_ae_kernel also sums the synthesis slabs
+    ST_TRY(backward_syn(d, L, grads, w, stream, &syn_slabs, &syn_nyq));      // the slab sum rides in a later launch: post_ae_kernel (fused geometries) / wide_grad_finish_kernel (wide ones)
     return backward_ae(d, L, params, grads, knobs, g_mag_hat, g_mag, reg_coef, w, stream, syn_slabs, &syn_nyq);
 }
 static int backward_p2(const st_dims* d, const Layout& L, float* grads, const float* x, WS& w, void* stream, float* stage = nullptr)
