@@ -398,7 +398,7 @@ struct SynReduce { const float* wg; int nz; float* gSr; float* gSi; float* norm_
 __global__ void __launch_bounds__(256)
 wide_grad_finish_kernel(const float* __restrict__ slabs0, int nslab, size_t SL, const GradTab tab, float* __restrict__ g0, float* __restrict__ g1,
                         const int n_fin = 1 << 30, const float* __restrict__ red_ws = nullptr, const int red_parts = 0, const int PG = 0,
-                        const SynReduce syn = SynReduce{})
+                        const SynReduce syn = SynReduce{}, float* __restrict__ norm_e = nullptr)      // norm_e: one |g| partial per block of the first two roles, slot = y * (n_fin + n_red) + x
 {
     float* g = blockIdx.y ? g1 : g0;
     const int n_red = red_ws ? (PG + 63) / 64 : 0;
@@ -431,7 +431,10 @@ wide_grad_finish_kernel(const float* __restrict__ slabs0, int nslab, size_t SL, 
         }
         rr[pl][col] = s;
         __syncthreads();
-        if (pl == 0 && mine) g[i] = (rr[0][col] + rr[1][col]) + (rr[2][col] + rr[3][col]);
+        if (pl != 0) return;
+        const float r = mine ? (rr[0][col] + rr[1][col]) + (rr[2][col] + rr[3][col]) : 0.f;
+        if (mine) g[i] = r;
+        if (norm_e) { const float t = wave_sum(fabsf(r)); if (col == 0) norm_e[blockIdx.y * (n_fin + n_red) + blockIdx.x] = t; }
         return;
     }
     const float* slabs = slabs0 + (size_t)blockIdx.y * nslab * SL;      // net y: its slabs follow net 0's
@@ -458,10 +461,13 @@ wide_grad_finish_kernel(const float* __restrict__ slabs0, int nslab, size_t SL, 
     }
     red[pl][col] = s;
     __syncthreads();
-    if (pl != 0 || !live) return;
-    s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
-    const int o = e / n1, i = e - o * n1;
-    if (i < tab.in[l]) g[tab.gw[l] + o * tab.in[l] + i] = s; else g[tab.gb[l] + o] = s;
+    if (pl != 0) return;
+    s = live ? (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]) : 0.f;
+    if (live) {
+        const int o = e / n1, i = e - o * n1;
+        if (i < tab.in[l]) g[tab.gw[l] + o * tab.in[l] + i] = s; else g[tab.gb[l] + o] = s;
+    }
+    if (norm_e) { const float t = wave_sum(fabsf(s)); if (col == 0) norm_e[blockIdx.y * (n_fin + n_red) + blockIdx.x] = t; }
 }
 
 }  // namespace stw

@@ -193,6 +193,8 @@ static int g_frs_nt = 1;     // synthesis frames GEMM against the transposed fol
 static int g_xt = 0;       // 1: M/N-contiguous operands staged k-quad-major (st_gemm.h XT; st_set_tuning(7001), diagnostics).  MEASURED SLOWER at B=256 although
                            // conflict-free with a third fewer LDS cycles: analysis wgrad 173 vs 145 us, synthesis frames 63 vs 60 us (16 more prefetch
                            // registers -> 4 instead of 4.5 waves per SIMD, and 16 v_mov per micro-tile): the k-major staging stays the default
+static const int NORM_E_PARTIALS = 32;     // |g| partials of the autoencoder gradient range (st_dims.clip_all) when they come from l1_partial_kernel
+static const int NORM_E_MAX = 4096;        // room for the per-block partials of the reducing kernels themselves (post_ae_kernel / wide_grad_finish_kernel)
 static int g_wide_pair = 1;  // wide geometries, 16-bit: the layer-1 / layer-9 GEMMs of the two autoencoders as ONE launch each (gemm_half_pair_kernel); 0 = two launches (st_set_tuning(9960 + n), diagnostics)
 static int g_wide_dvp = 1;   // wide geometries: layer-1 data gradient (+ polar backward) as one fused kernel; 0 = two GEMMs + polar_bwd (st_set_tuning(9900), diagnostics)
 static int g_nt_mi = 0;     // fp32 NT x NT GEMMs with 64 x 96 wave tiles (MI = 2): 0 off; bit 0 analysis forward <4,16,2>, bit 1 <2,32,2>, bit 2 frames / dgrad <2,16,2>  (st_set_tuning(9800 + n), experiments)
@@ -747,7 +749,7 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
                        const float* ae_m, const float* ae_p, const float* mag_hat, const float* phs_hat, const float* dAA,
                        const float* g_mag_hat, float reg_coef, float* dmag, float* dphs, WideWS& w, float* g_m, float* g_p,
                        bool have_fwd, void* stream, const PolarSink* sink = nullptr, bool* sink_used = nullptr,
-                       const stw::SynReduce* syn = nullptr, bool* syn_done = nullptr)
+                       const stw::SynReduce* syn = nullptr, bool* syn_done = nullptr, float* norm_e = nullptr, int* n_norm_e = nullptr)
 {
     hipStream_t s = st_stream(stream);
     const int FP = L.KP / 2, F = d->F, T = d->T, OT = d->OT, R = (int)w.R, Tp = w.Tp;
@@ -813,9 +815,11 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
         for (int l = 1; l < 8; ++l) tab.out[l] = 0;                 // the finish kernel only scatters layers 1 and 9
         wide_wgrad_pair(d, w, 0, out, in, s, wide_ht);
         if (!g_wide_dvp) for (int a = 0; a < 2; ++a) dgrad(a, 0, false);
+        if (norm_e && 2 * ((w.so[9] + 63) / 64 + (L.PG + 63) / 64) > NORM_E_MAX) norm_e = nullptr;
         hipLaunchKernelGGL(stw::wide_grad_finish_kernel, dim3((w.so[9] + 63) / 64 + (L.PG + 63) / 64 + (syn ? st_norm_partials(d) : 0), 2), dim3(256), 0, s, w.slabs, w.nsplit, w.SL, tab, g_m, g_p,
-                           (w.so[9] + 63) / 64, (const float*)w.inner_ws, inner_parts, L.PG, syn ? *syn : stw::SynReduce{});
+                           (w.so[9] + 63) / 64, (const float*)w.inner_ws, inner_parts, L.PG, syn ? *syn : stw::SynReduce{}, norm_e);
         if (syn && syn_done) *syn_done = true;
+        if (norm_e && n_norm_e) *n_norm_e = 2 * ((w.so[9] + 63) / 64 + (L.PG + 63) / 64);
         if (g_wide_dvp) {
             stw::DvPolarArgs q;
             q.DA1m = w.DA[0][0]; q.DA1p = w.DA[1][0]; q.TLm = w.TL[0]; q.TLp = w.TL[1]; q.W1m = ae_m + L.go.w[0]; q.W1p = ae_p + L.go.w[0];
@@ -849,7 +853,8 @@ static int ae_bwd_impl(const st_dims* d, const float* mag, const float* phs, con
                        const float* ae_m, const float* ae_p, const float* mag_hat, const float* phs_hat,
                        const float* dAA, const float* g_mag_hat, float reg_coef, float* dmag, float* dphs, float* ws,
                        float* g_m, float* g_p, bool have_fwd, void* stream, bool* defer_reduce = nullptr,
-                       const PolarSink* sink = nullptr, bool* sink_used = nullptr, const stw::SynReduce* syn = nullptr, bool* syn_done = nullptr)
+                       const PolarSink* sink = nullptr, bool* sink_used = nullptr, const stw::SynReduce* syn = nullptr, bool* syn_done = nullptr,
+                       float* norm_e = nullptr, int* n_norm_e = nullptr)
 {
     // defer_reduce: in -> the caller will sum the workgroup partials itself (post_ae_kernel, together with the polar backward);
     // out -> false if this geometry's path already reduced them (wide geometries)
@@ -858,7 +863,7 @@ static int ae_bwd_impl(const st_dims* d, const float* mag, const float* phs, con
     if (ae_is_wide(d)) {
         if (defer_reduce) *defer_reduce = false;
         WideWS w; wide_carve(d, ws, &w);
-        return ae_wide_bwd(d, L, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, dmag, dphs, w, g_m, g_p, have_fwd, stream, sink, sink_used, syn, syn_done);
+        return ae_wide_bwd(d, L, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, dmag, dphs, w, g_m, g_p, have_fwd, stream, sink, sink_used, syn, syn_done, norm_e, n_norm_e);
     }
     const size_t lds = (size_t)sta::ae_bwd_lds_floats(AE_BWD_NW) * sizeof(float);
     static_assert((size_t)sta::ae_bwd_lds_floats(AE_BWD_NW) * sizeof(float) <= 160 * 1024, "ae_bwd LDS budget");
@@ -1040,7 +1045,6 @@ extern "C" int st_debug_read_stage_cycles(unsigned long long* out32)
 }
 
 // ------------------------------------------------------------------------------ workspace
-static const int NORM_E_PARTIALS = 32;     // |g| partials of the autoencoder gradient range (st_dims.clip_all)
 struct WS {
     float *re, *im, *mag, *phs, *mag_hat, *phs_hat, *AA, *dAA, *Sfold, *SfoldT, *frs, *y_hat, *dsyn, *dmag, *dphs, *dG, *xp;
     float *wg, *aews, *loss_p, *reg_p, *norm_a, *norm_s, *norm_e;
@@ -1049,6 +1053,7 @@ struct WS {
     // 16-bit GEMM operands (st_gemm16.h), each written by its producer in the layout of its fp32 counterpart: padded x/2, the analysis
     // bases as rows (bin, re | im) [2F][N], the folded synthesis bases [KP][N] and [N][KP], the spectra, the padded d syn, d G
     unsigned short *xp16, *W16, *Sfold16, *SfoldT16, *AA16, *dsyn16, *dG16;
+    int n_norm_e;      // > 0: the autoencoder backward of this call left that many |g| partials of its gradients in norm_e (clip_all needs no l1_partial launch)
     bool g16;          // this call runs the 16-bit operand pipeline (set by the entry point after carve(): use_g16(); the autograd entries and the
                        // four-stage schedule keep fp32 operands + gemm_half_kernel)
     size_t bytes;
@@ -1068,7 +1073,7 @@ static void carve(const st_dims* d, void* base, WS* w)
     w->dmag = take(RT * F); w->dphs = take(RT * F); w->dG = take(RT * KP);
     w->wg = take(st_wgrad_ws_floats(d)); w->aews = take(st_ae_bwd_ws_floats(d));
     w->loss_p = take(st_ola_loss_partials(d)); w->reg_p = take(st_ae_fwd_partials(d));
-    w->norm_a = take(st_norm_partials(d)); w->norm_s = take(st_norm_partials(d)); w->norm_e = take(NORM_E_PARTIALS);
+    w->norm_a = take(st_norm_partials(d)); w->norm_s = take(st_norm_partials(d)); w->norm_e = take(NORM_E_MAX); w->n_norm_e = 0;
     auto take16 = [&](size_t n) { return reinterpret_cast<unsigned short*>(take((n + 1) / 2)); };      // always sized for three planes: 19 MB
     w->pl_W = take16((size_t)3 * 2 * F * N); w->pl_Sfold = take16((size_t)3 * KP * N); w->pl_SfoldT = take16((size_t)3 * KP * N);
     // (+ 256: the 128-wide tiles of the TN kernel read up to 96 elements past the last row of an M/N-contiguous operand; masked outputs)
@@ -1345,7 +1350,8 @@ static int backward_ae(const st_dims* d, const Layout& L, const float* params, f
         syn.nyq = stm::NyqJob{}; syn.nyq.on = 0; if (syn_nyq) syn.nyq = *syn_nyq;
     }
     ST_TRY(ae_bwd_impl(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.dAA, g_mag_hat, reg_coef, w.dmag, w.dphs,
-                       w.aews, grads + L.offs[4], grads + L.offs[22], true, stream, &deferred, &sink, &sink_used, syn.wg ? &syn : nullptr, &syn_done));      // the forward left its AE state in w.aews
+                       w.aews, grads + L.offs[4], grads + L.offs[22], true, stream, &deferred, &sink, &sink_used, syn.wg ? &syn : nullptr, &syn_done,
+                       (d->clip_all && ae_is_wide(d)) ? w.norm_e : nullptr, &w.n_norm_e));      // the forward left its AE state in w.aews
     if (syn.wg && !syn_done) {                         // the path taken had no launch to ride in (all-GEMM variant): the reduce as a launch of its own
         hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(st_norm_partials(d)), dim3(256), 0, st_stream(stream),
                            syn.wg, syn.nz, syn.gSr, syn.gSi, syn.norm_s, d->N, d->F, L.KP, 1, 0, 2 * d->F, (float*)nullptr, syn.nyq);
@@ -1378,6 +1384,8 @@ static int backward_ae(const st_dims* d, const Layout& L, const float* params, f
     a.nyq = stm::NyqJob{}; a.nyq.on = 0; if (syn_nyq) a.nyq = *syn_nyq;
     a.dG16 = nullptr; a.ht = 0;
     if (w.g16) { a.dG16 = w.dG16; a.ht = gemm_ht(d->prec); a.dG = nullptr; }      // the analysis weight-gradient GEMM is the only consumer on this path
+    a.norm_e = nullptr;
+    if (d->clip_all && a.n_red <= NORM_E_MAX) { a.norm_e = w.norm_e; w.n_norm_e = a.n_red; }
     hipLaunchKernelGGL(stm::post_ae_kernel, dim3(a.n_red + a.n_polar + (syn_slabs > 0 ? st_norm_partials(d) : 0)), dim3(256), 0, st_stream(stream), a);
     ST_LAUNCHED("post_ae");
     return ST_OK;
@@ -1549,10 +1557,13 @@ static int train_step_impl(const st_dims* d, float* params, float* grads, float*
     const float inv_s = 1.0f / loss_scale_of(d);            // the gradients carry the loss scale: unscale inside the optimizer
     stm::FinArgs f = fin_args(d, w.loss_p, w.reg_p, w.norm_a, w.norm_s, inv_s);
     if (d->clip_all) {                                       // train.py:136: the norm runs over every parameter
-        hipLaunchKernelGGL(stm::l1_partial_kernel, dim3(NORM_E_PARTIALS), dim3(256), 0, st_stream(stream),
-                           grads + L.n_stft, L.total - L.n_stft, 1.0f, w.norm_e);
-        ST_LAUNCHED("l1_partial_ae");
-        f.norm_e = w.norm_e; f.n_ne = NORM_E_PARTIALS;
+        if (w.n_norm_e > 0) { f.norm_e = w.norm_e; f.n_ne = w.n_norm_e; }      // the kernels that summed the autoencoder gradients left their |g| partials
+        else {
+            hipLaunchKernelGGL(stm::l1_partial_kernel, dim3(NORM_E_PARTIALS), dim3(256), 0, st_stream(stream),
+                               grads + L.n_stft, L.total - L.n_stft, 1.0f, w.norm_e);
+            ST_LAUNCHED("l1_partial_ae");
+            f.norm_e = w.norm_e; f.n_ne = NORM_E_PARTIALS;
+        }
     }
     return clip_adam_impl(params, grads, m, v, L.total, d->clip_all ? L.total : L.n_stft, scalars, inv_s, lr, beta1, beta2, eps, step, &f, stream, dev_hyper);
 }

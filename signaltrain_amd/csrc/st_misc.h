@@ -417,8 +417,11 @@ unstage_l1_kernel(const float* __restrict__ stage, float* __restrict__ gRe, floa
 
 // ---------------------------------------------------------------- per-wave AE gradient partial reduce
 // ws[nparts][2][PG] -> g_m[PG], g_p[PG].  Block = 64 columns x 4 partial-lanes; 8 loads in flight per thread.
+// norm_out != NULL: the block also publishes sum |g| of the 64 gradient values it produced (slot `slot`): the clip over ALL parameters (st_dims.clip_all)
+// needs the L1 norm of the autoencoder range, which was a 5 us launch of its own over 77 KB.
 __device__ __forceinline__ void ae_grad_reduce_block(const float* __restrict__ ws, const int nparts, const int PG,
-                                                     float* __restrict__ g_m, float* __restrict__ g_p, const int bx, const int ae)
+                                                     float* __restrict__ g_m, float* __restrict__ g_p, const int bx, const int ae,
+                                                     float* __restrict__ norm_out = nullptr, const int slot = 0)
 {
     __shared__ float red[4][64];
     const int col = threadIdx.x & 63, pl = threadIdx.x >> 6;
@@ -437,7 +440,10 @@ __device__ __forceinline__ void ae_grad_reduce_block(const float* __restrict__ w
     }
     red[pl][col] = s;
     __syncthreads();
-    if (pl == 0 && i < PG) (ae ? g_p : g_m)[i] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    if (pl != 0) return;                                   // wave 0 holds the 64 results
+    const float r = i < PG ? (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]) : 0.f;
+    if (i < PG) (ae ? g_p : g_m)[i] = r;
+    if (norm_out) { const float t = wave_sum(fabsf(r)); if (col == 0) norm_out[slot] = t; }
 }
 __global__ void __launch_bounds__(256)
 ae_grad_reduce_kernel(const float* __restrict__ ws, int nparts, int PG, float* __restrict__ g_m, float* __restrict__ g_p)
@@ -454,12 +460,13 @@ struct PostAeArgs {
     int n_polar; const float* wg; int wg_nz; float* gSr; float* gSi; float* norm_s; int N; NyqJob nyq;
     unsigned short* dG16; int ht;          // 16-bit configurations: d G rounded to the GEMM operand type (dG itself may then be NULL)
     unsigned polar_total, polar_magic;     // polar_total > 0: the polar blocks walk the flattened element space (polar_bwd_flat)
+    float* norm_e;                         // n_red |g| partials of the autoencoder gradients (st_dims.clip_all), or NULL
 };
 __global__ void __launch_bounds__(256)
 post_ae_kernel(const PostAeArgs a)
 {
     const int blk = blockIdx.x;
-    if (blk < a.n_red) { const int ae = blk / a.n_red_x; ae_grad_reduce_block(a.ws, a.nparts, a.PG, a.g_m, a.g_p, blk - ae * a.n_red_x, ae); }
+    if (blk < a.n_red) { const int ae = blk / a.n_red_x; ae_grad_reduce_block(a.ws, a.nparts, a.PG, a.g_m, a.g_p, blk - ae * a.n_red_x, ae, a.norm_e, blk); }
     else if (blk < a.n_red + a.n_polar && a.polar_total) polar_bwd_flat(a.re, a.im, a.dmag, a.dphs, a.g_mag, a.dG, a.F, a.KP, a.sat, (unsigned)(blk - a.n_red), a.polar_total, a.polar_magic, a.dG16, a.ht);
     else if (blk < a.n_red + a.n_polar) { const int q = blk - a.n_red, r = q / a.gx; polar_bwd_block(a.re, a.im, a.dmag, a.dphs, a.g_mag, a.dG, a.F, a.KP, a.sat, q - r * a.gx, r, a.dG16, a.ht); }
     else wgrad_reduce_block(a.wg, a.wg_nz, a.gSr, a.gSi, a.norm_s, a.N, a.F, a.KP, 1, blk - a.n_red - a.n_polar, nullptr, a.nyq);
