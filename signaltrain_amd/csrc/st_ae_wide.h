@@ -43,11 +43,14 @@ struct ActStore {          // layers 1..8 forward: out[row][col] = ELU(acc + bia
     __device__ void operator()(int m0, int n0, const f32x16 (&acc)[NJ]) const {
         const int lane = threadIdx.x & 63;
         ColInfo ci[NJ]; col_info(ci, n0, lane, R, FP, F);
+        float bvv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int row = m0 + d_row(i, lane); bvv[i] = bias[row < M ? row : M - 1]; }      // one batch of loads, not one wait per row
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = m0 + d_row(i, lane);
             if (row < M) {
-                const float bv = bias[row];
+                const float bv = bvv[i];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     if (ci[j].ok) out[(size_t)row * R + ci[j].col] = ci[j].real ? elu_f(acc[j][i] + bv) : 0.f;
@@ -61,18 +64,27 @@ struct OutStore {          // layer 9 forward (nn_proc.py:113-117, :322): e = EL
     __device__ void operator()(int m0, int n0, const f32x16 (&acc)[NJ]) const {
         const int lane = threadIdx.x & 63;
         ColInfo ci[NJ]; col_info(ci, n0, lane, R, FP, F);
+        // all 48 tail values (and the 16 biases) are requested BEFORE the first is used, from clamped -- always valid -- addresses: inside the
+        // predicated store loop each load was followed by its own wait (48 dependent round trips: this epilogue was most of a 32 us launch for 0.2 GFLOP)
+        float tl[16][NJ], bv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = m0 + d_row(i, lane), rc = row < M ? row : M - 1;
+            bv[i] = bias[rc];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) tl[i][j] = outp ? tail[(size_t)rc * R + (ci[j].ok ? ci[j].col : 0)] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = m0 + d_row(i, lane);
             if (row < M) {
-                const float bv = bias[row];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     if (ci[j].ok) {
-                        const float e = elu_f(acc[j][i] + bv);
+                        const float e = elu_f(acc[j][i] + bv[i]);
                         const size_t ix = (size_t)row * R + ci[j].col;
                         e9[ix] = ci[j].real ? e : 0.f;
-                        if (outp && ci[j].real) { const float tl = tail[ix]; outp[((size_t)ci[j].b * M + row) * F + ci[j].f] = mode ? e + tl : e * tl; }
+                        if (outp && ci[j].real) outp[((size_t)ci[j].b * M + row) * F + ci[j].f] = mode ? e + tl[i][j] : e * tl[i][j];
                     }
                 }
             }
