@@ -159,20 +159,24 @@ wide_dv_polar_kernel(const DvPolarArgs a)
     __syncthreads();
     // thread i < T owns input column i of W1 [64][T] (coalesced across threads, NO integer division: e / T for 22 k elements was 6 k of this
     // kernel's 9 k vector instructions per wave), sixteen loads in flight
-    if (tid < T) {
-        for (int n = 0; n < 2; ++n) {
+    // (threads [0, T) stage the first net, [T, 2 T) the second: four batches of loads per thread instead of eight -- the staging is dependent round
+    // trips, ~10 us of a 55 us kernel in which every wave handles about one row group)
+    if (tid < 2 * T) {
+        const int n = tid >= T, ti = tid - n * T;
+        {
             const float* W = n ? a.W1p : a.W1m;
+            float* const im = n ? img[1] : img[0];
 #pragma unroll
             for (int o0 = 0; o0 < 64; o0 += 16) {
                 float v[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = W[(o0 + u) * T + tid];
+                for (int u = 0; u < 16; ++u) v[u] = W[(o0 + u) * T + ti];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const int o = o0 + u;
-                    const int idx = (((o >> 2) * TP + tid) << 2) + (o & 3);
-                    if constexpr (BF) reinterpret_cast<unsigned short*>(img[n])[idx] = sta::st_half_bits<BF>(v[u]);
-                    else img[n][idx] = v[u];
+                    const int idx = (((o >> 2) * TP + ti) << 2) + (o & 3);
+                    if constexpr (BF) reinterpret_cast<unsigned short*>(im)[idx] = sta::st_half_bits<BF>(v[u]);
+                    else im[idx] = v[u];
                 }
             }
         }
@@ -264,7 +268,7 @@ wide_dv_polar_kernel(const DvPolarArgs a)
                 }
             }
         };
-        for (int it = 0; it < NIT; it += 2) {
+        for (int it = 0; it < NIT; it += 2) {               // (a third look-ahead slot -- inputs of tile it + 2 in flight -- spills: 256 registers + 88 bytes of scratch)
             load_tile(it + 1 < NIT ? it + 1 : it, 1);
             tile(it, std::integral_constant<int, 0>{});
             if (it + 1 < NIT) {                             // wave-uniform
