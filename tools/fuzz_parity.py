@@ -11,7 +11,7 @@ a fused bf16 step is chaotic at that level (one flipped rounding per few thousan
 Round 2 (f32x3 = three-plane bfloat16 split against the fp32 oracle at fp32 tolerances, and f16_all added to the draw; 400 s):
 628 configurations, fp32 and f32x3 all green (the same "soft" analysis-gradient conditioning lines in both), 4 level-2 outliers
 (bf16_all 4-5e-2 at B <= 9, f16_all 1.0-1.3e-2 at B <= 3) of the kind described above.
-Round 3 (400 s, profiles/r03_fuzz_parity.txt): 628 configurations, fp32 and f32x3 all green, 4 level-2 outliers of the same kind (bf16_all 4-5e-2 at B <= 9, f16_all 1.3e-2 at B = 2).
+Round 3 (400 s, profiles/r03_fuzz_parity.txt): 628 configurations, fp32 and f32x3 all green, 4 level-2 outliers of the same kind (bf16_all 4-5e-2 at B <= 9, f16_all 1.3e-2 at B = 2); after the wide-path pass, 500 s: 806 configurations, fp32 / f32x3 green, 6 such outliers (bf16_all 4-7e-2 at B <= 9, f16_all 1.0-1.3e-2 at B <= 3).
     python tools/fuzz_parity.py [seconds]"""
 import sys, time, random; sys.path.insert(0, '.')
 from tests import gpu_checks as G
