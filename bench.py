@@ -116,6 +116,8 @@ def main():
                          f"--steps {args.steps} --warmup {args.warmup}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (there is no CPU fallback of the product path)")
+    if os.environ.get("ST_BENCH_SHARE_GPU"):          # tests only: every rank on GPU 0 (with ST_RCCL_LIB = the RCCL test double) -- runs this file's N > 1 path on a one-GPU box
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
