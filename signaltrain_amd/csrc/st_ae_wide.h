@@ -321,8 +321,11 @@ wide_in_kernel(const float* __restrict__ mag, const float* __restrict__ phs, con
     if ((int)row < T) {
         const float* sm = mag + ((size_t)b * T + row) * F;
         const float* sp = phs + ((size_t)b * T + row) * F;
-        vm = make_float4(f0 < F ? sm[f0] : 0.f, f0 + 1 < F ? sm[f0 + 1] : 0.f, f0 + 2 < F ? sm[f0 + 2] : 0.f, f0 + 3 < F ? sm[f0 + 3] : 0.f);
-        vp = make_float4(f0 < F ? sp[f0] : 0.f, f0 + 1 < F ? sp[f0 + 1] : 0.f, f0 + 2 < F ? sp[f0 + 2] : 0.f, f0 + 3 < F ? sp[f0 + 3] : 0.f);
+        float m4[4], p4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int fc = f0 + q < F ? f0 + q : F - 1; m4[q] = sm[fc]; p4[q] = sp[fc]; }      // eight unconditional loads (clamped), then the selects
+        vm = make_float4(f0 < F ? m4[0] : 0.f, f0 + 1 < F ? m4[1] : 0.f, f0 + 2 < F ? m4[2] : 0.f, f0 + 3 < F ? m4[3] : 0.f);
+        vp = make_float4(f0 < F ? p4[0] : 0.f, f0 + 1 < F ? p4[1] : 0.f, f0 + 2 < F ? p4[2] : 0.f, f0 + 3 < F ? p4[3] : 0.f);
         dm = Vm + (size_t)row * R + (size_t)b * FP; dp = Vp + (size_t)row * R + (size_t)b * FP;
     } else {
         const int k = (int)row - T;
@@ -386,8 +389,15 @@ wide_dout_kernel(const float* __restrict__ dAA, int nslab, size_t slab, const fl
         float d9m = 0.f, d9p = 0.f, tm = 0.f, tp = 0.f;
         if (f < F) {
             float gre = 0.f, gim = 0.f;
-            if (to >= to_lo && to <= to_hi)
-                for (int z = 0; z < nslab; ++z) { gre += dAA[z * slab + (size_t)ro * KP + f]; gim += dAA[z * slab + (size_t)ro * KP + FP + f]; }
+            if (to >= to_lo && to <= to_hi) {           // up to 8 slabs requested together (fixed order of additions)
+                for (int z0 = 0; z0 < nslab; z0 += 8) {
+                    float ur[8], ui[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { const int z = z0 + q < nslab ? z0 + q : nslab - 1; ur[q] = dAA[z * slab + (size_t)ro * KP + f]; ui[q] = dAA[z * slab + (size_t)ro * KP + FP + f]; }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (z0 + q < nslab) { gre += ur[q]; gim += ui[q]; }
+                }
+            }
             const float mh = mag_hat[(size_t)ro * F + f], ph = phs_hat[(size_t)ro * F + f];
             float sn, cs; st_sincos(ph, sn, cs);                             // as the d-out stage of sta::ae_bwd_kernel
             const float wf = expf(expfac * (float)f);

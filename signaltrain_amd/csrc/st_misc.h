@@ -76,7 +76,7 @@ ola_loss_kernel(const float* __restrict__ frs, const float* __restrict__ x, cons
         if (t1 > OT - 1) t1 = OT - 1;
         const float* fb = frs + (size_t)b * OT * N;
         float s = 0.f;
-        for (int t = t0; t <= t1; ++t) {            // up to 6 split-K slabs of the synthesis GEMM, loads issued together, fixed order
+        for (int t = t0; t <= t1; ++t) {            // up to 6 split-K slabs of the synthesis GEMM, loads issued together, fixed order (all frames' loads at once measured 7 % slower: 24 loads for 9 live ones)
             const size_t o = (size_t)t * N + (N + j - H * t);
             float v[6];
 #pragma unroll
@@ -157,16 +157,27 @@ __device__ __forceinline__ void fold_tile(const float* __restrict__ Sr, const fl
     const int ntn = N / 32, tk = tile / ntn, tn = tile - tk * ntn;
     const int half = KP / 2;
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;          // 32 columns x 8 row-lanes
+    // all eight loads of a thread (row k and its mirror N - k for four rows) are requested before the first is used, from clamped -- always valid -- rows:
+    // inside the row conditions each one was its own round trip
+    float a0[4], a1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = tk * 32 + ry + 8 * j, n = tn * 32 + cx;
         const bool is_im = row >= half;
         const int k = is_im ? row - half : row;
         const float* S = is_im ? Si : Sr;
+        const int kc = k < F ? k : F - 1, km = (k >= 1 && k <= F - 2) ? N - k : N - 1;
+        a0[j] = S[(size_t)kc * N + n]; a1[j] = S[(size_t)km * N + n];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = tk * 32 + ry + 8 * j, n = tn * 32 + cx;
+        const bool is_im = row >= half;
+        const int k = is_im ? row - half : row;
         float v = 0.f;
         if (k < F) {
-            v = S[(size_t)k * N + n];
-            if (k >= 1 && k <= F - 2) { const float u = S[(size_t)(N - k) * N + n]; v += is_im ? -u : u; }
+            v = a0[j];
+            if (k >= 1 && k <= F - 2) v += is_im ? -a1[j] : a1[j];
         }
         if (Sfold16) Sfold16[(size_t)row * N + n] = st_to_h16(v, ht); else Sfold[(size_t)row * N + n] = v;
         tl[ry + 8 * j][cx] = v;
@@ -312,9 +323,12 @@ nyquist_chunk(const NyqJob& q, float* __restrict__ gRe, float* __restrict__ gIm,
     const int n4 = (is_im ? blk - per : blk) * (NYQ_CW / 4) + (threadIdx.x & 63), grp = threadIdx.x >> 6;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (4 * n4 < N)
-        for (int p = grp; p < q.P; p += 4) {
-            const float4 u = *reinterpret_cast<const float4*>(q.part + ((size_t)p * 2 + (is_im ? 1 : 0)) * N + 4 * n4);
-            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        for (int p0 = grp; p0 < q.P; p0 += 32) {            // eight partials in flight per trip (same order of additions)
+            float4 u[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int p = p0 + 4 * j < q.P ? p0 + 4 * j : grp; u[j] = *reinterpret_cast<const float4*>(q.part + ((size_t)p * 2 + (is_im ? 1 : 0)) * N + 4 * n4); }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (p0 + 4 * j < q.P) { v.x += u[j].x; v.y += u[j].y; v.z += u[j].z; v.w += u[j].w; }
         }
     part[grp][threadIdx.x & 63] = v;
     __syncthreads();
@@ -350,9 +364,14 @@ wgrad_reduce_block(const float* __restrict__ ws, int nz, float* __restrict__ gRe
     float na = 0.f;
     for (int n4 = threadIdx.x; n4 < N / 4; n4 += blockDim.x) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int z = 0; z < nz; ++z) {
-            const float4 u = reinterpret_cast<const float4*>(ws + z * slab + (size_t)src * N)[n4];
-            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        // eight slabs requested before the first is added (same summation order, same bits): as one load per trip of a run-time loop every slab was its
+        // own memory round trip -- 7 of them at B = 256 -- and this 4 MB kernel took 9 us
+        for (int z0 = 0; z0 < nz; z0 += 8) {
+            float4 u[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int z = z0 + j < nz ? z0 + j : nz - 1; u[j] = reinterpret_cast<const float4*>(ws + z * slab + (size_t)src * N)[n4]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (z0 + j < nz) { v.x += u[j].x; v.y += u[j].y; v.z += u[j].z; v.w += u[j].w; }
         }
         reinterpret_cast<float4*>(g + (size_t)k * N)[n4] = v;
         if (stage) reinterpret_cast<float4*>(stage + (size_t)row * N)[n4] = v;      // packed copy [2F][N] of the live rows (data-parallel all-reduce buffer)
