@@ -2,7 +2,9 @@
 
 signaltrain/audio.py:23-49 (sliding_window), :78-196 (normish, pinknoise, randsine, box, expdecay, pluck) and :296-334 (synth_input_sample
 for the compressor's chooser set {0,1,2,4,6,7}, datasets.py:317) with numpy's global generator, draw for draw like the reference, plus the
-item / batch assembly of SynthAudioDataSet.gen_single_chunk (datasets.py:312-334).  The product generates its training data on the GPU
+item / batch assembly of SynthAudioDataSet.gen_single_chunk (datasets.py:312-334).  PINNED: tools/capture_golden_r4.py runs the imported
+reference's synth_input_sample / gen_single_chunk at fixed numpy seeds, asserts this module reproduces them bit for bit and writes
+tests/golden/g11_host_signals.npz (re-checked without the reference by tests/test_oracle_golden.py).  The product generates its training data on the GPU
 (signaltrain_amd/csrc/st_feed.h, signaltrain_amd/audio_device.py); these functions are what the distributional tests of that feed compare against
 and what the long-file inference test windows its signal with.  Only tests/ import this module."""
 import numpy as np
@@ -94,7 +96,8 @@ def synth_input_sample(t, chooser=None, randfunc=np.random.rand, t0_fac=None):
     elif chooser == 6:
         y = box(t, t0_fac=t0_fac) * (2 * np.random.rand(n) - 1)
     elif chooser == 7:
-        y = pluck(t, t0_fac=t0_fac) + (0.3 * randfunc() + 0.1) * pinknoise(n)
+        amp_n = 0.3 * randfunc() + 0.1            # drawn BEFORE pluck() (audio.py:317-318)
+        y = pluck(t, t0_fac=t0_fac) + amp_n * pinknoise(n)
     else:
         raise NotImplementedError(f"signaltrain_amd.audio: test signal {chooser} is not built (compressor set is 0,1,2,4,6,7)")
     return y * np.random.choice([-1, 1]) + np.random.rand(n) * 1e-8

@@ -358,3 +358,24 @@ def test_g10_reference_checkpoint_layout(golden_dir, tmp_path):
     raw = torch.load(f2, weights_only=False)
     assert tuple(raw.keys()) == tuple(g["top_keys"]) and list(raw["state_dict"].keys()) == names
     assert sorted(raw["optimizer"]["param_groups"][0].keys()) == sorted(k for k in g["opt_group_keys"] if k != "momentum")
+
+
+def test_g11_host_signal_generators(golden_dir):
+    """oracle/host_audio.py (the checker of the device feed's signal families) against the reference's synth_input_sample (audio.py:296-334) and
+    SynthAudioDataSet.gen_single_chunk (datasets.py:312-334) at fixed seeds of numpy's global generator: bit for bit (tools/capture_golden_r4.py)."""
+    from oracle import host_audio as H
+    from signaltrain_amd import audio as A
+    g = load(golden_dir, "g11_host_signals.npz")
+    n, sr = int(g["n"]), int(g["sr"])
+    t = np.arange(n, dtype=np.float32) / sr
+    for c in g["choosers"]:
+        for s in g["seeds"]:
+            np.random.seed(int(s))
+            y = H.synth_input_sample(t, int(c))
+            assert np.array_equal(y, g[f"sig_c{c}_s{s}"]), f"chooser {c} seed {s}"
+    eff = A.Compressor_4c()
+    for s in g["item_seeds"]:
+        np.random.seed(int(s))
+        x, y, k = H.gen_single_chunk(t, eff, n // 2, augment=True)
+        assert np.array_equal(np.asarray(k, np.float64), g[f"item_k_s{s}"]) and np.array_equal(np.asarray(x, np.float64), g[f"item_x_s{s}"])
+        close(y, g[f"item_y_s{s}"], 2e-6, f"compressor target, item seed {s}")
