@@ -17,7 +17,9 @@ if __name__ == "__main__":
     p.add_argument('--gpus', type=int, default=None, help="data-parallel world size this job is meant to run on; launch with "
                    "`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 run_train.py --gpus N ...` "
                    "(one process per GPU); checked against WORLD_SIZE")
-    p.add_argument('--device-feed', action='store_true', help="generate every training minibatch on the GPU (signal generators + compressor kernels) and keep the validation set in HBM, instead of the 10-worker CPU DataLoader")
+    p.add_argument('--device-feed', action='store_true', default=True, help="(default) generate every training minibatch on the GPU (st_synth_comp4c) and keep the validation set in HBM")
+    p.add_argument('--host-feed', dest='device_feed', action='store_false', help="the reference's feed instead: a torch DataLoader with 10 CPU workers over the Dataset items")
+    p.add_argument('--resume-optimizer', action='store_true', help="restore Adam's moments (and, if the checkpoint belongs to this schedule, the position in the run) from --checkpoint")
     p.add_argument('-b', '--batch', type=int, help="batch size (per GPU)", default=200)
     p.add_argument('--checkpoint', help='name of checkpoint .tar file to start from', default='modelcheckpoint.tar')
     p.add_argument('-c', '--compand', help='accepted for compatibility', action='store_true')
@@ -49,6 +51,6 @@ if __name__ == "__main__":
     train.train(epochs=args.epochs, n_data_points=args.num, batch_size=args.batch, device=torch.device("cuda", local),
                 effect=effect, datapath=(args.path if args.effect == 'files' else None), sr=args.sr, scale_factor=args.scale, shrink_factor=args.shrink, apex_opt=args.apex,
                 target_type=args.target, lr_max=args.lrmax, in_checkpointname=args.checkpoint, compand=args.compand,
-                compute_dtype=args.dtype, device_feed=args.device_feed)
+                compute_dtype=args.dtype, device_feed=args.device_feed, resume_optimizer=args.resume_optimizer)
     if dist.is_initialized():
         dist.destroy_process_group()

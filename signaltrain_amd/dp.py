@@ -112,7 +112,7 @@ class DataParallel:
     def mean_loss_lagged(self):
         """The loss for the progress line WITHOUT draining the GPU queue: the scalars of this call are copied to pinned host memory behind the
         work issued so far, and the value RETURNED is the one requested by the previous call (i.e. it lags by one reporting interval, 10
-        steps in train_loop; nan on the first call).  The reference reads loss.item() every 10 batches (train.py:125), which stalls the
+        steps in train_loop; None on the first call -- "no value yet", so that a genuinely NaN loss still reaches the log).  The reference reads loss.item() every 10 batches (train.py:125), which stalls the
         host until the queue is empty -- at 0.3 ms per step that stall is a tenth of the loop.  Single-process only (data parallel needs
         the collective of mean_loss)."""
         eng = self.engine
@@ -122,7 +122,7 @@ class DataParallel:
             self._pin = [torch.zeros(8, dtype=torch.float32).pin_memory(), torch.zeros(8, dtype=torch.float32).pin_memory()]
             self._pin_ev = [None, None]; self._pin_i = 0
         i = self._pin_i
-        prev = float("nan")
+        prev = None
         j = 1 - i
         if self._pin_ev[j] is not None:
             self._pin_ev[j].synchronize()                # recorded >= one interval ago: long done

@@ -103,7 +103,7 @@ def _train_loop(dp, model, engine, effect, device, epochs, batch_size, lr_sched,
                 # the progress line shows the loss of the PREVIOUS reporting point (no queue drain, dp.mean_loss_lagged); f16 needs the
                 # overflow counter now anyway, and data parallel its collective
                 lval = dp.mean_loss() if (engine.compute_dtype.startswith("f16") or dp.world > 1) else dp.mean_loss_lagged()
-                if lval == lval:
+                if lval is not None:                                 # None = the lagged read has no value yet; a NaN loss is logged as nan (train.py:125-129)
                     n_loss += 1
                     avg_loss = beta * avg_loss + (1 - beta) * lval
                     smoothed_loss = avg_loss / (1 - beta ** (status_every * n_loss))
@@ -140,16 +140,17 @@ def _train_loop(dp, model, engine, effect, device, epochs, batch_size, lr_sched,
 
 def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=None, plot_every=10, cp_every=25, sr=44100,
           datapath=None, scale_factor=1, shrink_factor=4, apex_opt="O0", target_type="stream", lr_max=1e-4,
-          in_checkpointname='modelcheckpoint.tar', compand=False, num_workers=10, device_feed=False, compute_dtype=None,
+          in_checkpointname='modelcheckpoint.tar', compand=False, num_workers=10, device_feed=True, compute_dtype=None,
           resume_optimizer=False):
     """train.py:167-278.  datapath: directory with Train/ and Val/ wav pairs (datasets.AudioFileDataSet, the reference's
     file feed, e.g. the LA2A set of BASELINE configs[3]; pass effect=audio.FileEffect(datapath)); compand is refused by that dataset.
     apex_opt: "O0" = fp32 (the parity path); "O1" / "O2" / "O3" = the reference's Apex mixed precision (train.py:254-255),
     here float16 operands with fp32 accumulation, a loss scale and the L1 clip over all parameters (train.py:133-136) --
     compute_dtype "f16_all".  Extra keywords (not in the reference): compute_dtype overrides the arithmetic ("f32", "bf16",
-    "bf16_all", "f16", "f16_all"; bf16 is the MI355X-native choice and needs no loss scale); device_feed: the synthetic task's minibatches are
-    always generated on the GPU (csrc/st_feed.h; "recycle": one device-resident training set re-sampled each epoch), for file datasets
-    device_feed=True gathers the windows on the device instead of the CPU DataLoader; resume_optimizer: False (default, the reference's behaviour: train `epochs`
+    "bf16_all", "f16", "f16_all"; bf16 is the MI355X-native choice and needs no loss scale); device_feed: True (default) = the synthetic task's minibatches are
+    generated on the GPU (csrc/st_feed.h; "recycle": one device-resident training set re-sampled each epoch) and file datasets gather their windows on the
+    device; False = the reference's feed, a torch DataLoader with `num_workers` CPU workers over the Dataset's __getitem__ (two to three orders of magnitude
+    below the step rate; printed when chosen); resume_optimizer: False (default, the reference's behaviour: train `epochs`
     more epochs from the loaded weights with a fresh optimizer and schedule -- its fine-tune workflow); True restores Adam's moments
     from the checkpoint (which the reference saves but never reads back, train.py:229) and, if the checkpoint belongs to THIS schedule
     (its epoch counter is below `epochs` and its step count lies inside the 1-cycle table), also the position in the run."""
@@ -176,19 +177,6 @@ def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=N
     seed_data_streams(dist.get_rank() if dist.is_initialized() else 0)            # identical weights above, distinct minibatches below
     start_epoch, start_iter, lr_resume = 0, 0, None
     lr_sched, mom_sched = learningrate.get_1cycle_schedule(lr_max=lr_max, n_data_points=n_data_points, epochs=epochs, batch_size=batch_size)
-    if state_dict != {} and resume_optimizer and rv.get('optimizer'):
-        lr_resume = engine.load_optimizer_state_dict(rv['optimizer'])
-        if lr_resume is not None:
-            ck_epoch, ck_iter = int(rv.get('epoch', 0)), engine.step_count
-            per_epoch = max(n_data_points // batch_size, 1)
-            if ck_epoch < epochs and ck_iter < len(lr_sched) and ck_iter == ck_epoch * per_epoch:
-                start_epoch, start_iter = ck_epoch, ck_iter
-                print(f"Optimizer state restored: {start_iter} steps done, resuming at epoch {start_epoch + 1} with lr = {lr_resume:.3e}")
-            else:
-                # a finished run, or a checkpoint of another n_data_points / batch_size / epochs: its position means nothing in this schedule
-                print(f"WARNING: the checkpoint's position (epoch {ck_epoch}, step {ck_iter}) does not belong to this schedule ({epochs} epochs of "
-                      f"{per_epoch} steps): Adam's moments are kept, epoch / step / learning rate restart at the beginning")
-                lr_resume = None
     if datapath is not None:
         # pre-recorded input / target pairs (train.py:241-246; BASELINE configs[3]): windows gathered on the device from the preloaded audio
         dataset = datasets.AudioFileDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points, path=datapath + "/Train/", y_size=out_chunk_size,
@@ -206,17 +194,24 @@ def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=N
     else:
         # synthetic effect: every training minibatch is generated ON the GPU (one st_synth_comp4c launch per minibatch for the comp_4c
         # effects), as the reference's non-recycled dataset does on its CPU workers (train.py:233-248); device_feed="recycle": one dataset
-        # generated up front and re-sampled by index each epoch (the reference's recycle=True mode).  There is no CPU-worker path for the
-        # synthetic task (device_feed=False is accepted for compatibility): ~100 windows/s per core against 3-8 x 10^5 per second for the step.
+        # generated up front and re-sampled by index each epoch (the reference's recycle=True mode); device_feed=False: the reference's CPU-worker
+        # DataLoader (~100 windows/s per core against 3-8 x 10^5 per second for the step).
         # Validation: the reference's recycled set (train.py:237-238), resident in HBM.
         dataset = datasets.SynthAudioDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points, y_size=out_chunk_size, augment=True)
         t0 = time.time()
-        if device_feed == "recycle":
+        if not device_feed:
+            # the reference's own feed (train.py:233-248): CPU workers behind a DataLoader, items from SynthAudioDataSet.__getitem__
+            print(f"device_feed=False: training minibatches come from {num_workers} CPU DataLoader workers (reference-style feed; expect ~10^2-10^3 windows/s)")
+            dataloader = DataLoader(dataset, batch_size=batch_size, num_workers=num_workers, shuffle=True, worker_init_fn=datasets.worker_init, drop_last=True)
+        elif device_feed == "recycle":
             dev_ds = datasets.DeviceRecycledDataSet(chunk_size, effect, sr=sr, datapoints=n_data_points, y_size=out_chunk_size, augment=True, device=device)
 
             class _DevLoader:                      # iterable with the DataLoader's per-epoch semantics
                 def __iter__(self_inner):
                     return dev_ds.batches(batch_size, shuffle=True)
+
+                def __len__(self_inner):
+                    return n_data_points // batch_size
             dataloader = _DevLoader()
         else:
             dataloader = datasets.DeviceSynthLoader(dataset, batch_size, device)
@@ -227,6 +222,22 @@ def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=N
                 return val_ds.batches(batch_size, shuffle=False)
         dataloader_val = _ValLoader()
         print(f"device-side data feed ready in {time.time() - t0:.1f} s ({n_data_points // 4} validation windows resident in HBM)")
+    if state_dict != {} and resume_optimizer and rv.get('optimizer'):
+        lr_resume = engine.load_optimizer_state_dict(rv['optimizer'])
+        if lr_resume is not None:
+            ck_epoch, ck_iter = int(rv.get('epoch', 0)), engine.step_count
+            try:
+                per_epoch = max(len(dataloader), 1)                 # the loader's own length (file datasets, recycled sets, drop_last)
+            except TypeError:
+                per_epoch = max(n_data_points // batch_size, 1)
+            if ck_epoch < epochs and ck_iter < len(lr_sched) and ck_iter == ck_epoch * per_epoch:
+                start_epoch, start_iter = ck_epoch, ck_iter
+                print(f"Optimizer state restored: {start_iter} steps done, resuming at epoch {start_epoch + 1} with lr = {lr_resume:.3e}")
+            else:
+                # a finished run, or a checkpoint of another n_data_points / batch_size / epochs: its position means nothing in this schedule
+                print(f"WARNING: the checkpoint's position (epoch {ck_epoch}, step {ck_iter}) does not belong to this schedule ({epochs} epochs of "
+                      f"{per_epoch} steps): Adam's moments are kept, epoch / step / learning rate restart at the beginning")
+                lr_resume = None
     logfilename = "vl_avg_out.dat"
     open(logfilename, "a").close()
     train_loop(model, engine, effect, device, epochs, batch_size, lr_sched, mom_sched, dataloader, dataloader_val,

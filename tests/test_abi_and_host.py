@@ -121,11 +121,20 @@ def test_audio_and_dataset_contract(golden_dir):
     x, yy, k = host_audio.batch(2, 8192, audio.Compressor_4c(), 2048)
     assert x.shape == (2, 8192) and yy.shape == (2, 2048) and k.shape == (2, 4) and x.dtype == np.float32 and k.dtype == np.float32
     assert np.all(np.abs(k) <= 0.5) and np.abs(x).max() < 1.5
-    # the product's dataset has no per-item host generator: minibatches are made on the GPU (batch_device)
-    ds = datasets.SynthAudioDataSet(8192, audio.Compressor_4c(), y_size=2048)
+    # the torch Dataset contract of the reference (datasets.py:305-334): items behind __getitem__ / a DataLoader, recycle=True keeps them fixed.
+    # Here (no GPU) the items come from the CPU-device form of the batched generators + the effect's host go()
+    ds = datasets.SynthAudioDataSet(8192, audio.Compressor_4c(), y_size=2048, item_chunk=4)
     assert len(ds) == 8000
-    with pytest.raises(NotImplementedError):
-        ds[0]
+    xi, yi, ki = ds[0]
+    assert xi.shape == (8192,) and yi.shape == (2048,) and ki.shape == (4,) and xi.dtype == np.float32 and ki.dtype == np.float32
+    assert np.all(np.abs(ki) <= 0.5) and 0.05 < np.abs(xi).max() < 1.5 and np.isfinite(yi).all()
+    # the target IS the effect of the input at those knobs (up to the polarity flip of do_augment, applied to both)
+    yy2 = audio.Compressor_4c().go(xi, ki)[0][-2048:]
+    assert np.abs(yy2 - yi).max() < 1e-5
+    xb, yb, kb = next(iter(torch.utils.data.DataLoader(ds, batch_size=3, num_workers=0)))
+    assert tuple(xb.shape) == (3, 8192) and tuple(yb.shape) == (3, 2048) and tuple(kb.shape) == (3, 4)
+    rec = datasets.SynthAudioDataSet(8192, audio.Compressor_4c(), datapoints=5, y_size=2048, recycle=True, item_chunk=4)
+    assert rec.x.shape == (5, 8192) and rec.y.shape == (5, 2048) and np.array_equal(rec[3][0], rec[3][0]) and not np.array_equal(rec[3][0], rec[4][0])
 
 
 def test_cpu_port_matches_oracle():
