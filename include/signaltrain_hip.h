@@ -80,8 +80,19 @@ int st_kp(int F);
 const char* st_last_error(void);
 int st_version(void);
 
-/* Tuning knob (process-wide): k-tile depth of the GEMM family, 16 (default) or 32. */
+/* Diagnostic switches (process-wide; NEVER set by the product path): st_set_tuning(code) selects kernel variants kept for comparison
+ * (codes: st_api.hip).  They are one readable state: st_get_tuning / st_tuning_defaults fill out[0..n) in a fixed order and return the
+ * number of switches (out may be NULL), st_reset_tuning restores the shipped defaults; the test-suite asserts the state is at the
+ * defaults after every test.  Timing-only ablations (results invalid) exist only in -DST_DIAG builds. */
 int st_set_tuning(int bk);
+int st_get_tuning(int* out, int n);
+int st_tuning_defaults(int* out, int n);
+int st_reset_tuning(void);
+/* The arithmetic a call with these dims ACTUALLY runs (an ST_PREC_* code).  Equal to d->prec except where a geometry cannot take the
+ * requested level: the wide autoencoder path (T > 32 or OT > 16, e.g. the 65536-sample window) needs an even batch for 16-bit Linear
+ * layers (its K = B * 528 reduction runs in 32-deep k-tiles); with an odd B its autoencoder layers stay fp32 and this returns
+ * ST_PREC_BF16 / ST_PREC_F16 for ST_PREC_BF16_ALL / ST_PREC_F16_ALL.  The Python engine warns and reports it (StepEngine.effective_dtype). */
+int st_effective_prec(const st_dims* d);
 /* Timing-only ablation switches for diagnostics (bit0: skip k-loop loads/stores, bit1: skip barriers, bit2: skip MFMAs);
  * results are INVALID when non-zero.  Never set by the product path. */
 int st_set_debug(int v);
@@ -253,13 +264,21 @@ int st_dp_clip_adam(const st_dims* d, float* params, float* grads, float* m, flo
  *   st_dp_train_step  one whole data-parallel optimisation step driven from C (no host code between the buckets):
  *                     st_loss_backward_p1 -> all-reduce grads[offs[2]..) || st_loss_backward_p2_staged -> all-reduce the
  *                     packed live analysis rows (`stage`, 2*F*N floats, caller-owned) -> st_unstage_analysis ->
- *                     st_dp_clip_adam(1/world).  p == NULL or world == 1 (and !force_exchange): plain st_train_step. */
+ *                     st_dp_clip_adam(1/world).  p == NULL or world == 1 (and bit 0 of force_exchange clear): plain st_train_step.
+ *                     force_exchange is a bit set: 1 = run the exchange even with one rank (tests, overhead measurements);
+ *                     2 = split the LAST exchange by basis -- the real rows' all-reduce runs under the weight-gradient GEMM of the imaginary
+ *                         rows, so F*N values (2.1 MB) stay exposed instead of 2*F*N;
+ *                     4 = the last exchange on bfloat16 values (ncclBfloat16; first half of `stage`), honoured only where the autoencoder
+ *                         layers already run in 16 bits (ST_PREC_*_ALL): half the exposed bytes.
+ *                     The sum of the synthesis weight-gradient slabs runs on the communicator stream, beside the autoencoder backward.
+ *   st_dp_rccl_version  ncclGetVersion of the bound library (0 if it exports none): evidence for multi-GPU bench lines. */
 typedef struct st_dp st_dp;
 int st_dp_unique_id(void* id128);
 int st_dp_init(const void* id128, int rank, int world, st_dp** out);
 int st_dp_destroy(st_dp* p);
 int st_dp_rank(const st_dp* p);
 int st_dp_world(const st_dp* p);
+int st_dp_rccl_version(const st_dp* p);
 int st_dp_allreduce(st_dp* p, float* buf, int64_t n, void* stream);
 int st_dp_broadcast(st_dp* p, float* buf, int64_t n, int root, void* stream);
 int st_dp_sync(st_dp* p, void* stream);

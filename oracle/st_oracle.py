@@ -347,7 +347,10 @@ def _ae_bwd(dout, v, knobs, P, prefix, mode, hs):
         da = dh * elu_grad_from_out(h_out[:, :, :dh.shape[2]])   # hs[4] also carries the knob columns
         da2 = da.reshape(-1, da.shape[2])
         grads[f"{prefix}.{name}.weight"] = _ra(da2).T @ _ra(h_in.reshape(-1, h_in.shape[2]))
-        grads[f"{prefix}.{name}.bias"] = da2.sum(0)
+        # wide geometries (T > 32 or OT > 16: st_ae_wide.h) run layers 1 and 9 as GEMMs in which the bias gradient rides along as a row of ones,
+        # i.e. it is the sum of the ROUNDED dA under AE_ROUND; everywhere else it is summed from the fp32 accumulators
+        wide_gemm_layer = (T > 32 or OT > 16) and li in (0, len(AE_LAYERS) - 1)
+        grads[f"{prefix}.{name}.bias"] = (_ra(da2) if wide_gemm_layer else da2).sum(0)
         dh = _ra(da) @ _ra(W)
         if name == "fnn_addknobs":
             dh = dh[:, :, :W.shape[0]]                       # drop the knob columns (no grad to knobs)

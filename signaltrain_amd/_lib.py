@@ -40,6 +40,10 @@ SIGNATURES = {
     "st_last_error": (C.c_char_p, []),
     "st_version": (_i, []),
     "st_set_tuning": (_i, [_i]),
+    "st_get_tuning": (_i, [C.POINTER(C.c_int), _i]),
+    "st_tuning_defaults": (_i, [C.POINTER(C.c_int), _i]),
+    "st_reset_tuning": (_i, []),
+    "st_effective_prec": (_i, [_D]),
     "st_set_debug": (_i, [_i]),
     "st_debug_read_stage_cycles": (_i, [C.POINTER(C.c_uint64)]),
     "st_profile_enable": (_i, [_i]),
@@ -99,6 +103,7 @@ SIGNATURES = {
     "st_dp_destroy": (_i, [_p]),
     "st_dp_rank": (_i, [_p]),
     "st_dp_world": (_i, [_p]),
+    "st_dp_rccl_version": (_i, [_p]),
     "st_dp_allreduce": (_i, [_p, _p, C.c_int64, _p]),
     "st_dp_broadcast": (_i, [_p, _p, C.c_int64, _i, _p]),
     "st_dp_sync": (_i, [_p, _p]),

@@ -204,14 +204,20 @@ static int g_wg_mode_set(int v);
 static int g_wsplit_max = 16, g_wsplit_div = 200, g_an_waves = 4, g_syn_split = 3, g_frs_split = 3, g_wide_fused = 1, g_wsplit_half = 0;      // frames: 3, 4 measured equal, 6 slower (only 66 k-tiles to split)
 extern "C" int st_set_tuning(int bk)
 {
-    if (bk >= 96800 && bk < 96928) { g_g16_abl = bk - 96800; return ST_OK; }      // timing-only ablations of the 16-bit analysis GEMM (bits 3..5: its k-loop)
+#ifdef ST_DIAG      // timing-only ablations (results INVALID by construction): compiled only into diagnostic builds (make EXTRA=-DST_DIAG), never into the product library
+    if (bk >= 96800 && bk < 96928) { g_g16_abl = bk - 96800; return ST_OK; }      // 16-bit analysis GEMM (bits 3..5: its k-loop)
+#else
+    if ((bk >= 96800 && bk < 96928) || (bk >= 9680 && bk < 9690)) return st_fail(ST_ERR_ARG, "st_set_tuning(%d): timing-only ablation, needs a -DST_DIAG build", bk);
+#endif
     if (bk >= 9960) { g_wide_pair = bk - 9960; return ST_OK; }
     if (bk >= 9950 && bk < 9960) { g_nt128 = bk - 9950; return ST_OK; }
     if (bk >= 9900) { g_wide_dvp = bk - 9900; return ST_OK; }
     if (bk >= 9800) { g_nt_mi = bk - 9800; return ST_OK; }
     if (bk >= 9700) { g_g16_split = bk - 9700; return ST_OK; }
     if (bk >= 9690 && bk < 9700) { g_g16_dma = bk - 9690; return ST_OK; }
+#ifdef ST_DIAG
     if (bk >= 9680 && bk < 9690) { g_g16_abl = bk - 9680; return ST_OK; }
+#endif
     if (bk >= 9600) { const int v = bk - 9600; if (v == 32 || v == 64) g_g16_bk = v; else g_g16 = v; return ST_OK; }
     if (bk >= 9500) { const int v = bk - 9500; if (v == 16 || v == 32) g_tn_bk = v; else g_tn128 = v; return ST_OK; }
     if (bk >= 9400) { g_pl_bf16 = bk - 9400; return ST_OK; }
@@ -231,6 +237,36 @@ extern "C" int st_set_tuning(int bk)
     if (bk >= 100) return g_wg_mode_set(bk - 100);           // 100 / 101: weight-gradient tile mode (diagnostics)
     if (bk != 16 && bk != 32) return st_fail(ST_ERR_ARG, "bk must be 16 or 32"); g_bk = bk; g_an_bk = bk; return ST_OK;
 }
+// The diagnostic switches above as ONE readable state: st_get_tuning() reports them in a fixed order, st_reset_tuning() restores the shipped
+// defaults.  The product path never sets them; tests/conftest.py asserts after every test that the state is back at ST_TUNING_DEFAULTS
+// (a wrong default can then not ship unnoticed, and a test cannot leak a switch into the next one).
+#define ST_TUNING_LIST(X) X(g_dbg, 0) X(g_ae_split, -1) X(g_pl_bf16, 0) X(g_wg_split, 0) X(g_pl_dgrad, 0) X(g_pl_shape, 3) X(g_g16, 1) X(g_g16_bk, 64) X(g_g16_dma, 0) \
+    X(g_g16_abl, 0) X(g_g16_split, 0) X(g_nt128, 1) X(g_tn128, 1) X(g_tn_bk, 32) X(g_frs_nt, 1) X(g_xt, 0) X(g_wide_pair, 1) X(g_wide_dvp, 1) X(g_nt_mi, 0) X(g_an_bk, 32) \
+    X(g_bk, 16) X(g_wsplit_max, 16) X(g_wsplit_div, 200) X(g_an_waves, 4) X(g_syn_split, 3) X(g_frs_split, 3) X(g_wide_fused, 1) X(g_wsplit_half, 0) X(g_wg_mode, 0)
+static int g_wg_mode = 0;
+extern "C" int st_get_tuning(int* out, int n)
+{
+    int i = 0;
+#define X(v_, d_) if (out && i < n) out[i] = v_; ++i;
+    ST_TUNING_LIST(X)
+#undef X
+    return i;                      // number of switches (call with out = NULL to size the array)
+}
+extern "C" int st_tuning_defaults(int* out, int n)
+{
+    int i = 0;
+#define X(v_, d_) if (out && i < n) out[i] = d_; ++i;
+    ST_TUNING_LIST(X)
+#undef X
+    return i;
+}
+extern "C" int st_reset_tuning(void)
+{
+#define X(v_, d_) v_ = d_;
+    ST_TUNING_LIST(X)
+#undef X
+    return ST_OK;
+}
 // Arithmetic of a call = st_dims::prec (ST_PREC_*; round 1 had a process-wide switch here, which raced between engines):
 // half type (0 none / 1 bfloat16 / 2 float16) of the STFT GEMM operands and of the autoencoder layers.
 // gemm_ht: 3 = fp32 operands as three bfloat16 planes (ST_PREC_F32X3; st_gemm.h gemm_half_kernel PL = 3)
@@ -248,7 +284,6 @@ static inline float loss_scale_of(const st_dims* d) { return d->loss_scale > 0.f
 // (half the barriers); every other GEMM of the step is faster with 16 (more workgroups per CU)
 #define ST_GEMM_AN(W_, ...) ST_GEMM_BK(g_an_bk, W_, __VA_ARGS__)
 // weight-gradient GEMMs: g_wg_mode 0 = three waves share a 96x96 tile (32x96 strips), 1 = one wave per 96x96 tile
-static int g_wg_mode = 0;
 static int g_wg_mode_set(int v) { g_wg_mode = v; return ST_OK; }
 // ST_PREC_F32X3: the weight-gradient GEMMs reduce along the ROWS of both operands (k-major staging, 4x4 register transposes); their
 // in-kernel three-plane split measured slower than the fp32 MFMA kernel (176 vs 141 us, 62 vs 55 us at B = 256), so that precision
@@ -641,6 +676,13 @@ extern "C" int st_synthesis_wgrad(const st_dims* d, const float* AA, const float
 // padded to a multiple of 32 columns and K = R operands need R % 32 == 0, else the whole wide path stays fp32 -- wide_ht,
 // a local of every user of ST_WGEMM: 0 fp32 / 1 bf16 / 2 fp16)
 static inline int wide_half_type(const st_dims* d, int R) { return R % 32 == 0 ? ae_ht(d->prec) : 0; }
+extern "C" int st_effective_prec(const st_dims* d)
+{
+    if (!d) return -1;
+    if (ae_is_wide(d) && ae_ht(d->prec) && wide_half_type(d, d->B * (st_kp_of(d->F) / 2)) == 0)
+        return d->prec == ST_PREC_BF16_ALL ? ST_PREC_BF16 : ST_PREC_F16;
+    return d->prec;
+}
 #define ST_WGEMM(...) do { if (wide_ht == 1) stg::launch_half<2, 1>(__VA_ARGS__); else if (wide_ht == 2) stg::launch_half<2, 2>(__VA_ARGS__); \
                            else stg::launch<2, 16>(__VA_ARGS__, g_dbg); } while (0)
 // the same GEMM for both autoencoders: ONE launch in the 16-bit configurations (gemm_half_pair_kernel), two on the fp32 kernel
@@ -939,7 +981,7 @@ extern "C" int st_polar_bwd(const st_dims* d, const float* re, const float* im, 
 // half = -1: both bases in one GEMM (M = KP rows of dG^T); half = 0 / 1: only the real / imaginary basis (M = KP/2), so
 // that in data parallel the first half's all-reduce runs under the second half's GEMM (st_loss_backward_stage).
 static int analysis_wgrad_impl(const st_dims* d, const float* dG, const float* sig, bool padded, float in_scale, float* ws,
-                               float* gWr, float* gWi, float* norm_partial, void* stream, int half = -1, float* stage = nullptr)
+                               float* gWr, float* gWi, float* norm_partial, void* stream, int half = -1, float* stage = nullptr, int stage_bf16 = 0)
 {
     const int KP = st_kp_of(d->F);
     const stg::RowMap ma = stg::live_frames(d->T, d->H, d->N, d->N, d->L);   // all-zero frames contribute nothing
@@ -974,7 +1016,7 @@ static int analysis_wgrad_impl(const st_dims* d, const float* dG, const float* s
     // grid: the gradient rows of this call, then (whole tensor / second half) the Nyquist blocks resp. the unused partial slots
     const int nrows = half < 0 ? 2 * d->F : d->F, extra = half == 0 ? 0 : stm::nyq_blocks(d->N);
     hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(nrows + extra), dim3(256), 0, st_stream(stream),
-                       ws, ns, gWr, gWi, norm_partial, d->N, d->F, KP, 0, half > 0 ? d->F : 0, nrows, stage, nyq);
+                       ws, ns, gWr, gWi, norm_partial, d->N, d->F, KP, 0, half > 0 ? d->F : 0, nrows, stage, nyq, 0, stage_bf16);
     ST_LAUNCHED("analysis_wgrad_reduce");
     return ST_OK;
 }
@@ -1255,20 +1297,21 @@ static int g16_wsplit(const st_dims* d, int R)
 }
 // A: [rows (b, t)][KP] 16-bit (d G or the spectra), B: frames of a padded 16-bit signal whose first N elements are zero (the block of zeros)
 static int wgrad16(const st_dims* d, const unsigned short* A, unsigned SA1, const unsigned short* Bsig, unsigned SB1, const stg::RowMap& map, int R,
-                   float* slabs, int ns, void* stream)
+                   float* slabs, int ns, void* stream, int m0 = 0, int M = -1)      // [m0, m0 + M): the output rows (= columns of A) of this launch; default all KP
 {
     const int KP = st_kp_of(d->F);
+    if (M < 0) M = KP;
     const unsigned short* lo = A < Bsig ? A : Bsig;
     ST_REQ((size_t)(A - lo) + (size_t)R / map.Tv * SA1 + 256 < ((size_t)1 << 30) && (size_t)(Bsig - lo) + (size_t)R / map.Tv * SB1 + 256 < ((size_t)1 << 30) && map.Tv >= 2 &&
            SA1 < (1u << 23) && SB1 < (1u << 23), "16-bit weight-gradient GEMM: operands out of the 32-bit / 24-bit addressing range (B=%d)", d->B);
     stg::TN16Job j;
-    j.base = lo; j.a0 = (unsigned)(A - lo); j.b0 = (unsigned)(Bsig - lo); j.zero = j.b0;
+    j.base = lo; j.a0 = (unsigned)(A - lo) + (unsigned)m0; j.b0 = (unsigned)(Bsig - lo); j.zero = j.b0;
     j.SA1 = SA1; j.SA2 = (unsigned)KP; j.SB1 = SB1; j.SB2 = (unsigned)d->H;
     j.magic = map.magic; j.Tv = map.Tv; j.t_lo = map.t_lo; j.K = R;
-    stg::StoreC ep{slabs, KP, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
+    stg::StoreC ep{slabs + (size_t)m0 * d->N, M, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
     const int ht = gemm_ht(d->prec);
-    if (g_g16_bk == 32) { if (ht == 2) ST_TRY((stg::launch16_tn<2, 32>(j, ep, KP, d->N, ns, st_stream(stream)))); else ST_TRY((stg::launch16_tn<1, 32>(j, ep, KP, d->N, ns, st_stream(stream)))); }
-    else { if (ht == 2) ST_TRY((stg::launch16_tn<2, 64>(j, ep, KP, d->N, ns, st_stream(stream)))); else ST_TRY((stg::launch16_tn<1, 64>(j, ep, KP, d->N, ns, st_stream(stream)))); }
+    if (g_g16_bk == 32) { if (ht == 2) ST_TRY((stg::launch16_tn<2, 32>(j, ep, M, d->N, ns, st_stream(stream)))); else ST_TRY((stg::launch16_tn<1, 32>(j, ep, M, d->N, ns, st_stream(stream)))); }
+    else { if (ht == 2) ST_TRY((stg::launch16_tn<2, 64>(j, ep, M, d->N, ns, st_stream(stream)))); else ST_TRY((stg::launch16_tn<1, 64>(j, ep, M, d->N, ns, st_stream(stream)))); }
     return ST_OK;
 }
 
@@ -1397,7 +1440,7 @@ static int backward_p1(const st_dims* d, const Layout& L, const float* params, f
     ST_TRY(backward_syn(d, L, grads, w, stream, &syn_slabs, &syn_nyq));      // the slab sum rides in a later launch: post_ae_kernel (fused geometries) / wide_grad_finish_kernel (wide ones)
     return backward_ae(d, L, params, grads, knobs, g_mag_hat, g_mag, reg_coef, w, stream, syn_slabs, &syn_nyq);
 }
-static int backward_p2(const st_dims* d, const Layout& L, float* grads, const float* x, WS& w, void* stream, float* stage = nullptr)
+static int backward_p2(const st_dims* d, const Layout& L, float* grads, const float* x, WS& w, void* stream, float* stage = nullptr, int stage_bf16 = 0)
 {
     (void)x;
     if (w.g16) {
@@ -1407,11 +1450,53 @@ static int backward_p2(const st_dims* d, const Layout& L, float* grads, const fl
         ST_LAUNCHED("analysis_wgrad");
         stm::NyqJob nq{}; nq.on = 0;
         hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(st_norm_partials(d)), dim3(256), 0, st_stream(stream),
-                           w.wg, ns, grads + L.offs[0], grads + L.offs[1], w.norm_a, d->N, d->F, KP, 0, 0, 2 * d->F, stage, nq);
+                           w.wg, ns, grads + L.offs[0], grads + L.offs[1], w.norm_a, d->N, d->F, KP, 0, 0, 2 * d->F, stage, nq, 0, stage_bf16);
         ST_LAUNCHED("analysis_wgrad_reduce");
         return ST_OK;
     }
-    return analysis_wgrad_impl(d, w.dG, w.xp, true, 1.0f, w.wg, grads + L.offs[0], grads + L.offs[1], w.norm_a, stream, -1, stage);
+    return analysis_wgrad_impl(d, w.dG, w.xp, true, 1.0f, w.wg, grads + L.offs[0], grads + L.offs[1], w.norm_a, stream, -1, stage, stage_bf16);
+}
+// ONE basis (half 0 = real, 1 = imaginary) of the analysis weight gradient -- its GEMM over that basis' rows and its slab reduce (gradient rows, packed
+// stage rows [half * F, half * F + F)) -- so that the data-parallel exchange of the first basis runs under the GEMM of the second (st_dp_train_step,
+// exchange flag 2): only F * N values (2.1 MB; 1.05 MB bf16-packed) stay exposed behind the last GEMM of the step.  Each half fills the chip with twice
+// the k-slices of the whole-tensor launch (half the tiles), so the two launches together do the work of the one.  nyq_io carries the Nyquist partials'
+// description (128 x 128-tile form: formed for BOTH bases by the first launch) from half 0 to half 1.
+static int analysis_wgrad_half(const st_dims* d, const Layout& L, float* grads, WS& w, int half, float* stage, int stage_bf16, stm::NyqJob* nyq_io, void* stream)
+{
+    const int KP = st_kp_of(d->F), F = d->F, N = d->N, m0 = half ? KP / 2 : 0;
+    const stg::RowMap ma = stg::live_frames(d->T, d->H, d->N, d->N, d->L);
+    const int R = ma.rows(d->B);
+    const int room = (int)((st_wgrad_ws_floats(d) - (size_t)64 * 2 * N) / ((size_t)KP * N));      // slabs the workspace holds (the Nyquist partials sit behind them)
+    const int per = stm::nyq_blocks(N) / 2;
+    int ns;
+    const stg::TNOperand ta{w.dG + m0, (unsigned)(d->T * KP), (unsigned)KP}, tb{w.xp, (unsigned)(d->L + 2 * d->N), (unsigned)d->H};
+    if (w.g16) {
+        const int tiles = ((KP / 2 + 127) / 128) * (N / 128);
+        ns = g_g16_split > 0 ? g_g16_split : (2 * num_cus()) / (tiles > 0 ? tiles : 1);
+        if (ns > R / 128) ns = R / 128; if (ns > room) ns = room; if (ns < 1) ns = 1;
+        ST_TRY(wgrad16(d, w.dG16, (unsigned)(d->T * KP), w.xp16, (unsigned)(d->L + 2 * d->N), ma, R, w.wg, ns, stream, m0, KP / 2));
+        if (!half) { *nyq_io = stm::NyqJob{}; nyq_io->on = 0; }
+    } else if (use_tn128(d, true) && stg::tn128_fits(ta, tb, w.xp, ma, N / 2, N, (size_t)d->B * d->T * KP, (size_t)d->B * (d->L + 2 * d->N))) {
+        const int mh = (N / 2) / 128, tiles = mh * (N / 128);
+        ns = num_cus() / (tiles > 0 ? tiles : 1); if (ns > 16) ns = 16; if (ns > R / 64) ns = R / 64; if (ns > room) ns = room; if (ns < 1) ns = 1;
+        float* part = w.wg + (size_t)room * KP * N;
+        int P = 0;
+        // half 0 also forms the Nyquist partials of BOTH bases (its A origin is column 0: c0 = F - 1, c1 = KP / 2 + F - 1); half 1 has no Nyquist slice
+        if (g_tn_bk == 16) ST_TRY((stg::launch_tn128<16>(ta, tb, w.xp, ma, R, N / 2, mh, (unsigned)(KP / 2), N, w.wg + (size_t)m0 * N, N, (size_t)KP * N, ns, st_stream(stream),
+                                                          half ? nullptr : part, (unsigned)(F - 1), (unsigned)(KP / 2 + F - 1), &P)));
+        else ST_TRY((stg::launch_tn128<32>(ta, tb, w.xp, ma, R, N / 2, mh, (unsigned)(KP / 2), N, w.wg + (size_t)m0 * N, N, (size_t)KP * N, ns, st_stream(stream),
+                                            half ? nullptr : part, (unsigned)(F - 1), (unsigned)(KP / 2 + F - 1), &P)));
+        if (!half) { nyq_io->part = part; nyq_io->P = P; nyq_io->on = 1; }
+    } else {
+        ST_LAUNCHED("analysis_wgrad");
+        if (!half) { *nyq_io = stm::NyqJob{}; nyq_io->on = 0; }
+        return analysis_wgrad_impl(d, w.dG, w.xp, true, 1.0f, w.wg, grads + L.offs[0], grads + L.offs[1], w.norm_a, stream, half, stage, stage_bf16);
+    }
+    ST_LAUNCHED("analysis_wgrad");
+    hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(F + per), dim3(256), 0, st_stream(stream),
+                       w.wg, ns, grads + L.offs[0], grads + L.offs[1], w.norm_a, N, F, KP, 0, half * F, F, stage, *nyq_io, half * per, stage_bf16);
+    ST_LAUNCHED("analysis_wgrad_reduce");
+    return ST_OK;
 }
 static int backward_impl(const st_dims* d, const Layout& L, const float* params, float* grads, const float* x,
                          const float* knobs, const float* g_mag_hat, const float* g_mag, float reg_coef, WS& w, void* stream)
@@ -1778,6 +1863,7 @@ extern "C" int st_dp_init(const void* id128, int rank, int world, st_dp** out)
     hipError_t e = hipStreamCreateWithFlags(&p->cs, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ready[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->wgfree, hipEventDisableTiming);
     if (e != hipSuccess) { rc = st_fail(ST_ERR_LAUNCH, "st_dp_init: stream/event creation: %s", hipGetErrorString(e)); (void)p->CommDestroy(p->comm); delete p; return rc; }
     *out = p;
     return ST_OK;
@@ -1790,12 +1876,16 @@ extern "C" int st_dp_destroy(st_dp* p)
     if (p->comm) (void)p->CommDestroy(p->comm);
     for (int i = 0; i < 4; ++i) if (p->ready[i]) (void)hipEventDestroy(p->ready[i]);
     if (p->done) (void)hipEventDestroy(p->done);
+    if (p->wgfree) (void)hipEventDestroy(p->wgfree);
     if (p->cs) (void)hipStreamDestroy(p->cs);
     delete p;
     return ST_OK;
 }
 extern "C" int st_dp_rank(const st_dp* p) { return p ? p->rank : -1; }
 extern "C" int st_dp_world(const st_dp* p) { return p ? p->world : -1; }
+// ncclGetVersion of the library the communicator is bound to (e.g. 22606), 0 if it does not export one: bench.py prints it beside the world size every
+// rank reports, so that a multi-GPU line carries its own evidence of what the ranks met on
+extern "C" int st_dp_rccl_version(const st_dp* p) { int v = 0; if (p && p->GetVersion && p->GetVersion(&v) == ncclSuccess) return v; return 0; }
 
 // buf (n floats, in place, SUM) is all-reduced on the communicator stream once everything issued so far on `stream` has
 // finished; returns at once.  st_dp_sync makes `stream` wait for all collectives issued since the last sync.
@@ -1806,6 +1896,20 @@ extern "C" int st_dp_allreduce(st_dp* p, float* buf, int64_t n, void* stream)
     ST_HIP(hipEventRecord(ev, st_stream(stream)), "event record");
     ST_HIP(hipStreamWaitEvent(p->cs, ev, 0), "stream wait");
     ST_NCCL(p, p->AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, p->comm, p->cs), "ncclAllReduce");
+    return ST_OK;
+}
+// ... of `n` elements of `dt` on the communicator stream WITHOUT a new compute -> comm dependency (the caller has ordered the stream already)
+static int dp_allreduce_on_cs(st_dp* p, void* buf, int64_t n, ncclDataType_t dt)
+{
+    ST_NCCL(p, p->AllReduce(buf, buf, (size_t)n, dt, ncclSum, p->comm, p->cs), "ncclAllReduce");
+    return ST_OK;
+}
+// compute -> comm: everything issued so far on `stream` precedes what is issued on the communicator stream from here on
+static int dp_fork(st_dp* p, void* stream)
+{
+    hipEvent_t ev = p->ready[p->n_issued & 3]; p->n_issued++;
+    ST_HIP(hipEventRecord(ev, st_stream(stream)), "event record");
+    ST_HIP(hipStreamWaitEvent(p->cs, ev, 0), "stream wait");
     return ST_OK;
 }
 extern "C" int st_dp_broadcast(st_dp* p, float* buf, int64_t n, int root, void* stream)
@@ -1834,40 +1938,63 @@ extern "C" int st_dp_train_step(st_dp* p, const st_dims* d, float* params, float
                                 const float* x, const float* knobs, const float* y_true, void* ws, float* scalars,
                                 float lr, float beta1, float beta2, float eps, int step, int force_exchange, void* stream)
 {
-    if (!p || (p->world == 1 && !force_exchange))
+    if (!p || (p->world == 1 && !(force_exchange & 1)))
         return st_train_step(d, params, grads, m, v, x, knobs, y_true, ws, scalars, lr, beta1, beta2, eps, step, stream);
     Layout L; ST_TRY(make_layout(d, &L));
     ST_REQ(stage, "st_dp_train_step: null staging buffer");
     ST_REQ(params && grads && x && knobs && y_true && ws, "st_dp_train_step: null pointer");
     const float gs = (1.0f / (float)p->world) / loss_scale_of(d);          // 1/world and the loss scale leave the gradient together
-    // Three exchanges, each issued the moment its gradients are final (the communicator stream orders them):
+    // force_exchange is a bit set: 1 = run the exchange even with one rank; 2 = split the LAST exchange by basis (real rows under the GEMM of the imaginary
+    // ones: 2.1 MB exposed instead of 4.2); 4 = that exchange on bfloat16 values (only where the autoencoder layers already run in 16 bits: *_ALL)
+    const bool split_last = (force_exchange & 2) != 0;
+    const int pack16 = ((force_exchange & 4) != 0 && ae_ht(d->prec) != 0) ? 1 : 0;
+    // Exchanges, each issued the moment its gradients are final (the communicator stream orders them):
     //   synthesis bases (8.4 MB)  -- after their weight-gradient GEMM, BEFORE the autoencoder backward: hidden behind the longest
-    //                                kernels of the step (autoencoder backward + polar backward + analysis weight gradient);
+    //                                kernels of the step (autoencoder backward + polar backward + analysis weight gradient); the sum of
+    //                                the GEMM's split-K slabs itself runs ON the communicator stream, beside the autoencoder backward
+    //                                (round 3 ran it in line: a 9 us launch on the critical path that the single-GPU step folds into post_ae_kernel);
     //   autoencoders (67 KB)      -- after the autoencoder backward;
-    //   analysis bases            -- the 2F live rows, packed (4.2 MB), after the last GEMM of the step: the exposed one.
+    //   analysis bases            -- the 2F live rows, packed (4.2 MB), after the last GEMM of the step: the exposed one (split / packed: see the flags).
+    WS w; carve(d, ws, &w);
+    w.g16 = use_g16(d);
     {
-        WS w; carve(d, ws, &w);
-        w.g16 = use_g16(d);
         prof_mark("begin", stream);
         ST_TRY(forward_impl(d, L, params, x, knobs, y_true, nullptr, nullptr, nullptr, w, true, stream));
         const float reg_coef = loss_scale_of(d) * (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);
-        ST_TRY(backward_syn(d, L, grads, w, stream));                                  // slab reduce NOT deferred: the tensors are final here
-        ST_TRY(st_dp_allreduce(p, grads + L.offs[2], L.offs[4] - L.offs[2], stream));
+        int syn_slabs = 0; stm::NyqJob syn_nyq{}; syn_nyq.on = 0;
+        ST_TRY(backward_syn(d, L, grads, w, stream, &syn_slabs, &syn_nyq));             // GEMMs only; the slabs are summed on the communicator stream
+        ST_TRY(dp_fork(p, stream));
+        hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(st_norm_partials(d)), dim3(256), 0, p->cs,
+                           w.wg, syn_slabs, grads + L.offs[2], grads + L.offs[3], w.norm_s, d->N, d->F, L.KP, 1, 0, 2 * d->F, (float*)nullptr, syn_nyq);
+        ST_HIP(hipEventRecord(p->wgfree, p->cs), "event record");                       // the analysis weight-gradient GEMM reuses the slab buffer
+        ST_TRY(dp_allreduce_on_cs(p, grads + L.offs[2], L.offs[4] - L.offs[2], ncclFloat32));
         // The clip norm is that of the REDUCED, 1/world-scaled gradient.  The two ranges whose exchange is hidden get their |g| partials on the communicator
         // stream right behind their collective (hidden as well); only the analysis rows' share is formed after the exposed collective, in the pass that
         // copies them back (unstage_l1_kernel).  Same kernels, same order, same data on every rank: the norm is bit-identical across ranks.
         hipLaunchKernelGGL(stm::l1_partial_kernel, dim3(st_norm_partials(d)), dim3(256), 0, p->cs, grads + L.offs[2], L.offs[4] - L.offs[2], gs, w.norm_s);
-        ST_TRY(backward_ae(d, L, params, grads, knobs, nullptr, nullptr, reg_coef, w, stream));
+        ST_TRY(backward_ae(d, L, params, grads, knobs, nullptr, nullptr, reg_coef, w, stream, 0, nullptr));
         ST_TRY(st_dp_allreduce(p, grads + L.offs[4], L.total - L.offs[4], stream));
         if (d->clip_all) hipLaunchKernelGGL(stm::l1_partial_kernel, dim3(NORM_E_PARTIALS), dim3(256), 0, p->cs, grads + L.n_stft, L.total - L.n_stft, gs, w.norm_e);
+        ST_HIP(hipStreamWaitEvent(st_stream(stream), p->wgfree, 0), "stream wait");
     }
-    ST_TRY(st_loss_backward_p2_staged(d, grads, stage, x, ws, scalars, stream));
-    ST_TRY(st_dp_allreduce(p, stage, (int64_t)2 * d->F * d->N, stream));
+    const int64_t half_n = (int64_t)d->F * d->N;
+    if (!split_last) {
+        ST_TRY(backward_p2(d, L, grads, x, w, stream, stage, pack16));
+        ST_TRY(dp_fork(p, stream));
+        ST_TRY(dp_allreduce_on_cs(p, stage, 2 * half_n, pack16 ? ncclBfloat16 : ncclFloat32));
+    } else {
+        stm::NyqJob nyq{}; nyq.on = 0;
+        for (int h = 0; h < 2; ++h) {
+            ST_TRY(analysis_wgrad_half(d, L, grads, w, h, stage, pack16, &nyq, stream));
+            ST_TRY(dp_fork(p, stream));
+            void* part = pack16 ? (void*)(reinterpret_cast<unsigned short*>(stage) + (size_t)h * half_n) : (void*)(stage + (size_t)h * half_n);
+            ST_TRY(dp_allreduce_on_cs(p, part, half_n, pack16 ? ncclBfloat16 : ncclFloat32));
+        }
+    }
     ST_TRY(st_dp_sync(p, stream));
     {
-        WS w; carve(d, ws, &w);
         const int np = st_norm_partials(d);
-        hipLaunchKernelGGL(stm::unstage_l1_kernel, dim3(2 * d->F), dim3(256), 0, st_stream(stream), stage, grads + L.offs[0], grads + L.offs[1], d->F, d->N, gs, w.norm_a, np);
+        hipLaunchKernelGGL(stm::unstage_l1_kernel, dim3(2 * d->F), dim3(256), 0, st_stream(stream), stage, grads + L.offs[0], grads + L.offs[1], d->F, d->N, gs, w.norm_a, np, pack16);
         ST_LAUNCHED("unstage_l1");
         stm::FinArgs f = fin_args(d, w.loss_p, w.reg_p, w.norm_a, w.norm_s, 1.0f);
         if (d->clip_all) { f.norm_e = w.norm_e; f.n_ne = NORM_E_PARTIALS; }

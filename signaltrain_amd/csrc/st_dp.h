@@ -23,10 +23,12 @@ struct st_dp {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
     const char* (*GetErrorString)(ncclResult_t);
+    ncclResult_t (*GetVersion)(int*);     // optional (evidence only: bench.py prints which RCCL the ranks met on)
     ncclComm_t comm;
     int rank, world;
     hipStream_t cs;               // communicator stream: collectives run here, beside the compute stream
     hipEvent_t ready[4], done;    // compute -> comm ("bucket final") and comm -> compute ("all reduced")
+    hipEvent_t wgfree;            // comm -> compute: the synthesis slab sum (run on the communicator stream) has read the weight-gradient slabs
     int n_issued;
 };
 
@@ -54,6 +56,7 @@ static int bind(st_dp* p)
     ST_SYM(GetUniqueId, "ncclGetUniqueId"); ST_SYM(CommInitRank, "ncclCommInitRank"); ST_SYM(CommDestroy, "ncclCommDestroy");
     ST_SYM(AllReduce, "ncclAllReduce"); ST_SYM(Broadcast, "ncclBroadcast"); ST_SYM(GetErrorString, "ncclGetErrorString");
 #undef ST_SYM
+    *(void**)(&p->GetVersion) = dlsym(p->lib, "ncclGetVersion");
     return ST_OK;
 }
 

@@ -309,12 +309,24 @@ struct NyqJob {
     const float* part; int P;        // partials [P][2][N] (real row, imaginary row) written by the GEMM launch's extra workgroups
     int on;                          // 0: the Nyquist rows come from the slabs like every other row (gemm_kernel<3, ...> wrote them)
 };
+// The packed copy of the live analysis rows for the data-parallel exchange: fp32, or (st_dp_train_step exchange flag 4, the 16-bit configurations)
+// bfloat16 in the first half of the same buffer -- the exposed collective then moves half the bytes
+__device__ __forceinline__ void stage_store4(float* __restrict__ stage, const size_t elem, const float4 v, const int bf16)
+{
+    if (bf16) {
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        union { bf16x2_t h; unsigned u; } lo, hi;
+        lo.h = __builtin_convertvector((f32x2_t){v.x, v.y}, bf16x2_t); hi.h = __builtin_convertvector((f32x2_t){v.z, v.w}, bf16x2_t);
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(stage) + elem) = make_uint2(lo.u, hi.u);
+    } else *reinterpret_cast<float4*>(stage + elem) = v;
+}
 constexpr int NYQ_CW = 256;                              // output columns per Nyquist block (64 float4 lanes x 4 partial groups)
 __host__ __device__ static inline int nyq_blocks(int N) { return 2 * ((N + NYQ_CW - 1) / NYQ_CW); }
 __host__ __device__ static inline int norm_partial_count(int F, int N) { return 2 * F + nyq_blocks(N); }
 __device__ __forceinline__ void
 nyquist_chunk(const NyqJob& q, float* __restrict__ gRe, float* __restrict__ gIm, float* __restrict__ norm_partial,
-              const int N, const int F, const int blk, const int slot, float* __restrict__ stage)
+              const int N, const int F, const int blk, const int slot, float* __restrict__ stage, const int stage_bf16 = 0)
 {
     __shared__ float4 part[4][64];
     __shared__ float red[4];
@@ -337,7 +349,7 @@ nyquist_chunk(const NyqJob& q, float* __restrict__ gRe, float* __restrict__ gIm,
         const float4 a = part[0][threadIdx.x], b = part[1][threadIdx.x], c = part[2][threadIdx.x], d = part[3][threadIdx.x];
         v = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
         *reinterpret_cast<float4*>((is_im ? gIm : gRe) + (size_t)(F - 1) * N + 4 * n4) = v;
-        if (stage) *reinterpret_cast<float4*>(stage + (size_t)((is_im ? F : 0) + F - 1) * N + 4 * n4) = v;
+        if (stage) stage_store4(stage, (size_t)((is_im ? F : 0) + F - 1) * N + 4 * n4, v, stage_bf16);
         na = fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
     }
     const float tot = block_sum<4>(na, red);
@@ -345,11 +357,12 @@ nyquist_chunk(const NyqJob& q, float* __restrict__ gRe, float* __restrict__ gIm,
 }
 __device__ __forceinline__ void
 wgrad_reduce_block(const float* __restrict__ ws, int nz, float* __restrict__ gRe, float* __restrict__ gIm,
-                   float* __restrict__ norm_partial, int N, int F, int KP, int mode, const int row, float* __restrict__ stage, const NyqJob& nyq)
+                   float* __restrict__ norm_partial, int N, int F, int KP, int mode, const int row, float* __restrict__ stage, const NyqJob& nyq,
+                   const int stage_bf16 = 0)
 {
     __shared__ float red[4];                          // row: 0 .. 2F-1 : [0,F) real rows, [F,2F) imag rows; >= 2F: Nyquist blocks
     if (row >= 2 * F) {
-        if (nyq.on) nyquist_chunk(nyq, gRe, gIm, norm_partial, N, F, row - 2 * F, row, stage);
+        if (nyq.on) nyquist_chunk(nyq, gRe, gIm, norm_partial, N, F, row - 2 * F, row, stage, stage_bf16);
         else if (threadIdx.x == 0) norm_partial[row] = 0.f;      // the partial count is fixed (norm_partial_count): unused slots read as 0
         return;
     }
@@ -374,7 +387,7 @@ wgrad_reduce_block(const float* __restrict__ ws, int nz, float* __restrict__ gRe
             for (int j = 0; j < 8; ++j) if (z0 + j < nz) { v.x += u[j].x; v.y += u[j].y; v.z += u[j].z; v.w += u[j].w; }
         }
         reinterpret_cast<float4*>(g + (size_t)k * N)[n4] = v;
-        if (stage) reinterpret_cast<float4*>(stage + (size_t)row * N)[n4] = v;      // packed copy [2F][N] of the live rows (data-parallel all-reduce buffer)
+        if (stage) stage_store4(stage, (size_t)row * N + 4 * n4, v, stage_bf16);      // packed copy [2F][N] of the live rows (data-parallel all-reduce buffer)
         float a = fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
         if (mirror) {
             reinterpret_cast<float4*>(g + (size_t)(N - k) * N)[n4] = make_float4(sgn * v.x, sgn * v.y, sgn * v.z, sgn * v.w);
@@ -389,11 +402,12 @@ wgrad_reduce_block(const float* __restrict__ ws, int nz, float* __restrict__ gRe
 // never with the Nyquist form)
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ ws, int nz, float* __restrict__ gRe, float* __restrict__ gIm,
-                    float* __restrict__ norm_partial, int N, int F, int KP, int mode, int row0, int nrows, float* __restrict__ stage, const NyqJob nyq)
+                    float* __restrict__ norm_partial, int N, int F, int KP, int mode, int row0, int nrows, float* __restrict__ stage, const NyqJob nyq,
+                    const int extra0 = 0, const int stage_bf16 = 0)
 {
-    // blocks [0, nrows): gradient rows row0 ..; the rest: the Nyquist / unused partial slots 2F ..
-    const int row = (int)blockIdx.x < nrows ? (int)blockIdx.x + row0 : 2 * F + ((int)blockIdx.x - nrows);
-    wgrad_reduce_block(ws, nz, gRe, gIm, norm_partial, N, F, KP, mode, row, stage, nyq);
+    // blocks [0, nrows): gradient rows row0 ..; the rest: the Nyquist / unused partial slots 2F + extra0 .. (extra0: the one-basis launches of the split exchange)
+    const int row = (int)blockIdx.x < nrows ? (int)blockIdx.x + row0 : 2 * F + extra0 + ((int)blockIdx.x - nrows);
+    wgrad_reduce_block(ws, nz, gRe, gIm, norm_partial, N, F, KP, mode, row, stage, nyq, stage_bf16);
 }
 
 // L1 norm partials of an arbitrary flat range (data-parallel path: norm of the *reduced* gradient).
@@ -416,7 +430,7 @@ l1_partial_kernel(const float* __restrict__ g, int64_t n, float scale, float* __
 // pass over the whole STFT range, all of it exposed behind the last collective.
 __global__ void __launch_bounds__(256)
 unstage_l1_kernel(const float* __restrict__ stage, float* __restrict__ gRe, float* __restrict__ gIm, const int F, const int N, const float scale,
-                  float* __restrict__ partial, const int n_partial)
+                  float* __restrict__ partial, const int n_partial, const int stage_bf16 = 0)
 {
     __shared__ float red[4];
     const int row = blockIdx.x;                       // 0 .. 2F-1
@@ -425,7 +439,11 @@ unstage_l1_kernel(const float* __restrict__ stage, float* __restrict__ gRe, floa
     const float* src = stage + (size_t)row * N;
     float a = 0.f;
     for (int i = threadIdx.x; i < N / 4; i += 256) {
-        const float4 v = reinterpret_cast<const float4*>(src)[i];
+        float4 v;
+        if (stage_bf16) {          // the exchange ran on bfloat16 values (first half of the buffer): widen
+            const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(stage) + (size_t)row * N + 4 * i);
+            v = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+        } else v = reinterpret_cast<const float4*>(src)[i];
         reinterpret_cast<float4*>(dst)[i] = v;
         a += fabsf(v.x * scale) + fabsf(v.y * scale) + fabsf(v.z * scale) + fabsf(v.w * scale);
     }

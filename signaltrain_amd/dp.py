@@ -12,7 +12,8 @@ Two back ends:
         communicator and a communicator stream, and ONE C call (st_dp_train_step) runs phase 1 -> all-reduce [synthesis bases
         + autoencoders] (8.45 MB) || phase 2 (analysis weight gradient) -> all-reduce the packed live analysis rows (4.2 MB,
         the only exposed one) -> clip + Adam.  No Python between the buckets.  torch.distributed (any backend, gloo is enough) is
-        used only as the bootstrap channel for the 128-byte RCCL unique id.
+        used only as the bootstrap channel for the 128-byte RCCL unique id.  schedule="staged" splits that last exchange by basis (the real
+        rows' all-reduce under the GEMM of the imaginary rows: 2.1 MB exposed); pack16=True moves it as bfloat16 in the *_all arithmetic modes.
   backend="torch"                   the same protocol driven from Python over torch.distributed collectives (backend "nccl" ==
         RCCL, or "gloo" on CPU for the tests), with two schedules: "two_bucket" (as above) and "staged" (four stages / four
         ranges, only the last 2.1 MB exposed; measured +55..85 us of fixed cost on one GPU).
@@ -47,9 +48,10 @@ class DataParallel:
     """Wraps an engine exposing train_step / loss_backward_p1 / _p2 / grad_buckets / finish_buckets / clip_adam
     (+ loss_backward_stage / stage_bucket for the staged schedule, dp_train_step for the library back end)."""
 
-    def __init__(self, engine, process_group=None, force_collectives=False, schedule="two_bucket", backend=None):
+    def __init__(self, engine, process_group=None, force_collectives=False, schedule="two_bucket", backend=None, pack16=False):
         assert schedule in ("staged", "two_bucket"), schedule
         self.schedule = schedule
+        self.pack16 = bool(pack16)
         self.engine = engine
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -57,7 +59,7 @@ class DataParallel:
         self.force = bool(force_collectives)
         on_gpu = hasattr(engine, "dp_train_step") and getattr(getattr(engine, "device", None), "type", "cpu") == "cuda"
         if backend is None:
-            backend = "lib" if (on_gpu and schedule == "two_bucket") else "torch"
+            backend = "lib" if on_gpu else "torch"
         assert backend in ("lib", "torch"), backend
         if backend == "lib" and not on_gpu:
             raise RuntimeError("DataParallel(backend='lib') needs the HIP engine on a ROCm device")
@@ -90,7 +92,7 @@ class DataParallel:
         if self.world == 1 and not self.force:
             return eng.train_step(x, knobs, y, lr, **kw)
         if self.backend == "lib":
-            return eng.dp_train_step(x, knobs, y, lr, force_exchange=self.force, **kw)
+            return eng.dp_train_step(x, knobs, y, lr, force_exchange=self.force, split_last=(self.schedule == "staged"), pack16=self.pack16, **kw)
         if self.schedule == "two_bucket":
             eng.loss_backward_p1(x, knobs, y)
             b = eng.grad_buckets()

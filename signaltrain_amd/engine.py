@@ -86,6 +86,7 @@ class StepEngine:
             raise RuntimeError("signaltrain_amd.StepEngine needs a ROCm device (there is no CPU fallback)")
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
+        self._arith_checked = set()
         self.set_arithmetic(compute_dtype, loss_scale, clip_all)
         self.dims = dims
         self.max_batch = int(max_batch or dims.B)
@@ -158,7 +159,25 @@ class StepEngine:
             raise RuntimeError(f"batch {B} exceeds the engine's workspace (max_batch={self.max_batch})")
         d = self.dims.with_batch(B)
         d.prec, d.loss_scale, d.clip_all = _lib.PREC[self.compute_dtype], self.loss_scale, int(self.clip_all)
+        if (B, self.compute_dtype) not in self._arith_checked:
+            # no silent arithmetic switch: where this geometry / batch cannot take the requested level (st_effective_prec, e.g. an odd batch
+            # on the wide autoencoder path) say so once per (batch, dtype) and keep it readable in effective_dtype(B)
+            self._arith_checked.add((B, self.compute_dtype))
+            eff = int(self.lib.st_effective_prec(C.byref(d)))
+            if eff != d.prec:
+                import warnings
+                name = {v: k for k, v in _lib.PREC.items()}.get(eff, str(eff))
+                warnings.warn(f"signaltrain_amd: compute_dtype={self.compute_dtype!r} with batch {B} at this geometry (T={d.T}, OT={d.OT}) runs the "
+                              f"autoencoder layers in fp32 (effective arithmetic {name!r}): the wide autoencoder path needs an even batch for 16-bit "
+                              f"Linear layers", RuntimeWarning, stacklevel=3)
         return d
+
+    def effective_dtype(self, B=None):
+        """The arithmetic a batch of B windows actually runs in (st_effective_prec): compute_dtype, except where the geometry cannot take it."""
+        d = self.dims.with_batch(self.max_batch if B is None else B)
+        d.prec, d.loss_scale, d.clip_all = _lib.PREC[self.compute_dtype], self.loss_scale, int(self.clip_all)
+        eff = int(self.lib.st_effective_prec(C.byref(d)))
+        return {v: k for k, v in _lib.PREC.items()}.get(eff, str(eff))
 
     def _stream(self):
         """The current stream OF THIS ENGINE'S DEVICE (not of whatever device happens to be current)."""
@@ -328,15 +347,16 @@ class StepEngine:
         if getattr(self, "graph", None) is not None:
             self._call("st_graph_destroy", self.graph); self.graph = None
 
-    def dp_train_step(self, x, knobs, y, lr, betas=(0.9, 0.999), eps=1e-8, force_exchange=False):
+    def dp_train_step(self, x, knobs, y, lr, betas=(0.9, 0.999), eps=1e-8, force_exchange=False, split_last=False, pack16=False):
         """The data-parallel step driven from C (st_dp_train_step): this rank's shard, both gradient buckets all-reduced on the
-        library's RCCL communicator under the backward, clip after the reduction, replicated Adam."""
+        library's RCCL communicator under the backward, clip after the reduction, replicated Adam.  split_last: the last exchange by basis
+        (only 2.1 MB exposed); pack16: that exchange on bfloat16 values (the *_all arithmetic modes only)."""
         d, x, knobs, y = self._prep(x, knobs, y)
         self.step_count += 1; self.generation += 1; self.lr = float(lr)
         self._call("st_dp_train_step", self.dp, C.byref(d), _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.m),
                    _lib.ptr(self.v), _lib.ptr(self._stage_buf()), _lib.ptr(x), _lib.ptr(knobs), _lib.ptr(y), _lib.ptr(self.ws),
                    _lib.ptr(self.scalars), float(lr), float(betas[0]), float(betas[1]), float(eps),
-                   int(self.step_count), 1 if force_exchange else 0, self._stream())
+                   int(self.step_count), (1 if force_exchange else 0) | (2 if split_last else 0) | (4 if pack16 else 0), self._stream())
         return self.scalars
 
     def clip_adam(self, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):

@@ -29,3 +29,22 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def tuning_state_is_at_the_shipped_defaults():
+    """The library's diagnostic switches (st_set_tuning / st_set_debug) are process-wide: every test must leave them at the shipped defaults
+    (st_tuning_defaults), and the defaults themselves are frozen in tests/test_abi_and_host.py::test_tuning_defaults_are_frozen."""
+    yield
+    import ctypes as C
+    from signaltrain_amd import _lib
+    try:
+        lib = _lib.load()
+    except Exception:
+        return
+    n = lib.st_get_tuning(None, 0)
+    cur, dflt = (C.c_int * n)(), (C.c_int * n)()
+    lib.st_get_tuning(cur, n); lib.st_tuning_defaults(dflt, n)
+    leaked = [(i, cur[i], dflt[i]) for i in range(n) if cur[i] != dflt[i]]
+    lib.st_reset_tuning()
+    assert not leaked, f"a test left diagnostic switches set (index, value, default): {leaked}"

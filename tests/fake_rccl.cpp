@@ -27,7 +27,7 @@ extern "C" {
 
 typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4 } ncclResult_t;
 typedef struct { char internal[128]; } ncclUniqueId;
-typedef enum { ncclInt8 = 0, ncclFloat32 = 7 } ncclDataType_t;
+typedef enum { ncclInt8 = 0, ncclFloat32 = 7, ncclBfloat16 = 9 } ncclDataType_t;
 typedef enum { ncclSum = 0 } ncclRedOp_t;
 
 #define FAKE_MAX_RANKS 8
@@ -80,6 +80,20 @@ __global__ void fake_sum_kernel(const float* __restrict__ mine, const float* __r
         out[i] = s;
     }
 }
+
+// bfloat16 payloads (the packed last exchange of the 16-bit configurations): summed in fp32 in rank order, rounded to nearest even once
+__global__ void fake_sum_bf16_kernel(const unsigned short* __restrict__ mine, const unsigned short* __restrict__ others, unsigned short* __restrict__ out, size_t n, int rank, int world)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int r = 0; r < world; ++r) s += __uint_as_float((unsigned)((r == rank) ? mine[i] : others[(size_t)r * n + i]) << 16);
+        unsigned u = __float_as_uint(s);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        out[i] = (unsigned short)(u >> 16);
+    }
+}
+
+ncclResult_t ncclGetVersion(int* v) { if (!v) return ncclInvalidArgument; *v = -1; return ncclSuccess; }      // -1: "this is the test double"
 
 const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : "fake_rccl error"; }
 
@@ -135,12 +149,15 @@ ncclResult_t ncclCommDestroy(ncclComm_t c)
 
 ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t c, hipStream_t s)
 {
-    if (dt != ncclFloat32 || op != ncclSum || count * 4 > FAKE_SLOT_BYTES) return ncclInvalidArgument;
-    const size_t bytes = count * 4;
+    const size_t esz = dt == ncclBfloat16 ? 2 : 4;
+    if ((dt != ncclFloat32 && dt != ncclBfloat16) || op != ncclSum || count * esz > FAKE_SLOT_BYTES) return ncclInvalidArgument;
+    const size_t bytes = count * esz;
     if (hipMemcpyAsync(c->slots + (size_t)c->rank * FAKE_SLOT_BYTES, send, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return ncclUnhandledCudaError;
     if (barrier_on_stream(c, s, true) != hipSuccess) return ncclUnhandledCudaError;                 // all slots written
     for (int r = 0; r < c->world; ++r)
-        if (r != c->rank && hipMemcpyAsync(c->scratch + (size_t)r * count, c->slots + (size_t)r * FAKE_SLOT_BYTES, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return ncclUnhandledCudaError;
+        if (r != c->rank && hipMemcpyAsync((char*)c->scratch + (size_t)r * bytes, c->slots + (size_t)r * FAKE_SLOT_BYTES, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return ncclUnhandledCudaError;
+    if (dt == ncclBfloat16) hipLaunchKernelGGL(fake_sum_bf16_kernel, dim3(256), dim3(256), 0, s, (const unsigned short*)send, (const unsigned short*)c->scratch, (unsigned short*)recv, count, c->rank, c->world);
+    else
     hipLaunchKernelGGL(fake_sum_kernel, dim3(256), dim3(256), 0, s, (const float*)send, (const float*)c->scratch, (float*)recv, count, c->rank, c->world);
     if (barrier_on_stream(c, s, false) != hipSuccess) return ncclUnhandledCudaError;                // all slots read
     return hipGetLastError() == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;

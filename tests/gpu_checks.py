@@ -53,6 +53,19 @@ def dims_of(geo, B, K):
     return d
 
 
+def follow_effective_arithmetic(d):
+    """No silent arithmetic switch (st_effective_prec): where the geometry / batch cannot take 16-bit autoencoder layers (odd batch on the wide
+    path) the library runs them in fp32 and SAYS so -- the oracle then rounds the GEMM operands only.  Returns a restore callable."""
+    eff = int(_lib.load().st_effective_prec(C.byref(d)))
+    saved = O.AE_ROUND
+    if eff != d.prec and eff in (1, 3):
+        O.AE_ROUND = None
+
+    def restore():
+        O.AE_ROUND = saved
+    return restore
+
+
 def to_kp(re, im, KP):
     """[R,F] pair -> padded [R,KP] (re at 0.., im at KP/2..)."""
     R, F = re.shape
@@ -166,6 +179,14 @@ def run_all(B=3, seed=0, K=4, verbose=False, scale=1, scheme="lean", shrink=4):
     lib = _lib.load()
     geo, X, Y, KN, P = make_case(B, seed, K=K, scale=scale, scheme=scheme, shrink=shrink)
     d = dims_of(geo, B, K)
+    restore_oracle = follow_effective_arithmetic(d)
+    try:
+        return _run_all(lib, geo, X, Y, KN, P, d, B, K, verbose)
+    finally:
+        restore_oracle()
+
+
+def _run_all(lib, geo, X, Y, KN, P, d, B, K, verbose):
     KP = lib.st_kp(d.F); F, T, OT, N = d.F, d.T, d.OT, d.N
     res = []
     P64 = {k: v.astype(np.float64) for k, v in P.items()}
@@ -299,6 +320,14 @@ def run_fused(B=3, seed=1, K=4, steps=3, scale=1, scheme="lean", shrink=4):
     """Fused entry points: st_model_fwd, st_loss_backward, st_train_step x steps vs the oracle."""
     geo, X, Y, KN, P = make_case(B, seed, K=K, scale=scale, scheme=scheme, shrink=shrink)
     d = dims_of(geo, B, K)
+    restore_oracle = follow_effective_arithmetic(d)
+    try:
+        return _run_fused(geo, X, Y, KN, P, d, B, K, steps)
+    finally:
+        restore_oracle()
+
+
+def _run_fused(geo, X, Y, KN, P, d, B, K, steps):
     eng = new_engine(d)
     eng.load_state_dict(P)
     res = []

@@ -228,3 +228,33 @@ int main(void)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-500:])
     L, T, OT, F, y, total, wsb = (int(v) for v in r.stdout.split())
     assert (L, T, OT, F, y) == (8192, 25, 9, 513, 2048) and total == 4211096 and wsb > 100e6
+
+
+def test_tuning_defaults_are_frozen():
+    """The shipped values of the library's diagnostic switches (ST_TUNING_LIST in st_api.hip), in st_get_tuning's order.  A changed default has to be
+    changed HERE as well -- it cannot ship unnoticed -- and tests/conftest.py asserts after every test that the live state equals these values."""
+    lib = _lib.load()
+    n = lib.st_get_tuning(None, 0)
+    cur, dflt = (C.c_int * n)(), (C.c_int * n)()
+    assert lib.st_get_tuning(cur, n) == n and lib.st_tuning_defaults(dflt, n) == n
+    frozen = [0, -1, 0, 0, 0, 3, 1, 64, 0, 0, 0, 1, 1, 32, 1, 0, 1, 1, 0, 32, 16, 16, 200, 4, 3, 3, 1, 0, 0]
+    assert list(dflt) == frozen and list(cur) == frozen
+    # a switch is visible in the state and reset restores it; timing-only ablations (invalid results) are not in the product build
+    assert lib.st_set_tuning(9500) == 0 and list((lib.st_get_tuning(cur, n), cur)[1]) != frozen
+    assert lib.st_reset_tuning() == 0 and list((lib.st_get_tuning(cur, n), cur)[1]) == frozen
+    assert lib.st_set_tuning(9681) != 0 and lib.st_set_tuning(96801) != 0 and b"ST_DIAG" in lib.st_last_error()
+
+
+def test_effective_precision_is_reported():
+    """st_effective_prec: the 16-bit autoencoder level needs an even batch on the wide path (65536-sample window); with an odd batch the layers stay
+    fp32 and the library says so instead of switching arithmetic silently."""
+    lib = _lib.load()
+    d = _lib.st_dims()
+    assert lib.st_geometry(8.0, 4.0, 0, 4, 64, C.byref(d)) == 0
+    for prec, odd in ((2, 1), (4, 3)):
+        d.prec = prec
+        d.B = 64; assert lib.st_effective_prec(C.byref(d)) == prec
+        d.B = 63; assert lib.st_effective_prec(C.byref(d)) == odd
+    d.prec = 0; assert lib.st_effective_prec(C.byref(d)) == 0
+    assert lib.st_geometry(1.0, 4.0, 0, 4, 3, C.byref(d)) == 0          # fused geometry: any batch
+    d.prec = 2; assert lib.st_effective_prec(C.byref(d)) == 2

@@ -338,7 +338,7 @@ def test_scale8_golden_forward(golden_dir):
         assert e <= 1e-4 * np.abs(ref).max(), (name, e)
 
 
-@pytest.mark.parametrize("schedule,backend", [("two_bucket", "lib"), ("two_bucket", "torch"), ("staged", "torch")])
+@pytest.mark.parametrize("schedule,backend", [("two_bucket", "lib"), ("staged", "lib"), ("two_bucket", "torch"), ("staged", "torch")])
 def test_dp_collective_path_single_rank(schedule, backend):
     """The N > 1 step (backward phases / stages, each followed by the RCCL all-reduce of the range it finalised, running under
     the next one -> st_dp_clip_adam) executed on ONE GPU with a single-rank RCCL communicator must reproduce the fused single-GPU

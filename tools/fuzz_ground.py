@@ -32,7 +32,27 @@ CASES = [
     ("bf16_all", dict(B=1, seed=322, K=12, scale=2, scheme="lean", shrink=4)),
     ("bf16_all", dict(B=3, seed=382, K=8, scale=2, scheme="lean", shrink=4)),
 ]
+# ... and their even-batch neighbours: the same geometries (lean scale 2 = T 46 / shrink 1 = OT 25: both on the wide autoencoder path) and knob counts
+# K in {5, 8, 12}, where the 16-bit Linear layers really run in 16 bits
+CASES += [
+    ("bf16_all", dict(B=2, seed=50, K=4, scale=2, scheme="lean", shrink=4)),
+    ("bf16_all", dict(B=4, seed=382, K=8, scale=2, scheme="lean", shrink=4)),
+    ("bf16_all", dict(B=2, seed=322, K=12, scale=2, scheme="lean", shrink=4)),
+    ("bf16_all", dict(B=8, seed=977, K=8, scale=1, scheme="lean", shrink=1)),
+    ("f16_all", dict(B=4, seed=678, K=5, scale=2, scheme="lean", shrink=4)),
+    ("f16_all", dict(B=3, seed=11, K=12, scale=1, scheme="lean", shrink=4)),
+    ("bf16_all", dict(B=5, seed=12, K=5, scale=1, scheme="lean", shrink=2)),
+]
 NPERT = 8
+
+
+def effective(mode, kw):
+    from tests import gpu_checks as G
+    from signaltrain_amd import _lib
+    import ctypes
+    geo = O.geometry(kw["scale"], kw["shrink"], kw["scheme"])
+    d = G.dims_of(geo, kw["B"], kw["K"]); d.prec = 2 if mode.startswith("bf16") else 4
+    return {0: "f32", 1: "bf16", 2: "bf16_all", 3: "f16", 4: "f16_all"}[int(_lib.load().st_effective_prec(ctypes.byref(d)))]
 
 
 def tag(mode, kw):
@@ -45,6 +65,11 @@ def self_noise(mode, kw, npert=NPERT):
     geo, X, Y, KN, P = G.make_case(kw["B"], kw["seed"], K=kw["K"], scale=kw["scale"], scheme=kw["scheme"], shrink=kw["shrink"])
     rnd = O.bf16_round if mode.startswith("bf16") else O.fp16_round
     O.GEMM_ROUND = rnd; O.AE_ROUND = rnd
+    d = G.dims_of(geo, kw["B"], kw["K"]); d.prec = 2 if mode.startswith("bf16") else 4
+    from signaltrain_amd import _lib
+    import ctypes
+    if int(_lib.load().st_effective_prec(ctypes.byref(d))) != d.prec:      # odd batch on the wide path: the library runs (and reports) fp32 autoencoder layers
+        O.AE_ROUND = None
     if mode.startswith("f16"):
         O.LOSS_SCALE = 4096.0; O.CLIP_ALL = True
     try:
@@ -71,7 +96,7 @@ def self_noise(mode, kw, npert=NPERT):
 def main():
     gpu = len(sys.argv) > 1 and sys.argv[1] == "gpu"
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"); os.makedirs(out_dir, exist_ok=True)
-    cache = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_fuzz_self_noise.json")
+    cache = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_fuzz_self_noise.json")      # keyed by configuration; delete to recompute
     noise_all = json.load(open(cache)) if os.path.isfile(cache) else {}
     for mode, kw in CASES:
         tg = tag(mode, kw)
@@ -90,10 +115,10 @@ def main():
         tg = tag(mode, kw); nz = noise_all[tg]
         half = "bf16" if mode.startswith("bf16") else "f16"
         ftol = (G.mixed_mode.FUSED_TOL if half == "bf16" else G.mixed_mode.FUSED_TOL_F16)[2]
-        with G.mixed_mode(2, half=half):
+        with G.mixed_mode(2, half=half, tol_scale=(None if kw["scale"] != 8 else (40.0 if half == "bf16" else 20.0))):      # 174-frame rows: more flips per sum
             per = G.run_all(B=kw["B"], seed=kw["seed"], K=kw["K"], scale=kw["scale"], scheme=kw["scheme"], shrink=kw["shrink"])
         per_hard = [r for r in per if not r["ok"]]
-        per_worst = max(per, key=lambda r: r["rel"] / r["tol"])
+        per_worst = max(per, key=lambda r: r["rel"] / max(r["tol"], 1e-30))
         with G.mixed_mode(2, half=half, tol_scale=ftol):
             fused = G.run_fused(steps=1, **kw)
         flagged = [r for r in fused if not r["ok"]]
@@ -108,7 +133,7 @@ def main():
         if per_hard:
             verdict = "SUSPECT(per-op)"
         nbug += verdict != "noise"
-        print(f"{tg} | per-op {per_worst['name']} {per_worst['rel']:.1e} (tol {per_worst['tol']:.0e}; {len(per_hard)}/{len(per)} miss"
+        print(f"{tg} [runs as {effective(mode, kw)}] | per-op {per_worst['name']} {per_worst['rel']:.1e} (tol {per_worst['tol']:.0e}; {len(per_hard)}/{len(per)} miss"
               + (": " + ", ".join(f"{r['name']} {r['rel']:.1e}" for r in per_hard[:3]) if per_hard else "") + ") | "
               + ("; ".join(lines) if lines else "fused: nothing flagged on this box") + f" | {verdict}", flush=True)
     print(f"\n{len(CASES)} configurations, {nbug} not explained by the oracle's own spread")
