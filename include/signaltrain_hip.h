@@ -323,10 +323,14 @@ int st_compressor_4c(const float* x, const float* knobs_wc, float sr, int B, int
  * the pair (datasets.py:27-29).  Counter-based generator: window i of the stream `seed` is the same whatever the batching;
  * `first_window` = index of window 0 of this call.  K must be 4; knob_lo / knob_hi = Effect.knob_ranges (host arrays of 4).
  * chooser: -1 = drawn per window (the training feed); 0,1,2,4,6,7 force one signal family (tests).
- * pink_in: [B][L] unit-peak 1/f noise for windows longer than 8192 samples (the in-kernel FFT's limit), else NULL.
- * scratch: B * (L + 4) floats (may be NULL): with it (and L % 64 == 0) the effect's sequential attack / release stage runs one LANE per window
- * in a second, tiny launch (64 windows per wave) instead of one workgroup per window -- the form that runs beside the training step.
+ * pink_in: optional caller-made [B][L] unit-peak 1/f noise for windows longer than 8192 samples (the in-LDS FFT's limit); NULL: the library makes it --
+ * in LDS up to 8192 samples, by its own four-step inverse FFT through `scratch` for powers of two up to 65536 (BASELINE configs[4]'s window), both
+ * keyed by (seed, window index) like everything else of the window.
+ * scratch: st_synth_comp4c_scratch_floats(B, L) floats (B * (L + 4) up to 8192 samples; may be NULL there): with it (and L % 64 == 0) the effect's
+ * sequential attack / release stage runs one LANE per window in a second, tiny launch (64 windows per wave) instead of one workgroup per window --
+ * the form that runs beside the training step.
  * Outputs x [B][L], y [B][ysz], knobs [B][4] (fp32, normalised to [-0.5, 0.5]). */
+size_t st_synth_comp4c_scratch_floats(int B, int L);
 int st_synth_comp4c(unsigned seed, unsigned long long first_window, int B, int L, int ysz, int K, float sr,
                     const float* knob_lo, const float* knob_hi, int augment, int chooser, const float* pink_in,
                     float* x, float* y, float* knobs, float* scratch, void* stream);

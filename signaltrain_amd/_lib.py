@@ -58,6 +58,7 @@ SIGNATURES = {
     "st_ae_acts_floats": (C.c_size_t, [_D]),
     "st_ae_acts": (_i, [_D, _p, _p, _p, _i, _p, _p]),
     "st_compressor_4c": (_i, [_p, _p, C.c_float, C.c_int, C.c_int, C.c_int, _p, _p]),
+    "st_synth_comp4c_scratch_floats": (C.c_size_t, [_i, _i]),
     "st_synth_comp4c": (_i, [C.c_uint, C.c_ulonglong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float),
                              C.c_int, C.c_int, _p, _p, _p, _p, _p, _p]),
     "st_fe_frames": (_i, [C.c_int] * 4),

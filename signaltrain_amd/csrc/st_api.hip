@@ -1682,6 +1682,16 @@ extern "C" int st_compressor_4c(const float* x, const float* knobs_wc, float sr,
     ST_LAUNCHED("compressor_4c"); return ST_OK;
 }
 
+// scratch of st_synth_comp4c for the full-featured path: [gain curve B * L | world knobs 4 B] and, for power-of-two windows beyond the in-LDS FFT
+// (8192 < L <= 65536), [1/f noise B * L | per-window peaks | four-step FFT buffer 2 * min(B, 256) * L]
+static bool feed_long_fft(int L) { return L > stf::FFT_MAX && (L & (L - 1)) == 0 && L / stf::PL_N1 <= 256; }
+extern "C" size_t st_synth_comp4c_scratch_floats(int B, int L)
+{
+    if (B <= 0 || L <= 0) return 0;
+    size_t n = (size_t)B * (L + 4);
+    if (feed_long_fft(L)) n += (size_t)B * L + (size_t)st_round_up(B, 64) + (size_t)2 * (B < 256 ? B : 256) * L;
+    return n;
+}
 extern "C" int st_synth_comp4c(unsigned seed, unsigned long long first_window, int B, int L, int ysz, int K, float sr,
                                const float* knob_lo, const float* knob_hi, int augment, int chooser, const float* pink_in,
                                float* x, float* y, float* knobs, float* scratch, void* stream)
@@ -1690,14 +1700,41 @@ extern "C" int st_synth_comp4c(unsigned seed, unsigned long long first_window, i
     ST_REQ(B > 0 && L > 0 && ysz > 0 && ysz <= L && sr > 0.f && K == 4, "st_synth_comp4c: bad sizes (B=%d L=%d ysz=%d K=%d)", B, L, ysz, K);
     ST_REQ(chooser == -1 || chooser == 0 || chooser == 1 || chooser == 2 || chooser == 4 || chooser == 6 || chooser == 7 || chooser == 100, "st_synth_comp4c: signal family %d is not built (the compressor's set is 0,1,2,4,6,7)", chooser);
     const bool fft_ok = L <= stf::FFT_MAX && (L & (L - 1)) == 0;
-    ST_REQ(fft_ok || pink_in, "st_synth_comp4c: a %d-sample window needs the 1/f noise from the caller (pink_in): the in-kernel FFT handles powers of two up to %d", L, stf::FFT_MAX);
+    const bool long_fft = !fft_ok && !pink_in && scratch && feed_long_fft(L);      // scratch is then st_synth_comp4c_scratch_floats(B, L) floats (contract)
+    ST_REQ(fft_ok || pink_in || long_fft, "st_synth_comp4c: a %d-sample window needs either the 1/f noise from the caller (pink_in) or -- powers of two up to 65536 -- "
+           "st_synth_comp4c_scratch_floats() floats of scratch for the library's own transform", L);
     stf::FeedArgs a;
-    a.x = x; a.y = y; a.knobs = knobs; a.pink_in = pink_in; a.seed = seed; a.first = first_window;
+    a.x = x; a.y = y; a.knobs = knobs; a.pink_in = pink_in; a.pink_peak = nullptr; a.seed = seed; a.first = first_window;
     a.L = L; a.ysz = ysz; a.K = K; a.sr = sr; a.augment = augment; a.chooser = chooser;
     for (int k = 0; k < 4; ++k) { a.lo[k] = knob_lo[k]; a.hi[k] = knob_hi[k]; }
     const bool split = scratch && L % 64 == 0;
     a.gc = split ? scratch : nullptr; a.kw = split ? scratch + (size_t)B * L : nullptr;
-    const size_t lds = pink_in ? (split ? 0 : (size_t)stm::COMP_CH * sizeof(float)) : (size_t)stf::FFT_MAX * sizeof(float2);
+    if (long_fft) {
+        // the window's 1/f noise by the library's own four-step inverse FFT (st_feed.h pink_long_pass1 / 2), 256 windows at a time through the FFT buffer
+        float* pink = scratch + (size_t)B * (L + 4);
+        float* peak = pink + (size_t)B * L;
+        float2* fbuf = reinterpret_cast<float2*>(peak + st_round_up(B, 64));
+        const int N2 = L / stf::PL_N1;
+        for (int b0 = 0; b0 < B; b0 += 256) {
+            const int nb = B - b0 < 256 ? B - b0 : 256;
+            hipLaunchKernelGGL(stf::pink_long_pass1_kernel, dim3(stf::PL_N1 / stf::PL_G, nb), dim3(256), 0, st_stream(stream), seed, first_window + (unsigned long long)b0, L, chooser, fbuf, peak + b0);
+            hipLaunchKernelGGL(stf::pink_long_pass2_kernel, dim3(N2 / stf::PL_G, nb), dim3(256), 0, st_stream(stream), seed, first_window + (unsigned long long)b0, L, chooser,
+                               (const float2*)fbuf, pink + (size_t)b0 * L, peak + b0);
+        }
+        ST_LAUNCHED("pink_long");
+        a.pink_in = pink; a.pink_peak = peak;
+    }
+    const size_t lds = a.pink_in ? (split ? 0 : (size_t)stm::COMP_CH * sizeof(float)) : (size_t)stf::FFT_MAX * sizeof(float2);
+    if (lds >= 65536) {      // exactly 64 KB of dynamic LDS beside a few static bytes: ask for it explicitly (the 160 KB request of ensure_dyn_lds is refused for a kernel with static LDS)
+        static std::mutex mu; static std::set<int> done;
+        int dev = 0; (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(mu);
+        if (!done.count(dev)) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stf::synth_comp4c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return st_fail(ST_ERR_LAUNCH, "hipFuncSetAttribute(synth_comp4c_kernel, %zu B dynamic LDS): %s", lds, hipGetErrorString(e));
+            done.insert(dev);
+        }
+    }
     hipLaunchKernelGGL(stf::synth_comp4c_kernel, dim3(B), dim3(256), lds, st_stream(stream), a);
     ST_LAUNCHED("synth_comp4c");
     if (split) {

@@ -46,7 +46,8 @@ __device__ __forceinline__ float su01(const unsigned key, const unsigned s, cons
 
 struct FeedArgs {
     float* x; float* y; float* knobs;       // outputs
-    const float* pink_in;                   // [B][L] unit-peak 1/f noise for windows longer than the in-kernel FFT handles (else NULL)
+    const float* pink_in;                   // [B][L] 1/f noise for windows longer than the in-kernel FFT handles (else NULL): unit-peak from the caller, or
+    const float* pink_peak;                 // ... unnormalised from pink_long_pass1 / 2 below with its per-window peak here (NULL: pink_in is unit-peak)
     unsigned seed; unsigned long long first;   // global index of window 0 of this launch
     int L, ysz, K; float sr;
     float lo[4], hi[4];                     // knob ranges (Effect.knob_ranges, audio.py:493-510)
@@ -85,6 +86,105 @@ __device__ __forceinline__ float block_max(float v, float* red)
     return m;
 }
 
+// ---- 1/f noise of LONG windows (L = 2^m > FFT_MAX, e.g. the 65536-sample window of BASELINE configs[4]): the same inverse FFT of the real spectrum
+// (2u - 1) / sqrt(k + 1) (audio.py:85-94), as a four-step transform N = N1 * N2 (N1 = 256) through a global scratch -- two launches, no FFT library:
+//   y[N2 n1 + n2] = sum_k1 e^{2 pi i k1 n1 / N1} ( e^{2 pi i k1 n2 / N} sum_k2 X[k1 + N1 k2] e^{2 pi i k2 n2 / N2} )
+//   pass 1  (k1 fixed, eight k1 per workgroup): the spectrum values are GENERATED (counter-based, stream 7 of the window's key -- the same law and the
+//           same per-window reproducibility as the in-LDS transform of the short windows), N2-point transform over k2 in LDS, twiddle, -> scr[n2][k1];
+//   pass 2  (n2 fixed, eight n2 per workgroup): 256-point transform over k1 of a contiguous 2 KB row, real part -> pink[N2 n1 + n2], |.| peak -> peak[b]
+//           (atomicMax on the bits of a non-negative float); the generator kernel divides by the peak when it mixes the noise in.
+// Only windows whose family uses the noise (chooser 1, 7; 100 in tests) do any work: a third of the training stream.  Round 3 took this noise from
+// torch.fft (rocFFT) driven by a stateful torch.Generator: 2 ms of full-width GPU time per 2048 windows and not reproducible per window index.
+constexpr int PL_N1 = 256, PL_G = 8;
+__device__ __forceinline__ int feed_family(Draw& d, const int chooser)
+{
+    const int ci = d.randint(0, 6);
+    return chooser >= 0 ? chooser : (ci < 3 ? ci : (ci == 3 ? 4 : (ci == 4 ? 6 : 7)));
+}
+__device__ __forceinline__ unsigned feed_key(const unsigned seed, const unsigned long long w)
+{
+    return mix32(seed ^ mix32((unsigned)w + 1u) ^ mix32((unsigned)(w >> 32) + 0x51ED27u));
+}
+// G independent in-place inverse FFTs of length n = 2^logn in LDS (a[g * n + i], input stored bit-reversed), 256 threads
+__device__ __forceinline__ void ifft_batch_lds(float2* a, const int n, const int logn, const int G)
+{
+    const int half_total = G * (n >> 1);
+    for (int s = 1; s <= logn; ++s) {
+        const int half = 1 << (s - 1);
+        for (int j = threadIdx.x; j < half_total; j += 256) {
+            const int g = j / (n >> 1), jj = j - g * (n >> 1);
+            const int grp = jj >> (s - 1), pos = jj & (half - 1);
+            const int i0 = g * n + (grp << s) + pos, i1 = i0 + half;
+            float sn, cs; sincospif((float)pos / (float)half, &sn, &cs);
+            const float2 u = a[i0], v = a[i1];
+            const float2 t = make_float2(v.x * cs - v.y * sn, v.x * sn + v.y * cs);
+            a[i0] = make_float2(u.x + t.x, u.y + t.y);
+            a[i1] = make_float2(u.x - t.x, u.y - t.y);
+        }
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256)
+pink_long_pass1_kernel(const unsigned seed, const unsigned long long first, const int L, const int chooser, float2* __restrict__ scr, float* __restrict__ peak)
+{
+    __shared__ float2 lds[PL_G * 256];
+    const int b = blockIdx.y, N2 = L / PL_N1;
+    const unsigned long long w = first + (unsigned long long)b;
+    Draw d{feed_key(seed, w), 0u};
+    const unsigned key = d.key;
+    const int ch = feed_family(d, chooser);
+    if (!(ch == 1 || ch == 7 || ch == 100)) return;                     // workgroup-uniform
+    if (blockIdx.x == 0 && threadIdx.x == 0) peak[b] = 0.f;
+    int logn = 0; while ((1 << logn) < N2) ++logn;
+    const int k1_0 = blockIdx.x * PL_G;
+    for (int j = threadIdx.x; j < PL_G * N2; j += 256) {
+        const int g = j / N2, k2 = j - g * N2;
+        const int k = k1_0 + g + PL_N1 * k2;
+        const int kk = k <= L / 2 ? k : L - k;                           // Hermitian extension of a real spectrum
+        const float v = (2.f * su01(key, 7u, (unsigned)kk) - 1.f) * rsqrtf((float)kk + 1.f);
+        lds[g * N2 + (int)(__brev((unsigned)k2) >> (32 - logn))] = make_float2(v, 0.f);
+    }
+    __syncthreads();
+    ifft_batch_lds(lds, N2, logn, PL_G);
+    float2* out = scr + (size_t)b * L;
+    for (int j = threadIdx.x; j < PL_G * N2; j += 256) {
+        const int n2 = j / PL_G, g = j - n2 * PL_G, k1 = k1_0 + g;
+        float sn, cs; sincospif(2.0f * (float)(k1 * n2) / (float)L, &sn, &cs);      // k1 n2 < 2^24: exact in float
+        const float2 v = lds[g * N2 + n2];
+        out[(size_t)n2 * PL_N1 + k1] = make_float2(v.x * cs - v.y * sn, v.x * sn + v.y * cs);
+    }
+}
+__global__ void __launch_bounds__(256)
+pink_long_pass2_kernel(const unsigned seed, const unsigned long long first, const int L, const int chooser, const float2* __restrict__ scr,
+                       float* __restrict__ pink, float* __restrict__ peak)
+{
+    __shared__ float2 lds[PL_G * PL_N1];
+    __shared__ float red[4];
+    const int b = blockIdx.y, N2 = L / PL_N1;
+    const unsigned long long w = first + (unsigned long long)b;
+    Draw d{feed_key(seed, w), 0u};
+    const int ch = feed_family(d, chooser);
+    if (!(ch == 1 || ch == 7 || ch == 100)) return;
+    const int n2_0 = blockIdx.x * PL_G;
+    const float2* in = scr + (size_t)b * L + (size_t)n2_0 * PL_N1;
+    for (int j = threadIdx.x; j < PL_G * PL_N1; j += 256) {
+        const int g = j >> 8, k1 = j & 255;
+        lds[g * PL_N1 + (int)(__brev((unsigned)k1) >> 24)] = in[j];
+    }
+    __syncthreads();
+    ifft_batch_lds(lds, PL_N1, 8, PL_G);
+    float m = 0.f;
+    float* o = pink + (size_t)b * L;
+    for (int j = threadIdx.x; j < PL_G * PL_N1; j += 256) {
+        const int n1 = j / PL_G, g = j - n1 * PL_G;
+        const float v = lds[g * PL_N1 + n1].x;
+        o[(size_t)N2 * n1 + n2_0 + g] = v;
+        m = fmaxf(m, fabsf(v));
+    }
+    m = block_max(m, red);
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned*>(peak + b), __float_as_uint(m));
+}
+
 __global__ void __launch_bounds__(256)
 synth_comp4c_kernel(const FeedArgs a)
 {
@@ -93,13 +193,12 @@ synth_comp4c_kernel(const FeedArgs a)
     __shared__ float carry;
     const int b = blockIdx.x, L = a.L;
     const unsigned long long w = a.first + (unsigned long long)b;
-    Draw d{mix32(a.seed ^ mix32((unsigned)w + 1u) ^ mix32((unsigned)(w >> 32) + 0x51ED27u)), 0u};
+    Draw d{feed_key(a.seed, w), 0u};
     const unsigned key = d.key;
     const float dt = 1.0f / a.sr, tl = (float)(L - 1) * dt;
 
     // ---- the window's parameters (datasets.py:317, audio.py:296-334)
-    const int ci = d.randint(0, 6);
-    const int ch = a.chooser >= 0 ? a.chooser : (ci < 3 ? ci : (ci == 3 ? 4 : (ci == 4 ? 6 : 7)));      // {0, 1, 2, 4, 6, 7}
+    const int ch = feed_family(d, a.chooser);      // {0, 1, 2, 4, 6, 7}
     float kn[4], kw[4];
     for (int k = 0; k < 4; ++k) { kn[k] = d.beta(0.8f) - 0.5f; kw[k] = a.lo[k] + (kn[k] + 0.5f) * (a.hi[k] - a.lo[k]); }
     // randsine (audio.py:96-104)
@@ -137,7 +236,7 @@ synth_comp4c_kernel(const FeedArgs a)
         for (int n = threadIdx.x; n < L; n += 256) m = fmaxf(m, fabsf(fa[n].x));
         pink_peak = fmaxf(block_max(m, red), 1e-30f);
     }
-    auto pink = [&](const int n) { return a.pink_in ? a.pink_in[(size_t)b * L + n] : fa[n].x / pink_peak; };
+    if (a.pink_in && a.pink_peak) pink_peak = fmaxf(a.pink_peak[b], 1e-30f);
     auto sine = [&](const float t) { return s_amp[0] * __cosf(s_frq[0] * (t - s_t0[0])) + s_amp[1] * __cosf(s_frq[1] * (t - s_t0[1])); };
     auto plk = [&](const float t) {
         const float env = t < e_t0 ? e_lo : __expf(-e_dec * (t - e_t0)) * e_hi;
@@ -152,30 +251,55 @@ synth_comp4c_kernel(const FeedArgs a)
         for (int n = threadIdx.x; n < L; n += 256) { const float t = (float)n * dt; m = fmaxf(m, fabsf((ch == 0 || ch == 1) ? sine(t) : plk(t))); }
         scale = nrm_u / fmaxf(block_max(m, red), 1e-30f);
     }
-    // ---- pass 2: the window
-    float* xb = a.x + (size_t)b * L;
-    for (int n = threadIdx.x; n < L; n += 256) {
+    // ---- pass 2: the window -- four consecutive samples per thread and trip (16-byte loads of the long-window noise, 16-byte stores), and with the
+    // lane-per-window form of the effect the static gain curve of each sample right away, from the value in registers.  (Round 3 wrote the window and
+    // then re-read it sample by sample in a third loop: without __restrict__ every trip's load waited for the previous trip's store -- 256 dependent
+    // memory round trips per thread at the 65536-sample window, most of the generator's 300 us per window.)
+    float* __restrict__ xb = a.x + (size_t)b * L;
+    float* __restrict__ gcb = a.gc ? a.gc + (size_t)b * L : nullptr;
+    const float* __restrict__ pin = a.pink_in ? a.pink_in + (size_t)b * L : nullptr;
+    const float inv_peak = 1.0f / pink_peak;
+    auto sample = [&](const int n, const float pk) {
         const float t = (float)n * dt;
         float v;
         if (ch == 0) v = sine(t) * scale;
-        else if (ch == 1) v = sine(t) * scale + c_pink1 * pink(n) + c_white1 * (2.f * su01(key, 3u, (unsigned)n) - 1.f);
+        else if (ch == 1) v = sine(t) * scale + c_pink1 * pk + c_white1 * (2.f * su01(key, 3u, (unsigned)n) - 1.f);
         else if (ch == 2) v = plk(t) * scale;
         else if (ch == 4) v = boxv(n);
         else if (ch == 6) v = boxv(n) * (2.f * su01(key, 3u, (unsigned)n) - 1.f);
-        else if (ch == 100) v = pink(n);
-        else v = plk(t) * scale + c_pink7 * pink(n);
-        xb[n] = ch == 100 ? v : v * pol + su01(key, 5u, (unsigned)n) * 1e-8f;       // audio.py:333
+        else if (ch == 100) v = pk;
+        else v = plk(t) * scale + c_pink7 * pk;
+        return ch == 100 ? v : v * pol + su01(key, 5u, (unsigned)n) * 1e-8f;       // audio.py:333
+    };
+    if ((L & 3) == 0) {
+        for (int n4 = threadIdx.x; n4 < L / 4; n4 += 256) {
+            const int n = 4 * n4;
+            float4 pk = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (want_pink) {
+                if (pin) { pk = *reinterpret_cast<const float4*>(pin + n); if (a.pink_peak) { pk.x *= inv_peak; pk.y *= inv_peak; pk.z *= inv_peak; pk.w *= inv_peak; } }
+                else pk = make_float4(fa[n].x * inv_peak, fa[n + 1].x * inv_peak, fa[n + 2].x * inv_peak, fa[n + 3].x * inv_peak);
+            }
+            const float4 v = make_float4(sample(n, pk.x), sample(n + 1, pk.y), sample(n + 2, pk.z), sample(n + 3, pk.w));
+            *reinterpret_cast<float4*>(xb + n) = v;
+            if (gcb) *reinterpret_cast<float4*>(gcb + n) = make_float4(stm::comp_gain_curve(v.x, (double)kw[0], (double)kw[1]), stm::comp_gain_curve(v.y, (double)kw[0], (double)kw[1]),
+                                                                       stm::comp_gain_curve(v.z, (double)kw[0], (double)kw[1]), stm::comp_gain_curve(v.w, (double)kw[0], (double)kw[1]));
+        }
+    } else {
+        for (int n = threadIdx.x; n < L; n += 256) {
+            const float pk = want_pink ? (pin ? (a.pink_peak ? pin[n] * inv_peak : pin[n]) : fa[n].x * inv_peak) : 0.f;
+            const float v = sample(n, pk);
+            xb[n] = v;
+            if (gcb) gcb[n] = stm::comp_gain_curve(v, (double)kw[0], (double)kw[1]);
+        }
     }
     if (threadIdx.x == 0) { for (int k = 0; k < 4; ++k) if (k < a.K) a.knobs[(size_t)b * a.K + k] = kn[k]; }
-    __threadfence_block();
-    __syncthreads();                                                 // the window is complete (and the FFT buffer is dead)
-    // ---- the effect (audio.py:380-426) on the finished window
-    if (a.gc) {                                                      // workgroup-uniform: gain curve in parallel here, recurrence + apply lane-per-window
-        float* gcb = a.gc + (size_t)b * L;
-        for (int n = threadIdx.x; n < L; n += 256) gcb[n] = stm::comp_gain_curve(xb[n], (double)kw[0], (double)kw[1]);
+    if (a.gc) {                                                      // workgroup-uniform: the recurrence + apply run lane-per-window (comp_smooth_kernel, comp_apply_kernel)
         if (threadIdx.x == 0) { for (int k = 0; k < 4; ++k) a.kw[(size_t)b * 4 + k] = kw[k]; }
         return;
     }
+    __threadfence_block();
+    __syncthreads();                                                 // the window is complete (and the FFT buffer is dead)
+    // ---- the effect (audio.py:380-426) on the finished window, inside this workgroup
     const double alphaA = exp(-log(9.0) / ((double)a.sr * (double)kw[2])), alphaR = exp(-log(9.0) / ((double)a.sr * (double)kw[3]));
     stm::compressor_window(xb, a.y + (size_t)b * a.ysz, (double)kw[0], (double)kw[1], alphaA, alphaR, L, a.ysz, feed_lds, &carry);
 }

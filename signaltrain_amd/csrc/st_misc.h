@@ -660,6 +660,19 @@ __global__ void step_tick_kernel(float* __restrict__ scalars, const float* __res
 // copy of the gain curve, in chunks of CH samples so any window length fits.  State is rounded to float32 every step
 // exactly like the reference's float32 lin_A array; the step arithmetic is float64 (numpy float64 scalars alphaA/R).
 // y receives the LAST ysz samples of each processed window (the training target, datasets.py:327-330).
+// the static gain curve of one sample (audio.py:392-399), shared by the compressor kernels and the feed generator.  float32 arithmetic in the
+// reference's order: x_dB and gainChange_dB are float32 arrays there and the threshold / ratio weak Python scalars, so numpy evaluates
+// 20 * log10(|x| + 1e-8), the clip at -96 and thresh + (x_dB - thresh) / ratio - x_dB in float32 (golden G9 was captured that way).  Round 3 evaluated this
+// in float64 -- a software log10 of ~200 instructions per sample: it was most of the feed generator's 2.2 ms per 2048 windows at the 65536-sample window.
+__device__ __forceinline__ float comp_gain_curve(const float xv, const double thresh, const double ratio)
+{
+    const float th = (float)thresh, ra = (float)ratio;
+    float xdb = 20.0f * log10f(fabsf(xv) + 1e-8f);
+    xdb = fmaxf(xdb, -96.0f);
+    return xdb > th ? (th + (xdb - th) / ra) - xdb : 0.0f;
+}
+// dB -> linear (audio.py:421): np.power(10.0, lin_A / 20) on a float32 array
+__device__ __forceinline__ float comp_db_to_lin(const float g) { return exp10f(g / 20.0f); }
 constexpr int COMP_CH = 8192;
 // one window; g: LDS float[COMP_CH], carry: LDS float.  Called by every thread of a 256-thread workgroup.
 __device__ __forceinline__ void
@@ -669,13 +682,7 @@ compressor_window(const float* __restrict__ xb, float* __restrict__ yb, const do
     if (threadIdx.x == 0) *carry_p = 0.f;
     for (int c0 = 0; c0 < L; c0 += COMP_CH) {
         const int n = L - c0 < COMP_CH ? L - c0 : COMP_CH;
-        for (int i = threadIdx.x; i < n; i += 256) {
-            float xdb = (float)(20.0 * log10((double)fabsf(xb[c0 + i]) + 1e-8));
-            if (xdb < -96.0f) xdb = -96.0f;
-            float gc = 0.0f;
-            if ((double)xdb > thresh) gc = (float)(thresh + ((double)xdb - thresh) / ratio - (double)xdb);
-            g[i] = gc;
-        }
+        for (int i = threadIdx.x; i < n; i += 256) g[i] = comp_gain_curve(xb[c0 + i], thresh, ratio);
         __syncthreads();
         if (threadIdx.x == 0) {
             float prev = *carry_p;
@@ -707,7 +714,7 @@ compressor_window(const float* __restrict__ xb, float* __restrict__ yb, const do
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += 256) {
             const int j = c0 + i - (L - ysz);
-            if (j >= 0) yb[j] = (float)pow(10.0, (double)g[i] / 20.0) * xb[c0 + i];
+            if (j >= 0) yb[j] = comp_db_to_lin(g[i]) * xb[c0 + i];
         }
         __syncthreads();
     }
@@ -779,16 +786,7 @@ comp_apply_kernel(const float* __restrict__ x, const float* __restrict__ g, cons
     const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
     if (j >= ysz) return;
     const size_t i = (size_t)b * L + (L - ysz) + j;
-    y[(size_t)b * ysz + j] = (float)pow(10.0, (double)g[i] / 20.0) * x[i];
-}
-// the static gain curve of one sample (audio.py:392-399), shared by the kernels above and the feed generator
-__device__ __forceinline__ float comp_gain_curve(const float xv, const double thresh, const double ratio)
-{
-    float xdb = (float)(20.0 * log10((double)fabsf(xv) + 1e-8));
-    if (xdb < -96.0f) xdb = -96.0f;
-    float gc = 0.0f;
-    if ((double)xdb > thresh) gc = (float)(thresh + ((double)xdb - thresh) / ratio - (double)xdb);
-    return gc;
+    y[(size_t)b * ysz + j] = comp_db_to_lin(g[i]) * x[i];
 }
 __global__ void __launch_bounds__(256)
 compressor_4c_kernel(const float* __restrict__ x, const float* __restrict__ knobs_wc, float sr, int L, int ysz, float* __restrict__ y)

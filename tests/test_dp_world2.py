@@ -117,7 +117,8 @@ def test_world2_library_exchange_equals_single_process(tmp_path, dtype, delay_ra
     # fp32: reassociation of the batch sum only (<= 1e-5 rel on the parameters; Adam turns ulp noise on noise-level gradient
     # elements into a fraction of lr, hence the absolute floor the fused-vs-oracle checks use).  16-bit: each rank rounds its own
     # operands -- the shards' partial products are the same numbers, their fp32 sums re-associate.
-    tol = 2e-5 if dtype == "f32" else 2e-3
+    # (bound for one element: STEPS * LR = 3e-3 -- Adam's first steps move a parameter by ~lr * sign(g), and the sign of a noise-level gradient element may differ)
+    tol = 2e-5 if dtype == "f32" else 3e-3
     assert err <= tol, (dtype, err)
     for a, b in zip(ref_losses, r0["losses"]):
         assert abs(a - b) <= (1e-5 if dtype == "f32" else 2e-3) * abs(a), (ref_losses, r0["losses"])

@@ -88,11 +88,40 @@ def test_pink_noise_is_the_reference_construction():
     assert -0.6 < slope < -0.4, slope
 
 
-def test_long_window_takes_the_noise_from_rocfft():
+@pytest.mark.parametrize("Lw,ysz", [(65536, 16256), (16384, 4000)])
+def test_long_window_noise_by_the_library_s_own_transform(Lw, ysz):
+    """Windows beyond the in-LDS FFT (BASELINE configs[4]: 65536 samples; scale 2: 16384): the 1/f noise comes from the library's four-step inverse FFT
+    (st_feed.h pink_long_pass1 / 2) -- no FFT library on the path, and window i of a stream is the same whatever the batching.  Checked like the short
+    window's noise (unit peak, even sequence, 1/f slope), against a float64 inverse FFT of the spectrum recovered from the output itself, and end to end."""
     from signaltrain_amd import audio, datasets
     np.random.seed(3)
-    ds = datasets.SynthAudioDataSet(65536, audio.Compressor_4c(), y_size=16256, augment=True)
+    ds = datasets.SynthAudioDataSet(Lw, audio.Compressor_4c(), y_size=ysz, augment=True)
+    ds._feed_seed = 1234
+    z, _, _ = ds.batch_device(6, chooser=100)                        # the bare noise
+    assert getattr(ds, "_dev_gen", None) is None                     # the torch generator / rocFFT path was not taken
+    z = z.cpu().double()
+    assert float(z.abs().amax(1).min()) > 0.999 and float(z.abs().amax(1).max()) < 1.001
+    assert float((z[:, 1:Lw // 2] - z[:, Lw // 2 + 1:].flip(1)).abs().max()) < 5e-4               # real spectrum -> even sequence
+    spec = torch.fft.rfft(z, dim=1)                                  # checker side: the spectrum must be REAL, (2u - 1) / sqrt(k + 1) up to the peak scale
+    assert float(spec.imag.abs().max()) < 2e-3 * float(spec.real.abs().max())
+    k = np.arange(8, 6000)
+    slope = np.polyfit(np.log(k + 1.0), np.log(spec.abs().mean(0).numpy()[k]), 1)[0]
+    assert -0.6 < slope < -0.4, slope
+    u = spec.real * torch.sqrt(torch.arange(Lw // 2 + 1, dtype=torch.float64) + 1.0)              # ~ c_b (2u - 1): uniform on [-c_b, c_b] per window
+    u = u / u.abs().amax(1, keepdim=True)
+    assert abs(float(u.mean())) < 0.01 and abs(float(u.var()) - 1.0 / 3.0) < 0.01
+    # reproducible per window index whatever the batching (counter-based: the round-3 rocFFT path drew from a stateful generator)
+    ds._feed_count = 0
+    a, _, _ = ds.batch_device(6, chooser=100)
+    ds._feed_count = 2
+    b, _, _ = ds.batch_device(3, chooser=100)
+    assert torch.equal(a[2:5], b)
+    # end to end: training items at this window
+    ds._feed_count = 0
     x, y, kn = ds.batch_device(16)
-    assert x.shape == (16, 65536) and y.shape == (16, 16256) and bool(torch.isfinite(x).all()) and bool(torch.isfinite(y).all())
-    y2 = audio.Compressor_4c().go_device(x, kn, 16256)
+    assert x.shape == (16, Lw) and y.shape == (16, ysz) and bool(torch.isfinite(x).all()) and bool(torch.isfinite(y).all())
+    y2 = audio.Compressor_4c().go_device(x, kn, ysz)
     assert float((y - y2).abs().max()) <= 1e-6 * float(y2.abs().max())
+    ds._feed_count = 5
+    x2, _, _ = ds.batch_device(4)
+    assert torch.equal(x[5:9], x2)

@@ -11,7 +11,7 @@ For every configuration the sweep flagged (profiles/r03_fuzz_parity.txt "BAD" li
              oracle by fp32 rounding (~1e-7) at every intermediate, i.e. it IS such a perturbation;
   fused      tests.gpu_checks.run_fused (device consumes its own intermediates): the number the sweep flagged.
 
-Reading: fused <= ~2 x self-noise and per-op green  =>  the sweep's miss is the arithmetic's own irreproducibility at that size, and the
+Reading: fused <= ~3 x self-noise and per-op green (or below the same tensor's self-noise)  =>  the sweep's miss is the arithmetic's own irreproducibility at that size, and the
 per-config tolerance derived here (3 x self-noise, floor = the suite's fused tolerance) goes into tests/test_gpu_parity.py
 (test_fuzz_outliers_grounded).  fused >> self-noise or per-op red => a bug.
 
@@ -130,7 +130,10 @@ def main():
             lines.append(f"{r['name']} {r['rel']:.1e} vs {z if z is None else format(z, '.1e')} ({ratio:.1f}x)")
             if z is None or ratio > 3.0:
                 verdict = "SUSPECT"
-        if per_hard:
+        # a per-op miss counts only where it exceeds the oracle's own spread of that tensor: the autoencoder backward entry is itself a nine-layer chain
+        # (device and oracle start from identical inputs but round their own intermediates), so at T = 174 its last layers sit at the noise of the chain
+        per_real = [r for r in per_hard if r["rel"] > nz.get(r["name"].replace("ae_bwd.g.", "grad."), 0.0)]
+        if per_real:
             verdict = "SUSPECT(per-op)"
         nbug += verdict != "noise"
         print(f"{tg} [runs as {effective(mode, kw)}] | per-op {per_worst['name']} {per_worst['rel']:.1e} (tol {per_worst['tol']:.0e}; {len(per_hard)}/{len(per)} miss"
