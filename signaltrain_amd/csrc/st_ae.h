@@ -391,6 +391,13 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     const int KQ = (K + 3) / 4;
     const int gstride = gridDim.x * NW;
     float reg = 0.f;
+    // frequency weights of the L1 term, one per bin (the table sits behind the two forward images; the host sizes the LDS request for it)
+    float* const wtab = lds + 2 * CL::FWD_TOTAL;
+    for (int i = tid; i < FP; i += NW * 64) wtab[i] = i < F ? expf(expfac * (float)i) : 0.f;
+    unsigned toF[4], toK[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { toF[r] = ST_MUL24(4 * g + r, F); toK[r] = ST_MUL24(4 * g + r, KP); }
+    __syncthreads();
 
     FwdIn cur;
     // block-fastest group numbering: the partial last round (ngroups is rarely a multiple of the wave count) then puts ONE
@@ -426,28 +433,31 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         { const float* const W[2] = ST_W2(CL::A6); const float* const bb[2] = ST_W2(CL::B6); layer_fwd<2, 2, 1, CL::O6, BF>(W, bb, h6, h7, g, c); }
         { const float* const W[2] = ST_W2(CL::A7); const float* const bb[2] = ST_W2(CL::B7); layer_fwd<2, 4, 2, CL::O7, BF>(W, bb, h7, h8, g, c); }
         { const float* const W[2] = ST_W2(CL::A8); const float* const bb[2] = ST_W2(CL::B8); layer_fwd<2, 1, 4, CL::O8, BF>(W, bb, h8, e9, g, c); }
-        // ---- epilogue (nn_proc.py:115,117,322-326)
-        const float wf = fv ? expf(expfac * (float)f) : 0.f;     // train.py:115-117 frequency weight
+        // ---- epilogue (nn_proc.py:115,117,322-326).  Round 4: the frequency weight comes from a per-workgroup LDS table (was a full-precision expf per
+        // group), the row offsets of a lane's four output frames are formed once before the loop, and the 16-bit type of the spectra is a compile-time
+        // constant in the 16-bit instantiations (it was converted BOTH ways and selected at run time): 785 -> ~700 vector instructions per row-group pair
+        const float wf = fv ? wtab[f] : 0.f;                     // train.py:115-117 frequency weight exp(expfac * f)
+        const unsigned boF = ST_MUL24(ST_MUL24(b, OT), F) + (unsigned)f, boK = ST_MUL24(ST_MUL24(b, OT), KP) + (unsigned)f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int to = 4 * g + r;
             if (to < OT) {
-                const unsigned ro = ST_MUL24(b, OT) + (unsigned)to;
                 float mh = 0.f, ph = 0.f, sn = 0.f, cs = 1.f;
                 if (fv) {
                     mh = e9[0][0][r] * cur.tl[0][r];               // 'sf' skip-filter
                     ph = e9[1][0][r] + cur.tl[1][r];               // phase residual
                     st_sincos(ph, sn, cs);
-                    stg32(mag_hat, ST_MUL24(ro, F) + (unsigned)f, mh);
-                    stg32(phs_hat, ST_MUL24(ro, F) + (unsigned)f, ph);
+                    stg32(mag_hat, boF + toF[r], mh);
+                    stg32(phs_hat, boF + toF[r], ph);
                     reg += fabsf(mh * wf);
                 }
                 if (AA16) {                                                   // wave-uniform
-                    AA16[ST_MUL24(ro, KP) + (unsigned)f] = st_to_h16(mh * cs, aa_ht);
-                    AA16[ST_MUL24(ro, KP) + (unsigned)(FP + f)] = st_to_h16(mh * sn, aa_ht);
+                    const int ht = BF ? BF : aa_ht;                           // *_all modes: the spectra's type IS the layers' type
+                    AA16[boK + toK[r]] = st_to_h16(mh * cs, ht);
+                    AA16[boK + toK[r] + (unsigned)FP] = st_to_h16(mh * sn, ht);
                 } else {
-                    stg32(AA, ST_MUL24(ro, KP) + (unsigned)f, mh * cs);       // f < FP always: pads get zeros
-                    stg32(AA, ST_MUL24(ro, KP) + (unsigned)(FP + f), mh * sn);
+                    stg32(AA, boK + toK[r], mh * cs);       // f < FP always: pads get zeros
+                    stg32(AA, boK + toK[r] + (unsigned)FP, mh * sn);
                 }
             }
         }

@@ -17,6 +17,7 @@
 #include "st_ae.h"
 #include "st_ae_wide.h"
 #include "st_ae_split.h"
+#include "st_ae32.h"
 #include "st_dp.h"
 #include "st_feed.h"
 
@@ -174,6 +175,7 @@ static int g_ae_split = -1;  // autoencoder backward of the fused geometries: 0 
                              // wave has nothing to overlap with -- and the split moves 66 MB more per step: h4 / d a4 / tails hand-over); 16-bit Linear layers -> split (the
                              // matrix pipe is then a separate unit and two waves per SIMD overlap it with the ELU / conversion / transpose work: 102 -> 48 + 44 us at
                              // B = 256, 354 -> 152 + 138 us at B = 1024, bf16_all)
+static int g_ae32 = 1;       // 16-bit autoencoder forward of the fused geometries on 32-row groups / v_mfma_f32_32x32x16 (st_ae32.h); 0 = the 16-row kernel of st_ae.h (st_set_tuning(8100 + n))
 static int g_pl_bf16 = 0;    // ST_PREC_BF16*: analysis / frames GEMMs on the plane kernel with ONE plane (bf16 copies of the bases, k-chunk-major).  MEASURED SLOWER at B = 256
                              // (analysis 53.8 vs 49.8 us + 12 us for the copies): three MFMAs per 16-deep k-tile and barrier; needs a 64-deep tile   (st_set_tuning(9400 + n))
 static int g_wg_split = 0;   // ST_PREC_F32X3: weight-gradient GEMMs on the in-kernel three-plane split instead of the fp32 MFMA kernel (see ST_GEMM_WG)   (st_set_tuning(9300 + n))
@@ -225,6 +227,7 @@ extern "C" int st_set_tuning(int bk)
     if (bk >= 9200) { g_pl_dgrad = bk - 9200; return ST_OK; }
     if (bk >= 9100) { g_pl_shape = bk - 9100; return ST_OK; }
     if (bk >= 9000) { g_frs_nt = bk - 9000; return ST_OK; }
+    if (bk >= 8100 && bk < 8110) { g_ae32 = bk - 8100; return ST_OK; }           // 8100 / 8101: 16-bit autoencoder forward on 16-row / 32-row groups (st_ae32.h)
     if (bk >= 8000) { g_ae_split = bk == 8002 ? -1 : bk - 8000; return ST_OK; }     // 8000 / 8001 / 8002: single-kernel / split autoencoder backward / by precision
     if (bk >= 7000) { g_xt = bk - 7000; return ST_OK; }
     if (bk >= 6000) { g_wsplit_half = bk - 6000; return ST_OK; }  // 6000 + n: split-K of the half (one-basis) analysis weight-gradient GEMMs of st_loss_backward_stage (0: as the full GEMM)
@@ -242,7 +245,7 @@ extern "C" int st_set_tuning(int bk)
 // (a wrong default can then not ship unnoticed, and a test cannot leak a switch into the next one).
 #define ST_TUNING_LIST(X) X(g_dbg, 0) X(g_ae_split, -1) X(g_pl_bf16, 0) X(g_wg_split, 0) X(g_pl_dgrad, 0) X(g_pl_shape, 3) X(g_g16, 1) X(g_g16_bk, 64) X(g_g16_dma, 0) \
     X(g_g16_abl, 0) X(g_g16_split, 0) X(g_nt128, 1) X(g_tn128, 1) X(g_tn_bk, 32) X(g_frs_nt, 1) X(g_xt, 0) X(g_wide_pair, 1) X(g_wide_dvp, 1) X(g_nt_mi, 0) X(g_an_bk, 32) \
-    X(g_bk, 16) X(g_wsplit_max, 16) X(g_wsplit_div, 200) X(g_an_waves, 4) X(g_syn_split, 3) X(g_frs_split, 3) X(g_wide_fused, 1) X(g_wsplit_half, 0) X(g_wg_mode, 0)
+    X(g_bk, 16) X(g_wsplit_max, 16) X(g_wsplit_div, 200) X(g_an_waves, 4) X(g_syn_split, 3) X(g_frs_split, 3) X(g_wide_fused, 1) X(g_wsplit_half, 0) X(g_wg_mode, 0) X(g_ae32, 1)
 static int g_wg_mode = 0;
 extern "C" int st_get_tuning(int* out, int n)
 {
@@ -493,15 +496,20 @@ static int ae_fwd_impl(const st_dims* d, const float* mag, const float* phs, con
     }
     ST_REQ((size_t)d->B * d->T * d->F < ((size_t)1 << 30) && (size_t)d->B * d->OT * L.KP < ((size_t)1 << 30),
            "st_ae_fwd: batch too large for the kernel's 32-bit element offsets (B=%d)", d->B);
-    const size_t lds = (size_t)2 * sta::CL::FWD_TOTAL * sizeof(float);
+    const size_t lds = ((size_t)2 * sta::CL::FWD_TOTAL + (size_t)(L.KP / 2)) * sizeof(float);      // two forward images + the per-bin frequency weights
     const float expfac = (float)(7.0 / d->F);
 #define ST_AE_FWD_LAUNCH(HT_) do { ST_DYN_LDS((sta::ae_fwd_kernel<AE_FWD_NW, HT_>)); \
         hipLaunchKernelGGL((sta::ae_fwd_kernel<AE_FWD_NW, HT_>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, st_stream(stream), \
                            mag, phs, knobs, ae_m, ae_p, L.go, mag_hat, phs_hat, AA, reg_partial, \
                            d->B, d->T, d->OT, d->F, d->K, L.KP, expfac, ws, AA16, aa_ht); } while (0)
+    const bool use32 = g_ae32 && ae_ht(d->prec) != 0 && L.KP / 2 <= 17 * 32 && AE_FWD_NW == 8;
+#define ST_AE_FWD32_LAUNCH(HT_) do { ST_DYN_LDS((sta::ae_fwd32_kernel<AE_FWD_NW, HT_>)); \
+        hipLaunchKernelGGL((sta::ae_fwd32_kernel<AE_FWD_NW, HT_>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), (size_t)sta::ae32_lds_floats(L.KP / 2) * sizeof(float), st_stream(stream), \
+                           mag, phs, knobs, ae_m, ae_p, L.go, mag_hat, phs_hat, AA, reg_partial, \
+                           d->B, d->T, d->OT, d->F, d->K, L.KP, expfac, ws, AA16, aa_ht); } while (0)
     switch (ae_ht(d->prec)) {
-    case 1: ST_AE_FWD_LAUNCH(1); break;
-    case 2: ST_AE_FWD_LAUNCH(2); break;
+    case 1: if (use32) ST_AE_FWD32_LAUNCH(1); else ST_AE_FWD_LAUNCH(1); break;
+    case 2: if (use32) ST_AE_FWD32_LAUNCH(2); else ST_AE_FWD_LAUNCH(2); break;
     default:
         if (ae_fwd_nw(d) == 11) {
             ST_DYN_LDS((sta::ae_fwd_kernel<11, 0>));
@@ -510,6 +518,7 @@ static int ae_fwd_impl(const st_dims* d, const float* mag, const float* phs, con
         } else ST_AE_FWD_LAUNCH(0);
     }
 #undef ST_AE_FWD_LAUNCH
+#undef ST_AE_FWD32_LAUNCH
     ST_LAUNCHED("ae_fwd"); return ST_OK;
 }
 
@@ -1683,13 +1692,14 @@ extern "C" int st_compressor_4c(const float* x, const float* knobs_wc, float sr,
 }
 
 // scratch of st_synth_comp4c for the full-featured path: [gain curve B * L | world knobs 4 B] and, for power-of-two windows beyond the in-LDS FFT
-// (8192 < L <= 65536), [1/f noise B * L | per-window peaks | four-step FFT buffer 2 * min(B, 256) * L]
+// (8192 < L <= 65536), [1/f noise B * L | per-window peaks | four-step FFT buffer 2 * min(B, 1024) * L]
+static const int FEED_FFT_SUB = 1024;      // windows per pass-1 / pass-2 launch pair of the long-window noise (a launch pair costs ~50 us whatever its size: few, large ones)
 static bool feed_long_fft(int L) { return L > stf::FFT_MAX && (L & (L - 1)) == 0 && L / stf::PL_N1 <= 256; }
 extern "C" size_t st_synth_comp4c_scratch_floats(int B, int L)
 {
     if (B <= 0 || L <= 0) return 0;
     size_t n = (size_t)B * (L + 4);
-    if (feed_long_fft(L)) n += (size_t)B * L + (size_t)st_round_up(B, 64) + (size_t)2 * (B < 256 ? B : 256) * L;
+    if (feed_long_fft(L)) n += (size_t)B * L + (size_t)st_round_up(B, 64) + (size_t)2 * (B < FEED_FFT_SUB ? B : FEED_FFT_SUB) * L;
     return n;
 }
 extern "C" int st_synth_comp4c(unsigned seed, unsigned long long first_window, int B, int L, int ysz, int K, float sr,
@@ -1710,13 +1720,13 @@ extern "C" int st_synth_comp4c(unsigned seed, unsigned long long first_window, i
     const bool split = scratch && L % 64 == 0;
     a.gc = split ? scratch : nullptr; a.kw = split ? scratch + (size_t)B * L : nullptr;
     if (long_fft) {
-        // the window's 1/f noise by the library's own four-step inverse FFT (st_feed.h pink_long_pass1 / 2), 256 windows at a time through the FFT buffer
+        // the window's 1/f noise by the library's own four-step inverse FFT (st_feed.h pink_long_pass1 / 2), 1024 windows at a time through the FFT buffer
         float* pink = scratch + (size_t)B * (L + 4);
         float* peak = pink + (size_t)B * L;
         float2* fbuf = reinterpret_cast<float2*>(peak + st_round_up(B, 64));
         const int N2 = L / stf::PL_N1;
-        for (int b0 = 0; b0 < B; b0 += 256) {
-            const int nb = B - b0 < 256 ? B - b0 : 256;
+        for (int b0 = 0; b0 < B; b0 += FEED_FFT_SUB) {
+            const int nb = B - b0 < FEED_FFT_SUB ? B - b0 : FEED_FFT_SUB;
             hipLaunchKernelGGL(stf::pink_long_pass1_kernel, dim3(stf::PL_N1 / stf::PL_G, nb), dim3(256), 0, st_stream(stream), seed, first_window + (unsigned long long)b0, L, chooser, fbuf, peak + b0);
             hipLaunchKernelGGL(stf::pink_long_pass2_kernel, dim3(N2 / stf::PL_G, nb), dim3(256), 0, st_stream(stream), seed, first_window + (unsigned long long)b0, L, chooser,
                                (const float2*)fbuf, pink + (size_t)b0 * L, peak + b0);
@@ -2061,6 +2071,7 @@ static int attr_prepare(const st_dims* d)
         ST_PREP3((stw::wide_dv_polar_kernel<0>), (stw::wide_dv_polar_kernel<1>), (stw::wide_dv_polar_kernel<2>));
     } else {
         ST_PREP3((sta::ae_fwd_kernel<AE_FWD_NW, 0>), (sta::ae_fwd_kernel<AE_FWD_NW, 1>), (sta::ae_fwd_kernel<AE_FWD_NW, 2>));
+        if (ht == 1) ST_DYN_LDS((sta::ae_fwd32_kernel<AE_FWD_NW, 1>)); else if (ht == 2) ST_DYN_LDS((sta::ae_fwd32_kernel<AE_FWD_NW, 2>));
         if (ht == 0) ST_DYN_LDS((sta::ae_fwd_kernel<11, 0>));
         ST_PREP3((sta::ae_bwd_part_kernel<AE_SPLIT_NW, 1, 0, false>), (sta::ae_bwd_part_kernel<AE_SPLIT_NW, 1, 1, false>), (sta::ae_bwd_part_kernel<AE_SPLIT_NW, 1, 2, false>));
         ST_PREP3((sta::ae_bwd_part_kernel<AE_SPLIT_NW, 2, 0, false>), (sta::ae_bwd_part_kernel<AE_SPLIT_NW, 2, 1, false>), (sta::ae_bwd_part_kernel<AE_SPLIT_NW, 2, 2, false>));

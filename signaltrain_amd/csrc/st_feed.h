@@ -95,7 +95,7 @@ __device__ __forceinline__ float block_max(float v, float* red)
 //           (atomicMax on the bits of a non-negative float); the generator kernel divides by the peak when it mixes the noise in.
 // Only windows whose family uses the noise (chooser 1, 7; 100 in tests) do any work: a third of the training stream.  Round 3 took this noise from
 // torch.fft (rocFFT) driven by a stateful torch.Generator: 2 ms of full-width GPU time per 2048 windows and not reproducible per window index.
-constexpr int PL_N1 = 256, PL_G = 8;
+constexpr int PL_N1 = 256, PL_G = 16;      // 16 transforms per workgroup: 128-byte segments in pass 1's transposed store, 64-byte ones in pass 2's
 __device__ __forceinline__ int feed_family(Draw& d, const int chooser)
 {
     const int ci = d.randint(0, 6);
@@ -105,29 +105,34 @@ __device__ __forceinline__ unsigned feed_key(const unsigned seed, const unsigned
 {
     return mix32(seed ^ mix32((unsigned)w + 1u) ^ mix32((unsigned)(w >> 32) + 0x51ED27u));
 }
-// G independent in-place inverse FFTs of length n = 2^logn in LDS (a[g * n + i], input stored bit-reversed), 256 threads
-__device__ __forceinline__ void ifft_batch_lds(float2* a, const int n, const int logn, const int G)
+// G independent in-place inverse FFTs of length n = 2^logn in LDS (a[g * n + i], input stored bit-reversed), 256 threads; tw[k] = e^{2 pi i k / n}, k < n / 2
+__device__ __forceinline__ void ifft_batch_lds(float2* a, const float2* tw, const int n, const int logn, const int G)
 {
     const int half_total = G * (n >> 1);
     for (int s = 1; s <= logn; ++s) {
-        const int half = 1 << (s - 1);
+        const int half = 1 << (s - 1), tstep = n >> s;
         for (int j = threadIdx.x; j < half_total; j += 256) {
             const int g = j / (n >> 1), jj = j - g * (n >> 1);
             const int grp = jj >> (s - 1), pos = jj & (half - 1);
             const int i0 = g * n + (grp << s) + pos, i1 = i0 + half;
-            float sn, cs; sincospif((float)pos / (float)half, &sn, &cs);
+            const float2 w = tw[pos * tstep];
             const float2 u = a[i0], v = a[i1];
-            const float2 t = make_float2(v.x * cs - v.y * sn, v.x * sn + v.y * cs);
+            const float2 t = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
             a[i0] = make_float2(u.x + t.x, u.y + t.y);
             a[i1] = make_float2(u.x - t.x, u.y - t.y);
         }
         __syncthreads();
     }
 }
+__device__ __forceinline__ void twiddle_table(float2* tw, const int n)
+{
+    for (int k = threadIdx.x; k < n / 2; k += 256) { float sn, cs; sincospif(2.0f * (float)k / (float)n, &sn, &cs); tw[k] = make_float2(cs, sn); }
+}
 __global__ void __launch_bounds__(256)
 pink_long_pass1_kernel(const unsigned seed, const unsigned long long first, const int L, const int chooser, float2* __restrict__ scr, float* __restrict__ peak)
 {
     __shared__ float2 lds[PL_G * 256];
+    __shared__ float2 tw[128];
     const int b = blockIdx.y, N2 = L / PL_N1;
     const unsigned long long w = first + (unsigned long long)b;
     Draw d{feed_key(seed, w), 0u};
@@ -136,6 +141,7 @@ pink_long_pass1_kernel(const unsigned seed, const unsigned long long first, cons
     if (!(ch == 1 || ch == 7 || ch == 100)) return;                     // workgroup-uniform
     if (blockIdx.x == 0 && threadIdx.x == 0) peak[b] = 0.f;
     int logn = 0; while ((1 << logn) < N2) ++logn;
+    twiddle_table(tw, N2);
     const int k1_0 = blockIdx.x * PL_G;
     for (int j = threadIdx.x; j < PL_G * N2; j += 256) {
         const int g = j / N2, k2 = j - g * N2;
@@ -145,7 +151,7 @@ pink_long_pass1_kernel(const unsigned seed, const unsigned long long first, cons
         lds[g * N2 + (int)(__brev((unsigned)k2) >> (32 - logn))] = make_float2(v, 0.f);
     }
     __syncthreads();
-    ifft_batch_lds(lds, N2, logn, PL_G);
+    ifft_batch_lds(lds, tw, N2, logn, PL_G);
     float2* out = scr + (size_t)b * L;
     for (int j = threadIdx.x; j < PL_G * N2; j += 256) {
         const int n2 = j / PL_G, g = j - n2 * PL_G, k1 = k1_0 + g;
@@ -159,12 +165,14 @@ pink_long_pass2_kernel(const unsigned seed, const unsigned long long first, cons
                        float* __restrict__ pink, float* __restrict__ peak)
 {
     __shared__ float2 lds[PL_G * PL_N1];
+    __shared__ float2 tw[PL_N1 / 2];
     __shared__ float red[4];
     const int b = blockIdx.y, N2 = L / PL_N1;
     const unsigned long long w = first + (unsigned long long)b;
     Draw d{feed_key(seed, w), 0u};
     const int ch = feed_family(d, chooser);
     if (!(ch == 1 || ch == 7 || ch == 100)) return;
+    twiddle_table(tw, PL_N1);
     const int n2_0 = blockIdx.x * PL_G;
     const float2* in = scr + (size_t)b * L + (size_t)n2_0 * PL_N1;
     for (int j = threadIdx.x; j < PL_G * PL_N1; j += 256) {
@@ -172,7 +180,7 @@ pink_long_pass2_kernel(const unsigned seed, const unsigned long long first, cons
         lds[g * PL_N1 + (int)(__brev((unsigned)k1) >> 24)] = in[j];
     }
     __syncthreads();
-    ifft_batch_lds(lds, PL_N1, 8, PL_G);
+    ifft_batch_lds(lds, tw, PL_N1, 8, PL_G);
     float m = 0.f;
     float* o = pink + (size_t)b * L;
     for (int j = threadIdx.x; j < PL_G * PL_N1; j += 256) {

@@ -340,6 +340,8 @@ def test_engine_on_a_non_current_device_or_stream():
     ("bf16_all", (9693,), (9690,)),       # 16-bit analysis forward + data gradient on the LDS-DMA kernel (producer / consumer waves)
     ("f16_all", (9693,), (9690,)),
     ("bf16_all", (9600,), (9601,)),       # converting GEMM (gemm_half_kernel) instead of the pre-rounded 16-bit operand pipeline
+    ("bf16_all", (8100,), (8101,)),       # 16-bit autoencoder forward on 16-row groups (st_ae.h) instead of the 32-row kernel (st_ae32.h)
+    ("f16_all", (8100,), (8101,)),
 ])
 def test_alternative_code_paths_agree(dtype, codes, restore):
     """The variants kept behind st_set_tuning (measured slower, or experiments) compute the same thing as the default path: loss and

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import numpy as np, torch
 from signaltrain_amd import audio, datasets, _lib
 lib = _lib.load()
-for L, ysz, B in ((8192, 2048, 256), (8192, 2048, 2048), (65536, 16256, 64)):
+for L, ysz, B in ((8192, 2048, 256), (8192, 2048, 2048), (65536, 16256, 64), (65536, 16256, 2048)):
     ds = datasets.SynthAudioDataSet(L, audio.Compressor_4c(), y_size=ysz)
     for _ in range(3): ds.batch_device(B)
     torch.cuda.synchronize(); t0 = time.time(); n = 20
