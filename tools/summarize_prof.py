@@ -41,6 +41,12 @@ for sub, cname in (("pmc3", "FETCH_SIZE"), ("pmc4", "WRITE_SIZE")):
                 k = r["Kernel_Name"].split("(")[0]; acc[k] += float(r["Counter_Value"]); cnt[k] += 1
         for k in acc:
             traffic[k][cname + "_KB"] = acc[k] / cnt[k]
+# rocprofv3's own average duration per kernel (kernel-trace stats of the same command): bench.py's roofline prefers it over its in-process HIP-event
+# timing (which reads 2-3 us high per launch) when the file matches the sources it runs
+for f in sorted(glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True)):
+    for r in csv.DictReader(open(f)):
+        k = r["Name"].split("(")[0]
+        traffic[k]["avg_ns"] = float(r["AverageNs"]); traffic[k]["calls"] = int(r["Calls"])
 if traffic:
     # meta: which sources and which bench arguments these counters were measured on (bench.py refuses anything else)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
