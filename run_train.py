@@ -22,7 +22,7 @@ if __name__ == "__main__":
     p.add_argument('--resume-optimizer', action='store_true', help="restore Adam's moments (and, if the checkpoint belongs to this schedule, the position in the run) from --checkpoint")
     p.add_argument('-b', '--batch', type=int, help="batch size (per GPU)", default=200)
     p.add_argument('--checkpoint', help='name of checkpoint .tar file to start from', default='modelcheckpoint.tar')
-    p.add_argument('-c', '--compand', help='accepted for compatibility', action='store_true')
+    p.add_argument('-c', '--compand', help='mu-law compand the audio of a file dataset (datasets.py:218-220)', action='store_true')
     p.add_argument('--effect', help='effect to learn', default='comp_4c', choices=['comp_4c', 'comp_4c_large', 'files'])
     p.add_argument('--epochs', type=int, default=1000)
     p.add_argument('--lrmax', type=float, help="maximum learning rate", default=1e-4)

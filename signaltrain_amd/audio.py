@@ -116,9 +116,20 @@ class Compressor_4c_Large(Compressor_4c):
 
 
 # ------------------------------------------------------------------------------------------------ wav files + file-defined effects
+def mu_compand(y, mu=32):
+    """audio.py:339-340: mu-law companding (run_train.py --compand, datasets.py:218-220, utils/predict_long.py:38-40)."""
+    return np.sign(y) * np.log(1 + mu * np.abs(y)) / np.log(1 + mu)
+
+
+def mu_decompand(y, mu=32):
+    """audio.py:343-344."""
+    return np.sign(y) / mu * ((1 + mu) ** np.abs(y) - 1)
+
+
 def read_audio_file(filename, sr=44100, mono=True, norm=False, dtype=np.float32, **_ignored):
-    """audio.py:207-255: a wav file as float in [-1, 1] (int16 / 32767), first channel if `mono`; other sample rates are refused
-    (the reference resamples them through librosa, which is not part of this feed)."""
+    """audio.py:207-255: a wav file as float in [-1, 1] (int16 / 32767), first channel if `mono`.  A file at another sample rate is resampled to
+    `sr` with a polyphase filter (scipy.signal.resample_poly; the reference calls librosa.resample there -- another low-pass design, so such
+    files agree with the reference's to the filters' pass-band ripple, not bit for bit)."""
     from scipy.io import wavfile
     import warnings
     with warnings.catch_warnings():
@@ -128,9 +139,13 @@ def read_audio_file(filename, sr=44100, mono=True, norm=False, dtype=np.float32,
         signal = signal[:, 0]
     if signal.dtype == np.int16:
         signal = np.array(signal / 32767.0, dtype=dtype)
-    if read_sr != int(sr):
-        raise NotImplementedError(f"{filename}: sample rate {read_sr} Hz, expected {sr} Hz (resample the dataset first)")
     signal = signal.astype(dtype, copy=False)
+    if read_sr != int(sr):
+        from math import gcd
+        from scipy.signal import resample_poly
+        g = gcd(int(sr), int(read_sr))
+        print(f"read_audio_file: {filename}: resampling {read_sr} Hz -> {int(sr)} Hz")
+        signal = resample_poly(signal.astype(np.float64), int(sr) // g, int(read_sr) // g, axis=0).astype(dtype)
     if norm:
         m = np.max(np.abs(signal))
         signal = signal / m if m > 0 else signal

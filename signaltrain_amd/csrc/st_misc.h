@@ -634,7 +634,8 @@ clip_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict
         }
         ST_ADAM1(x) ST_ADAM1(y) ST_ADAM1(z) ST_ADAM1(w)
 #undef ST_ADAM1
-        reinterpret_cast<float4*>(g)[i] = G;       // clipped gradient is observable in the reference (p.grad)
+        if (sc != 1.0f) reinterpret_cast<float4*>(g)[i] = G;       // the clipped / rescaled gradient is observable in the reference (p.grad); with sc == 1 (clip inactive, one rank,
+                                                                   // no loss scale) the buffer already holds these very values: 12.6 MB of writes less per step
         reinterpret_cast<float4*>(m)[i] = M;
         reinterpret_cast<float4*>(v)[i] = V;
         reinterpret_cast<float4*>(p)[i] = P;

