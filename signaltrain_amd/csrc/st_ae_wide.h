@@ -288,19 +288,9 @@ __global__ void pad_rows_kernel(const float* __restrict__ src, int rows, int col
     dst[i] = c < cols ? src[r * cols + c] : 0.f;
 }
 
-// The zero-padded copies of W_1 ([64][Tp]) and W_5 ([16][32]) of both autoencoders (was four pad_rows launches, then one of its own, now extra
-// blocks of wide_in_kernel)
-struct PadJobs { const float* src[4]; float* dst[4]; int rows[4], cols[4], pitch[4], blk0[5]; };
-__device__ __forceinline__ void pad_rows4_block(const PadJobs& j, const int blk)
-{
-    int q = 0;
-#pragma unroll
-    for (int k = 1; k < 4; ++k) q += blk >= j.blk0[k];
-    const int i = (blk - j.blk0[q]) * 256 + threadIdx.x;
-    if (i >= j.rows[q] * j.pitch[q]) return;
-    const int r = i / j.pitch[q], c = i - r * j.pitch[q];
-    j.dst[q][i] = c < j.cols[q] ? j.src[q][r * j.cols[q] + c] : 0.f;
-}
+// The zero-padded copies of W_1 ([64][Tp]) and W_5 ([16][32]) of both autoencoders ride in this kernel (per-op entry) or in prep_kernel (fused step): stm::PadJobs
+using stm::PadJobs;
+using stm::pad_rows4_block;
 // Inputs in the feature-major layout: V[a][t][b*FP + f] = (mag | phs)[b][t][f]; knob rows 16.. of the layer-5 input.
 // Flattened over (row, window, quad of bins): one thread = four bins of both nets = eight 4-byte loads (the [B][T][F] rows are 4-byte aligned
 // only) and two 16-byte stores (FP % 4 == 0).  Round 3: as one block per (row, window) with a 256-stride loop over 528 bins -- the third

@@ -198,6 +198,7 @@ static int g_xt = 0;       // 1: M/N-contiguous operands staged k-quad-major (st
 static const int NORM_E_PARTIALS = 32;     // |g| partials of the autoencoder gradient range (st_dims.clip_all) when they come from l1_partial_kernel
 static const int NORM_E_MAX = 4096;        // room for the per-block partials of the reducing kernels themselves (post_ae_kernel / wide_grad_finish_kernel)
 static int g_wide_pair = 1;  // wide geometries, 16-bit: the layer-1 / layer-9 GEMMs of the two autoencoders as ONE launch each (gemm_half_pair_kernel); 0 = two launches (st_set_tuning(9960 + n), diagnostics)
+static int g_wide_direct = 1; // wide geometries: the analysis epilogue writes the wide autoencoder path's feature-major input itself (no wide_in_kernel in the fused step); 0 = copy kernel (st_set_tuning(9970 + n), diagnostics)
 static int g_wide_dvp = 1;   // wide geometries: layer-1 data gradient (+ polar backward) as one fused kernel; 0 = two GEMMs + polar_bwd (st_set_tuning(9900), diagnostics)
 static int g_nt_mi = 0;     // fp32 NT x NT GEMMs with 64 x 96 wave tiles (MI = 2): 0 off; bit 0 analysis forward <4,16,2>, bit 1 <2,32,2>, bit 2 frames / dgrad <2,16,2>  (st_set_tuning(9800 + n), experiments)
 static int g_an_bk = 32;   // k-tile depth of the analysis forward GEMM (see ST_GEMM_AN)
@@ -211,6 +212,7 @@ extern "C" int st_set_tuning(int bk)
 #else
     if ((bk >= 96800 && bk < 96928) || (bk >= 9680 && bk < 9690)) return st_fail(ST_ERR_ARG, "st_set_tuning(%d): timing-only ablation, needs a -DST_DIAG build", bk);
 #endif
+    if (bk >= 9970 && bk < 9980) { g_wide_direct = bk - 9970; return ST_OK; }
     if (bk >= 9960) { g_wide_pair = bk - 9960; return ST_OK; }
     if (bk >= 9950 && bk < 9960) { g_nt128 = bk - 9950; return ST_OK; }
     if (bk >= 9900) { g_wide_dvp = bk - 9900; return ST_OK; }
@@ -245,7 +247,7 @@ extern "C" int st_set_tuning(int bk)
 // (a wrong default can then not ship unnoticed, and a test cannot leak a switch into the next one).
 #define ST_TUNING_LIST(X) X(g_dbg, 0) X(g_ae_split, -1) X(g_pl_bf16, 0) X(g_wg_split, 0) X(g_pl_dgrad, 0) X(g_pl_shape, 3) X(g_g16, 1) X(g_g16_bk, 64) X(g_g16_dma, 0) \
     X(g_g16_abl, 0) X(g_g16_split, 0) X(g_nt128, 1) X(g_tn128, 1) X(g_tn_bk, 32) X(g_frs_nt, 1) X(g_xt, 0) X(g_wide_pair, 1) X(g_wide_dvp, 1) X(g_nt_mi, 0) X(g_an_bk, 32) \
-    X(g_bk, 16) X(g_wsplit_max, 16) X(g_wsplit_div, 200) X(g_an_waves, 4) X(g_syn_split, 3) X(g_frs_split, 3) X(g_wide_fused, 1) X(g_wsplit_half, 0) X(g_wg_mode, 0) X(g_ae32, 1)
+    X(g_bk, 16) X(g_wsplit_max, 16) X(g_wsplit_div, 200) X(g_an_waves, 4) X(g_syn_split, 3) X(g_frs_split, 3) X(g_wide_fused, 1) X(g_wsplit_half, 0) X(g_wg_mode, 0) X(g_ae32, 1) X(g_wide_direct, 1)
 static int g_wg_mode = 0;
 extern "C" int st_get_tuning(int* out, int n)
 {
@@ -430,17 +432,21 @@ extern "C" size_t st_ae_bwd_ws_floats(const st_dims* d)
 }
 static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, const float* phs, const float* knobs,
                        const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA, float* reg_partial,
-                       WideWS& w, void* stream, unsigned short* AA16 = nullptr);
+                       WideWS& w, void* stream, unsigned short* AA16 = nullptr, bool in_done = false);
 
 // ------------------------------------------------------------------------------ per-op entry points
+// Feature-major destination of the polar epilogue on wide geometries (st_gemm.h PolarStore::Vm / Vp): the wide autoencoder path's input layout
+struct PolarWide { float* Vm; float* Vp; int FP; unsigned RV; };
+static inline void polar_wide_set(stg::PolarStore& ep, const PolarWide* pw) { if (pw && pw->Vm) { ep.Vm = pw->Vm; ep.Vp = pw->Vp; ep.FP = pw->FP; ep.RV = pw->RV; } }
 // `padded`: sig is the workspace copy [B][N + L + N] (zero margins, input scale applied) written by pad_scale_kernel.
 static int analysis_fwd_impl(const st_dims* d, const float* sig, bool padded, const float* Wr, const float* Wi, float in_scale,
-                             float* re, float* im, float* mag, float* phs, void* stream, bool dead_frames_done = false)
+                             float* re, float* im, float* mag, float* phs, void* stream, bool dead_frames_done = false, const PolarWide* pw = nullptr)
 {
     const stg::RowMap map = stg::live_frames(d->T, d->H, d->N, d->N, d->L);   // frames entirely inside the Conv1d padding are skipped
     const int R = map.rows(d->B);
     stg::AnalysisW bl{Wr, Wi, d->F, d->N};
     stg::PolarStore ep{re, im, mag, phs, R, d->F, map};
+    polar_wide_set(ep, pw);
     if (padded) {
         stg::FramedNT<true> al{sig, d->L, d->H, d->N, R, d->N, 1.0f, map};
         if (gemm_ht(d->prec) == 0 && (g_nt_mi & 1)) stg::launch<4, 16, 2>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream), g_dbg);
@@ -474,7 +480,7 @@ static int pad_scale(const float* in, float* out, int B, int Ls, int pad, float 
 // AA16 != NULL (fused step of the 16-bit GEMM configurations): the spectra are written rounded to the operand type, not as fp32
 static int ae_fwd_impl(const st_dims* d, const float* mag, const float* phs, const float* knobs,
                        const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA,
-                       float* reg_partial, float* ws, void* stream, unsigned short* AA16 = nullptr);
+                       float* reg_partial, float* ws, void* stream, unsigned short* AA16 = nullptr, bool wide_in_done = false);
 extern "C" int st_ae_fwd(const st_dims* d, const float* mag, const float* phs, const float* knobs,
                          const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA,
                          float* reg_partial, float* ws, void* stream)
@@ -483,7 +489,7 @@ extern "C" int st_ae_fwd(const st_dims* d, const float* mag, const float* phs, c
 }
 static int ae_fwd_impl(const st_dims* d, const float* mag, const float* phs, const float* knobs,
                        const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA,
-                       float* reg_partial, float* ws, void* stream, unsigned short* AA16)
+                       float* reg_partial, float* ws, void* stream, unsigned short* AA16, bool wide_in_done)
 {
     Layout L; ST_TRY(make_layout(d, &L));
     const int aa_ht = AA16 ? gemm_ht(d->prec) : 0;
@@ -492,7 +498,7 @@ static int ae_fwd_impl(const st_dims* d, const float* mag, const float* phs, con
         ST_REQ(mag_hat, "st_ae_fwd: the code-only pass exists for the fused geometries only");
         ST_REQ(ws, "st_ae_fwd: this geometry (T=%d, OT=%d) needs st_ae_fwd_ws_floats() floats of workspace", d->T, d->OT);
         WideWS w; wide_carve(d, ws, &w);
-        return ae_wide_fwd(d, L, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, AA, reg_partial, w, stream, AA16);
+        return ae_wide_fwd(d, L, mag, phs, knobs, ae_m, ae_p, mag_hat, phs_hat, AA, reg_partial, w, stream, AA16, wide_in_done);
     }
     ST_REQ((size_t)d->B * d->T * d->F < ((size_t)1 << 30) && (size_t)d->B * d->OT * L.KP < ((size_t)1 << 30),
            "st_ae_fwd: batch too large for the kernel's 32-bit element offsets (B=%d)", d->B);
@@ -701,7 +707,7 @@ extern "C" int st_effective_prec(const st_dims* d)
         else { ST_WGEMM(A0_, B0_, E0_, M_, N_, K_, NS_, S_); ST_WGEMM(A1_, B1_, E1_, M_, N_, K_, NS_, S_); } } while (0)
 static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, const float* phs, const float* knobs,
                        const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA, float* reg_partial,
-                       WideWS& w, void* stream, unsigned short* AA16)
+                       WideWS& w, void* stream, unsigned short* AA16, bool in_done)
 {
     hipStream_t s = st_stream(stream);
     const int FP = L.KP / 2, F = d->F, T = d->T, OT = d->OT, R = (int)w.R, Tp = w.Tp;
@@ -709,7 +715,7 @@ static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, cons
     ST_REQ(w.R * (size_t)(T > 64 ? T : 64) < ((size_t)1 << 30), "wide autoencoder path: batch too large (B=%d)", d->B);
     const stg::RowMap id = stg::all_frames(1);
     int out[9], in[9]; ae_shapes(d, out, in);
-    {
+    if (!in_done) {      // the fused step's analysis GEMM wrote V itself and prep_kernel did the side jobs (round 4); the per-op entry copies here
         stw::PadJobs pj; int blk = 0;
         for (int a = 0; a < 2; ++a) {
             const float* ae = a ? ae_p : ae_m;
@@ -723,8 +729,8 @@ static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, cons
         const int n_copy = (int)(((size_t)(T + d->K) * d->B * (FP / 4) + 255) / 256);
         hipLaunchKernelGGL(stw::wide_in_kernel, dim3(n_copy + blk), dim3(256), 0, s, mag, phs, knobs, w.V[0], w.V[1], w.H[0][3], w.H[1][3],
                            d->B, T, F, FP, d->K, n_copy, pj);
+        ST_LAUNCHED("ae_wide_in");
     }
-    ST_LAUNCHED("ae_wide_in");
     // layers 1..8: GEMM for layer 1 (K = T); layers 2..8 either one fused kernel for both nets (default) or seven more GEMMs
     if (g_wide_fused) {
         stg::PlainNT al0{w.W1p[0], out[0], Tp, Tp, id}, al1{w.W1p[1], out[0], Tp, Tp, id};
@@ -1190,13 +1196,14 @@ static int planes_prepare(const st_dims* d, const float* Wr, const float* Wi, WS
     ST_LAUNCHED("planes");
     return ST_OK;
 }
-static int analysis_fwd_planes(const st_dims* d, WS& w, float* re, float* im, float* mag, float* phs, void* stream)
+static int analysis_fwd_planes(const st_dims* d, WS& w, float* re, float* im, float* mag, float* phs, void* stream, const PolarWide* pw = nullptr)
 {
     const stg::RowMap map = stg::live_frames(d->T, d->H, d->N, d->N, d->L);
     const int R = map.rows(d->B);
     stg::FramedNT<true> al{w.xp, d->L, d->H, d->N, R, d->N, 1.0f, map};
     stg::ChunkP bl{w.pl_W, 2 * d->F};
     stg::PolarStore ep{re, im, mag, phs, R, d->F, map};
+    polar_wide_set(ep, pw);
     if (planes_of(d) == 1) ST_TRY((stg::launch_planes<4, 1>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream))));
     else if (g_pl_shape == 1) ST_TRY((stg::launch_planes<2, 3, 2>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream))));
     else if (g_pl_shape == 2) ST_TRY((stg::launch_planes<4, 3, 2>(al, bl, ep, R, 2 * d->F, d->N, 1, st_stream(stream))));
@@ -1246,7 +1253,7 @@ static bool use_g16(const st_dims* d)
     return g_g16 && (ht == 1 || ht == 2) && !g_pl_bf16 && d->N % 128 == 0 && num_cus() > 0;
 }
 #define ST_G16(CALL_) do { if (gemm_ht(d->prec) == 2) ST_TRY((stg::CALL_<2>)); else ST_TRY((stg::CALL_<1>)); } while (0)
-static int analysis_fwd16(const st_dims* d, WS& w, float* re, float* im, float* mag, float* phs, void* stream)
+static int analysis_fwd16(const st_dims* d, WS& w, float* re, float* im, float* mag, float* phs, void* stream, const PolarWide* pw = nullptr)
 {
     const stg::RowMap map = stg::live_frames(d->T, d->H, d->N, d->N, d->L);
     const int R = map.rows(d->B);
@@ -1254,6 +1261,7 @@ static int analysis_fwd16(const st_dims* d, WS& w, float* re, float* im, float* 
     if (g_g16_abl & 4) ra.S2 &= ~7u;              // timing only: 16-byte aligned frame rows
     const stg::Rows16 rb = stg::rows16_plain(w.W16, (unsigned)d->N, 2 * d->F);
     stg::PolarStore ep{re, im, mag, phs, R, d->F, map};
+    polar_wide_set(ep, pw);
     if (g_g16_abl & 1) ep.mag = ep.phs = nullptr;
     if (g_g16_abl & 2) ep.re = ep.im = nullptr;
     if ((g_g16_dma & 1) && d->N % 64 == 0) {
@@ -1331,6 +1339,11 @@ static int forward_impl(const st_dims* d, const Layout& L, const float* params, 
     const float* Wr = params + L.offs[0]; const float* Wi = params + L.offs[1];
     const float* Sr = params + L.offs[2]; const float* Si = params + L.offs[3];
     const float* ae_m = params + L.offs[4]; const float* ae_p = params + L.offs[22];
+    // wide geometries (round 4): the analysis epilogue writes mag / phs straight into the wide autoencoder path's feature-major input
+    const bool wide_direct = ae_is_wide(d) && g_wide_direct && (size_t)d->B * (L.KP / 2) * (size_t)(d->T > 64 ? d->T : 64) < ((size_t)1 << 30);
+    WideWS ww; if (wide_direct) wide_carve(d, w.aews, &ww);
+    PolarWide pwide{nullptr, nullptr, 0, 0u};
+    if (wide_direct) pwide = PolarWide{ww.V[0], ww.V[1], L.KP / 2, (unsigned)ww.R};
     // saved-for-backward state always lives in the workspace; user-visible outputs are copies
     {   // one launch: x/2 (nn_proc.py:307) with the Conv1d padding materialised, the Hermitian fold of the synthesis bases
         // (cls_fe_dft.py:109-110 on the weights) and the exact zeros of the frames that lie wholly in the padding
@@ -1344,18 +1357,38 @@ static int forward_impl(const st_dims* d, const Layout& L, const float* params, 
         a.n_dead = n_dead; a.ht = w.g16 ? gemm_ht(d->prec) : 0; a.n_w16 = 0;
         a.xp16 = w.xp16; a.Sfold16 = w.Sfold16; a.SfoldT16 = w.SfoldT16; a.W16 = w.W16; a.Wr = Wr; a.Wi = Wi;
         if (a.ht) a.n_w16 = (int)(((size_t)2 * d->F * (d->N / 4) + 255) / 256);
-        hipLaunchKernelGGL(stm::prep_kernel, dim3(a.n_pad + a.n_fold + n_dead + a.n_w16), dim3(256), 0, st_stream(stream), a);
+        a.wd = stm::PrepWide{}; a.wd.n_vpad = a.wd.n_kn = a.wd.n_pj = 0;
+        if (wide_direct) {       // wide geometries: the side jobs of the feature-major input (see stm::PrepWide)
+            const int FP = L.KP / 2, Tp = ww.Tp;
+            a.wd.Vm = ww.V[0]; a.wd.Vp = ww.V[1]; a.wd.FP = FP; a.wd.B = d->B; a.wd.R = (unsigned)ww.R;
+            a.wd.H4Km = ww.H[0][3]; a.wd.H4Kp = ww.H[1][3]; a.wd.knobs = knobs; a.wd.K = d->K;
+            int blk = 0;
+            for (int n = 0; n < 2; ++n) {
+                const float* ae = n ? ae_p : ae_m;
+                a.wd.pj.src[2 * n] = ae + L.go.w[0]; a.wd.pj.dst[2 * n] = ww.W1p[n]; a.wd.pj.rows[2 * n] = 64; a.wd.pj.cols[2 * n] = d->T; a.wd.pj.pitch[2 * n] = Tp;
+                a.wd.pj.blk0[2 * n] = blk; blk += (64 * Tp + 255) / 256;
+                a.wd.pj.src[2 * n + 1] = ae + L.go.w[4]; a.wd.pj.dst[2 * n + 1] = ww.W5p[n]; a.wd.pj.rows[2 * n + 1] = 16; a.wd.pj.cols[2 * n + 1] = 16 + d->K; a.wd.pj.pitch[2 * n + 1] = 32;
+                a.wd.pj.blk0[2 * n + 1] = blk; blk += 2;
+            }
+            a.wd.pj.blk0[4] = blk; a.wd.n_pj = blk;
+            a.wd.n_vpad = (int)(((size_t)d->B * d->T * (FP - d->F) + 255) / 256); if (a.wd.n_vpad < 1) a.wd.n_vpad = 1;
+            a.wd.n_kn = (int)(((size_t)d->K * d->B * (FP / 4) + 255) / 256);
+        }
+        hipLaunchKernelGGL(stm::prep_kernel, dim3(a.n_pad + a.n_fold + n_dead + a.wd.n_vpad + a.wd.n_kn + a.wd.n_pj + a.n_w16), dim3(256), 0, st_stream(stream), a);
         ST_LAUNCHED("prep");
     }
     const bool planes = use_planes(d) && !w.g16;
-    if (w.g16) ST_TRY(analysis_fwd16(d, w, save ? w.re : nullptr, save ? w.im : nullptr, w.mag, w.phs, stream));
+    // a training call (target given, no user-visible |STFT| requested) on the direct wide path needs mag / phs ONLY in the feature-major layout
+    const bool polar_rows = !(wide_direct && y_true && !mag);
+    float* const pmag = polar_rows ? w.mag : nullptr; float* const pphs = polar_rows ? w.phs : nullptr;
+    if (w.g16) ST_TRY(analysis_fwd16(d, w, save ? w.re : nullptr, save ? w.im : nullptr, pmag, pphs, stream, &pwide));
     else if (planes) {
         ST_TRY(planes_prepare(d, Wr, Wi, w, stream));
-        ST_TRY(analysis_fwd_planes(d, w, save ? w.re : nullptr, save ? w.im : nullptr, w.mag, w.phs, stream));
+        ST_TRY(analysis_fwd_planes(d, w, save ? w.re : nullptr, save ? w.im : nullptr, pmag, pphs, stream, &pwide));
     } else
-    ST_TRY(analysis_fwd_impl(d, w.xp, true, Wr, Wi, 1.0f, save ? w.re : nullptr, save ? w.im : nullptr, w.mag, w.phs, stream, true));
+    ST_TRY(analysis_fwd_impl(d, w.xp, true, Wr, Wi, 1.0f, save ? w.re : nullptr, save ? w.im : nullptr, pmag, pphs, stream, true, &pwide));
     ST_TRY(ae_fwd_impl(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.AA, w.reg_p,
-                       (ae_is_wide(d) || (save && ae_use_split(d))) ? w.aews : nullptr, stream, w.g16 ? w.AA16 : nullptr));     // fused geometries: the code h4 is kept for the split backward
+                       (ae_is_wide(d) || (save && ae_use_split(d))) ? w.aews : nullptr, stream, w.g16 ? w.AA16 : nullptr, wide_direct));     // fused geometries: the code h4 is kept for the split backward
     if (w.g16) ST_TRY(synthesis_frames16(d, w, stream)); else
     if (planes) ST_TRY(synthesis_frames_planes(d, w, stream)); else
     ST_TRY(synthesis_frames_impl(d, w.AA, w.Sfold, w.SfoldT, w.frs, stream));

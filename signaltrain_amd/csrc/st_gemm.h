@@ -304,6 +304,9 @@ struct BiasStore {    // out[row*ld + col] = acc + bias[col]   (Conv1d bias; bia
 // of row r and the odd lane that of row r+1, so every lane does ONE sqrt and ONE atan2 per register pair.
 struct PolarStore {
     float* re; float* im; float* mag; float* phs; int R, F; RowMap map;
+    // round 4, wide geometries: mag / phs ALSO (or, with mag == phs == NULL, only) in the feature-major layout of the wide autoencoder path,
+    // V[t][b * FP + bin] with RV = B * FP columns per frame row (st_ae_wide.h); NULL: off
+    float* Vm = nullptr; float* Vp = nullptr; int FP = 0; unsigned RV = 0;
     template <int NJX>
     __device__ void operator()(int m0, int n0, const f32x16 (&acc)[NJX]) const {
         const int lane = threadIdx.x & 63;
@@ -311,7 +314,9 @@ struct PolarStore {
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
             const int row = m0 + d_row(i + (odd ? 1 : 0), lane);
-            const size_t rbase = (size_t)(row < R ? map.full(row) : 0) * F;
+            int wb = 0, wt = 0; map.split(row < R ? row : 0, wb, wt);
+            const size_t rbase = (size_t)((int)__umul24((unsigned)wb, (unsigned)map.T) + wt) * F;
+            const size_t vbase = (size_t)wt * RV + (size_t)wb * FP;
 #pragma unroll
             for (int j = 0; j < NJX; ++j) {
                 const int bin = (n0 + 32 * j + (lane & 31)) >> 1;
@@ -322,8 +327,12 @@ struct PolarStore {
                     const size_t idx = rbase + bin;
                     if (re) re[idx] = vr;
                     if (im) im[idx] = vi;
-                    if (mag) mag[idx] = __builtin_amdgcn_sqrtf(vr * vr + vi * vi);      // v_sqrt_f32, 1 ulp
-                    if (phs) phs[idx] = st_atan2f(vi, vr + 1e-7f);
+                    if (mag || phs || Vm) {
+                        const float mg = __builtin_amdgcn_sqrtf(vr * vr + vi * vi), ph = st_atan2f(vi, vr + 1e-7f);      // v_sqrt_f32, 1 ulp
+                        if (mag) mag[idx] = mg;
+                        if (phs) phs[idx] = ph;
+                        if (Vm) { Vm[vbase + bin] = mg; Vp[vbase + bin] = ph; }
+                    }
                 }
             }
         }

@@ -138,6 +138,28 @@ pad_scale_kernel(const float* __restrict__ in, float* __restrict__ out, int Ls, 
 // launches of 6-8 us each, mostly launch ramp): [0, n_pad) the padded, pre-scaled signal copy; [n_pad, n_pad + n_fold) the Hermitian
 // fold of the synthesis bases (they change only in the optimizer, but the workspace is the caller's and may be re-carved between
 // steps, so the fold is rebuilt per step -- 12 MB of traffic, as 32 x 32 tiles written in both orientations); the rest zeroes the frames that lie wholly in the Conv1d padding.
+// The zero-padded copies of W_1 ([64][Tp]) and W_5 ([16][32]) of both autoencoders for the wide autoencoder path (st_ae_wide.h): up to four row-padding jobs
+struct PadJobs { const float* src[4]; float* dst[4]; int rows[4], cols[4], pitch[4], blk0[5]; };
+__device__ __forceinline__ void pad_rows4_block(const PadJobs& j, const int blk)
+{
+    int q = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) q += blk >= j.blk0[k];
+    const int i = (blk - j.blk0[q]) * 256 + threadIdx.x;
+    if (i >= j.rows[q] * j.pitch[q]) return;
+    const int r = i / j.pitch[q], c = i - r * j.pitch[q];
+    j.dst[q][i] = c < j.cols[q] ? j.src[q][r * j.cols[q] + c] : 0.f;
+}
+// Round 4, wide geometries (T > 32 or OT > 16): the analysis GEMM's polar epilogue writes mag / phs STRAIGHT into the feature-major layout the wide
+// autoencoder path reads (V[a][t][b * FP + f], st_ae_wide.h) -- the transposing copy kernel in between (wide_in_kernel: 91 MB, 18 us at the
+// 65536-sample window) is gone from the fused step.  What that kernel did on the side moves here: the pad columns f in [F, FP) and the all-padding
+// frames of V as zeros, the knob rows of the layer-5 input, the zero-padded weight copies.
+struct PrepWide {
+    float *Vm, *Vp; int FP, B; unsigned R;            // R = B * FP columns
+    float *H4Km, *H4Kp; const float* knobs; int K;     // knob rows 16 + k of the layer-5 input of both nets
+    PadJobs pj;
+    int n_vpad, n_kn, n_pj;                            // block counts of the three jobs (0: not a wide geometry)
+};
 struct PrepArgs {
     const float* x; float* xp; int Ls, pad; float scale; int nbx, n_pad;
     const float* Sr; const float* Si; float* Sfold; float* SfoldT; int N, F, KP, n_fold;
@@ -145,6 +167,7 @@ struct PrepArgs {
     // 16-bit configurations (st_gemm16.h): ht = 1 bf16 / 2 fp16 -- the padded waveform and both folds go out in 16 bits INSTEAD of fp32,
     // and n_w16 more blocks write the F used rows of the analysis bases as rows (bin, re | im) interleaved: W16[2 bin + part][N]
     int ht; unsigned short *xp16, *Sfold16, *SfoldT16, *W16; const float* Wr; const float* Wi; int n_w16, n_dead;
+    PrepWide wd;
 };
 // 32 x 32 tile of the folded synthesis bases, written twice: Sfold [KP][N] (rows k: the K-contiguous operand of the synthesis data-gradient
 // GEMM) and its transpose SfoldT [N][KP] (rows n: the K-contiguous operand of the synthesis FRAMES GEMM, which otherwise has to take
@@ -195,9 +218,38 @@ prep_kernel(const PrepArgs a)
     const int blk = blockIdx.x;
     if (blk < a.n_pad) { const int b = blk / a.nbx; pad_scale_block(a.x, a.xp, a.Ls, a.pad, a.scale, blk - b * a.nbx, a.nbx, b, a.ht ? a.xp16 : nullptr, a.ht); }
     else if (blk < a.n_pad + a.n_fold) fold_tile(a.Sr, a.Si, a.Sfold, a.SfoldT, a.N, a.F, a.KP, blk - a.n_pad, a.ht ? a.Sfold16 : nullptr, a.ht ? a.SfoldT16 : nullptr, a.ht);
-    else if (blk < a.n_pad + a.n_fold + a.n_dead) zero_dead_frame(a.re, a.im, a.mag, a.phs, a.T, a.F, a.t_lo, a.Tv, blk - a.n_pad - a.n_fold);
+    else if (blk < a.n_pad + a.n_fold + a.n_dead) {
+        zero_dead_frame(a.re, a.im, a.mag, a.phs, a.T, a.F, a.t_lo, a.Tv, blk - a.n_pad - a.n_fold);
+        if (a.wd.n_vpad) {                           // ... and the same frame of the feature-major copy, pad columns included
+            const int nd = a.T - a.Tv, j0 = blk - a.n_pad - a.n_fold, b = j0 / nd, j = j0 - b * nd, t = j < a.t_lo ? j : j + a.Tv;
+            const size_t o = (size_t)t * a.wd.R + (size_t)b * a.wd.FP;
+            for (int f = threadIdx.x; f < a.wd.FP; f += 256) { a.wd.Vm[o + f] = 0.f; a.wd.Vp[o + f] = 0.f; }
+        }
+    }
+    else if (blk < a.n_pad + a.n_fold + a.n_dead + a.wd.n_vpad) {          // pad columns f in [F, FP) of every frame of V
+        const int np = a.wd.FP - a.F;
+        const unsigned idx = (unsigned)(blk - a.n_pad - a.n_fold - a.n_dead) * 256u + threadIdx.x;
+        if (np > 0 && idx < (unsigned)a.wd.B * (unsigned)a.T * (unsigned)np) {
+            const unsigned bt = idx / (unsigned)np, pcol = idx - bt * (unsigned)np, b = bt / (unsigned)a.T, t = bt - b * (unsigned)a.T;
+            const size_t o = (size_t)t * a.wd.R + (size_t)b * a.wd.FP + a.F + pcol;
+            a.wd.Vm[o] = 0.f; a.wd.Vp[o] = 0.f;
+        }
+    }
+    else if (blk < a.n_pad + a.n_fold + a.n_dead + a.wd.n_vpad + a.wd.n_kn) {   // knob rows: H4K[16 + k][b * FP + f] = knobs[b][k] (0 in the pad columns)
+        const unsigned Q = (unsigned)a.wd.FP / 4, idx = (unsigned)(blk - a.n_pad - a.n_fold - a.n_dead - a.wd.n_vpad) * 256u + threadIdx.x;
+        if (idx < (unsigned)a.wd.K * (unsigned)a.wd.B * Q) {
+            const unsigned kb = idx / Q, j = idx - kb * Q, k = kb / (unsigned)a.wd.B, b = kb - k * (unsigned)a.wd.B;
+            const int f0 = 4 * (int)j;
+            const float v = a.wd.knobs[b * a.wd.K + k];
+            const float4 q = make_float4(f0 < a.F ? v : 0.f, f0 + 1 < a.F ? v : 0.f, f0 + 2 < a.F ? v : 0.f, f0 + 3 < a.F ? v : 0.f);
+            const size_t o = (size_t)(16 + k) * a.wd.R + (size_t)b * a.wd.FP;
+            reinterpret_cast<float4*>(a.wd.H4Km + o)[j] = q; reinterpret_cast<float4*>(a.wd.H4Kp + o)[j] = q;
+        }
+    }
+    else if (blk < a.n_pad + a.n_fold + a.n_dead + a.wd.n_vpad + a.wd.n_kn + a.wd.n_pj)
+        pad_rows4_block(a.wd.pj, blk - a.n_pad - a.n_fold - a.n_dead - a.wd.n_vpad - a.wd.n_kn);
     else {                                           // analysis bases, 4 taps per thread
-        const size_t i4 = (size_t)(blk - a.n_pad - a.n_fold - a.n_dead) * 256 + threadIdx.x, n4 = a.N / 4;
+        const size_t i4 = (size_t)(blk - a.n_pad - a.n_fold - a.n_dead - a.wd.n_vpad - a.wd.n_kn - a.wd.n_pj) * 256 + threadIdx.x, n4 = a.N / 4;
         if (i4 < (size_t)2 * a.F * n4) {
             const int jrow = (int)(i4 / n4), c = (int)(i4 - (size_t)jrow * n4);
             const float4 v = reinterpret_cast<const float4*>(((jrow & 1) ? a.Wi : a.Wr) + (size_t)(jrow >> 1) * a.N)[c];

@@ -405,3 +405,34 @@ def test_fuzz_outliers_grounded(idx):
         fused = G.run_fused(steps=1, **kw)
     bad = [r for r in fused if not r["ok"] and "conv_analysis" not in r["name"] and r["rel"] > 3.0 * noise.get(r["name"], 0.0)]
     assert not bad, [(r["name"], r["rel"], r["tol"], noise.get(r["name"])) for r in bad]
+
+
+@pytest.mark.parametrize("dtype,scale,shrink", [("f32", 2, 4), ("f16_all", 2, 4), ("bf16_all", 1, 1), ("f32", 8, 4)])
+def test_wide_direct_input_equals_copy_kernel(dtype, scale, shrink):
+    """Wide geometries (round 4): the analysis GEMM's polar epilogue writes mag / phs straight into the feature-major input of the wide autoencoder
+    path and prep_kernel does the copy kernel's side jobs (pad columns, all-padding frames, knob rows, padded weight copies).  Same values, same
+    arithmetic downstream: loss and all 40 gradient tensors are BITWISE those of the copy-kernel form (st_set_tuning(9970)), and the user-visible
+    |STFT| of a forward call is still written."""
+    import numpy as np, torch
+    from tests import gpu_checks as G
+    from signaltrain_amd import _lib
+    from signaltrain_amd.engine import StepEngine
+    lib = _lib.load()
+    B, K = 2, 4
+    geo, X, Y, KN, P = G.make_case(B, 23, K=K, scale=scale, shrink=shrink)
+    x, kn, y = G.t(X), G.t(KN), G.t(Y)
+
+    def run():
+        d = G.dims_of(geo, B, K)
+        eng = StepEngine(d, G.DEV, compute_dtype=dtype); eng.load_state_dict(P)
+        eng.loss_backward(x, kn, y); torch.cuda.synchronize()
+        g = eng.grads.clone(); l = float(eng.scalars[0])
+        yh, mag, mh = eng.forward(x, kn); torch.cuda.synchronize()
+        return g, l, mag.clone()
+    g1, l1, m1 = run()
+    try:
+        _lib.check(lib.st_set_tuning(9970), "st_set_tuning")
+        g0, l0, m0 = run()
+    finally:
+        _lib.check(lib.st_set_tuning(9971), "st_set_tuning")
+    assert l0 == l1 and torch.equal(g0, g1) and torch.equal(m0, m1) and float(m1.abs().max()) > 0
