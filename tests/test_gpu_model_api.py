@@ -373,6 +373,40 @@ def test_dp_collective_path_single_rank(schedule, backend):
         dist.destroy_process_group()
 
 
+def test_dp_packed_exchange_through_real_rccl_single_rank():
+    """The bf16-packed last exchange (exchange flag 4, `DataParallel(pack16=True)`) through the REAL RCCL with one rank: ncclBfloat16 all-reduce of the packed analysis
+    rows, widened by unstage_l1_kernel.  With one rank the only difference to the fused step is the bf16 rounding of those gradient rows: same loss, parameters
+    within the 16-bit modes' step-level tolerance; in an fp32 engine the flag is ignored (bitwise the plain exchange)."""
+    import socket
+    import torch.distributed as dist
+    from tests import gpu_checks as G
+    from signaltrain_amd.engine import StepEngine
+    from signaltrain_amd.dp import DataParallel
+    B, K = 4, 4
+    geo, X, Y, KN, P = G.make_case(B, 21, K=K)
+    d = G.dims_of(geo, B, K)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        x, kn, y = G.t(X), G.t(KN), G.t(Y)
+        for dtype, tol in (("bf16_all", 3e-3), ("f32", 0.0)):
+            e1 = StepEngine(d, G.DEV, compute_dtype=dtype); e1.load_state_dict(P)
+            e2 = StepEngine(d, G.DEV, compute_dtype=dtype); e2.load_state_dict(P)
+            ref = DataParallel(e1, force_collectives=True, schedule="staged", backend="lib")
+            dp = DataParallel(e2, force_collectives=True, schedule="staged", backend="lib", pack16=True)
+            for it in range(2):
+                ref.train_step(x, kn, y, 1e-3); dp.train_step(x, kn, y, 1e-3)
+                torch.cuda.synchronize()
+                assert abs(ref.mean_loss() - dp.mean_loss()) <= 1e-3 * abs(ref.mean_loss()) + 1e-12
+                err = (e1.params - e2.params).abs().max().item()
+                assert err <= tol, (dtype, it, err)
+            if dtype == "bf16_all":
+                assert (e1.grads - e2.grads).abs().max().item() > 0          # the packed exchange really rounded the analysis rows
+            ref.close(); dp.close()
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("scale,B", [(1, 5), (8, 2)])
 def test_staged_backward_is_bitwise_the_fused_backward(scale, B):
     """the four data-parallel stages (st_loss_backward_stage) leave exactly the gradients and loss scalars

@@ -12,6 +12,9 @@ Round 2 (f32x3 = three-plane bfloat16 split against the fp32 oracle at fp32 tole
 628 configurations, fp32 and f32x3 all green (the same "soft" analysis-gradient conditioning lines in both), 4 level-2 outliers
 (bf16_all 4-5e-2 at B <= 9, f16_all 1.0-1.3e-2 at B <= 3) of the kind described above.
 Round 3 (400 s, profiles/r03_fuzz_parity.txt): 628 configurations, fp32 and f32x3 all green, 4 level-2 outliers of the same kind (bf16_all 4-5e-2 at B <= 9, f16_all 1.3e-2 at B = 2); after the wide-path pass, 500 s: 806 configurations, fp32 / f32x3 green, 6 such outliers (bf16_all 4-7e-2 at B <= 9, f16_all 1.0-1.3e-2 at B <= 3).
+Round 4 (500 s, profiles/r04_fuzz_parity.txt): 824 configurations incl. odd batches on the wide path again (the library reports its effective arithmetic, the oracle follows); fp32 / f32x3 /
+bf16 / bf16_all green; ONE hard line -- f16_all, L = 65536, B = 2, K = 16, seed 482: 1.3e-2 on the layer-1 weight gradient of the phase net -- the configuration tools/fuzz_ground.py shows to sit at
+0.7 x the oracle's own spread (1.8e-2); the sweep held scale 8 to the scale-1 tolerance (8e-3) where the suite uses 2 x that: same multiplier here now.
     python tools/fuzz_parity.py [seconds]"""
 import sys, time, random; sys.path.insert(0, '.')
 from tests import gpu_checks as G
@@ -31,7 +34,7 @@ while time.time() - t0 < float(sys.argv[1] if len(sys.argv) > 1 else 150):
         if bf == 3:
             with G.split_mode(): res = G.run_fused(**kw)
         elif bf == 4:
-            with G.mixed_mode(2, half="f16", tol_scale=G.mixed_mode.FUSED_TOL_F16[2]): res = G.run_fused(**kw)
+            with G.mixed_mode(2, half="f16", tol_scale=G.mixed_mode.FUSED_TOL_F16[2] * (2.0 if scale == 8 else 1.0)): res = G.run_fused(**kw)      # as tests/test_gpu_parity.py: 174-frame rows, more roundings per sum
         elif bf:
             with G.bf16_mode(bf, tol_scale=G.bf16_mode.FUSED_TOL[bf]): res = G.run_fused(**kw)
         else:
