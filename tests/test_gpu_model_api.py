@@ -641,6 +641,30 @@ def test_train_driver_device_feed(tmp_path):
         os.chdir(cwd)
 
 
+def test_train_driver_host_feed_and_dataset_items(tmp_path):
+    """The reference's own feed: train.train(device_feed=False) = a torch DataLoader with CPU workers over SynthAudioDataSet.__getitem__ (workers generate
+    with the CPU-device form of the batched generators + the effect's host helper; the main process may use the GPU generators), and the Dataset contract on a GPU box:
+    items out of a device-generated chunk, recycle=True fixed items."""
+    from signaltrain_amd import train, audio, nn_proc, datasets
+    nn_proc._QUIET = True
+    np.random.seed(5)
+    ds = datasets.SynthAudioDataSet(8192, audio.Compressor_4c(), datapoints=12, y_size=2048, item_chunk=8)
+    x, y, k = ds[0]
+    assert x.shape == (8192,) and y.shape == (2048,) and k.shape == (4,) and x.dtype == np.float32 and np.abs(x).max() > 0.05
+    y2 = audio.Compressor_4c().go(x, k)[0][-2048:]                       # the target IS the effect of the input at those knobs (device compressor vs host helper)
+    assert np.abs(y2 - y).max() < 2e-5 * max(1.0, np.abs(y2).max())
+    rec = datasets.SynthAudioDataSet(8192, audio.Compressor_4c(), datapoints=5, y_size=2048, recycle=True, item_chunk=4)
+    assert rec.x.shape == (5, 8192) and np.array_equal(rec[2][0], rec[2][0]) and not np.array_equal(rec[2][0], rec[3][0])
+    cwd = os.getcwd(); os.chdir(tmp_path)
+    try:
+        torch.manual_seed(0); np.random.seed(0)
+        train.train(effect=audio.Compressor_4c(), epochs=1, n_data_points=64, batch_size=16, device=torch.device("cuda:0"), num_workers=2, device_feed=False, lr_max=2e-4)
+        lines = [l.split() for l in open("vl_avg_out.dat").read().strip().splitlines()]
+        assert len(lines) >= 1 and all(np.isfinite(float(l[-1])) for l in lines)
+    finally:
+        os.chdir(cwd)
+
+
 def test_train_driver_bf16_all(tmp_path):
     """train.train(compute_dtype="bf16_all"): the mixed-precision step (bf16 operands in the STFT GEMMs and the autoencoder
     layers, fp32 master weights / optimizer) through the driver, device-resident data: its validation-loss trajectory over four
