@@ -250,6 +250,31 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz, const int nz
 #endif
 }
 
+// Two-dimensional variant for GEMMs whose BOTH operands are larger than what a band leaves in one L2 (the analysis forward: 46 x 11 tiles, A = 10.5 MB
+// of waveform, B = 4.2 MB of bases; with bands of tile columns every XCD streamed all of A: 100 MB fetched for 12.6 MB of operands, flagged since round 1).
+// The eight XCDs own a 4 x 2 grid of blocks of (tile rows, tile columns); an XCD's contiguous range of the block-major tile sequence lies in its block (+- a
+// few tiles: block sizes are not all equal), whose A rows (1/4) and B panel (1/2) fit a 4 MB L2 together.  No split-K (bz = 0).
+__device__ __forceinline__ void xcd_tile_2d(int& bx, int& by, int& bz)
+{
+    bx = blockIdx.x; by = blockIdx.y; bz = 0;
+#if ST_XCD_SWIZZLE
+    const int nx = gridDim.x, ny = gridDim.y;
+    const int T = nx * ny;
+    if (T < 64 || nx < 2 || ny < 4) { xcd_tile(bx, by, bz); return; }
+    const int L = bx + nx * by;
+    const int j = L & 7, q = T >> 3, r = T & 7;
+    int p = j * q + (j < r ? j : r) + (L >> 3);               // position in the block-major sequence
+#pragma unroll
+    for (int blk = 0; blk < 8; ++blk) {
+        const int rb = blk >> 1, cb = blk & 1;
+        const int r0 = (rb * ny) >> 2, r1 = ((rb + 1) * ny) >> 2, c0 = (cb * nx) >> 1, c1 = ((cb + 1) * nx) >> 1;
+        const int sz = (r1 - r0) * (c1 - c0);
+        if (p < sz) { const int rr = p / (c1 - c0); by = r0 + rr; bx = c0 + (p - rr * (c1 - c0)); return; }
+        p -= sz;
+    }
+#endif
+}
+
 // ------------------------------------------------------------------------------ epilogues
 // D layout of v_mfma_f32_32x32x2_f32: reg i of lane l holds
 //   row = (i&3) + 8*(i>>2) + 4*(l>>5),  col = l&31.
@@ -339,6 +364,8 @@ struct PolarStore {
     }
 };
 
+template <class E> constexpr bool kPolarEpi = false;
+template <> constexpr bool kPolarEpi<PolarStore> = true;
 template <class L, class = void> struct has_tn_params { static constexpr bool value = false; };
 template <class L> struct has_tn_params<L, decltype((void)L::kParams)> { static constexpr bool value = L::kParams; };
 
@@ -391,7 +418,8 @@ gemm_kernel(const AL al, const BL bl, const EPI epi, const int K, const int kspl
     __shared__ __attribute__((aligned(16))) float Bs[2 * B_SZ];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int tbx, tby, tbz; xcd_tile(tbx, tby, tbz);
+    int tbx, tby, tbz;
+    if constexpr (kPolarEpi<EPI>) xcd_tile_2d(tbx, tby, tbz); else xcd_tile(tbx, tby, tbz);      // the analysis forward (never split-K): 2-D blocks of tiles per XCD
     const int m_blk = tby * BM, n_blk = tbx * BN;
     const int k_begin = tbz * ksplit;
     const int k_end = (k_begin + ksplit < K) ? k_begin + ksplit : K;

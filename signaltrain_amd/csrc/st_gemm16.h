@@ -64,7 +64,8 @@ gemm16_nt_kernel(const Rows16 ra, const Rows16 rb, const EPI epi, const int K, c
     h16_t* const Bs = g16_lds + 2 * TS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    int tbx, tby, tbz; xcd_tile(tbx, tby, tbz);
+    int tbx, tby, tbz;
+    if constexpr (kPolarEpi<EPI>) xcd_tile_2d(tbx, tby, tbz); else xcd_tile(tbx, tby, tbz);      // analysis forward: 2-D blocks of tiles per XCD (st_gemm.h)
     const int m_blk = tby * 128, n_blk = tbx * 128;
     const int k_begin = tbz * ksplit;
     const int k_end = (k_begin + ksplit < K) ? k_begin + ksplit : K;
