@@ -622,6 +622,37 @@ __device__ __forceinline__ void to_T(float* scr, const f32x4 (&d)[TL], f32x4 (&t
         for (int r = 0; r < 4; ++r) t[k][r] = scr[k * 320 + (4 * g + r) * 20 + c];
 }
 
+// Round 4, 16-bit Linear layers: the ACTIVATION operand of a weight gradient (h^T: rows on the k index) is only ever used rounded to 16 bits -- so it is
+// transposed IN 16 bits: the lane's packed quad (features 4g .. 4g + 3 of row c: the very value the forward MFMA chain consumes) goes to a [row][16 features]
+// half-precision scratch with one ds_write_b64, and the LDS transpose read of gfx950 (ds_read_b64_tr_b16: lane i of a 16-lane group supplies the address of k row
+// i >> 2, columns 4 (i & 3) .. + 3 of a [4 k][16] block and receives the four k of column i) hands lane (g, c) the rows 4g .. 4g + 3 of feature c, packed:
+// ONE write + ONE read per 16 x 16 tile instead of one ds_write_b128 + four ds_read_b32 + two conversions.  (d A^T stays fp32: the bias gradient sums it unrounded.)
+template <int BF> struct TTy { typedef f32x4 type; };
+template <> struct TTy<1> { typedef s16x4 type; };
+template <> struct TTy<2> { typedef s16x4 type; };
+template <int TL, int BF>
+__device__ __forceinline__ void to_Th(float* scr, const f32x4 (&d)[TL], typename TTy<BF>::type (&t)[TL], const int g, const int c)
+{
+    if constexpr (BF == 0) to_T<TL>(scr, d, t, g, c);
+    else {
+        short* hs = reinterpret_cast<short*>(scr);
+#pragma unroll
+        for (int k = 0; k < TL; ++k) *reinterpret_cast<s16x4*>(hs + k * 256 + c * 16 + 4 * g) = pack_h4<BF>(d[k]);
+#pragma unroll
+        for (int k = 0; k < TL; ++k)
+            t[k] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(hs + k * 256 + (4 * g + (c >> 2)) * 16 + 4 * (c & 3)));
+    }
+}
+template <int BF>
+__device__ __forceinline__ typename TTy<BF>::type tt_splat(const float v)      // the same value in every row (a knob feature)
+{
+    if constexpr (BF == 0) return (f32x4){v, v, v, v};
+    else return pack_h4<BF>((f32x4){v, v, v, v});
+}
+// wgrad_reg with the activation operand in its transposed type (fp32 quads, or packed 16-bit quads from to_Th)
+template <int OTL, int ITL, int BF>
+__device__ __forceinline__ void wgrad_regh(f32x4 (&dW)[OTL][ITL], float (&db)[OTL], const f32x4 (&daT)[OTL], const typename TTy<BF>::type (&hT)[ITL]);
+
 template <int OTL, int ITL, int BF = 0>
 __device__ __forceinline__ void dgradD_fr(const f32x4 (&fr)[ITL * OTL], const f32x4 (&da)[OTL], f32x4 (&dh)[ITL])
 {
@@ -683,6 +714,20 @@ __device__ __forceinline__ void wgrad_reg(f32x4 (&dW)[OTL][ITL], float (&db)[OTL
 #endif
         }
         db[ot] += (daT[ot][0] + daT[ot][1]) + (daT[ot][2] + daT[ot][3]);
+    }
+}
+template <int OTL, int ITL, int BF>
+__device__ __forceinline__ void wgrad_regh(f32x4 (&dW)[OTL][ITL], float (&db)[OTL], const f32x4 (&daT)[OTL], const typename TTy<BF>::type (&hT)[ITL])
+{
+    if constexpr (BF == 0) wgrad_reg<OTL, ITL, 0>(dW, db, daT, hT);
+    else {
+#pragma unroll
+        for (int ot = 0; ot < OTL; ++ot) {
+            const s16x4 pdt = pack_bf16x4(daT[ot]);
+#pragma unroll
+            for (int it = 0; it < ITL; ++it) dW[ot][it] = ST_MFMA16B(pdt, hT[it], dW[ot][it]);
+            db[ot] += (daT[ot][0] + daT[ot][1]) + (daT[ot][2] + daT[ot][3]);
+        }
     }
 }
 // Flush of one wave's persistent accumulators into the workgroup's LDS gradient image ([o][INP] row-major): the caller
@@ -979,15 +1024,16 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); } \
         ST_FENCE(); } while (0)
 #define ST_BWD_STAGE(O_, I_, FD_, DA_, DAT_, HP_, HTP_, DAP_, DATP_, RW_, RB_, NEXT_) \
-        to_T<I_>(XH, HP_, HTP_, g, c); ST_FENCE(); \
+        to_Th<I_, BF>(XH, HP_, HTP_, g, c); ST_FENCE(); \
         dgradD_fr<O_, I_, BF>(FD_, DA_, DAP_); mul_elu_grad<I_>(DAP_, HP_); \
         to_T<I_>(XD, DAP_, DATP_, g, c); NEXT_; \
-        wgrad_reg<O_, I_, BF>(RW_, RB_, DAT_, HTP_); \
+        wgrad_regh<O_, I_, BF>(RW_, RB_, DAT_, HTP_); \
         ST_PIPE(BF ? O_ * I_ : O_ * I_ * 4);
-        f32x4 hT8[4], da8[4], daT8[4], fd8[2 * 4];
+        typedef typename TTy<BF>::type tt_t;      // transposed activation operands: fp32 quads, or packed 16-bit quads (to_Th)
+        tt_t hT8[4]; f32x4 da8[4], daT8[4], fd8[2 * 4];
         if constexpr (INNER) {                     // dH8 arrives from the layer-9 data-gradient GEMM; h8^T is still needed for ELU' and dW8
             frags_dgrad<4, 2, CL::I7, BF>(fd8, lw + CL::G7, g, c);
-            to_T<4>(XH, h8, hT8, g, c);
+            to_Th<4, BF>(XH, h8, hT8, g, c);
 #pragma unroll
             for (int ot = 0; ot < 4; ++ot) da8[ot] = dh8[ot];
             mul_elu_grad<4>(da8, h8); to_T<4>(XD, da8, daT8, g, c);
@@ -1002,38 +1048,38 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         }
         ST_T(8);
         // layer 8 (32 -> 64)
-        f32x4 hT7[2], da7[2], daT7[2], fd7[1 * 2];
+        tt_t hT7[2]; f32x4 da7[2], daT7[2], fd7[1 * 2];
         ST_BWD_STAGE(4, 2, fd8, da8, daT8, h7, hT7, da7, daT7, rW8, rb8, (frags_dgrad<2, 1, CL::I6, BF>(fd7, lw + CL::G6, g, c)))
         ST_T(9);
         // layer 7 (16 -> 32)
-        f32x4 hT6[1], da6[1], daT6[1], fd6[1];
+        tt_t hT6[1]; f32x4 da6[1], daT6[1], fd6[1];
         ST_BWD_STAGE(2, 1, fd7, da7, daT7, h6, hT6, da6, daT6, rW7, rb7, (frags_dgrad<1, 1, CL::I5, BF>(fd6, lw + CL::G5, g, c)))
         ST_T(10);
         // layer 6 (16 -> 16)
-        f32x4 hT5[1], da5[1], daT5[1], fd5[1];
+        tt_t hT5[1]; f32x4 da5[1], daT5[1], fd5[1];
         ST_BWD_STAGE(1, 1, fd6, da6, daT6, h5, hT5, da5, daT5, rW6, rb6, (frags_dgrad<1, 1, CL::I4, BF>(fd5, lw + CL::G4, g, c)))
         // layer 5 ([h4 ; knobs] -> 16): weight gradient over both input tiles, data gradient to h4 only
-        f32x4 hT4[1], hT4k[2], da4[1], daT4[1], fd4[1];
+        tt_t hT4[1], hT4k[2]; f32x4 da4[1], daT4[1], fd4[1];
         {
-            to_T<1>(XH, h4, hT4, g, c); ST_FENCE();
+            to_Th<1, BF>(XH, h4, hT4, g, c); ST_FENCE();
             dgradD_fr<1, 1, BF>(fd5, da5, da4); mul_elu_grad<1>(da4, h4);
             to_T<1>(XD, da4, daT4, g, c); frags_dgrad<1, 1, CL::I3, BF>(fd4, lw + CL::G3, g, c); ST_FENCE();
             hT4k[0] = hT4[0];
-            hT4k[1] = (f32x4){knT, knT, knT, knT};                   // features 16 + c = knob c, every row
-            wgrad_reg<1, 2, BF>(rW5, rb5, daT5, hT4k);
+            hT4k[1] = tt_splat<BF>(knT);                               // features 16 + c = knob c, every row
+            wgrad_regh<1, 2, BF>(rW5, rb5, daT5, hT4k);
         }
         // layer 4 (16 -> 16)
-        f32x4 hT3[1], da3[1], daT3[1], fd3[2 * 1];
+        tt_t hT3[1]; f32x4 da3[1], daT3[1], fd3[2 * 1];
         ST_BWD_STAGE(1, 1, fd4, da4, daT4, h3, hT3, da3, daT3, rW4, rb4, (frags_dgrad<1, 2, CL::I2, BF>(fd3, lw + CL::G2, g, c)))
         ST_T(11);
         // layer 3 (32 -> 16)
-        f32x4 hT2[2], da2[2], daT2[2], fd2[4 * 2];
+        tt_t hT2[2]; f32x4 da2[2], daT2[2], fd2[4 * 2];
         ST_BWD_STAGE(1, 2, fd3, da3, daT3, h2, hT2, da2, daT2, rW3, rb3, (frags_dgrad<2, 4, CL::I1, BF>(fd2, lw + CL::G1, g, c)))
         ST_T(12);
         // layer 2 (64 -> 32)
-        f32x4 hT1[4], da1[4], daT1[4], fd1[2 * 4];
+        tt_t hT1[4]; f32x4 da1[4], daT1[4], fd1[2 * 4];
         if constexpr (INNER) {                     // dA1 goes back to memory for the layer-1 GEMMs
-            to_T<4>(XH, h1, hT1, g, c); ST_FENCE();
+            to_Th<4, BF>(XH, h1, hT1, g, c); ST_FENCE();
             dgradD_fr<2, 4, BF>(fd2, da2, da1); mul_elu_grad<4>(da1, h1);
             const unsigned col0 = (unsigned)b * FP + (unsigned)(grp - b * gpw) * 16;
 #pragma unroll
@@ -1041,7 +1087,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
 #pragma unroll
                 for (int r = 0; r < 4; ++r) stg32(dvout, (unsigned)(16 * ot + 4 * g + r) * Rw + col0 + c, da1[ot][r]);
             ST_FENCE();
-            wgrad_reg<2, 4, BF>(rW2, rb2, daT2, hT1);
+            wgrad_regh<2, 4, BF>(rW2, rb2, daT2, hT1);
         } else {
             ST_BWD_STAGE(2, 4, fd2, da2, daT2, h1, hT1, da1, daT1, rW2, rb2, (frags_dgrad<4, 2, CL::I0, BF>(fd1, lw + CL::G0, g, c)))
         }

@@ -89,10 +89,10 @@ __device__ inline void ae_load_lds_tab(float* lds, const int total, const AETab 
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); } \
         ST_FENCE(); } while (0)
 #define ST_BWD_STAGE2(O_, I_, FD_, DA_, DAT_, HP_, HTP_, DAP_, DATP_, RW_, RB_, NEXT_) \
-        to_T<I_>(XH, HP_, HTP_, g, c); ST_FENCE(); \
+        to_Th<I_, BF>(XH, HP_, HTP_, g, c); ST_FENCE(); \
         dgradD_fr<O_, I_, BF>(FD_, DA_, DAP_); mul_elu_grad<I_>(DAP_, HP_); \
         to_T<I_>(XD, DAP_, DATP_, g, c); NEXT_; \
-        wgrad_reg<O_, I_, BF>(RW_, RB_, DAT_, HTP_); \
+        wgrad_regh<O_, I_, BF>(RW_, RB_, DAT_, HTP_); \
         ST_PIPE2(BF ? O_ * I_ : O_ * I_ * 4);
 
 // grid (x: workgroups, y: net 0 = magnitude 'sf' / 1 = phase); NW = 8 waves = two per SIMD.  h4x / da4x: [net][group][lane] float4
@@ -236,27 +236,28 @@ ae_bwd_part_kernel(const float* __restrict__ mag, const float* __restrict__ phs,
                 S0[to * SP + c] = d9;                          // [feature t'][row c] -> read back transposed below
             }
             // ---- backward 9..5
-            f32x4 hT8[4], da8[4], daT8[4], fd8[2 * 4];
+            typedef typename TTy<BF>::type tt_t;
+            tt_t hT8[4]; f32x4 da8[4], daT8[4], fd8[2 * 4];
             {
                 f32x4 daT9[1], fd9[4 * 1];
                 frags_dgrad<1, 4, CL::I8, BF>(fd9, lw + P::G8, g, c);
                 daT9[0] = *reinterpret_cast<const f32x4*>(S0 + c * SP + 4 * g);
                 ST_BWD_STAGE2(1, 4, fd9, da9, daT9, h8, hT8, da8, daT8, rW9, rb9, (frags_dgrad<4, 2, CL::I7, BF>(fd8, lw + P::G7, g, c)))
             }
-            f32x4 hT7[2], da7[2], daT7[2], fd7[1 * 2];
+            tt_t hT7[2]; f32x4 da7[2], daT7[2], fd7[1 * 2];
             ST_BWD_STAGE2(4, 2, fd8, da8, daT8, h7, hT7, da7, daT7, rW8, rb8, (frags_dgrad<2, 1, CL::I6, BF>(fd7, lw + P::G6, g, c)))
-            f32x4 hT6[1], da6[1], daT6[1], fd6[1];
+            tt_t hT6[1]; f32x4 da6[1], daT6[1], fd6[1];
             ST_BWD_STAGE2(2, 1, fd7, da7, daT7, h6, hT6, da6, daT6, rW7, rb7, (frags_dgrad<1, 1, CL::I5, BF>(fd6, lw + P::G5, g, c)))
-            f32x4 hT5[1], da5[1], daT5[1], fd5[1];
+            tt_t hT5[1]; f32x4 da5[1], daT5[1], fd5[1];
             ST_BWD_STAGE2(1, 1, fd6, da6, daT6, h5, hT5, da5, daT5, rW6, rb6, (frags_dgrad<1, 1, CL::I4, BF>(fd5, lw + P::G4, g, c)))
             // layer 5 ([h4 ; knobs] -> 16): weight gradient over both input tiles, data gradient to h4 only -> d a4 leaves the kernel
-            f32x4 hT4[1], hT4k[2], da4[1];
+            tt_t hT4[1], hT4k[2]; f32x4 da4[1];
             {
-                to_T<1>(XH, h4, hT4, g, c); ST_FENCE();
+                to_Th<1, BF>(XH, h4, hT4, g, c); ST_FENCE();
                 dgradD_fr<1, 1, BF>(fd5, da5, da4); mul_elu_grad<1>(da4, h4);
                 hT4k[0] = hT4[0];
-                hT4k[1] = (f32x4){knT, knT, knT, knT};
-                wgrad_reg<1, 2, BF>(rW5, rb5, daT5, hT4k);
+                hT4k[1] = tt_splat<BF>(knT);
+                wgrad_regh<1, 2, BF>(rW5, rb5, daT5, hT4k);
             }
             {
                 float d0 = da4[0][0], d1 = da4[0][1], d2 = da4[0][2], d3 = da4[0][3];
@@ -336,10 +337,15 @@ ae_bwd_part_kernel(const float* __restrict__ mag, const float* __restrict__ phs,
             f32x4 h1[4], h2[2], h3[1];
             f32x4 fr1[4 * 2]; frags_fwd<4, 2, CL::O0, BF>(fr1, lw + P::A0, g, c);
             f32x4 fr2[2 * 4]; frags_fwd<2, 4, CL::O1, BF>(fr2, lw + P::A1, g, c);
+            typedef typename TTy<BF>::type tt_t;
+            tt_t vT[2];
+            if constexpr (BF) to_Th<2, BF>(S0, cur.v, vT, g, c);          // 16-bit layers: the input rows transposed in 16 bits right away (one write + one transpose read per tile)
+            else {
 #pragma unroll
             for (int it = 0; it < 2; ++it)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) S0[(16 * it + 4 * g + r) * SP + c] = cur.v[it][r];   // [feature t][row c]: read back transposed for the layer-1 wgrad
+            }
             ST_FENCE();
             fwdD_fr<4, 2, BF>(fr1, lw + P::B0, cur.v, h1, g);
             f32x4 fr3[1 * 2]; frags_fwd<1, 2, CL::O2, BF>(fr3, lw + P::A2, g, c); ST_FENCE(); fwdD_fr<2, 4, BF>(fr2, lw + P::B1, h1, h2, g);
@@ -348,15 +354,17 @@ ae_bwd_part_kernel(const float* __restrict__ mag, const float* __restrict__ phs,
             to_T<1>(XD, da4, daT4, g, c);
             ST_FENCE(); fwdD_fr<1, 2, BF>(fr3, lw + P::B2, h2, h3, g);
             // ---- backward 4..1
-            f32x4 hT3[1], da3[1], daT3[1], fd3[2 * 1];
+            tt_t hT3[1]; f32x4 da3[1], daT3[1], fd3[2 * 1];
             ST_BWD_STAGE2(1, 1, fd4, da4, daT4, h3, hT3, da3, daT3, rW4, rb4, (frags_dgrad<1, 2, CL::I2, BF>(fd3, lw + P::G2, g, c)))
-            f32x4 hT2[2], da2[2], daT2[2], fd2[4 * 2];
+            tt_t hT2[2]; f32x4 da2[2], daT2[2], fd2[4 * 2];
             ST_BWD_STAGE2(1, 2, fd3, da3, daT3, h2, hT2, da2, daT2, rW3, rb3, (frags_dgrad<2, 4, CL::I1, BF>(fd2, lw + P::G1, g, c)))
-            f32x4 hT1[4], da1[4], daT1[4], fd1[2 * 4];
+            tt_t hT1[4]; f32x4 da1[4], daT1[4], fd1[2 * 4];
             ST_BWD_STAGE2(2, 4, fd2, da2, daT2, h1, hT1, da1, daT1, rW2, rb2, (frags_dgrad<4, 2, CL::I0, BF>(fd1, lw + P::G0, g, c)))
-            f32x4 vT[2], dv[2];
+            f32x4 dv[2];
+            if constexpr (BF == 0) {
 #pragma unroll
-            for (int it = 0; it < 2; ++it) vT[it] = *reinterpret_cast<const f32x4*>(S0 + (16 * it + c) * SP + 4 * g);
+                for (int it = 0; it < 2; ++it) vT[it] = *reinterpret_cast<const f32x4*>(S0 + (16 * it + c) * SP + 4 * g);
+            }
             float tl[2][4];
             {
                 const unsigned tb = ST_MUL24(ST_MUL24(b, T), F) + (unsigned)(fv ? f : 0);
@@ -367,7 +375,7 @@ ae_bwd_part_kernel(const float* __restrict__ mag, const float* __restrict__ phs,
             }
             ST_FENCE();
             dgradD_fr<4, 2, BF>(fd1, da1, dv);
-            wgrad_reg<4, 2, BF>(rW1, rb1, daT1, vT);
+            wgrad_regh<4, 2, BF>(rW1, rb1, daT1, vT);
             // ---- d input rows (+ tails)
             float dvs[2][4];
 #pragma unroll
