@@ -343,6 +343,16 @@ int st_synth_comp4c(unsigned seed, unsigned long long first_window, int B, int L
 size_t st_model_input_grad_ws_floats(const st_dims* d);
 int st_model_input_grad(const st_dims* d, const float* params, void* ws, float* scratch, float* gxh, void* stream);
 
+/* Gradient w.r.t. the knob settings for arbitrary upstream gradients (same meaning as st_model_bwd's): what the reference's autograd hands to a
+ * knobs tensor that requires grad -- nn_proc.py:92-93 repeats the settings over the rows of a window and concatenates them in front of
+ * fnn_addknobs of both autoencoders (nn_proc.py:332-333).  g_knobs [B][K].  The exact, SLOW route: one forward + backward per window, whose
+ * fnn_addknobs bias gradients are that window's row sums of d a5; the reference's training never asks for this gradient (knobs are data), so
+ * the hot kernels carry nothing for it.  grads_scratch: st_param_offsets() floats, overwritten.  The saved-for-backward state of `ws` belongs
+ * to the last window afterwards: run st_model_fwd(save_for_backward = 1) again before st_model_bwd.  Where a single window cannot take the
+ * requested 16-bit arithmetic (st_effective_prec) the passes run the autoencoder layers in fp32. */
+int st_model_knob_grad(const st_dims* d, const float* params, float* grads_scratch, const float* x, const float* knobs,
+                       const float* g_y_hat, const float* g_mag_hat, const float* g_mag, void* ws, float* g_knobs, void* stream);
+
 /* ---- generic learned-basis front end: SURVEY.md row a15, signaltrain/cls_fe_dct_bases.py ------------------------------
  * Analysis.forward (:129-136)  = Conv1d(1 -> C, kernel KW, stride hop, padding pad, bias) transposed to [B][T][C];
  * Synthesis.forward (:174-179) = ConvTranspose1d(C -> 1, kernel KW, stride hop) with `crop` samples cut from both ends.

@@ -353,7 +353,10 @@ def _ae_bwd(dout, v, knobs, P, prefix, mode, hs):
         grads[f"{prefix}.{name}.bias"] = (_ra(da2) if wide_gemm_layer else da2).sum(0)
         dh = _ra(da) @ _ra(W)
         if name == "fnn_addknobs":
-            dh = dh[:, :, :W.shape[0]]                       # drop the knob columns (no grad to knobs)
+            # the knob columns of the concatenated input (nn_proc.py:92-93: knobs repeated over the rows of a window, then torch.cat):
+            # their gradient is the sum over the window's rows -- what autograd hands to a knobs tensor that requires grad
+            grads["__d_knobs__"] = dh[:, :, W.shape[0]:].sum(1)      # [B, K]
+            dh = dh[:, :, :W.shape[0]]
     dv += dh
     return np.transpose(dv, (0, 2, 1)), grads
 
@@ -392,6 +395,7 @@ def model_loss_bwd(x, knobs, y_true, P, geo, scale_by_freq=True):
     dmag, g_m = _ae_bwd(dmag_hat, c["mag"], knobs, P, "mpaec.aenc", "sf", c["hs_m"])
     dphs, g_p = _ae_bwd(dphs_hat, c["phs"], knobs, P, "mpaec.phs_aenc", "", c["hs_p"])
     dphs[:, T - OT:, :] += dphs_hat
+    d_knobs = g_m.pop("__d_knobs__") + g_p.pop("__d_knobs__")       # both autoencoders read the same knob settings (nn_proc.py:332-333)
     re, im = c["re"], c["im"]
     rp = re + dt.type(EPS_ATAN)
     den = rp * rp + im * im
@@ -411,7 +415,7 @@ def model_loss_bwd(x, knobs, y_true, P, geo, scale_by_freq=True):
              STFT_KEYS[2]: gSr[:, None, :], STFT_KEYS[3]: gSi[:, None, :]}
     grads.update(g_m); grads.update(g_p)
     c.update(dict(dy=dy, dAre=dAre, dAim=dAim, dmag_hat=dmag_hat, dphs_hat=dphs_hat,
-                  dmag=dmag, dphs=dphs, dre=dre, dim=dim, out=out))
+                  dmag=dmag, dphs=dphs, dre=dre, dim=dim, out=out, d_knobs=d_knobs))
     return loss, grads, c
 
 

@@ -88,6 +88,7 @@ SIGNATURES = {
     "st_clip_adam": (_i, [_p, _p, _p, _p, C.c_int64, C.c_int64, _p, _f, _f, _f, _f, _f, _i, _p]),
     "st_model_fwd": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "st_model_bwd": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "st_model_knob_grad": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "st_loss_backward": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "st_loss_backward_p1": (_i, [_D, _p, _p, _p, _p, _p, _p, _p]),
     "st_loss_backward_p2": (_i, [_D, _p, _p, _p, _p, _p]),

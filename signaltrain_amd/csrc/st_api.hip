@@ -1566,6 +1566,44 @@ extern "C" int st_model_bwd(const st_dims* d, const float* params, float* grads,
     return backward_impl(d, L, params, grads, x, knobs, g_mag_hat, g_mag, 0.0f, w, stream);
 }
 
+// d (anything downstream) / d knobs for arbitrary upstream gradients -- what autograd hands to a knobs tensor that requires grad (nn_proc.py:92-93: the
+// knob settings are repeated over the rows of a window and concatenated in front of fnn_addknobs of BOTH autoencoders, nn_proc.py:332-333).  With
+// d a5 the gradient at that layer's pre-activation, d knobs[b][k] = sum over nets, rows of window b, outputs o of  W5[o][16 + k] * d a5[row][o]: the row sum is
+// exactly the layer's BIAS gradient of a batch that holds window b alone.  So: one forward + backward per window (B = 1), then 16 x K multiply-adds
+// on the two bias gradients.  Deliberately the slow, exact route (B launch-bound passes, ~0.3 ms each): the reference's training never asks for this
+// gradient (knobs are data), so the hot kernels carry no per-window reduction for it.  grads_scratch: L.total floats, overwritten; the saved-for-backward
+// state of `ws` afterwards belongs to the LAST window -- run the forward again before st_model_bwd.  At geometries where a single window cannot take
+// the requested 16-bit arithmetic (st_effective_prec: the wide autoencoder path, odd batch) these passes run the autoencoder layers in fp32.
+__global__ void knob_grad_kernel(const float* __restrict__ Wm, const float* __restrict__ gbm, const float* __restrict__ Wp, const float* __restrict__ gbp,
+                                 const int K, float* __restrict__ out)
+{
+    const int k = threadIdx.x;
+    if (k >= K) return;
+    float s = 0.f, t = 0.f;
+    for (int o = 0; o < 16; ++o) { s += Wm[o * (16 + K) + 16 + k] * gbm[o]; t += Wp[o * (16 + K) + 16 + k] * gbp[o]; }
+    out[k] = s + t;
+}
+extern "C" int st_model_knob_grad(const st_dims* d, const float* params, float* grads_scratch, const float* x, const float* knobs,
+                                  const float* g_y_hat, const float* g_mag_hat, const float* g_mag, void* ws, float* g_knobs, void* stream)
+{
+    Layout L; ST_TRY(make_layout(d, &L));
+    ST_REQ(params && grads_scratch && x && knobs && g_y_hat && ws && g_knobs, "st_model_knob_grad: null pointer");
+    ST_REQ(d->K >= 1 && d->K <= 64, "st_model_knob_grad: K = %d", d->K);
+    st_dims d1 = *d; d1.B = 1;
+    Layout L1; ST_TRY(make_layout(&d1, &L1));
+    const size_t w5 = (size_t)L1.offs[4] + (size_t)L1.go.w[4], b5 = (size_t)L1.offs[4] + (size_t)L1.go.b[4];
+    for (int b = 0; b < d->B; ++b) {
+        const float* xb = x + (size_t)b * d->L; const float* kb = knobs + (size_t)b * d->K;
+        ST_TRY(st_model_fwd(&d1, params, xb, kb, nullptr, nullptr, nullptr, ws, 1, stream));
+        ST_TRY(st_model_bwd(&d1, params, grads_scratch, xb, kb, g_y_hat + (size_t)b * d->y, g_mag_hat ? g_mag_hat + (size_t)b * d->OT * d->F : nullptr,
+                            g_mag ? g_mag + (size_t)b * d->T * d->F : nullptr, ws, stream));
+        hipLaunchKernelGGL(knob_grad_kernel, dim3(1), dim3(64), 0, st_stream(stream), params + w5, grads_scratch + b5, params + w5 + L1.PG, grads_scratch + b5 + L1.PG,
+                           d->K, g_knobs + (size_t)b * d->K);
+    }
+    ST_LAUNCHED("knob_grad");
+    return ST_OK;
+}
+
 extern "C" int st_loss_backward(const st_dims* d, const float* params, float* grads, const float* x, const float* knobs,
                                 const float* y_true, float* y_hat, float* mag, float* mag_hat, void* ws,
                                 float* scalars, void* stream)

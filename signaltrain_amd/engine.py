@@ -210,6 +210,22 @@ class StepEngine:
                    _lib.ptr(y_hat), _lib.ptr(mag), _lib.ptr(mag_hat), _lib.ptr(self.ws), 1 if save_for_backward else 0, self._stream())
         return y_hat, mag, mag_hat
 
+    def knob_grad(self, x, knobs, g_y_hat, g_mag_hat=None, g_mag=None):
+        """d / d knobs [B, K] for the upstream gradients of backward() (st_model_knob_grad; nn_proc.py:92-93 under autograd).  The exact, slow route:
+        one forward + backward per window.  Overwrites the workspace's saved-for-backward state (call forward(save_for_backward=True) again before
+        backward()); the parameter gradients of these passes go to a scratch buffer, self.grads is left alone."""
+        d, x, knobs, _ = self._prep(x, knobs)
+        d.loss_scale = 0.0
+        f = lambda t: None if t is None else t.to(device=self.device, dtype=torch.float32).contiguous()
+        g_y_hat, g_mag_hat, g_mag = f(g_y_hat), f(g_mag_hat), f(g_mag)
+        if getattr(self, "_knob_scratch", None) is None:
+            self._knob_scratch = torch.zeros_like(self.grads)
+        out = torch.empty(d.B, d.K, dtype=torch.float32, device=self.device)
+        self.generation += 1
+        self._call("st_model_knob_grad", C.byref(d), _lib.ptr(self.params), _lib.ptr(self._knob_scratch), _lib.ptr(x), _lib.ptr(knobs),
+                   _lib.ptr(g_y_hat), _lib.ptr(g_mag_hat), _lib.ptr(g_mag), _lib.ptr(self.ws), _lib.ptr(out), self._stream())
+        return out
+
     def backward(self, x, knobs, g_y_hat, g_mag_hat=None, g_mag=None):
         """Autograd backward for arbitrary upstream gradients (after forward(save_for_backward=True))."""
         d, x, knobs, _ = self._prep(x, knobs)

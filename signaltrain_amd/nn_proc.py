@@ -130,20 +130,22 @@ class _STModelFn(torch.autograd.Function):
     def backward(ctx, g_y, g_mag, g_mh):
         x, knobs = ctx.saved_tensors
         eng = ctx.model._engine
-        if eng is not ctx.engine or eng.generation != ctx.generation:
-            eng.forward(x, knobs, save_for_backward=True)          # the workspace was reused since this graph's forward: rebuild its state
         if g_y is None:
             g_y = torch.zeros(x.shape[0], eng.dims.y, device=x.device)
-        eng.backward(x, knobs, g_y, g_mh, g_mag)
+        gk = None
         if ctx.needs_input_grad[2]:
-            raise NotImplementedError("signaltrain_amd.st_model: the gradient w.r.t. the knob settings is not built "
-                                      "(the reference's training never needs it: knobs are data)")
+            # knobs that require grad (nn_proc.py:92-93 under autograd): the exact per-window route of st_model_knob_grad -- slow (one forward + backward
+            # per window: the reference's training never asks for it), and it leaves the LAST window's state in the workspace
+            gk = eng.knob_grad(x, knobs, g_y, g_mh, g_mag)
+        if gk is not None or eng is not ctx.engine or eng.generation != ctx.generation:
+            eng.forward(x, knobs, save_for_backward=True)          # the workspace was reused since this graph's forward: rebuild its state
+        eng.backward(x, knobs, g_y, g_mh, g_mag)
         gx = eng.input_grad(x, g_y) if ctx.needs_input_grad[1] else None     # something trainable upstream of the model
         # one flat clone, then per-parameter views of it: autograd accumulates into .grad, so the engine's gradient buffer
         # (overwritten by the next backward) must not be handed out itself
         flat = eng.grads.clone()
         grads = tuple(eng.layout.views(flat).values())
-        return (None, gx, None) + grads
+        return (None, gx, gk) + grads
 
 
 class AsymMPAEC(nn.Module):

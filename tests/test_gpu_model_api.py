@@ -618,6 +618,64 @@ def test_autograd_all_three_outputs(golden_dir):
         assert e <= 2e-4, (k, e)
 
 
+def test_knob_gradient_matches_reference_autograd(golden_dir):
+    """knobs.requires_grad_(): d loss / d knobs through the drop-in model (st_model_knob_grad: the exact per-window route) against the REFERENCE's own
+    autograd (golden G12: the G3 / G4 inputs and weights, calc_loss with train.py's frequency weighting) -- and the parameter gradients of the same
+    backward() still those of golden G4 (the knob passes must not leak into them)."""
+    from signaltrain_amd import loss_functions
+    from tests.golden_util import ae_keys
+    m, g, P, geo = _golden_model(golden_dir)
+    g4 = np.load(os.path.join(golden_dir, "g4_backward.npz")); g12 = np.load(os.path.join(golden_dir, "g12_knob_grad.npz"))
+    x, yt = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["y"]).cuda()
+    kn = torch.from_numpy(g["knobs"]).cuda().requires_grad_(True)
+    y, mag, mag_hat = m.forward(x, kn)
+    sbf = torch.exp((7. / 513) * torch.arange(0., 513, device="cuda")).expand_as(mag_hat).float()
+    loss = loss_functions.calc_loss(y, yt, mag_hat, scale_by_freq=sbf)
+    loss.backward()
+    ref = g12["d_knobs"]
+    got = kn.grad.detach().cpu().numpy().astype(np.float64)
+    assert got.shape == ref.shape == (2, 4)
+    assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max(), (got, ref)       # fp32 tolerance of the other gradients (G4)
+    grads = {k: p.grad.detach().cpu().numpy().astype(np.float64) for k, p in m.named_parameters()}
+    for k in ae_keys():
+        assert np.abs(grads[k] - g4["g_" + k]).max() <= 2e-4 * np.abs(g4["g_" + k]).max() + 1e-12, k
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16_all"])
+def test_knob_gradient_all_three_outputs(golden_dir, dtype):
+    """The knob gradient for upstream gradients of ALL outputs (<y_hat, p1> + <mag, p2> + <mag_hat, p3>; mag does not depend on the knobs), B = 3 with
+    distinct windows, vs float64 torch-CPU autograd of the reference op sequence (oracle/torch_cpu_step.forward) -- and the per-window route is
+    really per window: window 1's gradient is unchanged when the other windows of the batch change."""
+    from oracle import torch_cpu_step as TC
+    m, g, P, geo = _golden_model(golden_dir)
+    m.set_compute_dtype(dtype)
+    rng = np.random.default_rng(21)
+    B = 3
+    x = (0.3 * rng.standard_normal((B, geo["L"]))).astype(np.float32)
+    kn = (rng.random((B, 4)) - 0.5).astype(np.float32)
+    p1 = rng.standard_normal((B, geo["y"])).astype(np.float32)
+    p2 = (0.1 * rng.standard_normal((B, geo["T"], geo["F"]))).astype(np.float32)
+    p3 = (0.1 * rng.standard_normal((B, geo["OT"], geo["F"]))).astype(np.float32)
+    P64 = {k: torch.tensor(np.asarray(v), dtype=torch.float64) for k, v in P.items()}
+    k64 = torch.tensor(kn, dtype=torch.float64, requires_grad=True)
+    y, mg, mh = TC.forward(P64, torch.tensor(x, dtype=torch.float64), k64)
+    ((y * torch.tensor(p1, dtype=torch.float64)).sum() + (mg * torch.tensor(p2, dtype=torch.float64)).sum()
+     + (mh * torch.tensor(p3, dtype=torch.float64)).sum()).backward()
+    ref = k64.grad.numpy()
+
+    def run(xx):
+        kg = torch.from_numpy(kn).cuda().requires_grad_(True)
+        yg, mgg, mhg = m.forward(torch.from_numpy(xx).cuda(), kg)
+        ((yg * torch.from_numpy(p1).cuda()).sum() + (mgg * torch.from_numpy(p2).cuda()).sum() + (mhg * torch.from_numpy(p3).cuda()).sum()).backward()
+        return kg.grad.detach().cpu().numpy().astype(np.float64)
+    got = run(x)
+    tol = 2e-4 if dtype == "f32" else 6e-2           # 16-bit Linear layers: the tolerance class of the other bf16_all gradients (tests/gpu_checks.py)
+    assert np.abs(got - ref).max() <= tol * np.abs(ref).max(), (got, ref)
+    x2 = x.copy(); x2[0] *= -0.5; x2[2] = x2[2][::-1]
+    got2 = run(x2)
+    assert np.array_equal(got2[1], got[1]) and not np.array_equal(got2[0], got[0])
+
+
 def test_train_driver_device_feed(tmp_path):
     """train.train(device_feed=True): recycled synthetic dataset resident in HBM (effect computed on the GPU), random index
     gathers per minibatch -- no CPU workers in the loop; the loss must go down over a few epochs of a tiny dataset."""

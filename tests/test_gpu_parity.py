@@ -407,6 +407,30 @@ def test_fuzz_outliers_grounded(idx):
     assert not bad, [(r["name"], r["rel"], r["tol"], noise.get(r["name"])) for r in bad]
 
 
+@pytest.mark.parametrize("scale,shrink,K,B", [(1, 4, 4, 3), (1, 4, 3, 2), (1, 2, 7, 2), (2, 4, 4, 3), (8, 4, 3, 2)])
+def test_knob_gradient_against_oracle(scale, shrink, K, B):
+    """st_model_knob_grad (d loss / d knobs; nn_proc.py:92-93 under autograd) against the oracle's d_knobs (pinned to the reference's autograd by golden
+    G12) with the training loss's own upstream gradients: fused geometries, 3 / 7 knobs, an odd batch, and the wide autoencoder path (lean scale 2,
+    the 65536-sample window).  fp32, the tolerance of the parameter gradients."""
+    import numpy as np, torch
+    from oracle import st_oracle as O
+    from tests import gpu_checks as G
+    geo, X, Y, KN, P = G.make_case(B=B, seed=31, scale=scale, shrink=shrink, K=K)
+    _, _, c = O.model_loss_bwd(X, KN, Y, P, geo)
+    F = geo["F"]
+    w = O.freq_weights(F, np.float32)
+    g_mh = (np.float32(O.L1_LAMBDA / 10) / np.float32(B * geo["OT"] * F) * np.sign(c["mag_hat"]) * w).astype(np.float32)      # the L1 term of calc_loss (loss_functions.py:36)
+    d = G.dims_of(geo, B, K)
+    eng = G.new_engine(d); eng.load_state_dict(P)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(G.DEV)
+    before = eng.grads.clone()
+    got = eng.knob_grad(dev(X), dev(KN), dev(c["dy"]), dev(g_mh)).cpu().numpy().astype(np.float64)
+    ref = c["d_knobs"].astype(np.float64)
+    assert got.shape == ref.shape == (B, K)
+    assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max(), (got, ref)
+    assert torch.equal(eng.grads, before)                 # the per-window passes write a scratch buffer, not the engine's gradients
+
+
 @pytest.mark.parametrize("dtype,scale,shrink", [("f32", 2, 4), ("f16_all", 2, 4), ("bf16_all", 1, 1), ("f32", 8, 4)])
 def test_wide_direct_input_equals_copy_kernel(dtype, scale, shrink):
     """Wide geometries (round 4): the analysis GEMM's polar epilogue writes mag / phs straight into the feature-major input of the wide autoencoder

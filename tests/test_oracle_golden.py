@@ -379,3 +379,18 @@ def test_g11_host_signal_generators(golden_dir):
         x, y, k = H.gen_single_chunk(t, eff, n // 2, augment=True)
         assert np.array_equal(np.asarray(k, np.float64), g[f"item_k_s{s}"]) and np.array_equal(np.asarray(x, np.float64), g[f"item_x_s{s}"])
         close(y, g[f"item_y_s{s}"], 2e-6, f"compressor target, item seed {s}")
+
+
+def test_g12_knob_gradient(golden_dir):
+    """Golden G12 (tools/capture_golden_r4.py): the reference's autograd w.r.t. a knobs tensor that requires grad (nn_proc.py:92-93: knob settings
+    repeated over a window's rows, concatenated in front of fnn_addknobs of both autoencoders) for the G3 / G4 inputs and weights; pins the oracle's
+    d_knobs (model_loss_bwd cache), the checker of st_model_knob_grad."""
+    g3 = load(golden_dir, "g3_forward.npz"); g = load(golden_dir, "g12_knob_grad.npz")
+    geo = O.geometry(1, 4)
+    P = golden_params(golden_dir, geo)
+    loss, _, c = O.model_loss_bwd(g3["x"].astype(np.float64), g3["knobs"].astype(np.float64), g3["y"].astype(np.float64), P, geo)
+    close(loss, g["loss"], 3e-5, "loss")
+    assert c["d_knobs"].shape == g["d_knobs"].shape == (2, 4)
+    close(c["d_knobs"], g["d_knobs"], 2e-5, "d knobs (float64 oracle)")
+    _, _, c32 = O.model_loss_bwd(g3["x"], g3["knobs"], g3["y"], P, geo)
+    close(c32["d_knobs"], g["d_knobs"], 2e-4, "d knobs (float32 oracle)")
