@@ -155,6 +155,125 @@ wide_dv_polar_kernel(const DvPolarArgs a)
     const int T = a.T, TP = (T + 15) / 16 * 16, NIT = TP / 16;
     constexpr int RW = BF ? 32 : 64;                        // floats per image row block: 16-bit images take half the room
     float* const img[2] = {dvp_lds, dvp_lds + RW * TP};      // G[(o >> 2)][i][o & 3] per net
+    const int gpw = a.FP / 16, ngroups = a.B * gpw;
+    const unsigned R = (unsigned)a.B * a.FP;
+    // The NWV waves of a workgroup take ADJACENT 16-bin groups and walk the frame tiles together: a group touches only 64 bytes of every
+    // [B][T][F] row, eight neighbours touch 512 contiguous bytes at about the same time (DRAM page / L2 line locality: with the waves on
+    // different frames of ONE group the kernel ran at 1.3 TB/s).
+    // Round 4: the unit of work is (block of NWV adjacent groups, frame tile), and every workgroup takes an equal, contiguous share of the units.
+    // Whole groups per workgroup left 124 of 256 CUs idle at the 65536-sample window (2112 groups = 264 blocks: 132 workgroups took two blocks
+    // each, i.e. 22 dependent tile steps, the rest none); now every workgroup walks 11 or 12 tile steps and re-reads d a1 where its share
+    // crosses a block boundary.
+    constexpr int NWV = 8;
+    const int nblk = (ngroups + NWV - 1) / NWV, nitems = nblk * NIT;
+    const int i_lo = (int)((long long)blockIdx.x * nitems / (int)gridDim.x), i_hi = (int)((long long)(blockIdx.x + 1) * nitems / (int)gridDim.x);
+    struct Geo { int it, b, f; bool gv, fv; unsigned col; };
+    auto geo_of = [&](const int item) {
+        Geo q;
+        const int gb = item / NIT; q.it = item - gb * NIT;
+        const int gw = gb * NWV + wave;
+        const int grp = gw < ngroups ? gw : ngroups - 1;
+        q.gv = gw < ngroups;
+        q.b = grp / gpw; q.f = (grp - q.b * gpw) * 16 + c;
+        q.fv = q.gv && q.f < a.F;
+        q.col = (unsigned)q.b * a.FP + (unsigned)q.f;
+        return q;
+    };
+    f32x4 da[2][4];
+    sta::s16x4 pd[2][4];
+    int cur_gb = -1;
+    float xr[3][4], yr[3][4], tm[3][4], tp[3][4], gm[3][4];
+    auto load_tile = [&](const int item, const int s_) {
+        const Geo q = geo_of(item);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = 16 * q.it + 4 * g + r;
+            const bool ok = q.fv && t < T;
+            const unsigned o = ((unsigned)q.b * T + (unsigned)(ok ? t : 0)) * (unsigned)a.F + (unsigned)(q.fv ? q.f : 0);
+            const bool tl = ok && t >= T - a.OT;
+            const unsigned qq = (unsigned)(tl ? t - (T - a.OT) : 0) * R + q.col;
+            xr[s_][r] = a.re ? sta::ldg32(a.re, o) : 0.f; yr[s_][r] = a.re ? sta::ldg32(a.im, o) : 0.f;
+            gm[s_][r] = a.g_mag ? sta::ldg32(a.g_mag, o) : 0.f;
+            const float u = sta::ldg32(a.TLm, qq), v = sta::ldg32(a.TLp, qq);
+            tm[s_][r] = tl ? u : 0.f; tp[s_][r] = tl ? v : 0.f;
+        }
+    };
+    // two frame tiles per trip so that the look-ahead buffers are indexed statically (a run-time buffer index put them in scratch)
+    auto tile = [&](const int item, auto sb) {
+        constexpr int SB = decltype(sb)::value;
+        const Geo q = geo_of(item);
+        const int it = q.it, b = q.b, f = q.f;
+        const bool gv = q.gv, fv = q.fv;
+        if (item / NIT != cur_gb) {                          // workgroup-uniform: a new block of groups -- its d a1 (D layout: 16 + 16 dwords per lane from the feature-major buffers)
+            cur_gb = item / NIT;
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    da[0][ot][r] = sta::ldg32(a.DA1m, (unsigned)(16 * ot + 4 * g + r) * R + q.col);
+                    da[1][ot][r] = sta::ldg32(a.DA1p, (unsigned)(16 * ot + 4 * g + r) * R + q.col);
+                }
+            if constexpr (BF) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int ot = 0; ot < 4; ++ot) pd[n][ot] = sta::pack_h4<BF>(da[n][ot]);
+            }
+        }
+        f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const f32x4 w = sta::frag_read<BF>(img[n], ((4 * ot + g) * TP + 16 * it + c) << 2);
+                if constexpr (BF) acc[n] = sta::mfma16h<BF>(sta::frag_bits(w), pd[n][ot], acc[n]);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[n] = ST_MFMA16(w[r], da[n][ot][r], acc[n]);
+                }
+            }
+        // tile `it` of dv in D layout: lane (g, c), register r <-> frame t = 16 it + 4 g + r, row c
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = 16 * it + 4 * g + r;
+            if (t >= T) continue;
+            const unsigned o = ((unsigned)b * T + (unsigned)t) * (unsigned)a.F + (unsigned)(fv ? f : 0);
+            const float dm = fv ? acc[0][r] + tm[SB][r] : 0.f, dp = fv ? acc[1][r] + tp[SB][r] : 0.f;
+            if (a.dmag && fv) { sta::stg32(a.dmag, o, dm); sta::stg32(a.dphs, o, dp); }
+            if (a.re) {
+                float gre = 0.f, gim = 0.f;
+                if (fv) {                      // stm::polar_bwd_block's formulas (v_rcp_f32 / v_sqrt_f32: 1 ulp, against a 1e-4 tolerance)
+                    const float x = xr[SB][r], y = yr[SB][r];
+                    const float dmt = dm + gm[SB][r];
+                    const float m2 = x * x + y * y;
+                    const float inv = m2 > 0.f ? __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(m2)) : 0.f;
+                    const float rp = x + 1e-7f;
+                    const float rden = __builtin_amdgcn_rcpf(rp * rp + y * y);
+                    gre = dmt * x * inv - dp * y * rden;
+                    gim = dmt * y * inv + dp * rp * rden;
+                    if (a.sat > 0.f) { gre = __builtin_amdgcn_fmed3f(gre, -a.sat, a.sat); gim = __builtin_amdgcn_fmed3f(gim, -a.sat, a.sat); }
+                }
+                const size_t go = ((size_t)b * T + t) * a.KP + f;          // f < FP = KP / 2: pad columns get zeros
+                if (gv && a.dG16) { a.dG16[go] = st_to_h16(gre, a.ht); a.dG16[go + a.FP] = st_to_h16(gim, a.ht); }
+                if (gv && a.dG) { a.dG[go] = gre; a.dG[go + a.FP] = gim; }
+            }
+        }
+    };
+    // the first two items' inputs and the first block's d a1 are requested BEFORE the layer-1 weights are staged into LDS (dependent round trips, ~10 us
+    // of this kernel): they travel while the staging runs
+    if (i_lo < i_hi) {
+        const Geo q0 = geo_of(i_lo);
+        cur_gb = i_lo / NIT;
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                da[0][ot][r] = sta::ldg32(a.DA1m, (unsigned)(16 * ot + 4 * g + r) * R + q0.col);
+                da[1][ot][r] = sta::ldg32(a.DA1p, (unsigned)(16 * ot + 4 * g + r) * R + q0.col);
+            }
+        load_tile(i_lo, 0);
+        load_tile(i_lo + 1 < i_hi ? i_lo + 1 : i_lo, 1);
+    }
     for (int e = tid; e < 2 * RW * TP; e += 512) dvp_lds[e] = 0.f;
     __syncthreads();
     // thread i < T owns input column i of W1 [64][T] (coalesced across threads, NO integer division: e / T for 22 k elements was 6 k of this
@@ -182,99 +301,27 @@ wide_dv_polar_kernel(const DvPolarArgs a)
         }
     }
     __syncthreads();
-    const int gpw = a.FP / 16, ngroups = a.B * gpw;
-    const unsigned R = (unsigned)a.B * a.FP;
-    // The NWV waves of a workgroup take ADJACENT 16-bin groups and walk the frame tiles together: a group touches only 64 bytes of every
-    // [B][T][F] row, eight neighbours touch 512 contiguous bytes at about the same time (DRAM page / L2 line locality: with the waves on
-    // different frames of ONE group the kernel ran at 1.3 TB/s).  One tile of look-ahead for the inputs of the next frame tile.
-    constexpr int NWV = 8;
-    const int per = (ngroups + (int)gridDim.x * NWV - 1) / ((int)gridDim.x * NWV) * NWV;       // groups per workgroup, a multiple of NWV
-    for (int g0 = (int)blockIdx.x * per; g0 < ((int)blockIdx.x + 1) * per && g0 < ngroups; g0 += NWV) {
-        const int grp = g0 + wave < ngroups ? g0 + wave : ngroups - 1;
-        const bool gv = g0 + wave < ngroups;
-        const int b = grp / gpw, f = (grp - b * gpw) * 16 + c;
-        const bool fv = gv && f < a.F;
-        const unsigned col = (unsigned)b * a.FP + (unsigned)f;
-        f32x4 da[2][4];
-#pragma unroll
-        for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                da[0][ot][r] = sta::ldg32(a.DA1m, (unsigned)(16 * ot + 4 * g + r) * R + col);
-                da[1][ot][r] = sta::ldg32(a.DA1p, (unsigned)(16 * ot + 4 * g + r) * R + col);
-            }
-        float xr[2][4], yr[2][4], tm[2][4], tp[2][4], gm[2][4];
-        auto load_tile = [&](const int it, const int s_) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int t = 16 * it + 4 * g + r;
-                const bool ok = fv && t < T;
-                const unsigned o = ((unsigned)b * T + (unsigned)(ok ? t : 0)) * (unsigned)a.F + (unsigned)(fv ? f : 0);
-                const bool tl = ok && t >= T - a.OT;
-                const unsigned q = (unsigned)(tl ? t - (T - a.OT) : 0) * R + col;
-                xr[s_][r] = a.re ? sta::ldg32(a.re, o) : 0.f; yr[s_][r] = a.re ? sta::ldg32(a.im, o) : 0.f;
-                gm[s_][r] = a.g_mag ? sta::ldg32(a.g_mag, o) : 0.f;
-                const float u = sta::ldg32(a.TLm, q), v = sta::ldg32(a.TLp, q);
-                tm[s_][r] = tl ? u : 0.f; tp[s_][r] = tl ? v : 0.f;
-            }
-        };
-        load_tile(0, 0);
-        sta::s16x4 pd[2][4];
-        if constexpr (BF) {
+    if constexpr (BF) {
+        if (i_lo < i_hi) {
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
                 for (int ot = 0; ot < 4; ++ot) pd[n][ot] = sta::pack_h4<BF>(da[n][ot]);
         }
-        // two frame tiles per trip so that the look-ahead buffers are indexed statically (a run-time buffer index put them in scratch)
-        auto tile = [&](const int it, auto sb) {
-            constexpr int SB = decltype(sb)::value;
-            f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    const f32x4 w = sta::frag_read<BF>(img[n], ((4 * ot + g) * TP + 16 * it + c) << 2);
-                    if constexpr (BF) acc[n] = sta::mfma16h<BF>(sta::frag_bits(w), pd[n][ot], acc[n]);
-                    else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[n] = ST_MFMA16(w[r], da[n][ot][r], acc[n]);
-                    }
-                }
-            // tile `it` of dv in D layout: lane (g, c), register r <-> frame t = 16 it + 4 g + r, row c
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int t = 16 * it + 4 * g + r;
-                if (t >= T) continue;
-                const unsigned o = ((unsigned)b * T + (unsigned)t) * (unsigned)a.F + (unsigned)(fv ? f : 0);
-                const float dm = fv ? acc[0][r] + tm[SB][r] : 0.f, dp = fv ? acc[1][r] + tp[SB][r] : 0.f;
-                if (a.dmag && fv) { sta::stg32(a.dmag, o, dm); sta::stg32(a.dphs, o, dp); }
-                if (a.re) {
-                    float gre = 0.f, gim = 0.f;
-                    if (fv) {                      // stm::polar_bwd_block's formulas (v_rcp_f32 / v_sqrt_f32: 1 ulp, against a 1e-4 tolerance)
-                        const float x = xr[SB][r], y = yr[SB][r];
-                        const float dmt = dm + gm[SB][r];
-                        const float m2 = x * x + y * y;
-                        const float inv = m2 > 0.f ? __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(m2)) : 0.f;
-                        const float rp = x + 1e-7f;
-                        const float rden = __builtin_amdgcn_rcpf(rp * rp + y * y);
-                        gre = dmt * x * inv - dp * y * rden;
-                        gim = dmt * y * inv + dp * rp * rden;
-                        if (a.sat > 0.f) { gre = __builtin_amdgcn_fmed3f(gre, -a.sat, a.sat); gim = __builtin_amdgcn_fmed3f(gim, -a.sat, a.sat); }
-                    }
-                    const size_t go = ((size_t)b * T + t) * a.KP + f;          // f < FP = KP / 2: pad columns get zeros
-                    if (gv && a.dG16) { a.dG16[go] = st_to_h16(gre, a.ht); a.dG16[go + a.FP] = st_to_h16(gim, a.ht); }
-                    if (gv && a.dG) { a.dG[go] = gre; a.dG[go + a.FP] = gim; }
-                }
-            }
-        };
-        for (int it = 0; it < NIT; it += 2) {               // (a third look-ahead slot -- inputs of tile it + 2 in flight -- spills: 256 registers + 88 bytes of scratch)
-            load_tile(it + 1 < NIT ? it + 1 : it, 1);
-            tile(it, std::integral_constant<int, 0>{});
-            if (it + 1 < NIT) {                             // wave-uniform
-                load_tile(it + 2 < NIT ? it + 2 : it + 1, 0);
-                tile(it + 1, std::integral_constant<int, 1>{});
-            }
+    }
+    // TWO tiles of look-ahead (three statically indexed slots; the balanced form of the kernel needs 118 registers, the whole-group form sat at the
+    // 256-register line with one): the inputs of items i + 1 and i + 2 are in flight while item i is computed
+    for (int item = i_lo; item < i_hi; item += 3) {
+        const int last = i_hi - 1;
+        load_tile(item + 2 < i_hi ? item + 2 : last, 2);
+        tile(item, std::integral_constant<int, 0>{});
+        if (item + 1 < i_hi) {                             // workgroup-uniform
+            load_tile(item + 3 < i_hi ? item + 3 : last, 0);
+            tile(item + 1, std::integral_constant<int, 1>{});
+        }
+        if (item + 2 < i_hi) {
+            load_tile(item + 4 < i_hi ? item + 4 : last, 1);
+            tile(item + 2, std::integral_constant<int, 2>{});
         }
     }
 }

@@ -888,7 +888,9 @@ static int ae_wide_bwd(const st_dims* d, const Layout& L, const float* mag, cons
             const int TP16 = (T + 15) / 16 * 16, groups = d->B * (FP / 16);
             ST_REQ(TP16 <= 192, "wide autoencoder path: T = %d frames exceeds the layer-1 data-gradient kernel's 192", T);
             const size_t lds = (size_t)2 * (wide_ht ? 32 : 64) * TP16 * sizeof(float);          // 16-bit images take half the room
-            int grid = (groups + 7) / 8; if (grid > num_cus()) grid = num_cus();      // 8 adjacent groups per workgroup pass, one workgroup per CU
+            int grid = ((groups + 7) / 8) * (TP16 / 16); if (grid > num_cus()) grid = num_cus();      // units of (8 adjacent groups, 16-frame tile), shared equally; one workgroup per CU
+                                                                                                      // (two or three per CU measured slower: 146.6 / 155.5 us against 141.1 for the whole
+                                                                                                      // wide backward -- every workgroup stages the layer-1 weights, ~10 us of dependent loads)
 #define ST_DVP(HT_) do { ST_DYN_LDS((stw::wide_dv_polar_kernel<HT_>)); hipLaunchKernelGGL((stw::wide_dv_polar_kernel<HT_>), dim3(grid), dim3(512), lds, s, q); } while (0)
             switch (wide_ht) { case 1: ST_DVP(1); break; case 2: ST_DVP(2); break; default: ST_DVP(0); }
 #undef ST_DVP
