@@ -325,6 +325,21 @@ static int ae_fwd_nw(const st_dims* d)
     auto cost = [&](int nw) { int grid = (groups + nw - 1) / nw; if (grid > c) grid = c; const int rounds = (groups + grid * nw - 1) / (grid * nw); return rounds * nw; };
     return cost(11) < cost(AE_FWD_NW) ? 11 : AE_FWD_NW;
 }
+// Wide path, layers 2..8 (ae_inner_fwd_kernel: 116-126 registers, up to four waves per SIMD): waves per workgroup out of {8, 9, 12} by
+// rounds x waves sharing the busiest SIMD.  B = 64 at the 65536-sample window is 2112 = 256 * 8.25 groups: with 8 waves 64 of the 2048 waves walked a
+// second group (two rounds for 3 % more work); 9 waves on 235 workgroups take one.
+static int ae_inner_nw(const st_dims* d)
+{
+    const int groups = ae_fwd_groups(d), c = num_cus();
+    int best = AE_FWD_NW, best_cost = 1 << 30;
+    for (int nw : {8, 9, 12}) {
+        int grid = (groups + nw - 1) / nw; if (grid > c) grid = c;
+        const int rounds = (groups + grid * nw - 1) / (grid * nw), cost = rounds * ((nw + 3) / 4);
+        if (cost < best_cost) { best_cost = cost; best = nw; }
+    }
+    return best;
+}
+static int ae_inner_grid(const st_dims* d) { const int nw = ae_inner_nw(d); int g = (ae_fwd_groups(d) + nw - 1) / nw; int c = num_cus(); return g < c ? g : c; }
 static int ae_fwd_grid(const st_dims* d) { const int nw = ae_fwd_nw(d); int g = (ae_fwd_groups(d) + nw - 1) / nw; int c = num_cus(); return g < c ? g : c; }
 static int ae_bwd_grid(const st_dims* d) { int groups = d->B * (st_kp_of(d->F) / 32); int g = (groups + AE_BWD_NW - 1) / AE_BWD_NW; int c = num_cus() / 2; if (c < 1) c = 1; return g < c ? g : c; }
 // split-K factors.  fp32 MFMA tiles are long serial chains (48 MFMAs x 64 cycles per k-tile per wave), so a GEMM
@@ -752,11 +767,13 @@ static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, cons
     }
     if (g_wide_fused) {
         const size_t lds = (size_t)2 * sta::CL::FWD_TOTAL * sizeof(float);
-#define ST_AE_INNER_FWD(HT_) do { ST_DYN_LDS((sta::ae_inner_fwd_kernel<AE_FWD_NW, HT_>)); \
-            hipLaunchKernelGGL((sta::ae_inner_fwd_kernel<AE_FWD_NW, HT_>), dim3(ae_fwd_grid(d)), dim3(AE_FWD_NW * 64), lds, s, \
+#define ST_AE_INNER_FWD_(NW_, HT_) do { ST_DYN_LDS((sta::ae_inner_fwd_kernel<NW_, HT_>)); \
+            hipLaunchKernelGGL((sta::ae_inner_fwd_kernel<NW_, HT_>), dim3(ae_inner_grid(d)), dim3(NW_ * 64), lds, s, \
                                w.H[0][0], w.H[1][0], knobs, ae_m, ae_p, L.go, w.H[0][7], w.H[1][7], d->B, F, d->K, L.KP); } while (0)
+#define ST_AE_INNER_FWD(HT_) do { const int nw_ = ae_inner_nw(d); if (nw_ == 9) ST_AE_INNER_FWD_(9, HT_); else if (nw_ == 12) ST_AE_INNER_FWD_(12, HT_); else ST_AE_INNER_FWD_(AE_FWD_NW, HT_); } while (0)
         switch (wide_ht) { case 1: ST_AE_INNER_FWD(1); break; case 2: ST_AE_INNER_FWD(2); break; default: ST_AE_INNER_FWD(0); }
 #undef ST_AE_INNER_FWD
+#undef ST_AE_INNER_FWD_
     }
     {
         stg::PlainNT al0{ae_m + L.go.w[8], OT, 64, 64, id}, al1{ae_p + L.go.w[8], OT, 64, 64, id};
@@ -2140,6 +2157,8 @@ static int attr_prepare(const st_dims* d)
 #define ST_PREP3(K0_, K1_, K2_) do { if (ht == 1) ST_DYN_LDS(K1_); else if (ht == 2) ST_DYN_LDS(K2_); else ST_DYN_LDS(K0_); } while (0)
     if (ae_is_wide(d)) {
         ST_PREP3((sta::ae_inner_fwd_kernel<AE_FWD_NW, 0>), (sta::ae_inner_fwd_kernel<AE_FWD_NW, 1>), (sta::ae_inner_fwd_kernel<AE_FWD_NW, 2>));
+        ST_PREP3((sta::ae_inner_fwd_kernel<9, 0>), (sta::ae_inner_fwd_kernel<9, 1>), (sta::ae_inner_fwd_kernel<9, 2>));
+        ST_PREP3((sta::ae_inner_fwd_kernel<12, 0>), (sta::ae_inner_fwd_kernel<12, 1>), (sta::ae_inner_fwd_kernel<12, 2>));
         ST_PREP3((sta::ae_bwd_kernel<AE_BWD_NW, false, true, 0, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, true, 1, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, true, 2, 0>));
         ST_PREP3((stw::wide_dv_polar_kernel<0>), (stw::wide_dv_polar_kernel<1>), (stw::wide_dv_polar_kernel<2>));
     } else {
