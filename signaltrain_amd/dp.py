@@ -126,9 +126,11 @@ class DataParallel:
         i = self._pin_i
         prev = None
         j = 1 - i
+        self.lagged_scalars = None
         if self._pin_ev[j] is not None:
             self._pin_ev[j].synchronize()                # recorded >= one interval ago: long done
             prev = float(self._pin[j][0])
+            self.lagged_scalars = self._pin[j].clone()   # all eight scalars of that reporting point ([5] = steps skipped on overflow so far): the fp16 loss-scale policy reads them here
         with torch.cuda.device(eng.device):
             self._pin[i].copy_(eng.scalars, non_blocking=True)
             ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(eng.device))

@@ -85,6 +85,8 @@ def _train_loop(dp, model, engine, effect, device, epochs, batch_size, lr_sched,
     opt = engine.optimizer_view()         # state_dict() in torch.optim.Adam's layout for misc.save_checkpoint
     windows, t_train, t_last = 0, 0.0, 0.0
     clean_steps, n_loss = 0, 0
+    seen_overflows, skip_overflow_report = 0, False
+    engine.scalars[5] = 0.0               # steps skipped on overflow, cumulative from here (device-side store, no sync)
     for epoch in range(int(start_epoch), epochs):
         if is_main:
             print("")
@@ -102,18 +104,35 @@ def _train_loop(dp, model, engine, effect, device, epochs, batch_size, lr_sched,
             if 0 == batch_num % status_every:                        # train.py:124-129 (the only device->host sync)
                 # the progress line shows the loss of the PREVIOUS reporting point (no queue drain, dp.mean_loss_lagged); f16 needs the
                 # overflow counter now anyway, and data parallel its collective
-                lval = dp.mean_loss() if (engine.compute_dtype.startswith("f16") or dp.world > 1) else dp.mean_loss_lagged()
+                f16 = engine.compute_dtype.startswith("f16")
+                lagged = dp.world == 1                               # one process: no queue drain, also not for the fp16 overflow counter (below)
+                lval = dp.mean_loss_lagged() if lagged else dp.mean_loss()
                 if lval is not None:                                 # None = the lagged read has no value yet; a NaN loss is logged as nan (train.py:125-129)
                     n_loss += 1
                     avg_loss = beta * avg_loss + (1 - beta) * lval
                     smoothed_loss = avg_loss / (1 - beta ** (status_every * n_loss))
-                if engine.compute_dtype.startswith("f16"):
-                    # loss-scale policy of Apex's dynamic scaler at this loop's only sync point: halve on overflow (the kernel
+                if f16:
+                    # loss-scale policy of Apex's dynamic scaler at this loop's reporting point: halve on overflow (the kernel
                     # already skipped those steps), double after 2000 clean steps.  Gated on the arithmetic, not on the current
-                    # scale: a scale that overflows halved its way down to 1 must be able to grow back
-                    if engine.overflow_steps():
-                        engine.loss_scale = max(engine.loss_scale / 2.0, 1.0); clean_steps = 0
+                    # scale: a scale that overflows halved its way down to 1 must be able to grow back.
+                    # One process: the counter comes with the lagged scalars (the value of the PREVIOUS reporting point, cumulative, never reset
+                    # here), so the policy reacts one interval later and the queue is never drained -- reading it directly stalled the host
+                    # every status_every steps.  The interval right after a halving ran partly under the old scale: its overflows are not
+                    # counted a second time.  Data parallel: the direct read, beside the collective mean_loss() already is.
+                    if lagged:
+                        sc = getattr(dp, "lagged_scalars", None)
+                        over = 0
+                        if sc is not None:
+                            cum = int(sc[5]); over = cum - seen_overflows; seen_overflows = cum
+                            if skip_overflow_report:
+                                over, skip_overflow_report = 0, False
+                        have = sc is not None
                     else:
+                        over, have = engine.overflow_steps(), True
+                    if over:
+                        engine.loss_scale = max(engine.loss_scale / 2.0, 1.0); clean_steps = 0
+                        skip_overflow_report = lagged
+                    elif have:
                         clean_steps += status_every
                         if clean_steps >= 2000:
                             engine.loss_scale = min(engine.loss_scale * 2.0, 2.0 ** 24); clean_steps = 0

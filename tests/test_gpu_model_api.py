@@ -778,6 +778,38 @@ def test_clip_scope_explains_f16_loss():
     assert rel["f16_all/ca0"] > rel["f16_all"] + 0.08 and abs(rel["f16_all/ca0"] - rel["bf16_all"]) < 0.10, rel
 
 
+def test_train_loop_fp16_loss_scale_policy_without_queue_drain(tmp_path, monkeypatch):
+    """train.train(compute_dtype="f16_all") from a loss scale that overflows fp16 (2^31): the loop's policy -- fed by the LAGGED copy of the scalars, no
+    device->host sync per reporting interval -- must halve its way down until steps go through (the kernel skips overflowed steps meanwhile), count each
+    overflow interval once, and end with finite parameters and a recorded validation loss."""
+    from signaltrain_amd import train, audio, nn_proc
+    nn_proc._QUIET = True
+    made = []
+    orig = nn_proc.st_model.engine
+
+    def engine_with_big_scale(self, *a, **k):
+        e = orig(self, *a, **k)
+        if not made:
+            e.loss_scale = 2.0 ** 31
+        made.append(e)
+        return e
+    monkeypatch.setattr(nn_proc.st_model, "engine", engine_with_big_scale)
+    cwd = os.getcwd(); os.chdir(tmp_path)
+    try:
+        torch.manual_seed(0); np.random.seed(0)
+        train.train(effect=audio.Compressor_4c(), epochs=1, n_data_points=16 * 600, batch_size=16, device=torch.device("cuda:0"),
+                    num_workers=2, device_feed=True, compute_dtype="f16_all", lr_max=2e-4)
+        eng = made[0]
+        skipped = int(eng.scalars[5].item())
+        assert 2.0 ** 12 <= eng.loss_scale < 2.0 ** 31, eng.loss_scale       # came down (one halving per two reporting intervals), did not collapse
+        assert 0 < skipped < 500, skipped                                      # the early steps were skipped, the later ones ran
+        assert eng.step_count == 600 and torch.isfinite(eng.params).all()
+        lines = [l.split() for l in open("vl_avg_out.dat").read().strip().splitlines()]
+        assert lines and np.isfinite(float(lines[-1][-1]))
+    finally:
+        os.chdir(cwd)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "f32x3"])
 def test_graph_step_equals_eager_steps(golden_dir, dtype):
     """st_graph_*: the whole optimisation step captured once as a HIP graph (step counter and learning rate on the device, looked
