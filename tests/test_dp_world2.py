@@ -129,21 +129,22 @@ if __name__ == "__main__":
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_share_one_gpu():
-    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one rank per process), both ranks on GPU 0 and the library's
-    exchange bound to the RCCL test double: the N > 1 code path of the bench (gloo bootstrap, library communicator, pre-warm agreed over ranks,
+@pytest.mark.parametrize("N", [2, 8])
+def test_bench_ranks_share_one_gpu(N):
+    """bench.py exactly as the driver launches it for N = 2 and N = 8 (torch.distributed.run, one rank per process), all ranks on GPU 0 and the library's
+    exchange bound to the RCCL test double: the N > 1 code path of the bench (gloo bootstrap, library communicator of N ranks, pre-warm agreed over ranks,
     barrier + max-over-ranks timing, one JSON line from rank 0) runs before the driver's 8-GPU node does."""
     import json, socket
     _build_fake()
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
     env = dict(os.environ, ST_RCCL_LIB=FAKE, ST_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--prewarm-s", "0.05", "--no-roofline", "--no-cpu-baseline", "--no-f32x3", "--no-graph", "--batch", "32"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(N), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(N), "--steps", "4", "--warmup", "2", "--prewarm-s", "0.05", "--no-roofline", "--no-cpu-baseline", "--no-f32x3", "--no-graph", "--batch", "32"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["config"]["global_batch"] == 64 and d["value"] > 0
+    assert d["n_gpus"] == N and d["steps"] == 4 and d["scaling"] == "weak" and d["config"]["global_batch"] == 32 * N and d["value"] > 0
     assert d["config"].get("dp_backend") == "lib", d["config"]
-    assert d["config"]["dp_world_min"] == d["config"]["dp_world_max"] == 2 and d["config"]["rccl_version"] == "test double", d["config"]
+    assert d["config"]["dp_world_min"] == d["config"]["dp_world_max"] == N and d["config"]["rccl_version"] == "test double", d["config"]
