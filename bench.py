@@ -300,7 +300,7 @@ def main():
             # comes from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS command on THIS build (tools/profile_gpu.sh ->
             # profiles/*_pmc_traffic*.json, which records the hash of the library sources and the bench arguments it measured):
             # a file measured on other sources or another workload is refused and traffic stays null.
-            traffic, tsrc, rocprof_us = None, None, None
+            traffic, traffic_raw, tsrc, rocprof_us = None, None, None, None
             try:
                 import glob
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -316,8 +316,13 @@ def main():
                         refused.append(os.path.basename(cand)); continue
                     hit = [v for k, v in tj.get("kernels", {}).items() if any(q in k for q in keys) and ("FETCH_SIZE_KB" in v or "avg_ns" in v)]
                     if hit and all("FETCH_SIZE_KB" in h and "WRITE_SIZE_KB" in h for h in hit):
-                        traffic = sum(h["FETCH_SIZE_KB"] + h["WRITE_SIZE_KB"] for h in hit) * 1024.0      # all launches of the logical kernel
-                        tsrc = os.path.basename(cand) + " (FETCH_SIZE + WRITE_SIZE per dispatch, rocprofv3 --pmc passes of this command on sources " + want["src_sha"] + "; uncorrected)"
+                        # MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE tallies the 128-byte fabric requests at 64 bytes -- double it; WRITE_SIZE at face value.
+                        # Calibrated on two kernels of known traffic in these very profiles (profiles/r04_rocprofv3_summary_f32.txt): clip_adam_kernel reads 63.0 MB and
+                        # writes 50.4 MB (FETCH_SIZE 31.0 MB, WRITE_SIZE 47.2 MB), comp_apply_kernel reads 4.19 MB and writes 2.10 MB (2.05 / 2.05 MB).
+                        traffic_raw = sum(h["FETCH_SIZE_KB"] + h["WRITE_SIZE_KB"] for h in hit) * 1024.0   # all launches of the logical kernel
+                        traffic = sum(2.0 * h["FETCH_SIZE_KB"] + h["WRITE_SIZE_KB"] for h in hit) * 1024.0
+                        tsrc = (os.path.basename(cand) + " (2 x FETCH_SIZE + WRITE_SIZE per dispatch: separate rocprofv3 --pmc passes of this command on sources " + want["src_sha"]
+                                + "; the factor 2 is the guide's gfx950 correction of FETCH_SIZE, checked here against clip_adam_kernel and comp_apply_kernel whose bytes are known)")
                         if all("avg_ns" in h for h in hit) and not dom.startswith("ae_wide"):          # rocprofv3's own kernel durations of the same command (kernel-trace stats); the wide path's logical kernel is a dozen launches, only some of them keyed here
                             rocprof_us = sum(h["avg_ns"] for h in hit) * 1e-3
                         break
@@ -328,7 +333,7 @@ def main():
             # `achieved` / `frac` come from the HIP events this process records around every launch (they read ~2-3 us high per launch: the events
             # themselves); when a rocprofv3 kernel trace of this command on these sources exists its average is quoted beside them
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                               "frac": ach / peak, "traffic": traffic, "traffic_source": tsrc,
+                               "frac": ach / peak, "traffic": traffic, "traffic_source": tsrc, **({"traffic_uncorrected": traffic_raw} if traffic is not None else {}),
                                "algorithmic_flops_per_launch": flops_k[dom], "avg_launch_us": rows[dom][0] * 1e3,
                                "timing": "in-process HIP events on the launch stream (~2-3 us high per launch)",
                                **({"rocprof_avg_launch_us": rocprof_us, "frac_rocprof": flops_k[dom] / (rocprof_us * 1e-6) / 1e12 / peak} if rocprof_us else {}),
