@@ -40,6 +40,25 @@ constexpr int NL = 9;
 // the autoencoder base: weight l at w[l], bias at b[l]); same for the gradient buffer.
 struct AEOffsets { int w[NL]; int b[NL]; };
 
+// Group enumeration of the forward kernels (round 4).  Neighbouring row groups share the 128-byte lines of the [B][T][F] arrays (a 16-row group reads 64 bytes of
+// every row, a 32-row group 128 bytes at an arbitrary alignment: rows are F * 4 = 2052 bytes): with "workgroup-fastest" numbering neighbours ran on neighbouring
+// WORKGROUPS, i.e. on different XCDs, and every shared line crossed the fabric twice (FETCH_SIZE of the 32-row forward: 2 x 26.0 MB for 26.3 MB of inputs).
+// Workgroups go round-robin over the 8 XCDs, so XCD x = blockIdx.x & 7 now owns a contiguous eighth of the groups and walks it workgroup-fastest WITHIN the XCD
+// (wave * S + slot: the partial last round still puts one extra group on every workgroup instead of a full round on a few).  Grids that are not a multiple of 8
+// keep the old numbering.
+struct GroupWalk { int first, end, stride; };
+__device__ __forceinline__ GroupWalk fwd_group_walk(const int ngroups, const int NW, const int wave)
+{
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    if ((G & 7) == 0) {
+        const int S = G >> 3, x = b & 7, slot = b >> 3;
+        const int per = (ngroups + 7) >> 3;
+        const int lo = x * per, hi = lo + per < ngroups ? lo + per : ngroups;
+        return GroupWalk{lo + wave * S + slot, hi, S * NW};
+    }
+    return GroupWalk{wave * G + b, ngroups, G * NW};
+}
+
 // Compile-time LDS layout (floats).  Padded shapes OUTp x INp per layer:
 //   l = 0: 64 x 32 (IN = T)   1: 32 x 64   2: 16 x 32   3: 16 x 16   4: 16 x 32 (IN = 16 + K)   5: 16 x 16   6: 32 x 16
 //   7: 64 x 32   8: 16 x 64 (OUT = OT)
@@ -389,7 +408,6 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     const int FP = KP / 2, gpw = FP / 16;              // groups per window
     const int ngroups = B * gpw;
     const int KQ = (K + 3) / 4;
-    const int gstride = gridDim.x * NW;
     float reg = 0.f;
     // frequency weights of the L1 term, one per bin (the table sits behind the two forward images; the host sizes the LDS request for it)
     float* const wtab = lds + 2 * CL::FWD_TOTAL;
@@ -402,18 +420,19 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     FwdIn cur;
     // block-fastest group numbering: the partial last round (ngroups is rarely a multiple of the wave count) then puts ONE
     // extra group on every workgroup instead of a full extra round on the first few workgroups while the rest idle
-    int grp = wave * gridDim.x + blockIdx.x;
-    if (grp < ngroups) {
+    const GroupWalk gw = fwd_group_walk(ngroups, NW, wave);      // XCD-contiguous since round 4 (above)
+    int grp = gw.first;
+    if (grp < gw.end) {
         const int b = grp / gpw, f = (grp - b * gpw) * 16 + c;
         fwd_load(cur, mag, phs, knobs, K, b, f, f < F, T, OT, F, g);
         fwd_mask(cur, K, f < F, T, OT, g);
     }
-    for (; grp < ngroups; grp += gstride) {
+    for (; grp < gw.end; grp += gw.stride) {
         asm volatile("" ::: "memory");      // keep the (loop-invariant) LDS weight fetches inside the loop: hoisting them spills
         const int b = grp / gpw, f = (grp - b * gpw) * 16 + c;
         const bool fv = f < F;
         FwdIn nxt;
-        const int gn = grp + gstride < ngroups ? grp + gstride : grp;      // last iteration: harmless reload of this group
+        const int gn = grp + gw.stride < gw.end ? grp + gw.stride : grp;      // last iteration: harmless reload of this group
         const int bn = gn / gpw, fn = (gn - bn * gpw) * 16 + c;
         fwd_load(nxt, mag, phs, knobs, K, bn, fn, fn < F, T, OT, F, g);
 

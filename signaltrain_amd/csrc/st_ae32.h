@@ -143,7 +143,7 @@ ae_fwd32_kernel(const float* __restrict__ mag, const float* __restrict__ phs, co
     __syncthreads();
 
     constexpr int GPW = 17;
-    const int ngroups = B * GPW, gstride = gridDim.x * NW;
+    const int ngroups = B * GPW;
     const int ng16 = B * (FP / 16);                     // 16-row groups of the h4 exchange buffer
     float reg = 0.f;
     int sfeat[8];
@@ -162,7 +162,8 @@ ae_fwd32_kernel(const float* __restrict__ mag, const float* __restrict__ phs, co
 #pragma unroll
     for (int j = 0; j < 8; ++j) { koff[j] = (unsigned)(sfeat[j] < K ? sfeat[j] : 0); okk |= (sfeat[j] < K ? 1u : 0u) << j; }
 
-    for (int grp = wave * gridDim.x + blockIdx.x; grp < ngroups; grp += gstride) {
+    const GroupWalk gw = fwd_group_walk(ngroups, NW, wave);      // an XCD owns a contiguous eighth of the groups (st_ae.h): shared 128-byte lines stay in one L2
+    for (int grp = gw.first; grp < gw.end; grp += gw.stride) {
         asm volatile("" ::: "memory");
         const int b = grp / GPW, jg = grp - b * GPW, f = 32 * jg + n;
         const bool fv = f < F;
