@@ -561,16 +561,8 @@ extern "C" int st_synthesis_frames(const st_dims* d, const float* AA, const floa
     ST_TRY(check_dims(d)); ST_REQ(AA && Sfold && frs, "st_synthesis_frames: null pointer");
     return synthesis_frames_impl(d, AA, Sfold, nullptr, frs, stream);
 }
-// k-slices that carry work on the 128 x 128 NT kernel: as many as fill the CUs with one workgroup each, at most the consumer's slab count
-static int nt128_active(int M, int Nc, int nslabs)
-{
-    const int tiles = ((M + 127) / 128) * ((Nc + 127) / 128);
-    int a = num_cus() / (tiles > 0 ? tiles : 1);
-    if (a < 1) a = 1;
-    return a < nslabs ? a : nslabs;
-}
-// only where one workgroup per CU covers the whole GEMM (the B = 256 headline geometry: 112 / 126 tiles x 2 k-slices); larger problems stay on
-// gemm_kernel<4, ...> / <2, ...>, whose smaller tiles balance better over several rounds
+// only where one workgroup per CU covers the whole GEMM (the B = 256 headline geometry: 112 / 126 tiles x 2 k-slices before the structural zeros are
+// dropped); larger problems stay on gemm_kernel<4, ...> / <2, ...>, whose smaller tiles balance better over several rounds
 static bool use_nt128(const st_dims* d, int M, int Nc) { return g_nt128 && gemm_ht(d->prec) == 0 && d->N % 32 == 0 && ((M + 127) / 128) * ((Nc + 127) / 128) * 2 <= num_cus(); }
 static int synthesis_frames_impl(const st_dims* d, const float* AA, const float* Sfold, const float* SfoldT, float* frs, void* stream)
 {
@@ -583,10 +575,12 @@ static int synthesis_frames_impl(const st_dims* d, const float* AA, const float*
     stg::StoreC ep{frs, R, d->N, d->N, (size_t)d->B * d->OT * d->N, ms};
     if (SfoldT && g_frs_nt) {
         stg::PlainNT bt{SfoldT, d->N, KP, KP, stg::all_frames(1)};
-        if (use_nt128(d, R, d->N)) {
-            const stg::NTRows ra{AA, (unsigned)(d->OT * KP), (unsigned)KP, ms.magic, ms.Tv, ms.t_lo, R}, rb{SfoldT, (unsigned)KP, 0u, 0u, 1, 0, d->N};
-            const int nsl = frames_split(R);
-            ST_TRY(stg::launch_nt128(ra, rb, ep, R, d->N, KP, nsl, nt128_active(R, d->N, nsl), st_stream(stream)));
+        stg::NTWork wk;
+        if (use_nt128(d, R, d->N) && stg::ntw_frames(wk, ms, d->B, d->H, d->N, d->N, d->y, KP, frames_split(R), num_cus())) {
+            // frame-major rows; only the tile columns whose taps survive the crop (cls_fe_dft.py:113): the others are never read by ola_loss_kernel
+            const stg::NTRows ra = stg::ntrows_frame_major(AA, (unsigned)(d->OT * KP), (unsigned)KP, ms, d->B, R), rb{SfoldT, (unsigned)KP, 0u, 0u, 1, 0, d->N};
+            const stg::StoreSlab es{frs, R, d->N, d->N, (size_t)d->B * d->OT * d->N, stg::frame_major(ms, d->B)};
+            ST_TRY(stg::launch_nt128(ra, rb, es, wk, st_stream(stream)));
         }
         else if (R >= 4096) ST_GEMM(4, al, bt, ep, R, d->N, KP, 1, st_stream(stream));
         else if (gemm_ht(d->prec) == 0 && (g_nt_mi & 4)) stg::launch<2, 16, 2>(al, bt, ep, R, d->N, KP, frames_split(R), st_stream(stream), g_dbg);
@@ -595,6 +589,28 @@ static int synthesis_frames_impl(const st_dims* d, const float* AA, const float*
     else if (R >= 4096) ST_GEMM(4, al, bl, ep, R, d->N, KP, 1, st_stream(stream));
     else ST_GEMM(2, al, bl, ep, R, d->N, KP, frames_split(R), st_stream(stream));
     ST_LAUNCHED("synthesis_frames"); return ST_OK;
+}
+
+// Host-side view of the work list of the 128 x 128-tile synthesis GEMMs (st_gemm_tn.h, round 5): which = 0 the frames GEMM, 1 the data gradient.
+// out[2 i], out[2 i + 1] = the packed entry i (tile row | tile column << 8 | slab << 16 | first zero-filled slab << 20 | kind << 24;  first k-tile | k-tiles << 16,
+// k-tiles of 32); head4 = {slabs, col_h, col_stride, frame-major windows per frame}.  Returns the number of entries (= workgroups), 0 when this geometry
+// does not run on the work-list kernel, < 0 on bad arguments.  No device work: the CPU test-suite checks the list against the cropping rule of cls_fe_dft.py:113.
+extern "C" int st_nt128_worklist(const st_dims* d, int which, int ncus, unsigned* out, int cap, int* head4)
+{
+    if (check_dims(d) != ST_OK || !out || !head4 || cap < 0 || (which != 0 && which != 1)) return -1;
+    const int KP = st_kp_of(d->F);
+    const stg::RowMap ms = synth_live(d);
+    const int R = ms.rows(d->B);
+    if (ncus <= 0) ncus = num_cus();
+    stg::NTWork wk; wk.n = 0;
+    const int Nc = which ? KP : d->N;
+    if (!(g_nt128 && gemm_ht(d->prec) == 0 && d->N % 32 == 0 && ((R + 127) / 128) * ((Nc + 127) / 128) * 2 <= ncus)) return 0;
+    const bool ok = which ? stg::ntw_dgrad(wk, ms, d->B, d->H, d->N, d->N, d->y, d->F, KP, R >= 4096 ? 1 : synth_split(R), ncus)
+                          : stg::ntw_frames(wk, ms, d->B, d->H, d->N, d->N, d->y, KP, frames_split(R), ncus);
+    if (!ok) return 0;
+    head4[0] = wk.nslabs; head4[1] = wk.col_h; head4[2] = wk.col_stride; head4[3] = d->B;
+    for (int i = 0; i < wk.n && i < cap; ++i) { out[2 * i] = wk.e[i].x; out[2 * i + 1] = wk.e[i].y; }
+    return wk.n;
 }
 
 static int ola_loss_impl(const st_dims* d, const float* frs, const float* x, const float* y_true,
@@ -627,9 +643,14 @@ static int synthesis_dgrad_impl(const st_dims* d, const float* dsyn, bool padded
     const int ns = R >= 4096 ? 1 : synth_split(R);
     if (padded) {
         stg::FramedNT<true> al{dsyn, d->y, d->H, d->N, R, d->N, 1.0f, ms};
-        if (use_nt128(d, R, KP)) {
-            const stg::NTRows ra{dsyn, (unsigned)(d->y + 2 * d->N), (unsigned)d->H, ms.magic, ms.Tv, ms.t_lo, R}, rb{Sfold, (unsigned)d->N, 0u, 0u, 1, 0, KP};
-            ST_TRY(stg::launch_nt128(ra, rb, ep, R, KP, d->N, ns, nt128_active(R, KP, ns), st_stream(stream)));
+        stg::NTWork wk;
+        if (use_nt128(d, R, KP) && stg::ntw_dgrad(wk, ms, d->B, d->H, d->N, d->N, d->y, d->F, KP, ns, num_cus())) {
+            // frame-major rows, per tile row only the taps that lie inside d syn (the margins of the padded copy are zeros), Nyquist columns apart
+            const stg::NTRows ra = stg::ntrows_frame_major(dsyn, (unsigned)(d->y + 2 * d->N), (unsigned)d->H, ms, d->B, R);
+            const stg::NTRows rb = wk.col_h ? stg::NTRows{Sfold, (unsigned)((KP / 2) * d->N), (unsigned)d->N, stg::rowmap_magic(d->F - 1), d->F - 1, 0, 2 * (d->F - 1)}
+                                            : stg::NTRows{Sfold, (unsigned)d->N, 0u, 0u, 1, 0, KP};
+            const stg::StoreSlab es{dAA, R, KP, KP, (size_t)d->B * d->OT * KP, stg::frame_major(ms, d->B)};
+            ST_TRY(stg::launch_nt128(ra, rb, es, wk, st_stream(stream)));
         }
         else if (R >= 4096) ST_GEMM(4, al, bl, ep, R, KP, d->N, ns, st_stream(stream));
         else if (gemm_ht(d->prec) == 0 && (g_nt_mi & 4)) stg::launch<2, 16, 2>(al, bl, ep, R, KP, d->N, ns, st_stream(stream), g_dbg);
@@ -654,8 +675,21 @@ static bool use_tn128(const st_dims* d, bool padded)
     const int ht = gemm_ht(d->prec);
     return g_tn128 && padded && (ht == 0 || (ht == 3 && !g_wg_split)) && d->N % 256 == 0 && g_wg_mode == 0;
 }
+// Frame-major reduction order (round 5): k -> frame t_lo + k / B, window k % B.  The operands keep their layout; only the strides swap roles and the
+// origin moves to frame t_lo.  B >= 2 (the kernel divides by the inner count with a multiply-high); B = 1 keeps the window-major order (identical rows).
+struct TNFrameMajor { stg::TNOperand a, b; stg::RowMap map; stg::FrameTrim trim; bool on; };
+static TNFrameMajor tn_frame_major(const stg::TNOperand& ta, const stg::TNOperand& tb, const stg::RowMap& live, int B, int H, int Ntaps, int pad, int Ls)
+{
+    TNFrameMajor f; f.on = B >= 2; f.a = ta; f.b = tb; f.map = live; f.trim = stg::FrameTrim{}; f.trim.on = 0;
+    if (!f.on) return f;
+    f.a = stg::TNOperand{ta.base + (size_t)live.t_lo * ta.S2, ta.S2, ta.S1};
+    f.b = stg::TNOperand{tb.base + (size_t)live.t_lo * tb.S2, tb.S2, tb.S1};
+    f.map.Tv = B; f.map.t_lo = 0; f.map.magic = stg::rowmap_magic(B); f.map.fm = 0;      // the kernel's (outer, inner) = (frame, window)
+    f.trim = stg::frame_trim(live, B, H, Ntaps, pad, Ls);
+    return f;
+}
 static int wgrad_tn128(const st_dims* d, const stg::TNOperand& ta, const stg::TNOperand& tb, const float* zeros, const stg::RowMap& map, int R,
-                       float* ws, int ns, stm::NyqJob* nyq, void* stream)
+                       float* ws, int ns, stm::NyqJob* nyq, void* stream, const stg::FrameTrim* trim)
 {
     const int KP = st_kp_of(d->F);
     const int mh = (d->N / 2) / 128;
@@ -663,8 +697,8 @@ static int wgrad_tn128(const st_dims* d, const stg::TNOperand& ta, const stg::TN
     float* part = ws + (size_t)ns * KP * d->N;
     int P = 0;
     const unsigned c0 = (unsigned)(d->F - 1), c1 = (unsigned)(KP / 2 + d->F - 1);
-    if (g_tn_bk == 16) ST_TRY((stg::launch_tn128<16>(ta, tb, zeros, map, R, d->N, mh, (unsigned)(KP / 2), d->N, ws, d->N, (size_t)KP * d->N, ns, st_stream(stream), part, c0, c1, &P)));
-    else ST_TRY((stg::launch_tn128<32>(ta, tb, zeros, map, R, d->N, mh, (unsigned)(KP / 2), d->N, ws, d->N, (size_t)KP * d->N, ns, st_stream(stream), part, c0, c1, &P)));
+    if (g_tn_bk == 16) ST_TRY((stg::launch_tn128<16>(ta, tb, zeros, map, R, d->N, mh, (unsigned)(KP / 2), d->N, ws, d->N, (size_t)KP * d->N, ns, st_stream(stream), part, c0, c1, &P, trim)));
+    else ST_TRY((stg::launch_tn128<32>(ta, tb, zeros, map, R, d->N, mh, (unsigned)(KP / 2), d->N, ws, d->N, (size_t)KP * d->N, ns, st_stream(stream), part, c0, c1, &P, trim)));
     nyq->part = part; nyq->P = P; nyq->on = 1;
     return ST_OK;
 }
@@ -679,7 +713,8 @@ static int synthesis_wgrad_impl(const st_dims* d, const float* AA, const float* 
     const stg::TNOperand ta{AA, (unsigned)(d->OT * KP), (unsigned)KP}, tb{dsyn, (unsigned)(d->y + 2 * d->N), (unsigned)d->H};
     if (use_tn128(d, padded) && stg::tn128_fits(ta, tb, dsyn, ms, d->N, d->N, (size_t)d->B * d->OT * KP, (size_t)d->B * (d->y + 2 * d->N))) {
         ns = tn_split(R, d->N);
-        ST_TRY(wgrad_tn128(d, ta, tb, dsyn, ms, R, ws, ns, &nyq, stream));
+        const TNFrameMajor fm = tn_frame_major(ta, tb, ms, d->B, d->H, d->N, d->N, d->y);      // taps of d syn's frames outside the crop are zeros: skipped per tile column
+        ST_TRY(wgrad_tn128(d, fm.a, fm.b, dsyn, fm.map, R, ws, ns, &nyq, stream, &fm.trim));
     } else {
         stg::PlainTN al{AA, R, KP, KP, ms};
         stg::StoreC ep{ws, KP, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
@@ -1039,7 +1074,8 @@ static int analysis_wgrad_impl(const st_dims* d, const float* dG, const float* s
     const stg::TNOperand ta{dG, (unsigned)(d->T * KP), (unsigned)KP}, tb{sig, (unsigned)(d->L + 2 * d->N), (unsigned)d->H};
     if (half < 0 && use_tn128(d, padded) && stg::tn128_fits(ta, tb, sig, ma, d->N, d->N, (size_t)d->B * d->T * KP, (size_t)d->B * (d->L + 2 * d->N))) {
         ns = tn_split(R, d->N);
-        ST_TRY(wgrad_tn128(d, ta, tb, sig, ma, R, ws, ns, &nyq, stream));
+        const TNFrameMajor fm = tn_frame_major(ta, tb, ma, d->B, d->H, d->N, d->N, d->L);      // taps of the partly padded frames (Conv1d padding, cls_fe_dft.py:28-31) are zeros: skipped per tile column
+        ST_TRY(wgrad_tn128(d, fm.a, fm.b, sig, fm.map, R, ws, ns, &nyq, stream, &fm.trim));
     } else {
         stg::PlainTN al{dG + m0, R, KP, M, ma};
         stg::StoreC ep{ws + (size_t)m0 * d->N, M, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
@@ -1542,11 +1578,12 @@ static int analysis_wgrad_half(const st_dims* d, const Layout& L, float* grads, 
         ns = num_cus() / (tiles > 0 ? tiles : 1); if (ns > 16) ns = 16; if (ns > R / 64) ns = R / 64; if (ns > room) ns = room; if (ns < 1) ns = 1;
         float* part = w.wg + (size_t)room * KP * N;
         int P = 0;
+        const TNFrameMajor fm = tn_frame_major(ta, tb, ma, d->B, d->H, N, N, d->L);
         // half 0 also forms the Nyquist partials of BOTH bases (its A origin is column 0: c0 = F - 1, c1 = KP / 2 + F - 1); half 1 has no Nyquist slice
-        if (g_tn_bk == 16) ST_TRY((stg::launch_tn128<16>(ta, tb, w.xp, ma, R, N / 2, mh, (unsigned)(KP / 2), N, w.wg + (size_t)m0 * N, N, (size_t)KP * N, ns, st_stream(stream),
-                                                          half ? nullptr : part, (unsigned)(F - 1), (unsigned)(KP / 2 + F - 1), &P)));
-        else ST_TRY((stg::launch_tn128<32>(ta, tb, w.xp, ma, R, N / 2, mh, (unsigned)(KP / 2), N, w.wg + (size_t)m0 * N, N, (size_t)KP * N, ns, st_stream(stream),
-                                            half ? nullptr : part, (unsigned)(F - 1), (unsigned)(KP / 2 + F - 1), &P)));
+        if (g_tn_bk == 16) ST_TRY((stg::launch_tn128<16>(fm.a, fm.b, w.xp, fm.map, R, N / 2, mh, (unsigned)(KP / 2), N, w.wg + (size_t)m0 * N, N, (size_t)KP * N, ns, st_stream(stream),
+                                                          half ? nullptr : part, (unsigned)(F - 1), (unsigned)(KP / 2 + F - 1), &P, &fm.trim)));
+        else ST_TRY((stg::launch_tn128<32>(fm.a, fm.b, w.xp, fm.map, R, N / 2, mh, (unsigned)(KP / 2), N, w.wg + (size_t)m0 * N, N, (size_t)KP * N, ns, st_stream(stream),
+                                            half ? nullptr : part, (unsigned)(F - 1), (unsigned)(KP / 2 + F - 1), &P, &fm.trim)));
         if (!half) { nyq_io->part = part; nyq_io->P = P; nyq_io->on = 1; }
     } else {
         ST_LAUNCHED("analysis_wgrad");
@@ -2171,7 +2208,7 @@ static int attr_prepare(const st_dims* d)
         else ST_PREP3((sta::ae_bwd_kernel<AE_BWD_NW, false, false, 0, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 1, 0>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 2, 0>));
     }
 #undef ST_PREP3
-    if (g_nt128 && gemm_ht(d->prec) == 0) ST_DYN_LDS((stg::gemm_nt128_kernel<stg::StoreC>));
+    if (g_nt128 && gemm_ht(d->prec) == 0) ST_DYN_LDS((stg::gemm_nt128_kernel));
     if (use_g16(d)) {           // st_gemm16.h: 72 / 80 KB of LDS with 64-deep k-tiles
         if (gemm_ht(d->prec) == 2) {
             ST_DYN_LDS((stg::gemm16_nt256_kernel<2, stg::PolarStore>)); ST_DYN_LDS((stg::gemm16_nt256_kernel<2, stg::StoreC>));

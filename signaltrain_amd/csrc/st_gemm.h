@@ -42,8 +42,17 @@ constexpr int PK = BK + 4;    // row pitch (floats) of an NT tile in LDS
 // instructions -- it was most of the 8 VALU-per-MFMA of the weight-gradient GEMMs.  magic = 0 means Tv = 1.
 struct RowMap {
     int Tv, t_lo, T; unsigned magic;
+    int fm;     // round 5: 0 = window-major compact rows (r = b * Tv + (t - t_lo)); fm = B > 0: FRAME-major (r = (t - t_lo) * B + b, magic = that of B) --
+                // the rows of one frame are contiguous, so a 128-row tile has one frame index (or a short run of them) and with it ONE live tap range:
+                // the partly padded / partly cropped frames' structural zeros (cls_fe_dft.py:28-31, :113) can be skipped per tile (st_gemm_tn.h)
     __host__ __device__ int rows(int B) const { return B * Tv; }
     __device__ void split(int r, int& b, int& t) const {
+        if (fm) {
+            const int q = magic ? (int)__umulhi((unsigned)r, magic) : r;
+            b = r - (int)__umul24((unsigned)q, (unsigned)fm);
+            t = t_lo + q;
+            return;
+        }
         b = magic ? (int)__umulhi((unsigned)r, magic) : r;
         t = t_lo + (r - (int)__umul24((unsigned)b, (unsigned)Tv));
     }
@@ -56,12 +65,14 @@ static inline RowMap live_frames(int T, int H, int N, int pad, int Ls)
     int lo = 0, hi = T - 1;
     while (lo < T && H * lo - pad + N <= 0) ++lo;
     while (hi >= lo && H * hi - pad >= Ls) --hi;
-    RowMap m; m.t_lo = lo; m.Tv = hi - lo + 1; m.T = T;
+    RowMap m; m.t_lo = lo; m.Tv = hi - lo + 1; m.T = T; m.fm = 0;
     if (m.Tv <= 0) { m.Tv = T; m.t_lo = 0; }
     m.magic = rowmap_magic(m.Tv);
     return m;
 }
-static inline RowMap all_frames(int T) { RowMap m; m.Tv = T; m.t_lo = 0; m.T = T; m.magic = rowmap_magic(T); return m; }
+static inline RowMap all_frames(int T) { RowMap m; m.Tv = T; m.t_lo = 0; m.T = T; m.fm = 0; m.magic = rowmap_magic(T); return m; }
+// the same live frames enumerated frame-major over B windows (B = 1: both orders coincide)
+static inline RowMap frame_major(RowMap m, int B) { m.fm = B; m.magic = B > 1 ? rowmap_magic(B) : 0u; return m; }
 
 // float4 at a 32-bit ELEMENT offset from a wave-uniform base: saddr + voffset addressing, no 64-bit arithmetic per load
 // (the host keeps every operand below 2^30 elements).

@@ -34,7 +34,29 @@ struct TNJob {
     int mh; unsigned mstride;      // tile row tm -> first A column = output row: (tm % mh) * 128 + (tm / mh) * mstride
     // the rows the tiles do not cover (the Nyquist bin of each basis): per-window-group partial dot products, see nyq_partial
     float* nyq_out; unsigned nyq_c0, nyq_c1; int nyq_P, Nc, nsplit;
+    // round 5 (frame-major reduction order only, see FrameTrim): tile column tx (taps [128 tx, 128 tx + 128) of operand B) is structurally zero outside
+    // the reduction rows [fa[tx] * fB, fb[tx] * fB) -- the k-slices of that tile column divide THAT range
+    int trim, fB; unsigned char fa[64], fb[64];
 };
+// Reduction rows a tile column needs.  Operand B of the weight-gradient GEMMs is the frame matrix of a zero-padded signal (x / 2 with its Conv1d padding,
+// cls_fe_dft.py:28-31; d syn with the cropped margins of cls_fe_dft.py:113): tap n of frame t is a structural zero unless pad <= H t + n < pad + Ls.  With the
+// reduction rows enumerated FRAME-major (all windows of frame t_lo, then t_lo + 1, ...) the frames that carry anything for taps [128 j, 128 j + 128) are a
+// contiguous run [fa, fb) -- 21-22 of the 23 analysis frames, 5-6 of the 7 synthesis frames at the default geometry: 7.6 % / 25 % of the MACs skipped.
+struct FrameTrim { int on, B; unsigned char fa[64], fb[64]; };
+static inline FrameTrim frame_trim(const RowMap& live, int B, int H, int Ntaps, int pad, int Ls)
+{
+    FrameTrim f; f.on = (Ntaps % 128 == 0 && Ntaps / 128 <= 64 && live.Tv <= 255) ? 1 : 0; f.B = B;
+    for (int j = 0; j < 64; ++j) { f.fa[j] = 0; f.fb[j] = (unsigned char)(live.Tv <= 255 ? live.Tv : 255); }
+    if (!f.on) return f;
+    for (int j = 0; j < Ntaps / 128; ++j) {
+        const int n0 = 128 * j;
+        int a = 0, b = live.Tv;
+        while (a < b && H * (live.t_lo + a) + n0 + 127 < pad) ++a;
+        while (b > a && H * (live.t_lo + b - 1) + n0 >= pad + Ls) --b;
+        f.fa[j] = (unsigned char)a; f.fb[j] = (unsigned char)b;
+    }
+    return f;
+}
 
 // One extra z-slice of workgroups (blockIdx.z == nsplit) forms the two Nyquist rows C[c][n] = sum_k A[k][c] * B[k][n], c in {nyq_c0, nyq_c1},
 // as nyq_P partial sums over groups of windows: out[p][0 | 1][n].  Light vector work (K / nyq_P rows of float4 FMAs per thread) that runs
@@ -88,8 +110,14 @@ gemm_tn128_kernel(const TNJob j, float* __restrict__ out, const int ldo, const s
     int tbx, tby, tbz; xcd_tile(tbx, tby, tbz, j.nsplit);
     const unsigned rowA = (unsigned)(tby % j.mh) * 128u + (unsigned)(tby / j.mh) * j.mstride;
     const unsigned colB = (unsigned)tbx * 128u;
-    const int k_begin = tbz * ksplit;
-    const int k_end = (k_begin + ksplit < j.K) ? k_begin + ksplit : j.K;
+    int k_begin = tbz * ksplit;
+    int k_end = (k_begin + ksplit < j.K) ? k_begin + ksplit : j.K;
+    if (j.trim) {                                        // the rows that carry anything for this tile column, divided among the k-slices (workgroup-uniform)
+        const int lo = (int)j.fa[tbx] * j.fB, hi = (int)j.fb[tbx] * j.fB;
+        const int per = ((hi - lo + j.nsplit - 1) / j.nsplit + BKT - 1) / BKT * BKT;
+        k_begin = lo + tbz * per;
+        k_end = (k_begin + per < hi) ? k_begin + per : hi;      // a last k-tile may run past hi: those rows are structural zeros of B for this tile column (or past K: masked)
+    }
 
     const int c4 = tid & 31, kr = tid >> 5;
     // BYTE offsets from j.base; every product below has 24-bit factors (host-checked): full-rate v_mad_u32_u24 instead of the
@@ -206,13 +234,15 @@ static inline bool tn128_fits(const TNOperand& A, const TNOperand& B, const floa
 template <int BKT>
 static inline int launch_tn128(const TNOperand& A, const TNOperand& B, const float* zeros, const RowMap& map, int K,
                                int M, int mh, unsigned mstride, int Nc, float* out, int ldo, size_t slab, int nsplit, hipStream_t s,
-                               float* nyq_out = nullptr, unsigned nyq_c0 = 0, unsigned nyq_c1 = 0, int* nyq_P = nullptr)
+                               float* nyq_out = nullptr, unsigned nyq_c0 = 0, unsigned nyq_c1 = 0, int* nyq_P = nullptr, const FrameTrim* trim = nullptr)
 {
     const float* lo = A.base < B.base ? A.base : B.base; if (zeros < lo) lo = zeros;
     TNJob j;
     j.base = lo; j.a0 = (unsigned)(A.base - lo); j.b0 = (unsigned)(B.base - lo); j.zero = (unsigned)(zeros - lo);
     j.SA1 = A.S1; j.SA2 = A.S2; j.SB1 = B.S1; j.SB2 = B.S2;
     j.magic = map.magic; j.Tv = map.Tv; j.t_lo = map.t_lo; j.K = K; j.mh = mh; j.mstride = mstride;
+    j.trim = (trim && trim->on) ? 1 : 0; j.fB = trim ? trim->B : 0;
+    for (int i = 0; i < 64; ++i) { j.fa[i] = trim ? trim->fa[i] : 0; j.fb[i] = trim ? trim->fb[i] : 0; }
     int ksplit = K;
     if (nsplit > 1) ksplit = st_round_up((K + nsplit - 1) / nsplit, BKT);
     constexpr size_t lds = (size_t)4 * BKT * 128 * sizeof(float);
@@ -227,13 +257,26 @@ static inline int launch_tn128(const TNOperand& A, const TNOperand& B, const flo
 
 }  // namespace stg
 
-// ================================================================================================ NT x NT on the same 128 x 128 tiles (round 3)
+// ================================================================================================ NT x NT on the same 128 x 128 tiles (round 3; work list: round 5)
 //   C[m][n] = sum_k A[m][k] * B[n][k],  both operands K-contiguous:  the synthesis FRAMES GEMM (cls_fe_dft.py:112 as a GEMM: A = spectra AA
-//   [live frames][KP], B = transposed fold [N][KP]) -- 58 us = 53 % of the fp32 peak on the 64 x 96 workgroup tiles of gemm_kernel<2, ...>
-//   (M = 1792 live frames only: 19 x 11 small tiles x 3 k-slices).  Here: 14 x 8 tiles of 128 x 128 x 2 k-slices = 224 workgroups, one per CU;
-//   row-major LDS tiles [row][BK + 4] (a global float4 along k = one ds_write_b128; a lane's 16 k of its row = four ds_read_b128, conflict-free at
-//   pitch 36), lane half h takes k in [16 h, 16 h + 16) of the 32-deep tile as in gemm_kernel; row offsets are per-thread constants and the k
-//   offset rides in the scalar base: NO address arithmetic in the loop.
+//   [live frames][KP], B = transposed fold [N][KP]) and the synthesis DATA-GRADIENT GEMM (A = frames of the padded d syn, B = fold [KP][N]).
+//   128 x 128 tiles, one workgroup per CU; row-major LDS tiles [row][BK + 4] (a global float4 along k = one ds_write_b128; a lane's 16 k of its
+//   row = four ds_read_b128, conflict-free at pitch 36), lane half h takes k in [16 h, 16 h + 16) of the 32-deep tile as in gemm_kernel; row
+//   offsets are per-thread constants and the k offset rides in the scalar base: NO address arithmetic in the loop.
+//
+//   Round 5 -- the STRUCTURAL ZEROS of the transposed convolution are not multiplied any more.  ConvTranspose1d(stride H) followed by the crop
+//   wave_form[:, :, N:-N] (cls_fe_dft.py:112-113) keeps, of output frame t', only the taps n with N <= H t' + n < N + y: at the default geometry
+//   frames 1, 2, 6, 7 keep 384 / 768 / 768 / 384 of their 1024 taps -- a quarter of the frames GEMM's outputs are cropped away and a quarter of the
+//   data-gradient GEMM's reduction reads the zero margins of the padded d syn.  With the compact rows enumerated FRAME-major (RowMap::fm) a 128-row
+//   tile has one frame index (B a multiple of 128; otherwise a short run of them, whose union is used), so the host can say per tile which taps
+//   live: the kernel runs a WORK LIST (one entry per workgroup, in the kernel arguments) of (tile row, tile column, k range, slab) --
+//     frames GEMM:   only the tile columns that hold live taps (84 of 112 tiles at B = 256), which leaves room for a third k-slice on 256 CUs;
+//     data gradient: per tile row the live k range only, cut into as many slices as keep every slice <= 384 taps (3 / 2 / 1 slices for whole /
+//                    three-quarter / three-eighth frames: 240 workgroups of equal length instead of 252 of length 512); slabs a tile row does not
+//                    use are zero-filled by its first slice, so the consumers' slab count stays a function of the geometry alone.
+//   KP = 2 * 528 columns are 8 tiles of 128 + 32: as in gemm_tn128_kernel the two Nyquist columns (bin F - 1 of d an_real / d an_imag) do not get a
+//   ninth, 87 %-empty tile column -- the tile columns cover bins [0, F - 1) of each half (column map: GEMM column c -> (c % nh) + (c / nh) * stride) and
+//   one light workgroup per tile row (kind 1) forms the two Nyquist columns as plain dot products.
 namespace stg {
 
 struct NTRows { const float* base; unsigned S1, S2, magic; int Tv, t_lo, R; };      // row r -> base[off(r) + k]; off = b * S1 + t * S2, (b, t) = split(min(r, R - 1)); magic == 0: b = r, t = 0
@@ -244,10 +287,68 @@ __device__ __forceinline__ unsigned ntrows_off(const NTRows& o, const int r)
     const unsigned t = o.magic ? (unsigned)o.t_lo + (rc - b * (unsigned)o.Tv) : 0u;
     return b * o.S1 + t * o.S2;
 }
+// the rows of a [windows][frames] array enumerated frame-major (RowMap::fm): row r -> frame t_lo + r / B, window r % B
+static inline NTRows ntrows_frame_major(const float* base, unsigned s_window, unsigned s_frame, const RowMap& live, int B, int R)
+{
+    return NTRows{base + (size_t)live.t_lo * s_frame, s_frame, s_window, B > 1 ? rowmap_magic(B) : 0u, B, 0, R};      // "b" = r / B = the frame, "t" = r % B = the window
+}
 
-template <class EPI>
+constexpr int NTW_MAX = 320;                               // work-list entries (one workgroup each); 2.5 KB of kernel arguments
+struct NTWork {
+    int n, nslabs;                                         // entries; slabs the consumer sums
+    int col_h, col_stride;                                 // output column of GEMM column c: (c % col_h) + (c / col_h) * col_stride  (col_h = 0: c)
+    unsigned nyq_b[2], nyq_col[2];                         // kind 1: element offsets (from rb.base) of the two B rows, and their output columns
+    uint2 e[NTW_MAX];                                      // x = tile row | tile column << 8 | slab << 16 | first slab to zero-fill << 20 | kind << 24;  y = first k-tile | k-tiles << 16
+};
+
+// slab z, 32 x 64 block of a wave: out[z][full_row][col]
+struct StoreSlab {
+    float* out; int M, Nc, ld; size_t slab; RowMap map;
+    __device__ void operator()(const int z, const int m0, const int n0, const f32x16 (&acc)[2]) const {
+        const int lane = threadIdx.x & 63;
+        float* o = out + (size_t)z * slab;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = m0 + d_row(i, lane);
+            if (row < M) {
+                float* orow = o + (size_t)map.full(row) * ld;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = n0 + 32 * j + (lane & 31);
+                    if (col < Nc) orow[col] = acc[j][i];
+                }
+            }
+        }
+    }
+};
+
+// kind 1: the two columns the tiles leave out, for the 128 rows of tile row mt: out[0][row][col_c] = sum_k A[row][k] * Brow_c[k] over the entry's k range,
+// zeros in the other slabs.  Thread = (row, column): the B row is wave-uniform.
+__device__ __forceinline__ void nt128_nyquist(const NTRows& ra, const NTRows& rb, const StoreSlab& epi, const NTWork& wk, const int m_blk, const int k_begin, const int k_end)
+{
+    const int row = m_blk + (threadIdx.x & 127), cc = threadIdx.x >> 7;
+    const float* a = ra.base + ntrows_off(ra, row);
+    const float* b = rb.base + wk.nyq_b[cc];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int k = k_begin; k < k_end; k += 32) {
+        f32x4 va[8], vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { va[u] = *reinterpret_cast<const f32x4*>(a + k + 4 * u); vb[u] = *reinterpret_cast<const f32x4*>(b + k + 4 * u); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            s0 = __builtin_fmaf(va[u][0], vb[u][0], s0); s1 = __builtin_fmaf(va[u][1], vb[u][1], s1);
+            s2 = __builtin_fmaf(va[u][2], vb[u][2], s2); s3 = __builtin_fmaf(va[u][3], vb[u][3], s3);
+        }
+    }
+    if (row < epi.M) {
+        float* o = epi.out + (size_t)epi.map.full(row) * epi.ld + wk.nyq_col[cc];
+        o[0] = (s0 + s1) + (s2 + s3);
+        for (int z = 1; z < wk.nslabs; ++z) o[(size_t)z * epi.slab] = 0.f;
+    }
+}
+
 __global__ void __launch_bounds__(256)
-gemm_nt128_kernel(const NTRows ra, const NTRows rb, const EPI epi, const int K, const int ksplit, const int nzero)
+gemm_nt128_kernel(const NTRows ra, const NTRows rb, const StoreSlab epi, const NTWork wk)
 {
     constexpr int BKT = 32, LD = BKT + 4, TS = 128 * LD;
     constexpr int NP = 4;                                  // 256 threads = 32 rows x 8 float4 per pass
@@ -255,10 +356,10 @@ gemm_nt128_kernel(const NTRows ra, const NTRows rb, const EPI epi, const int K, 
     float* const As = nt_lds;
     float* const Bs = nt_lds + 2 * TS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    int tbx, tby, tbz; xcd_tile(tbx, tby, tbz);
-    const int m_blk = tby * 128, n_blk = tbx * 128;
-    const int k_begin = tbz * ksplit;
-    const int k_end = (k_begin + ksplit < K) ? k_begin + ksplit : K;
+    const uint2 ent = wk.e[blockIdx.x];                    // workgroup-uniform (scalar loads from the kernel-argument segment)
+    const int m_blk = (int)(ent.x & 255u) * 128, n_blk = (int)((ent.x >> 8) & 255u) * 128, tbz = (int)((ent.x >> 16) & 15u), zf = (int)((ent.x >> 20) & 15u);
+    const int k_begin = (int)(ent.y & 0xffffu) * BKT, k_end = k_begin + (int)(ent.y >> 16) * BKT;
+    if (ent.x >> 24) { nt128_nyquist(ra, rb, epi, wk, m_blk, k_begin, k_end); return; }
 
     const int lr = tid >> 3, lk = (tid & 7) * 4;
     unsigned ao[NP], bo[NP];
@@ -346,35 +447,116 @@ gemm_nt128_kernel(const NTRows ra, const NTRows rb, const EPI epi, const int K, 
             cur ^= 1;
         }
     }
+    // output columns of this tile (tile columns never straddle col_h: it is a multiple of 128)
+    const int c_blk = wk.col_h ? (n_blk % wk.col_h) + (n_blk / wk.col_h) * wk.col_stride : n_blk;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) epi(m_blk + wm * 64 + 32 * mi, n_blk + wn * 64, acc[mi]);
-    if (nzero > 0 && tbz == 0) {                           // the slabs no k-slice computes: this tile of each, zeros
+    for (int mi = 0; mi < 2; ++mi) epi(tbz, m_blk + wm * 64 + 32 * mi, c_blk + wn * 64, acc[mi]);
+    if (zf < wk.nslabs) {                                  // the slabs no k-slice of this tile computes: zeros
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[mi][nj][i] = 0.f;
-        for (int z = 0; z < nzero; ++z) {
-            const EPI ez = epi.slab_shifted((int)gridDim.z + z);
+        for (int z = zf; z < wk.nslabs; ++z) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) ez(m_blk + wm * 64 + 32 * mi, n_blk + wn * 64, acc[mi]);
+            for (int mi = 0; mi < 2; ++mi) epi(z, m_blk + wm * 64 + 32 * mi, c_blk + wn * 64, acc[mi]);
         }
     }
 }
 
-// nslabs: slabs the consumer sums (grid z); nactive <= nslabs: k-slices that carry work -- the others start past K and store zeros
-// (the consumers' slab counts are a function of the geometry alone; this kernel fills the chip with fewer, longer slices).
-// Launched with MORE than half the LDS of a CU so that no two workgroups share one: with tiles x nactive <= #CUs every workgroup then has a CU
-// to itself -- measured without this, 224 + 112 workgroups at 2 per CU: the dispatcher doubled up heavy ones and the GEMM took 79 us (61 TFLOP/s).
-template <class EPI>
-static inline int launch_nt128(const NTRows& ra, const NTRows& rb, const EPI& epi, int M, int Nc, int K, int nslabs, int nactive, hipStream_t s)
+// ---- host side: the work list
+// Frames [f0, f1] (absolute indices) of the rows [r0, r1) of a frame-major compact enumeration over B windows
+static inline void ntw_tile_frames(const RowMap& live, int B, int R, int mt, int& f0, int& f1)
 {
-    int ksplit = K;
-    if (nactive > 1) ksplit = st_round_up((K + nactive - 1) / nactive, 32);
+    const int r0 = mt * 128, r1 = (r0 + 128 < R ? r0 + 128 : R) - 1;
+    f0 = live.t_lo + r0 / B; f1 = live.t_lo + r1 / B;
+}
+// Taps n of frames f0..f1 (union) that land in [pad, pad + Ls) at position H f + n:  [lo, hi), 0 <= lo < hi <= N
+static inline void ntw_live_taps(int f0, int f1, int H, int N, int pad, int Ls, int& lo, int& hi)
+{
+    lo = pad - H * f1; if (lo < 0) lo = 0;                 // monotone in f: the union of the intervals is the interval of the extremes
+    hi = pad + Ls - H * f0; if (hi > N) hi = N;
+    if (hi <= lo) { lo = 0; hi = N; }                      // cannot happen for live frames; be safe
+}
+static inline void ntw_push(NTWork& w, int mt, int nt, int z, int zf, int kind, int k0, int kl)
+{
+    w.e[w.n++] = make_uint2((unsigned)mt | (unsigned)nt << 8 | (unsigned)z << 16 | (unsigned)zf << 20 | (unsigned)kind << 24, (unsigned)k0 | (unsigned)kl << 16);
+}
+// entries are built in (slab, tile row, tile column) order; workgroup i runs on XCD i % 8, so XCD j gets the j-th contiguous eighth of that order
+// (one band of A rows / one k-slice of B per L2, as xcd_tile does for the grid-shaped launches)
+static inline void ntw_xcd_order(NTWork& w)
+{
+    uint2 tmp[NTW_MAX];
+    const int T = w.n, q = T >> 3, r = T & 7;
+    for (int L = 0; L < T; ++L) { const int j = L & 7; tmp[L] = w.e[j * q + (j < r ? j : r) + (L >> 3)]; }
+    for (int L = 0; L < T; ++L) w.e[L] = tmp[L];
+}
+// Frames GEMM: M = live frames (frame-major), columns = the N taps, reduction K (a multiple of 32).  false: does not fit the list.
+static inline bool ntw_frames(NTWork& w, const RowMap& live, int B, int H, int N, int pad, int Ls, int K, int nslabs, int ncus)
+{
+    const int R = live.rows(B), MT = (R + 127) / 128;
+    if (N % 128 || K % 32 || MT > 255 || N / 128 > 255 || K / 32 > 0xffff || nslabs > 15) return false;
+    int tiles = 0, c0[256], c1[256];
+    for (int mt = 0; mt < MT; ++mt) {
+        int f0, f1, lo, hi; ntw_tile_frames(live, B, R, mt, f0, f1); ntw_live_taps(f0, f1, H, N, pad, Ls, lo, hi);
+        c0[mt] = lo / 128; c1[mt] = (hi + 127) / 128; tiles += c1[mt] - c0[mt];
+    }
+    int nact = ncus / (tiles > 0 ? tiles : 1); if (nact > nslabs) nact = nslabs; if (nact > K / 32) nact = K / 32; if (nact < 1) nact = 1;
+    if (tiles * nact > NTW_MAX) return false;
+    w.n = 0; w.nslabs = nslabs; w.col_h = 0; w.col_stride = 0; w.nyq_b[0] = w.nyq_b[1] = w.nyq_col[0] = w.nyq_col[1] = 0u;
+    const int kt = K / 32;
+    for (int z = 0; z < nact; ++z) {
+        const int k0 = (int)((long long)kt * z / nact), k1 = (int)((long long)kt * (z + 1) / nact);
+        for (int mt = 0; mt < MT; ++mt)
+            for (int nt = c0[mt]; nt < c1[mt]; ++nt) ntw_push(w, mt, nt, z, z == 0 ? nact : nslabs, 0, k0, k1 - k0);
+    }
+    ntw_xcd_order(w);
+    return true;
+}
+// Data gradient: M = live frames (frame-major), reduction = the N taps of a frame (per tile row: the live ones only), columns = KP = 2 * FP spectral
+// columns; F - 1 a multiple of 128: 2 (F - 1) / 128 tile columns + the two Nyquist columns as kind-1 entries, else ceil(KP / 128) plain tile columns.
+static inline bool ntw_dgrad(NTWork& w, const RowMap& live, int B, int H, int N, int pad, int Ls, int F, int KP, int nslabs, int ncus)
+{
+    const int R = live.rows(B), MT = (R + 127) / 128;
+    const bool nyq = (F - 1) % 128 == 0 && F > 1;
+    const int NT = nyq ? 2 * (F - 1) / 128 : (KP + 127) / 128;
+    if (N % 32 || MT > 255 || NT > 255 || N / 32 > 0xffff || nslabs > 15) return false;
+    int k0[256], k1[256];
+    for (int mt = 0; mt < MT; ++mt) {
+        int f0, f1, lo, hi; ntw_tile_frames(live, B, R, mt, f0, f1); ntw_live_taps(f0, f1, H, N, pad, Ls, lo, hi);
+        k0[mt] = lo / 32; k1[mt] = (hi + 31) / 32;
+    }
+    // the shortest slice length (k-tiles) whose slice count per tile row stays within the slabs and whose workgroups fit the CUs
+    int kmax = 0, total = 0;
+    for (int c = 1; c <= N / 32; ++c) {
+        int sum = 0; bool ok = true;
+        for (int mt = 0; mt < MT; ++mt) { const int s = (k1[mt] - k0[mt] + c - 1) / c; if (s > nslabs) { ok = false; break; } sum += s; }
+        if (ok && sum * NT + (nyq ? MT : 0) <= ncus) { kmax = c; total = sum * NT + (nyq ? MT : 0); break; }
+    }
+    if (!kmax || total > NTW_MAX) return false;
+    w.n = 0; w.nslabs = nslabs;
+    w.col_h = nyq ? F - 1 : 0; w.col_stride = KP / 2;
+    w.nyq_b[0] = (unsigned)(F - 1) * (unsigned)N; w.nyq_b[1] = (unsigned)(KP / 2 + F - 1) * (unsigned)N; w.nyq_col[0] = (unsigned)(F - 1); w.nyq_col[1] = (unsigned)(KP / 2 + F - 1);
+    for (int z = 0; z < nslabs; ++z)
+        for (int mt = 0; mt < MT; ++mt) {
+            const int len = k1[mt] - k0[mt], s = (len + kmax - 1) / kmax;
+            if (z >= s) continue;
+            const int a = k0[mt] + (int)((long long)len * z / s), b = k0[mt] + (int)((long long)len * (z + 1) / s);
+            for (int nt = 0; nt < NT; ++nt) ntw_push(w, mt, nt, z, z == 0 ? s : nslabs, 0, a, b - a);
+        }
+    ntw_xcd_order(w);
+    if (nyq) for (int mt = 0; mt < MT; ++mt) ntw_push(w, mt, 0, 0, nslabs, 1, k0[mt], k1[mt] - k0[mt]);      // behind the tiles: dispatched last, on the CUs the tiles leave free
+    return true;
+}
+
+// Launched with MORE than half the LDS of a CU so that no two workgroups share one: with <= #CUs entries every workgroup then has a CU
+// to itself -- measured without this, 224 + 112 workgroups at 2 per CU: the dispatcher doubled up heavy ones and the GEMM took 79 us (61 TFLOP/s).
+static inline int launch_nt128(const NTRows& ra, const NTRows& rb, const StoreSlab& epi, const NTWork& wk, hipStream_t s)
+{
     constexpr size_t lds = (size_t)84 * 1024;              // tiles: 4 * 128 * 36 * 4 = 72 KB; 84 KB > 160 / 2 keeps a CU to one workgroup
-    const int rc = ::ensure_dyn_lds((const void*)gemm_nt128_kernel<EPI>, "gemm_nt128_kernel"); if (rc) return rc;
-    hipLaunchKernelGGL((gemm_nt128_kernel<EPI>), dim3((Nc + 127) / 128, (M + 127) / 128, nactive > 1 ? nactive : 1), dim3(256), lds, s, ra, rb, epi, K, ksplit, nslabs - (nactive > 1 ? nactive : 1));
+    const int rc = ::ensure_dyn_lds((const void*)gemm_nt128_kernel, "gemm_nt128_kernel"); if (rc) return rc;
+    hipLaunchKernelGGL(gemm_nt128_kernel, dim3(wk.n), dim3(256), lds, s, ra, rb, epi, wk);
     return 0;
 }
 

@@ -242,8 +242,10 @@ def _run_all(lib, geo, X, Y, KN, P, d, B, K, verbose):
     frs = z(lib.st_synth_frame_slabs(C.byref(d)), B * OT, N)
     _lib.check(lib.st_synthesis_frames(C.byref(d), _lib.ptr(AAo), _lib.ptr(Sfold), _lib.ptr(frs), stream()), "synth")
     frs_ref = O._r(c["Are"].reshape(-1, F)) @ O._r(fr_) + O._r(c["Aim"].reshape(-1, F)) @ O._r(fi_)     # O._r: identity unless bf16_mode
-    # only frames that reach the cropped output are computed (t with 0 < H t and H t - N < y)
-    live = np.array([(geo["H"] * tt > 0) and (geo["H"] * tt - N < geo["y"]) for tt in range(OT)])
+    # only what reaches the cropped output is computed (cls_fe_dft.py:113): frames t with 0 < H t and H t - N < y, and of the partly cropped frames
+    # only the tile columns that hold surviving taps (round 5: N <= H t + n < N + y) -- compared on exactly the taps the overlap-add reads
+    live = (geo["H"] * np.arange(OT)[:, None] + np.arange(N)[None, :] >= N) & (geo["H"] * np.arange(OT)[:, None] + np.arange(N)[None, :] < N + geo["y"])
+    assert live.any(1)[1:-1].all()
     res.append(err("synthesis.frames", n(frs).sum(0).reshape(B, OT, N)[:, live], frs_ref.reshape(B, OT, N)[:, live]))
     y_hat, dsyn = z(B, d.y), z(B, d.y)
     lp = z(lib.st_ola_loss_partials(C.byref(d)))

@@ -1,0 +1,54 @@
+"""The spread of the checked QUANTITY itself, per configuration (CPU only; numpy + the oracle).
+
+tests/gpu_checks.py holds every gradient tensor of a fused step to 2e-4 of the tensor maximum against the float64 oracle.  For the analysis-basis
+gradients that tolerance is not always meaningful: d atan2(im, re) = (-im, re) / (re^2 + im^2) (nn_proc.py:309-310 under autograd) turns an absolute
+error e in re / im -- fp32 GEMM rounding, ~1e-7 of the largest bin -- into a relative error e / mag of that bin's gradient, and near-silent bins
+(mag ~ 1e-5 of the maximum) exist in comp_4c windows.  Rounds 1-4 filtered such misses BY TENSOR NAME; this module measures instead, for the
+configuration at hand, how far the oracle moves when its OWN arithmetic changes:
+
+    f32     the oracle in float32 arithmetic vs the oracle in float64, same fp32 inputs (the reference, PyTorch fp32, is on this side),
+    noise   the float64 oracle under `npert` independent 1e-6 relative perturbations of inputs and parameters, max over draws,
+
+both as max|difference| / max|tensor| per gradient tensor ("grad.<name>"), as |difference| / |loss| for "step.loss", and as max absolute parameter
+difference after one clip + Adam step ("train0.params").  gpu_checks.grounded() accepts a miss of the fixed tolerance only when the device's error
+is within 3 x that spread -- for ANY tensor, no names.
+"""
+import numpy as np
+from oracle import st_oracle as O
+
+
+def _step_params(G, P, lr):
+    """Parameters after one clip + Adam step from gradients G (train.py:136-147 ordering), float32 like the optimizer."""
+    g = {k: (np.asarray(v, np.float64) / O.LOSS_SCALE).astype(np.float32) for k, v in G.items()}
+    O.clip_l1_stft(g)
+    Pq = {k: np.asarray(P[k], np.float32).copy() for k in O.param_order()}
+    M = {k: np.zeros_like(v) for k, v in Pq.items()}; V = {k: np.zeros_like(v) for k, v in Pq.items()}
+    O.adam_step(Pq, g, M, V, 1, lr)
+    return Pq
+
+
+def oracle_spread(B, seed, K=4, scale=1, scheme="lean", shrink=4, npert=8, steps=1):
+    from tests import gpu_checks as G                     # make_case only (numpy); no GPU touched
+    geo, X, Y, KN, P = G.make_case(B, seed, K=K, scale=scale, scheme=scheme, shrink=shrink)
+    lr = O.get_1cycle_schedule(lr_max=1e-3, n_data_points=200, epochs=1, batch_size=2)[0][0]
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    X64, K64, Y64 = X.astype(np.float64), KN.astype(np.float64), Y.astype(np.float64)
+    l0, G0, _ = O.model_loss_bwd(X64, K64, Y64, P64, geo)
+    p0 = _step_params(G0, P, lr)
+
+    def diff(l1, G1):
+        d = {"grad." + k.replace("mpaec.", ""): float(np.abs(G0[k] - G1[k]).max() / max(np.abs(G0[k]).max(), 1e-30)) for k in G0}
+        d["step.loss"] = abs(l0 - l1) / abs(l0)
+        p1 = _step_params(G1, P, lr)
+        d["train0.params"] = float(max(np.abs(p0[k].astype(np.float64) - p1[k]).max() for k in p0))
+        return d
+    l32, G32, _ = O.model_loss_bwd(X, KN, Y, P, geo)
+    out = {"f32": diff(float(l32), {k: v.astype(np.float64) for k, v in G32.items()}), "noise": {}}
+    for s in range(npert):
+        rng = np.random.default_rng(1000 + s)
+        Pp = {k: v * (1 + 1e-6 * rng.standard_normal(v.shape)) for k, v in P64.items()}
+        Xp = X64 * (1 + 1e-6 * rng.standard_normal(X64.shape))
+        l1, G1, _ = O.model_loss_bwd(Xp, K64, Y64, Pp, geo)
+        for k, v in diff(l1, G1).items():
+            out["noise"][k] = max(out["noise"].get(k, 0.0), v)
+    return out

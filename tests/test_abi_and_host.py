@@ -258,3 +258,91 @@ def test_effective_precision_is_reported():
     d.prec = 0; assert lib.st_effective_prec(C.byref(d)) == 0
     assert lib.st_geometry(1.0, 4.0, 0, 4, 3, C.byref(d)) == 0          # fused geometry: any batch
     d.prec = 2; assert lib.st_effective_prec(C.byref(d)) == 2
+
+
+@pytest.mark.parametrize("B,shrink", [(256, 4), (128, 4), (192, 4), (64, 4), (3, 4), (1, 4), (256, 8), (100, 2)])
+def test_nt128_worklist_covers_exactly_the_live_taps(B, shrink):
+    """Round 5: the 128 x 128-tile synthesis GEMMs no longer multiply the structural zeros of the cropped transposed convolution
+    (cls_fe_dft.py:112-113: of output frame t' only the taps n with N <= H t' + n < N + y survive the crop).  Host logic only (st_nt128_worklist):
+    frames GEMM -- every live (frame, tap) lies in a listed tile, each listed tile gets its whole reduction exactly once per active slab and zeros
+    in the others; data gradient -- every tile row's slices partition a k range that holds all its frames' live taps, every spectral column is
+    produced exactly once per slab (tiles + the Nyquist entries), unused slabs are zero-filled; never more workgroups than CUs."""
+    lib = _lib.load()
+    ncus = 256
+    d = _lib.geometry(1, shrink, 4, B)
+    N, H, OT, y, F = d.N, d.H, d.OT, d.y, d.F
+    KP = lib.st_kp(F)
+    live_t = [t for t in range(OT) if H * t + N > N and H * t < N + y]        # frames with at least one tap inside the crop [N, N + y)
+    t_lo, Tv = live_t[0], len(live_t)
+    assert live_t == list(range(t_lo, t_lo + Tv))
+    R = B * Tv
+
+    def tap_range(t):
+        return max(0, N - H * t), min(N, N + y - H * t)
+
+    def entries(which):
+        out = (C.c_uint * (2 * 512))(); head = (C.c_int * 4)()
+        n = lib.st_nt128_worklist(C.byref(d), which, ncus, out, 512, head)
+        assert n >= 0
+        ents = [dict(mt=out[2 * i] & 255, nt=(out[2 * i] >> 8) & 255, z=(out[2 * i] >> 16) & 15, zf=(out[2 * i] >> 20) & 15, kind=out[2 * i] >> 24,
+                     k0=out[2 * i + 1] & 0xffff, kl=out[2 * i + 1] >> 16) for i in range(n)]
+        return n, ents, list(head)
+
+    # ---------------------------------------------------------------- frames GEMM: C[row][tap] over k in [0, KP)
+    n, ents, head = entries(0)
+    if ((R + 127) // 128) * (N // 128) * 2 > ncus:
+        assert n == 0
+    else:
+        nsl = lib.st_synth_frame_slabs(C.byref(d))
+        assert 0 < n <= ncus and head[0] == nsl and head[1] == 0 and head[3] == B and all(e["kind"] == 0 for e in ents)
+        tiles = {}
+        for e in ents:
+            tiles.setdefault((e["mt"], e["nt"]), []).append(e)
+        for (mt, nt), es in tiles.items():
+            es.sort(key=lambda e: e["z"])
+            nact = len(es)
+            assert [e["z"] for e in es] == list(range(nact)) and nact <= nsl
+            assert es[0]["k0"] == 0 and es[-1]["k0"] + es[-1]["kl"] == KP // 32
+            assert all(es[i]["k0"] + es[i]["kl"] == es[i + 1]["k0"] for i in range(nact - 1))
+            assert es[0]["zf"] == nact and all(e["zf"] == nsl for e in es[1:])       # slabs [nact, nsl) zero-filled once
+        for r in range(R):                                     # frame-major compact rows
+            t = t_lo + r // B
+            lo, hi = tap_range(t)
+            for ntile in range(N // 128):
+                live = lo < 128 * ntile + 128 and hi > 128 * ntile
+                if live:
+                    assert (r // 128, ntile) in tiles, (r, t, ntile)
+        if B % 128 == 0:                                       # one frame per tile row: nothing but live tiles is computed
+            for (mt, nt) in tiles:
+                lo, hi = tap_range(t_lo + (128 * mt) // B)
+                assert lo < 128 * nt + 128 and hi > 128 * nt
+        if (B, shrink) == (256, 4):
+            assert len(tiles) == 84 and n == 252               # 84 of 112 tiles, three k-slices: one workgroup per CU
+    # ---------------------------------------------------------------- data gradient: C[row][spectral column] over the taps
+    n, ents, head = entries(1)
+    if ((R + 127) // 128) * ((KP + 127) // 128) * 2 > ncus:
+        assert n == 0
+    else:
+        nsl = lib.st_synth_slabs(C.byref(d))
+        assert 0 < n <= ncus and head[0] == nsl
+        col_h, col_stride = head[1], head[2]
+        assert (col_h, col_stride) == (F - 1, KP // 2)         # N = 1024: the Nyquist columns are kind-1 entries
+        MT = (R + 127) // 128
+        for mt in range(MT):
+            rows = range(128 * mt, min(128 * mt + 128, R))
+            lo = min(tap_range(t_lo + r // B)[0] for r in rows); hi = max(tap_range(t_lo + r // B)[1] for r in rows)
+            mine = [e for e in ents if e["mt"] == mt]
+            nyq = [e for e in mine if e["kind"] == 1]
+            assert len(nyq) == 1 and 32 * nyq[0]["k0"] <= lo and 32 * (nyq[0]["k0"] + nyq[0]["kl"]) >= hi
+            cols = sorted(set(e["nt"] for e in mine if e["kind"] == 0))
+            assert cols == list(range(2 * (F - 1) // 128))
+            for nt in cols:
+                es = sorted((e for e in mine if e["kind"] == 0 and e["nt"] == nt), key=lambda e: e["z"])
+                s = len(es)
+                assert [e["z"] for e in es] == list(range(s)) and s <= nsl and es[0]["zf"] == s and all(e["zf"] == nsl for e in es[1:])
+                assert 32 * es[0]["k0"] <= lo and 32 * (es[-1]["k0"] + es[-1]["kl"]) >= hi
+                assert all(es[i]["k0"] + es[i]["kl"] == es[i + 1]["k0"] for i in range(s - 1))
+                if B % 128 == 0:                               # no k-tile outside the live taps
+                    assert 32 * es[0]["k0"] >= lo - 31 and 32 * (es[-1]["k0"] + es[-1]["kl"]) <= hi + 31
+        if (B, shrink) == (256, 4):
+            assert n == 240 + 14 and max(e["kl"] for e in ents if e["kind"] == 0) == 12      # 3 / 2 / 1 slices of <= 384 taps, Nyquist columns on the 14 spare CUs
