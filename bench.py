@@ -301,6 +301,7 @@ def main():
             # profiles/*_pmc_traffic*.json, which records the hash of the library sources and the bench arguments it measured):
             # a file measured on other sources or another workload is refused and traffic stays null.
             traffic, traffic_raw, tsrc, rocprof_us = None, None, None, None
+            step_traffic, step_launches, mfma_busy = None, None, None
             try:
                 import glob
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -323,6 +324,17 @@ def main():
                         traffic = sum(2.0 * h["FETCH_SIZE_KB"] + h["WRITE_SIZE_KB"] for h in hit) * 1024.0
                         tsrc = (os.path.basename(cand) + " (2 x FETCH_SIZE + WRITE_SIZE per dispatch: separate rocprofv3 --pmc passes of this command on sources " + want["src_sha"]
                                 + "; the factor 2 is the guide's gfx950 correction of FETCH_SIZE, checked here against clip_adam_kernel and comp_apply_kernel whose bytes are known)")
+                        # round 5 (VERDICT round 4, next #3d): the WHOLE step's memory-side bytes from the same file -- every library kernel (namespaces st?::) times its launches
+                        # per step (launches of a kernel / launches of the once-per-step optimizer kernel) -- beside the algorithmic bytes of SURVEY.md 8(d):
+                        # batch I/O (x, y, knobs) + Adam (read p, g, m, v; write p, m, v) + one read of the weights and one write of the gradients
+                        lk = {k: v for k, v in tj.get("kernels", {}).items() if any(ns in k for ns in ("stg::", "sta::", "stm::", "stw::", "stf::")) and "FETCH_SIZE_KB" in v and "WRITE_SIZE_KB" in v and v.get("calls")}
+                        once = [v["calls"] for k, v in lk.items() if "clip_adam_kernel" in k]
+                        if once:
+                            step_traffic = sum((2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0 * v["calls"] / once[0] for v in lk.values())
+                            step_launches = sum(v["calls"] / once[0] for v in lk.values())
+                        mf = [h for h in hit if "SQ_VALU_MFMA_BUSY_CYCLES" in h and h.get("GRBM_GUI_ACTIVE")]
+                        if mf and len(mf) == len(hit):      # SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's SIMDs (4 per CU); GRBM_GUI_ACTIVE = the dispatch's cycles
+                            mfma_busy = sum(h["SQ_VALU_MFMA_BUSY_CYCLES"] for h in mf) / (4.0 * torch.cuda.get_device_properties(dev).multi_processor_count * sum(h["GRBM_GUI_ACTIVE"] for h in mf))
                         if all("avg_ns" in h for h in hit) and not dom.startswith("ae_wide"):          # rocprofv3's own kernel durations of the same command (kernel-trace stats); the wide path's logical kernel is a dozen launches, only some of them keyed here
                             rocprof_us = sum(h["avg_ns"] for h in hit) * 1e-3
                         break
@@ -338,6 +350,16 @@ def main():
                                "timing": "in-process HIP events on the launch stream (~2-3 us high per launch)",
                                **({"rocprof_avg_launch_us": rocprof_us, "frac_rocprof": flops_k[dom] / (rocprof_us * 1e-6) / 1e12 / peak} if rocprof_us else {}),
                                **({"launches_per_step": 2, "note": "ae_bwd = ae_bwd_dec + ae_bwd_enc (two launches, times and FLOPs summed)"} if dom == "ae_bwd" and "ae_bwd_dec" in rows else {})}
+            # whole-step traffic against the algorithmic bytes: where the 16-bit configurations lose
+            n_par = int(eng.layout.total)
+            step_alg = float(B) * (d.L + d.y + d.K) * 4.0 + 7.0 * 4.0 * n_par + 2.0 * 4.0 * n_par
+            out["roofline"]["step_algorithmic_bytes"] = step_alg
+            out["roofline"]["step_traffic"] = step_traffic
+            if step_traffic is not None:
+                out["roofline"]["step_traffic_ratio"] = step_traffic / step_alg
+                out["roofline"]["step_kernel_launches"] = step_launches
+                out["roofline"]["step_traffic_note"] = "sum over the step's kernels of (2 x FETCH_SIZE + WRITE_SIZE) x launches per step, same PMC file as `traffic`"
+            out["roofline"]["mfma_busy"] = mfma_busy        # SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x GRBM_GUI_ACTIVE) of the roofline kernel, same file; null without a source-matched PMC pass
             if args.dtype.endswith("_all") and dom.startswith("ae_"):
                 # honest label: with 16-bit Linear layers the autoencoder kernels spend ~7 % of their time in MFMAs; what bounds them is vector-ALU work (ELU / ELU',
                 # conversions, transposes) and LDS fragment traffic (PMC: profiles/r03_rocprofv3_summary_bf16_all.txt), so the fraction of the MFMA peak is small by construction

@@ -23,7 +23,8 @@ if __name__ == "__main__":
     p.add_argument('-b', '--batch', type=int, help="batch size (per GPU)", default=200)
     p.add_argument('--checkpoint', help='name of checkpoint .tar file to start from', default='modelcheckpoint.tar')
     p.add_argument('-c', '--compand', help='mu-law compand the audio of a file dataset (datasets.py:218-220)', action='store_true')
-    p.add_argument('--effect', help='effect to learn', default='comp_4c', choices=['comp_4c', 'comp_4c_large', 'files'])
+    p.add_argument('--effect', help="effect to learn, the reference's keys (run_train.py:55-80): comp_4c | comp_large | files are built here "
+                   "(comp_4c_large is kept as an alias of comp_large); the reference's other keys are named in the error message", default='comp_4c')
     p.add_argument('--epochs', type=int, default=1000)
     p.add_argument('--lrmax', type=float, help="maximum learning rate", default=1e-4)
     p.add_argument('-n', '--num', type=int, help='number of data points per epoch', default=200000)
@@ -33,6 +34,16 @@ if __name__ == "__main__":
     p.add_argument('--shrink', type=int, help='shrink output chunk relative to input by this divisor', default=4)
     p.add_argument('-t', '--target', help='accepted for compatibility', default="stream")
     args = p.parse_args()
+    # the reference's effect table (run_train.py:55-80); the hot path carries the 4-knob compressor family and file pairs
+    EFFECTS = {'comp_4c': 'Compressor_4c', 'comp_large': 'Compressor_4c_Large', 'comp_4c_large': 'Compressor_4c_Large', 'files': 'FileEffect'}
+    NOT_BUILT = ('comp', 'comp_t', 'comp_one', 'denoise', 'lowpass')      # audio.Compressor / Comp_Just_Thresh / Compressor_4c_OneSetting / Denoise / LowPass
+    if args.effect not in EFFECTS:
+        if args.effect in NOT_BUILT or 'VST' in args.effect:
+            raise SystemExit(f"--effect {args.effect}: a key of the reference's run_train.py that signaltrain_amd does not build (its scope is the comp_4c training path: "
+                             f"{', '.join(k for k in EFFECTS if k != 'comp_4c_large')}); not built: {', '.join(NOT_BUILT)}, VST*")
+        raise SystemExit(f"Effect option '{args.effect}' is not yet added (available: {', '.join(k for k in EFFECTS if k != 'comp_4c_large')})")       # run_train.py:79-80
+    if args.target not in ("chunk", "stream"):
+        raise SystemExit(f"Error, invalid target type: {args.target}")                # run_train.py:90-92
 
     import torch.distributed as dist
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -47,7 +58,7 @@ if __name__ == "__main__":
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")              # one node: do not depend on the host name resolving
         dist.init_process_group("gloo")
     from signaltrain_amd import audio, train
-    effect = audio.FileEffect(args.path, sr=args.sr) if args.effect == 'files' else (audio.Compressor_4c() if args.effect == 'comp_4c' else audio.Compressor_4c_Large())
+    effect = audio.FileEffect(args.path, sr=args.sr) if args.effect == 'files' else getattr(audio, EFFECTS[args.effect])()
     train.train(epochs=args.epochs, n_data_points=args.num, batch_size=args.batch, device=torch.device("cuda", local),
                 effect=effect, datapath=(args.path if args.effect == 'files' else None), sr=args.sr, scale_factor=args.scale, shrink_factor=args.shrink, apex_opt=args.apex,
                 target_type=args.target, lr_max=args.lrmax, in_checkpointname=args.checkpoint, compand=args.compand,

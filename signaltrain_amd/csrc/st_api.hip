@@ -191,6 +191,10 @@ static int g_g16_split = 0;  // k-slices of its weight-gradient GEMMs (0: by res
 static int g_nt128 = 1;      // fp32 synthesis frames / data-gradient GEMMs on the 128 x 128-tile NT kernel (st_gemm_tn.h); 0 = gemm_kernel<2, ...> (st_set_tuning(9950), diagnostics)
 static int g_tn128 = 1;      // weight-gradient GEMMs on the 128 x 128-tile kernel (st_gemm_tn.h) where it applies; 0 = gemm_kernel<3, ...> (st_set_tuning(9500), diagnostics)
 static int g_tn_bk = 32;     // its k-tile depth (st_set_tuning(9516 / 9532))
+static int g_tn_fm = 3;      // round 5: frame-major reduction order + per-tile-column row ranges (structural zeros skipped) in the 128 x 128 weight-gradient GEMMs: bit 0 synthesis
+                             // (25 % of its reduction rows are cropped taps: 41.7 -> 37.0 us), bit 1 analysis (7.6 %: 113.8 -> 109.5 us)   (st_set_tuning(9540 + bits), diagnostics)
+static int g_g16_crop = 15;  // round 5, 16-bit operand pipeline: structural zeros skipped (frame-major rows): bit 0 frames GEMM (dead tile columns return), bit 1 data gradient (live taps per tile row),
+                             // bit 2 / bit 3 synthesis / analysis weight gradient (reduction rows per tile column)   (st_set_tuning(9560 + bits), diagnostics)
 static int g_frs_nt = 1;     // synthesis frames GEMM against the transposed fold (both operands K-contiguous); 0 = the k-major form (st_set_tuning(9000), diagnostics)
 static int g_xt = 0;       // 1: M/N-contiguous operands staged k-quad-major (st_gemm.h XT; st_set_tuning(7001), diagnostics).  MEASURED SLOWER at B=256 although
                            // conflict-free with a third fewer LDS cycles: analysis wgrad 173 vs 145 us, synthesis frames 63 vs 60 us (16 more prefetch
@@ -223,6 +227,8 @@ extern "C" int st_set_tuning(int bk)
     if (bk >= 9680 && bk < 9690) { g_g16_abl = bk - 9680; return ST_OK; }
 #endif
     if (bk >= 9600) { const int v = bk - 9600; if (v == 32 || v == 64) g_g16_bk = v; else g_g16 = v; return ST_OK; }
+    if (bk >= 9560 && bk < 9576) { g_g16_crop = bk - 9560; return ST_OK; }
+    if (bk >= 9540 && bk < 9544) { g_tn_fm = bk - 9540; return ST_OK; }
     if (bk >= 9500) { const int v = bk - 9500; if (v == 16 || v == 32) g_tn_bk = v; else g_tn128 = v; return ST_OK; }
     if (bk >= 9400) { g_pl_bf16 = bk - 9400; return ST_OK; }
     if (bk >= 9300) { g_wg_split = bk - 9300; return ST_OK; }
@@ -247,7 +253,7 @@ extern "C" int st_set_tuning(int bk)
 // (a wrong default can then not ship unnoticed, and a test cannot leak a switch into the next one).
 #define ST_TUNING_LIST(X) X(g_dbg, 0) X(g_ae_split, -1) X(g_pl_bf16, 0) X(g_wg_split, 0) X(g_pl_dgrad, 0) X(g_pl_shape, 3) X(g_g16, 1) X(g_g16_bk, 64) X(g_g16_dma, 0) \
     X(g_g16_abl, 0) X(g_g16_split, 0) X(g_nt128, 1) X(g_tn128, 1) X(g_tn_bk, 32) X(g_frs_nt, 1) X(g_xt, 0) X(g_wide_pair, 1) X(g_wide_dvp, 1) X(g_nt_mi, 0) X(g_an_bk, 32) \
-    X(g_bk, 16) X(g_wsplit_max, 16) X(g_wsplit_div, 200) X(g_an_waves, 4) X(g_syn_split, 3) X(g_frs_split, 3) X(g_wide_fused, 1) X(g_wsplit_half, 0) X(g_wg_mode, 0) X(g_ae32, 1) X(g_wide_direct, 1)
+    X(g_bk, 16) X(g_wsplit_max, 16) X(g_wsplit_div, 200) X(g_an_waves, 4) X(g_syn_split, 3) X(g_frs_split, 3) X(g_wide_fused, 1) X(g_wsplit_half, 0) X(g_wg_mode, 0) X(g_ae32, 1) X(g_wide_direct, 1) X(g_tn_fm, 3) X(g_g16_crop, 15)
 static int g_wg_mode = 0;
 extern "C" int st_get_tuning(int* out, int n)
 {
@@ -678,9 +684,9 @@ static bool use_tn128(const st_dims* d, bool padded)
 // Frame-major reduction order (round 5): k -> frame t_lo + k / B, window k % B.  The operands keep their layout; only the strides swap roles and the
 // origin moves to frame t_lo.  B >= 2 (the kernel divides by the inner count with a multiply-high); B = 1 keeps the window-major order (identical rows).
 struct TNFrameMajor { stg::TNOperand a, b; stg::RowMap map; stg::FrameTrim trim; bool on; };
-static TNFrameMajor tn_frame_major(const stg::TNOperand& ta, const stg::TNOperand& tb, const stg::RowMap& live, int B, int H, int Ntaps, int pad, int Ls)
+static TNFrameMajor tn_frame_major(const stg::TNOperand& ta, const stg::TNOperand& tb, const stg::RowMap& live, int B, int H, int Ntaps, int pad, int Ls, bool enable)
 {
-    TNFrameMajor f; f.on = B >= 2; f.a = ta; f.b = tb; f.map = live; f.trim = stg::FrameTrim{}; f.trim.on = 0;
+    TNFrameMajor f; f.on = enable && B >= 2; f.a = ta; f.b = tb; f.map = live; f.trim = stg::FrameTrim{}; f.trim.on = 0;
     if (!f.on) return f;
     f.a = stg::TNOperand{ta.base + (size_t)live.t_lo * ta.S2, ta.S2, ta.S1};
     f.b = stg::TNOperand{tb.base + (size_t)live.t_lo * tb.S2, tb.S2, tb.S1};
@@ -713,7 +719,7 @@ static int synthesis_wgrad_impl(const st_dims* d, const float* AA, const float* 
     const stg::TNOperand ta{AA, (unsigned)(d->OT * KP), (unsigned)KP}, tb{dsyn, (unsigned)(d->y + 2 * d->N), (unsigned)d->H};
     if (use_tn128(d, padded) && stg::tn128_fits(ta, tb, dsyn, ms, d->N, d->N, (size_t)d->B * d->OT * KP, (size_t)d->B * (d->y + 2 * d->N))) {
         ns = tn_split(R, d->N);
-        const TNFrameMajor fm = tn_frame_major(ta, tb, ms, d->B, d->H, d->N, d->N, d->y);      // taps of d syn's frames outside the crop are zeros: skipped per tile column
+        const TNFrameMajor fm = tn_frame_major(ta, tb, ms, d->B, d->H, d->N, d->N, d->y, (g_tn_fm & 1) != 0);      // taps of d syn's frames outside the crop are zeros: skipped per tile column
         ST_TRY(wgrad_tn128(d, fm.a, fm.b, dsyn, fm.map, R, ws, ns, &nyq, stream, &fm.trim));
     } else {
         stg::PlainTN al{AA, R, KP, KP, ms};
@@ -1074,7 +1080,7 @@ static int analysis_wgrad_impl(const st_dims* d, const float* dG, const float* s
     const stg::TNOperand ta{dG, (unsigned)(d->T * KP), (unsigned)KP}, tb{sig, (unsigned)(d->L + 2 * d->N), (unsigned)d->H};
     if (half < 0 && use_tn128(d, padded) && stg::tn128_fits(ta, tb, sig, ma, d->N, d->N, (size_t)d->B * d->T * KP, (size_t)d->B * (d->L + 2 * d->N))) {
         ns = tn_split(R, d->N);
-        const TNFrameMajor fm = tn_frame_major(ta, tb, ma, d->B, d->H, d->N, d->N, d->L);      // taps of the partly padded frames (Conv1d padding, cls_fe_dft.py:28-31) are zeros: skipped per tile column
+        const TNFrameMajor fm = tn_frame_major(ta, tb, ma, d->B, d->H, d->N, d->N, d->L, (g_tn_fm & 2) != 0);      // taps of the partly padded frames (Conv1d padding, cls_fe_dft.py:28-31) are zeros: skipped per tile column
         ST_TRY(wgrad_tn128(d, fm.a, fm.b, sig, fm.map, R, ws, ns, &nyq, stream, &fm.trim));
     } else {
         stg::PlainTN al{dG + m0, R, KP, M, ma};
@@ -1332,12 +1338,14 @@ static int synthesis_frames16(const st_dims* d, WS& w, void* stream)
     const int KP = st_kp_of(d->F);
     const stg::RowMap ms = synth_live(d);
     const int R = ms.rows(d->B);
-    const stg::Rows16 ra = stg::rows16(w.AA16, (unsigned)(d->OT * KP), (unsigned)KP, ms, R);
+    const bool crop = (g_g16_crop & 1) && d->N % 128 == 0;
+    const stg::Rows16 ra = crop ? stg::rows16_frame_major(w.AA16, (unsigned)(d->OT * KP), (unsigned)KP, ms, d->B, R) : stg::rows16(w.AA16, (unsigned)(d->OT * KP), (unsigned)KP, ms, R);
     const stg::Rows16 rb = stg::rows16_plain(w.SfoldT16, (unsigned)KP, d->N);
-    stg::StoreC ep{w.frs, R, d->N, d->N, (size_t)d->B * d->OT * d->N, ms};
+    stg::StoreC ep{w.frs, R, d->N, d->N, (size_t)d->B * d->OT * d->N, crop ? stg::frame_major(ms, d->B) : ms};
+    const stg::Crop16 cr{crop ? 1 : 0, d->B, d->H, d->N, d->N, d->y, ms.t_lo, R, 1};      // tile columns without a tap inside the crop (cls_fe_dft.py:113) are not computed: ola_loss_kernel never reads them
     const int ns = frames_split(R);
-    if (gemm_ht(d->prec) == 2) ST_TRY((stg::launch16_nt<2>(ra, rb, ep, R, d->N, KP, ns, st_stream(stream))));
-    else ST_TRY((stg::launch16_nt<1>(ra, rb, ep, R, d->N, KP, ns, st_stream(stream))));
+    if (gemm_ht(d->prec) == 2) ST_TRY((stg::launch16_nt<2>(ra, rb, ep, R, d->N, KP, ns, st_stream(stream), true, &cr)));
+    else ST_TRY((stg::launch16_nt<1>(ra, rb, ep, R, d->N, KP, ns, st_stream(stream), true, &cr)));
     ST_LAUNCHED("synthesis_frames"); return ST_OK;
 }
 static int synthesis_dgrad16(const st_dims* d, WS& w, void* stream)
@@ -1345,16 +1353,18 @@ static int synthesis_dgrad16(const st_dims* d, WS& w, void* stream)
     const int KP = st_kp_of(d->F);
     const stg::RowMap ms = synth_live(d);
     const int R = ms.rows(d->B);
-    const stg::Rows16 ra = stg::rows16(w.dsyn16, (unsigned)(d->y + 2 * d->N), (unsigned)d->H, ms, R);
+    const bool crop = (g_g16_crop & 2) && !(g_g16_dma & 2);
+    const stg::Rows16 ra = crop ? stg::rows16_frame_major(w.dsyn16, (unsigned)(d->y + 2 * d->N), (unsigned)d->H, ms, d->B, R) : stg::rows16(w.dsyn16, (unsigned)(d->y + 2 * d->N), (unsigned)d->H, ms, R);
     const stg::Rows16 rb = stg::rows16_plain(w.Sfold16, (unsigned)d->N, KP);
-    stg::StoreC ep{w.dAA, R, KP, KP, (size_t)d->B * d->OT * KP, ms};
+    stg::StoreC ep{w.dAA, R, KP, KP, (size_t)d->B * d->OT * KP, crop ? stg::frame_major(ms, d->B) : ms};
+    const stg::Crop16 cr{crop ? 2 : 0, d->B, d->H, d->N, d->N, d->y, ms.t_lo, R, 1};      // per tile row only the taps that lie inside d syn: the rest of the padded copy is zeros
     const int ns = R >= 4096 ? 1 : synth_split(R);
     if ((g_g16_dma & 2) && d->N % 64 == 0 && d->N / 64 >= ns) {
         if (gemm_ht(d->prec) == 2) ST_TRY((stg::launch16_nt256<2>(ra, rb, ep, R, KP, d->N, ns, st_stream(stream))));
         else ST_TRY((stg::launch16_nt256<1>(ra, rb, ep, R, KP, d->N, ns, st_stream(stream))));
     }
-    else if (gemm_ht(d->prec) == 2) ST_TRY((stg::launch16_nt<2>(ra, rb, ep, R, KP, d->N, ns, st_stream(stream))));
-    else ST_TRY((stg::launch16_nt<1>(ra, rb, ep, R, KP, d->N, ns, st_stream(stream))));
+    else if (gemm_ht(d->prec) == 2) ST_TRY((stg::launch16_nt<2>(ra, rb, ep, R, KP, d->N, ns, st_stream(stream), true, &cr)));
+    else ST_TRY((stg::launch16_nt<1>(ra, rb, ep, R, KP, d->N, ns, st_stream(stream), true, &cr)));
     ST_LAUNCHED("synthesis_dgrad"); return ST_OK;
 }
 // k-slices of a 16-bit weight-gradient GEMM: about two workgroups per CU (their time is staging, not matrix work), never slices under
@@ -1369,7 +1379,8 @@ static int g16_wsplit(const st_dims* d, int R)
 }
 // A: [rows (b, t)][KP] 16-bit (d G or the spectra), B: frames of a padded 16-bit signal whose first N elements are zero (the block of zeros)
 static int wgrad16(const st_dims* d, const unsigned short* A, unsigned SA1, const unsigned short* Bsig, unsigned SB1, const stg::RowMap& map, int R,
-                   float* slabs, int ns, void* stream, int m0 = 0, int M = -1)      // [m0, m0 + M): the output rows (= columns of A) of this launch; default all KP
+                   float* slabs, int ns, void* stream, int m0 = 0, int M = -1,      // [m0, m0 + M): the output rows (= columns of A) of this launch; default all KP
+                   int trim_Ls = 0)                                                  // > 0: frame-major reduction order, rows per tile column trimmed to the frames with a tap inside [pad, pad + Ls) (round 5)
 {
     const int KP = st_kp_of(d->F);
     if (M < 0) M = KP;
@@ -1380,6 +1391,17 @@ static int wgrad16(const st_dims* d, const unsigned short* A, unsigned SA1, cons
     j.base = lo; j.a0 = (unsigned)(A - lo) + (unsigned)m0; j.b0 = (unsigned)(Bsig - lo); j.zero = j.b0;
     j.SA1 = SA1; j.SA2 = (unsigned)KP; j.SB1 = SB1; j.SB2 = (unsigned)d->H;
     j.magic = map.magic; j.Tv = map.Tv; j.t_lo = map.t_lo; j.K = R;
+    j.trim = 0; j.fB = 0; j.nsplit = 1;
+    for (int i = 0; i < 64; ++i) { j.fa[i] = 0; j.fb[i] = 0; }
+    if (trim_Ls > 0 && d->B >= 2) {
+        const stg::FrameTrim ft = stg::frame_trim(map, d->B, d->H, d->N, d->N, trim_Ls);
+        // (outer, inner) = (frame, window): the strides swap roles, the origins move to frame t_lo (the zero block stays where it is)
+        j.a0 += (unsigned)map.t_lo * (unsigned)KP; j.b0 += (unsigned)map.t_lo * (unsigned)d->H;
+        j.SA1 = (unsigned)KP; j.SA2 = SA1; j.SB1 = (unsigned)d->H; j.SB2 = SB1;
+        j.magic = stg::rowmap_magic(d->B); j.Tv = d->B; j.t_lo = 0;
+        j.trim = ft.on; j.fB = d->B;
+        for (int i = 0; i < 64; ++i) { j.fa[i] = ft.fa[i]; j.fb[i] = ft.fb[i]; }
+    }
     stg::StoreC ep{slabs + (size_t)m0 * d->N, M, d->N, d->N, (size_t)KP * d->N, stg::all_frames(1)};
     const int ht = gemm_ht(d->prec);
     if (g_g16_bk == 32) { if (ht == 2) ST_TRY((stg::launch16_tn<2, 32>(j, ep, M, d->N, ns, st_stream(stream)))); else ST_TRY((stg::launch16_tn<1, 32>(j, ep, M, d->N, ns, st_stream(stream)))); }
@@ -1464,7 +1486,7 @@ static int backward_syn(const st_dims* d, const Layout& L, float* grads, WS& w, 
         ST_TRY(synthesis_dgrad16(d, w, stream));
         const stg::RowMap ms = synth_live(d);
         const int R = ms.rows(d->B), KP = st_kp_of(d->F), ns = g16_wsplit(d, R);
-        ST_TRY(wgrad16(d, w.AA16, (unsigned)(d->OT * KP), w.dsyn16, (unsigned)(d->y + 2 * d->N), ms, R, w.wg, ns, stream));
+        ST_TRY(wgrad16(d, w.AA16, (unsigned)(d->OT * KP), w.dsyn16, (unsigned)(d->y + 2 * d->N), ms, R, w.wg, ns, stream, 0, -1, (g_g16_crop & 4) ? d->y : 0));
         ST_LAUNCHED("synthesis_wgrad");
         if (defer_slabs) { *defer_slabs = ns; if (defer_nyq) { *defer_nyq = stm::NyqJob{}; defer_nyq->on = 0; } return ST_OK; }
         stm::NyqJob nq{}; nq.on = 0;
@@ -1543,7 +1565,7 @@ static int backward_p2(const st_dims* d, const Layout& L, float* grads, const fl
     if (w.g16) {
         const stg::RowMap ma = stg::live_frames(d->T, d->H, d->N, d->N, d->L);
         const int R = ma.rows(d->B), KP = st_kp_of(d->F), ns = g16_wsplit(d, R);
-        ST_TRY(wgrad16(d, w.dG16, (unsigned)(d->T * KP), w.xp16, (unsigned)(d->L + 2 * d->N), ma, R, w.wg, ns, stream));
+        ST_TRY(wgrad16(d, w.dG16, (unsigned)(d->T * KP), w.xp16, (unsigned)(d->L + 2 * d->N), ma, R, w.wg, ns, stream, 0, -1, (g_g16_crop & 8) ? d->L : 0));
         ST_LAUNCHED("analysis_wgrad");
         stm::NyqJob nq{}; nq.on = 0;
         hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(st_norm_partials(d)), dim3(256), 0, st_stream(stream),
@@ -1571,14 +1593,14 @@ static int analysis_wgrad_half(const st_dims* d, const Layout& L, float* grads, 
         const int tiles = ((KP / 2 + 127) / 128) * (N / 128);
         ns = g_g16_split > 0 ? g_g16_split : (2 * num_cus()) / (tiles > 0 ? tiles : 1);
         if (ns > R / 128) ns = R / 128; if (ns > room) ns = room; if (ns < 1) ns = 1;
-        ST_TRY(wgrad16(d, w.dG16, (unsigned)(d->T * KP), w.xp16, (unsigned)(d->L + 2 * d->N), ma, R, w.wg, ns, stream, m0, KP / 2));
+        ST_TRY(wgrad16(d, w.dG16, (unsigned)(d->T * KP), w.xp16, (unsigned)(d->L + 2 * d->N), ma, R, w.wg, ns, stream, m0, KP / 2, (g_g16_crop & 8) ? d->L : 0));
         if (!half) { *nyq_io = stm::NyqJob{}; nyq_io->on = 0; }
     } else if (use_tn128(d, true) && stg::tn128_fits(ta, tb, w.xp, ma, N / 2, N, (size_t)d->B * d->T * KP, (size_t)d->B * (d->L + 2 * d->N))) {
         const int mh = (N / 2) / 128, tiles = mh * (N / 128);
         ns = num_cus() / (tiles > 0 ? tiles : 1); if (ns > 16) ns = 16; if (ns > R / 64) ns = R / 64; if (ns > room) ns = room; if (ns < 1) ns = 1;
         float* part = w.wg + (size_t)room * KP * N;
         int P = 0;
-        const TNFrameMajor fm = tn_frame_major(ta, tb, ma, d->B, d->H, N, N, d->L);
+        const TNFrameMajor fm = tn_frame_major(ta, tb, ma, d->B, d->H, N, N, d->L, (g_tn_fm & 2) != 0);
         // half 0 also forms the Nyquist partials of BOTH bases (its A origin is column 0: c0 = F - 1, c1 = KP / 2 + F - 1); half 1 has no Nyquist slice
         if (g_tn_bk == 16) ST_TRY((stg::launch_tn128<16>(fm.a, fm.b, w.xp, fm.map, R, N / 2, mh, (unsigned)(KP / 2), N, w.wg + (size_t)m0 * N, N, (size_t)KP * N, ns, st_stream(stream),
                                                           half ? nullptr : part, (unsigned)(F - 1), (unsigned)(KP / 2 + F - 1), &P, &fm.trim)));

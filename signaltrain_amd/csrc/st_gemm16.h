@@ -40,6 +40,16 @@ __device__ __forceinline__ unsigned rows16_off(const Rows16& o, const int r)
 }
 static inline Rows16 rows16(const h16_t* base, unsigned S1, unsigned S2, const RowMap& m, int R) { return Rows16{base, S1, S2, m.magic, m.Tv, m.t_lo, R}; }
 static inline Rows16 rows16_plain(const h16_t* base, unsigned ld, int R) { return Rows16{base, ld, 0u, 0u, 1, 0, R}; }
+// the rows of a [windows][frames] array enumerated FRAME-major (RowMap::fm, round 5): row r -> frame t_lo + r / B, window r % B
+static inline Rows16 rows16_frame_major(const h16_t* base, unsigned s_window, unsigned s_frame, const RowMap& live, int B, int R)
+{
+    return Rows16{base + (size_t)live.t_lo * s_frame, s_frame, s_window, B > 1 ? rowmap_magic(B) : 0u, B, 0, R};
+}
+// Round 5: the structural zeros of the cropped transposed convolution (cls_fe_dft.py:112-113; see st_gemm_tn.h) in the 16-bit synthesis GEMMs.  Rows are the live
+// frames enumerated frame-major; frames f0..f1 of a tile row keep the taps [lo, hi) = [pad - H f1, pad + Ls - H f0) n [0, N).
+//   mode 1 (frames GEMM, columns = taps): a tile whose columns hold no live tap returns at once -- nothing reads it;
+//   mode 2 (data gradient, reduction = taps): the k-slices of a tile row divide ITS live tap range (rounded to the k-tile: the extra taps are zeros of the padded d syn).
+struct Crop16 { int mode, B, H, N, pad, Ls, t_lo, R, nsplit; };
 
 template <int HT> struct frag16 { typedef st_bf16x8 type; };
 template <> struct frag16<2> { typedef st_f16x8 type; };
@@ -53,7 +63,7 @@ __device__ __forceinline__ f32x16 mfma16x(const typename frag16<HT>::type a, con
 // ------------------------------------------------------------------------------ NT x NT:  C[m][n] = sum_k A[m][k] * B[n][k]
 template <int HT, int BKH, class EPI>
 __global__ void __launch_bounds__(256)
-gemm16_nt_kernel(const Rows16 ra, const Rows16 rb, const EPI epi, const int K, const int ksplit)
+gemm16_nt_kernel(const Rows16 ra, const Rows16 rb, const EPI epi, const int K, const int ksplit, const Crop16 cr)
 {
     typedef typename frag16<HT>::type frag_t;
     constexpr int LD = BKH + 8;                          // elements per LDS row
@@ -67,8 +77,21 @@ gemm16_nt_kernel(const Rows16 ra, const Rows16 rb, const EPI epi, const int K, c
     int tbx, tby, tbz;
     if constexpr (kPolarEpi<EPI>) xcd_tile_2d(tbx, tby, tbz); else xcd_tile(tbx, tby, tbz);      // analysis forward: 2-D blocks of tiles per XCD (st_gemm.h)
     const int m_blk = tby * 128, n_blk = tbx * 128;
-    const int k_begin = tbz * ksplit;
-    const int k_end = (k_begin + ksplit < K) ? k_begin + ksplit : K;
+    int k_begin = tbz * ksplit;
+    int k_end = (k_begin + ksplit < K) ? k_begin + ksplit : K;
+    if (cr.mode) {                                        // workgroup-uniform
+        const int r1 = (m_blk + 128 < cr.R ? m_blk + 128 : cr.R) - 1;
+        const int f0 = cr.t_lo + m_blk / cr.B, f1 = cr.t_lo + r1 / cr.B;
+        int lo = cr.pad - cr.H * f1, hi = cr.pad + cr.Ls - cr.H * f0;
+        lo = lo < 0 ? 0 : lo; hi = hi > cr.N ? cr.N : hi;
+        if (cr.mode == 1) { if (n_blk + 128 <= lo || n_blk >= hi) return; }
+        else {
+            const int klo = lo / BKH * BKH, khi = (hi + BKH - 1) / BKH * BKH;
+            const int per = ((khi - klo + cr.nsplit - 1) / cr.nsplit + BKH - 1) / BKH * BKH;
+            k_begin = klo + tbz * per;
+            k_end = (k_begin + per < khi) ? k_begin + per : khi;
+        }
+    }
 
     const int lr = tid / TPR, lk = (tid % TPR) * 8;
     unsigned ao[NP], bo[NP];
@@ -286,6 +309,7 @@ struct TN16Job {
     unsigned a0, b0, zero;         // origins; >= 128 + 32 zero elements for A rows past K
     unsigned SA1, SA2, SB1, SB2;   // element (k, c): a0 + b * SA1 + t * SA2 + c  /  b0 + b * SB1 + t * SB2 + c,  (b, t) = split(k)
     unsigned magic; int Tv, t_lo, K;
+    int trim, fB, nsplit; unsigned char fa[64], fb[64];      // round 5, frame-major reduction order: tile column tx needs the rows [fa[tx] * fB, fb[tx] * fB) only (st_gemm_tn.h FrameTrim)
 };
 template <int HT, int BKH>
 __global__ void __launch_bounds__(256)
@@ -303,8 +327,14 @@ gemm16_tn_kernel(const TN16Job j, const StoreC epi, const int ksplit)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     int tbx, tby, tbz; xcd_tile(tbx, tby, tbz);
     const int m_blk = tby * 128, n_blk = tbx * 128;
-    const int k_begin = tbz * ksplit;
-    const int k_end = (k_begin + ksplit < j.K) ? k_begin + ksplit : j.K;
+    int k_begin = tbz * ksplit;
+    int k_end = (k_begin + ksplit < j.K) ? k_begin + ksplit : j.K;
+    if (j.trim) {                                         // the rows that carry anything for this tile column, divided among the k-slices
+        const int lo = (int)j.fa[tbx] * j.fB, hi = (int)j.fb[tbx] * j.fB;
+        const int per = ((hi - lo + j.nsplit - 1) / j.nsplit + BKH - 1) / BKH * BKH;
+        k_begin = lo + tbz * per;
+        k_end = (k_begin + per < hi) ? k_begin + per : hi;      // a last k-tile may run past hi: structural zeros of B for this tile column (or past K: masked)
+    }
 
     const int lk = tid >> 4, lc = (tid & 15) * 8;
     const unsigned la = 2u * (j.a0 + (unsigned)m_blk + (unsigned)lc), lb = 2u * (j.b0 + (unsigned)n_blk + (unsigned)lc), lz = 2u * (j.zero + (unsigned)lc);
@@ -387,19 +417,20 @@ gemm16_tn_kernel(const TN16Job j, const StoreC epi, const int ksplit)
 
 // ------------------------------------------------------------------------------ host side
 template <int HT, class EPI>
-static inline int launch16_nt(const Rows16& ra, const Rows16& rb, const EPI& epi, int M, int Nc, int K, int nsplit, hipStream_t s, bool allow64 = true)
+static inline int launch16_nt(const Rows16& ra, const Rows16& rb, const EPI& epi, int M, int Nc, int K, int nsplit, hipStream_t s, bool allow64 = true, const Crop16* crop = nullptr)
 {
     dim3 grid((Nc + 127) / 128, (M + 127) / 128, nsplit > 1 ? nsplit : 1);
+    Crop16 cr{}; cr.mode = 0; if (crop) cr = *crop; cr.nsplit = nsplit > 1 ? nsplit : 1;
     const bool k64 = allow64 && K % 64 == 0 && (nsplit <= 1 || (K / 64) % nsplit == 0);
     if (k64) {
         int ksplit = K; if (nsplit > 1) ksplit = st_round_up((K + nsplit - 1) / nsplit, 64);
         constexpr size_t lds = (size_t)4 * 128 * (64 + 8) * sizeof(h16_t);
         const int rc = ::ensure_dyn_lds((const void*)gemm16_nt_kernel<HT, 64, EPI>, "gemm16_nt_kernel"); if (rc) return rc;
-        hipLaunchKernelGGL((gemm16_nt_kernel<HT, 64, EPI>), grid, dim3(256), lds, s, ra, rb, epi, K, ksplit);
+        hipLaunchKernelGGL((gemm16_nt_kernel<HT, 64, EPI>), grid, dim3(256), lds, s, ra, rb, epi, K, ksplit, cr);
     } else {
         int ksplit = K; if (nsplit > 1) ksplit = st_round_up((K + nsplit - 1) / nsplit, 32);
         constexpr size_t lds = (size_t)4 * 128 * (32 + 8) * sizeof(h16_t);
-        hipLaunchKernelGGL((gemm16_nt_kernel<HT, 32, EPI>), grid, dim3(256), lds, s, ra, rb, epi, K, ksplit);
+        hipLaunchKernelGGL((gemm16_nt_kernel<HT, 32, EPI>), grid, dim3(256), lds, s, ra, rb, epi, K, ksplit, cr);
     }
     return 0;
 }
@@ -418,9 +449,10 @@ template <int HT, int BKH>
 static inline int launch16_tn(const TN16Job& j, const StoreC& epi, int M, int Nc, int nsplit, hipStream_t s)
 {
     int ksplit = j.K; if (nsplit > 1) ksplit = st_round_up((j.K + nsplit - 1) / nsplit, BKH);
+    TN16Job jj = j; jj.nsplit = nsplit > 1 ? nsplit : 1;
     constexpr size_t lds = (size_t)4 * BKH * (128 + 32) * sizeof(h16_t);
     if (lds > 65536) { const int rc = ::ensure_dyn_lds((const void*)gemm16_tn_kernel<HT, BKH>, "gemm16_tn_kernel"); if (rc) return rc; }
-    hipLaunchKernelGGL((gemm16_tn_kernel<HT, BKH>), dim3((Nc + 127) / 128, (M + 127) / 128, nsplit > 1 ? nsplit : 1), dim3(256), lds, s, j, epi, ksplit);
+    hipLaunchKernelGGL((gemm16_tn_kernel<HT, BKH>), dim3((Nc + 127) / 128, (M + 127) / 128, nsplit > 1 ? nsplit : 1), dim3(256), lds, s, jj, epi, ksplit);
     return 0;
 }
 

@@ -64,12 +64,11 @@ static inline FrameTrim frame_trim(const RowMap& live, int B, int H, int Ntaps, 
 __device__ __forceinline__ void nyq_partial(const TNJob& j, const int p)
 {
     if (p >= j.nyq_P) return;
-    const int W = j.K / j.Tv;                                   // windows
-    const int per = (W + j.nyq_P - 1) / j.nyq_P, w0 = p * per, w1 = (w0 + per < W) ? w0 + per : W;
+    // partial p = the reduction rows [k0, k1) (round 5: plain row ranges -- with the frame-major order "groups of windows" would be 7-23 long groups)
+    const int per = (j.K + j.nyq_P - 1) / j.nyq_P, k0 = p * per, k1 = (k0 + per < j.K) ? k0 + per : j.K;
     for (int n4 = threadIdx.x; n4 < j.Nc / 4; n4 += 256) {
         float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-        // rows k = w * Tv + i, eight at a time with all their loads issued before the first FMA (the order of the sum stays k-ascending)
-        const int k0 = w0 * j.Tv, k1 = w1 * j.Tv;
+        // eight rows at a time with all their loads issued before the first FMA (the order of the sum stays k-ascending)
         for (int kb = k0; kb < k1; kb += 8) {
             float a0[8], a1[8]; float4 x[8];
 #pragma unroll
@@ -249,7 +248,7 @@ static inline int launch_tn128(const TNOperand& A, const TNOperand& B, const flo
     if (lds > 65536) { const int rc = ::ensure_dyn_lds((const void*)gemm_tn128_kernel<BKT>, "gemm_tn128_kernel"); if (rc) return rc; }
     const int nz = nsplit > 1 ? nsplit : 1, tiles = (Nc / 128) * (M / 128);
     j.nsplit = nz; j.Nc = Nc; j.nyq_out = nyq_out; j.nyq_c0 = nyq_c0; j.nyq_c1 = nyq_c1;
-    j.nyq_P = tiles < 64 ? tiles : 64; { const int W = K / map.Tv; if (j.nyq_P > W) j.nyq_P = W; }
+    j.nyq_P = tiles < 64 ? tiles : 64; { const int W = K / 8 > 0 ? K / 8 : 1; if (j.nyq_P > W) j.nyq_P = W; }      // partials of >= 8 reduction rows
     if (nyq_P) *nyq_P = j.nyq_P;
     hipLaunchKernelGGL((gemm_tn128_kernel<BKT>), dim3(Nc / 128, M / 128, nz + (nyq_out ? 1 : 0)), dim3(256), lds, s, j, out, ldo, slab, ksplit);
     return 0;
@@ -323,27 +322,40 @@ struct StoreSlab {
 };
 
 // kind 1: the two columns the tiles leave out, for the 128 rows of tile row mt: out[0][row][col_c] = sum_k A[row][k] * Brow_c[k] over the entry's k range,
-// zeros in the other slabs.  Thread = (row, column): the B row is wave-uniform.
+// zeros in the other slabs.  A wave takes rows wave, wave + 4, ...; its 64 lanes read 1 KB of the row at a time (the first version gave every thread a
+// row of its own: 64 cache lines per load instruction, 27 us of address-path time -- longer than the tiles it runs beside) and reduce by lane exchange.
 __device__ __forceinline__ void nt128_nyquist(const NTRows& ra, const NTRows& rb, const StoreSlab& epi, const NTWork& wk, const int m_blk, const int k_begin, const int k_end)
 {
-    const int row = m_blk + (threadIdx.x & 127), cc = threadIdx.x >> 7;
-    const float* a = ra.base + ntrows_off(ra, row);
-    const float* b = rb.base + wk.nyq_b[cc];
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (int k = k_begin; k < k_end; k += 32) {
-        f32x4 va[8], vb[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* b0 = rb.base + wk.nyq_b[0];
+    const float* b1 = rb.base + wk.nyq_b[1];
+    for (int r0 = wave; r0 < 128; r0 += 16) {               // four rows in flight per wave
+        float s0[4], s1[4];
+        const float* a[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { va[u] = *reinterpret_cast<const f32x4*>(a + k + 4 * u); vb[u] = *reinterpret_cast<const f32x4*>(b + k + 4 * u); }
+        for (int u = 0; u < 4; ++u) { s0[u] = 0.f; s1[u] = 0.f; a[u] = ra.base + ntrows_off(ra, m_blk + r0 + 4 * u); }
+        for (int k = k_begin + 4 * lane; k < k_end; k += 256) {
+            const f32x4 vb0 = *reinterpret_cast<const f32x4*>(b0 + k), vb1 = *reinterpret_cast<const f32x4*>(b1 + k);
+            f32x4 va[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            s0 = __builtin_fmaf(va[u][0], vb[u][0], s0); s1 = __builtin_fmaf(va[u][1], vb[u][1], s1);
-            s2 = __builtin_fmaf(va[u][2], vb[u][2], s2); s3 = __builtin_fmaf(va[u][3], vb[u][3], s3);
+            for (int u = 0; u < 4; ++u) va[u] = *reinterpret_cast<const f32x4*>(a[u] + k);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s0[u] += (va[u][0] * vb0[0] + va[u][1] * vb0[1]) + (va[u][2] * vb0[2] + va[u][3] * vb0[3]);
+                s1[u] += (va[u][0] * vb1[0] + va[u][1] * vb1[1]) + (va[u][2] * vb1[2] + va[u][3] * vb1[3]);
+            }
         }
-    }
-    if (row < epi.M) {
-        float* o = epi.out + (size_t)epi.map.full(row) * epi.ld + wk.nyq_col[cc];
-        o[0] = (s0 + s1) + (s2 + s3);
-        for (int z = 1; z < wk.nslabs; ++z) o[(size_t)z * epi.slab] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { s0[u] += __shfl_xor(s0[u], m); s1[u] += __shfl_xor(s1[u], m); }
+            const int row = m_blk + r0 + 4 * u;
+            if (lane < 2 && row < epi.M) {
+                float* o = epi.out + (size_t)epi.map.full(row) * epi.ld + wk.nyq_col[lane];
+                o[0] = lane ? s1[u] : s0[u];
+                for (int z = 1; z < wk.nslabs; ++z) o[(size_t)z * epi.slab] = 0.f;
+            }
+        }
     }
 }
 

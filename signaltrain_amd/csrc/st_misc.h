@@ -713,10 +713,13 @@ __global__ void step_tick_kernel(float* __restrict__ scalars, const float* __res
 // copy of the gain curve, in chunks of CH samples so any window length fits.  State is rounded to float32 every step
 // exactly like the reference's float32 lin_A array; the step arithmetic is float64 (numpy float64 scalars alphaA/R).
 // y receives the LAST ysz samples of each processed window (the training target, datasets.py:327-330).
-// the static gain curve of one sample (audio.py:392-399), shared by the compressor kernels and the feed generator.  float32 arithmetic in the
-// reference's order: x_dB and gainChange_dB are float32 arrays there and the threshold / ratio weak Python scalars, so numpy evaluates
-// 20 * log10(|x| + 1e-8), the clip at -96 and thresh + (x_dB - thresh) / ratio - x_dB in float32 (golden G9 was captured that way).  Round 3 evaluated this
-// in float64 -- a software log10 of ~200 instructions per sample: it was most of the feed generator's 2.2 ms per 2048 windows at the 65536-sample window.
+// the static gain curve of one sample (audio.py:392-399), shared by the compressor kernels and the feed generator.  float32 arithmetic, which is what the
+// reference's lines give under NUMPY's promotion rules (x_dB / gainChange_dB float32 arrays, threshold / ratio weak Python scalars: 20 * log10(|x| + 1e-8),
+// the clip at -96 and thresh + (x_dB - thresh) / ratio - x_dB all stay float32) -- the way golden G9 was captured, with numba's @jit stubbed to the identity
+// (tools/_ref_import.py; numba is not in this image).  Under the real @jit(nopython=True) a float32 array plus the float64 literal 1e-8 promotes to float64,
+// so x_dB, the threshold compare and gainChange are float64 until the store into the float32 array: the two differ by ~1e-7 relative (one float32 rounding of
+// x_dB), far below anything a training TARGET needs, and which of them "the reference" is depends on whether numba is installed.  Round 3
+// evaluated this in float64 -- a software log10 of ~200 instructions per sample: most of the feed generator's 2.2 ms per 2048 windows at the 65536-sample window.
 __device__ __forceinline__ float comp_gain_curve(const float xv, const double thresh, const double ratio)
 {
     const float th = (float)thresh, ra = (float)ratio;

@@ -13,7 +13,9 @@ Two back ends:
         + autoencoders] (8.45 MB) || phase 2 (analysis weight gradient) -> all-reduce the packed live analysis rows (4.2 MB,
         the only exposed one) -> clip + Adam.  No Python between the buckets.  torch.distributed (any backend, gloo is enough) is
         used only as the bootstrap channel for the 128-byte RCCL unique id.  schedule="staged" splits that last exchange by basis (the real
-        rows' all-reduce under the GEMM of the imaginary rows: 2.1 MB exposed); pack16=True moves it as bfloat16 in the *_all arithmetic modes.
+        rows' all-reduce under the GEMM of the imaginary rows: 2.1 MB exposed); pack16=True moves it as bfloat16 in the *_all arithmetic modes -- OPT-IN and lossy beyond the mode's own rounding: RCCL reduces in the payload type, so a ring over W ranks
+        rounds the partial sum W - 1 times (relative error of the analysis-basis gradient and of the clip norm derived from it ~ 2^-9 sqrt(W - 1): ~1e-2 at W = 8, 2-3
+        significant digits).  The two-rank tests model that per-hop rounding (tests/fake_rccl.cpp); check convergence on the real node before relying on it.
   backend="torch"                   the same protocol driven from Python over torch.distributed collectives (backend "nccl" ==
         RCCL, or "gloo" on CPU for the tests), with two schedules: "two_bucket" (as above) and "staged" (four stages / four
         ranges, only the last 2.1 MB exposed; measured +55..85 us of fixed cost on one GPU).

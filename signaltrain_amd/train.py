@@ -162,7 +162,7 @@ def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=N
           in_checkpointname='modelcheckpoint.tar', compand=False, num_workers=10, device_feed=True, compute_dtype=None,
           resume_optimizer=False):
     """train.py:167-278.  datapath: directory with Train/ and Val/ wav pairs (datasets.AudioFileDataSet, the reference's
-    file feed, e.g. the LA2A set of BASELINE configs[3]; pass effect=audio.FileEffect(datapath)); compand is refused by that dataset.
+    file feed, e.g. the LA2A set of BASELINE configs[3]; pass effect=audio.FileEffect(datapath)); compand: mu-law compand that dataset's audio (datasets.py:218-220).
     apex_opt: "O0" = fp32 (the parity path); "O1" / "O2" / "O3" = the reference's Apex mixed precision (train.py:254-255),
     here float16 operands with fp32 accumulation, a loss scale and the L1 clip over all parameters (train.py:133-136) --
     compute_dtype "f16_all".  Extra keywords (not in the reference): compute_dtype overrides the arithmetic ("f32", "bf16",
@@ -206,6 +206,7 @@ def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=N
             class _FileLoader:
                 def __init__(self_inner, ds): self_inner.ds = ds
                 def __iter__(self_inner): return self_inner.ds.device_batches(batch_size, device)
+                def __len__(self_inner): return len(self_inner.ds) // batch_size      # minibatches per epoch (device_batches drops the remainder, like drop_last=True)
             dataloader, dataloader_val = _FileLoader(dataset), _FileLoader(dataset_val)
         else:
             dataloader = DataLoader(dataset, batch_size=batch_size, num_workers=num_workers, shuffle=True, worker_init_fn=datasets.worker_init, drop_last=True)
@@ -239,6 +240,9 @@ def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=N
         class _ValLoader:
             def __iter__(self_inner):
                 return val_ds.batches(batch_size, shuffle=False)
+
+            def __len__(self_inner):
+                return (n_data_points // 4) // batch_size
         dataloader_val = _ValLoader()
         print(f"device-side data feed ready in {time.time() - t0:.1f} s ({n_data_points // 4} validation windows resident in HBM)")
     if state_dict != {} and resume_optimizer and rv.get('optimizer'):

@@ -81,15 +81,24 @@ __global__ void fake_sum_kernel(const float* __restrict__ mine, const float* __r
     }
 }
 
-// bfloat16 payloads (the packed last exchange of the 16-bit configurations): summed in fp32 in rank order, rounded to nearest even once
+// bfloat16 payloads (the packed last exchange of the 16-bit configurations): summed the way a RING reduction sums them -- every hop adds two bfloat16
+// values and forwards the bfloat16-ROUNDED partial sum (RCCL's reduce-scatter moves the payload type), so the result carries world - 1 roundings, not one
+// (a single final rounding is strictly more accurate than the real collective and would not bound its error).  Rank order.
+__device__ __forceinline__ unsigned short fake_bf16_rne(float s)
+{
+    unsigned u = __float_as_uint(s);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
 __global__ void fake_sum_bf16_kernel(const unsigned short* __restrict__ mine, const unsigned short* __restrict__ others, unsigned short* __restrict__ out, size_t n, int rank, int world)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int r = 0; r < world; ++r) s += __uint_as_float((unsigned)((r == rank) ? mine[i] : others[(size_t)r * n + i]) << 16);
-        unsigned u = __float_as_uint(s);
-        u += 0x7fffu + ((u >> 16) & 1u);
-        out[i] = (unsigned short)(u >> 16);
+        unsigned short acc = (0 == rank) ? mine[i] : others[i];
+        for (int r = 1; r < world; ++r) {
+            const unsigned short v = (r == rank) ? mine[i] : others[(size_t)r * n + i];
+            acc = fake_bf16_rne(__uint_as_float((unsigned)acc << 16) + __uint_as_float((unsigned)v << 16));
+        }
+        out[i] = acc;
     }
 }
 

@@ -99,9 +99,13 @@ class mixed_mode:
     FUSED_TOL = {1: 30.0, 2: 200.0}          # tol_scale for run_fused under the two levels (3e-3 / 2e-2), bf16
     FUSED_TOL_F16 = {1: 10.0, 2: 40.0}       # fp16: 8x finer rounding
 
-    def __init__(self, level=1, tol_scale=None, half="bf16", loss_scale=None, clip_all=None):
+    def __init__(self, level=1, tol_scale=None, half="bf16", loss_scale=None, clip_all=None, oracle_rounds=True):
         assert half in ("bf16", "f16") and level in (1, 2)
         self.level, self.half = level, half
+        # oracle_rounds = False: the device runs the 16-bit mode against the UNROUNDED fp32-grade oracle (same loss scale / clip scope: those are the
+        # reference's Apex semantics, train.py:133-136, not roundings) -- the loose check SURVEY.md section 5 prescribes for the modes that have no
+        # runnable reference here; tolerances then are the stated per-class bounds of tests/test_gpu_parity.py::test_16bit_modes_against_the_unrounded_oracle
+        self.oracle_rounds = bool(oracle_rounds)
         self.tol_scale = tol_scale          # override, e.g. the 65536-sample geometry at level 2 (174-frame rows: more flips per sum)
         self.loss_scale = (4096.0 if half == "f16" else 0.0) if loss_scale is None else float(loss_scale)
         self.clip_all = (half == "f16") if clip_all is None else bool(clip_all)
@@ -111,8 +115,8 @@ class mixed_mode:
         rnd = O.bf16_round if self.half == "bf16" else O.fp16_round
         PREC_LEVEL = {("bf16", 1): 1, ("bf16", 2): 2, ("f16", 1): 3, ("f16", 2): 4}[(self.half, self.level)]
         LOSS_SCALE, CLIP_ALL = self.loss_scale, self.clip_all
-        O.GEMM_ROUND = rnd
-        O.AE_ROUND = rnd if self.level >= 2 else None
+        O.GEMM_ROUND = rnd if self.oracle_rounds else None
+        O.AE_ROUND = rnd if (self.level >= 2 and self.oracle_rounds) else None
         O.LOSS_SCALE = self.loss_scale if self.loss_scale > 0 else 1.0
         O.CLIP_ALL = self.clip_all
         base = (10.0 if self.level == 1 else 20.0) if self.half == "bf16" else (3.0 if self.level == 1 else 10.0)
@@ -318,23 +322,25 @@ def _run_all(lib, geo, X, Y, KN, P, d, B, K, verbose):
     return res
 
 
-def run_fused(B=3, seed=1, K=4, steps=3, scale=1, scheme="lean", shrink=4):
-    """Fused entry points: st_model_fwd, st_loss_backward, st_train_step x steps vs the oracle."""
+def run_fused(B=3, seed=1, K=4, steps=3, scale=1, scheme="lean", shrink=4, oracle_dtype="f64"):
+    """Fused entry points: st_model_fwd, st_loss_backward, st_train_step x steps vs the oracle (float64 from the same fp32 inputs; oracle_dtype="f32":
+    the oracle's forward / backward in float32 arithmetic instead -- the reference's own precision, tools/fuzz_ground_f32.py)."""
     geo, X, Y, KN, P = make_case(B, seed, K=K, scale=scale, scheme=scheme, shrink=shrink)
     d = dims_of(geo, B, K)
     restore_oracle = follow_effective_arithmetic(d)
     try:
-        return _run_fused(geo, X, Y, KN, P, d, B, K, steps)
+        return _run_fused(geo, X, Y, KN, P, d, B, K, steps, oracle_dtype)
     finally:
         restore_oracle()
 
 
-def _run_fused(geo, X, Y, KN, P, d, B, K, steps):
+def _run_fused(geo, X, Y, KN, P, d, B, K, steps, oracle_dtype="f64"):
     eng = new_engine(d)
     eng.load_state_dict(P)
     res = []
-    P64 = {k: v.astype(np.float64) for k, v in P.items()}
-    loss, G, c = O.model_loss_bwd(X.astype(np.float64), KN.astype(np.float64), Y.astype(np.float64), P64, geo)
+    odt = np.float64 if oracle_dtype == "f64" else np.float32
+    P64 = {k: v.astype(odt) for k, v in P.items()}
+    loss, G, c = O.model_loss_bwd(X.astype(odt), KN.astype(odt), Y.astype(odt), P64, geo)
     y_hat, mag, mag_hat = eng.forward(t(X), t(KN))
     res += [err("fwd.y_hat", n(y_hat), c["out"]), err("fwd.mag", n(mag), c["mag"]), err("fwd.mag_hat", n(mag_hat), c["mag_hat"])]
     outs = eng.loss_backward(t(X), t(KN), t(Y), want_outputs=True)

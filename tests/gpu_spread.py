@@ -52,3 +52,52 @@ def oracle_spread(B, seed, K=4, scale=1, scheme="lean", shrink=4, npert=8, steps
         for k, v in diff(l1, G1).items():
             out["noise"][k] = max(out["noise"].get(k, 0.0), v)
     return out
+
+
+# ----------------------------------------------------------------------------- grading a run against the spread
+import json, os
+CACHE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_fuzz_f32_spread.json")
+
+
+def case_tag(kw):
+    return f"f32 B={kw['B']} K={kw.get('K', 4)} scale={kw.get('scale', 1)} {kw.get('scheme', 'lean')} shrink={kw.get('shrink', 4)} seed={kw['seed']}"
+
+
+def spread_of(kw, npert=8, cache=CACHE):
+    """oracle_spread(**kw), through the committed cache (fp32 arithmetic modes only: the rounding switches of the oracle are not part of the key)."""
+    plain = O.GEMM_ROUND is None and O.AE_ROUND is None and O.LOSS_SCALE == 1.0 and not O.CLIP_ALL
+    tab = json.load(open(cache)) if (plain and os.path.isfile(cache)) else {}
+    tg = case_tag(kw)
+    if tg in tab:
+        return tab[tg]
+    sp = oracle_spread(npert=npert, **{k: kw[k] for k in ("B", "seed", "K", "scale", "scheme", "shrink") if k in kw})
+    if plain:
+        tab[tg] = sp
+        try:
+            json.dump(tab, open(cache, "w"), indent=1, sort_keys=True)
+        except OSError:
+            pass
+    return sp
+
+
+def grounded(res, kw, mult=3.0, npert=8):
+    """Re-grade the misses of gpu_checks.run_fused(**kw): a check that missed its fixed tolerance passes iff the device's error is within `mult` x the
+    spread of that quantity for THIS configuration (max of f32-vs-f64 and self-noise).  Applies to every tensor the spread covers (all 40 gradient
+    tensors, the loss, the parameters after the first step) -- no tensor is exempt by name, and checks the spread does not cover stay failures.
+    Returns the list of checks that remain failed; every re-graded check carries 'spread' and 'ratio'."""
+    bad = [r for r in res if not r["ok"]]
+    if not bad:
+        return []
+    sp = spread_of(kw, npert=npert)
+    still = []
+    for r in bad:
+        key = "train0.params" if r["name"].startswith("train0.params") else r["name"]
+        if key not in sp["f32"]:
+            still.append(r); continue
+        s = max(sp["f32"][key], sp["noise"].get(key, 0.0))
+        r["spread"] = s; r["ratio"] = r["rel"] / s if s > 0 else float("inf")
+        if r["rel"] <= mult * s:
+            r["ok"] = True; r["grounded"] = True
+        else:
+            still.append(r)
+    return still

@@ -394,3 +394,42 @@ def test_g12_knob_gradient(golden_dir):
     close(c["d_knobs"], g["d_knobs"], 2e-5, "d knobs (float64 oracle)")
     _, _, c32 = O.model_loss_bwd(g3["x"], g3["knobs"], g3["y"], P, geo)
     close(c32["d_knobs"], g["d_knobs"], 2e-4, "d knobs (float32 oracle)")
+
+
+@pytest.mark.parametrize("ci", [0, 1])
+def test_g13_near_silent_backward(golden_dir, ci):
+    """G13 (tools/capture_golden_r5.py): two window sets with near-silent STFT bins through the REFERENCE's fp32 autograd.  The reference's own analysis-basis
+    gradient sits 4e-4 ... 1.1e-3 of the tensor maximum away from the float64 evaluation of the same formulas (stored as ref_vs_f64): d atan2(im, re + 1e-7)
+    (nn_proc.py:309-310) amplifies the fp32 rounding of re / im by 1 / mag.  Pinned here: (i) that distance really exceeds the suite's fixed 2e-4 -- so a
+    fixed tolerance on these two tensors cannot be met by ANY fp32 implementation, the reference included, and tests/gpu_spread.py's per-configuration spread
+    is the honest bound; (ii) the oracle in float64 and in float32 both agree with the reference within 3 x that distance on the analysis bases and at fp32
+    rounding level (2e-5) on the synthesis bases; (iii) loss and the autoencoder gradients' maxima at 1e-4."""
+    from tests import gpu_checks as G                       # make_case only (numpy)
+    g = np.load(os.path.join(golden_dir, "g13_near_silent_backward.npz"))
+    pre = f"c{ci}_"
+    B, seed, K = (int(v) for v in g[pre + "cfg"])
+    geo, X, Y, KN, P = G.make_case(B, seed, K=K)
+    l64, g64, _ = O.model_loss_bwd(X.astype(np.float64), KN.astype(np.float64), Y.astype(np.float64), {k: v.astype(np.float64) for k, v in P.items()}, geo)
+    l32, g32, _ = O.model_loss_bwd(X, KN, Y, P, geo)
+    assert abs(l64 - float(g[pre + "loss"])) <= 3e-5 * abs(l64) and abs(float(l32) - float(g[pre + "loss"])) <= 3e-5 * abs(l64)
+    PROJ = projections(seed=17)
+    worst_an = 0.0
+    for k in STFT_KEYS:
+        d_ref = float(g[pre + "ref_vs_f64_" + k])
+        an = "analysis" in k
+        worst_an = max(worst_an, d_ref if an else 0.0)
+        if not an:
+            assert d_ref < 2e-5
+        for name, og in (("f64", g64[k]), ("f32", g32[k].astype(np.float64))):
+            m = og[:, 0, :]
+            sc = float(g[pre + "max_" + k])
+            tol = (3.0 * d_ref if an else 2e-5) * sc
+            assert np.abs(m[SAMPLE_ROWS] - g[pre + "rows_" + k]).max() <= tol, (k, name)
+            # a projection sums 1024 elements with |weights| <= 1: its error is bounded by 1024 x the element bound (and is far below it)
+            assert np.abs(PROJ @ m - g[pre + "proj_" + k]).max() <= 1024 * tol, (k, name)
+            assert abs(np.abs(m).sum() - float(g[pre + "l1_" + k])) <= (1e-3 if an else 1e-4) * float(g[pre + "l1_" + k]), (k, name)
+    assert worst_an > 2e-4                                  # (i)
+    for k in ae_keys():
+        if (pre + "max_" + k) in g:
+            ref = float(g[pre + "max_" + k])
+            assert abs(np.abs(g64[k]).max() - ref) <= 1e-4 * max(ref, 1e-30), k

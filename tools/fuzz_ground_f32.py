@@ -59,12 +59,11 @@ def tag(mode, kw):
 def main():
     gpu = len(sys.argv) > 1 and sys.argv[1] == "gpu"
     from tests import gpu_spread as S
-    spread = json.load(open(CACHE)) if os.path.isfile(CACHE) else {}
+    spread = {}
     for mode, kw in CASES:
         tg = tag("f32", kw)                # the spread is a property of the configuration, not of the device mode (f32x3 is checked against the fp32 oracle too)
-        if tg not in spread:
-            spread[tg] = S.oracle_spread(npert=NPERT, **kw)
-            json.dump(spread, open(CACHE, "w"), indent=1, sort_keys=True)
+        assert tg == S.case_tag(kw)
+        spread[tg] = S.spread_of(kw, npert=NPERT)      # through the committed cache (profiles/r05_fuzz_f32_spread.json)
         s = spread[tg]
         print(f"[spread] {tg}: " + ", ".join(f"{k.replace('grad.dft_analysis.conv_analysis_', 'g.an_').replace('.weight', '')} f32-vs-f64 {s['f32'].get(k, 0):.1e} / self-noise {s['noise'].get(k, 0):.1e}" for k in AN), flush=True)
     if not gpu:
@@ -74,9 +73,8 @@ def main():
     nsus = 0
     for mode, kw in CASES:
         s = spread[tag("f32", kw)]
-        ctx = G.split_mode() if mode == "f32x3" else G.mixed_mode.__new__(G.mixed_mode)
         if mode == "f32x3":
-            with ctx:
+            with G.split_mode():
                 res, res32 = G.run_fused(steps=1, **kw), G.run_fused(steps=1, oracle_dtype="f32", **kw)
         else:
             res, res32 = G.run_fused(steps=1, **kw), G.run_fused(steps=1, oracle_dtype="f32", **kw)

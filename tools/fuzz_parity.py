@@ -1,8 +1,8 @@
 """Randomized parity sweep (GPU): random geometry / batch / knob count / precision through tests.gpu_checks.run_fused
 for a fixed wall-clock budget.  Not part of the pytest suite (its coverage is fixed cases); run ad hoc:
     gpurun -- 'timeout 600 python tools/fuzz_parity.py'
-"soft" lines are analysis-basis gradient outliers (atan2 conditioning at near-zero bins, judged separately by the
-weighted checks in the suite).  In bf16 mode with B = 1 a single operand landing on the other side of a bf16 rounding
+"soft" lines (round 5): checks that missed their fixed tolerance but sit within 3 x the measured spread of that quantity for that configuration
+(tests/gpu_spread.py; until round 4 such lines were filtered by tensor name -- "conv_analysis" -- without evidence).  In bf16 mode with B = 1 a single operand landing on the other side of a bf16 rounding
 boundary is 0.4 % of one of only OT = 9 summands, so an occasional 2-4e-3 max-relative outlier there is rounding, not a bug.
 Round-1 result: 260 configurations in 150 s, 0 hard failures in fp32, 1 such bf16 B=1 outlier.
 With the bf16 levels drawn at random (1 = STFT GEMMs, 2 = also the autoencoder layers; fused tolerances 3e-3 / 2e-2 = the
@@ -40,11 +40,19 @@ while time.time() - t0 < float(sys.argv[1] if len(sys.argv) > 1 else 150):
             with G.bf16_mode(bf, tol_scale=G.bf16_mode.FUSED_TOL[bf]): res = G.run_fused(**kw)
         else:
             res = G.run_fused(**kw)
-        bad = [r for r in res if not r["ok"] and "conv_analysis" not in r["name"]]      # analysis-gradient outliers = atan2 conditioning, checked separately
-        soft = [r for r in res if not r["ok"] and "conv_analysis" in r["name"]]
+        miss = [r for r in res if not r["ok"]]
+        # round 5: no tensor is exempt by name.  A miss of the fixed tolerance in the fp32-grade modes is graded on the spot against the spread of that quantity for this
+        # configuration (tests/gpu_spread.py: float32-vs-float64 oracle, float64 oracle under 1e-6 perturbations -- CPU work, ~10-60 s, cached in profiles/); in the 16-bit modes the
+        # fused tolerances already ARE the measured noise floors, a miss there is a hard line (tools/fuzz_ground.py grounds those)
+        bad, soft = miss, []
+        if miss and bf in (0, 3):
+            from tests import gpu_spread as S
+            bad = S.grounded(res, kw)
+            soft = [r for r in miss if r.get("grounded")]
     except Exception as e:
         bad = [dict(name="EXC " + str(e)[:160], rel=0)]; soft = []
     n += 1; nbad += bool(bad)
     if bad or soft:
-        print(("BAD " if bad else "soft"), kw, ("f32", "bf16", "bf16_all", "f32x3", "f16_all")[bf], [(r['name'], f"{r['rel']:.1e}") for r in (bad + soft)[:4]], flush=True)
+        print(("BAD " if bad else "soft"), kw, ("f32", "bf16", "bf16_all", "f32x3", "f16_all")[bf],
+              [(r['name'], f"{r['rel']:.1e}") + ((f"{r['ratio']:.2f} x spread",) if "ratio" in r else ()) for r in (bad + soft)[:4]], flush=True)
 print(f"{n} random configurations, {nbad} with hard failures, {time.time()-t0:.0f} s")

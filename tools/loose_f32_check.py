@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""The 16-bit arithmetic modes against the UNROUNDED oracle (missing #3 / weak #2).
+
+Every other 16-bit check in the suite compares the device with an oracle that rounds the same operands (gpu_checks.mixed_mode): that shows the
+kernels compute what the rounding oracle computes, not that the rounding oracle is an acceptable training step.  Here the device runs bf16 / bf16_all /
+f16 / f16_all and the oracle runs plain float64 from the same fp32 inputs (the reference's fp32 model, pinned by the goldens); the numbers are the modes'
+own accuracy, per tensor class:
+
+    forward      y_hat, |STFT|, mag_hat            (max error / max|reference|)
+    loss         the training loss                 (relative)
+    stft grads   the four basis gradients          (max error / max over the pair)
+    ae grads     the 36 autoencoder gradients      (max error / max|reference| per tensor; the worst tensor)
+    params       parameters after one / two steps  (max absolute difference; Adam's first step is lr * sign(g): lr = 6.7e-5)
+
+    gpurun -- python tools/loose_f32_check.py        # table -> profiles/r05_16bit_vs_unrounded_oracle.txt
+The bounds asserted in tests/test_gpu_parity.py::test_16bit_modes_against_the_unrounded_oracle are ~2-3 x the worst line of this table.
+"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests import gpu_checks as G
+
+CASES = [dict(B=3, seed=1, K=4), dict(B=8, seed=21, K=4), dict(B=13, seed=7, K=3), dict(B=2, seed=5, K=4, scale=8), dict(B=4, seed=9, K=4, shrink=2)]
+MODES = [("bf16", 1, "bf16"), ("bf16_all", 2, "bf16"), ("f16", 1, "f16"), ("f16_all", 2, "f16")]
+
+
+def classes(res):
+    out = {}
+    for r in res:
+        n = r["name"]
+        if n.startswith(("fwd.", "step.y_hat")): c = "forward"
+        elif n in ("step.loss",) or n.endswith(".loss"): c = "loss"
+        elif n.startswith("grad.dft_"): c = "stft grads"
+        elif n.startswith("grad."): c = "ae grads"
+        elif ".params" in n: c = "params"
+        elif n == "step.l1norm": c = "l1norm"
+        else: c = "other"
+        if r["rel"] > out.get(c, (0, ""))[0]:
+            out[c] = (r["rel"], n)
+    return out
+
+
+def main():
+    print("mode | case | " + " | ".join(("forward", "loss", "stft grads", "ae grads", "l1norm", "params")))
+    worst = {}
+    for name, level, half in MODES:
+        for kw in CASES:
+            with G.mixed_mode(level, half=half, tol_scale=1e12, oracle_rounds=False):
+                res = G.run_fused(steps=2, **kw)
+            c = classes(res)
+            print(f"{name} | {kw} | " + " | ".join(f"{c.get(k, (0, ''))[0]:.2e}" for k in ("forward", "loss", "stft grads", "ae grads", "l1norm", "params")), flush=True)
+            for k, v in c.items():
+                if v[0] > worst.get((name, k), (0, ""))[0]:
+                    worst[(name, k)] = (v[0], v[1], kw)
+    print("\nworst per mode and class:")
+    for (m, k), v in sorted(worst.items()):
+        print(f"  {m:9s} {k:11s} {v[0]:.2e}  ({v[1]}, {v[2]})")
+
+
+if __name__ == "__main__":
+    main()

@@ -41,6 +41,15 @@ for sub, cname in (("pmc3", "FETCH_SIZE"), ("pmc4", "WRITE_SIZE")):
                 k = r["Kernel_Name"].split("(")[0]; acc[k] += float(r["Counter_Value"]); cnt[k] += 1
         for k in acc:
             traffic[k][cname + "_KB"] = acc[k] / cnt[k]
+# round 5: the matrix-pipe / busy counters of the first PMC pass ride along (per-dispatch averages), so that bench.py can quote MFMA-busy for its roofline kernel
+for f in sorted(glob.glob(os.path.join(root, "pmc1", "**", "*counter_collection.csv"), recursive=True)):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_INSTS_MFMA", "SQ_INSTS_VALU"):
+            k = r["Kernel_Name"].split("(")[0]; acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+    for k in acc:
+        for c, v in acc[k].items():
+            traffic[k][c] = v / cnt[(k, c)]
 # rocprofv3's own average duration per kernel (kernel-trace stats of the same command): bench.py's roofline prefers it over its in-process HIP-event
 # timing (which reads 2-3 us high per launch) when the file matches the sources it runs
 for f in sorted(glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True)):
