@@ -743,10 +743,13 @@ extern "C" int st_synthesis_wgrad(const st_dims* d, const float* AA, const float
 
 
 // ------------------------------------------------------------------------------ wide-geometry autoencoders (st_ae_wide.h)
-// BM = 64, k-tile 16 (every K below is a multiple of 16 or checked).  Level-2 precision: the bf16 kernel (k-tile 32: W1 is
-// padded to a multiple of 32 columns and K = R operands need R % 32 == 0, else the whole wide path stays fp32 -- wide_ht,
-// a local of every user of ST_WGEMM: 0 fp32 / 1 bf16 / 2 fp16)
-static inline int wide_half_type(const st_dims* d, int R) { return R % 32 == 0 ? ae_ht(d->prec) : 0; }
+// BM = 64, k-tile 16 (every K below is a multiple of 16 or checked).  Level-2 precision: the 16-bit kernel (k-tile 32: W1 is padded to a multiple of 32
+// columns).  The weight-gradient GEMMs reduce over the R = B * 528 columns: a multiple of 32 for even batches; for ODD batches (R = 16 mod 32) they run
+// the same kernel on 16-deep k-tiles (round 5) -- until round 4 an odd batch dropped the whole wide path to fp32 layers (and said so: st_effective_prec),
+// the last place where the arithmetic of a call depended on its batch size.  wide_ht, a local of every user of ST_WGEMM: 0 fp32 / 1 bf16 / 2 fp16.
+static inline int wide_half_type(const st_dims* d, int R) { (void)R; return ae_ht(d->prec); }
+// The arithmetic a call REALLY runs.  Since round 5 that is the request for every geometry and batch; the entry stays so that callers (and the tests) can
+// keep asserting it instead of assuming it.
 extern "C" int st_effective_prec(const st_dims* d)
 {
     if (!d) return -1;
@@ -842,6 +845,10 @@ static void wide_wgrad(const st_dims* d, WideWS& w, int a, int l, const int* out
     stg::PlainNT al{w.DA[a][l], out[l], R, R, id};
     stg::PlainNT bl{Hin, in[l] + 1, R, R, id};
     stg::StoreC ep{w.slabs + (size_t)a * w.nsplit * w.SL + w.so[l], out[l], in[l] + 1, in[l] + 1, w.SL, id};
+    if (wide_ht && R % 32) {      // odd batch: the reduction length is 16 mod 32 -> 16-deep k-tiles of the same kernel
+        if (wide_ht == 1) stg::launch_half<2, 1, 1, 16>(al, bl, ep, out[l], in[l] + 1, R, w.nsplit, s); else stg::launch_half<2, 2, 1, 16>(al, bl, ep, out[l], in[l] + 1, R, w.nsplit, s);
+        return;
+    }
     ST_WGEMM(al, bl, ep, out[l], in[l] + 1, R, w.nsplit, s);
 }
 
@@ -855,6 +862,14 @@ static void wide_wgrad_pair(const st_dims* d, WideWS& w, int l, const int* out, 
     stg::StoreC ep0{w.slabs + w.so[l], out[l], in[l] + 1, in[l] + 1, w.SL, id};
     stg::StoreC ep1 = ep0;
     if (!(g_wide_pair && wide_ht)) ep1.out = w.slabs + (size_t)w.nsplit * w.SL + w.so[l];      // two launches: each with its own z = 0 .. nsplit - 1
+    if (wide_ht && R % 32) {      // odd batch: 16-deep k-tiles (see wide_wgrad)
+        if (g_wide_pair) {
+            if (wide_ht == 1) stg::launch_half_pair<2, 1, 1, 16>(al0, bl0, ep0, al1, bl1, ep1, out[l], in[l] + 1, R, w.nsplit, s);
+            else stg::launch_half_pair<2, 2, 1, 16>(al0, bl0, ep0, al1, bl1, ep1, out[l], in[l] + 1, R, w.nsplit, s);
+        } else if (wide_ht == 1) { stg::launch_half<2, 1, 1, 16>(al0, bl0, ep0, out[l], in[l] + 1, R, w.nsplit, s); stg::launch_half<2, 1, 1, 16>(al1, bl1, ep1, out[l], in[l] + 1, R, w.nsplit, s); }
+        else { stg::launch_half<2, 2, 1, 16>(al0, bl0, ep0, out[l], in[l] + 1, R, w.nsplit, s); stg::launch_half<2, 2, 1, 16>(al1, bl1, ep1, out[l], in[l] + 1, R, w.nsplit, s); }
+        return;
+    }
     ST_WGEMM_PAIR(al0, bl0, ep0, al1, bl1, ep1, out[l], in[l] + 1, R, w.nsplit, s);
 }
 

@@ -246,18 +246,17 @@ def test_tuning_defaults_are_frozen():
 
 
 def test_effective_precision_is_reported():
-    """st_effective_prec: the 16-bit autoencoder level needs an even batch on the wide path (65536-sample window); with an odd batch the layers stay
-    fp32 and the library says so instead of switching arithmetic silently."""
+    """st_effective_prec = the arithmetic a call really runs.  Until round 4 the wide autoencoder path (T > 32 or OT > 16: the 65536-sample window, lean
+    scale 2, shrink 1) needed an EVEN batch for 16-bit Linear layers and ran fp32 layers for odd ones -- reported, but a cliff.  Round 5: its weight-gradient
+    GEMMs take 16-deep k-tiles when B * 528 is 16 mod 32, so the effective arithmetic equals the request for every geometry and every batch."""
     lib = _lib.load()
     d = _lib.st_dims()
-    assert lib.st_geometry(8.0, 4.0, 0, 4, 64, C.byref(d)) == 0
-    for prec, odd in ((2, 1), (4, 3)):
-        d.prec = prec
-        d.B = 64; assert lib.st_effective_prec(C.byref(d)) == prec
-        d.B = 63; assert lib.st_effective_prec(C.byref(d)) == odd
-    d.prec = 0; assert lib.st_effective_prec(C.byref(d)) == 0
-    assert lib.st_geometry(1.0, 4.0, 0, 4, 3, C.byref(d)) == 0          # fused geometry: any batch
-    d.prec = 2; assert lib.st_effective_prec(C.byref(d)) == 2
+    for scale, shrink in ((8.0, 4.0), (2.0, 4.0), (1.0, 1.0), (1.0, 4.0)):
+        for B in (1, 3, 9, 63, 64):
+            assert lib.st_geometry(scale, shrink, 0, 4, B, C.byref(d)) == 0
+            for prec in (0, 1, 2, 3, 4, 5):
+                d.prec = prec
+                assert lib.st_effective_prec(C.byref(d)) == prec, (scale, shrink, B, prec)
 
 
 @pytest.mark.parametrize("B,shrink", [(256, 4), (128, 4), (192, 4), (64, 4), (3, 4), (1, 4), (256, 8), (100, 2)])

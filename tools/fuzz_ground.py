@@ -96,7 +96,7 @@ def self_noise(mode, kw, npert=NPERT):
 def main():
     gpu = len(sys.argv) > 1 and sys.argv[1] == "gpu"
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"); os.makedirs(out_dir, exist_ok=True)
-    cache = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_fuzz_self_noise.json")      # keyed by configuration; delete to recompute
+    cache = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_fuzz_self_noise.json")      # keyed by configuration; delete to recompute
     noise_all = json.load(open(cache)) if os.path.isfile(cache) else {}
     for mode, kw in CASES:
         tg = tag(mode, kw)

@@ -8,7 +8,8 @@ own accuracy, per tensor class:
 
     forward      y_hat, |STFT|, mag_hat            (max error / max|reference|)
     loss         the training loss                 (relative)
-    stft grads   the four basis gradients          (max error / max over the pair)
+    synthesis / analysis grads   the basis gradients (max error / max over the pair); the ANALYSIS bases are the ill-conditioned tensors of tests/gpu_spread.py:
+                 d atan2 amplifies the 2^-9 / 2^-12 operand roundings of re / im by 1 / mag at near-silent bins
     ae grads     the 36 autoencoder gradients      (max error / max|reference| per tensor; the worst tensor)
     params       parameters after one / two steps  (max absolute difference; Adam's first step is lr * sign(g): lr = 6.7e-5)
 
@@ -29,7 +30,8 @@ def classes(res):
         n = r["name"]
         if n.startswith(("fwd.", "step.y_hat")): c = "forward"
         elif n in ("step.loss",) or n.endswith(".loss"): c = "loss"
-        elif n.startswith("grad.dft_"): c = "stft grads"
+        elif n.startswith("grad.dft_analysis"): c = "analysis grads"
+        elif n.startswith("grad.dft_synthesis"): c = "synthesis grads"
         elif n.startswith("grad."): c = "ae grads"
         elif ".params" in n: c = "params"
         elif n == "step.l1norm": c = "l1norm"
@@ -40,14 +42,14 @@ def classes(res):
 
 
 def main():
-    print("mode | case | " + " | ".join(("forward", "loss", "stft grads", "ae grads", "l1norm", "params")))
+    print("mode | case | " + " | ".join(("forward", "loss", "synthesis grads", "analysis grads", "ae grads", "l1norm", "params")))
     worst = {}
     for name, level, half in MODES:
         for kw in CASES:
             with G.mixed_mode(level, half=half, tol_scale=1e12, oracle_rounds=False):
                 res = G.run_fused(steps=2, **kw)
             c = classes(res)
-            print(f"{name} | {kw} | " + " | ".join(f"{c.get(k, (0, ''))[0]:.2e}" for k in ("forward", "loss", "stft grads", "ae grads", "l1norm", "params")), flush=True)
+            print(f"{name} | {kw} | " + " | ".join(f"{c.get(k, (0, ''))[0]:.2e}" for k in ("forward", "loss", "synthesis grads", "analysis grads", "ae grads", "l1norm", "params")), flush=True)
             for k, v in c.items():
                 if v[0] > worst.get((name, k), (0, ""))[0]:
                     worst[(name, k)] = (v[0], v[1], kw)
