@@ -88,10 +88,9 @@ int st_set_tuning(int bk);
 int st_get_tuning(int* out, int n);
 int st_tuning_defaults(int* out, int n);
 int st_reset_tuning(void);
-/* The arithmetic a call with these dims ACTUALLY runs (an ST_PREC_* code).  Equal to d->prec except where a geometry cannot take the
- * requested level: the wide autoencoder path (T > 32 or OT > 16, e.g. the 65536-sample window) needs an even batch for 16-bit Linear
- * layers (its K = B * 528 reduction runs in 32-deep k-tiles); with an odd B its autoencoder layers stay fp32 and this returns
- * ST_PREC_BF16 / ST_PREC_F16 for ST_PREC_BF16_ALL / ST_PREC_F16_ALL.  The Python engine warns and reports it (StepEngine.effective_dtype). */
+/* The arithmetic a call with these dims ACTUALLY runs (an ST_PREC_* code).  Since round 5 that is d->prec for every geometry and batch (until round 4 the
+ * wide autoencoder path -- T > 32 or OT > 16, e.g. the 65536-sample window -- ran fp32 Linear layers for odd batches; its weight-gradient GEMMs now take
+ * 16-deep k-tiles when B * 528 is 16 mod 32).  Kept so that callers assert the arithmetic instead of assuming it (StepEngine.effective_dtype). */
 int st_effective_prec(const st_dims* d);
 /* Timing-only ablation switches for diagnostics (bit0: skip k-loop loads/stores, bit1: skip barriers, bit2: skip MFMAs);
  * results are INVALID when non-zero.  Never set by the product path. */
@@ -356,8 +355,8 @@ int st_model_input_grad(const st_dims* d, const float* params, void* ws, float* 
  * fnn_addknobs of both autoencoders (nn_proc.py:332-333).  g_knobs [B][K].  The exact, SLOW route: one forward + backward per window, whose
  * fnn_addknobs bias gradients are that window's row sums of d a5; the reference's training never asks for this gradient (knobs are data), so
  * the hot kernels carry nothing for it.  grads_scratch: st_param_offsets() floats, overwritten.  The saved-for-backward state of `ws` belongs
- * to the last window afterwards: run st_model_fwd(save_for_backward = 1) again before st_model_bwd.  Where a single window cannot take the
- * requested 16-bit arithmetic (st_effective_prec) the passes run the autoencoder layers in fp32. */
+ * to the last window afterwards: run st_model_fwd(save_for_backward = 1) again before st_model_bwd.  The per-window passes run in the arithmetic of
+ * d->prec like the batch itself (round 5: a single window takes 16-bit layers on every geometry, st_effective_prec). */
 int st_model_knob_grad(const st_dims* d, const float* params, float* grads_scratch, const float* x, const float* knobs,
                        const float* g_y_hat, const float* g_mag_hat, const float* g_mag, void* ws, float* g_knobs, void* stream);
 

@@ -98,7 +98,7 @@ def test_ae_bwd_repeatable():
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16_all", "f16_all"])
-@pytest.mark.parametrize("scale,B", [(1, 256), (8, 64)])
+@pytest.mark.parametrize("scale,B", [(1, 256), (8, 64), (1, 104), (1, 192)])
 def test_full_size_batch_properties(dtype, scale, B):
     """The per-GPU workloads of BASELINE configs[1..4] at FULL size -- 256 windows of 8192 samples, 64 windows of 65536 -- in the three
     arithmetic modes the configs name: properties that do not need the (slow) oracle.  Windows are independent, the loss is a mean over
@@ -107,7 +107,9 @@ def test_full_size_batch_properties(dtype, scale, B):
     and two runs give identical bits.  Exercises the full-size tiling / split-K / reduction paths (128 x 128 weight-gradient tiles + Nyquist
     partials, the 16-bit operand pipeline, the wide autoencoder path).  16-bit modes: every product is exact in fp32 on both sides, only
     fp32 sums re-associate -- and d loss / d y_hat carries 1 / (B y), a power of two between full and half batch, which commutes with the
-    rounding for bf16: tolerance 2e-3.  fp16: the polar backward SATURATES its output at +-65504 before the weight-gradient GEMM narrows it
+    rounding for bf16: tolerance 2e-3.  Round 5: B = 104 and 192 at the short window -- 128-row tiles of the frame-major row order that hold parts of TWO frames
+    (the union of their live tap ranges is computed) resp. one and a half tiles per frame, against halves (52, 96) whose work lists differ: the structural-zero
+    skipping of st_gemm_tn.h / st_gemm16.h must not depend on how the frames fall on the tiles.  fp16: the polar backward SATURATES its output at +-65504 before the weight-gradient GEMM narrows it
     (1e7-sized atan2 sub-gradients on near-silent frames x loss scale 4096) and small values go subnormal -- a half batch's 2x
     larger gradients saturate / round where the full batch's do not, so the property holds to ~1 % only (measured 0.7 %): tolerance 2e-2."""
     import numpy as np, torch
@@ -382,7 +384,7 @@ def _fuzz_cases():
     return m
 
 
-@pytest.mark.parametrize("idx", range(13))
+@pytest.mark.parametrize("idx", range(14))
 def test_fuzz_outliers_grounded(idx):
     """VERDICT round 3 weak #1.  The six 16-bit configurations the randomized sweep flagged (profiles/r03_fuzz_parity.txt) and their even-batch / other-K
     neighbours (tools/fuzz_ground.py CASES; table: profiles/r04_fuzz_grounding.txt).  Five of the six were the SILENT fp32 fallback of the wide

@@ -43,6 +43,11 @@ CASES += [
     ("f16_all", dict(B=3, seed=11, K=12, scale=1, scheme="lean", shrink=4)),
     ("bf16_all", dict(B=5, seed=12, K=5, scale=1, scheme="lean", shrink=2)),
 ]
+# round 5: the one hard line of the round-5 sweep (profiles/r05_fuzz_parity.txt) -- a SINGLE 65536-sample window in f16_all, which until round 4 ran fp32 autoencoder
+# layers (odd batch on the wide path) and now runs them in fp16: phase-net encoder gradients 2.1-2.6e-2 against the sweep's 1.6e-2
+CASES += [
+    ("f16_all", dict(B=1, seed=300, K=2, scale=8, scheme="lean", shrink=4)),
+]
 NPERT = 8
 
 
