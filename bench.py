@@ -333,8 +333,9 @@ def main():
                             step_traffic = sum((2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0 * v["calls"] / once[0] for v in lk.values())
                             step_launches = sum(v["calls"] / once[0] for v in lk.values())
                         mf = [h for h in hit if "SQ_VALU_MFMA_BUSY_CYCLES" in h and h.get("GRBM_GUI_ACTIVE")]
-                        if mf and len(mf) == len(hit):      # SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's SIMDs (4 per CU); GRBM_GUI_ACTIVE = the dispatch's cycles
-                            mfma_busy = sum(h["SQ_VALU_MFMA_BUSY_CYCLES"] for h in mf) / (4.0 * torch.cuda.get_device_properties(dev).multi_processor_count * sum(h["GRBM_GUI_ACTIVE"] for h in mf))
+                        if mf and len(mf) == len(hit):      # SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's SIMDs (4 per CU); GRBM_GUI_ACTIVE is summed over the 8 XCDs
+                            # (ae_bwd, fp32: 3.6e6 for a 177 us dispatch = 8 x 448 k cycles) -- so the dispatch's cycles are GRBM_GUI_ACTIVE / 8
+                            mfma_busy = sum(h["SQ_VALU_MFMA_BUSY_CYCLES"] for h in mf) / (4.0 * torch.cuda.get_device_properties(dev).multi_processor_count * sum(h["GRBM_GUI_ACTIVE"] for h in mf) / 8.0)
                         if all("avg_ns" in h for h in hit) and not dom.startswith("ae_wide"):          # rocprofv3's own kernel durations of the same command (kernel-trace stats); the wide path's logical kernel is a dozen launches, only some of them keyed here
                             rocprof_us = sum(h["avg_ns"] for h in hit) * 1e-3
                         break
@@ -359,7 +360,7 @@ def main():
                 out["roofline"]["step_traffic_ratio"] = step_traffic / step_alg
                 out["roofline"]["step_kernel_launches"] = step_launches
                 out["roofline"]["step_traffic_note"] = "sum over the step's kernels of (2 x FETCH_SIZE + WRITE_SIZE) x launches per step, same PMC file as `traffic`"
-            out["roofline"]["mfma_busy"] = mfma_busy        # SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x GRBM_GUI_ACTIVE) of the roofline kernel, same file; null without a source-matched PMC pass
+            out["roofline"]["mfma_busy"] = mfma_busy        # SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) of the roofline kernel, same file; null without a source-matched PMC pass
             if args.dtype.endswith("_all") and dom.startswith("ae_"):
                 # honest label: with 16-bit Linear layers the autoencoder kernels spend ~7 % of their time in MFMAs; what bounds them is vector-ALU work (ELU / ELU',
                 # conversions, transposes) and LDS fragment traffic (PMC: profiles/r03_rocprofv3_summary_bf16_all.txt), so the fraction of the MFMA peak is small by construction

@@ -153,11 +153,12 @@ int st_synthesis_frames(const st_dims* d, const float* AA, const float* Sfold, f
 
 /* Diagnostics, host only (no device work): the work list of the 128 x 128-tile synthesis GEMMs -- which = 0 st_synthesis_frames, 1 st_synthesis_dgrad's
  * padded form inside the fused step -- after the structural zeros of the cropped transposed convolution (cls_fe_dft.py:112-113) are dropped.
- * out[2 i] = tile row | tile column << 8 | slab << 16 | first zero-filled slab << 20 | kind << 24 (kind 1: the two Nyquist columns of a tile row),
- * out[2 i + 1] = first k-tile | k-tiles << 16 (k-tiles of 32); rows are the live frames enumerated frame-major (row = (t' - t'_lo) * B + b);
- * head4 = {slabs, col_h, col_stride, B} (tile column c covers output columns (128 c % col_h) + (128 c / col_h) * col_stride ... + 128; col_h = 0: 128 c).
- * ncus <= 0: the current device's CU count.  Returns the entry count (one workgroup each), 0 if the geometry does not use this kernel. */
-int st_nt128_worklist(const st_dims* d, int which, int ncus, unsigned* out, int cap, int* head4);
+ * out[i] = tile row (8 bits) | tile column (6) << 8 | slab (2) << 14 | first zero-filled slab (2; 0 = none) << 16 | kind (1; 1: the two Nyquist columns of a
+ * tile row) << 18 | first k unit (6) << 19 | k units (7) << 25; rows are the live frames enumerated frame-major (row = (t' - t'_lo) * B + b);
+ * head6 = {slabs, col_h, col_stride, B, k-tiles (of 32) per k unit, k-tiles of the whole reduction} (tile column c covers output columns
+ * (128 c % col_h) + (128 c / col_h) * col_stride ... + 128; col_h = 0: 128 c).  ncus <= 0: the current device's CU count.
+ * Returns the entry count (one workgroup each; more than ncus = several rounds), 0 if the geometry does not use this kernel. */
+int st_nt128_worklist(const st_dims* d, int which, int ncus, unsigned* out, int cap, int* head6);
 
 /* cls_fe_dft.py:112-113 overlap-add + crop, nn_proc.py:332,340 residual and x2,
  * loss_functions.py:9-10 log-cosh partial sums and d loss/d syn.

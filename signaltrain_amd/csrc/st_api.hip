@@ -567,9 +567,9 @@ extern "C" int st_synthesis_frames(const st_dims* d, const float* AA, const floa
     ST_TRY(check_dims(d)); ST_REQ(AA && Sfold && frs, "st_synthesis_frames: null pointer");
     return synthesis_frames_impl(d, AA, Sfold, nullptr, frs, stream);
 }
-// only where one workgroup per CU covers the whole GEMM (the B = 256 headline geometry: 112 / 126 tiles x 2 k-slices before the structural zeros are
-// dropped); larger problems stay on gemm_kernel<4, ...> / <2, ...>, whose smaller tiles balance better over several rounds
-static bool use_nt128(const st_dims* d, int M, int Nc) { return g_nt128 && gemm_ht(d->prec) == 0 && d->N % 32 == 0 && ((M + 127) / 128) * ((Nc + 127) / 128) * 2 <= num_cus(); }
+// the 128 x 128-tile work-list kernel (st_gemm_tn.h): fp32 products, up to 255 tile rows; whether a geometry / batch fits the list (and with how many k-slices) is the
+// list builder's decision (ntw_frames / ntw_dgrad return false -> gemm_kernel<4, ...> / <2, ...>)
+static bool use_nt128(const st_dims* d, int M, int Nc) { (void)Nc; return g_nt128 && gemm_ht(d->prec) == 0 && d->N % 32 == 0 && (M + 127) / 128 <= 255; }
 static int synthesis_frames_impl(const st_dims* d, const float* AA, const float* Sfold, const float* SfoldT, float* frs, void* stream)
 {
     const int KP = st_kp_of(d->F);
@@ -598,24 +598,24 @@ static int synthesis_frames_impl(const st_dims* d, const float* AA, const float*
 }
 
 // Host-side view of the work list of the 128 x 128-tile synthesis GEMMs (st_gemm_tn.h, round 5): which = 0 the frames GEMM, 1 the data gradient.
-// out[2 i], out[2 i + 1] = the packed entry i (tile row | tile column << 8 | slab << 16 | first zero-filled slab << 20 | kind << 24;  first k-tile | k-tiles << 16,
-// k-tiles of 32); head4 = {slabs, col_h, col_stride, frame-major windows per frame}.  Returns the number of entries (= workgroups), 0 when this geometry
-// does not run on the work-list kernel, < 0 on bad arguments.  No device work: the CPU test-suite checks the list against the cropping rule of cls_fe_dft.py:113.
-extern "C" int st_nt128_worklist(const st_dims* d, int which, int ncus, unsigned* out, int cap, int* head4)
+// out[i] = the packed entry i (tile row (8 bits) | tile column (6) << 8 | slab (2) << 14 | first zero-filled slab (2; 0 = none) << 16 | kind (1) << 18 | first k unit (6) << 19 |
+// k units (7) << 25); head6 = {slabs, col_h, col_stride, frame-major windows per frame, k-tiles (of 32) per k unit, k-tiles of the whole reduction}.  Returns the number of
+// entries (= workgroups), 0 when this geometry does not run on the work-list kernel, < 0 on bad arguments.  No device work: the CPU test-suite checks the list against the
+// cropping rule of cls_fe_dft.py:113.
+extern "C" int st_nt128_worklist(const st_dims* d, int which, int ncus, unsigned* out, int cap, int* head6)
 {
-    if (check_dims(d) != ST_OK || !out || !head4 || cap < 0 || (which != 0 && which != 1)) return -1;
+    if (check_dims(d) != ST_OK || !out || !head6 || cap < 0 || (which != 0 && which != 1)) return -1;
     const int KP = st_kp_of(d->F);
     const stg::RowMap ms = synth_live(d);
     const int R = ms.rows(d->B);
     if (ncus <= 0) ncus = num_cus();
     stg::NTWork wk; wk.n = 0;
-    const int Nc = which ? KP : d->N;
-    if (!(g_nt128 && gemm_ht(d->prec) == 0 && d->N % 32 == 0 && ((R + 127) / 128) * ((Nc + 127) / 128) * 2 <= ncus)) return 0;
+    if (!use_nt128(d, R, which ? KP : d->N)) return 0;
     const bool ok = which ? stg::ntw_dgrad(wk, ms, d->B, d->H, d->N, d->N, d->y, d->F, KP, R >= 4096 ? 1 : synth_split(R), ncus)
                           : stg::ntw_frames(wk, ms, d->B, d->H, d->N, d->N, d->y, KP, frames_split(R), ncus);
     if (!ok) return 0;
-    head4[0] = wk.nslabs; head4[1] = wk.col_h; head4[2] = wk.col_stride; head4[3] = d->B;
-    for (int i = 0; i < wk.n && i < cap; ++i) { out[2 * i] = wk.e[i].x; out[2 * i + 1] = wk.e[i].y; }
+    head6[0] = wk.nslabs; head6[1] = wk.col_h; head6[2] = wk.col_stride; head6[3] = d->B; head6[4] = wk.kunit; head6[5] = wk.kt_total;
+    for (int i = 0; i < wk.n && i < cap; ++i) out[i] = wk.e[i];
     return wk.n;
 }
 

@@ -292,13 +292,18 @@ static inline NTRows ntrows_frame_major(const float* base, unsigned s_window, un
     return NTRows{base + (size_t)live.t_lo * s_frame, s_frame, s_window, B > 1 ? rowmap_magic(B) : 0u, B, 0, R};      // "b" = r / B = the frame, "t" = r % B = the window
 }
 
-constexpr int NTW_MAX = 320;                               // work-list entries (one workgroup each); 2.5 KB of kernel arguments
+constexpr int NTW_MAX = 768;                               // work-list entries (one workgroup each): 3 KB of kernel arguments
 struct NTWork {
     int n, nslabs;                                         // entries; slabs the consumer sums
     int col_h, col_stride;                                 // output column of GEMM column c: (c % col_h) + (c / col_h) * col_stride  (col_h = 0: c)
+    int kunit, kt_total;                                   // k ranges are in units of kunit k-tiles (1 unless the reduction has more than 64 k-tiles), clamped to kt_total k-tiles
     unsigned nyq_b[2], nyq_col[2];                         // kind 1: element offsets (from rb.base) of the two B rows, and their output columns
-    uint2 e[NTW_MAX];                                      // x = tile row | tile column << 8 | slab << 16 | first slab to zero-fill << 20 | kind << 24;  y = first k-tile | k-tiles << 16
+    unsigned e[NTW_MAX];                                   // tile row (8 bits) | tile column (6) << 8 | slab (2) << 14 | first slab to zero-fill (2) << 16 | kind (1) << 18 | first k unit (6) << 19 | k units (7) << 25
 };
+static inline unsigned ntw_pack(int mt, int nt, int z, int zf, int kind, int k0, int kl)
+{
+    return (unsigned)mt | (unsigned)nt << 8 | (unsigned)z << 14 | (unsigned)zf << 16 | (unsigned)kind << 18 | (unsigned)k0 << 19 | (unsigned)kl << 25;
+}
 
 // slab z, 32 x 64 block of a wave: out[z][full_row][col]
 struct StoreSlab {
@@ -368,10 +373,12 @@ gemm_nt128_kernel(const NTRows ra, const NTRows rb, const StoreSlab epi, const N
     float* const As = nt_lds;
     float* const Bs = nt_lds + 2 * TS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const uint2 ent = wk.e[blockIdx.x];                    // workgroup-uniform (scalar loads from the kernel-argument segment)
-    const int m_blk = (int)(ent.x & 255u) * 128, n_blk = (int)((ent.x >> 8) & 255u) * 128, tbz = (int)((ent.x >> 16) & 15u), zf = (int)((ent.x >> 20) & 15u);
-    const int k_begin = (int)(ent.y & 0xffffu) * BKT, k_end = k_begin + (int)(ent.y >> 16) * BKT;
-    if (ent.x >> 24) { nt128_nyquist(ra, rb, epi, wk, m_blk, k_begin, k_end); return; }
+    const unsigned ent = wk.e[blockIdx.x];                 // workgroup-uniform (a scalar load from the kernel-argument segment)
+    const int m_blk = (int)(ent & 255u) * 128, n_blk = (int)((ent >> 8) & 63u) * 128, tbz = (int)((ent >> 14) & 3u), zf = (int)((ent >> 16) & 3u);
+    const int k_begin = (int)((ent >> 19) & 63u) * wk.kunit * BKT;
+    int k_end = k_begin + (int)(ent >> 25) * wk.kunit * BKT;
+    if (k_end > wk.kt_total * BKT) k_end = wk.kt_total * BKT;
+    if ((ent >> 18) & 1u) { nt128_nyquist(ra, rb, epi, wk, m_blk, k_begin, k_end); return; }
 
     const int lr = tid >> 3, lk = (tid & 7) * 4;
     unsigned ao[NP], bo[NP];
@@ -463,7 +470,7 @@ gemm_nt128_kernel(const NTRows ra, const NTRows rb, const StoreSlab epi, const N
     const int c_blk = wk.col_h ? (n_blk % wk.col_h) + (n_blk / wk.col_h) * wk.col_stride : n_blk;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) epi(tbz, m_blk + wm * 64 + 32 * mi, c_blk + wn * 64, acc[mi]);
-    if (zf < wk.nslabs) {                                  // the slabs no k-slice of this tile computes: zeros
+    if (zf > 0 && zf < wk.nslabs) {                        // the slabs no k-slice of this tile computes (zf = the first of them, on the tile's slice 0 only): zeros
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -493,35 +500,52 @@ static inline void ntw_live_taps(int f0, int f1, int H, int N, int pad, int Ls, 
 }
 static inline void ntw_push(NTWork& w, int mt, int nt, int z, int zf, int kind, int k0, int kl)
 {
-    w.e[w.n++] = make_uint2((unsigned)mt | (unsigned)nt << 8 | (unsigned)z << 16 | (unsigned)zf << 20 | (unsigned)kind << 24, (unsigned)k0 | (unsigned)kl << 16);
+    w.e[w.n++] = ntw_pack(mt, nt, z, zf, kind, k0, kl);
 }
 // entries are built in (slab, tile row, tile column) order; workgroup i runs on XCD i % 8, so XCD j gets the j-th contiguous eighth of that order
 // (one band of A rows / one k-slice of B per L2, as xcd_tile does for the grid-shaped launches)
 static inline void ntw_xcd_order(NTWork& w)
 {
-    uint2 tmp[NTW_MAX];
+    unsigned tmp[NTW_MAX];
     const int T = w.n, q = T >> 3, r = T & 7;
     for (int L = 0; L < T; ++L) { const int j = L & 7; tmp[L] = w.e[j * q + (j < r ? j : r) + (L >> 3)]; }
     for (int L = 0; L < T; ++L) w.e[L] = tmp[L];
 }
+// Cost of a launch of `wgs` workgroups whose longest k-loop has `ktiles` k-tiles, one workgroup per CU: rounds x (fixed + per k-tile), in us (B = 256 measurements:
+// 252 workgroups x 11 k-tiles 31.5 us, 224 x 16.5 43.4 us).  Only used to RANK slice counts.
+static inline double ntw_cost(int wgs, int ktiles, int ncus) { return (double)((wgs + ncus - 1) / ncus) * (6.0 + 2.35 * (double)ktiles); }
+// several rounds only if they are well filled (one workgroup per CU: a last round at 30 % costs a whole round -- there the smaller tiles of gemm_kernel<4 / 2, ...> balance better)
+static inline bool ntw_rounds_ok(int wgs, int ncus) { const int r = (wgs + ncus - 1) / ncus; return r <= 1 || (double)wgs >= 0.85 * (double)r * (double)ncus; }
+static inline bool ntw_header(NTWork& w, int nslabs, int ktiles)
+{
+    w.n = 0; w.nslabs = nslabs; w.col_h = 0; w.col_stride = 0; w.nyq_b[0] = w.nyq_b[1] = w.nyq_col[0] = w.nyq_col[1] = 0u;
+    w.kunit = (ktiles + 63) / 64; w.kt_total = ktiles;
+    return nslabs >= 1 && nslabs <= 3 && ktiles >= 1 && (ktiles + w.kunit - 1) / w.kunit <= 127;      // slab / zero-fill fields are 2 bits
+}
 // Frames GEMM: M = live frames (frame-major), columns = the N taps, reduction K (a multiple of 32).  false: does not fit the list.
+// Round 5b: more workgroups than CUs are allowed (several rounds of one workgroup per CU: B = 512 runs 504 entries in two rounds, 64 us against 107 on
+// gemm_kernel<2, ...>); the k-slice count is the cheapest of 1 .. slabs by ntw_cost.
 static inline bool ntw_frames(NTWork& w, const RowMap& live, int B, int H, int N, int pad, int Ls, int K, int nslabs, int ncus)
 {
     const int R = live.rows(B), MT = (R + 127) / 128;
-    if (N % 128 || K % 32 || MT > 255 || N / 128 > 255 || K / 32 > 0xffff || nslabs > 15) return false;
+    if (N % 128 || K % 32 || MT > 255 || N / 128 > 63 || !ntw_header(w, nslabs, K / 32)) return false;
     int tiles = 0, c0[256], c1[256];
     for (int mt = 0; mt < MT; ++mt) {
         int f0, f1, lo, hi; ntw_tile_frames(live, B, R, mt, f0, f1); ntw_live_taps(f0, f1, H, N, pad, Ls, lo, hi);
         c0[mt] = lo / 128; c1[mt] = (hi + 127) / 128; tiles += c1[mt] - c0[mt];
     }
-    int nact = ncus / (tiles > 0 ? tiles : 1); if (nact > nslabs) nact = nslabs; if (nact > K / 32) nact = K / 32; if (nact < 1) nact = 1;
-    if (tiles * nact > NTW_MAX) return false;
-    w.n = 0; w.nslabs = nslabs; w.col_h = 0; w.col_stride = 0; w.nyq_b[0] = w.nyq_b[1] = w.nyq_col[0] = w.nyq_col[1] = 0u;
-    const int kt = K / 32;
+    const int ku = (w.kt_total + w.kunit - 1) / w.kunit;   // reduction length in k units
+    int nact = 0; double best = 0.0;
+    for (int c = 1; c <= nslabs && c <= ku; ++c) {
+        if (tiles * c > NTW_MAX) break;
+        const double t = ntw_cost(tiles * c, ((ku + c - 1) / c) * w.kunit, ncus);
+        if (!nact || t < best - 1e-9) { nact = c; best = t; }
+    }
+    if (!nact || !ntw_rounds_ok(tiles * nact, ncus)) return false;
     for (int z = 0; z < nact; ++z) {
-        const int k0 = (int)((long long)kt * z / nact), k1 = (int)((long long)kt * (z + 1) / nact);
+        const int k0 = (int)((long long)ku * z / nact), k1 = (int)((long long)ku * (z + 1) / nact);
         for (int mt = 0; mt < MT; ++mt)
-            for (int nt = c0[mt]; nt < c1[mt]; ++nt) ntw_push(w, mt, nt, z, z == 0 ? nact : nslabs, 0, k0, k1 - k0);
+            for (int nt = c0[mt]; nt < c1[mt]; ++nt) ntw_push(w, mt, nt, z, (z == 0 && nact < nslabs) ? nact : 0, 0, k0, k1 - k0);
     }
     ntw_xcd_order(w);
     return true;
@@ -533,32 +557,41 @@ static inline bool ntw_dgrad(NTWork& w, const RowMap& live, int B, int H, int N,
     const int R = live.rows(B), MT = (R + 127) / 128;
     const bool nyq = (F - 1) % 128 == 0 && F > 1;
     const int NT = nyq ? 2 * (F - 1) / 128 : (KP + 127) / 128;
-    if (N % 32 || MT > 255 || NT > 255 || N / 32 > 0xffff || nslabs > 15) return false;
-    int k0[256], k1[256];
+    if (N % 32 || MT > 255 || NT > 63 || !ntw_header(w, nslabs, N / 32)) return false;
+    const int U = w.kunit;
+    int k0[256], k1[256];                                  // live range of a tile row, in k units (rounded outward: the extra taps are zeros of the padded d syn)
     for (int mt = 0; mt < MT; ++mt) {
         int f0, f1, lo, hi; ntw_tile_frames(live, B, R, mt, f0, f1); ntw_live_taps(f0, f1, H, N, pad, Ls, lo, hi);
-        k0[mt] = lo / 32; k1[mt] = (hi + 31) / 32;
+        k0[mt] = lo / (32 * U); k1[mt] = (hi + 32 * U - 1) / (32 * U);
     }
-    // the shortest slice length (k-tiles) whose slice count per tile row stays within the slabs and whose workgroups fit the CUs
-    int kmax = 0, total = 0;
-    for (int c = 1; c <= N / 32; ++c) {
-        int sum = 0; bool ok = true;
-        for (int mt = 0; mt < MT; ++mt) { const int s = (k1[mt] - k0[mt] + c - 1) / c; if (s > nslabs) { ok = false; break; } sum += s; }
-        if (ok && sum * NT + (nyq ? MT : 0) <= ncus) { kmax = c; total = sum * NT + (nyq ? MT : 0); break; }
+    // slice length c (k units): every tile row is cut into ceil(len / c) <= slabs equal slices; the cheapest c by ntw_cost
+    const int ku = (w.kt_total + U - 1) / U;
+    int cbest = 0, wbest = 0; double best = 0.0;
+    for (int c = 1; c <= ku; ++c) {
+        int sum = 0, longest = 0; bool ok = true;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int len = k1[mt] - k0[mt], sl = (len + c - 1) / c;
+            if (sl > nslabs) { ok = false; break; }
+            sum += sl; const int each = (len + sl - 1) / sl; if (each > longest) longest = each;
+        }
+        if (!ok) continue;
+        const int wgs = sum * NT + (nyq ? MT : 0);
+        if (wgs > NTW_MAX) continue;
+        const double t = ntw_cost(wgs, longest * U, ncus);
+        if (!cbest || t < best - 1e-9) { cbest = c; best = t; wbest = wgs; }
     }
-    if (!kmax || total > NTW_MAX) return false;
-    w.n = 0; w.nslabs = nslabs;
+    if (!cbest || !ntw_rounds_ok(wbest, ncus)) return false;
     w.col_h = nyq ? F - 1 : 0; w.col_stride = KP / 2;
     w.nyq_b[0] = (unsigned)(F - 1) * (unsigned)N; w.nyq_b[1] = (unsigned)(KP / 2 + F - 1) * (unsigned)N; w.nyq_col[0] = (unsigned)(F - 1); w.nyq_col[1] = (unsigned)(KP / 2 + F - 1);
     for (int z = 0; z < nslabs; ++z)
         for (int mt = 0; mt < MT; ++mt) {
-            const int len = k1[mt] - k0[mt], s = (len + kmax - 1) / kmax;
-            if (z >= s) continue;
-            const int a = k0[mt] + (int)((long long)len * z / s), b = k0[mt] + (int)((long long)len * (z + 1) / s);
-            for (int nt = 0; nt < NT; ++nt) ntw_push(w, mt, nt, z, z == 0 ? s : nslabs, 0, a, b - a);
+            const int len = k1[mt] - k0[mt], sl = (len + cbest - 1) / cbest;
+            if (z >= sl) continue;
+            const int a = k0[mt] + (int)((long long)len * z / sl), b = k0[mt] + (int)((long long)len * (z + 1) / sl);
+            for (int nt = 0; nt < NT; ++nt) ntw_push(w, mt, nt, z, (z == 0 && sl < nslabs) ? sl : 0, 0, a, b - a);
         }
     ntw_xcd_order(w);
-    if (nyq) for (int mt = 0; mt < MT; ++mt) ntw_push(w, mt, 0, 0, nslabs, 1, k0[mt], k1[mt] - k0[mt]);      // behind the tiles: dispatched last, on the CUs the tiles leave free
+    if (nyq) for (int mt = 0; mt < MT; ++mt) ntw_push(w, mt, 0, 0, 0, 1, k0[mt], k1[mt] - k0[mt]);      // behind the tiles: dispatched last, on the CUs the tiles leave free
     return true;
 }
 

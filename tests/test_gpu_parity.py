@@ -30,6 +30,30 @@ def test_fused_step_parity(B, seed, K, steps):
     _assert_ok(G.run_fused(B=B, seed=seed, K=K, steps=steps))
 
 
+@pytest.mark.parametrize("mode", ["f32", "f32x3", "bf16_all", "f16_all"])
+@pytest.mark.parametrize("B,seed", [(64, 11), (130, 12)])
+def test_trimmed_tiles_against_the_oracle(mode, B, seed):
+    """Round 5: batches at which the structural-zero skipping of st_gemm_tn.h / st_gemm16.h is ACTIVE, against the oracle (the randomized sweep and the small
+    fixed cases stay below 19 windows, where one 128-row tile holds every frame and nothing is skipped).  B = 64: tile rows of two frames each (frames 1-2: taps
+    [256, 1024); frames 6-7: [0, 768)); B = 130: the first tile row is frame 1 alone (taps [640, 1024): 3 of 8 tile columns / 384 of 1024 reduction taps), the
+    following ones straddle two frames.  Fused forward, loss, all 40 gradient tensors, clip norm and one optimizer step; misses of the fixed fp32 tolerance on
+    ill-conditioned tensors are graded against the measured spread (tests/gpu_spread.py), never by name."""
+    from tests import gpu_checks as G
+    from tests import gpu_spread as S
+    kw = dict(B=B, seed=seed, K=4)
+    if mode == "f32":
+        res = G.run_fused(steps=1, **kw)
+    elif mode == "f32x3":
+        with G.split_mode():
+            res = G.run_fused(steps=1, **kw)
+    else:
+        half = "bf16" if mode.startswith("bf16") else "f16"
+        with G.mixed_mode(2, half=half, tol_scale=(G.mixed_mode.FUSED_TOL if half == "bf16" else G.mixed_mode.FUSED_TOL_F16)[2]):
+            res = G.run_fused(steps=1, **kw)
+    still = S.grounded(res, kw) if mode in ("f32", "f32x3") else [r for r in res if not r["ok"]]
+    assert not still, [(r["name"], r["rel"], r["tol"], r.get("spread")) for r in still]
+
+
 def test_legacy_large_fft_scheme():
     """nn_proc.py:374-376 (scale_scheme != 'lean'): ft and hop scale with the window -- scale 2: N=2048, H=768, F=1025,
     T=25, OT=9.  Same kernels, different GEMM sizes / spectral pitch."""
