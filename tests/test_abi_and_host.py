@@ -356,3 +356,16 @@ def test_nt128_worklist_covers_exactly_the_live_taps(B, shrink):
             assert n == 480 + 28 and max(e["kl"] for e in ents if e["kind"] == 0) == 12
     else:
         assert B > 1024
+
+
+def test_run_train_accepts_the_reference_effect_keys():
+    """run_train.py --effect: the reference's keys (run_train.py:55-80).  comp_4c / comp_large / files are built (argument parsing only here: the run itself
+    needs a GPU); the reference's other keys and unknown ones exit with a message that names what is available, as the reference does for unknown effects."""
+    import subprocess, sys
+    run = lambda *a: subprocess.run([sys.executable, os.path.join(ROOT, "run_train.py"), *a], capture_output=True, text=True, timeout=300)
+    r = run("--effect", "denoise")
+    assert r.returncode != 0 and "does not build" in r.stderr and "comp_large" in r.stderr
+    r = run("--effect", "bogus")
+    assert r.returncode != 0 and "is not yet added" in r.stderr
+    r = run("--effect", "comp_large", "--target", "nope")
+    assert r.returncode != 0 and "invalid target type" in r.stderr            # comp_large passed the effect check (argparse used to reject it)
