@@ -567,9 +567,25 @@ extern "C" int st_synthesis_frames(const st_dims* d, const float* AA, const floa
     ST_TRY(check_dims(d)); ST_REQ(AA && Sfold && frs, "st_synthesis_frames: null pointer");
     return synthesis_frames_impl(d, AA, Sfold, nullptr, frs, stream);
 }
-// the 128 x 128-tile work-list kernel (st_gemm_tn.h): fp32 products, up to 255 tile rows; whether a geometry / batch fits the list (and with how many k-slices) is the
-// list builder's decision (ntw_frames / ntw_dgrad return false -> gemm_kernel<4, ...> / <2, ...>)
-static bool use_nt128(const st_dims* d, int M, int Nc) { (void)Nc; return g_nt128 && gemm_ht(d->prec) == 0 && d->N % 32 == 0 && (M + 127) / 128 <= 255; }
+// Fraction of the synthesis frames' taps that the crop of cls_fe_dft.py:113 throws away (the structural zeros the work list skips): 25 % at the 8192-sample window
+// (7 live frames), 4 % at the 65536-sample window (44 live frames)
+static double synth_crop_fraction(const st_dims* d)
+{
+    const stg::RowMap ms = synth_live(d);
+    long live = 0;
+    for (int t = ms.t_lo; t < ms.t_lo + ms.Tv; ++t) { int lo, hi; stg::ntw_live_taps(t, t, d->H, d->N, d->N, d->y, lo, hi); live += hi - lo; }
+    return 1.0 - (double)live / ((double)ms.Tv * (double)d->N);
+}
+// the 128 x 128-tile work-list kernel (st_gemm_tn.h): fp32 products, up to 255 tile rows.  Used where one workgroup per CU covers the whole GEMM in one round (the rule
+// of rounds 3-4: small batches at any geometry) or where the crop is worth the frame-major row order (>= 10 % of the taps: every geometry of the 8192-sample window) --
+// several rounds are then fine (B = 512: 61 / 69 us against 107 / 107 on gemm_kernel<2, ...>).  MEASURED the other way at the 65536-sample window (B = 64, 4 % cropped, 510 workgroups
+// in two rounds): 80 / 77 us against 64 / 65 -- a tile's 128 rows there are 64 windows 194 KB apart; that geometry stays on the small-tile kernel.  Whether a list fits (and with
+// how many k-slices) is the builder's decision (ntw_frames / ntw_dgrad return false -> gemm_kernel<4, ...> / <2, ...>).
+static bool use_nt128(const st_dims* d, int M, int Nc)
+{
+    if (!(g_nt128 && gemm_ht(d->prec) == 0 && d->N % 32 == 0 && (M + 127) / 128 <= 255)) return false;
+    return ((M + 127) / 128) * ((Nc + 127) / 128) * 2 <= num_cus() || synth_crop_fraction(d) >= 0.10;
+}
 static int synthesis_frames_impl(const st_dims* d, const float* AA, const float* Sfold, const float* SfoldT, float* frs, void* stream)
 {
     const int KP = st_kp_of(d->F);
