@@ -148,7 +148,9 @@ int st_synth_fold(const st_dims* d, const float* Sr, const float* Si, float* Sfo
 int st_synth_slabs(const st_dims* d);
 int st_synth_frame_slabs(const st_dims* d);
 
-/* cls_fe_dft.py:112 ConvTranspose1d as a GEMM: frs[B*OT,N] = AA[B*OT,KP] * Sfold[KP,N] (live frames only). */
+/* cls_fe_dft.py:112 ConvTranspose1d as a GEMM: frs[B*OT,N] = AA[B*OT,KP] * Sfold[KP,N] -- only what survives the crop of cls_fe_dft.py:113: frames that
+ * lie wholly in the cropped margins are not computed, and (round 5, 128 x 128-tile path) of the partly cropped frames only the 128-tap tile columns that hold
+ * a tap n with N <= H t + n < N + y.  st_ola_loss reads exactly those taps; everything else in frs is left as it was. */
 int st_synthesis_frames(const st_dims* d, const float* AA, const float* Sfold, float* frs, void* stream);
 
 /* Diagnostics, host only (no device work): the work list of the 128 x 128-tile synthesis GEMMs -- which = 0 st_synthesis_frames, 1 st_synthesis_dgrad's

@@ -415,7 +415,9 @@ def test_fuzz_outliers_grounded(idx):
     autoencoder path for odd batches (lean scale 2 and shrink 1 are wide geometries): the device ran fp32 autoencoder layers against an oracle rounding
     them to 16 bits.  The library now reports its effective arithmetic (st_effective_prec) and the checks' oracle follows it: per-op green at the per-op
     tolerance, fused within max(suite tolerance, 3 x the oracle's own spread for that configuration) -- profiles/r05_fuzz_self_noise.json, the rounding
-    oracle against itself under eight 1e-6 perturbations.  The sixth (f16_all, 65536-sample window, K = 16) sits inside that spread."""
+    oracle against itself under eight 1e-6 perturbations.  The sixth (f16_all, 65536-sample window, K = 16) sits inside that spread.
+    Round 5: the wide path takes 16-bit layers for ODD batches too, so all of these run the requested arithmetic (the self-noise table was recomputed with the layers
+    rounded everywhere), and the one hard line of the round-5 sweep -- a single 65536-sample window in f16_all, seed 300 -- is case 13 (0.4-0.6 x its spread)."""
     import json
     from tests import gpu_checks as G
     m = _fuzz_cases()

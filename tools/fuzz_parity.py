@@ -16,6 +16,11 @@ Round 4 (500 s, profiles/r04_fuzz_parity.txt): 824 configurations incl. odd batc
 bf16 / bf16_all green; ONE hard line -- f16_all, L = 65536, B = 2, K = 16, seed 482: 1.3e-2 on the layer-1 weight gradient of the phase net -- the configuration tools/fuzz_ground.py shows to sit at
 0.7 x the oracle's own spread (1.8e-2); the sweep held scale 8 to the scale-1 tolerance (8e-3) where the suite uses 2 x that: same multiplier here now.
 Re-run on the final round-4 sources (2ebbf655b2257caa; 500 s): 824 configurations, 0 hard failures in any of the six arithmetic modes.
+Round 5 (500 s, profiles/r05_fuzz_parity.txt): no tensor is exempt by name any more -- a miss of a fixed fp32 tolerance is graded on the spot against the measured spread of that
+quantity for that configuration (tests/gpu_spread.py).  777-794 configurations (odd batches on the wide path now run 16-bit layers), 20 "soft" lines, every one within 1.6 x its spread
+(bound: 3 x); ONE hard line -- f16_all, L = 65536, a single window (B = 1, K = 2, seed 300): phase-net encoder gradients 2.1-2.6e-2 against the sweep's 1.6e-2 -- which tools/fuzz_ground.py
+shows at 0.4-0.6 x the rounding oracle's own spread for that window (4.1-6.6e-2; its analysis-basis gradients move by 120 % under a 1e-6 perturbation): the 14th case of
+tests/test_gpu_parity.py::test_fuzz_outliers_grounded.
     python tools/fuzz_parity.py [seconds]"""
 import sys, time, random; sys.path.insert(0, '.')
 from tests import gpu_checks as G

@@ -15,6 +15,7 @@ prof f16_all "--dtype f16_all"
 prof bf16_all_b1024 "--dtype bf16_all --batch 1024"
 prof scale8_b64_f32 "--scale 8 --batch 64"
 prof scale8_b64_f16_all "--scale 8 --batch 64 --dtype f16_all"
+[ -n "$ONLY_PROF" ] && { ls $OUT | wc -l; exit 0; }      # ONLY_PROF=1: the profiles / PMC passes alone (after a source change that does not move any number, e.g. a header comment)
 cd $REPO
 b() { timeout 600 python bench.py $2 > $OUT/bench_$1.json 2> $OUT/bench_$1.err; tail -c 600 $OUT/bench_$1.json | head -c 300; echo; }
 b bf16 "--dtype bf16 --no-cpu-baseline"
