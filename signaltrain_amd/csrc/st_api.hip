@@ -639,6 +639,22 @@ static int ola_loss_impl(const st_dims* d, const float* frs, const float* x, con
                          float* y_hat, float* dsyn, int dsyn_pad, float* loss_partial, void* stream, unsigned short* dsyn16 = nullptr)
 {
     const float inv = loss_scale_of(d) / ((float)d->B * (float)d->y);     // d loss / d y_hat, times the loss scale (train.py:134-135)
+    {   // four samples per thread (round 5) where the geometry and the pointers allow 16-byte accesses: always inside the fused step
+        const int ns = st_synth_frame_slabs(d), nslot = (d->y + 255) / 256;
+        auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        const bool ok4 = d->H % 4 == 0 && d->N % 4 == 0 && d->y % 4 == 0 && d->L % 4 == 0 && dsyn_pad % 4 == 0 && ns >= 1 && ns <= 3 && (d->N + d->H - 1) / d->H <= 3 &&
+                         al16(frs) && al16(x) && al16(y_true) && al16(y_hat) && al16(dsyn) && al16(dsyn16) && ((size_t)d->B * d->OT * d->N) % 4 == 0;
+        if (ok4) {
+            const dim3 grid((d->y / 4 + 255) / 256, d->B);
+            const size_t slab = (size_t)d->B * d->OT * d->N;
+            unsigned short* d16 = dsyn ? dsyn16 : nullptr; const int ht = dsyn16 ? gemm_ht(d->prec) : 0;
+#define ST_OLA4(NS_) hipLaunchKernelGGL((stm::ola_loss4_kernel<NS_>), grid, dim3(256), 0, st_stream(stream), frs, x, y_true, y_hat, dsyn, loss_partial, d->L, d->N, d->H, d->OT, d->y, inv, slab, dsyn_pad, nslot, d16, ht)
+            if (ns == 3) ST_OLA4(3); else if (ns == 2) ST_OLA4(2); else ST_OLA4(1);
+#undef ST_OLA4
+            ST_LAUNCHED("ola_loss");
+            return ST_OK;
+        }
+    }
     hipLaunchKernelGGL(stm::ola_loss_kernel, dim3((d->y + 255) / 256, d->B), dim3(256), 0, st_stream(stream),
                        frs, x, y_true, y_hat, dsyn, loss_partial, d->L, d->N, d->H, d->OT, d->y, inv,
                        st_synth_frame_slabs(d), (size_t)d->B * d->OT * d->N, dsyn_pad, dsyn ? dsyn16 : nullptr, dsyn16 ? gemm_ht(d->prec) : 0);

@@ -111,6 +111,83 @@ ola_loss_kernel(const float* __restrict__ frs, const float* __restrict__ x, cons
     }
 }
 
+// Round 5: the same, FOUR output samples per thread.  H, N, y (and with them every frame offset N + j - H t) are multiples of 4 for the reference's geometries, so the
+// (at most three) frames x (at most three) slabs a sample quartet needs are 16-byte loads, all nine issued before the first add; same order of additions per sample as
+// ola_loss_kernel (frames outer, slabs inner): y_hat is bit-identical.  The scalar kernel issued 6 dword loads per frame (3 of them dummies) inside a run-time-bounded
+// loop -- 2-3 dependent round trips per thread, 3.1 TB/s at B = 256 and 2.0 TB/s at the 65536-sample window.  Loss partials keep their slot count (ceil(y / 256) per
+// window, st_ola_loss_partials): a block owns four consecutive slots, writes the first and zeroes the rest.
+template <int NS>
+__global__ void __launch_bounds__(256)
+ola_loss4_kernel(const float* __restrict__ frs, const float* __restrict__ x, const float* __restrict__ y_true,
+                 float* __restrict__ y_hat, float* __restrict__ dsyn, float* __restrict__ loss_partial,
+                 int L, int N, int H, int OT, int ysz, float inv_count, size_t slab, int dsyn_pad, int nslot,
+                 unsigned short* __restrict__ dsyn16 = nullptr, int ht = 0)
+{
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const int j = 4 * (blockIdx.x * 256 + threadIdx.x);
+    float lc = 0.f;
+    if (j < ysz) {
+        const int t0 = j / H + 1;                     // first frame with N + j - H t < N  (the same for j .. j + 3: H is a multiple of 4)
+        int t1 = (N + j) / H;                         // last frame with N + j - H t >= 0
+        if (t1 > OT - 1) t1 = OT - 1;
+        const float* fb = frs + (size_t)b * OT * N;
+        float4 v[3][NS];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {                 // all loads first (a frame past t1 re-reads frame t1: valid address, value dropped)
+            const int t = t0 + u <= t1 ? t0 + u : t1;
+            const size_t o = (size_t)t * N + (size_t)(N + j - H * t);
+#pragma unroll
+            for (int z = 0; z < NS; ++z) v[u][z] = *reinterpret_cast<const float4*>(fb + z * slab + o);
+        }
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), yt = xv;
+        if (x) xv = *reinterpret_cast<const float4*>(x + (size_t)b * L + (L - ysz) + j);
+        if (y_true) yt = *reinterpret_cast<const float4*>(y_true + (size_t)b * ysz + j);
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const bool live = t0 + u <= t1;
+#pragma unroll
+            for (int z = 0; z < NS; ++z) {
+                s[0] += live ? v[u][z].x : 0.f; s[1] += live ? v[u][z].y : 0.f; s[2] += live ? v[u][z].z : 0.f; s[3] += live ? v[u][z].w : 0.f;
+            }
+        }
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yt.x, yt.y, yt.z, yt.w};
+        float out[4], ds[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            out[q] = x ? 2.0f * (s[q] + 0.5f * xs[q]) : s[q];
+            const float dlt = ys[q] - out[q];
+            const float a = fabsf(dlt);
+            float l1;
+            if (a < 8.0f) { const float u = expm1f(0.5f * a); const float sh = 0.5f * (u + u / (u + 1.0f)); l1 = log1pf(2.0f * sh * sh); }
+            else l1 = a + log1pf(__expf(-2.0f * a)) - 0.69314718056f;
+            lc += y_true ? l1 : 0.f;
+            ds[q] = -2.0f * tanhf(dlt) * inv_count;
+        }
+        if (y_hat) *reinterpret_cast<float4*>(y_hat + (size_t)b * ysz + j) = make_float4(out[0], out[1], out[2], out[3]);
+        if (y_true) {
+            const size_t o = (size_t)b * (ysz + 2 * dsyn_pad) + dsyn_pad + j;
+            if (dsyn16) *reinterpret_cast<uint2*>(dsyn16 + o) = st_to_h16x4(make_float4(ds[0], ds[1], ds[2], ds[3]), ht);
+            else if (dsyn) *reinterpret_cast<float4*>(dsyn + o) = make_float4(ds[0], ds[1], ds[2], ds[3]);
+        }
+    }
+    if ((dsyn || dsyn16) && dsyn_pad > 0) {      // zero margins of the padded gradient signal (2*pad floats per window)
+        const size_t ro = (size_t)b * (ysz + 2 * dsyn_pad);
+        for (int m = blockIdx.x * 256 + threadIdx.x; m < 2 * dsyn_pad; m += gridDim.x * 256) {
+            if (dsyn16) dsyn16[ro + (m < dsyn_pad ? m : ysz + m)] = 0;
+            else dsyn[ro + (m < dsyn_pad ? m : ysz + m)] = 0.f;
+        }
+    }
+    if (loss_partial) {
+        const float tot = block_sum<4>(lc, red);
+        if (threadIdx.x < 4) {
+            const int slot = 4 * blockIdx.x + threadIdx.x;
+            if (slot < nslot) loss_partial[blockIdx.y * nslot + slot] = threadIdx.x == 0 ? tot : 0.f;
+        }
+    }
+}
+
 // out[b][pad + Ls + pad] = zero margins | s * in[b][Ls]: the padded, pre-scaled signal the framed GEMM loaders read
 // (x/2 of nn_proc.py:307 with the Conv1d padding of cls_fe_dft.py:28-31 materialised once per step, 10 MB at B=256).
 __device__ __forceinline__ void pad_scale_block(const float* __restrict__ in, float* __restrict__ out, const int Ls, const int pad, const float s,
