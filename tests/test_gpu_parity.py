@@ -400,6 +400,49 @@ def test_alternative_code_paths_agree(dtype, codes, restore):
         assert (alt[k] - ref[k]).abs().max().item() <= tol * sc + 1e-12, (dtype, codes, k)
 
 
+@pytest.mark.parametrize("dtype,codes,restore", [
+    ("f32", (9950,), (9951,)),            # small-tile gemm_kernel<2, ...> (window-major rows, every tap multiplied) instead of the work-list kernel
+    ("f32", (9540,), (9543,)),            # weight gradients over ALL reduction rows in window-major order instead of the per-tile-column row ranges
+    ("f32", (9500,), (9501,)),            # weight gradients on gemm_kernel<3, ...> instead of the 128 x 128-tile kernel
+    ("bf16_all", (9560,), (9575,)),       # 16-bit synthesis GEMMs / weight gradients without the structural-zero skipping
+    ("f16_all", (9560,), (9575,)),
+])
+def test_structural_zero_paths_agree_with_the_full_products(dtype, codes, restore):
+    """Round 5: at a batch where the skipping is ACTIVE (B = 130: the first tile row is frame 1 alone, the others straddle two frames) the trimmed paths give what the
+    untrimmed ones give -- the skipped products are exact zeros, so fp32 results differ by reassociation only (2e-5 of each tensor's largest element) and the 16-bit ones
+    by the rounding noise a different summation order causes.  Loss and all 40 gradient tensors."""
+    import numpy as np, torch
+    from tests import gpu_checks as G
+    from signaltrain_amd import _lib
+    from signaltrain_amd.engine import StepEngine
+    lib = _lib.load()
+    B, K = 130, 4
+    geo, X, Y, KN, P = G.make_case(8, 19, K=K)
+    rng = np.random.default_rng(3)
+    reps = (B + 7) // 8
+    X = (np.tile(X, (reps, 1))[:B] * rng.uniform(0.4, 1.0, (B, 1))).astype(np.float32)
+    Y = (np.tile(Y, (reps, 1))[:B] * rng.uniform(0.4, 1.0, (B, 1))).astype(np.float32)
+    KN = (rng.random((B, K)) - 0.5).astype(np.float32)
+    x, kn, y = G.t(X), G.t(KN), G.t(Y)
+
+    def run():
+        d = G.dims_of(geo, B, K)
+        eng = StepEngine(d, G.DEV, compute_dtype=dtype); eng.load_state_dict(P)
+        eng.loss_backward(x, kn, y); torch.cuda.synchronize()
+        return {k: v.clone() for k, v in eng.layout.views(eng.grads).items()}, float(eng.scalars[0])
+    ref, l_ref = run()
+    try:
+        for c in codes: _lib.check(lib.st_set_tuning(c), "st_set_tuning")
+        alt, l_alt = run()
+    finally:
+        for c in restore: _lib.check(lib.st_set_tuning(c), "st_set_tuning")
+    tol = 2e-5 if dtype == "f32" else 3e-2
+    assert abs(l_alt - l_ref) <= tol * abs(l_ref), (l_ref, l_alt)
+    for k in ref:
+        sc = ref[k].abs().max().item()
+        assert (alt[k] - ref[k]).abs().max().item() <= tol * sc + 1e-12, (dtype, codes, k, (alt[k] - ref[k]).abs().max().item(), sc)
+
+
 # ------------------------------------------------------------------------------------------------ the randomized sweep's 16-bit outliers, grounded
 def _fuzz_cases():
     import importlib.util
