@@ -9,7 +9,7 @@ configuration at hand, how far the oracle moves when its OWN arithmetic changes:
     f32     the oracle in float32 arithmetic vs the oracle in float64, same fp32 inputs (the reference, PyTorch fp32, is on this side),
     noise   the float64 oracle under `npert` independent 1e-6 relative perturbations of inputs and parameters, max over draws,
 
-both as max|difference| / max|tensor| per gradient tensor ("grad.<name>"), as |difference| / |loss| for "step.loss", and as max absolute parameter
+both as max|difference| / max|tensor| per gradient tensor ("grad.<name>") and forward output ("fwd.y_hat", "fwd.mag_hat", "fwd.mag": the atan2 branch cut), as |difference| / |loss| for "step.loss", and as max absolute parameter
 difference after one clip + Adam step ("train0.params").  gpu_checks.grounded() accepts a miss of the fixed tolerance only when the device's error
 is within 3 x that spread -- for ANY tensor, no names.
 """
@@ -33,23 +33,27 @@ def oracle_spread(B, seed, K=4, scale=1, scheme="lean", shrink=4, npert=8, steps
     lr = O.get_1cycle_schedule(lr_max=1e-3, n_data_points=200, epochs=1, batch_size=2)[0][0]
     P64 = {k: v.astype(np.float64) for k, v in P.items()}
     X64, K64, Y64 = X.astype(np.float64), KN.astype(np.float64), Y.astype(np.float64)
-    l0, G0, _ = O.model_loss_bwd(X64, K64, Y64, P64, geo)
+    l0, G0, c0 = O.model_loss_bwd(X64, K64, Y64, P64, geo)
     p0 = _step_params(G0, P, lr)
 
-    def diff(l1, G1):
+    def diff(l1, G1, c1):
         d = {"grad." + k.replace("mpaec.", ""): float(np.abs(G0[k] - G1[k]).max() / max(np.abs(G0[k]).max(), 1e-30)) for k in G0}
+        # the forward outputs have a spread too, rarely: atan2 is DISCONTINUOUS at its branch cut (re < 0, im ~ 0: phs jumps by 2 pi) and the phase autoencoder is
+        # not 2 pi-periodic, so a bin on the cut moves that window's y_hat by ~1e-4 under a 1e-6 perturbation (nn_proc.py:310, :326; found by the round-5 sweep at B = 64)
+        for nm, key in (("fwd.y_hat", "out"), ("step.y_hat", "out"), ("fwd.mag_hat", "mag_hat"), ("fwd.mag", "mag")):
+            d[nm] = float(np.abs(np.asarray(c0[key], np.float64) - np.asarray(c1[key], np.float64)).max() / max(np.abs(c0[key]).max(), 1e-30))
         d["step.loss"] = abs(l0 - l1) / abs(l0)
         p1 = _step_params(G1, P, lr)
         d["train0.params"] = float(max(np.abs(p0[k].astype(np.float64) - p1[k]).max() for k in p0))
         return d
-    l32, G32, _ = O.model_loss_bwd(X, KN, Y, P, geo)
-    out = {"f32": diff(float(l32), {k: v.astype(np.float64) for k, v in G32.items()}), "noise": {}}
+    l32, G32, c32 = O.model_loss_bwd(X, KN, Y, P, geo)
+    out = {"f32": diff(float(l32), {k: v.astype(np.float64) for k, v in G32.items()}, c32), "noise": {}}
     for s in range(npert):
         rng = np.random.default_rng(1000 + s)
         Pp = {k: v * (1 + 1e-6 * rng.standard_normal(v.shape)) for k, v in P64.items()}
         Xp = X64 * (1 + 1e-6 * rng.standard_normal(X64.shape))
-        l1, G1, _ = O.model_loss_bwd(Xp, K64, Y64, Pp, geo)
-        for k, v in diff(l1, G1).items():
+        l1, G1, c1 = O.model_loss_bwd(Xp, K64, Y64, Pp, geo)
+        for k, v in diff(l1, G1, c1).items():
             out["noise"][k] = max(out["noise"].get(k, 0.0), v)
     return out
 
