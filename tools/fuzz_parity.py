@@ -24,7 +24,7 @@ tests/test_gpu_parity.py::test_fuzz_outliers_grounded.
     python tools/fuzz_parity.py [seconds] [big]"""
 import sys, time, random; sys.path.insert(0, '.')
 from tests import gpu_checks as G
-random.seed(1234)
+random.seed(int(sys.argv[3]) if len(sys.argv) > 3 else 1234)
 BIG = len(sys.argv) > 2 and sys.argv[2] == "big"      # round 5: batches of 33..160 windows at the 8192-sample window -- where 128-row tiles of the frame-major row order hold one or two
                                                        # frames and the structural-zero skipping of st_gemm_tn.h / st_gemm16.h is active (the default draw stays below 19 windows: one tile holds every frame)
 t0 = time.time(); nbad = 0; n = 0
