@@ -111,7 +111,12 @@ int st_geometry(double scale_factor, double shrink_factor, int legacy, int K, in
  * total length in floats (or <0). */
 int64_t st_param_offsets(const st_dims* d, int64_t* offs /*[40]*/);
 
-/* Workspace sizes in bytes for st_model_fwd / st_train_step (pure functions of dims). */
+/* Workspace sizes in bytes for st_model_fwd / st_train_step (pure functions of dims).
+ * Contract on its contents: the library never reads a workspace element that the same step has not written -- but it does not write every element.
+ * Regions the trimmed kernels skip stay as the caller left them: the padding columns [F, FP) of both halves of every dAA slab (the data gradient
+ * covers the F spectral columns only; the autoencoder backward masks f >= F) and the 128-tap tile columns of frs that hold only cropped taps
+ * (st_ola_loss reads live taps only).  Zero-fill the buffer once after allocating it (signaltrain_amd.engine does: torch.zeros) if anything
+ * other than the library -- a debug dump, a new consumer -- is going to look at those regions; stale bytes there may read as NaN. */
 size_t st_workspace_bytes(const st_dims* d);
 
 /* ---------------------------------------------------------------- per-op entry points --- */
@@ -158,18 +163,29 @@ int st_synthesis_frames(const st_dims* d, const float* AA, const float* Sfold, f
  * out[i] = tile row (8 bits) | tile column (6) << 8 | slab (2) << 14 | first zero-filled slab (2; 0 = none) << 16 | kind (1; 1: the two Nyquist columns of a
  * tile row) << 18 | first k unit (6) << 19 | k units (7) << 25; rows are the live frames enumerated frame-major (row = (t' - t'_lo) * B + b);
  * head6 = {slabs, col_h, col_stride, B, k-tiles (of 32) per k unit, k-tiles of the whole reduction} (tile column c covers output columns
- * (128 c % col_h) + (128 c / col_h) * col_stride ... + 128; col_h = 0: 128 c).  ncus <= 0: the current device's CU count.
+ * (128 c % col_h) + (128 c / col_h) * col_stride ... + 128; col_h = 0: 128 c).  ncus <= 0: the current device's CU count; with ncus > 0 the result
+ * is a pure function of (d, which, ncus) -- no device query.
  * Returns the entry count (one workgroup each; more than ncus = several rounds), 0 if the geometry does not use this kernel. */
 int st_nt128_worklist(const st_dims* d, int which, int ncus, unsigned* out, int cap, int* head6);
 
+/* Diagnostics, host only: 1 if the frame-major row order may be used for a GEMM with R = (live frames) * B compact rows, i.e. if the kernels' division of a
+ * row index r < R by B through a multiply-high with floor(2^32 / B) + 1 is exact (r * B < 2^32 for every r); 0: those launches keep the window-major order
+ * and the untrimmed / uncropped tile sets.  (cls_fe_dft.py:28-31, :112-113: the trimming is an optimisation of the padded / cropped frames, never a
+ * change of results.) */
+int st_fm_div_exact(int R, int B);
+
 /* cls_fe_dft.py:112-113 overlap-add + crop, nn_proc.py:332,340 residual and x2,
  * loss_functions.py:9-10 log-cosh partial sums and d loss/d syn.
- * y_true may be NULL (inference): then only y_hat is produced. */
+ * y_true may be NULL (inference): then only y_hat is produced.
+ * loss_partial[b * st_ola_loss_partials() + s] = the sum over samples [256 s, 256 s + 256) of window b, always by the same summation tree
+ * (quads in sample order, then a balanced binary tree over the quad sums): the bits do not depend on the pointers' alignment, which only
+ * selects between the 16-byte and the 4-byte access form of the kernel. */
 int st_ola_loss(const st_dims* d, const float* frs, const float* x, const float* y_true,
                 float* y_hat, float* dsyn, float* loss_partial, void* stream);
 int st_ola_loss_partials(const st_dims* d);
 
-/* Backward of the synthesis GEMM wrt its input: dAA[B*OT,KP] = frames(dsyn) * Sfold^T. */
+/* Backward of the synthesis GEMM wrt its input: dAA[B*OT,KP] = frames(dsyn) * Sfold^T.  Columns [F, KP/2) and [KP/2 + F, KP) (the padding of the
+ * spectral pitch) are written as zeros by the small-tile kernels and LEFT AS THEY WERE by the work-list kernel (see st_workspace_bytes). */
 int st_synthesis_dgrad(const st_dims* d, const float* dsyn, const float* Sfold, float* dAA, void* stream);
 
 /* Weight gradient of the synthesis bases (folded then unfolded to Sr/Si [N,N]); also emits

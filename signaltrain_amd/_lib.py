@@ -73,6 +73,7 @@ SIGNATURES = {
     "st_synth_slabs": (_i, [_D]),
     "st_synth_frame_slabs": (_i, [_D]),
     "st_nt128_worklist": (_i, [_D, _i, _i, C.POINTER(C.c_uint), _i, C.POINTER(C.c_int)]),
+    "st_fm_div_exact": (_i, [_i, _i]),
     "st_synth_fold": (_i, [_D, _p, _p, _p, _p]),
     "st_synthesis_frames": (_i, [_D, _p, _p, _p, _p]),
     "st_ola_loss": (_i, [_D, _p, _p, _p, _p, _p, _p, _p]),

@@ -576,15 +576,21 @@ static double synth_crop_fraction(const st_dims* d)
     for (int t = ms.t_lo; t < ms.t_lo + ms.Tv; ++t) { int lo, hi; stg::ntw_live_taps(t, t, d->H, d->N, d->N, d->y, lo, hi); live += hi - lo; }
     return 1.0 - (double)live / ((double)ms.Tv * (double)d->N);
 }
+// the frame-major row order splits a compact row r < R = frames * B into (frame, window) with a multiply-high by the reciprocal of B
+// (RowMap::magic, rowmap_magic()), which is exact only while r * B < 2^32.  Every switch that turns the frame-major order on asks this first; past the bound
+// (B = 32768 at 7 live frames) the launch keeps the window-major order, i.e. the untrimmed / uncropped kernels of round 4.
+static inline bool fm_div_exact(int R, int B) { return R >= 0 && B >= 1 && (unsigned long long)(unsigned)R * (unsigned long long)(unsigned)B < (1ull << 32); }
+extern "C" int st_fm_div_exact(int R, int B) { return fm_div_exact(R, B) ? 1 : 0; }
 // the 128 x 128-tile work-list kernel (st_gemm_tn.h): fp32 products, up to 255 tile rows.  Used where one workgroup per CU covers the whole GEMM in one round (the rule
 // of rounds 3-4: small batches at any geometry) or where the crop is worth the frame-major row order (>= 10 % of the taps: every geometry of the 8192-sample window) --
 // several rounds are then fine (B = 512: 61 / 69 us against 107 / 107 on gemm_kernel<2, ...>).  MEASURED the other way at the 65536-sample window (B = 64, 4 % cropped, 510 workgroups
 // in two rounds): 80 / 77 us against 64 / 65 -- a tile's 128 rows there are 64 windows 194 KB apart; that geometry stays on the small-tile kernel.  Whether a list fits (and with
 // how many k-slices) is the builder's decision (ntw_frames / ntw_dgrad return false -> gemm_kernel<4, ...> / <2, ...>).
-static bool use_nt128(const st_dims* d, int M, int Nc)
+static bool use_nt128(const st_dims* d, int M, int Nc, int ncus = 0)      // a pure function of (d, ncus) once ncus > 0 (st_nt128_worklist's override: ADVICE round 5)
 {
-    if (!(g_nt128 && gemm_ht(d->prec) == 0 && d->N % 32 == 0 && (M + 127) / 128 <= 255)) return false;
-    return ((M + 127) / 128) * ((Nc + 127) / 128) * 2 <= num_cus() || synth_crop_fraction(d) >= 0.10;
+    if (!(g_nt128 && gemm_ht(d->prec) == 0 && d->N % 32 == 0 && (M + 127) / 128 <= 255 && fm_div_exact(M, d->B))) return false;
+    if (ncus <= 0) ncus = num_cus();
+    return ((M + 127) / 128) * ((Nc + 127) / 128) * 2 <= ncus || synth_crop_fraction(d) >= 0.10;
 }
 static int synthesis_frames_impl(const st_dims* d, const float* AA, const float* Sfold, const float* SfoldT, float* frs, void* stream)
 {
@@ -626,7 +632,7 @@ extern "C" int st_nt128_worklist(const st_dims* d, int which, int ncus, unsigned
     const int R = ms.rows(d->B);
     if (ncus <= 0) ncus = num_cus();
     stg::NTWork wk; wk.n = 0;
-    if (!use_nt128(d, R, which ? KP : d->N)) return 0;
+    if (!use_nt128(d, R, which ? KP : d->N, ncus)) return 0;
     const bool ok = which ? stg::ntw_dgrad(wk, ms, d->B, d->H, d->N, d->N, d->y, d->F, KP, R >= 4096 ? 1 : synth_split(R), ncus)
                           : stg::ntw_frames(wk, ms, d->B, d->H, d->N, d->N, d->y, KP, frames_split(R), ncus);
     if (!ok) return 0;
@@ -718,7 +724,7 @@ static bool use_tn128(const st_dims* d, bool padded)
 struct TNFrameMajor { stg::TNOperand a, b; stg::RowMap map; stg::FrameTrim trim; bool on; };
 static TNFrameMajor tn_frame_major(const stg::TNOperand& ta, const stg::TNOperand& tb, const stg::RowMap& live, int B, int H, int Ntaps, int pad, int Ls, bool enable)
 {
-    TNFrameMajor f; f.on = enable && B >= 2; f.a = ta; f.b = tb; f.map = live; f.trim = stg::FrameTrim{}; f.trim.on = 0;
+    TNFrameMajor f; f.on = enable && B >= 2 && fm_div_exact(live.Tv * B, B); f.a = ta; f.b = tb; f.map = live; f.trim = stg::FrameTrim{}; f.trim.on = 0;
     if (!f.on) return f;
     f.a = stg::TNOperand{ta.base + (size_t)live.t_lo * ta.S2, ta.S2, ta.S1};
     f.b = stg::TNOperand{tb.base + (size_t)live.t_lo * tb.S2, tb.S2, tb.S1};
@@ -1211,6 +1217,8 @@ extern "C" int st_debug_read_stage_cycles(unsigned long long* out32)
 
 // ------------------------------------------------------------------------------ workspace
 struct WS {
+    // dAA, frs: NOT every element is written per step (the pitch-padding columns [F, FP) of dAA's halves, the all-cropped tiles of frs): no consumer may read those -- the
+    // contract is stated at st_workspace_bytes in the header; the Python engine zero-fills the buffer once when it allocates it
     float *re, *im, *mag, *phs, *mag_hat, *phs_hat, *AA, *dAA, *Sfold, *SfoldT, *frs, *y_hat, *dsyn, *dmag, *dphs, *dG, *xp;
     float *wg, *aews, *loss_p, *reg_p, *norm_a, *norm_s, *norm_e;
     // bfloat16 planes of the operands that are written once per step (st_gemm_planes.h): [3][same layout as the fp32 tensor]
@@ -1385,7 +1393,7 @@ static int synthesis_frames16(const st_dims* d, WS& w, void* stream)
     const int KP = st_kp_of(d->F);
     const stg::RowMap ms = synth_live(d);
     const int R = ms.rows(d->B);
-    const bool crop = (g_g16_crop & 1) && d->N % 128 == 0;
+    const bool crop = (g_g16_crop & 1) && d->N % 128 == 0 && fm_div_exact(R, d->B);
     const stg::Rows16 ra = crop ? stg::rows16_frame_major(w.AA16, (unsigned)(d->OT * KP), (unsigned)KP, ms, d->B, R) : stg::rows16(w.AA16, (unsigned)(d->OT * KP), (unsigned)KP, ms, R);
     const stg::Rows16 rb = stg::rows16_plain(w.SfoldT16, (unsigned)KP, d->N);
     stg::StoreC ep{w.frs, R, d->N, d->N, (size_t)d->B * d->OT * d->N, crop ? stg::frame_major(ms, d->B) : ms};
@@ -1400,7 +1408,7 @@ static int synthesis_dgrad16(const st_dims* d, WS& w, void* stream)
     const int KP = st_kp_of(d->F);
     const stg::RowMap ms = synth_live(d);
     const int R = ms.rows(d->B);
-    const bool crop = (g_g16_crop & 2) && !(g_g16_dma & 2);
+    const bool crop = (g_g16_crop & 2) && !(g_g16_dma & 2) && fm_div_exact(R, d->B);
     const stg::Rows16 ra = crop ? stg::rows16_frame_major(w.dsyn16, (unsigned)(d->y + 2 * d->N), (unsigned)d->H, ms, d->B, R) : stg::rows16(w.dsyn16, (unsigned)(d->y + 2 * d->N), (unsigned)d->H, ms, R);
     const stg::Rows16 rb = stg::rows16_plain(w.Sfold16, (unsigned)d->N, KP);
     stg::StoreC ep{w.dAA, R, KP, KP, (size_t)d->B * d->OT * KP, crop ? stg::frame_major(ms, d->B) : ms};
@@ -1440,7 +1448,7 @@ static int wgrad16(const st_dims* d, const unsigned short* A, unsigned SA1, cons
     j.magic = map.magic; j.Tv = map.Tv; j.t_lo = map.t_lo; j.K = R;
     j.trim = 0; j.fB = 0; j.nsplit = 1;
     for (int i = 0; i < 64; ++i) { j.fa[i] = 0; j.fb[i] = 0; }
-    if (trim_Ls > 0 && d->B >= 2) {
+    if (trim_Ls > 0 && d->B >= 2 && fm_div_exact(R, d->B)) {
         const stg::FrameTrim ft = stg::frame_trim(map, d->B, d->H, d->N, d->N, trim_Ls);
         // (outer, inner) = (frame, window): the strides swap roles, the origins move to frame t_lo (the zero block stays where it is)
         j.a0 += (unsigned)map.t_lo * (unsigned)KP; j.b0 += (unsigned)map.t_lo * (unsigned)d->H;

@@ -105,9 +105,15 @@ ola_loss_kernel(const float* __restrict__ frs, const float* __restrict__ x, cons
             else dsyn[ro + (m < dsyn_pad ? m : ysz + m)] = 0.f;
         }
     }
-    if (loss_partial) {
-        const float tot = block_sum<4>(lc, red);
-        if (threadIdx.x == 0) loss_partial[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+    if (loss_partial) {      // the canonical tree of a slot (described at ola_loss4_kernel below): quads in sample order, then a balanced tree over the 64 quad sums
+        const int lane = threadIdx.x & 63, g = lane & ~3;
+        const float a0 = __shfl(lc, g), a1 = __shfl(lc, g + 1), a2 = __shfl(lc, g + 2), a3 = __shfl(lc, g + 3);
+        float q = ((a0 + a1) + a2) + a3;
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) q += __shfl_xor(q, o);      // the 16 quads of this wave: levels 1-4 of the tree
+        if (lane == 0) red[threadIdx.x >> 6] = q;
+        __syncthreads();
+        if (threadIdx.x == 0) loss_partial[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);      // levels 5 and 6
     }
 }
 
@@ -115,7 +121,10 @@ ola_loss_kernel(const float* __restrict__ frs, const float* __restrict__ x, cons
 // (at most three) frames x (at most three) slabs a sample quartet needs are 16-byte loads, all nine issued before the first add; same order of additions per sample as
 // ola_loss_kernel (frames outer, slabs inner): y_hat is bit-identical.  The scalar kernel issued 6 dword loads per frame (3 of them dummies) inside a run-time-bounded
 // loop -- 2-3 dependent round trips per thread, 3.1 TB/s at B = 256 and 2.0 TB/s at the 65536-sample window.  Loss partials keep their slot count (ceil(y / 256) per
-// window, st_ola_loss_partials): a block owns four consecutive slots, writes the first and zeroes the rest.
+// window, st_ola_loss_partials) AND their bits (the first version summed 1024 samples into one slot and zeroed three, so the loss depended on which kernel the
+// pointers' alignment selected): slot s = samples [256 s, 256 s + 256) of the window, summed by ONE tree in both kernels -- quads ((l0 + l1) + l2) + l3 in sample order, then the
+// balanced binary tree over the 64 quad sums by quad index (xor butterfly, offsets 1, 2, 4, ..., 32; a + b == b + a, so every lane holds the same bits).  Here a wave's 64 lanes
+// hold exactly the 64 quads of one slot; the scalar kernel gathers a quad from four lanes, runs levels 1-4 inside each wave and levels 5-6 over its four waves.
 template <int NS>
 __global__ void __launch_bounds__(256)
 ola_loss4_kernel(const float* __restrict__ frs, const float* __restrict__ x, const float* __restrict__ y_true,
@@ -123,7 +132,6 @@ ola_loss4_kernel(const float* __restrict__ frs, const float* __restrict__ x, con
                  int L, int N, int H, int OT, int ysz, float inv_count, size_t slab, int dsyn_pad, int nslot,
                  unsigned short* __restrict__ dsyn16 = nullptr, int ht = 0)
 {
-    __shared__ float red[4];
     const int b = blockIdx.y;
     const int j = 4 * (blockIdx.x * 256 + threadIdx.x);
     float lc = 0.f;
@@ -179,12 +187,12 @@ ola_loss4_kernel(const float* __restrict__ frs, const float* __restrict__ x, con
             else dsyn[ro + (m < dsyn_pad ? m : ysz + m)] = 0.f;
         }
     }
-    if (loss_partial) {
-        const float tot = block_sum<4>(lc, red);
-        if (threadIdx.x < 4) {
-            const int slot = 4 * blockIdx.x + threadIdx.x;
-            if (slot < nslot) loss_partial[blockIdx.y * nslot + slot] = threadIdx.x == 0 ? tot : 0.f;
-        }
+    if (loss_partial) {      // a wave's 64 quads ARE one slot (256 samples): the same tree as the scalar kernel's, no LDS, no barrier
+        float q = lc;        // ((l0 + l1) + l2) + l3, formed sequentially above
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) q += __shfl_xor(q, o);
+        const int slot = 4 * blockIdx.x + (threadIdx.x >> 6);
+        if ((threadIdx.x & 63) == 0 && slot < nslot) loss_partial[blockIdx.y * nslot + slot] = q;
     }
 }
 

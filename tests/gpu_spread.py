@@ -67,28 +67,40 @@ def case_tag(kw):
     return f"f32 B={kw['B']} K={kw.get('K', 4)} scale={kw.get('scale', 1)} {kw.get('scheme', 'lean')} shrink={kw.get('shrink', 4)} seed={kw['seed']}"
 
 
-def spread_of(kw, npert=8, cache=CACHE):
-    """oracle_spread(**kw), through the committed cache (fp32 arithmetic modes only: the rounding switches of the oracle are not part of the key)."""
+_MEM = {}      # spreads computed by THIS process for configurations the committed table does not hold
+
+
+def spread_of(kw, npert=8, cache=CACHE, write=False):
+    """oracle_spread(**kw), through the committed cache (fp32 arithmetic modes only: the rounding switches of the oracle are not part of the key).
+    The committed file is READ-ONLY here (pytest must not rewrite a tracked file, and the unlocked read-modify-write raced under
+    pytest-xdist): a configuration it does not hold is computed and kept in process memory.  Only tools/fuzz_ground_f32.py passes write=True."""
     plain = O.GEMM_ROUND is None and O.AE_ROUND is None and O.LOSS_SCALE == 1.0 and not O.CLIP_ALL
     tab = json.load(open(cache)) if (plain and os.path.isfile(cache)) else {}
     tg = case_tag(kw)
     if tg in tab:
         return tab[tg]
+    if plain and tg in _MEM:
+        return _MEM[tg]
     sp = oracle_spread(npert=npert, **{k: kw[k] for k in ("B", "seed", "K", "scale", "scheme", "shrink") if k in kw})
     if plain:
-        tab[tg] = sp
-        try:
-            json.dump(tab, open(cache, "w"), indent=1, sort_keys=True)
-        except OSError:
-            pass
+        _MEM[tg] = sp
+        if write:
+            tab[tg] = sp
+            tmp = cache + f".tmp{os.getpid()}"
+            json.dump(tab, open(tmp, "w"), indent=1, sort_keys=True)
+            os.replace(tmp, cache)
     return sp
+
+
+CAP_TOL = 10.0      # a grounded miss may never exceed this many times the check's own fixed tolerance, whatever the spread says
 
 
 def grounded(res, kw, mult=3.0, npert=8):
     """Re-grade the misses of gpu_checks.run_fused(**kw): a check that missed its fixed tolerance passes iff the device's error is within `mult` x the
     spread of that quantity for THIS configuration (max of f32-vs-f64 and self-noise).  Applies to every tensor the spread covers (all 40 gradient
     tensors, the loss, the parameters after the first step) -- no tensor is exempt by name, and checks the spread does not cover stay failures.
-    Returns the list of checks that remain failed; every re-graded check carries 'spread' and 'ratio'."""
+    The accepted error is capped at CAP_TOL x the check's fixed tolerance.  Returns the list of checks that remain failed; every re-graded check carries
+    'spread' and 'ratio'."""
     bad = [r for r in res if not r["ok"]]
     if not bad:
         return []
@@ -100,7 +112,9 @@ def grounded(res, kw, mult=3.0, npert=8):
             still.append(r); continue
         s = max(sp["f32"][key], sp["noise"].get(key, 0.0))
         r["spread"] = s; r["ratio"] = r["rel"] / s if s > 0 else float("inf")
-        if r["rel"] <= mult * s:
+        # accepted bound = min(mult x spread, CAP_TOL x the fixed tolerance): at a configuration with a large self-noise (a bin on atan2's branch cut moves
+        # y_hat by 2.4e-4, a near-silent bin moves an analysis-basis gradient by 1e-2) a genuinely wrong result of that size must not pass
+        if r["rel"] <= min(mult * s, CAP_TOL * r["tol"]):
             r["ok"] = True; r["grounded"] = True
         else:
             still.append(r)

@@ -358,6 +358,41 @@ def test_nt128_worklist_covers_exactly_the_live_taps(B, shrink):
         assert B > 1024
 
 
+def test_frame_major_division_bound_and_worklist_is_a_pure_function():
+    """ADVICE round 5.  (1) The frame-major row order splits a compact row r into (r // B, r % B) with a multiply-high by floor(2^32 / B) + 1
+    (st_gemm.h RowMap::magic); that is exact only while r * B < 2^32.  st_fm_div_exact is the host-side gate every frame-major switch asks: where it
+    says yes the multiply-high is exact for the rows near every multiple of B up to R (brute force on the boundary rows, where it fails first), and
+    just past the bound a wrong quotient exists (B = 32768 at 7 live frames: r >= 2^17 + ...).  (2) st_nt128_worklist with an explicit CU count
+    is a pure function of its arguments: two different counts give the lists their own cost model asks for, never the probed device's."""
+    lib = _lib.load()
+
+    def mulhi_div(r, B):
+        magic = (1 << 32) // B + 1
+        return (r * magic) >> 32
+
+    def first_wrong(R, B):
+        for q in range(1, R // B + 1):            # the quotient is first wrong just below a multiple of B (or at it)
+            for r in (q * B - 1, q * B):
+                if r < R and mulhi_div(r, B) != r // B:
+                    return r
+        return None
+
+    for B, Tv in [(256, 7), (1024, 23), (4096, 7), (24000, 7), (32768, 7), (40000, 7), (65536, 23), (9000, 46)]:
+        R = B * Tv
+        ok = lib.st_fm_div_exact(R, B)
+        assert ok == (1 if R * B < (1 << 32) else 0)
+        if ok:
+            assert first_wrong(R, B) is None
+    assert lib.st_fm_div_exact(7 * 32768, 32768) == 0 and first_wrong(7 * 32768, 32768) is not None       # the advisor's case really is wrong without the gate
+    # (2) purity in ncus: B = 3 has 1 tile row -- with 8 "CUs" the one-round rule fails, the crop rule (>= 10 % of the taps) still holds: the list does not depend on a device
+    d = _lib.geometry(1, 4, 4, 256)
+    out = (C.c_uint * 1024)(); head = (C.c_int * 6)()
+    n256 = lib.st_nt128_worklist(C.byref(d), 0, 256, out, 1024, head); a = list(out[:n256])
+    n256b = lib.st_nt128_worklist(C.byref(d), 0, 256, out, 1024, head); b = list(out[:n256b])
+    n304 = lib.st_nt128_worklist(C.byref(d), 0, 304, out, 1024, head)
+    assert n256 == n256b == 252 and a == b and n304 > 0
+
+
 def test_run_train_accepts_the_reference_effect_keys():
     """run_train.py --effect: the reference's keys (run_train.py:55-80).  comp_4c / comp_large / files are built (argument parsing only here: the run itself
     needs a GPU); the reference's other keys and unknown ones exit with a message that names what is available, as the reference does for unknown effects."""

@@ -611,3 +611,50 @@ def test_16bit_modes_against_the_unrounded_oracle(mode, level, half, kw):
     assert set(got) <= set(bounds), sorted(set(got) - set(bounds))
     over = {k: (v, bounds[k]) for k, v in got.items() if not (v[0] <= bounds[k])}
     assert not over, over
+
+
+@pytest.mark.parametrize("B,nslab_scale", [(3, 1), (5, 8)])
+def test_ola_loss_partials_do_not_depend_on_pointer_alignment(B, nslab_scale):
+    """st_ola_loss picks the four-samples-per-thread kernel when every pointer is 16-byte aligned and the one-sample kernel otherwise.
+    Both sum slot s = samples [256 s, 256 s + 256) of a window by the same tree, so the loss partials -- not only y_hat and d syn -- are bit-identical
+    whichever one runs (the first four-wide version summed 1024 samples into one slot and zeroed three).  The same buffers are handed over once aligned and
+    once from views that start 4 bytes into their allocation."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from signaltrain_amd import _lib
+    from tests import gpu_checks as G
+    lib = _lib.load()
+    geo, X, Y, KN, P = G.make_case(B=B, seed=20 + B, scale=nslab_scale)
+    d = G.dims_of(geo, B, 4)
+    N, OT, ysz, L = geo["N"], geo["OT"], geo["y"], geo["L"]
+    ns = lib.st_synth_frame_slabs(C.byref(d))
+    nlp = lib.st_ola_loss_partials(C.byref(d)) // B      # slots per window (the entry returns the whole array's length)
+    assert nlp == (ysz + 255) // 256
+    rng = np.random.default_rng(7)
+    frs_h = (0.05 * rng.standard_normal((ns, B * OT, N))).astype(np.float32)
+
+    def run(off):      # off floats into each allocation: 0 -> every pointer 16-byte aligned, 1 -> none
+        def buf(a):
+            flat = torch.zeros(a.size + 8, dtype=torch.float32, device=G.DEV)
+            v = flat[off:off + a.size]
+            v.copy_(torch.from_numpy(a.reshape(-1)).to(G.DEV))
+            return flat, v
+        keep = []
+        ptrs = []
+        for a in (frs_h, X, Y, np.zeros((B, ysz), np.float32), np.zeros((B, ysz), np.float32), np.zeros((B * nlp,), np.float32)):
+            flat, v = buf(a); keep.append((flat, v)); ptrs.append(C.c_void_p(v.data_ptr()))
+            assert (v.data_ptr() % 16 == 0) == (off == 0)
+        _lib.check(lib.st_ola_loss(C.byref(d), *ptrs, G.stream()), "ola")
+        torch.cuda.synchronize()
+        return [keep[i][1].cpu().numpy().copy() for i in (3, 4, 5)]
+
+    ya, da, la = run(0)
+    yb, db, lb = run(1)
+    assert np.array_equal(ya.view(np.uint32), yb.view(np.uint32)) and np.array_equal(da.view(np.uint32), db.view(np.uint32))
+    assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), f"loss partials differ: max {np.abs(la - lb).max():.3e}"
+    assert np.count_nonzero(la) == la.size      # every slot carries its own 256 samples (no zeroed slots)
+    # ... and they are the log-cosh sums (float64 reference from the device's own y_hat)
+    lc = np.zeros((B, nlp * 256)); lc[:, :ysz] = np.log(np.cosh(Y.astype(np.float64) - ya.reshape(B, ysz).astype(np.float64)))
+    ref = lc.reshape(B, nlp, 256).sum(-1).reshape(-1)
+    assert np.allclose(la, ref, rtol=2e-5, atol=1e-7)

@@ -63,7 +63,7 @@ def main():
     for mode, kw in CASES:
         tg = tag("f32", kw)                # the spread is a property of the configuration, not of the device mode (f32x3 is checked against the fp32 oracle too)
         assert tg == S.case_tag(kw)
-        spread[tg] = S.spread_of(kw, npert=NPERT)      # through the committed cache (profiles/r05_fuzz_f32_spread.json)
+        spread[tg] = S.spread_of(kw, npert=NPERT, write=True)      # through the committed cache (profiles/r05_fuzz_f32_spread.json)
         s = spread[tg]
         print(f"[spread] {tg}: " + ", ".join(f"{k.replace('grad.dft_analysis.conv_analysis_', 'g.an_').replace('.weight', '')} f32-vs-f64 {s['f32'].get(k, 0):.1e} / self-noise {s['noise'].get(k, 0):.1e}" for k in AN), flush=True)
     if not gpu:
