@@ -345,15 +345,16 @@ __device__ __forceinline__ void layer5_fwd(const float* const (&lw)[NC], const f
 // tails (t = T-OT + 4g + r, OT <= 16).  Loaded in one burst and prefetched one group ahead.
 struct FwdIn { f32x4 v[2][2]; float tl[2][4]; float kn[4]; };   // kn: knob 4q + g for the (up to 4) knob k-steps of layer 5
 
-// RAW loads from clamped (always valid) addresses; fwd_mask() zeroes the padding rows / bins / knobs afterwards.  The
+// RAW loads from clamped (always valid) addresses; the fwd_mask_*() zero the padding rows / bins / knobs afterwards.  The
 // selects must not sit right behind the loads, and the prefetch must not sit in a conditional block: either makes the
 // compiler wait for the loads on the spot, turning the one-group-ahead prefetch into a synchronous load.
-__device__ __forceinline__ void fwd_load(FwdIn& in, const float* __restrict__ mag, const float* __restrict__ phs,
-                                         const float* __restrict__ knobs, const int K,
-                                         const int b, const int f, const bool fv, const int T, const int OT, const int F, const int g)
+// Round 6: three parts.  Only the input rows (consumed by layer 1 at the very top) are prefetched one group ahead; the knobs (layer 5) and the tails (epilogue)
+// of a group are loaded at ITS top and masked where they are consumed -- 12 fewer loop-carried registers (the kernel with the kept activations spilled at three
+// waves per SIMD, and a spill reload in the epilogue waits for every store issued before it).  In-place refills of loop-carried registers were tried and
+// removed: a refill that meets its older value at the loop latch is COPIED there, and the copy waits for the load on the spot.
+__device__ __forceinline__ void fwd_load_v(FwdIn& in, const float* __restrict__ mag, const float* __restrict__ phs,
+                                           const int b, const int f, const bool fv, const int T, const int F, const int g)
 {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { const int kn = 4 * q + g; in.kn[q] = ldg32(knobs, ST_MUL24(b, K) + (unsigned)(kn < K ? kn : 0)); }
     const unsigned base = ST_MUL24(ST_MUL24(b, T), F) + (unsigned)(fv ? f : 0);
 #pragma unroll
     for (int it = 0; it < 2; ++it)
@@ -363,6 +364,16 @@ __device__ __forceinline__ void fwd_load(FwdIn& in, const float* __restrict__ ma
             const unsigned o = base + ST_MUL24(t < T ? t : 0, F);
             in.v[0][it][r] = ldg32(mag, o); in.v[1][it][r] = ldg32(phs, o);
         }
+}
+__device__ __forceinline__ void fwd_load_kn(FwdIn& in, const float* __restrict__ knobs, const int K, const int b, const int g)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int kn = 4 * q + g; in.kn[q] = ldg32(knobs, ST_MUL24(b, K) + (unsigned)(kn < K ? kn : 0)); }
+}
+__device__ __forceinline__ void fwd_load_tl(FwdIn& in, const float* __restrict__ mag, const float* __restrict__ phs,
+                                            const int b, const int f, const bool fv, const int T, const int OT, const int F, const int g)
+{
+    const unsigned base = ST_MUL24(ST_MUL24(b, T), F) + (unsigned)(fv ? f : 0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int to = 4 * g + r;
@@ -370,23 +381,69 @@ __device__ __forceinline__ void fwd_load(FwdIn& in, const float* __restrict__ ma
         in.tl[0][r] = ldg32(mag, o); in.tl[1][r] = ldg32(phs, o);
     }
 }
-__device__ __forceinline__ void fwd_mask(FwdIn& in, const int K, const bool fv, const int T, const int OT, const int g)
+__device__ __forceinline__ void fwd_mask_v(f32x4 (&v)[2][2], const FwdIn& in, const bool fv, const int T, const int g)
 {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) in.kn[q] = (4 * q + g) < K ? in.kn[q] : 0.f;
 #pragma unroll
     for (int it = 0; it < 2; ++it)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool ok = fv && 16 * it + 4 * g + r < T;
-            in.v[0][it][r] = ok ? in.v[0][it][r] : 0.f; in.v[1][it][r] = ok ? in.v[1][it][r] : 0.f;
+            v[0][it][r] = ok ? in.v[0][it][r] : 0.f; v[1][it][r] = ok ? in.v[1][it][r] : 0.f;
         }
+}
+__device__ __forceinline__ void fwd_mask_kn(float (&kn)[4], const FwdIn& in, const int K, const int g)
+{
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const bool ok = fv && 4 * g + r < OT; in.tl[0][r] = ok ? in.tl[0][r] : 0.f; in.tl[1][r] = ok ? in.tl[1][r] : 0.f; }
+    for (int q = 0; q < 4; ++q) kn[q] = (4 * q + g) < K ? in.kn[q] : 0.f;
+}
+__device__ __forceinline__ void fwd_mask_tl(float (&tl)[2][4], const FwdIn& in, const bool fv, const int OT, const int g)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const bool ok = fv && 4 * g + r < OT; tl[0][r] = ok ? in.tl[0][r] : 0.f; tl[1][r] = ok ? in.tl[1][r] : 0.f; }
+}
+
+// Round 6: the post-ELU activations of both nets KEPT for the backward (what the reference's autograd keeps, nn_proc.py:77-126) instead of being recomputed there.
+// Per (net, 16-row group) 17 tiles of 16 x 16 in D layout, [net][group][tile][lane] float4: h1 tiles 0-3, h2 4-5, h3 6, h4 7, h5 8, h6 9, h7 10-11, h8 12-15,
+// ELU(a9) 16 -- every store / load is one fully coalesced 1 KB access per wave, 17 KB per (net, group), 2 * groups * 17 KB per step (294 MB at B = 256).
+constexpr int AE_SV_TILES = 17;
+#ifndef ST_SV_NT
+#define ST_SV_NT 1
+#endif
+// p: WAVE-UNIFORM base of the (net, group) block (the callers pass the group through readfirstlane), lane16 = lane * 16: the accesses compile to the
+// saddr + 32-bit voffset form with the tile as an immediate / scalar offset -- no 64-bit vector address per access.
+template <int NTL>
+__device__ __forceinline__ void sv_store(float* __restrict__ p, const unsigned lane16, const int tile0, const f32x4 (&h)[NTL])
+{
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        f32x4* q = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p + (tile0 + t) * 256) + (size_t)lane16);
+#ifdef ST_SV_X2
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(__builtin_shufflevector(h[t], h[t], 0, 1), reinterpret_cast<f32x2_t*>(q));
+        __builtin_nontemporal_store(__builtin_shufflevector(h[t], h[t], 2, 3), reinterpret_cast<f32x2_t*>(q) + 1);
+#elif ST_SV_NT & 1
+        __builtin_nontemporal_store(h[t], q);
+#else
+        *q = h[t];
+#endif
+    }
+}
+template <int NTL>
+__device__ __forceinline__ void sv_load(const float* __restrict__ p, const unsigned lane16, const int tile0, f32x4 (&h)[NTL])
+{
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const f32x4* q = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p + (tile0 + t) * 256) + (size_t)lane16);
+#if ST_SV_NT & 2
+        h[t] = __builtin_nontemporal_load(q);
+#else
+        h[t] = *q;
+#endif
+    }
 }
 
 // grid.x workgroups of NW waves; each wave walks 16-row groups: group id = b*(FP/16) + fg.  Requires T <= 32, OT <= 16, K <= 16.
-template <int NW, int BF = 0>      // BF: bf16 operands in the nine Linear layers (st_set_precision(2))
+template <int NW, int BF = 0, bool SV = false>      // BF: bf16 operands in the nine Linear layers (st_set_precision(2)); SV: keep the activations (sv != NULL)
 __global__ void __launch_bounds__(NW * 64)
 ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, const float* __restrict__ knobs,
               const float* __restrict__ ae_m, const float* __restrict__ ae_p, const AEOffsets go,
@@ -395,8 +452,9 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
               const int B, const int T, const int OT, const int F, const int K, const int KP, const float expfac,
               float* __restrict__ h4x = nullptr,      // optional: the 16-wide code h4 of both nets, [net][group][lane] float4 in D layout, for
                                                       // the split backward (st_ae_split.h); mag_hat == NULL: h4 only (no other output is written)
-              unsigned short* __restrict__ AA16 = nullptr, const int aa_ht = 0)      // 16-bit GEMM configurations (st_gemm16.h): the spectra go out rounded to
+              unsigned short* __restrict__ AA16 = nullptr, const int aa_ht = 0,      // 16-bit GEMM configurations (st_gemm16.h): the spectra go out rounded to
                                                       // the operand type (1 bf16 / 2 fp16) INSTEAD of fp32 -- their only consumers are the two synthesis GEMMs
+              float* __restrict__ sv = nullptr)       // SV: the kept activations of both nets (layout above)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -417,45 +475,57 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     for (int r = 0; r < 4; ++r) { toF[r] = ST_MUL24(4 * g + r, F); toK[r] = ST_MUL24(4 * g + r, KP); }
     __syncthreads();
 
-    FwdIn cur;
+    f32x4 vin[2][2];      // masked input rows of the current group (loop-carried: taken over from the prefetch at the end of the previous iteration)
     // block-fastest group numbering: the partial last round (ngroups is rarely a multiple of the wave count) then puts ONE
     // extra group on every workgroup instead of a full extra round on the first few workgroups while the rest idle
     const GroupWalk gw = fwd_group_walk(ngroups, NW, wave);      // XCD-contiguous since round 4 (above)
     int grp = gw.first;
     if (grp < gw.end) {
         const int b = grp / gpw, f = (grp - b * gpw) * 16 + c;
-        fwd_load(cur, mag, phs, knobs, K, b, f, f < F, T, OT, F, g);
-        fwd_mask(cur, K, f < F, T, OT, g);
+        FwdIn first; fwd_load_v(first, mag, phs, b, f, f < F, T, F, g); fwd_mask_v(vin, first, f < F, T, g);
     }
     for (; grp < gw.end; grp += gw.stride) {
         asm volatile("" ::: "memory");      // keep the (loop-invariant) LDS weight fetches inside the loop: hoisting them spills
         const int b = grp / gpw, f = (grp - b * gpw) * 16 + c;
         const bool fv = f < F;
-        FwdIn nxt;
         const int gn = grp + gw.stride < gw.end ? grp + gw.stride : grp;      // last iteration: harmless reload of this group
         const int bn = gn / gpw, fn = (gn - bn * gpw) * 16 + c;
-        fwd_load(nxt, mag, phs, knobs, K, bn, fn, fn < F, T, OT, F, g);
+        FwdIn cur;      // RAW loads: the NEXT group's input rows, THIS group's knobs and tails
+        fwd_load_v(cur, mag, phs, bn, fn, fn < F, T, F, g); fwd_load_kn(cur, knobs, K, b, g); fwd_load_tl(cur, mag, phs, b, f, fv, T, OT, F, g);
 
         f32x4 h1[2][4], h2[2][2], h3[2][1], h4[2][1], h5[2][1], h6[2][1], h7[2][2], h8[2][4], e9[2][1];
-        { const float* const W[2] = ST_W2(CL::A0); const float* const bb[2] = ST_W2(CL::B0); layer_fwd<2, 4, 2, CL::O0, BF>(W, bb, cur.v, h1, g, c); }
-        { const float* const W[2] = ST_W2(CL::A1); const float* const bb[2] = ST_W2(CL::B1); layer_fwd<2, 2, 4, CL::O1, BF>(W, bb, h1, h2, g, c); }
-        { const float* const W[2] = ST_W2(CL::A2); const float* const bb[2] = ST_W2(CL::B2); layer_fwd<2, 1, 2, CL::O2, BF>(W, bb, h2, h3, g, c); }
-        { const float* const W[2] = ST_W2(CL::A3); const float* const bb[2] = ST_W2(CL::B3); layer_fwd<2, 1, 1, CL::O3, BF>(W, bb, h3, h4, g, c); }
+        // kept activations: wave-uniform bases of (net 0, grp) and (net 1, grp) -- net 1 sits ngroups * 17 KB further on
+        const int grp_u = SV ? __builtin_amdgcn_readfirstlane(grp) : 0;
+#ifdef ST_SV_DIAG
+        float* const sv0 = SV ? sv + (size_t)(grp_u & ST_SV_DIAG) * (AE_SV_TILES * 256) : nullptr;      // timing only: every store stays in the L2 / MALL
+#else
+        float* const sv0 = SV ? sv + (size_t)grp_u * (AE_SV_TILES * 256) : nullptr;
+#endif
+        float* const sv1 = SV ? sv0 + (size_t)ngroups * (AE_SV_TILES * 256) : nullptr;
+        const unsigned lane16 = (unsigned)lane << 4;
+#define ST_SV(t0_, h_) do { if constexpr (SV) { sv_store(sv0, lane16, t0_, h_[0]); sv_store(sv1, lane16, t0_, h_[1]); } } while (0)
+        { const float* const W[2] = ST_W2(CL::A0); const float* const bb[2] = ST_W2(CL::B0); layer_fwd<2, 4, 2, CL::O0, BF>(W, bb, vin, h1, g, c); } ST_SV(0, h1);
+        { const float* const W[2] = ST_W2(CL::A1); const float* const bb[2] = ST_W2(CL::B1); layer_fwd<2, 2, 4, CL::O1, BF>(W, bb, h1, h2, g, c); } ST_SV(4, h2);
+        { const float* const W[2] = ST_W2(CL::A2); const float* const bb[2] = ST_W2(CL::B2); layer_fwd<2, 1, 2, CL::O2, BF>(W, bb, h2, h3, g, c); } ST_SV(6, h3);
+        { const float* const W[2] = ST_W2(CL::A3); const float* const bb[2] = ST_W2(CL::B3); layer_fwd<2, 1, 1, CL::O3, BF>(W, bb, h3, h4, g, c); } ST_SV(7, h4);
         if (h4x) {
             float4* hv = reinterpret_cast<float4*>(h4x);
             hv[(size_t)grp * 64 + lane] = make_float4(h4[0][0][0], h4[0][0][1], h4[0][0][2], h4[0][0][3]);
             hv[((size_t)ngroups + grp) * 64 + lane] = make_float4(h4[1][0][0], h4[1][0][1], h4[1][0][2], h4[1][0][3]);
         }
-        if (!mag_hat) { fwd_mask(nxt, K, fn < F, T, OT, g); cur = nxt; continue; }     // h4-only pass (wave-uniform)
-        layer5_fwd<2, BF>(lw, h4, cur.kn, KQ, h5, g, c);
-        { const float* const W[2] = ST_W2(CL::A5); const float* const bb[2] = ST_W2(CL::B5); layer_fwd<2, 1, 1, CL::O5, BF>(W, bb, h5, h6, g, c); }
-        { const float* const W[2] = ST_W2(CL::A6); const float* const bb[2] = ST_W2(CL::B6); layer_fwd<2, 2, 1, CL::O6, BF>(W, bb, h6, h7, g, c); }
-        { const float* const W[2] = ST_W2(CL::A7); const float* const bb[2] = ST_W2(CL::B7); layer_fwd<2, 4, 2, CL::O7, BF>(W, bb, h7, h8, g, c); }
-        { const float* const W[2] = ST_W2(CL::A8); const float* const bb[2] = ST_W2(CL::B8); layer_fwd<2, 1, 4, CL::O8, BF>(W, bb, h8, e9, g, c); }
+        if (mag_hat) {                                                           // else: h4-only pass (wave-uniform)
+        float knv[4]; fwd_mask_kn(knv, cur, K, g);
+        layer5_fwd<2, BF>(lw, h4, knv, KQ, h5, g, c); ST_SV(8, h5);
+        { const float* const W[2] = ST_W2(CL::A5); const float* const bb[2] = ST_W2(CL::B5); layer_fwd<2, 1, 1, CL::O5, BF>(W, bb, h5, h6, g, c); } ST_SV(9, h6);
+        { const float* const W[2] = ST_W2(CL::A6); const float* const bb[2] = ST_W2(CL::B6); layer_fwd<2, 2, 1, CL::O6, BF>(W, bb, h6, h7, g, c); } ST_SV(10, h7);
+        { const float* const W[2] = ST_W2(CL::A7); const float* const bb[2] = ST_W2(CL::B7); layer_fwd<2, 4, 2, CL::O7, BF>(W, bb, h7, h8, g, c); } ST_SV(12, h8);
+        { const float* const W[2] = ST_W2(CL::A8); const float* const bb[2] = ST_W2(CL::B8); layer_fwd<2, 1, 4, CL::O8, BF>(W, bb, h8, e9, g, c); } ST_SV(16, e9);
+#undef ST_SV
         // ---- epilogue (nn_proc.py:115,117,322-326).  Round 4: the frequency weight comes from a per-workgroup LDS table (was a full-precision expf per
         // group), the row offsets of a lane's four output frames are formed once before the loop, and the 16-bit type of the spectra is a compile-time
         // constant in the 16-bit instantiations (it was converted BOTH ways and selected at run time): 785 -> ~700 vector instructions per row-group pair
         const float wf = fv ? wtab[f] : 0.f;                     // train.py:115-117 frequency weight exp(expfac * f)
+        float tlv[2][4]; fwd_mask_tl(tlv, cur, fv, OT, g);
         const unsigned boF = ST_MUL24(ST_MUL24(b, OT), F) + (unsigned)f, boK = ST_MUL24(ST_MUL24(b, OT), KP) + (unsigned)f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -463,8 +533,8 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             if (to < OT) {
                 float mh = 0.f, ph = 0.f, sn = 0.f, cs = 1.f;
                 if (fv) {
-                    mh = e9[0][0][r] * cur.tl[0][r];               // 'sf' skip-filter
-                    ph = e9[1][0][r] + cur.tl[1][r];               // phase residual
+                    mh = e9[0][0][r] * tlv[0][r];               // 'sf' skip-filter
+                    ph = e9[1][0][r] + tlv[1][r];               // phase residual
                     st_sincos(ph, sn, cs);
                     stg32(mag_hat, boF + toF[r], mh);
                     stg32(phs_hat, boF + toF[r], ph);
@@ -480,7 +550,8 @@ ae_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
                 }
             }
         }
-        fwd_mask(nxt, K, fn < F, T, OT, g); cur = nxt;
+        }
+        fwd_mask_v(vin, cur, fn < F, T, g);                                     // take over the next group's input rows
     }
     if (reg_partial) {
         reg = wave_sum(reg);
@@ -787,7 +858,11 @@ constexpr int ae_bwd_lds_floats(int nw) { return (CL::BWD_TOTAL + nw * AE_BWD_SC
 // bit 1 = T - OT == 16 (the default geometry): the skip-filter tails mag[b, T-OT+t', f] ARE the second input tile already in
 // registers.  Both exist to cut global-load INSTRUCTIONS: the four waves of a workgroup issue their ~50 scattered dword loads
 // per group at the same moment and queue at the CU's one address path (the "loads issue" stage was 11 % of a group).
-template <int NW, bool TIMED, bool INNER = false, int BF = 0, int VAR = 1>      // BF: 16-bit operands in all Linear-layer products (ST_PREC_*_ALL)
+// SAVED (round 6; fused geometries, fp32): no forward recompute -- the post-ELU activations come from the buffer the forward kernel kept (ae_fwd_kernel<.., SV>;
+// ELU' needs only the OUTPUT of ELU).  A third of the kernel's MFMAs, the ELU transcendentals and the forward fragment reads go; with nothing left at the top
+// of a group to hide a memory round trip behind, EVERY per-group input is loaded one full group ahead and IN PLACE: right behind the last use of a register
+// set in this group, the same registers are refilled for the next one (no second buffer, no copies).
+template <int NW, bool TIMED, bool INNER = false, int BF = 0, int VAR = 1, bool SAVED = false>      // BF: 16-bit operands in all Linear-layer products (ST_PREC_*_ALL)
 __global__ void __launch_bounds__(NW * 64, 1)
 ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, const float* __restrict__ knobs,
               const float* __restrict__ ae_m, const float* __restrict__ ae_p, const AEOffsets go, const int PG,
@@ -797,8 +872,9 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
               const int B, const int T, const int OT, const int F, const int K, const int KP,
               const int to_lo, const int to_hi,      // live synthesis frames: dAA rows outside are treated as zero
               const int nslab, const size_t slab,     // dAA arrives as split-K slabs of the synthesis dgrad GEMM
-              const int dbg)
+              const int dbg, const float* __restrict__ sv = nullptr)      // SAVED: the kept activations ([net][group][17 tiles][lane] float4)
 {
+    static_assert(!SAVED || (!INNER && BF == 0), "the kept-activation backward exists for the fused fp32 geometries");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int ae = blockIdx.y;
     const bool timing = TIMED && (dbg & 256) && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x >> 6) == 0;
@@ -877,45 +953,67 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
     if (grp < ngroups) { load_kn(grp, kn, knT); mask_kn(kn, knT); }
     const unsigned Rw = (unsigned)B * FP;              // INNER: columns of the feature-major buffers
 
+    constexpr bool GM = (VAR & 1) != 0, TAIL16 = (VAR & 2) != 0;
+    // d-out inputs of a group (D layout: t' = 4g + r): RAW loads from clamped addresses, nothing consumed here
+    float q_x[4][3], q_y[4][3], q_ph[4], q_mh[4], q_mt[4], q_gm[4];
+    auto load_q = [&](const int gq) {
+        const int bq = gq / gpw, fq0 = (gq - bq * gpw) * 16 + c;
+        const bool fvq = fq0 < F;
+        const int fq = fvq ? fq0 : 0;
+        // wave-uniform base pointers for the slabs and the imaginary half: the six dAA loads of a row share ONE offset register
+        const size_t o1 = nslab > 1 ? slab : 0, o2 = nslab > 2 ? 2 * slab : 0;
+        const float* const dA0 = dAA, * const dA1 = dAA + o1, * const dA2 = dAA + o2;
+        const float* const dB0 = dA0 + FP, * const dB1 = dA1 + FP, * const dB2 = dA2 + FP;
+        const unsigned bOT = ST_MUL24(bq, OT), btF = ST_MUL24(ST_MUL24(bq, T), F) + (unsigned)fq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int to = 4 * g + r;
+            const bool ok = fvq && to < OT;
+            const bool lv = ok && to >= to_lo && to <= to_hi;
+            const unsigned ro = bOT + (unsigned)(ok ? to : 0);
+            // up to 3 split-K slabs: all six loads are issued together (a runtime-trip-count loop here serialised ~12
+            // memory round trips per group)
+            const unsigned p0 = ST_MUL24(lv ? ro : 0u, KP) + (unsigned)fq;
+            const unsigned pF = ST_MUL24(ro, F) + (unsigned)fq;
+#if ST_AE_ABLATE & 1
+            q_x[r][0] = q_x[r][1] = q_x[r][2] = q_y[r][0] = q_y[r][1] = q_y[r][2] = 1e-3f * (float)(p0 & 7); q_ph[r] = 0.3f; q_mh[r] = 0.2f + 1e-3f * (float)(pF & 3);
+#else
+            q_x[r][0] = ldg32(dA0, p0); q_x[r][1] = ldg32(dA1, p0); q_x[r][2] = ldg32(dA2, p0);
+            q_y[r][0] = ldg32(dB0, p0); q_y[r][1] = ldg32(dB1, p0); q_y[r][2] = ldg32(dB2, p0);
+            q_ph[r] = ldg32(phs_hat, pF); q_mh[r] = ldg32(mag_hat, pF);
+#endif
+            if constexpr (GM) q_gm[r] = ldg32(g_mag_hat, pF); else q_gm[r] = 0.f;
+            if constexpr (!TAIL16) q_mt[r] = ldg32(vin, btF + ST_MUL24(ok ? T - OT + to : 0, F));
+        }
+    };
+    // SAVED: the kept activations of this net, loop-carried -- tiles of the NEXT group replace a set right behind its last use
+    f32x4 s_h1[4], s_h2[2], s_h3[1], s_h4[1], s_h5[1], s_h6[1], s_h7[2], s_h8[4], s_e9[1];
+    const float* const svn = SAVED ? sv + (size_t)ae * ngroups * (AE_SV_TILES * 256) : nullptr;
+    const unsigned lane16 = (unsigned)lane << 4;
+#ifdef ST_SV_DIAG
+    auto svp = [&](const int gq) { return svn + (size_t)(__builtin_amdgcn_readfirstlane(gq) & ST_SV_DIAG) * (AE_SV_TILES * 256); };
+#else
+    auto svp = [&](const int gq) { return svn + (size_t)__builtin_amdgcn_readfirstlane(gq) * (AE_SV_TILES * 256); };      // wave-uniform
+#endif
+    if constexpr (SAVED) {
+        if (grp < ngroups) {
+            load_q(grp);
+            const float* const p = svp(grp);
+            sv_load(p, lane16, 16, s_e9); sv_load(p, lane16, 12, s_h8); sv_load(p, lane16, 10, s_h7); sv_load(p, lane16, 9, s_h6); sv_load(p, lane16, 8, s_h5);
+            sv_load(p, lane16, 7, s_h4); sv_load(p, lane16, 6, s_h3); sv_load(p, lane16, 4, s_h2); sv_load(p, lane16, 0, s_h1);
+        }
+    }
+
     for (; grp < ngroups; grp += gstride) {
+        ST_T(16);
         asm volatile("" ::: "memory");      // keep the (loop-invariant) LDS weight fetches inside the loop
         const int b = grp / gpw, f = (grp - b * gpw) * 16 + c;
         const bool fv = f < F;
-        const int fq = fv ? f : 0;
         // ---- d-out inputs for this group (D layout: t' = 4g + r), issued early.  (Slicing these 53 loads between the
         // forward stages to overlap their issue with MFMA execution was measured: no gain.)
         // Raw values only: the slab sums and masks are formed in the d-out stage -- arithmetic on a loaded value up here
         // makes the wave wait in the middle of the burst (the memory counter is in-order).
-        constexpr bool GM = (VAR & 1) != 0, TAIL16 = (VAR & 2) != 0;
-        float q_x[4][3], q_y[4][3], q_ph[4], q_mh[4], q_mt[4], q_gm[4];
-        if constexpr (!INNER) {
-            // wave-uniform base pointers for the slabs and the imaginary half: the six dAA loads of a row share ONE offset register
-            const size_t o1 = nslab > 1 ? slab : 0, o2 = nslab > 2 ? 2 * slab : 0;
-            const float* const dA0 = dAA, * const dA1 = dAA + o1, * const dA2 = dAA + o2;
-            const float* const dB0 = dA0 + FP, * const dB1 = dA1 + FP, * const dB2 = dA2 + FP;
-            const unsigned bOT = ST_MUL24(b, OT), btF = ST_MUL24(ST_MUL24(b, T), F) + (unsigned)fq;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int to = 4 * g + r;
-                const bool ok = fv && to < OT;
-                const bool lv = ok && to >= to_lo && to <= to_hi;
-                const unsigned ro = bOT + (unsigned)(ok ? to : 0);
-                // up to 3 split-K slabs: all six loads are issued together (a runtime-trip-count loop here serialised ~12
-                // memory round trips per group)
-                const unsigned p0 = ST_MUL24(lv ? ro : 0u, KP) + (unsigned)fq;
-                const unsigned pF = ST_MUL24(ro, F) + (unsigned)fq;
-#if ST_AE_ABLATE & 1
-                q_x[r][0] = q_x[r][1] = q_x[r][2] = q_y[r][0] = q_y[r][1] = q_y[r][2] = 1e-3f * (float)(p0 & 7); q_ph[r] = 0.3f; q_mh[r] = 0.2f + 1e-3f * (float)(pF & 3);
-#else
-                q_x[r][0] = ldg32(dA0, p0); q_x[r][1] = ldg32(dA1, p0); q_x[r][2] = ldg32(dA2, p0);
-                q_y[r][0] = ldg32(dB0, p0); q_y[r][1] = ldg32(dB1, p0); q_y[r][2] = ldg32(dB2, p0);
-                q_ph[r] = ldg32(phs_hat, pF); q_mh[r] = ldg32(mag_hat, pF);
-#endif
-                if constexpr (GM) q_gm[r] = ldg32(g_mag_hat, pF); else q_gm[r] = 0.f;
-                if constexpr (TAIL16) q_mt[r] = vr[1][r];          // t = T - OT + 4g + r = 16 + 4g + r: input tile 1 of this lane (already masked)
-                else q_mt[r] = ldg32(vin, btF + ST_MUL24(ok ? T - OT + to : 0, F));
-            }
-        }
+        if constexpr (!INNER && !SAVED) load_q(grp);
         // INNER: layer-1 outputs in both layouts and the gradient entering layer 8's output, straight from the
         // feature-major buffers (D layout: feature 16 tile + 4g + r at column col0 + c)
         f32x4 h1in[4], dh8[4];
@@ -944,6 +1042,18 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         // Rolling fragment prefetch: each stage first issues the LDS reads of the NEXT layer's fragments, then runs its own
         // MFMA chain, so no stage starts by waiting for an LDS round trip (one wave per SIMD: nothing else would hide it).
         f32x4 h1[4], h2[2], h3[1], h4[1], h5[1], h6[1], h7[2], h8[4], e9[1];
+        f32x4 fr9[1 * 4];
+        if constexpr (SAVED) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Vs[(16 * it + 4 * g + r) * SP + c] = vr[it][r];   // [feature t][row c]: read back transposed for the layer-1 wgrad
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { h1[k] = s_h1[k]; h8[k] = s_h8[k]; }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { h2[k] = s_h2[k]; h7[k] = s_h7[k]; }
+            h3[0] = s_h3[0]; h4[0] = s_h4[0]; h5[0] = s_h5[0]; h6[0] = s_h6[0]; e9[0] = s_e9[0];
+        } else {
         f32x4 fr2[2 * 4];
         if constexpr (INNER) {
 #pragma unroll
@@ -973,10 +1083,10 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         f32x4 fr7[2 * 1]; frags_fwd<2, 1, CL::O6, BF>(fr7, lw + CL::A6, g, c); ST_FENCE(); fwdD_fr<1, 1, BF>(fr6, lw + CL::B5, h5, h6, g);
         f32x4 fr8[4 * 2]; frags_fwd<4, 2, CL::O7, BF>(fr8, lw + CL::A7, g, c); ST_FENCE(); fwdD_fr<2, 1, BF>(fr7, lw + CL::B6, h6, h7, g);
         ST_T(4);
-        f32x4 fr9[1 * 4];
         if constexpr (!INNER) frags_fwd<1, 4, CL::O8, BF>(fr9, lw + CL::A8, g, c);
         ST_FENCE(); fwdD_fr<4, 2, BF>(fr8, lw + CL::B7, h7, h8, g);
         ST_T(5);
+        }
         // ---- d out (D layout: t' = 4g + r), part A: everything that does not need e9 -- polar->rect backward of nn_proc.py:322-326 and
         // the L1 term of loss_functions.py:36 -- sits in the SAME scheduling region as the layer-9 MFMAs (one dependent chain of 16,
         // 512 cycles of matrix pipe with nothing else to issue) and is paced into their shadows: one MFMA, then seven VALU.
@@ -1002,10 +1112,10 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
                 const float dph = mh * (gim * cs - gre * sn);
                 // one formula for both nets (x * 1.0f is exact): magnitude d9 = dmh * mag_tail * ELU', tail = dmh * e9; phase d9 = dph * ELU', tail = dph
                 dxA[r] = ok ? (ae == 0 ? dmh : dph) : 0.f;
-                mtA[r] = ae == 0 ? q_mt[r] : 1.f;
+                mtA[r] = ae == 0 ? (TAIL16 ? vr[1][r] : q_mt[r]) : 1.f;      // TAIL16: t = T - OT + 4g + r = 16 + 4g + r is input tile 1 of this lane (already masked)
             }
-            fwdD_fr<1, 4, BF>(fr9, lw + CL::B8, h8, e9, g);
-            if constexpr (BF == 0) {
+            if constexpr (!SAVED) fwdD_fr<1, 4, BF>(fr9, lw + CL::B8, h8, e9, g);
+            if constexpr (BF == 0 && !SAVED) {
 #pragma unroll
                 for (int p_ = 0; p_ < 16; ++p_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 7, 0); }
             }
@@ -1026,6 +1136,10 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
                 Ys[to * SP + c] = d9;                      // [feature t'][row c] -> read back transposed below
             }
         }
+        // SAVED: in-place refills for the NEXT group, each right behind the last use of its registers in this one (every load gets a whole group to land)
+#define ST_REFILL(...) do { if constexpr (SAVED) { ST_FENCE(); __VA_ARGS__; ST_FENCE(); } } while (0)
+        const float* const svq = SAVED ? svp(gnext) : nullptr;
+        ST_REFILL(load_q(gnext); sv_load(svq, lane16, 16, s_e9));
         // ------------------------------------------------------------------ backward through the layers
         // T layout: lane (g,c), reg r  <->  row 4g + r, feature 16*tile + c.
         // Every stage l runs in the order   [hT_{l-1} = to_T(h_{l-1})]  ->  data gradient MFMAs (fragments fd_l were fetched
@@ -1064,19 +1178,23 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             daT9[0] = *reinterpret_cast<const f32x4*>(Ys + c * SP + 4 * g);
             ST_T(7);
             ST_BWD_STAGE(1, 4, fd9, da9, daT9, h8, hT8, da8, daT8, rW9, rb9, (frags_dgrad<4, 2, CL::I7, BF>(fd8, lw + CL::G7, g, c)))
+            ST_REFILL(sv_load(svq, lane16, 12, s_h8));
         }
         ST_T(8);
         // layer 8 (32 -> 64)
         tt_t hT7[2]; f32x4 da7[2], daT7[2], fd7[1 * 2];
         ST_BWD_STAGE(4, 2, fd8, da8, daT8, h7, hT7, da7, daT7, rW8, rb8, (frags_dgrad<2, 1, CL::I6, BF>(fd7, lw + CL::G6, g, c)))
+        ST_REFILL(sv_load(svq, lane16, 10, s_h7));
         ST_T(9);
         // layer 7 (16 -> 32)
         tt_t hT6[1]; f32x4 da6[1], daT6[1], fd6[1];
         ST_BWD_STAGE(2, 1, fd7, da7, daT7, h6, hT6, da6, daT6, rW7, rb7, (frags_dgrad<1, 1, CL::I5, BF>(fd6, lw + CL::G5, g, c)))
+        ST_REFILL(sv_load(svq, lane16, 9, s_h6));
         ST_T(10);
         // layer 6 (16 -> 16)
         tt_t hT5[1]; f32x4 da5[1], daT5[1], fd5[1];
         ST_BWD_STAGE(1, 1, fd6, da6, daT6, h5, hT5, da5, daT5, rW6, rb6, (frags_dgrad<1, 1, CL::I4, BF>(fd5, lw + CL::G4, g, c)))
+        ST_REFILL(sv_load(svq, lane16, 8, s_h5));
         // layer 5 ([h4 ; knobs] -> 16): weight gradient over both input tiles, data gradient to h4 only
         tt_t hT4[1], hT4k[2]; f32x4 da4[1], daT4[1], fd4[1];
         {
@@ -1087,13 +1205,16 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             hT4k[1] = tt_splat<BF>(knT);                               // features 16 + c = knob c, every row
             wgrad_regh<1, 2, BF>(rW5, rb5, daT5, hT4k);
         }
+        ST_REFILL(sv_load(svq, lane16, 7, s_h4));
         // layer 4 (16 -> 16)
         tt_t hT3[1]; f32x4 da3[1], daT3[1], fd3[2 * 1];
         ST_BWD_STAGE(1, 1, fd4, da4, daT4, h3, hT3, da3, daT3, rW4, rb4, (frags_dgrad<1, 2, CL::I2, BF>(fd3, lw + CL::G2, g, c)))
+        ST_REFILL(sv_load(svq, lane16, 6, s_h3));
         ST_T(11);
         // layer 3 (32 -> 16)
         tt_t hT2[2]; f32x4 da2[2], daT2[2], fd2[4 * 2];
         ST_BWD_STAGE(1, 2, fd3, da3, daT3, h2, hT2, da2, daT2, rW3, rb3, (frags_dgrad<2, 4, CL::I1, BF>(fd2, lw + CL::G1, g, c)))
+        ST_REFILL(sv_load(svq, lane16, 4, s_h2));
         ST_T(12);
         // layer 2 (64 -> 32)
         tt_t hT1[4]; f32x4 da1[4], daT1[4], fd1[2 * 4];
@@ -1109,6 +1230,7 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             wgrad_regh<2, 4, BF>(rW2, rb2, daT2, hT1);
         } else {
             ST_BWD_STAGE(2, 4, fd2, da2, daT2, h1, hT1, da1, daT1, rW2, rb2, (frags_dgrad<4, 2, CL::I0, BF>(fd1, lw + CL::G0, g, c)))
+            ST_REFILL(sv_load(svq, lane16, 0, s_h1));
         }
         ST_T(13);
         // layer 1 (T -> 64): input rows transposed through the wave's scratch
@@ -1122,7 +1244,17 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
         }
 #undef ST_BWD_STAGE
 #undef ST_PIPE
+#undef ST_REFILL
         ST_T(14);
+        // Round 6: the NEXT group's input rows / knobs are taken over HERE, ahead of this group's stores.  Behind them (as until round 5) the wait for these
+        // loads -- the memory counter is in-order and counts stores too -- also waited for the write acknowledgements of the stores just issued: one exposed
+        // round trip per group, the "loads issue" stage that stayed at ~10 % of a group through rounds 2-5 whatever was done to the loads themselves.
+        if constexpr (!INNER) {
+            mask_v(gnext, vn);
+            vr[0] = vn[0]; vr[1] = vn[1];
+        }
+        mask_kn(knn, knTn); kn = knn; knT = knTn;
+        ST_T(17);
         // ------------------------------------------------------------------ d input rows (+ skip / residual tails)
         if constexpr (!INNER) {
         // Materialise the accumulators in VGPRs HERE, in the block of the MFMAs that produce them: the stores below sit in
@@ -1152,11 +1284,6 @@ ae_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phs, cons
             }
         }
         ST_T(15);
-        if constexpr (!INNER) {
-            mask_v(gnext, vn);
-            vr[0] = vn[0]; vr[1] = vn[1];
-        }
-        mask_kn(knn, knTn); kn = knn; knT = knTn;
     }
     // ---------------------------------------------------------------------- workgroup partial gradients
     // All LDS contents are dead now.  Every wave stores its accumulators into ITS OWN gradient image (dW_l as [o][INp] at

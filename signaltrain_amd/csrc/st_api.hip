@@ -170,6 +170,7 @@ extern "C" int st_set_debug(int v) { g_dbg = v; return ST_OK; }
 namespace sta { extern __device__ unsigned long long g_ae_stage_cycles[32]; }
 // Diagnostics: read (and clear) the per-stage s_memtime accumulators of ae_bwd_kernel (st_set_debug(256)).
 extern "C" int st_debug_read_stage_cycles(unsigned long long* out32);
+static int g_ae_save = 1;    // fused geometries, fp32 autoencoder layers: 1 = the forward kernel keeps the activations and the backward reads them (round 6), 0 = the backward recomputes them (st_set_tuning(8200 / 8201))
 static int g_ae_split = -1;  // autoencoder backward of the fused geometries: 0 = the single kernel (st_set_tuning(8000)), 1 = the two kernels of st_ae_split.h (8001),
                              // -1 = by precision (8002, default): fp32 -> single (179.5 us against 87.0 + 92.4 us at B = 256 -- equal: the fp32 MFMA holds the vector ALUs, a partner
                              // wave has nothing to overlap with -- and the split moves 66 MB more per step: h4 / d a4 / tails hand-over); 16-bit Linear layers -> split (the
@@ -236,6 +237,7 @@ extern "C" int st_set_tuning(int bk)
     if (bk >= 9100) { g_pl_shape = bk - 9100; return ST_OK; }
     if (bk >= 9000) { g_frs_nt = bk - 9000; return ST_OK; }
     if (bk >= 8100 && bk < 8110) { g_ae32 = bk - 8100; return ST_OK; }           // 8100 / 8101: 16-bit autoencoder forward on 16-row / 32-row groups (st_ae32.h)
+    if (bk == 8200 || bk == 8201) { g_ae_save = bk - 8200; return ST_OK; }      // autoencoder backward: recompute / read the kept activations
     if (bk >= 8000) { g_ae_split = bk == 8002 ? -1 : bk - 8000; return ST_OK; }     // 8000 / 8001 / 8002: single-kernel / split autoencoder backward / by precision
     if (bk >= 7000) { g_xt = bk - 7000; return ST_OK; }
     if (bk >= 6000) { g_wsplit_half = bk - 6000; return ST_OK; }  // 6000 + n: split-K of the half (one-basis) analysis weight-gradient GEMMs of st_loss_backward_stage (0: as the full GEMM)
@@ -251,7 +253,7 @@ extern "C" int st_set_tuning(int bk)
 // The diagnostic switches above as ONE readable state: st_get_tuning() reports them in a fixed order, st_reset_tuning() restores the shipped
 // defaults.  The product path never sets them; tests/conftest.py asserts after every test that the state is back at ST_TUNING_DEFAULTS
 // (a wrong default can then not ship unnoticed, and a test cannot leak a switch into the next one).
-#define ST_TUNING_LIST(X) X(g_dbg, 0) X(g_ae_split, -1) X(g_pl_bf16, 0) X(g_wg_split, 0) X(g_pl_dgrad, 0) X(g_pl_shape, 3) X(g_g16, 1) X(g_g16_bk, 64) X(g_g16_dma, 0) \
+#define ST_TUNING_LIST(X) X(g_dbg, 0) X(g_ae_split, -1) X(g_ae_save, 1) X(g_pl_bf16, 0) X(g_wg_split, 0) X(g_pl_dgrad, 0) X(g_pl_shape, 3) X(g_g16, 1) X(g_g16_bk, 64) X(g_g16_dma, 0) \
     X(g_g16_abl, 0) X(g_g16_split, 0) X(g_nt128, 1) X(g_tn128, 1) X(g_tn_bk, 32) X(g_frs_nt, 1) X(g_xt, 0) X(g_wide_pair, 1) X(g_wide_dvp, 1) X(g_nt_mi, 0) X(g_an_bk, 32) \
     X(g_bk, 16) X(g_wsplit_max, 16) X(g_wsplit_div, 200) X(g_an_waves, 4) X(g_syn_split, 3) X(g_frs_split, 3) X(g_wide_fused, 1) X(g_wsplit_half, 0) X(g_wg_mode, 0) X(g_ae32, 1) X(g_wide_direct, 1) X(g_tn_fm, 3) X(g_g16_crop, 15)
 static int g_wg_mode = 0;
@@ -438,6 +440,12 @@ static int ae_split_grid(const st_dims* d) { int g = (ae_fwd_groups(d) + AE_SPLI
 // 16-bit operands in the split form were tried (decoder + encoder halves 49 + 45 us against 101 us for the single kernel, the step did not
 // move) and are NOT instantiated: the compiler emitted a cross-block MFMA-result hazard in the 16-bit encoder half (tools/check_mfma_hazards.py).
 static bool ae_use_split(const st_dims* d) { return (g_ae_split < 0 ? ae_ht(d->prec) != 0 : g_ae_split != 0) && !ae_is_wide(d) && !(g_dbg & 256); }
+// Round 6: kept activations of the fused fp32 autoencoders ([net][group][17 tiles][64 lanes] float4, st_ae.h): the workspace always has room for them where the
+// autoencoder layers run in fp32 (the tuning switch picks the kernels, not the size); they sit BEHIND the workgroup partials.
+static size_t ae_sv_floats(const st_dims* d) { return (!ae_is_wide(d) && ae_ht(d->prec) == 0) ? (size_t)2 * ae_fwd_groups(d) * sta::AE_SV_TILES * 256 : 0; }
+static int ae_parts_max(const st_dims* d) { return ae_split_grid(d) > ae_bwd_grid(d) ? ae_split_grid(d) : ae_bwd_grid(d); }
+static bool ae_use_saved(const st_dims* d) { return g_ae_save && !ae_is_wide(d) && ae_ht(d->prec) == 0 && !ae_use_split(d); }
+static float* ae_sv_ptr(const st_dims* d, const Layout& L, float* aews) { return aews + 2 * ae_h4_floats(d) + (size_t)ae_parts_max(d) * 2 * L.PG; }
 extern "C" size_t st_ae_fwd_ws_floats(const st_dims* d)
 {
     if (check_dims(d) != ST_OK) return 0;
@@ -448,8 +456,7 @@ extern "C" size_t st_ae_bwd_ws_floats(const st_dims* d)
 {
     Layout L; if (make_layout(d, &L) != ST_OK) return 0;
     if (ae_is_wide(d)) { WideWS w; wide_carve(d, nullptr, &w); return w.floats; }
-    const int parts = ae_split_grid(d) > ae_bwd_grid(d) ? ae_split_grid(d) : ae_bwd_grid(d);
-    return 2 * ae_h4_floats(d) + (size_t)parts * 2 * L.PG;
+    return 2 * ae_h4_floats(d) + (size_t)ae_parts_max(d) * 2 * L.PG + ae_sv_floats(d);
 }
 static int ae_wide_fwd(const st_dims* d, const Layout& L, const float* mag, const float* phs, const float* knobs,
                        const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA, float* reg_partial,
@@ -501,7 +508,7 @@ static int pad_scale(const float* in, float* out, int B, int Ls, int pad, float 
 // AA16 != NULL (fused step of the 16-bit GEMM configurations): the spectra are written rounded to the operand type, not as fp32
 static int ae_fwd_impl(const st_dims* d, const float* mag, const float* phs, const float* knobs,
                        const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA,
-                       float* reg_partial, float* ws, void* stream, unsigned short* AA16 = nullptr, bool wide_in_done = false);
+                       float* reg_partial, float* ws, void* stream, unsigned short* AA16 = nullptr, bool wide_in_done = false, float* sv = nullptr);
 extern "C" int st_ae_fwd(const st_dims* d, const float* mag, const float* phs, const float* knobs,
                          const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA,
                          float* reg_partial, float* ws, void* stream)
@@ -510,8 +517,8 @@ extern "C" int st_ae_fwd(const st_dims* d, const float* mag, const float* phs, c
 }
 static int ae_fwd_impl(const st_dims* d, const float* mag, const float* phs, const float* knobs,
                        const float* ae_m, const float* ae_p, float* mag_hat, float* phs_hat, float* AA,
-                       float* reg_partial, float* ws, void* stream, unsigned short* AA16, bool wide_in_done)
-{
+                       float* reg_partial, float* ws, void* stream, unsigned short* AA16, bool wide_in_done, float* sv)
+{      // sv != NULL (fused fp32 geometries, training step): the activations are kept for the backward (ae_sv_floats)
     Layout L; ST_TRY(make_layout(d, &L));
     const int aa_ht = AA16 ? gemm_ht(d->prec) : 0;
     ST_REQ(mag && phs && knobs && ae_m && ae_p && ((mag_hat && phs_hat && AA) || (!mag_hat && !phs_hat && !AA && ws)), "st_ae_fwd: null pointer");
@@ -538,7 +545,14 @@ static int ae_fwd_impl(const st_dims* d, const float* mag, const float* phs, con
     case 1: if (use32) ST_AE_FWD32_LAUNCH(1); else ST_AE_FWD_LAUNCH(1); break;
     case 2: if (use32) ST_AE_FWD32_LAUNCH(2); else ST_AE_FWD_LAUNCH(2); break;
     default:
-        if (ae_fwd_nw(d) == 11) {
+        if (sv) {
+            ST_REQ(mag_hat, "st_ae_fwd: internal: kept activations on a code-only pass");
+#define ST_AE_FWD_SV(NW_) do { ST_DYN_LDS((sta::ae_fwd_kernel<NW_, 0, true>)); \
+            hipLaunchKernelGGL((sta::ae_fwd_kernel<NW_, 0, true>), dim3(ae_fwd_grid(d)), dim3(NW_ * 64), lds, st_stream(stream), \
+                               mag, phs, knobs, ae_m, ae_p, L.go, mag_hat, phs_hat, AA, reg_partial, d->B, d->T, d->OT, d->F, d->K, L.KP, expfac, ws, AA16, aa_ht, sv); } while (0)
+            if (ae_fwd_nw(d) == 11) ST_AE_FWD_SV(11); else ST_AE_FWD_SV(AE_FWD_NW);
+#undef ST_AE_FWD_SV
+        } else if (ae_fwd_nw(d) == 11) {
             ST_DYN_LDS((sta::ae_fwd_kernel<11, 0>));
             hipLaunchKernelGGL((sta::ae_fwd_kernel<11, 0>), dim3(ae_fwd_grid(d)), dim3(11 * 64), lds, st_stream(stream),
                                mag, phs, knobs, ae_m, ae_p, L.go, mag_hat, phs_hat, AA, reg_partial, d->B, d->T, d->OT, d->F, d->K, L.KP, expfac, ws, AA16, aa_ht);
@@ -1074,6 +1088,20 @@ static int ae_bwd_impl(const st_dims* d, const float* mag, const float* phs, con
                        dmag, dphs, parts, d->B, d->T, d->OT, d->F, d->K, L.KP, live.t_lo, live.t_lo + live.Tv - 1, st_synth_slabs(d), (size_t)d->B * d->OT * L.KP, g_dbg); } while (0)
     // kernel variant: 1 = an upstream d/d mag_hat arrives (autograd entry), 2 = T - OT == 16 (tails already in registers), 0 = neither
     const int var = g_mag_hat ? 1 : (d->T - d->OT == 16 ? 2 : 0);
+    if (have_fwd && ae_use_saved(d)) {               // round 6: the forward of this workspace kept the activations -- no recompute
+        const float* sv = ae_sv_ptr(d, L, ws);
+#define ST_AE_BWD_SV(VAR_, TIMED_) do { ST_DYN_LDS((sta::ae_bwd_kernel<AE_BWD_NW, TIMED_, false, 0, VAR_, true>)); \
+        hipLaunchKernelGGL((sta::ae_bwd_kernel<AE_BWD_NW, TIMED_, false, 0, VAR_, true>), dim3(grid, 2), dim3(AE_BWD_NW * 64), lds, st_stream(stream), \
+                       mag, phs, knobs, ae_m, ae_p, L.go, L.PG, mag_hat, phs_hat, dAA, g_mag_hat, reg_coef, expfac, \
+                       dmag, dphs, parts, d->B, d->T, d->OT, d->F, d->K, L.KP, live.t_lo, live.t_lo + live.Tv - 1, st_synth_slabs(d), (size_t)d->B * d->OT * L.KP, g_dbg, sv); } while (0)
+        if (g_dbg & 256) { ST_REQ(var == 2, "the stage-timer build covers the fp32 training step at T - OT == 16 only"); ST_AE_BWD_SV(2, true); }      // tools/ae_stage_times.py
+        else if (var == 1) ST_AE_BWD_SV(1, false); else if (var == 2) ST_AE_BWD_SV(2, false); else ST_AE_BWD_SV(0, false);
+#undef ST_AE_BWD_SV
+        ST_LAUNCHED("ae_bwd");
+        if (defer_reduce && *defer_reduce) return ST_OK;
+        hipLaunchKernelGGL(stm::ae_grad_reduce_kernel, dim3((L.PG + 63) / 64, 2), dim3(256), 0, st_stream(stream), parts, grid, L.PG, g_m, g_p);
+        ST_LAUNCHED("ae_grad_reduce"); return ST_OK;
+    }
 #define ST_AE_BWD_VARS(HT_) do { if (var == 1) ST_AE_BWD_LAUNCH(false, HT_, 1); else if (var == 2) ST_AE_BWD_LAUNCH(false, HT_, 2); else ST_AE_BWD_LAUNCH(false, HT_, 0); } while (0)
     if (g_dbg & 256) {                               // stage-timer build (tools/ae_stage_times.py): the default-geometry training variant
         ST_REQ(var == 2 && ae_ht(d->prec) == 0, "the stage-timer build covers the fp32 training step at T - OT == 16 only");
@@ -1519,8 +1547,10 @@ static int forward_impl(const st_dims* d, const Layout& L, const float* params, 
         ST_TRY(analysis_fwd_planes(d, w, save ? w.re : nullptr, save ? w.im : nullptr, pmag, pphs, stream, &pwide));
     } else
     ST_TRY(analysis_fwd_impl(d, w.xp, true, Wr, Wi, 1.0f, save ? w.re : nullptr, save ? w.im : nullptr, pmag, pphs, stream, true, &pwide));
+    float* sv = nullptr;
+    if (save && ae_use_saved(d)) { Layout Ls; ST_TRY(make_layout(d, &Ls)); sv = ae_sv_ptr(d, Ls, w.aews); }      // round 6: the activations stay for the backward
     ST_TRY(ae_fwd_impl(d, w.mag, w.phs, knobs, ae_m, ae_p, w.mag_hat, w.phs_hat, w.AA, w.reg_p,
-                       (ae_is_wide(d) || (save && ae_use_split(d))) ? w.aews : nullptr, stream, w.g16 ? w.AA16 : nullptr, wide_direct));     // fused geometries: the code h4 is kept for the split backward
+                       (ae_is_wide(d) || (save && ae_use_split(d))) ? w.aews : nullptr, stream, w.g16 ? w.AA16 : nullptr, wide_direct, sv));     // fused geometries: the code h4 is kept for the split backward
     if (w.g16) ST_TRY(synthesis_frames16(d, w, stream)); else
     if (planes) ST_TRY(synthesis_frames_planes(d, w, stream)); else
     ST_TRY(synthesis_frames_impl(d, w.AA, w.Sfold, w.SfoldT, w.frs, stream));
@@ -2278,7 +2308,8 @@ static int attr_prepare(const st_dims* d)
     } else {
         ST_PREP3((sta::ae_fwd_kernel<AE_FWD_NW, 0>), (sta::ae_fwd_kernel<AE_FWD_NW, 1>), (sta::ae_fwd_kernel<AE_FWD_NW, 2>));
         if (ht == 1) ST_DYN_LDS((sta::ae_fwd32_kernel<AE_FWD_NW, 1>)); else if (ht == 2) ST_DYN_LDS((sta::ae_fwd32_kernel<AE_FWD_NW, 2>));
-        if (ht == 0) ST_DYN_LDS((sta::ae_fwd_kernel<11, 0>));
+        if (ht == 0) { ST_DYN_LDS((sta::ae_fwd_kernel<11, 0>)); ST_DYN_LDS((sta::ae_fwd_kernel<11, 0, true>)); ST_DYN_LDS((sta::ae_fwd_kernel<AE_FWD_NW, 0, true>));
+                       ST_DYN_LDS((sta::ae_bwd_kernel<AE_BWD_NW, false, false, 0, 0, true>)); ST_DYN_LDS((sta::ae_bwd_kernel<AE_BWD_NW, false, false, 0, 1, true>)); ST_DYN_LDS((sta::ae_bwd_kernel<AE_BWD_NW, false, false, 0, 2, true>)); }
         ST_PREP3((sta::ae_bwd_part_kernel<AE_SPLIT_NW, 1, 0, false>), (sta::ae_bwd_part_kernel<AE_SPLIT_NW, 1, 1, false>), (sta::ae_bwd_part_kernel<AE_SPLIT_NW, 1, 2, false>));
         ST_PREP3((sta::ae_bwd_part_kernel<AE_SPLIT_NW, 2, 0, false>), (sta::ae_bwd_part_kernel<AE_SPLIT_NW, 2, 1, false>), (sta::ae_bwd_part_kernel<AE_SPLIT_NW, 2, 2, false>));
         if (d->T - d->OT == 16) ST_PREP3((sta::ae_bwd_kernel<AE_BWD_NW, false, false, 0, 2>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 1, 2>), (sta::ae_bwd_kernel<AE_BWD_NW, false, false, 2, 2>));

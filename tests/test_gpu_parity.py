@@ -372,6 +372,9 @@ def test_engine_on_a_non_current_device_or_stream():
 @pytest.mark.parametrize("dtype,codes,restore", [
     ("f32", (9000,), (9001,)),            # synthesis frames GEMM in the k-major form
     ("f32", (8001,), (8002,)),            # two-kernel autoencoder backward in fp32
+    ("f32", (8200,), (8201,)),            # round 6: autoencoder backward that RECOMPUTES the activations instead of reading the ones the forward kept
+    ("bf16", (8200,), (8201,)),           # ... with 16-bit STFT GEMMs around the fp32 autoencoders
+    ("f32x3", (8200,), (8201,)),
     ("bf16_all", (8000,), (8002,)),       # single-kernel autoencoder backward with 16-bit Linear layers
     ("f16_all", (8000,), (8002,)),
     ("f32", (7001,), (7000,)),            # k-quad-major transposed staging of the weight-gradient GEMMs
@@ -417,6 +420,45 @@ def test_alternative_code_paths_agree(dtype, codes, restore):
     for k in ref:
         sc = ref[k].abs().max().item()
         assert (alt[k] - ref[k]).abs().max().item() <= tol * sc + 1e-12, (dtype, codes, k)
+
+
+@pytest.mark.parametrize("B", [3, 64, 130])
+def test_kept_activations_backward_is_the_recompute_backward_bit_for_bit(B):
+    """Round 6: the fused fp32 step keeps the autoencoders' post-ELU activations in the forward kernel (what the reference's autograd keeps, nn_proc.py:77-126) and the
+    backward kernel reads them instead of recomputing the forward chain.  Same values, same order of every sum: loss, all 40 gradient tensors and the parameters after
+    two optimizer steps are IDENTICAL BITS to the recomputing backward (st_set_tuning(8200)), at a small batch, at a batch with several rounds per wave and at one whose
+    last groups are ragged."""
+    import numpy as np, torch
+    from tests import gpu_checks as G
+    from signaltrain_amd import _lib
+    from signaltrain_amd.engine import StepEngine
+    lib = _lib.load()
+    K = 4
+    geo, X, Y, KN, P = G.make_case(8, 23, K=K)
+    rng = np.random.default_rng(11)
+    reps = (B + 7) // 8
+    X = (np.tile(X, (reps, 1))[:B] * rng.uniform(0.4, 1.0, (B, 1))).astype(np.float32)
+    Y = (np.tile(Y, (reps, 1))[:B] * rng.uniform(0.4, 1.0, (B, 1))).astype(np.float32)
+    KN = (rng.random((B, K)) - 0.5).astype(np.float32)
+    x, kn, y = G.t(X), G.t(KN), G.t(Y)
+
+    def run():
+        d = G.dims_of(geo, B, K)
+        eng = StepEngine(d, G.DEV); eng.load_state_dict(P)
+        eng.loss_backward(x, kn, y); torch.cuda.synchronize()
+        g = {k: v.clone() for k, v in eng.layout.views(eng.grads).items()}; l = float(eng.scalars[0])
+        eng.train_step(x, kn, y, 1e-3); eng.train_step(x, kn, y, 1e-3); torch.cuda.synchronize()
+        return g, l, eng.params.clone()
+    g_keep, l_keep, p_keep = run()
+    try:
+        _lib.check(lib.st_set_tuning(8200), "st_set_tuning")
+        g_rec, l_rec, p_rec = run()
+    finally:
+        _lib.check(lib.st_set_tuning(8201), "st_set_tuning")
+    assert l_keep == l_rec
+    for k in g_keep:
+        assert torch.equal(g_keep[k], g_rec[k]), k
+    assert torch.equal(p_keep, p_rec)
 
 
 @pytest.mark.parametrize("dtype,codes,restore", [

@@ -24,8 +24,8 @@ for _ in range(N): eng.loss_backward(x, kn, y)
 torch.cuda.synchronize()
 lib.st_set_debug(0)
 lib.st_debug_read_stage_cycles(buf)
-names = ["loads issue", "fwd L1", "fwd L2", "fwd L3-5", "fwd L6-7", "fwd L8", "fwd L9", "d-out", "bwd 9", "bwd 8", "bwd 7", "bwd 6-4", "bwd 3", "bwd 2", "bwd 1", "store dv"]
-tot = sum(buf[:16])
+names = ["loads issue", "fwd L1", "fwd L2", "fwd L3-5", "fwd L6-7", "fwd L8", "fwd L9", "d-out", "bwd 9", "bwd 8", "bwd 7", "bwd 6-4", "bwd 3", "bwd 2", "bwd 1", "store dv", "latch", "takeover"]
+tot = sum(buf[:18])
 groups = 17 * N     # wave 0 of block 0 processes ceil(8448/512) groups per launch
 print("s_memtime ticks (constant 100 MHz clock => 1 tick = 10 ns = ~24 shader cycles); per group:")
 for i, nme in enumerate(names):
