@@ -360,6 +360,11 @@ def main():
                 out["roofline"]["step_traffic_ratio"] = step_traffic / step_alg
                 out["roofline"]["step_kernel_launches"] = step_launches
                 out["roofline"]["step_traffic_note"] = "sum over the step's kernels of (2 x FETCH_SIZE + WRITE_SIZE) x launches per step, same PMC file as `traffic`"
+            kept = int(lib.st_ae_kept_activation_bytes(C.byref(eng._dims(B))))
+            if kept:      # round 6: what the forward keeps for the backward (the reference's autograd keeps the same tensors); NOT part of SURVEY 8(d)'s algorithmic bytes
+                out["roofline"]["step_kept_activation_bytes"] = 2 * kept
+                out["roofline"]["step_kept_activation_note"] = ("autoencoder activations written once by ae_fwd and read once by ae_bwd (instead of recomputing the forward chain: "
+                                                                 "-40 us of matrix + vector work for +12 us of stores at B = 256); counted in step_traffic, not in step_algorithmic_bytes")
             out["roofline"]["mfma_busy"] = mfma_busy        # SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) of the roofline kernel, same file; null without a source-matched PMC pass
             if args.dtype.endswith("_all") and dom.startswith("ae_"):
                 # honest label: with 16-bit Linear layers the autoencoder kernels spend ~7 % of their time in MFMAs; what bounds them is vector-ALU work (ELU / ELU',

@@ -201,6 +201,12 @@ int st_ae_bwd(const st_dims* d, const float* mag, const float* phs, const float*
               const float* dAA, const float* g_mag_hat /* optional extra d/d mag_hat */, float reg_coef,
               float* dmag, float* dphs, float* ws, float* g_m, float* g_p, void* stream);
 size_t st_ae_bwd_ws_floats(const st_dims* d);
+/* Round 6.  In the fused step (st_model_fwd with save_for_backward / st_loss_backward / st_train_step) of the fused geometries with fp32 autoencoder
+ * layers, the forward kernel KEEPS the post-ELU activations of both nets -- what the reference's autograd keeps (nn_proc.py:77-126) -- in the
+ * autoencoder workspace behind the gradient partials, and the backward reads them instead of recomputing the forward chain.  Returns the bytes the
+ * forward writes (and the backward reads back) per call: 2 nets x B * ceil(F / 16) row groups x 17 KB (294 MB at B = 256); 0 where the path is not
+ * taken (16-bit autoencoder layers, wide geometries, st_set_tuning(8200)).  st_ae_bwd on its own (no forward in the same workspace) recomputes. */
+size_t st_ae_kept_activation_bytes(const st_dims* d);
 
 /* Backward of nn_proc.py:309-310: dG[B*T,KP] (d re | d im) from (re,im,dmag,dphs). */
 int st_polar_bwd(const st_dims* d, const float* re, const float* im, const float* dmag, const float* dphs,

@@ -82,6 +82,7 @@ SIGNATURES = {
     "st_synthesis_wgrad": (_i, [_D, _p, _p, _p, _p, _p, _p, _p]),
     "st_ae_bwd": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p]),
     "st_ae_bwd_ws_floats": (C.c_size_t, [_D]),
+    "st_ae_kept_activation_bytes": (C.c_size_t, [_D]),
     "st_polar_bwd": (_i, [_D, _p, _p, _p, _p, _p, _p, _p]),
     "st_analysis_wgrad": (_i, [_D, _p, _p, _f, _p, _p, _p, _p, _p]),
     "st_wgrad_ws_floats": (C.c_size_t, [_D]),

@@ -406,6 +406,9 @@ __device__ __forceinline__ void fwd_mask_tl(float (&tl)[2][4], const FwdIn& in, 
 // Per (net, 16-row group) 17 tiles of 16 x 16 in D layout, [net][group][tile][lane] float4: h1 tiles 0-3, h2 4-5, h3 6, h4 7, h5 8, h6 9, h7 10-11, h8 12-15,
 // ELU(a9) 16 -- every store / load is one fully coalesced 1 KB access per wave, 17 KB per (net, group), 2 * groups * 17 KB per step (294 MB at B = 256).
 constexpr int AE_SV_TILES = 17;
+// ST_SV_NT: bit 0 = the stores, bit 1 = the loads carry the non-temporal hint.  Measured (B = 256, lab notebook): stores without it 81 us (ae_fwd), with it 76;
+// the loads make no difference.  ST_SV_DIAG=<mask> (timing only, results INVALID): every (net, group) block lands on block (group & mask), i.e. the stores
+// stay in the L2 (mask 15) or the Infinity Cache (mask 1023) -- how the store cost was split into issue / fabric / HBM parts.
 #ifndef ST_SV_NT
 #define ST_SV_NT 1
 #endif
@@ -417,11 +420,7 @@ __device__ __forceinline__ void sv_store(float* __restrict__ p, const unsigned l
 #pragma unroll
     for (int t = 0; t < NTL; ++t) {
         f32x4* q = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p + (tile0 + t) * 256) + (size_t)lane16);
-#ifdef ST_SV_X2
-        typedef float f32x2_t __attribute__((ext_vector_type(2)));
-        __builtin_nontemporal_store(__builtin_shufflevector(h[t], h[t], 0, 1), reinterpret_cast<f32x2_t*>(q));
-        __builtin_nontemporal_store(__builtin_shufflevector(h[t], h[t], 2, 3), reinterpret_cast<f32x2_t*>(q) + 1);
-#elif ST_SV_NT & 1
+#if ST_SV_NT & 1
         __builtin_nontemporal_store(h[t], q);
 #else
         *q = h[t];

@@ -452,6 +452,11 @@ extern "C" size_t st_ae_fwd_ws_floats(const st_dims* d)
     if (!ae_is_wide(d)) return ae_h4_floats(d);             // optional for the forward alone (ws may be NULL: h4 is then not kept)
     WideWS w; wide_carve(d, nullptr, &w); return w.fwd_floats;
 }
+extern "C" size_t st_ae_kept_activation_bytes(const st_dims* d)
+{
+    if (check_dims(d) != ST_OK || !ae_use_saved(d)) return 0;
+    return ae_sv_floats(d) * sizeof(float);
+}
 extern "C" size_t st_ae_bwd_ws_floats(const st_dims* d)
 {
     Layout L; if (make_layout(d, &L) != ST_OK) return 0;
