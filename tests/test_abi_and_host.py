@@ -245,6 +245,28 @@ def test_tuning_defaults_are_frozen():
     assert lib.st_set_tuning(9681) != 0 and lib.st_set_tuning(96801) != 0 and b"ST_DIAG" in lib.st_last_error()
 
 
+def test_kept_activation_bytes_follow_geometry_and_arithmetic():
+    """Round 6: what a training-step forward keeps for the backward (st_ae_kept_activation_bytes) -- 2 nets x B * ceil(F / 16) row groups x 17 tiles of 1 KB where the
+    autoencoder layers run in fp32 on the fused kernels, nothing elsewhere (16-bit layers, the wide path, the recompute switch) -- and the autoencoder workspace has room for it."""
+    lib = _lib.load()
+    d = _lib.st_dims()
+    for B in (1, 3, 256, 1024):
+        assert lib.st_geometry(1.0, 4.0, 0, 4, B, C.byref(d)) == 0
+        for prec, keeps in ((0, True), (1, True), (3, True), (5, True), (2, False), (4, False)):       # f32, bf16 GEMMs, f16 GEMMs, f32x3 keep fp32 layers; bf16_all / f16_all do not
+            d.prec = prec
+            want = 2 * B * ((d.F + 15) // 16) * 17 * 1024 if keeps else 0
+            assert lib.st_ae_kept_activation_bytes(C.byref(d)) == want, (B, prec)
+            if keeps: assert lib.st_ae_bwd_ws_floats(C.byref(d)) * 4 > want and lib.st_workspace_bytes(C.byref(d)) > want
+        d.prec = 0
+        try:
+            assert lib.st_set_tuning(8200) == 0 and lib.st_ae_kept_activation_bytes(C.byref(d)) == 0
+        finally:
+            assert lib.st_set_tuning(8201) == 0
+    assert lib.st_geometry(8.0, 4.0, 0, 4, 64, C.byref(d)) == 0      # the 65536-sample window: wide path, feature-major activations of its own
+    d.prec = 0
+    assert lib.st_ae_kept_activation_bytes(C.byref(d)) == 0
+
+
 def test_effective_precision_is_reported():
     """st_effective_prec = the arithmetic a call really runs.  Until round 4 the wide autoencoder path (T > 32 or OT > 16: the 65536-sample window, lean
     scale 2, shrink 1) needed an EVEN batch for 16-bit Linear layers and ran fp32 layers for odd ones -- reported, but a cliff.  Round 5: its weight-gradient
