@@ -302,7 +302,11 @@ int st_dp_clip_adam(const st_dims* d, float* params, float* grads, float* m, flo
  *                         rows, so F*N values (2.1 MB) stay exposed instead of 2*F*N;
  *                     4 = the last exchange on bfloat16 values (ncclBfloat16; first half of `stage`), honoured only where the autoencoder
  *                         layers already run in 16 bits (ST_PREC_*_ALL): half the exposed bytes.
- *                     The sum of the synthesis weight-gradient slabs runs on the communicator stream, beside the autoencoder backward.
+ *                     The sum of the synthesis weight-gradient slabs runs on the communicator stream, beside the autoencoder backward
+ *                     (round 6: from a slab area of its own, so the analysis weight-gradient GEMM waits for nothing).  Round 6: without bit 1 the
+ *                     LAST exchange -- exposed whatever stream it runs on -- is issued in line on `stream` behind one join with the communicator
+ *                     stream (recorded behind the last hidden collective): two cross-stream hand-offs of ~10 us each less on the critical path
+ *                     (one rank, --force-dp: +44 -> +16 us over the plain step); every rank issues the collectives of the communicator in the same order.
  *   st_dp_rccl_version  ncclGetVersion of the bound library (0 if it exports none): evidence for multi-GPU bench lines. */
 typedef struct st_dp st_dp;
 int st_dp_unique_id(void* id128);

@@ -341,8 +341,8 @@ __device__ __forceinline__ void layer5_fwd(const float* const (&lw)[NC], const f
 #define ST_W2(off_) {lw[0] + (off_), lw[1] + (off_)}
 
 // ------------------------------------------------------------------------------------------ forward
-// Per-group inputs of one lane: layer-1 B operands (D layout: t = 16 it + 4g + r, T <= 32) and the skip/residual
-// tails (t = T-OT + 4g + r, OT <= 16).  Loaded in one burst and prefetched one group ahead.
+// Per-group inputs of one lane: layer-1 B operands (D layout: t = 16 it + 4g + r, T <= 32), the skip/residual
+// tails (t = T-OT + 4g + r, OT <= 16) and the knob values -- as RAW loads (fwd_load_* / fwd_mask_* below).
 struct FwdIn { f32x4 v[2][2]; float tl[2][4]; float kn[4]; };   // kn: knob 4q + g for the (up to 4) knob k-steps of layer 5
 
 // RAW loads from clamped (always valid) addresses; the fwd_mask_*() zero the padding rows / bins / knobs afterwards.  The

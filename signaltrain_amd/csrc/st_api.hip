@@ -170,6 +170,7 @@ extern "C" int st_set_debug(int v) { g_dbg = v; return ST_OK; }
 namespace sta { extern __device__ unsigned long long g_ae_stage_cycles[32]; }
 // Diagnostics: read (and clear) the per-stage s_memtime accumulators of ae_bwd_kernel (st_set_debug(256)).
 extern "C" int st_debug_read_stage_cycles(unsigned long long* out32);
+static int g_dp_inline = 1;  // st_dp_train_step: 1 = the last (exposed) exchange is issued in line on the compute stream (round 6), 0 = on the communicator stream between two hand-offs (st_set_tuning(8300 / 8301))
 static int g_ae_save = 1;    // fused geometries, fp32 autoencoder layers: 1 = the forward kernel keeps the activations and the backward reads them (round 6), 0 = the backward recomputes them (st_set_tuning(8200 / 8201))
 static int g_ae_split = -1;  // autoencoder backward of the fused geometries: 0 = the single kernel (st_set_tuning(8000)), 1 = the two kernels of st_ae_split.h (8001),
                              // -1 = by precision (8002, default): fp32 -> single (179.5 us against 87.0 + 92.4 us at B = 256 -- equal: the fp32 MFMA holds the vector ALUs, a partner
@@ -237,6 +238,7 @@ extern "C" int st_set_tuning(int bk)
     if (bk >= 9100) { g_pl_shape = bk - 9100; return ST_OK; }
     if (bk >= 9000) { g_frs_nt = bk - 9000; return ST_OK; }
     if (bk >= 8100 && bk < 8110) { g_ae32 = bk - 8100; return ST_OK; }           // 8100 / 8101: 16-bit autoencoder forward on 16-row / 32-row groups (st_ae32.h)
+    if (bk == 8300 || bk == 8301) { g_dp_inline = bk - 8300; return ST_OK; }      // last exchange of the data-parallel step: communicator stream / in line
     if (bk == 8200 || bk == 8201) { g_ae_save = bk - 8200; return ST_OK; }      // autoencoder backward: recompute / read the kept activations
     if (bk >= 8000) { g_ae_split = bk == 8002 ? -1 : bk - 8000; return ST_OK; }     // 8000 / 8001 / 8002: single-kernel / split autoencoder backward / by precision
     if (bk >= 7000) { g_xt = bk - 7000; return ST_OK; }
@@ -253,7 +255,7 @@ extern "C" int st_set_tuning(int bk)
 // The diagnostic switches above as ONE readable state: st_get_tuning() reports them in a fixed order, st_reset_tuning() restores the shipped
 // defaults.  The product path never sets them; tests/conftest.py asserts after every test that the state is back at ST_TUNING_DEFAULTS
 // (a wrong default can then not ship unnoticed, and a test cannot leak a switch into the next one).
-#define ST_TUNING_LIST(X) X(g_dbg, 0) X(g_ae_split, -1) X(g_ae_save, 1) X(g_pl_bf16, 0) X(g_wg_split, 0) X(g_pl_dgrad, 0) X(g_pl_shape, 3) X(g_g16, 1) X(g_g16_bk, 64) X(g_g16_dma, 0) \
+#define ST_TUNING_LIST(X) X(g_dbg, 0) X(g_ae_split, -1) X(g_ae_save, 1) X(g_dp_inline, 1) X(g_pl_bf16, 0) X(g_wg_split, 0) X(g_pl_dgrad, 0) X(g_pl_shape, 3) X(g_g16, 1) X(g_g16_bk, 64) X(g_g16_dma, 0) \
     X(g_g16_abl, 0) X(g_g16_split, 0) X(g_nt128, 1) X(g_tn128, 1) X(g_tn_bk, 32) X(g_frs_nt, 1) X(g_xt, 0) X(g_wide_pair, 1) X(g_wide_dvp, 1) X(g_nt_mi, 0) X(g_an_bk, 32) \
     X(g_bk, 16) X(g_wsplit_max, 16) X(g_wsplit_div, 200) X(g_an_waves, 4) X(g_syn_split, 3) X(g_frs_split, 3) X(g_wide_fused, 1) X(g_wsplit_half, 0) X(g_wg_mode, 0) X(g_ae32, 1) X(g_wide_direct, 1) X(g_tn_fm, 3) X(g_g16_crop, 15)
 static int g_wg_mode = 0;
@@ -385,6 +387,11 @@ extern "C" size_t st_wgrad_ws_floats(const st_dims* d)
     const int s2 = tn_split(d->B * d->T, d->N); if (s2 > s) s = s2;
     return (size_t)s * st_kp_of(d->F) * d->N + (size_t)64 * 2 * d->N;       // + the Nyquist partials of the 128 x 128-tile form
 }
+static size_t synth_wgrad_ws_floats(const st_dims* d) { return st_wgrad_ws_floats(d); }
+// Round 6: a second slab area for the SYNTHESIS weight gradient alone.  In the data-parallel step its slabs are summed on the communicator stream beside the autoencoder
+// backward; with a buffer of their own the analysis weight-gradient GEMM (which reuses the first area) needs no communicator -> compute wait before it starts -- one
+// barrier packet (~6 us of bubble on this stack) less on the compute stream.
+static size_t synth_wgrad_ws_floats(const st_dims* d);      // = st_wgrad_ws_floats(d): every slab-count rule of the fp32 and 16-bit weight-gradient launches is capped by that area's size
 extern "C" int st_synth_slabs(const st_dims* d) { return synth_split(synth_live_rows(d)); }
 // split-K slabs of the synthesis FRAMES GEMM (summed by ola_loss_kernel, which takes up to 6; the dgrad slabs are summed
 // inside ae_bwd_kernel where every extra slab costs 8 loads per row group, hence the separate, smaller count above)
@@ -1253,7 +1260,7 @@ struct WS {
     // dAA, frs: NOT every element is written per step (the pitch-padding columns [F, FP) of dAA's halves, the all-cropped tiles of frs): no consumer may read those -- the
     // contract is stated at st_workspace_bytes in the header; the Python engine zero-fills the buffer once when it allocates it
     float *re, *im, *mag, *phs, *mag_hat, *phs_hat, *AA, *dAA, *Sfold, *SfoldT, *frs, *y_hat, *dsyn, *dmag, *dphs, *dG, *xp;
-    float *wg, *aews, *loss_p, *reg_p, *norm_a, *norm_s, *norm_e;
+    float *wg, *wg2, *aews, *loss_p, *reg_p, *norm_a, *norm_s, *norm_e;      // wg2: the synthesis weight gradient's own slabs in the data-parallel step (synth_wgrad_ws_floats)
     // bfloat16 planes of the operands that are written once per step (st_gemm_planes.h): [3][same layout as the fp32 tensor]
     unsigned short *pl_W, *pl_Sfold, *pl_SfoldT;      // k-chunk-major: [K / 16][rows][3][16]
     // 16-bit GEMM operands (st_gemm16.h), each written by its producer in the layout of its fp32 counterpart: padded x/2, the analysis
@@ -1285,6 +1292,7 @@ static void carve(const st_dims* d, void* base, WS* w)
     // (+ 256: the 128-wide tiles of the TN kernel read up to 96 elements past the last row of an M/N-contiguous operand; masked outputs)
     w->xp16 = take16((size_t)d->B * (d->L + 2 * d->N) + 256); w->W16 = take16((size_t)2 * F * N); w->Sfold16 = take16(KP * N); w->SfoldT16 = take16(KP * N);
     w->AA16 = take16(RO * KP + 256); w->dsyn16 = take16((size_t)d->B * (d->y + 2 * d->N) + 256); w->dG16 = take16(RT * KP + 256);
+    w->wg2 = take(synth_wgrad_ws_floats(d));      // last: every earlier offset stays what it was
     w->g16 = false;
     w->bytes = off * sizeof(float);
 }
@@ -2248,11 +2256,14 @@ extern "C" int st_dp_train_step(st_dp* p, const st_dims* d, float* params, float
         ST_TRY(forward_impl(d, L, params, x, knobs, y_true, nullptr, nullptr, nullptr, w, true, stream));
         const float reg_coef = loss_scale_of(d) * (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);
         int syn_slabs = 0; stm::NyqJob syn_nyq{}; syn_nyq.on = 0;
+        float* const wg_main = w.wg;
+        if (g_dp_inline) w.wg = w.wg2;                                                  // round 6: the synthesis slabs in their own area (no wait before the analysis GEMM reuses the first)
         ST_TRY(backward_syn(d, L, grads, w, stream, &syn_slabs, &syn_nyq));             // GEMMs only; the slabs are summed on the communicator stream
         ST_TRY(dp_fork(p, stream));
         hipLaunchKernelGGL(stm::wgrad_reduce_kernel, dim3(st_norm_partials(d)), dim3(256), 0, p->cs,
                            w.wg, syn_slabs, grads + L.offs[2], grads + L.offs[3], w.norm_s, d->N, d->F, L.KP, 1, 0, 2 * d->F, (float*)nullptr, syn_nyq);
-        ST_HIP(hipEventRecord(p->wgfree, p->cs), "event record");                       // the analysis weight-gradient GEMM reuses the slab buffer
+        w.wg = wg_main;
+        if (!g_dp_inline) ST_HIP(hipEventRecord(p->wgfree, p->cs), "event record");     // the analysis weight-gradient GEMM reuses the slab buffer
         ST_TRY(dp_allreduce_on_cs(p, grads + L.offs[2], L.offs[4] - L.offs[2], ncclFloat32));
         // The clip norm is that of the REDUCED, 1/world-scaled gradient.  The two ranges whose exchange is hidden get their |g| partials on the communicator
         // stream right behind their collective (hidden as well); only the analysis rows' share is formed after the exposed collective, in the pass that
@@ -2261,10 +2272,21 @@ extern "C" int st_dp_train_step(st_dp* p, const st_dims* d, float* params, float
         ST_TRY(backward_ae(d, L, params, grads, knobs, nullptr, nullptr, reg_coef, w, stream, 0, nullptr));
         ST_TRY(st_dp_allreduce(p, grads + L.offs[4], L.total - L.offs[4], stream));
         if (d->clip_all) hipLaunchKernelGGL(stm::l1_partial_kernel, dim3(NORM_E_PARTIALS), dim3(256), 0, p->cs, grads + L.n_stft, L.total - L.n_stft, gs, w.norm_e);
-        ST_HIP(hipStreamWaitEvent(st_stream(stream), p->wgfree, 0), "stream wait");
+        if (!g_dp_inline) ST_HIP(hipStreamWaitEvent(st_stream(stream), p->wgfree, 0), "stream wait");
     }
     const int64_t half_n = (int64_t)d->F * d->N;
-    if (!split_last) {
+    bool last_in_line = false;
+    if (!split_last && g_dp_inline) {
+        // Round 6: the LAST exchange is exposed whatever stream it runs on (nothing is left to run beside it), so it is issued IN LINE on the compute stream:
+        // the two cross-stream hand-offs around it (compute -> communicator before, communicator -> compute after: ~10 us each on this stack, measured with one
+        // rank as a 21 us hole in front of the optimizer kernel) become ONE join that is recorded HERE, behind the last hidden collective, and has fired long
+        // before the GEMM below ends.  RCCL serialises the collectives of one communicator in issue order across streams; every rank issues the same order.
+        ST_HIP(hipEventRecord(p->done, p->cs), "event record");
+        ST_TRY(backward_p2(d, L, grads, x, w, stream, stage, pack16));
+        ST_HIP(hipStreamWaitEvent(st_stream(stream), p->done, 0), "stream wait");
+        ST_NCCL(p, p->AllReduce(stage, stage, (size_t)(2 * half_n), pack16 ? ncclBfloat16 : ncclFloat32, ncclSum, p->comm, st_stream(stream)), "ncclAllReduce");
+        last_in_line = true;
+    } else if (!split_last) {
         ST_TRY(backward_p2(d, L, grads, x, w, stream, stage, pack16));
         ST_TRY(dp_fork(p, stream));
         ST_TRY(dp_allreduce_on_cs(p, stage, 2 * half_n, pack16 ? ncclBfloat16 : ncclFloat32));
@@ -2272,12 +2294,19 @@ extern "C" int st_dp_train_step(st_dp* p, const st_dims* d, float* params, float
         stm::NyqJob nyq{}; nyq.on = 0;
         for (int h = 0; h < 2; ++h) {
             ST_TRY(analysis_wgrad_half(d, L, grads, w, h, stage, pack16, &nyq, stream));
-            ST_TRY(dp_fork(p, stream));
             void* part = pack16 ? (void*)(reinterpret_cast<unsigned short*>(stage) + (size_t)h * half_n) : (void*)(stage + (size_t)h * half_n);
+            if (h == 1 && g_dp_inline) {        // the second half's exchange is the exposed one: in line, behind the join recorded when the first half's was issued
+                ST_HIP(hipStreamWaitEvent(st_stream(stream), p->done, 0), "stream wait");
+                ST_NCCL(p, p->AllReduce(part, part, (size_t)half_n, pack16 ? ncclBfloat16 : ncclFloat32, ncclSum, p->comm, st_stream(stream)), "ncclAllReduce");
+                last_in_line = true;
+                break;
+            }
+            ST_TRY(dp_fork(p, stream));
             ST_TRY(dp_allreduce_on_cs(p, part, half_n, pack16 ? ncclBfloat16 : ncclFloat32));
+            if (g_dp_inline) ST_HIP(hipEventRecord(p->done, p->cs), "event record");
         }
     }
-    ST_TRY(st_dp_sync(p, stream));
+    if (!last_in_line) ST_TRY(st_dp_sync(p, stream));
     {
         const int np = st_norm_partials(d);
         hipLaunchKernelGGL(stm::unstage_l1_kernel, dim3(2 * d->F), dim3(256), 0, st_stream(stream), stage, grads + L.offs[0], grads + L.offs[1], d->F, d->N, gs, w.norm_a, np, pack16);

@@ -237,7 +237,7 @@ def test_tuning_defaults_are_frozen():
     n = lib.st_get_tuning(None, 0)
     cur, dflt = (C.c_int * n)(), (C.c_int * n)()
     assert lib.st_get_tuning(cur, n) == n and lib.st_tuning_defaults(dflt, n) == n
-    frozen = [0, -1, 1, 0, 0, 0, 3, 1, 64, 0, 0, 0, 1, 1, 32, 1, 0, 1, 1, 0, 32, 16, 16, 200, 4, 3, 3, 1, 0, 0, 1, 1, 3, 15]
+    frozen = [0, -1, 1, 1, 0, 0, 0, 3, 1, 64, 0, 0, 0, 1, 1, 32, 1, 0, 1, 1, 0, 32, 16, 16, 200, 4, 3, 3, 1, 0, 0, 1, 1, 3, 15]
     assert list(dflt) == frozen and list(cur) == frozen
     # a switch is visible in the state and reset restores it; timing-only ablations (invalid results) are not in the product build
     assert lib.st_set_tuning(9500) == 0 and list((lib.st_get_tuning(cur, n), cur)[1]) != frozen

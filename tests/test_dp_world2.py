@@ -51,6 +51,8 @@ def worker():
     assert dp.backend == "lib" and dp.world == world
     lib = __import__("signaltrain_amd._lib", fromlist=["load"]).load()
     assert lib.st_dp_world(eng.dp) == world and lib.st_dp_rccl_version(eng.dp) == -1        # the test double identifies itself
+    for code in os.environ.get("ST_TEST_TUNE", "").split():                                  # e.g. 8300: the last exchange on the communicator stream (the form until round 5)
+        assert lib.st_set_tuning(int(code)) == 0
     dp.broadcast_parameters()
     sl = slice(rank * bl, (rank + 1) * bl)
     x, kn, y = G.t(X[sl]), G.t(KN[sl]), G.t(Y[sl])
@@ -64,10 +66,10 @@ def worker():
     dist.destroy_process_group()
 
 
-def _run_world2(tmp_path, dtype, delay_rank=None, schedule="two_bucket", pack16=False):
+def _run_world2(tmp_path, dtype, delay_rank=None, schedule="two_bucket", pack16=False, tune=""):
     _build_fake()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, ST_RCCL_LIB=FAKE, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, ST_RCCL_LIB=FAKE, HSA_ENABLE_IPC_MODE_LEGACY="0", ST_TEST_TUNE=tune)
     if delay_rank is not None:
         env.update(ST_FAKE_RCCL_DELAY_RANK=str(delay_rank), ST_FAKE_RCCL_DELAY_US="20000")
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(r), "2", str(port), str(tmp_path), dtype, schedule, "1" if pack16 else "0"], env=env,
@@ -87,19 +89,21 @@ def _run_world2(tmp_path, dtype, delay_rank=None, schedule="two_bucket", pack16=
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype,delay_rank,schedule,pack16", [("f32", None, "two_bucket", False), ("f32", 1, "two_bucket", False), ("f32", 0, "two_bucket", False),
-                                                               ("bf16_all", 1, "two_bucket", False),
-                                                               ("f32", 1, "staged", False), ("f32", 0, "staged", False),        # the last exchange split by basis
-                                                               ("bf16_all", 0, "staged", False), ("f16_all", 1, "staged", False),
-                                                               ("bf16_all", 1, "two_bucket", True), ("bf16_all", 0, "staged", True)])      # ... and on bfloat16 values
-def test_world2_library_exchange_equals_single_process(tmp_path, dtype, delay_rank, schedule, pack16):
+@pytest.mark.parametrize("dtype,delay_rank,schedule,pack16,tune", [("f32", None, "two_bucket", False, ""), ("f32", 1, "two_bucket", False, ""), ("f32", 0, "two_bucket", False, ""),
+                                                               ("bf16_all", 1, "two_bucket", False, ""),
+                                                               ("f32", 1, "staged", False, ""), ("f32", 0, "staged", False, ""),        # the last exchange split by basis
+                                                               ("bf16_all", 0, "staged", False, ""), ("f16_all", 1, "staged", False, ""),
+                                                               ("bf16_all", 1, "two_bucket", True, ""), ("bf16_all", 0, "staged", True, ""),      # ... and on bfloat16 values
+                                                               ("f16_all", 0, "two_bucket", False, ""),                                       # clip over all parameters + the in-line last exchange
+                                                               ("f32", 1, "two_bucket", False, "8300"), ("bf16_all", 0, "two_bucket", True, "8300")])      # the last exchange on the communicator stream (rounds 2-5)
+def test_world2_library_exchange_equals_single_process(tmp_path, dtype, delay_rank, schedule, pack16, tune):
     """world-2 st_dp_train_step (two processes on one GPU, RCCL test double) == one process on the global batch.  staged: the analysis exchange as two
     collectives, the first under the second basis' GEMM; pack16: that exchange as bfloat16 (<= 2e-3, VERDICT round 3 next #4b); one rank delayed
     before every collective: a missing wait shows as a wrong sum."""
     import torch
     from tests import gpu_checks as G
     from signaltrain_amd.engine import StepEngine
-    r0, r1 = _run_world2(tmp_path, dtype, delay_rank, schedule, pack16)
+    r0, r1 = _run_world2(tmp_path, dtype, delay_rank, schedule, pack16, tune)
     # both replicas identical: same reduced gradient (the double sums in rank order), same clip, same Adam
     assert np.array_equal(r0["params"], r1["params"]), float(np.abs(r0["params"] - r1["params"]).max())
     assert np.array_equal(r0["grads"], r1["grads"])
