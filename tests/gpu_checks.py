@@ -160,9 +160,16 @@ def err(name, got, ref, tol=TOL, scale=None):
     bad = ~np.isfinite(got)
     e = float(np.max(np.where(bad, np.inf, d))) if got.size else 0.0
     worst = np.unravel_index(int(np.argmax(np.where(bad, np.inf, d))), d.shape) if got.size else ()
-    return dict(name=name, err=e, scale=sc, rel=e / max(sc, 1e-30), tol=tol, ok=bool(e <= tol * max(sc, 1e-30)),
-                worst=tuple(int(i) for i in worst), got=float(got[worst]) if got.size else 0.0,
-                ref=float(ref[worst]) if got.size else 0.0)
+    r = dict(name=name, err=e, scale=sc, rel=e / max(sc, 1e-30), tol=tol, ok=bool(e <= tol * max(sc, 1e-30)),
+             worst=tuple(int(i) for i in worst), got=float(got[worst]) if got.size else 0.0,
+             ref=float(ref[worst]) if got.size else 0.0)
+    if got.ndim >= 2 and got.size and not r["ok"]:
+        # WHERE a miss sits (round 6): how many leading-index slices ("rows": output channels of a weight tensor, i.e. frequency bins of the STFT bases) hold an
+        # element over the tolerance, and the error of everything outside the worst few.  A conditioning miss (one near-silent bin under d atan2) lives in a
+        # handful of rows; a kernel defect (a wrong tile, k range or slab) covers a tile's worth -- 96 / 128 rows or every row (tests/gpu_spread.py grounded()).
+        per_row = np.where(bad, np.inf, d).reshape(d.shape[0], -1).max(axis=1)
+        r["rows"] = int(d.shape[0]); r["rows_over"] = int((per_row > tol * max(sc, 1e-30)).sum())
+    return r
 
 
 def phase_err(name, got, ref, mag, tol=TOL):

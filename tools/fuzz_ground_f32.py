@@ -47,6 +47,11 @@ CASES = [
     ("f32", dict(B=1, seed=633, K=8, scale=8, scheme=_L, shrink=4)),
     ("f32", dict(B=9, seed=546, K=4, scale=1, scheme=_L, shrink=4)),
 ]
+# round 6, sweep with a fresh seed (profiles/r06_fuzz_parity_seed4242.txt): a SINGLE window at lean scale 2 whose analysis-basis gradient has a spread of ~1e-2 -- the
+# device sits at 0.3 x that, but above the 10 x tolerance cap of tests/gpu_spread.py, so the sweep calls it hard
+CASES += [
+    ("f32x3", dict(B=1, seed=499, K=2, scale=2, scheme=_L, shrink=4)),
+]
 NPERT = 8
 CACHE = os.path.join(ROOT, "profiles", "r05_fuzz_f32_spread.json")
 AN = ("grad.dft_analysis.conv_analysis_real.weight", "grad.dft_analysis.conv_analysis_imag.weight", "train0.params")

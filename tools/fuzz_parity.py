@@ -21,12 +21,20 @@ quantity for that configuration (tests/gpu_spread.py).  777-794 configurations (
 (bound: 3 x); ONE hard line -- f16_all, L = 65536, a single window (B = 1, K = 2, seed 300): phase-net encoder gradients 2.1-2.6e-2 against the sweep's 1.6e-2 -- which tools/fuzz_ground.py
 shows at 0.4-0.6 x the rounding oracle's own spread for that window (4.1-6.6e-2; its analysis-basis gradients move by 120 % under a 1e-6 perturbation): the 14th case of
 tests/test_gpu_parity.py::test_fuzz_outliers_grounded.
-    python tools/fuzz_parity.py [seconds] [big]"""
+Round 6, a FRESH seed (330 s, seed 4242: profiles/r06_fuzz_parity_seed4242.txt; big, 450 s, seed 77: profiles/r06_fuzz_parity_big_seed77.txt): 426 + 66 configurations, 25 soft lines, four hard
+lines, all four on the analysis-basis gradients: three f16_all (B = 13; single windows at legacy scale 2 and at L = 65536) -> tools/fuzz_ground.py cases 14-16, and one f32x3 single
+window at lean scale 2 whose device error is 0.3 x its spread but 14 x the fixed tolerance, i.e. over the cap of tests/gpu_spread.py -> accepted there now only as a LOCALIZED miss
+(<= 16 of the 1024 rows of the tensor over the tolerance), tools/fuzz_ground_f32.py case 21.
+    python tools/fuzz_parity.py [seconds] [big|small] [seed]"""
 import sys, time, random; sys.path.insert(0, '.')
 from tests import gpu_checks as G
 random.seed(int(sys.argv[3]) if len(sys.argv) > 3 else 1234)
 BIG = len(sys.argv) > 2 and sys.argv[2] == "big"      # round 5: batches of 33..160 windows at the 8192-sample window -- where 128-row tiles of the frame-major row order hold one or two
                                                        # frames and the structural-zero skipping of st_gemm_tn.h / st_gemm16.h is active (the default draw stays below 19 windows: one tile holds every frame)
+GROUND16 = True
+import importlib.util as _ilu, os as _os
+_spec = _ilu.spec_from_file_location("fuzz_ground", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "fuzz_ground.py"))
+FG = _ilu.module_from_spec(_spec); _spec.loader.exec_module(FG)
 t0 = time.time(); nbad = 0; n = 0
 while time.time() - t0 < float(sys.argv[1] if len(sys.argv) > 1 else 150):
     scale = random.choice([1, 1, 1, 2, 8]); scheme = "lean" if scale != 2 else random.choice(["lean", "legacy"])
@@ -52,16 +60,30 @@ while time.time() - t0 < float(sys.argv[1] if len(sys.argv) > 1 else 150):
         miss = [r for r in res if not r["ok"]]
         # round 5: no tensor is exempt by name.  A miss of the fixed tolerance in the fp32-grade modes is graded on the spot against the spread of that quantity for this
         # configuration (tests/gpu_spread.py: float32-vs-float64 oracle, float64 oracle under 1e-6 perturbations -- CPU work, ~10-60 s, cached in profiles/); in the 16-bit modes the
-        # fused tolerances already ARE the measured noise floors, a miss there is a hard line (tools/fuzz_ground.py grounds those)
+        # fused tolerances already ARE the measured noise floors of TYPICAL configurations; a miss there is graded against the rounding oracle's own spread below (round 6)
         bad, soft = miss, []
         if miss and bf in (0, 3):
             from tests import gpu_spread as S
             bad = S.grounded(res, kw)
+            soft = [r for r in miss if r.get("grounded")]
+        elif miss and GROUND16:
+            # round 6: the 16-bit lines are graded on the spot too -- the rounding oracle against itself under eight 1e-6 perturbations for THIS configuration
+            # (tools/fuzz_ground.py self_noise: CPU, 10-90 s) and the per-op run on oracle-fed inputs: "hard" is what neither explains
+            mode = {1: "bf16", 2: "bf16_all", 4: "f16_all"}[bf]
+            nz = FG.self_noise(mode, kw, level=1 if bf == 1 else 2)
+            for r in miss:
+                z = nz.get(r["name"]); r["spread"] = z
+                if z and r["rel"] <= 3.0 * z: r["ratio"] = r["rel"] / z; r["grounded"] = True
+            half = "bf16" if mode.startswith("bf16") else "f16"
+            with G.mixed_mode(1 if bf == 1 else 2, half=half, tol_scale=(None if scale != 8 or bf == 1 else (40.0 if half == "bf16" else 20.0))):
+                per = G.run_all(B=kw["B"], seed=kw["seed"], K=kw["K"], scale=kw["scale"], scheme=kw["scheme"], shrink=kw["shrink"])
+            per_bad = [dict(r, name="per-op " + r["name"]) for r in per if not r["ok"] and r["rel"] > nz.get(r["name"].replace("ae_bwd.g.", "grad."), 0.0)]
+            bad = [r for r in miss if not r.get("grounded")] + per_bad
             soft = [r for r in miss if r.get("grounded")]
     except Exception as e:
         bad = [dict(name="EXC " + str(e)[:160], rel=0)]; soft = []
     n += 1; nbad += bool(bad)
     if bad or soft:
         print(("BAD " if bad else "soft"), kw, ("f32", "bf16", "bf16_all", "f32x3", "f16_all")[bf],
-              [(r['name'], f"{r['rel']:.1e}") + ((f"{r['ratio']:.2f} x spread",) if "ratio" in r else ()) for r in (bad + soft)[:4]], flush=True)
+              [(r['name'], f"{r['rel']:.1e}") + ((f"{r['ratio']:.2f} x spread",) if "ratio" in r else ()) + ((f"in {r['rows_over']} of {r['rows']} rows",) if r.get("localized") else ()) for r in (bad + soft)[:4]], flush=True)
 print(f"{n} random configurations, {nbad} with hard failures, {time.time()-t0:.0f} s")
