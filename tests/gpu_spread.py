@@ -43,6 +43,10 @@ def oracle_spread(B, seed, K=4, scale=1, scheme="lean", shrink=4, npert=8, steps
         for nm, key in (("fwd.y_hat", "out"), ("step.y_hat", "out"), ("fwd.mag_hat", "mag_hat"), ("fwd.mag", "mag")):
             d[nm] = float(np.abs(np.asarray(c0[key], np.float64) - np.asarray(c1[key], np.float64)).max() / max(np.abs(c0[key]).max(), 1e-30))
         d["step.loss"] = abs(l0 - l1) / abs(l0)
+        # the published clip norm (sum |g| over the four STFT tensors, nn_proc.py:299-302) inherits the spread of the analysis-basis gradients: one near-silent bin whose row moves by
+        # 20 % of the tensor maximum moves the norm by 1 % (round 6: the sweep's seed-719 window; until then the norm was the one checked quantity without a spread)
+        n0, n1 = (sum(float(np.abs(np.asarray(G[k], np.float64)).sum()) for k in O.param_order()[:4]) for G in (G0, G1))
+        d["step.l1norm"] = abs(n0 - n1) / max(abs(n0), 1e-30)
         p1 = _step_params(G1, P, lr)
         d["train0.params"] = float(max(np.abs(p0[k].astype(np.float64) - p1[k]).max() for k in p0))
         return d
