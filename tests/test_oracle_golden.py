@@ -433,3 +433,44 @@ def test_g13_near_silent_backward(golden_dir, ci):
         if (pre + "max_" + k) in g:
             ref = float(g[pre + "max_" + k])
             assert abs(np.abs(g64[k]).max() - ref) <= 1e-4 * max(ref, 1e-30), k
+
+
+def test_spread_grading_rules_cap_and_localized_miss():
+    """tests/gpu_spread.grounded() on synthetic check records (no GPU, no oracle run: the spread of the configuration comes from the committed table).
+    A miss of the fixed tolerance is accepted (a) inside 3 x the spread and 10 x the tolerance; (b) round 6: over that cap only when the elements over the tolerance
+    sit in <= LOCAL_ROWS rows of a tensor with >= 8 x LOCAL_ROWS rows (a near-silent bin pollutes ONE row of an analysis-basis gradient, a wrong tile covers >= 96);
+    everything else stays a failure -- outside the spread, spread out over many rows, a scalar over the cap, a quantity the spread does not cover."""
+    from tests import gpu_spread as S
+    kw = dict(B=1, seed=499, K=2, scale=2, scheme="lean", shrink=4)           # profiles/r05_fuzz_f32_spread.json holds it (tools/fuzz_ground_f32.py case 21)
+    sp = S.spread_of(kw)
+    name = "grad.dft_analysis.conv_analysis_imag.weight"
+    s = max(sp["f32"][name], sp["noise"][name])
+    assert 5e-3 < s < 5e-2                                                       # a spread of ~1e-2: the configuration the localized rule was written for
+    tol = 2e-4
+    rec = lambda rel, **kwargs: dict(name=name, rel=rel, tol=tol, ok=False, err=rel, scale=1.0, **kwargs)
+    inside_cap = rec(5 * tol, rows=1024, rows_over=300)
+    assert S.grounded([inside_cap], kw) == [] and inside_cap["grounded"] and not inside_cap.get("localized")
+    local = rec(14 * tol, rows=1024, rows_over=1)
+    assert 14 * tol < 3 * s
+    assert S.grounded([local], kw) == [] and local["localized"]
+    edge = rec(14 * tol, rows=1024, rows_over=S.LOCAL_ROWS)
+    assert S.grounded([edge], kw) == []
+    for bad in (rec(14 * tol, rows=1024, rows_over=S.LOCAL_ROWS + 1),          # spread over more rows than a conditioning miss has
+                rec(14 * tol, rows=1024, rows_over=128),                          # a tile's worth
+                rec(14 * tol, rows=64, rows_over=1),                              # a tensor too small for "a few rows" to mean anything
+                rec(14 * tol),                                                    # no row information (a scalar): the cap stands
+                rec(3.5 * s, rows=1024, rows_over=1)):                            # localized but outside 3 x the spread
+        assert S.grounded([bad], kw) == [bad] and not bad["ok"], bad
+    unknown = dict(name="some.other.quantity", rel=1e-3, tol=1e-4, ok=False, err=1e-3, scale=1.0)
+    assert S.grounded([unknown], kw) == [unknown]
+    # the clip norm has a spread entry for configurations graded since round 6 ...
+    kw2 = dict(B=5, seed=719, K=12, scale=1, scheme="lean", shrink=4)
+    sp2 = S.spread_of(kw2)
+    assert 5e-3 < max(sp2["f32"]["step.l1norm"], sp2["noise"]["step.l1norm"]) < 2e-2
+    norm = dict(name="step.l1norm", rel=9.9e-3, tol=1e-3, ok=False, err=9.9e-3, scale=1.0)
+    assert S.grounded([norm], kw2) == []
+    # ... and stays a failure where the committed table predates it
+    old = dict(B=6, seed=576, K=4, scale=1, scheme="lean", shrink=8)
+    if "step.l1norm" not in S.spread_of(old)["f32"]:
+        norm_old = dict(name="step.l1norm", rel=2e-3, tol=1e-3, ok=False, err=2e-3, scale=1.0)
+        assert S.grounded([norm_old], old) == [norm_old]
