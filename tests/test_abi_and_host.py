@@ -426,3 +426,49 @@ def test_run_train_accepts_the_reference_effect_keys():
     assert r.returncode != 0 and "is not yet added" in r.stderr
     r = run("--effect", "comp_large", "--target", "nope")
     assert r.returncode != 0 and "invalid target type" in r.stderr            # comp_large passed the effect check (argparse used to reject it)
+
+
+def test_dims_edge_cases_are_refused_with_a_message():
+    """Edge cases at the C ABI, before any launch (host-side validation only: runs without a GPU).  Empty batch, a geometry that is not the reference's
+    (F != N/2 + 1, y != (OT - 1) H - N: nn_proc.py:357-385), more knobs than the fused kernels carry, an unknown arithmetic level, a negative / infinite loss
+    scale, and the MAXIMUM sizes: batches whose row count or operand sizes leave the 24-bit row / 32-bit element indexing of the kernels (include/signaltrain_hip.h)
+    are refused by name instead of wrapping around.  The largest admitted batch still reports a layout and a workspace size."""
+    import ctypes as C
+    lib = _lib.load()
+    good = _lib.geometry(1, 4, 4, 256)
+    assert lib.st_param_offsets(C.byref(good), None) > 0 and lib.st_workspace_bytes(C.byref(good)) > 0
+
+    def refused(mut, needle):
+        d = good.with_batch(good.B); mut(d)
+        assert lib.st_param_offsets(C.byref(d), None) == -1, needle
+        msg = lib.st_last_error().decode()
+        assert needle in msg, (needle, msg)
+        # a compute entry refuses the same dims before it looks at any pointer
+        assert lib.st_analysis_fwd(C.byref(d), None, None, None, 0.5, None, None, None, None, None) < 0
+    refused(lambda d: setattr(d, "B", 0), "non-positive")
+    refused(lambda d: setattr(d, "B", -3), "non-positive")
+    refused(lambda d: setattr(d, "K", -1), "non-positive")
+    refused(lambda d: setattr(d, "K", 17), "at most 16 knobs")
+    refused(lambda d: setattr(d, "F", d.F - 1), "F must be N/2+1")
+    refused(lambda d: setattr(d, "y", d.y + 4), "y must equal")
+    refused(lambda d: setattr(d, "OT", d.T + 1), "y must equal")           # OT > T also breaks y = (OT - 1) H - N first
+    refused(lambda d: setattr(d, "prec", 99), "ST_PREC")
+    refused(lambda d: setattr(d, "loss_scale", -1.0), "loss_scale")
+    refused(lambda d: setattr(d, "loss_scale", float("inf")), "loss_scale")
+    refused(lambda d: setattr(d, "L", d.L + 2), "required")                # ragged window length: L % 4
+    # maximum sizes: rows B * T < 2^24, B * T * KP and B * (L + 2 N) < 2^30 elements
+    kp = int(lib.st_kp(good.F))
+    b_max = min(((1 << 24) - 1) // good.T, ((1 << 30) - 1) // (good.T * kp), ((1 << 30) - 1) // (good.L + 2 * good.N))
+    ok = good.with_batch(b_max)
+    assert lib.st_param_offsets(C.byref(ok), None) > 0, lib.st_last_error()
+    assert lib.st_workspace_bytes(C.byref(ok)) > lib.st_workspace_bytes(C.byref(good))
+    refused(lambda d: setattr(d, "B", b_max + 1), "batch too large")
+    refused(lambda d: setattr(d, "B", 1 << 30), "batch too large")
+    # the 65536-sample window has its own, smaller limit
+    wide = _lib.geometry(8, 4, 4, 64)
+    kpw = int(lib.st_kp(wide.F))
+    bw = min(((1 << 24) - 1) // wide.T, ((1 << 30) - 1) // (wide.T * kpw), ((1 << 30) - 1) // (wide.L + 2 * wide.N))
+    assert bw < b_max and lib.st_param_offsets(C.byref(wide.with_batch(bw)), None) > 0
+    assert lib.st_param_offsets(C.byref(wide.with_batch(bw + 1)), None) == -1 and b"batch too large" in lib.st_last_error()
+    # a null dims pointer
+    assert lib.st_param_offsets(None, None) == -1 and b"null dims" in lib.st_last_error()

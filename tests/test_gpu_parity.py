@@ -706,3 +706,40 @@ def test_ola_loss_partials_do_not_depend_on_pointer_alignment(B, nslab_scale):
     lc = np.zeros((B, nlp * 256)); lc[:, :ysz] = np.log(np.cosh(Y.astype(np.float64) - ya.reshape(B, ysz).astype(np.float64)))
     ref = lc.reshape(B, nlp, 256).sum(-1).reshape(-1)
     assert np.allclose(la, ref, rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("scale,shrink,B", [(1, 4, 3), (1, 2, 4), (8, 4, 2)])
+@pytest.mark.parametrize("mode", ["f32", "f32x3", "bf16_all", "f16_all"])
+def test_digital_silence_through_the_fused_step(mode, scale, shrink, B):
+    """Edge case of the domain: DIGITAL SILENCE.  Window 0 is all zeros (input and target), window 1 starts with half a window of zeros -- frames that are exactly
+    zero, then frames that straddle the onset.  At an exactly silent bin re = im = 0: mag = 0, phs = atan2(0, 1e-7) = 0 (nn_proc.py:309-310), d|.| = 0 by the
+    sub-gradient the reference's autograd uses and d atan2 / d im = 1e7 (probed) -- finite, and multiplied by a frame of zeros in the analysis weight
+    gradient, so a silent frame contributes exactly nothing; under fp16 that 1e7 x loss scale 4096 is what the polar backward saturates before the GEMM narrows it
+    (inf x 0 would poison the basis gradient with NaN).  Forward, loss, all 40 gradient tensors, the clip norm and the parameters after one step against the oracle
+    at the suite's own tolerances, in the four arithmetic families and at both windows of BASELINE.json."""
+    import numpy as np
+    from tests import gpu_checks as G
+    geo, X, Y, KN, P = G.make_case(B, 77, K=4, scale=scale, shrink=shrink)
+    X = X.copy(); Y = Y.copy()
+    X[0] = 0.0; Y[0] = 0.0
+    X[1, : X.shape[1] // 2] = 0.0
+
+    def run():
+        d = G.dims_of(geo, B, 4)
+        restore = G.follow_effective_arithmetic(d)
+        try:
+            return G._run_fused(geo, X, Y, KN, P, d, B, 4, 1)
+        finally:
+            restore()
+    if mode == "f32":
+        res = run()
+    elif mode == "f32x3":
+        with G.split_mode(): res = run()
+    elif mode == "bf16_all":
+        with G.mixed_mode(2, half="bf16", tol_scale=G.mixed_mode.FUSED_TOL[2]): res = run()
+    else:
+        with G.mixed_mode(2, half="f16", tol_scale=G.mixed_mode.FUSED_TOL_F16[2] * (2.0 if scale == 8 else 1.0)): res = run()
+    assert len(res) == 48
+    assert all(np.isfinite(r["err"]) for r in res)
+    bad = [r for r in res if not r["ok"]]
+    assert not bad, [(r["name"], r["rel"], r["tol"]) for r in bad]
