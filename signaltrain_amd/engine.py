@@ -196,6 +196,12 @@ class StepEngine:
         assert x.shape == (d.B, d.L) and knobs.shape == (d.B, d.K), (x.shape, knobs.shape, d.as_dict())
         if y is not None:
             assert y.shape == (d.B, d.y), (y.shape, d.y)
+        if d.K == 0:
+            # a model WITHOUT knobs (nn_proc.py:92-93 concatenates an empty [B, 0] tensor): an empty tensor has no data pointer, the C ABI refuses NULL, and the
+            # kernels issue one clamped -- always valid -- load of knobs[0] per row group before they mask it: they get the address of a resident zero
+            if getattr(self, "_no_knobs", None) is None:
+                self._no_knobs = torch.zeros(4, dtype=torch.float32, device=self.device)
+            knobs = self._no_knobs
         return d, x, knobs, y
 
     # ---------------------------------------------------------------- forward / backward / step
@@ -215,6 +221,8 @@ class StepEngine:
         one forward + backward per window.  Overwrites the workspace's saved-for-backward state (call forward(save_for_backward=True) again before
         backward()); the parameter gradients of these passes go to a scratch buffer, self.grads is left alone."""
         d, x, knobs, _ = self._prep(x, knobs)
+        if d.K == 0:
+            return torch.empty(d.B, 0, dtype=torch.float32, device=self.device)
         d.loss_scale = 0.0
         f = lambda t: None if t is None else t.to(device=self.device, dtype=torch.float32).contiguous()
         g_y_hat, g_mag_hat, g_mag = f(g_y_hat), f(g_mag_hat), f(g_mag)
@@ -333,7 +341,7 @@ class StepEngine:
         d = self._dims(int(batch))
         dev = self.device
         self.gx = torch.zeros(d.B, d.L, dtype=torch.float32, device=dev)
-        self.gk = torch.zeros(d.B, d.K, dtype=torch.float32, device=dev)
+        self.gk = torch.zeros(d.B, d.K, dtype=torch.float32, device=dev) if d.K else torch.zeros(4, dtype=torch.float32, device=dev)      # K = 0: see _prep
         self.gy = torch.zeros(d.B, d.y, dtype=torch.float32, device=dev)
         self.g_lr = torch.as_tensor(np.asarray(lr_table, dtype=np.float32), device=dev).contiguous()
         self.scalars[6] = float(self.step_count)
@@ -354,7 +362,8 @@ class StepEngine:
         """One optimisation step = one hipGraphLaunch on the current stream.  x / knobs / y (optional) are copied into the
         graph's input buffers first; with all three None the buffers are used as they are (device-resident data)."""
         if x is not None:
-            self.gx.copy_(x); self.gk.copy_(knobs); self.gy.copy_(y)
+            self.gx.copy_(x); self.gy.copy_(y)
+            if self.dims.K: self.gk.copy_(knobs)
         self.step_count += 1; self.generation += 1
         self._call("st_graph_launch", self.graph, self._stream())
         return self.scalars

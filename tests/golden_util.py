@@ -47,3 +47,19 @@ def sample_rows(w):
 def projections(seed, n=4, size=1024):
     """n deterministic probe vectors (rows) used to fingerprint 1024x1024 tensors."""
     return hash_uniform((n, size), seed) * 2.0
+
+
+def g14_case(ci):
+    """The three edge cases of golden G14 (tools/capture_golden_r6.py), regenerated from portable generators: (geo, X, Y, KN, P, K).
+    0: a model without knobs; 1: one knob; 2: digital silence -- window 0 all zeros (input and target), window 1 half a window of zeros, window 2 plain."""
+    from tests import gpu_checks as G          # make_case only (numpy)
+    if ci == 0:
+        K = 0; geo, X, Y, KN, P = G.make_case(2, 5, K=K)
+    elif ci == 1:
+        K = 1; geo, X, Y, KN, P = G.make_case(2, 5, K=K)
+    else:
+        K = 4; geo, X, Y, KN, P = G.make_case(3, 77, K=K)
+        X = X.copy(); Y = Y.copy()
+        X[0] = 0.0; Y[0] = 0.0
+        X[1, : X.shape[1] // 2] = 0.0
+    return geo, X, Y, KN, P, K

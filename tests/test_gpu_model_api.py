@@ -895,3 +895,91 @@ def test_model_input_gradient_matches_torch_autograd():
     assert (y_hat.detach().double().cpu() - yr.detach()).abs().max() < 1e-4 * yr.detach().abs().max()
     e = (x.grad.double().cpu() - xd.grad).abs().max() / xd.grad.abs().max()
     assert e < 2e-5, float(e)
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2])
+def test_g14_edges_on_the_device(golden_dir, ci):
+    """Golden G14 (the reference's forward / loss / fp32 autograd on three edge cases: a model WITHOUT knobs, one knob, digital silence -- tools/capture_golden_r6.py)
+    against the HIP path directly: through the drop-in st_model + torch.autograd AND through the fused loss_backward entry.  y_hat and loss at 1e-4, the 36
+    autoencoder gradients at 2e-4 of the tensor maximum, the STFT gradients' sampled rows / projections / L1 norms at the suite's tolerances (analysis bases:
+    max(2e-4, 3 x the reference's own fp32 distance from float64))."""
+    from tests.golden_util import g14_case, ae_keys, projections, SAMPLE_ROWS, STFT_KEYS
+    from signaltrain_amd import nn_proc, loss_functions
+    nn_proc._QUIET = True
+    g = np.load(os.path.join(golden_dir, "g14_edges.npz"))
+    geo, X, Y, KN, P, K = g14_case(ci)
+    pre = f"c{ci}_"
+    m = nn_proc.st_model(scale_factor=1, shrink_factor=4, num_knobs=K)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in P.items()})
+    m = m.to("cuda:0")
+    x, kn, yt = torch.from_numpy(X).cuda(), torch.from_numpy(KN).cuda(), torch.from_numpy(Y).cuda()
+    assert kn.shape == (X.shape[0], K)
+    PROJ = projections(seed=23)
+    F = geo["F"]
+
+    def check(loss, y_hat, grads, what):
+        assert abs(loss - float(g[pre + "loss"])) <= 1e-4 * abs(float(g[pre + "loss"])), (what, loss, float(g[pre + "loss"]))
+        assert np.isfinite(y_hat).all() and np.abs(y_hat - g[pre + "y_hat"]).max() <= 1e-4 * np.abs(g[pre + "y_hat"]).max(), what
+        for k in ae_keys():
+            ref = g[pre + "g_" + k].astype(np.float64)
+            got = grads[k].reshape(ref.shape)
+            assert np.isfinite(got).all() and np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-12, (what, k)
+        for k in STFT_KEYS:
+            gk = grads[k].reshape(1024, 1024)
+            tol = max(2e-4, 3.0 * float(g[pre + "ref_vs_f64_" + k]) if "analysis" in k else 2e-4) * float(g[pre + "max_" + k])
+            assert np.isfinite(gk).all()
+            assert np.abs(gk[SAMPLE_ROWS] - g[pre + "rows_" + k]).max() <= tol, (what, k)
+            assert np.abs(PROJ @ gk - g[pre + "proj_" + k]).max() <= 1024 * tol, (what, k)
+            assert abs(np.abs(gk).sum() - float(g[pre + "l1_" + k])) <= 1e-3 * float(g[pre + "l1_" + k]), (what, k)
+    y, mag, mag_hat = m.forward(x, kn)
+    sbf = torch.exp((7. / F) * torch.arange(0., F, device="cuda")).expand_as(mag_hat).float()
+    loss = loss_functions.calc_loss(y, yt, mag_hat, scale_by_freq=sbf)
+    loss.backward()
+    check(loss.item(), y.detach().cpu().numpy(), {k: p.grad.detach().cpu().numpy().astype(np.float64) for k, p in m.named_parameters()}, "autograd")
+    eng = m.engine(x)
+    outs = eng.loss_backward(x, kn, yt, want_outputs=True); torch.cuda.synchronize()
+    check(float(eng.scalars[0]), outs[0].detach().cpu().numpy(), {k: v.detach().cpu().numpy().astype(np.float64) for k, v in eng.layout.views(eng.grads).items()}, "fused")
+    if ci == 2:                                  # the all-zero window: y_hat = 2 (syn + x / 2) of silence is what the model makes of a zero spectrum, the same bits as the oracle's convention allows
+        assert np.isfinite(mag.detach().cpu().numpy()).all() and float(mag[0].detach().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16_all", "f16_all"])
+def test_model_without_knobs_every_engine_entry(dtype):
+    """num_knobs = 0 (the reference builds it: nn_proc.py:92-93 concatenates an empty [B, 0] tensor; golden G14 case 0) through every engine entry that takes knobs:
+    forward, loss_backward and a train step against the oracle (run_fused, the mode's tolerances), the graph step against the eager step (same bits), the exchange
+    step with one rank, st_model_knob_grad (an empty [B, 0] result) and the standalone autoencoder module with return_acts.  An empty tensor has no data pointer and the
+    C ABI refuses NULL: the Python layer hands the kernels the address of a resident zero (engine._prep), which is what a C host has to do too."""
+    from tests import gpu_checks as G
+    from signaltrain_amd import nn_proc
+    from signaltrain_amd.engine import StepEngine
+    nn_proc._QUIET = True
+    kw = dict(B=3, seed=41, K=0, steps=2)
+    if dtype == "f32":
+        res = G.run_fused(**kw)
+    elif dtype == "bf16_all":
+        with G.mixed_mode(2, half="bf16", tol_scale=G.mixed_mode.FUSED_TOL[2]): res = G.run_fused(**kw)
+    else:
+        with G.mixed_mode(2, half="f16", tol_scale=G.mixed_mode.FUSED_TOL_F16[2]): res = G.run_fused(**kw)
+    bad = [r for r in res if not r["ok"]]
+    assert not bad, [(r["name"], r["rel"], r["tol"]) for r in bad]
+    geo, X, Y, KN, P = G.make_case(3, 41, K=0)
+    assert KN.shape == (3, 0)
+    d = G.dims_of(geo, 3, 0)
+    x, kn, y = G.t(X), G.t(KN), G.t(Y)
+    a = StepEngine(d, G.DEV, compute_dtype=dtype); a.load_state_dict(P)
+    b = StepEngine(d, G.DEV, compute_dtype=dtype); b.load_state_dict(P)
+    c = StepEngine(d, G.DEV, compute_dtype=dtype); c.load_state_dict(P)
+    lrs = [1e-3, 1e-3, 7e-4]
+    b.graph_capture(3, lrs)
+    for i in range(3):
+        a.train_step(x, kn, y, lrs[max(i - 1, 0)])
+        b.graph_step(x, kn, y)
+        c.dp_train_step(x, kn, y, lrs[max(i - 1, 0)], force_exchange=False)
+    torch.cuda.synchronize()
+    assert torch.equal(a.params, b.params) and torch.equal(a.params, c.params) and bool(torch.isfinite(a.params).all())
+    assert a.knob_grad(x, kn, torch.zeros_like(y)).shape == (3, 0)
+    if dtype == "f32":
+        ae = nn_proc.AsymAutoEncoder(T=geo["T"], R=64, K=0, OT=geo["OT"]).to(G.DEV)
+        v = torch.rand(2, geo["T"], geo["F"], device=G.DEV)
+        out, acts = ae.forward(v, torch.zeros(2, 0, device=G.DEV), skip_connections='sf', return_acts=True)
+        assert out.shape == (2, geo["OT"], geo["F"]) and bool(torch.isfinite(out).all()) and len(acts) == 10

@@ -474,3 +474,36 @@ def test_spread_grading_rules_cap_and_localized_miss():
     if "step.l1norm" not in S.spread_of(old)["f32"]:
         norm_old = dict(name="step.l1norm", rel=2e-3, tol=1e-3, ok=False, err=2e-3, scale=1.0)
         assert S.grounded([norm_old], old) == [norm_old]
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2])
+def test_g14_edges(golden_dir, ci):
+    """G14 (tools/capture_golden_r6.py): three edge cases of the model surface through the REFERENCE's forward / loss / fp32 autograd -- a model without knobs
+    (nn_proc.py:92-93 concatenates an empty tensor), one knob, and DIGITAL SILENCE (an all-zero window, a window that starts with half a window of zeros: 52 % of the
+    STFT bins are exactly zero; the reference takes d |.| = 0 and d atan2 / d im = 1e7 there, nn_proc.py:309-310).  The oracle in float64 reproduces loss (3e-5),
+    y_hat (1e-5), all 36 autoencoder gradients (1e-4 of the tensor maximum) and the fingerprints of the four STFT gradients (synthesis 2e-5; analysis
+    max(2e-5, 3 x the reference's own distance from float64), as in G13)."""
+    from tests.golden_util import g14_case
+    g = np.load(os.path.join(golden_dir, "g14_edges.npz"))
+    geo, X, Y, KN, P, K = g14_case(ci)
+    assert KN.shape == (X.shape[0], K)
+    l64, g64, c64 = O.model_loss_bwd(X.astype(np.float64), KN.astype(np.float64), Y.astype(np.float64), {k: v.astype(np.float64) for k, v in P.items()}, geo)
+    pre = f"c{ci}_"
+    assert abs(l64 - float(g[pre + "loss"])) <= 3e-5 * abs(l64)
+    assert np.abs(c64["out"] - g[pre + "y_hat"]).max() <= 1e-5 * np.abs(c64["out"]).max()
+    assert abs(np.abs(c64["mag"]).max() - float(g[pre + "mag_max"])) <= 1e-5 * float(g[pre + "mag_max"])
+    assert abs(np.abs(c64["mag_hat"]).max() - float(g[pre + "mag_hat_max"])) <= 1e-5 * float(g[pre + "mag_hat_max"])
+    if ci == 2:
+        assert (c64["mag"] == 0).mean() > 0.5 and np.all(c64["out"][0] == c64["out"][0]) and all(np.isfinite(v).all() for v in g64.values())
+    for k in ae_keys():
+        ref = g[pre + "g_" + k].astype(np.float64)
+        assert ref.shape == g64[k].shape, (k, ref.shape, g64[k].shape)
+        assert np.abs(g64[k] - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-30), k
+    PROJ = projections(seed=23)
+    for k in STFT_KEYS:
+        m = g64[k][:, 0, :]
+        sc = float(g[pre + "max_" + k])
+        tol = max(2e-5, 3.0 * float(g[pre + "ref_vs_f64_" + k]) if "analysis" in k else 2e-5) * sc
+        assert np.abs(m[SAMPLE_ROWS] - g[pre + "rows_" + k]).max() <= tol, k
+        assert np.abs(PROJ @ m - g[pre + "proj_" + k]).max() <= 1024 * tol, k
+        assert abs(np.abs(m).sum() - float(g[pre + "l1_" + k])) <= 1e-4 * float(g[pre + "l1_" + k]), k
