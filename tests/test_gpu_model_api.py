@@ -983,3 +983,43 @@ def test_model_without_knobs_every_engine_entry(dtype):
         v = torch.rand(2, geo["T"], geo["F"], device=G.DEV)
         out, acts = ae.forward(v, torch.zeros(2, 0, device=G.DEV), skip_connections='sf', return_acts=True)
         assert out.shape == (2, geo["OT"], geo["F"]) and bool(torch.isfinite(out).all()) and len(acts) == 10
+
+
+def test_growing_batch_recreates_the_engine_without_losing_state(golden_dir):
+    """The reference's flows change the batch under a live model: train.py trains at batch_size, predict_long runs 200 windows at a time (predict_long.py:44-47), a last
+    partial batch is smaller.  st_model sizes its engine for the largest batch seen so far and RE-CREATES it (parameters re-pointed into the new flat buffer) when a
+    larger one arrives.  Model A trains on batches of 4, 9, 2 windows with a torch optimizer (the reference-style loop, train.py:131-151) -- the engine is rebuilt in
+    the middle of the run, between a backward and the next forward; model B sees a 9-window batch first (no_grad), so it never rebuilds.  Same data, same kernels:
+    parameters, gradients and Adam moments must agree bit for bit, and the fused engine entry must see the same parameters afterwards."""
+    from signaltrain_amd import nn_proc, loss_functions
+    nn_proc._QUIET = True
+    mA, g, P, geo = _golden_model(golden_dir)
+    mB, _, _, _ = _golden_model(golden_dir)
+    rng = np.random.default_rng(12)
+    X = torch.from_numpy((0.3 * rng.standard_normal((9, geo["L"]))).astype(np.float32)).cuda()
+    Y = torch.from_numpy((0.3 * rng.standard_normal((9, geo["y"]))).astype(np.float32)).cuda()
+    KN = torch.from_numpy((rng.random((9, 4)) - 0.5).astype(np.float32)).cuda()
+    with torch.no_grad():
+        mB.forward(X, KN)                                    # B's engine is sized for 9 windows from the start
+    engB = mB.mpaec._engine
+    oA = torch.optim.Adam(mA.parameters(), lr=1e-3); oB = torch.optim.Adam(mB.parameters(), lr=1e-3)
+    rebuilt = []
+    for nb in (4, 9, 2):
+        for m, o in ((mA, oA), (mB, oB)):
+            before = m.mpaec._engine
+            y, mag, mag_hat = m.forward(X[:nb], KN[:nb])
+            if m is mA:
+                rebuilt.append(before is not None and m.mpaec._engine is not before)
+            sbf = torch.exp((7. / 513) * torch.arange(0., 513, device="cuda")).expand_as(mag_hat).float()
+            loss = loss_functions.calc_loss(y, Y[:nb], mag_hat, scale_by_freq=sbf)
+            o.zero_grad(); loss.backward(); m.clip_grad_norm_(); o.step()
+    assert rebuilt == [False, True, False] and mB.mpaec._engine is engB
+    for (ka, pa), (kb, pb) in zip(mA.named_parameters(), mB.named_parameters()):
+        assert ka == kb and torch.equal(pa, pb), ka
+        assert torch.equal(pa.grad, pb.grad), ka
+        sa, sb = oA.state[pa], oB.state[pb]
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), ka
+    # the fused entry of the rebuilt engine reads the very parameters the optimizer has been updating
+    eA, eB = mA.engine(X[:2]), mB.engine(X[:2])
+    eA.loss_backward(X[:2], KN[:2], Y[:2]); eB.loss_backward(X[:2], KN[:2], Y[:2]); torch.cuda.synchronize()
+    assert torch.equal(eA.params, eB.params) and torch.equal(eA.grads, eB.grads) and float(eA.scalars[0]) == float(eB.scalars[0])
