@@ -189,6 +189,9 @@ def train(effect=None, epochs=100, n_data_points=200000, batch_size=20, device=N
     if state_dict != {}:
         model.load_state_dict(state_dict)
     chunk_size, out_chunk_size = model.in_chunk_size, model.out_chunk_size
+    if n_data_points < batch_size or epochs < 1:
+        # the reference fails late and obscurely here (an epoch needs >= 10 minibatches: UnboundLocalError at train.py:158; the 1-cycle table is empty)
+        raise ValueError(f"train(): n_data_points = {n_data_points} with batch_size = {batch_size}, epochs = {epochs}: less than one minibatch per epoch -- nothing to train on")
     print("Model defined.  Number of trainable parameters:", sum(p.numel() for p in model.parameters() if p.requires_grad))
     model.to(device)
     model.set_compute_dtype(compute_dtype)

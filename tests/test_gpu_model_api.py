@@ -1023,3 +1023,25 @@ def test_growing_batch_recreates_the_engine_without_losing_state(golden_dir):
     eA, eB = mA.engine(X[:2]), mB.engine(X[:2])
     eA.loss_backward(X[:2], KN[:2], Y[:2]); eB.loss_backward(X[:2], KN[:2], Y[:2]); torch.cuda.synchronize()
     assert torch.equal(eA.params, eB.params) and torch.equal(eA.grads, eB.grads) and float(eA.scalars[0]) == float(eB.scalars[0])
+
+
+def test_train_driver_awkward_data_counts(tmp_path):
+    """Ragged ends of the driver (train.py:167-263): a number of data points that is not a multiple of the batch (the remainder is dropped, like the reference's
+    DataLoader with drop_last), a validation set smaller than one batch (n_data_points // 4 < batch_size: no validation minibatch -- the log files still get their line,
+    the MAE column says nan), and less than one training minibatch, which the reference meets late with an UnboundLocalError (train.py:125-158) and this driver refuses
+    up front by name."""
+    from signaltrain_amd import train, audio, nn_proc
+    nn_proc._QUIET = True
+    cwd = os.getcwd(); os.chdir(tmp_path)
+    try:
+        model = train.train(effect=audio.Compressor_4c(), epochs=2, n_data_points=100, batch_size=48, device=torch.device("cuda:0"))
+        eng = model.engine(torch.zeros(48, 8192, device="cuda"))
+        assert eng.step_count == 2 * (100 // 48)                          # 2 epochs x 2 whole minibatches, 4 windows dropped per epoch
+        lines = open("val_err_mae.dat").read().split("\n")[:2]
+        assert [l.split()[0] for l in lines] == ["1", "2"] and all(l.split()[1] == "nan" for l in lines)      # 25 validation windows < one batch of 48
+        assert len(open("vl_avg_out.dat").read().strip().split("\n")) == 2
+        assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
+        with pytest.raises(ValueError, match="less than one minibatch"):
+            train.train(effect=audio.Compressor_4c(), epochs=1, n_data_points=40, batch_size=48, device=torch.device("cuda:0"))
+    finally:
+        os.chdir(cwd)
