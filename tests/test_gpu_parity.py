@@ -743,3 +743,22 @@ def test_digital_silence_through_the_fused_step(mode, scale, shrink, B):
     assert all(np.isfinite(r["err"]) for r in res)
     bad = [r for r in res if not r["ok"]]
     assert not bad, [(r["name"], r["rel"], r["tol"]) for r in bad]
+
+
+@pytest.mark.parametrize("scale,scheme,shrink", [(8, "lean", 4), (2, "lean", 4), (2, "legacy", 4), (1, "lean", 1)])
+@pytest.mark.parametrize("mode", ["f32", "bf16_all", "f16_all"])
+def test_model_without_knobs_on_the_wide_geometries(mode, scale, scheme, shrink):
+    """num_knobs = 0 (golden G14 case 0 pins the oracle to the reference for it) where the autoencoders take the WIDE path (st_ae_wide.h: the 65536-sample window, lean and
+    legacy scale 2, shrink 1): the knob rows of the layer-5 input are an empty job of prep_kernel there, the inner kernels mask their clamped knob load.  Fused step
+    against the oracle at the mode's tolerances."""
+    from tests import gpu_checks as G
+    kw = dict(B=2, seed=41, K=0, steps=1, scale=scale, scheme=scheme, shrink=shrink)
+    if mode == "f32":
+        res = G.run_fused(**kw)
+    else:
+        half = "bf16" if mode == "bf16_all" else "f16"
+        ftol = (G.mixed_mode.FUSED_TOL if half == "bf16" else G.mixed_mode.FUSED_TOL_F16)[2] * (2.0 if scale == 8 else 1.0)
+        with G.mixed_mode(2, half=half, tol_scale=ftol):
+            res = G.run_fused(**kw)
+    bad = [r for r in res if not r["ok"]]
+    assert not bad, [(r["name"], r["rel"], r["tol"]) for r in bad]
