@@ -1045,3 +1045,28 @@ def test_train_driver_awkward_data_counts(tmp_path):
             train.train(effect=audio.Compressor_4c(), epochs=1, n_data_points=40, batch_size=48, device=torch.device("cuda:0"))
     finally:
         os.chdir(cwd)
+
+
+@pytest.mark.parametrize("n", [1000, 7000, 8192, 8193, 8192 + 2048, 8192 + 5 * 2048 - 1])
+def test_predict_long_ragged_lengths(golden_dir, n):
+    """predict_long (utils/predict_long.py:30-79) at the ragged ends: a signal shorter than one window (the reference's sliding_window builds a negative window count
+    there, audio.py:41-47; here the signal is zero-padded to one window and what is returned is what has a full lookback: nothing below chunk - out_chunk samples),
+    exactly one window, one sample more, whole hops, one sample short of whole hops.  Length and values against the oracle run window by window."""
+    from oracle import st_oracle as O
+    from signaltrain_amd.predict import predict_long
+    m, g, P, geo = _golden_model(golden_dir)
+    L, ysz = geo["L"], geo["y"]
+    rng = np.random.default_rng(n)
+    sig = (0.4 * np.sin(np.arange(n) * 0.013) + 0.05 * rng.standard_normal(n)).astype(np.float32)
+    kn = np.array([0.1, -0.3, 0.25, -0.45], np.float32)
+    y = predict_long(sig, kn, m, L, ysz, batch_size=2)
+    want = max(n - (L - ysz), 0)
+    assert y.dtype == np.float32 and y.shape == (want,)
+    if want == 0:
+        return
+    step = ysz
+    pad = (L - n) if n < L else ((step - (n - L) % step) % step)
+    sp = np.concatenate([sig, np.zeros(pad, np.float32)])
+    xw = np.stack([sp[i:i + L] for i in range(0, sp.size - L + 1, step)])
+    ref = O.model_fwd(np.ascontiguousarray(xw), np.tile(kn, (xw.shape[0], 1)), P, geo)[0].reshape(-1)[:want]
+    assert np.abs(y - ref).max() <= 1e-4 * np.abs(ref).max()
