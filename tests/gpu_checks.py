@@ -212,6 +212,8 @@ def _run_all(lib, geo, X, Y, KN, P, d, B, K, verbose):
     ae_m = flat[lay.offsets[4]:lay.offsets[22]]; ae_p = flat[lay.offsets[22]:]
     PG = lay.offsets[22] - lay.offsets[4]
     x, kn, y = t(X), t(KN), t(Y)
+    if K == 0:
+        kn = t(np.zeros(4, np.float32))      # a model without knobs: an empty tensor has no address and the ABI refuses NULL; the kernels mask their one clamped load
     z = lambda *s: torch.zeros(*s, device=DEV)
 
     # 1. analysis + polar

@@ -762,3 +762,7 @@ def test_model_without_knobs_on_the_wide_geometries(mode, scale, scheme, shrink)
             res = G.run_fused(**kw)
     bad = [r for r in res if not r["ok"]]
     assert not bad, [(r["name"], r["rel"], r["tol"]) for r in bad]
+    if mode == "f32":              # ... and every per-op C entry (66 checks; the knob pointer of a knob-less model is the address of a resident zero: gpu_checks._run_all)
+        per = G.run_all(B=2, seed=3, K=0, scale=scale, scheme=scheme, shrink=shrink)
+        bad = [r for r in per if not r["ok"]]
+        assert len(per) == 66 and not bad, [(r["name"], r["rel"], r["tol"]) for r in bad]

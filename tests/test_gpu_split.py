@@ -93,3 +93,25 @@ def test_split_trains_like_fp32():
         assert np.isfinite(l).all() and l[-60:].mean() < 0.5 * l[:10].mean(), (mode, l[:10].mean(), l[-60:].mean())     # it trains
         tail[mode] = float(l[-60:].mean())
     assert abs(tail["f32x3"] / tail["f32"] - 1.0) < 0.15, tail
+
+
+def test_split_known_limit_at_an_ill_conditioned_bin():
+    """Where "fp32-grade" ends (round 6, found by the geometry-corner sweep: profiles/r06_fuzz_parity_geo_seed2026.txt).  L = 65536, shrink 2 (T = 174, OT = 89), B = 4, seed 243: the exact
+    fp32 path is 4.5e-6 from the float64 oracle on every tensor; f32x3 misses the fixed 2e-4 on two -- the real analysis basis' gradient (9.5e-4) and the first layer of the phase
+    autoencoder (2.3e-4) -- each in ONE row of the tensor, at 5.6 x that quantity's spread.  The six-term bfloat16 split carries ~2 x the STFT error of the fp32 MFMA path
+    (profiles/r02_split_accuracy.txt: |STFT| 2.0e-6 vs 1.1e-6 against float64) and d atan2 amplifies it by 1 / mag at a near-silent bin.  Not a defect of a kernel (every other tensor of the
+    step, every other row of these two, is inside the fp32 tolerance) and not hidden either: this test pins the SIZE of it -- localized (<= 2 rows), < 8 x the spread, < 5 x the tolerance
+    -- so that the informational mode cannot drift further from the exact one without notice.  The headline and every parity claim are the exact-fp32 path's."""
+    from tests import gpu_checks as G
+    from tests import gpu_spread as S
+    kw = dict(B=4, seed=243, K=2, steps=1, scale=8, scheme="lean", shrink=2)
+    exact = G.run_fused(**kw)
+    assert all(r["ok"] for r in exact) and max(r["rel"] / r["tol"] for r in exact) < 0.1          # the exact path: a tenth of every tolerance
+    with G.split_mode():
+        res = G.run_fused(**kw)
+    miss = [r for r in res if not r["ok"]]
+    sp = S.spread_of(kw)
+    for r in miss:
+        s = max(sp["f32"][r["name"]], sp["noise"][r["name"]])
+        assert r["name"].startswith("grad.") and r.get("rows_over", 99) <= 2 and r["rel"] < 8.0 * s and r["rel"] < 5.0 * r["tol"], (r["name"], r["rel"], s, r.get("rows_over"))
+    assert len(miss) <= 3

@@ -25,10 +25,11 @@ Round 6, a FRESH seed (330 s, seed 4242: profiles/r06_fuzz_parity_seed4242.txt; 
 lines, all four on the analysis-basis gradients: three f16_all (B = 13; single windows at legacy scale 2 and at L = 65536) -> tools/fuzz_ground.py cases 14-16, and one f32x3 single
 window at lean scale 2 whose device error is 0.3 x its spread but 14 x the fixed tolerance, i.e. over the cap of tests/gpu_spread.py -> accepted there now only as a LOCALIZED miss
 (<= 16 of the 1024 rows of the tensor over the tolerance), tools/fuzz_ground_f32.py case 21.
-    python tools/fuzz_parity.py [seconds] [big|small] [seed]"""
+    python tools/fuzz_parity.py [seconds] [big|small|geo] [seed]"""
 import sys, time, random; sys.path.insert(0, '.')
 from tests import gpu_checks as G
 random.seed(int(sys.argv[3]) if len(sys.argv) > 3 else 1234)
+GEO = len(sys.argv) > 2 and sys.argv[2] == "geo"
 BIG = len(sys.argv) > 2 and sys.argv[2] == "big"      # round 5: batches of 33..160 windows at the 8192-sample window -- where 128-row tiles of the frame-major row order hold one or two
                                                        # frames and the structural-zero skipping of st_gemm_tn.h / st_gemm16.h is active (the default draw stays below 19 windows: one tile holds every frame)
 GROUND16 = True
@@ -43,6 +44,11 @@ while time.time() - t0 < float(sys.argv[1] if len(sys.argv) > 1 else 150):
     K = random.choice([1, 2, 3, 4, 4, 5, 8, 12, 16]); seed = random.randrange(1000)
     if BIG:
         scale, scheme, shrink, B = 1, "lean", random.choice([2, 4, 4, 8]), random.choice([33, 48, 64, 96, 100, 128, 130, 160])
+    if GEO:
+        # round 6: the geometry corners the default draw never visits -- every shrink factor at every window scale (the default ties shrink 4 to scale != 1), scale 4, and
+        # K = 0 (a model without knobs); all of them on the wide autoencoder path except (scale 1, shrink >= 2)
+        scale = random.choice([1, 2, 4, 4, 8, 8]); scheme = "lean" if scale != 2 else random.choice(["lean", "legacy"])
+        shrink = random.choice([1, 2, 4, 8]); B = random.choice([1, 2, 3, 4]); K = random.choice([0, 0, 1, 2, 3, 4, 7, 16])
     bf = random.choice([0, 0, 0, 3, 3, 1, 1, 2, 2, 4])     # 0 = fp32, 1 = bf16 GEMMs, 2 = bf16 GEMMs + autoencoder layers, 3 = f32x3 (fp32 oracle, fp32 tolerances), 4 = f16_all
     # odd batches on the wide path (scale 8): the library runs the autoencoder layers in fp32 there and reports it (st_effective_prec); the
     # checks' oracle follows (gpu_checks.follow_effective_arithmetic), so the sweep draws them again
