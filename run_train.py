@@ -20,7 +20,8 @@ if __name__ == "__main__":
     p.add_argument('--device-feed', action='store_true', default=True, help="(default) generate every training minibatch on the GPU (st_synth_comp4c) and keep the validation set in HBM")
     p.add_argument('--host-feed', dest='device_feed', action='store_false', help="the reference's feed instead: a torch DataLoader with 10 CPU workers over the Dataset items")
     p.add_argument('--resume-optimizer', action='store_true', help="restore Adam's moments (and, if the checkpoint belongs to this schedule, the position in the run) from --checkpoint")
-    p.add_argument('-b', '--batch', type=int, help="batch size (per GPU)", default=200)
+    p.add_argument('-b', '--batch', type=int, help="batch size (per GPU); the reference's default.  On MI355X multiples of 256 windows (8192-sample window) fill the tile rounds of the analysis "
+                                                        "forward: 379 k windows/s at 200, 418-426 k at 256, 477 k at 512 in fp32 (DESIGN.md section 5)", default=200)
     p.add_argument('--checkpoint', help='name of checkpoint .tar file to start from', default='modelcheckpoint.tar')
     p.add_argument('-c', '--compand', help='mu-law compand the audio of a file dataset (datasets.py:218-220)', action='store_true')
     p.add_argument('--effect', help="effect to learn, the reference's keys (run_train.py:55-80): comp_4c | comp_large | files are built here "
