@@ -95,7 +95,10 @@ class StepEngine:
         z = lambda: torch.zeros(n, dtype=torch.float32, device=self.device)
         self.params, self.grads, self.m, self.v = z(), z(), z(), z()
         dmax = dims.with_batch(self.max_batch)
-        self.ws = torch.zeros(self.lib.st_workspace_bytes(C.byref(dmax)), dtype=torch.uint8, device=self.device)
+        # set_arithmetic() may change the mode of a live engine and the workspace depends on it (fp32 autoencoder layers keep their activations: 294 MB at B = 256;
+        # the 16-bit modes carry operand copies): size it for the LARGEST mode, whatever arithmetic level `dims` happens to carry
+        nbytes = max(int(self.lib.st_workspace_bytes(C.byref(dmax.with_arith(prec=p, clip_all=ca)))) for p in _lib.PREC.values() for ca in (0, 1))
+        self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         self.scalars = torch.zeros(8, dtype=torch.float32, device=self.device)
         self.stage = None            # packed live analysis gradient rows (data parallel, allocated on first use)
         self.named = self.layout.views(self.params)

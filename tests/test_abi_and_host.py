@@ -472,3 +472,23 @@ def test_dims_edge_cases_are_refused_with_a_message():
     assert lib.st_param_offsets(C.byref(wide.with_batch(bw + 1)), None) == -1 and b"batch too large" in lib.st_last_error()
     # a null dims pointer
     assert lib.st_param_offsets(None, None) == -1 and b"null dims" in lib.st_last_error()
+
+
+def test_workspace_of_the_fp32_level_bounds_every_arithmetic_level():
+    """st_workspace_bytes depends on the arithmetic level of the dims (fp32 autoencoder layers keep their activations for the backward, the 16-bit levels carry
+    operand copies and the h4 exchange of the split backward).  Hosts size ONE workspace and may switch levels on a live engine (StepEngine.set_arithmetic,
+    st_model.set_compute_dtype): the size reported for ST_PREC_F32 must bound every other level's, at every geometry / batch / knob count / clip scope --
+    and StepEngine sizes by the maximum anyway."""
+    import ctypes as C
+    lib = _lib.load()
+    for scale, scheme in ((1, "lean"), (2, "lean"), (2, "legacy"), (8, "lean")):
+        for shrink in (1, 4, 8):
+            for B in (1, 3, 64, 130, 256, 257, 1024):
+                for K in (0, 4, 16):
+                    d = _lib.geometry(scale, shrink, K, B, scale_scheme=scheme)
+                    base = lib.st_workspace_bytes(C.byref(d.with_arith(prec=_lib.PREC["f32"], loss_scale=0.0, clip_all=0)))
+                    assert base > 0
+                    for name, p in _lib.PREC.items():
+                        for ca in (0, 1):
+                            n = lib.st_workspace_bytes(C.byref(d.with_arith(prec=p, loss_scale=(4096.0 if name.startswith("f16") else 0.0), clip_all=ca)))
+                            assert 0 < n <= base, (scale, scheme, shrink, B, K, name, ca, n, base)

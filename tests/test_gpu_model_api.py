@@ -1070,3 +1070,35 @@ def test_predict_long_ragged_lengths(golden_dir, n):
     xw = np.stack([sp[i:i + L] for i in range(0, sp.size - L + 1, step)])
     ref = O.model_fwd(np.ascontiguousarray(xw), np.tile(kn, (xw.shape[0], 1)), P, geo)[0].reshape(-1)[:want]
     assert np.abs(y - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+def test_switching_arithmetic_on_a_live_engine():
+    """StepEngine.set_arithmetic / st_model.set_compute_dtype on a LIVE engine: the workspace depends on the arithmetic level (fp32 autoencoder layers keep their activations
+    for the backward -- 73 MB at B = 64 --, the 16-bit levels carry operand copies).  An engine created from dims that carry a 16-bit level and then switched to fp32 used to
+    own a workspace sized for the 16-bit level (the fp32 backward would have written past its end); it is sized for the largest level now.  After the switch the engine's
+    step is bit for bit the step of an engine that was fp32 from the start, and switching back reproduces the 16-bit step."""
+    from tests import gpu_checks as G
+    from signaltrain_amd import _lib
+    from signaltrain_amd.engine import StepEngine
+    geo, X, Y, KN, P = G.make_case(8, 19, K=4)
+    B = 64
+    rng = np.random.default_rng(2)
+    X = (np.tile(X, (B // 8, 1)) * rng.uniform(0.5, 1.0, (B, 1))).astype(np.float32); Y = np.tile(Y, (B // 8, 1)).astype(np.float32); KN = np.tile(KN, (B // 8, 1)).astype(np.float32)
+    x, kn, y = G.t(X), G.t(KN), G.t(Y)
+    d16 = G.dims_of(geo, B, 4).with_arith(prec=_lib.PREC["bf16_all"])
+    live = StepEngine(d16, G.DEV, compute_dtype="bf16_all"); live.load_state_dict(P)
+    assert live.ws.numel() >= int(live.lib.st_workspace_bytes(__import__("ctypes").byref(d16.with_arith(prec=_lib.PREC["f32"]))))
+    ref16 = StepEngine(G.dims_of(geo, B, 4), G.DEV, compute_dtype="bf16_all"); ref16.load_state_dict(P)
+    ref32 = StepEngine(G.dims_of(geo, B, 4), G.DEV, compute_dtype="f32"); ref32.load_state_dict(P)
+    guard = torch.full((1 << 20,), 7.0, device=G.DEV)                        # something allocated right after the engines: must stay untouched
+    live.train_step(x, kn, y, 1e-3); ref16.train_step(x, kn, y, 1e-3)
+    assert torch.equal(live.params, ref16.params)
+    live.set_arithmetic("f32"); live.load_state_dict(P); live.m.zero_(); live.v.zero_(); live.step_count = 0
+    live.train_step(x, kn, y, 1e-3); ref32.train_step(x, kn, y, 1e-3)
+    torch.cuda.synchronize()
+    assert torch.equal(live.params, ref32.params) and torch.equal(live.grads, ref32.grads) and float(live.scalars[0]) == float(ref32.scalars[0])
+    live.set_arithmetic("bf16_all"); live.load_state_dict(P); live.m.zero_(); live.v.zero_(); live.step_count = 0
+    ref16.load_state_dict(P); ref16.m.zero_(); ref16.v.zero_(); ref16.step_count = 0
+    live.train_step(x, kn, y, 1e-3); ref16.train_step(x, kn, y, 1e-3)
+    torch.cuda.synchronize()
+    assert torch.equal(live.params, ref16.params) and bool((guard == 7.0).all())
