@@ -70,6 +70,20 @@ class _OptimizerView:
         return self.engine.optimizer_state_dict()
 
 
+def workspace_bytes_upto(lib, dims, max_batch):
+    """Bytes of ONE workspace that serves every batch of 1 .. max_batch windows at every arithmetic level and clip scope (st_workspace_bytes is a function of all three and
+    is monotonic in none of them: INTEGRATION.md "Sizing the workspace")."""
+    levels = [(p, ca) for p in _lib.PREC.values() for ca in (0, 1)]
+    best = 0
+    for b in range(1, int(max_batch) + 1):
+        db = dims.with_batch(b)
+        for p, ca in levels:
+            n = int(lib.st_workspace_bytes(C.byref(db.with_arith(prec=p, clip_all=ca))))
+            if n > best:
+                best = n
+    return best
+
+
 class StepEngine:
     """Holds device state for one model replica and drives the HIP step."""
 
@@ -97,7 +111,10 @@ class StepEngine:
         dmax = dims.with_batch(self.max_batch)
         # set_arithmetic() may change the mode of a live engine and the workspace depends on it (fp32 autoencoder layers keep their activations: 294 MB at B = 256;
         # the 16-bit modes carry operand copies): size it for the LARGEST mode, whatever arithmetic level `dims` happens to carry
-        nbytes = max(int(self.lib.st_workspace_bytes(C.byref(dmax.with_arith(prec=p, clip_all=ca)))) for p in _lib.PREC.values() for ca in (0, 1))
+        # ... and for every batch up to max_batch: the size is NOT monotonic in the batch (the split-K slab counts of the weight-gradient / synthesis GEMMs are picked per
+        # batch: at the default geometry 585 windows need 85.6 MB more than 586, 178 windows 70 MB more than 179 at shrink 1) and an engine sized for its largest batch
+        # serves smaller ones (a last partial batch, predict_long's remainder, validation).  ~12 host calls per batch size: tens of ms once per engine.
+        nbytes = max(workspace_bytes_upto(self.lib, dims, self.max_batch), int(self.lib.st_workspace_bytes(C.byref(dmax))))
         self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         self.scalars = torch.zeros(8, dtype=torch.float32, device=self.device)
         self.stage = None            # packed live analysis gradient rows (data parallel, allocated on first use)

@@ -492,3 +492,25 @@ def test_workspace_of_the_fp32_level_bounds_every_arithmetic_level():
                         for ca in (0, 1):
                             n = lib.st_workspace_bytes(C.byref(d.with_arith(prec=p, loss_scale=(4096.0 if name.startswith("f16") else 0.0), clip_all=ca)))
                             assert 0 < n <= base, (scale, scheme, shrink, B, K, name, ca, n, base)
+
+
+def test_one_workspace_serves_every_smaller_batch():
+    """st_workspace_bytes is NOT monotonic in the batch: the split-K slab counts of the weight-gradient / synthesis GEMMs are picked per batch, so e.g. 585 windows of 8192
+    samples need 85.6 MB MORE than 586 do, and 93 windows of 65536 samples 63 MB more than 94.  A host that sizes its workspace for its largest batch and then runs a smaller
+    one (a last partial batch, predict_long's remainder, a validation batch) would be written past the end.  engine.workspace_bytes_upto is what StepEngine allocates: the
+    maximum over every batch 1 .. max_batch, every arithmetic level and clip scope (INTEGRATION.md states the rule for C hosts)."""
+    import ctypes as C
+    from signaltrain_amd.engine import workspace_bytes_upto
+    lib = _lib.load()
+    seen_non_monotonic = False
+    for scale, shrink, bmax in ((1, 4, 586), (1, 4, 600), (1, 4, 256), (1, 1, 179), (8, 4, 94), (8, 4, 64), (2, 4, 342)):
+        d = _lib.geometry(scale, shrink, 4, bmax)
+        cap = workspace_bytes_upto(lib, d, bmax)
+        own = {name: lib.st_workspace_bytes(C.byref(d.with_arith(prec=p))) for name, p in _lib.PREC.items()}
+        assert cap >= max(own.values())
+        for b in range(1, bmax + 1):
+            for name, p in _lib.PREC.items():
+                n = lib.st_workspace_bytes(C.byref(d.with_batch(b).with_arith(prec=p, clip_all=int(name.startswith("f16")))))
+                assert 0 < n <= cap, (scale, shrink, bmax, b, name, n, cap)
+                seen_non_monotonic |= n > own[name]
+    assert seen_non_monotonic          # the property this test exists for (if the library ever becomes monotonic, drop this line and the loop stays a valid guarantee)

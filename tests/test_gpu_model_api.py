@@ -1102,3 +1102,27 @@ def test_switching_arithmetic_on_a_live_engine():
     live.train_step(x, kn, y, 1e-3); ref16.train_step(x, kn, y, 1e-3)
     torch.cuda.synchronize()
     assert torch.equal(live.params, ref16.params) and bool((guard == 7.0).all())
+
+
+def test_engine_sized_for_a_large_batch_runs_a_smaller_one_that_needs_more_workspace():
+    """st_workspace_bytes is not monotonic in the batch (tests/test_abi_and_host.py::test_one_workspace_serves_every_smaller_batch): at the default geometry 585 windows need
+    85.6 MB more than 586.  An engine created for up to 600 windows must run 585 inside its own workspace: its capacity is checked BEFORE anything is launched, a guard
+    allocation behind it stays untouched, and the step is bit for bit that of an engine created for exactly 585 windows."""
+    import ctypes as C
+    from tests import gpu_checks as G
+    from signaltrain_amd.engine import StepEngine
+    geo, X, Y, KN, P = G.make_case(5, 23, K=4)
+    B = 585
+    rng = np.random.default_rng(4)
+    X = (np.tile(X, (B // 5, 1)) * rng.uniform(0.5, 1.0, (B, 1))).astype(np.float32); Y = np.tile(Y, (B // 5, 1)).astype(np.float32); KN = np.tile(KN, (B // 5, 1)).astype(np.float32)
+    big = StepEngine(G.dims_of(geo, 600, 4), G.DEV, max_batch=600); big.load_state_dict(P)
+    need = int(big.lib.st_workspace_bytes(C.byref(G.dims_of(geo, B, 4))))
+    assert need > int(big.lib.st_workspace_bytes(C.byref(G.dims_of(geo, 600, 4))))          # the non-monotonic spot itself
+    assert big.ws.numel() >= need                                                              # ... which the engine covers (never launch into a short workspace)
+    guard = torch.full((1 << 22,), 3.0, device=G.DEV)
+    exact = StepEngine(G.dims_of(geo, B, 4), G.DEV); exact.load_state_dict(P)
+    x, kn, y = G.t(X), G.t(KN), G.t(Y)
+    big.train_step(x, kn, y, 1e-3); exact.train_step(x, kn, y, 1e-3)
+    torch.cuda.synchronize()
+    assert torch.equal(big.params, exact.params) and torch.equal(big.grads, exact.grads) and float(big.scalars[0]) == float(exact.scalars[0])
+    assert bool((guard == 3.0).all()) and bool(torch.isfinite(big.params).all())
