@@ -141,7 +141,7 @@ def test_ae_bwd_repeatable():
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16_all", "f16_all"])
-@pytest.mark.parametrize("scale,B", [(1, 256), (8, 64), (1, 104), (1, 192)])
+@pytest.mark.parametrize("scale,B", [(1, 256), (8, 64), (1, 104), (1, 192), (1, 2048), (8, 512)])
 def test_full_size_batch_properties(dtype, scale, B):
     """The per-GPU workloads of BASELINE configs[1..4] at FULL size -- 256 windows of 8192 samples, 64 windows of 65536 -- in the three
     arithmetic modes the configs name: properties that do not need the (slow) oracle.  Windows are independent, the loss is a mean over
@@ -154,7 +154,9 @@ def test_full_size_batch_properties(dtype, scale, B):
     (the union of their live tap ranges is computed) resp. one and a half tiles per frame, against halves (52, 96) whose work lists differ: the structural-zero
     skipping of st_gemm_tn.h / st_gemm16.h must not depend on how the frames fall on the tiles.  fp16: the polar backward SATURATES its output at +-65504 before the weight-gradient GEMM narrows it
     (1e7-sized atan2 sub-gradients on near-silent frames x loss scale 4096) and small values go subnormal -- a half batch's 2x
-    larger gradients saturate / round where the full batch's do not, so the property holds to ~1 % only (measured 0.7 %): tolerance 2e-2."""
+    larger gradients saturate / round where the full batch's do not, so the property holds to ~1 % only (measured 0.7 %): tolerance 2e-2.
+    Round 6: eight times the bench sizes -- 2048 windows of 8192 samples (47 104 frame rows: several rounds of every tile grid, work lists at their largest) and 512 windows
+    of 65536 samples (89 088 rows, 270 k autoencoder columns on the wide path) against their halves: the LARGE end of the size range, where nothing else in the suite goes."""
     import numpy as np, torch
     from tests import gpu_checks as G
     from signaltrain_amd.engine import StepEngine
