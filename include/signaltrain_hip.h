@@ -118,6 +118,13 @@ int64_t st_param_offsets(const st_dims* d, int64_t* offs /*[40]*/);
  * (st_ola_loss reads live taps only).  Zero-fill the buffer once after allocating it (signaltrain_amd.engine does: torch.zeros) if anything
  * other than the library -- a debug dump, a new consumer -- is going to look at those regions; stale bytes there may read as NaN. */
 size_t st_workspace_bytes(const st_dims* d);
+/* st_workspace_bytes answers for EXACTLY the dims it is given, and it is monotonic neither in the batch (the split-K slab counts of the weight-gradient /
+ * synthesis GEMMs are picked per batch: 585 windows of 8192 samples need 85.6 MB more than 586) nor in the arithmetic level (fp32 autoencoder layers keep
+ * their activations for the backward).  A host that allocates ONE workspace and then runs other batches or levels in it -- a last partial batch, an inference
+ * remainder, a change of st_dims.prec on a live model -- sizes it with this: the maximum over every batch 1 .. d->B, every ST_PREC_* level and both clip
+ * scopes (host arithmetic only; ~20 ms for 1024 windows).  0 for bad dims. */
+size_t st_workspace_bytes_max(const st_dims* d);
+/* The knobs pointer of every entry below: [B][K] fp32; with K == 0 (a model without knobs: nn_proc.py:92-93 concatenates an empty tensor) it may be NULL. */
 
 /* ---------------------------------------------------------------- per-op entry points --- */
 /* cls_fe_dft.py:50-58 Analysis.forward fused with nn_proc.py:309-310 (mag, phs).

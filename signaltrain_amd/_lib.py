@@ -51,6 +51,7 @@ SIGNATURES = {
     "st_geometry": (_i, [C.c_double, C.c_double, _i, _i, _i, _D]),
     "st_param_offsets": (C.c_int64, [_D, C.POINTER(C.c_int64)]),
     "st_workspace_bytes": (C.c_size_t, [_D]),
+    "st_workspace_bytes_max": (C.c_size_t, [_D]),
     "st_analysis_fwd": (_i, [_D, _p, _p, _p, _f, _p, _p, _p, _p, _p]),
     "st_ae_fwd": (_i, [_D, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "st_ae_fwd_ws_floats": (C.c_size_t, [_D]),

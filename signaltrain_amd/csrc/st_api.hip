@@ -533,7 +533,8 @@ static int ae_fwd_impl(const st_dims* d, const float* mag, const float* phs, con
 {      // sv != NULL (fused fp32 geometries, training step): the activations are kept for the backward (ae_sv_floats)
     Layout L; ST_TRY(make_layout(d, &L));
     const int aa_ht = AA16 ? gemm_ht(d->prec) : 0;
-    ST_REQ(mag && phs && knobs && ae_m && ae_p && ((mag_hat && phs_hat && AA) || (!mag_hat && !phs_hat && !AA && ws)), "st_ae_fwd: null pointer");
+    ST_REQ(mag && phs && (knobs || d->K == 0) && ae_m && ae_p && ((mag_hat && phs_hat && AA) || (!mag_hat && !phs_hat && !AA && ws)), "st_ae_fwd: null pointer");
+    if (!knobs) knobs = ae_m;      // K == 0: the kernels issue one clamped, masked load of knobs[0] -- any resident float will do
     if (ae_is_wide(d)) {
         ST_REQ(mag_hat, "st_ae_fwd: the code-only pass exists for the fused geometries only");
         ST_REQ(ws, "st_ae_fwd: this geometry (T=%d, OT=%d) needs st_ae_fwd_ws_floats() floats of workspace", d->T, d->OT);
@@ -1055,7 +1056,8 @@ static int ae_bwd_impl(const st_dims* d, const float* mag, const float* phs, con
     // defer_reduce: in -> the caller will sum the workgroup partials itself (post_ae_kernel, together with the polar backward);
     // out -> false if this geometry's path already reduced them (wide geometries)
     Layout L; ST_TRY(make_layout(d, &L));
-    ST_REQ(mag && phs && knobs && ae_m && ae_p && mag_hat && phs_hat && dAA && dmag && dphs && ws && g_m && g_p, "st_ae_bwd: null pointer");
+    ST_REQ(mag && phs && (knobs || d->K == 0) && ae_m && ae_p && mag_hat && phs_hat && dAA && dmag && dphs && ws && g_m && g_p, "st_ae_bwd: null pointer");
+    if (!knobs) knobs = ae_m;
     if (ae_is_wide(d)) {
         if (defer_reduce) *defer_reduce = false;
         WideWS w; wide_carve(d, ws, &w);
@@ -1315,7 +1317,8 @@ extern "C" size_t st_ae_acts_floats(const st_dims* d) { return (size_t)d->B * d-
 extern "C" int st_ae_acts(const st_dims* d, const float* v, const float* knobs, const float* ae, int sf, float* acts, void* stream)
 {
     Layout L; ST_TRY(make_layout(d, &L));
-    ST_REQ(v && knobs && ae && acts, "st_ae_acts: null pointer");
+    ST_REQ(v && (knobs || d->K == 0) && ae && acts, "st_ae_acts: null pointer");
+    if (!knobs) knobs = ae;
     stm::AeActsArgs a;
     a.v = v; a.knobs = knobs; a.ae = ae; a.B = d->B; a.T = d->T; a.OT = d->OT; a.F = d->F; a.K = d->K; a.sf = sf;
     for (int l = 0; l < 9; ++l) { a.w_off[l] = L.go.w[l]; a.b_off[l] = L.go.b[l]; }
@@ -1329,6 +1332,21 @@ extern "C" size_t st_workspace_bytes(const st_dims* d)
 {
     if (check_dims(d) != ST_OK) return 0;
     WS w; carve(d, nullptr, &w); return w.bytes;
+}
+// ONE workspace for every batch 1 .. d->B at every arithmetic level and clip scope: the exact size above is monotonic in none of them (header).
+extern "C" size_t st_workspace_bytes_max(const st_dims* d)
+{
+    if (check_dims(d) != ST_OK) return 0;
+    size_t best = 0;
+    st_dims q = *d;
+    for (int b = 1; b <= d->B; ++b)
+        for (int prec = ST_PREC_F32; prec <= ST_PREC_F32X3; ++prec)
+            for (int ca = 0; ca < 2; ++ca) {
+                q.B = b; q.prec = prec; q.clip_all = ca;
+                WS w; carve(&q, nullptr, &w);
+                if (w.bytes > best) best = w.bytes;
+            }
+    return best;
 }
 
 // ------------------------------------------------------------------------------ the plane GEMMs of the fused step (ST_PREC_F32X3)
@@ -1727,7 +1745,8 @@ extern "C" int st_model_fwd(const st_dims* d, const float* params, const float* 
                             float* y_hat, float* mag, float* mag_hat, void* ws, int save_for_backward, void* stream)
 {
     Layout L; ST_TRY(make_layout(d, &L));
-    ST_REQ(params && x && knobs && ws, "st_model_fwd: null pointer");
+    ST_REQ(params && x && (knobs || d->K == 0) && ws, "st_model_fwd: null pointer");
+    if (!knobs) knobs = params;
     WS w; carve(d, ws, &w);
     return forward_impl(d, L, params, x, knobs, nullptr, y_hat, mag, mag_hat, w, save_for_backward != 0, stream);
 }
@@ -1736,7 +1755,8 @@ extern "C" int st_model_bwd(const st_dims* d, const float* params, float* grads,
                             const float* g_y_hat, const float* g_mag_hat, const float* g_mag, void* ws, void* stream)
 {
     Layout L; ST_TRY(make_layout(d, &L));
-    ST_REQ(params && grads && x && knobs && g_y_hat && ws, "st_model_bwd: null pointer");
+    ST_REQ(params && grads && x && (knobs || d->K == 0) && g_y_hat && ws, "st_model_bwd: null pointer");
+    if (!knobs) knobs = params;
     WS w; carve(d, ws, &w);
     ST_TRY(pad_scale(g_y_hat, w.dsyn, d->B, d->y, d->N, 2.0f, stream));     // dsyn = 2 * g_y_hat, padded for the framed loaders
     return backward_impl(d, L, params, grads, x, knobs, g_mag_hat, g_mag, 0.0f, w, stream);
@@ -1785,7 +1805,8 @@ extern "C" int st_loss_backward(const st_dims* d, const float* params, float* gr
                                 float* scalars, void* stream)
 {
     Layout L; ST_TRY(make_layout(d, &L));
-    ST_REQ(params && grads && x && knobs && y_true && ws && scalars, "st_loss_backward: null pointer");
+    ST_REQ(params && grads && x && (knobs || d->K == 0) && y_true && ws && scalars, "st_loss_backward: null pointer");
+    if (!knobs) knobs = params;
     WS w; carve(d, ws, &w);
     w.g16 = use_g16(d);
     prof_mark("begin", stream);
@@ -1803,7 +1824,8 @@ extern "C" int st_loss_backward_p1(const st_dims* d, const float* params, float*
                                    const float* y_true, void* ws, void* stream)
 {
     Layout L; ST_TRY(make_layout(d, &L));
-    ST_REQ(params && grads && x && knobs && y_true && ws, "st_loss_backward_p1: null pointer");
+    ST_REQ(params && grads && x && (knobs || d->K == 0) && y_true && ws, "st_loss_backward_p1: null pointer");
+    if (!knobs) knobs = params;
     WS w; carve(d, ws, &w);
     w.g16 = use_g16(d);
     prof_mark("begin", stream);
@@ -1854,7 +1876,8 @@ extern "C" int st_loss_backward_stage(const st_dims* d, const float* params, flo
                                       const float* y_true, void* ws, float* scalars, int stage, void* stream)
 {
     Layout L; ST_TRY(make_layout(d, &L));
-    ST_REQ(params && grads && x && knobs && y_true && ws && scalars, "st_loss_backward_stage: null pointer");
+    ST_REQ(params && grads && x && (knobs || d->K == 0) && y_true && ws && scalars, "st_loss_backward_stage: null pointer");
+    if (!knobs) knobs = params;
     ST_REQ(stage >= 0 && stage < 4, "st_loss_backward_stage: stage %d not in 0..3", stage);
     WS w; carve(d, ws, &w);
     const float reg_coef = loss_scale_of(d) * (float)(2e-5 / 10.0) / ((float)d->B * (float)d->OT * (float)d->F);
@@ -1887,7 +1910,8 @@ static int train_step_impl(const st_dims* d, float* params, float* grads, float*
                            float lr, float beta1, float beta2, float eps, int step, void* stream, bool dev_hyper)
 {
     Layout L; ST_TRY(make_layout(d, &L));
-    ST_REQ(params && grads && x && knobs && y_true && ws && scalars, "st_train_step: null pointer");
+    ST_REQ(params && grads && x && (knobs || d->K == 0) && y_true && ws && scalars, "st_train_step: null pointer");
+    if (!knobs) knobs = params;
     WS w; carve(d, ws, &w);
     w.g16 = use_g16(d);
     prof_mark("begin", stream);
@@ -2236,7 +2260,8 @@ extern "C" int st_dp_train_step(st_dp* p, const st_dims* d, float* params, float
         return st_train_step(d, params, grads, m, v, x, knobs, y_true, ws, scalars, lr, beta1, beta2, eps, step, stream);
     Layout L; ST_TRY(make_layout(d, &L));
     ST_REQ(stage, "st_dp_train_step: null staging buffer");
-    ST_REQ(params && grads && x && knobs && y_true && ws, "st_dp_train_step: null pointer");
+    ST_REQ(params && grads && x && (knobs || d->K == 0) && y_true && ws, "st_dp_train_step: null pointer");
+    if (!knobs) knobs = params;
     const float gs = (1.0f / (float)p->world) / loss_scale_of(d);          // 1/world and the loss scale leave the gradient together
     // force_exchange is a bit set: 1 = run the exchange even with one rank; 2 = split the LAST exchange by basis (real rows under the GEMM of the imaginary
     // ones: 2.1 MB exposed instead of 4.2); 4 = that exchange on bfloat16 values (only where the autoencoder layers already run in 16 bits: *_ALL)
@@ -2375,7 +2400,8 @@ extern "C" int st_graph_create(const st_dims* d, float* params, float* grads, fl
                                const float* lr_table, int n_lr, float beta1, float beta2, float eps, void* stream, st_graph** out)
 {
     Layout L; ST_TRY(make_layout(d, &L));
-    ST_REQ(params && grads && m && v && x && knobs && y_true && ws && scalars && lr_table && n_lr > 0 && out, "st_graph_create: bad arguments");
+    ST_REQ(params && grads && m && v && x && (knobs || d->K == 0) && y_true && ws && scalars && lr_table && n_lr > 0 && out, "st_graph_create: bad arguments");
+    if (!knobs) knobs = params;
     ST_REQ(!g_prof, "st_graph_create: switch the event profiling off first (event records would be captured)");
     ST_TRY(attr_prepare(d));
     hipStream_t s = st_stream(stream);

@@ -71,17 +71,12 @@ class _OptimizerView:
 
 
 def workspace_bytes_upto(lib, dims, max_batch):
-    """Bytes of ONE workspace that serves every batch of 1 .. max_batch windows at every arithmetic level and clip scope (st_workspace_bytes is a function of all three and
-    is monotonic in none of them: INTEGRATION.md "Sizing the workspace")."""
-    levels = [(p, ca) for p in _lib.PREC.values() for ca in (0, 1)]
-    best = 0
-    for b in range(1, int(max_batch) + 1):
-        db = dims.with_batch(b)
-        for p, ca in levels:
-            n = int(lib.st_workspace_bytes(C.byref(db.with_arith(prec=p, clip_all=ca))))
-            if n > best:
-                best = n
-    return best
+    """Bytes of ONE workspace that serves every batch of 1 .. max_batch windows at every arithmetic level and clip scope: st_workspace_bytes_max (the exact
+    st_workspace_bytes is a function of all three and is monotonic in none of them: INTEGRATION.md "Sizing the workspace")."""
+    n = int(lib.st_workspace_bytes_max(C.byref(dims.with_batch(int(max_batch)))))
+    if n <= 0:
+        _lib.check(-1, "st_workspace_bytes_max")
+    return n
 
 
 class StepEngine:
@@ -113,7 +108,7 @@ class StepEngine:
         # the 16-bit modes carry operand copies): size it for the LARGEST mode, whatever arithmetic level `dims` happens to carry
         # ... and for every batch up to max_batch: the size is NOT monotonic in the batch (the split-K slab counts of the weight-gradient / synthesis GEMMs are picked per
         # batch: at the default geometry 585 windows need 85.6 MB more than 586, 178 windows 70 MB more than 179 at shrink 1) and an engine sized for its largest batch
-        # serves smaller ones (a last partial batch, predict_long's remainder, validation).  ~12 host calls per batch size: tens of ms once per engine.
+        # serves smaller ones (a last partial batch, predict_long's remainder, validation): st_workspace_bytes_max, tens of ms of host arithmetic once per engine.
         nbytes = max(workspace_bytes_upto(self.lib, dims, self.max_batch), int(self.lib.st_workspace_bytes(C.byref(dmax))))
         self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         self.scalars = torch.zeros(8, dtype=torch.float32, device=self.device)
@@ -217,11 +212,7 @@ class StepEngine:
         if y is not None:
             assert y.shape == (d.B, d.y), (y.shape, d.y)
         if d.K == 0:
-            # a model WITHOUT knobs (nn_proc.py:92-93 concatenates an empty [B, 0] tensor): an empty tensor has no data pointer, the C ABI refuses NULL, and the
-            # kernels issue one clamped -- always valid -- load of knobs[0] per row group before they mask it: they get the address of a resident zero
-            if getattr(self, "_no_knobs", None) is None:
-                self._no_knobs = torch.zeros(4, dtype=torch.float32, device=self.device)
-            knobs = self._no_knobs
+            knobs = None      # a model WITHOUT knobs (nn_proc.py:92-93 concatenates an empty [B, 0] tensor): an empty tensor has no data pointer; the C ABI takes NULL for K == 0
         return d, x, knobs, y
 
     # ---------------------------------------------------------------- forward / backward / step
@@ -361,7 +352,7 @@ class StepEngine:
         d = self._dims(int(batch))
         dev = self.device
         self.gx = torch.zeros(d.B, d.L, dtype=torch.float32, device=dev)
-        self.gk = torch.zeros(d.B, d.K, dtype=torch.float32, device=dev) if d.K else torch.zeros(4, dtype=torch.float32, device=dev)      # K = 0: see _prep
+        self.gk = torch.zeros(d.B, d.K, dtype=torch.float32, device=dev) if d.K else None      # K = 0: NULL (see _prep)
         self.gy = torch.zeros(d.B, d.y, dtype=torch.float32, device=dev)
         self.g_lr = torch.as_tensor(np.asarray(lr_table, dtype=np.float32), device=dev).contiguous()
         self.scalars[6] = float(self.step_count)

@@ -62,7 +62,7 @@ class AsymAutoEncoder(nn.Module):
         """The ten return_acts tensors of nn_proc.py:77-126 ([B, F, width] each) from the library's diagnostic kernel (st_ae_acts): plain
         fp32 FMAs per (window, bin) row -- the training kernels keep these activations in registers."""
         lib = _lib.load()
-        x = x_input.contiguous().float(); kn = knobs.contiguous().float() if self._K else torch.zeros(4, device=x_input.device)      # K = 0: an empty tensor has no address (engine._prep)
+        x = x_input.contiguous().float(); kn = knobs.contiguous().float() if self._K else None      # K = 0: an empty tensor has no address; the C ABI takes NULL then
         B, T, F = x.shape
         d = _lib.st_dims(); d.B, d.N, d.F, d.T, d.OT, d.K, d.H = B, 2 * (F - 1), F, T, self._OT, self._K, 384
         d.y = (d.OT - 1) * d.H - d.N; d.L = max(4 * d.y, 4)
@@ -96,7 +96,7 @@ class AsymAutoEncoder(nn.Module):
         for l in self.layer_list:
             for t in (l.weight, l.bias):
                 o = offs[4 + k] - offs[4]; packed[o:o + t.numel()] = t.detach().reshape(-1); k += 1
-        x = x_input.contiguous().float(); kn = knobs.contiguous().float() if self._K else torch.zeros(4, device=x_input.device)      # K = 0: an empty tensor has no address (engine._prep)
+        x = x_input.contiguous().float(); kn = knobs.contiguous().float() if self._K else None      # K = 0: an empty tensor has no address; the C ABI takes NULL then
         KP = lib.st_kp(F)
         mh = torch.empty(B, self._OT, F, device=x.device); ph = torch.empty_like(mh)
         AA = torch.empty(B * self._OT, KP, device=x.device)

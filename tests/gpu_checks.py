@@ -213,7 +213,7 @@ def _run_all(lib, geo, X, Y, KN, P, d, B, K, verbose):
     PG = lay.offsets[22] - lay.offsets[4]
     x, kn, y = t(X), t(KN), t(Y)
     if K == 0:
-        kn = t(np.zeros(4, np.float32))      # a model without knobs: an empty tensor has no address and the ABI refuses NULL; the kernels mask their one clamped load
+        kn = None                            # a model without knobs: an empty tensor has no address; the ABI takes NULL for K == 0
     z = lambda *s: torch.zeros(*s, device=DEV)
 
     # 1. analysis + polar

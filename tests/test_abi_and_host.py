@@ -498,7 +498,7 @@ def test_one_workspace_serves_every_smaller_batch():
     """st_workspace_bytes is NOT monotonic in the batch: the split-K slab counts of the weight-gradient / synthesis GEMMs are picked per batch, so e.g. 585 windows of 8192
     samples need 85.6 MB MORE than 586 do, and 93 windows of 65536 samples 63 MB more than 94.  A host that sizes its workspace for its largest batch and then runs a smaller
     one (a last partial batch, predict_long's remainder, a validation batch) would be written past the end.  engine.workspace_bytes_upto is what StepEngine allocates: the
-    maximum over every batch 1 .. max_batch, every arithmetic level and clip scope (INTEGRATION.md states the rule for C hosts)."""
+    maximum over every batch 1 .. max_batch, every arithmetic level and clip scope -- the C entry st_workspace_bytes_max (INTEGRATION.md "Sizing the workspace")."""
     import ctypes as C
     from signaltrain_amd.engine import workspace_bytes_upto
     lib = _lib.load()
@@ -514,3 +514,8 @@ def test_one_workspace_serves_every_smaller_batch():
                 assert 0 < n <= cap, (scale, shrink, bmax, b, name, n, cap)
                 seen_non_monotonic |= n > own[name]
     assert seen_non_monotonic          # the property this test exists for (if the library ever becomes monotonic, drop this line and the loop stays a valid guarantee)
+    # st_workspace_bytes_max IS that maximum (the C entry the engine calls), also from dims that carry a 16-bit level, and 0 for bad dims
+    d = _lib.geometry(1, 4, 4, 600)
+    brute = max(lib.st_workspace_bytes(C.byref(d.with_batch(b).with_arith(prec=p, clip_all=ca))) for b in range(1, 601) for p in _lib.PREC.values() for ca in (0, 1))
+    assert lib.st_workspace_bytes_max(C.byref(d)) == brute == lib.st_workspace_bytes_max(C.byref(d.with_arith(prec=_lib.PREC["bf16_all"], clip_all=1)))
+    assert lib.st_workspace_bytes_max(C.byref(d.with_batch(0))) == 0

@@ -947,8 +947,9 @@ def test_g14_edges_on_the_device(golden_dir, ci):
 def test_model_without_knobs_every_engine_entry(dtype):
     """num_knobs = 0 (the reference builds it: nn_proc.py:92-93 concatenates an empty [B, 0] tensor; golden G14 case 0) through every engine entry that takes knobs:
     forward, loss_backward and a train step against the oracle (run_fused, the mode's tolerances), the graph step against the eager step (same bits), the exchange
-    step with one rank, st_model_knob_grad (an empty [B, 0] result) and the standalone autoencoder module with return_acts.  An empty tensor has no data pointer and the
-    C ABI refuses NULL: the Python layer hands the kernels the address of a resident zero (engine._prep), which is what a C host has to do too."""
+    step with one rank, st_model_knob_grad (an empty [B, 0] result) and the standalone autoencoder module with return_acts.  An empty tensor has no data pointer: the C ABI
+    takes knobs == NULL when K == 0 (it refused it until the third session of round 6, so st_model(num_knobs=0) could not run a forward) and hands the kernels, which issue
+    one clamped and masked load of knobs[0] per row group, a resident address of its own."""
     from tests import gpu_checks as G
     from signaltrain_amd import nn_proc
     from signaltrain_amd.engine import StepEngine
