@@ -25,6 +25,8 @@ Round 6, a FRESH seed (330 s, seed 4242: profiles/r06_fuzz_parity_seed4242.txt; 
 lines, all four on the analysis-basis gradients: three f16_all (B = 13; single windows at legacy scale 2 and at L = 65536) -> tools/fuzz_ground.py cases 14-16, and one f32x3 single
 window at lean scale 2 whose device error is 0.3 x its spread but 14 x the fixed tolerance, i.e. over the cap of tests/gpu_spread.py -> accepted there now only as a LOCALIZED miss
 (<= 16 of the 1024 rows of the tensor over the tolerance), tools/fuzz_ground_f32.py case 21.
+The default draw again on the final sources (500 s, seed 1234, profiles/r06_fuzz_parity.txt): 772 configurations, 20 soft lines, 0 hard -- the f16_all single window of round 5 (seed 300) is
+graded on the spot now (0.4-0.6 x its spread).
     python tools/fuzz_parity.py [seconds] [big|small|geo] [seed]"""
 import sys, time, random; sys.path.insert(0, '.')
 from tests import gpu_checks as G
